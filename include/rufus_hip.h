@@ -1,0 +1,188 @@
+/* rufus_hip.h -- C-ABI of librufus_hip.so, the MI355X (gfx950) implementation of the RUFUS
+ * k-mer count -> unique-k-mer set difference -> read filter hot path.
+ *
+ * The reference (jandrewrfarrell/RUFUS) has no FFI: its boundary is a set of executables glued by
+ * bash (runRufus.sh:748-759).  The drop-in executables under rufus_amd/csrc/host/ keep that argv /
+ * file contract and call the entry points below; each entry point names the reference code whose
+ * arithmetic it replaces (paths relative to the reference root, "jf/" = src/modifiedJellyfish/).
+ *
+ * Conventions: plain C, opaque handles, return 0 on success or a negative RFX_E_* code; the
+ * caller owns every host buffer, the library owns device memory unless a function name ends in
+ * _dev (caller-provided device pointers).  One rfx_ctx per (process, device); a ctx and the
+ * objects made from it must be used from one thread at a time.  There is NO CPU fallback: every
+ * device entry point fails with RFX_E_NODEVICE when no gfx950 GPU is visible.
+ */
+#ifndef RUFUS_HIP_H
+#define RUFUS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFX_OK 0
+#define RFX_E_NODEVICE (-1) /* no usable gfx950 device / HIP runtime error at open */
+#define RFX_E_INVAL (-2)    /* bad argument */
+#define RFX_E_NOMEM (-3)    /* device or host allocation failed / hbm budget exceeded */
+#define RFX_E_FULL (-4)     /* count table cannot grow inside the budget (use a key range pass) */
+#define RFX_E_HIP (-5)      /* a HIP call failed; see rfx_last_error() */
+#define RFX_E_MIXEDCASE (-6) /* lower-case acgt present: count and filter encodings differ, pack separately */
+#define RFX_E_RANGE (-7)    /* output buffer too small */
+#define RFX_E_FORMAT (-8)   /* malformed input text / file */
+
+#define RFX_HISTO_BINS 10002 /* jf/sub_commands/histo_main.cc:33-89 with the default low=1 high=10000 inc=1 */
+
+typedef struct rfx_ctx rfx_ctx;
+typedef struct rfx_reads rfx_reads;     /* a block of 2-bit packed reads resident in HBM */
+typedef struct rfx_table rfx_table;     /* exact k-mer count table in HBM */
+typedef struct rfx_records rfx_records; /* (pos,key)-sorted records in HBM == payload of a .Jhash file */
+typedef struct rfx_set rfx_set;         /* mutant k-mer set (filter / annotate) */
+
+const char* rfx_version(void);
+const char* rfx_strerror(int code);
+const char* rfx_last_error(void); /* text of the last HIP failure on this thread */
+
+/* ---------------------------------------------------------------------------------------------
+ * Host-only helpers (no device needed)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Hash matrix of a 2^lsize-slot jellyfish table for k-mers: 2k columns of lsize bits.
+ * Replaces jf/include/jellyfish/large_hash_array.hpp:942-950 (RectangularBinaryMatrix(ceilLog2(size),
+ * 2k).randomize_pseudo_inverse()), jf/lib/misc.cc:74-80 (random_bits over the unseeded glibc
+ * random()) and jf/lib/rectangular_binary_matrix.cc:138-186,:209-216. */
+int rfx_jf_matrix(int lsize, int k, uint64_t* cols);
+/* pos = (M * key) & (2^lsize - 1); jf/include/jellyfish/rectangular_binary_matrix.hpp:206-243. */
+uint64_t rfx_jf_pos(const uint64_t* cols, int k, int lsize, uint64_t key);
+
+/* Packing.  A read of L bases occupies ceil(L/32) 64-bit code words (base i of the read at bits
+ * 2*(i%32) of word i/32, jellyfish codes A0 C1 G2 T3) and as many 32-bit mask words.
+ *   RFX_PACK_COUNT : acgt mask bit = base is one of ACGTacgt (jf/include/jellyfish/mer_dna.hpp:46-63);
+ *                    codes follow that table (lower case accepted).
+ *   RFX_PACK_FILTER: good mask bit = (qual-33 >= min_q as signed char) && base != 'N'
+ *                    (src/RUFUS.Filter.cpp:205); codes follow Util::HashToLong (src/Util.cpp:51-84):
+ *                    upper-case ACGT only, anything else encodes as A.
+ * Both flags together return RFX_E_MIXEDCASE if a lower-case c/g/t is present (the encodings differ).
+ * seq/qual are concatenated bytes, off[n_reads+1] their byte offsets (qual shares off; a missing
+ * quality byte -- qual == NULL -- reads as '\0', i.e. bad).  Outputs sized by rfx_pack_words();
+ * a block holds fewer than 2^32 words. */
+#define RFX_PACK_COUNT 1
+#define RFX_PACK_FILTER 2
+uint64_t rfx_pack_words(const uint64_t* off, uint32_t n_reads);
+int rfx_pack_reads(const char* seq, const char* qual, const uint64_t* off, uint32_t n_reads, int min_q, int flags,
+                   uint64_t* codes, uint32_t* acgt, uint32_t* good, uint32_t* word_off /* n_reads+1 */,
+                   uint32_t* len /* n_reads */);
+
+/* RUFUS.Filter hash-list loader (src/RUFUS.Filter.cpp:121-143; single_end: src/RUFUS.Filter.ss.cpp:
+ * 100-118): every line contributes HashToLong(kmer) and HashToLong(RevComp(kmer)) (src/Util.cpp:51-84,
+ * :187-210), returned here as forward keys in jellyfish encoding (first base most significant).
+ * keys_out may be NULL to query the count.  Returns the number of keys (2 per accepted line, not
+ * de-duplicated) or a negative code. */
+long rfx_hashlist_keys(const char* text, size_t n, int k, int single_end, uint64_t* keys_out, size_t cap);
+
+/* .Jhash header (jf/include/jellyfish/generic_file_header.hpp:96-121, file_header.hpp:33-110):
+ * 9-digit length + terse JSON + NUL pad to 8 bytes.  Writes into buf (cap bytes), returns its
+ * length or a negative code.  cmdline may be NULL. */
+long rfx_jhash_header(int k, int lsize, const uint64_t* cols, int canonical, int counter_len, int argc,
+                      const char* const* argv, char* buf, size_t cap);
+
+/* ---------------------------------------------------------------------------------------------
+ * Device context
+ * ------------------------------------------------------------------------------------------- */
+rfx_ctx* rfx_open(int device, size_t hbm_budget_bytes); /* NULL on failure (no CPU fallback) */
+void rfx_close(rfx_ctx*);
+int rfx_sync(rfx_ctx*);
+void* rfx_stream(rfx_ctx*); /* the hipStream_t every kernel of this ctx is launched on */
+
+/* Per-kernel HIP-event timing on the ctx stream (used by bench.py for roofline.achieved). */
+int rfx_prof_enable(rfx_ctx*, int on);
+int rfx_prof_reset(rfx_ctx*);
+int rfx_prof_query(rfx_ctx*, const char* kernel, double* total_ms, uint64_t* launches);
+int rfx_prof_names(rfx_ctx*, char* buf, size_t cap); /* '\n'-separated kernel names seen so far */
+
+/* ---------------------------------------------------------------------------------------------
+ * Read blocks
+ * ------------------------------------------------------------------------------------------- */
+/* H2D copy of a packed block (arrays as produced by rfx_pack_reads; good/acgt may be NULL when
+ * the block will only be counted / only be filtered). */
+rfx_reads* rfx_reads_upload(rfx_ctx*, const uint64_t* codes, const uint32_t* acgt, const uint32_t* good,
+                            const uint32_t* word_off, const uint32_t* len, uint32_t n_reads);
+void rfx_reads_free(rfx_reads*);
+uint32_t rfx_reads_count(const rfx_reads*);
+uint64_t rfx_reads_bases(const rfx_reads*);
+
+/* ---------------------------------------------------------------------------------------------
+ * K2: canonical k-mer count  (jellyfish count: jf/sub_commands/count_main.cc:148-180;
+ * jf/include/jellyfish/mer_iterator.hpp:59-88; hash_counter.hpp:98-119; large_hash_array.hpp:298-302)
+ * ------------------------------------------------------------------------------------------- */
+/* k <= 31 (32 when canonical).  lsize = ceilLog2 of jellyfish's -s.  Only k-mers whose pos lies in
+ * [pos_lo, pos_hi) are counted (pos_hi == 0 means 2^lsize): key-range passes / multi-GPU ownership.
+ * capacity_slots == 0 picks an initial size; the table grows by rehash inside the ctx budget. */
+rfx_table* rfx_count_begin(rfx_ctx*, int k, int canonical, int lsize, uint64_t capacity_slots, uint64_t pos_lo,
+                           uint64_t pos_hi);
+int rfx_count_add(rfx_table*, const rfx_reads*);
+/* Merge pre-aggregated (key,count) pairs (device pointers): owner-side reduce of the multi-GPU
+ * exchange, and the rehash path. */
+int rfx_count_add_pairs_dev(rfx_table*, const uint64_t* d_keys, const uint32_t* d_counts, uint64_t n);
+int rfx_count_stats(rfx_table*, uint64_t* distinct, uint64_t* capacity, uint64_t* max_displacement);
+void rfx_count_free(rfx_table*);
+
+/* K3: table -> records with lower <= count <= upper in (pos,key) order (jf/include/jellyfish/
+ * sorted_dumper.hpp:80-112, mer_heap.hpp:34-38; -L/-U at output count_main.cc:318-324) plus the
+ * count-of-counts histogram of exactly those records (histo_main.cc:33-89), histo may be NULL. */
+rfx_records* rfx_count_finish(rfx_table*, uint64_t lower, uint64_t upper, uint64_t* histo /* RFX_HISTO_BINS */);
+
+/* ---------------------------------------------------------------------------------------------
+ * Records (the .Jhash payload; jf/include/jellyfish/binary_dumper.hpp:44-48)
+ * ------------------------------------------------------------------------------------------- */
+uint64_t rfx_records_size(const rfx_records*);
+int rfx_records_k(const rfx_records*);
+int rfx_records_lsize(const rfx_records*);
+/* Formatted file records (ceil(2k/8) key bytes + counter_len count bytes, saturating) -> host. */
+int rfx_records_payload(const rfx_records*, void* out, size_t cap_bytes, int counter_len);
+int rfx_records_get(const rfx_records*, uint64_t* keys, uint32_t* counts, uint64_t* pos); /* any may be NULL */
+/* Load a payload read from a .Jhash file back into HBM (verifies (pos,key) order). */
+rfx_records* rfx_records_load(rfx_ctx*, int k, int lsize, const uint64_t* cols, const void* payload, uint64_t n,
+                              int counter_len);
+rfx_records* rfx_records_from_dev(rfx_ctx*, int k, int lsize, const uint64_t* cols, const uint64_t* d_keys,
+                                  const uint32_t* d_counts, uint64_t n); /* copies; computes pos */
+const uint64_t* rfx_records_dev_keys(const rfx_records*);
+const uint32_t* rfx_records_dev_counts(const rfx_records*);
+const uint64_t* rfx_records_dev_pos(const rfx_records*);
+int rfx_records_histo(const rfx_records*, uint64_t* histo /* RFX_HISTO_BINS */);
+void rfx_records_free(rfx_records*);
+
+/* ---------------------------------------------------------------------------------------------
+ * K4: set difference
+ * ------------------------------------------------------------------------------------------- */
+/* RUFUS's modified `jellyfish merge` (jf/jellyfish/merge_files.cc:69-155): keys present in exactly
+ * one of the inputs with count >= min_count (5 in the reference), in global (pos,key) order. */
+int rfx_merge_unique(rfx_ctx*, const rfx_records* const* files, int n_files, uint32_t min_count, uint64_t* keys_out,
+                     uint32_t* counts_out, uint64_t cap, uint64_t* n_out);
+/* `jellyfish query` lookups (jf/include/jellyfish/binary_dumper.hpp:156-203): count of each key, 0 if
+ * absent.  Keys must already be canonical when the database is. */
+int rfx_query(const rfx_records* db, const uint64_t* keys, uint64_t n, uint32_t* counts_out);
+/* Fused net semantics of runRufus.sh:925-926 + scripts/CheckJellyHashList.sh:12: subject keys with
+ * max(min_count,min_cov) <= count <= max_cov that occur in no other input, in (pos,key) order. */
+int rfx_unique_to_subject(rfx_ctx*, const rfx_records* subject, const rfx_records* const* others, int n_others,
+                          uint32_t min_count, uint32_t min_cov, uint32_t max_cov, uint64_t* keys_out,
+                          uint32_t* counts_out, uint64_t cap, uint64_t* n_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5: read filter (src/RUFUS.Filter.cpp:196-277, src/RUFUS.Filter.ss.cpp:164-203)
+ * ------------------------------------------------------------------------------------------- */
+rfx_set* rfx_set_build(rfx_ctx*, const uint64_t* fwd_keys, uint64_t n, int k); /* keys from rfx_hashlist_keys */
+uint64_t rfx_set_size(const rfx_set*);
+void rfx_set_free(rfx_set*);
+/* Per read: number of good-streak windows found in the set.  last_base_skipped = 1 reproduces the
+ * paired tool's `i < length-1` loop bound (src/RUFUS.Filter.cpp:203), 0 the single-end tool.
+ * hits_out[n_reads] and hitmask_out[ceil(n_reads/64)] (bit r%64 of word r/64 set when
+ * hits >= thresh) are host buffers, either may be NULL; *n_hit_reads counts reads over threshold. */
+int rfx_filter(rfx_set*, const rfx_reads*, int thresh, int last_base_skipped, uint32_t* hits_out,
+               uint64_t* hitmask_out, uint64_t* n_hit_reads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUFUS_HIP_H */

@@ -1,0 +1,382 @@
+"""ctypes binding of ``librufus_hip.so`` (C-ABI declared in ``include/rufus_hip.h``).
+
+Plumbing only: every compute call goes through the C-ABI into hand-written HIP kernels.  There is no
+CPU fallback -- importing works without a GPU (so the symbol table and the host-only helpers can be
+tested), but ``Context()`` raises ``RufusError`` when no gfx950 device is visible, and a missing
+shared library is an ``ImportError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librufus_hip.so")
+
+HISTO_BINS = 10002
+PACK_COUNT, PACK_FILTER = 1, 2
+E_FULL, E_RANGE, E_MIXEDCASE = -4, -7, -6
+
+u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
+
+# name -> (restype, argtypes); the unit tests check that every one of these is exported.
+SIGNATURES = {
+    "rfx_version": (C.c_char_p, []),
+    "rfx_strerror": (C.c_char_p, [C.c_int]),
+    "rfx_last_error": (C.c_char_p, []),
+    "rfx_jf_matrix": (C.c_int, [C.c_int, C.c_int, u64p]),
+    "rfx_jf_pos": (C.c_uint64, [u64p, C.c_int, C.c_int, C.c_uint64]),
+    "rfx_pack_words": (C.c_uint64, [u64p, C.c_uint32]),
+    "rfx_pack_reads": (C.c_int, [C.c_char_p, C.c_char_p, u64p, C.c_uint32, C.c_int, C.c_int, u64p, u32p, u32p, u32p,
+                                 u32p]),
+    "rfx_hashlist_keys": (C.c_long, [C.c_char_p, C.c_size_t, C.c_int, C.c_int, u64p, C.c_size_t]),
+    "rfx_jhash_header": (C.c_long, [C.c_int, C.c_int, u64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
+                                    C.c_char_p, C.c_size_t]),
+    "rfx_open": (C.c_void_p, [C.c_int, C.c_size_t]),
+    "rfx_close": (None, [C.c_void_p]),
+    "rfx_sync": (C.c_int, [C.c_void_p]),
+    "rfx_stream": (C.c_void_p, [C.c_void_p]),
+    "rfx_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "rfx_prof_reset": (C.c_int, [C.c_void_p]),
+    "rfx_prof_query": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), u64p]),
+    "rfx_prof_names": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "rfx_reads_upload": (C.c_void_p, [C.c_void_p, u64p, u32p, u32p, u32p, u32p, C.c_uint32]),
+    "rfx_reads_free": (None, [C.c_void_p]),
+    "rfx_reads_count": (C.c_uint32, [C.c_void_p]),
+    "rfx_reads_bases": (C.c_uint64, [C.c_void_p]),
+    "rfx_count_begin": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "rfx_count_add": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rfx_count_add_pairs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rfx_count_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "rfx_count_free": (None, [C.c_void_p]),
+    "rfx_count_finish": (C.c_void_p, [C.c_void_p, C.c_uint64, C.c_uint64, u64p]),
+    "rfx_records_size": (C.c_uint64, [C.c_void_p]),
+    "rfx_records_k": (C.c_int, [C.c_void_p]),
+    "rfx_records_lsize": (C.c_int, [C.c_void_p]),
+    "rfx_records_payload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "rfx_records_get": (C.c_int, [C.c_void_p, u64p, u32p, u64p]),
+    "rfx_records_load": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, u64p, C.c_void_p, C.c_uint64, C.c_int]),
+    "rfx_records_from_dev": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, u64p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    "rfx_records_dev_keys": (C.c_void_p, [C.c_void_p]),
+    "rfx_records_dev_counts": (C.c_void_p, [C.c_void_p]),
+    "rfx_records_dev_pos": (C.c_void_p, [C.c_void_p]),
+    "rfx_records_histo": (C.c_int, [C.c_void_p, u64p]),
+    "rfx_records_free": (None, [C.c_void_p]),
+    "rfx_merge_unique": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_uint32, u64p, u32p, C.c_uint64,
+                                   u64p]),
+    "rfx_query": (C.c_int, [C.c_void_p, u64p, C.c_uint64, u32p]),
+    "rfx_unique_to_subject": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_uint32,
+                                        C.c_uint32, C.c_uint32, u64p, u32p, C.c_uint64, u64p]),
+    "rfx_set_build": (C.c_void_p, [C.c_void_p, u64p, C.c_uint64, C.c_int]),
+    "rfx_set_size": (C.c_uint64, [C.c_void_p]),
+    "rfx_set_free": (None, [C.c_void_p]),
+    "rfx_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, u32p, u64p, u64p]),
+}
+
+
+class RufusError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library; a missing build is a hard error, never a silent fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(or `make -C rufus_amd/csrc`)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        L = lib()
+        raise RufusError(f"{what}: {L.rfx_strerror(rc).decode()} ({rc}) {L.rfx_last_error().decode()}")
+
+
+def _p(a, t):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def ceil_log2(x: int) -> int:
+    return max(0, (int(x) - 1).bit_length())
+
+
+# ---------------------------------------------------------------------------------------------------
+# host-only helpers
+# ---------------------------------------------------------------------------------------------------
+def jf_matrix(lsize: int, k: int) -> np.ndarray:
+    cols = np.zeros(2 * k, dtype=np.uint64)
+    _check(lib().rfx_jf_matrix(lsize, k, _p(cols, u64p)), "rfx_jf_matrix")
+    return cols
+
+
+def jf_pos(cols: np.ndarray, k: int, lsize: int, key: int) -> int:
+    cols = np.ascontiguousarray(cols, dtype=np.uint64)
+    return int(lib().rfx_jf_pos(_p(cols, u64p), k, lsize, int(key)))
+
+
+def hashlist_keys(text: bytes, k: int, single_end: bool = False) -> np.ndarray:
+    n = lib().rfx_hashlist_keys(text, len(text), k, int(single_end), None, 0)
+    if n < 0:
+        _check(int(n), "rfx_hashlist_keys")
+    out = np.zeros(max(n, 1), dtype=np.uint64)
+    n2 = lib().rfx_hashlist_keys(text, len(text), k, int(single_end), _p(out, u64p), len(out))
+    assert n2 == n
+    return out[:n]
+
+
+def jhash_header(k: int, lsize: int, cols: np.ndarray, canonical: bool = True, counter_len: int = 4, argv=()) -> bytes:
+    cols = np.ascontiguousarray(cols, dtype=np.uint64)
+    arr = (C.c_char_p * max(1, len(argv)))(*[a.encode() if isinstance(a, str) else a for a in argv])
+    buf = C.create_string_buffer(1 << 16)
+    n = lib().rfx_jhash_header(k, lsize, _p(cols, u64p), int(canonical), counter_len, len(argv), arr, buf, len(buf))
+    if n < 0:
+        _check(int(n), "rfx_jhash_header")
+    return buf.raw[:n]
+
+
+class PackedReads:
+    """Host-side packed block: 32 bases per 64-bit code word, one mask bit per base."""
+
+    def __init__(self, seq: bytes, off: np.ndarray, qual: bytes | None = None, min_q: int = 0,
+                 flags: int = PACK_COUNT):
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        n = len(off) - 1
+        L = lib()
+        nw = int(L.rfx_pack_words(_p(off, u64p), n))
+        self.n = n
+        self.codes = np.zeros(max(nw, 1), dtype=np.uint64)
+        self.acgt = np.zeros(max(nw, 1), dtype=np.uint32) if flags & PACK_COUNT else None
+        self.good = np.zeros(max(nw, 1), dtype=np.uint32) if flags & PACK_FILTER else None
+        self.word_off = np.zeros(n + 1, dtype=np.uint32)
+        self.len = np.zeros(max(n, 1), dtype=np.uint32)
+        _check(L.rfx_pack_reads(seq, qual, _p(off, u64p), n, min_q, flags, _p(self.codes, u64p), _p(self.acgt, u32p),
+                                _p(self.good, u32p), _p(self.word_off, u32p), _p(self.len, u32p)), "rfx_pack_reads")
+
+    @classmethod
+    def from_reads(cls, seqs, quals=None, min_q: int = 0, flags: int = PACK_COUNT):
+        lens = np.fromiter((len(s) for s in seqs), dtype=np.uint64, count=len(seqs))
+        off = np.zeros(len(seqs) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        q = None
+        if quals is not None:
+            # a quality string shorter than its read reads as '\0' (bad) past its end
+            q = b"".join((qq + b"\0" * (len(s) - len(qq)))[:len(s)] for s, qq in zip(seqs, quals))
+        return cls(b"".join(seqs), off, q, min_q, flags)
+
+
+# ---------------------------------------------------------------------------------------------------
+# device objects
+# ---------------------------------------------------------------------------------------------------
+class Context:
+    def __init__(self, device: int = 0, hbm_budget: int = 0):
+        self._h = lib().rfx_open(device, hbm_budget)
+        if not self._h:
+            raise RufusError("rfx_open failed (no CPU fallback): " + lib().rfx_last_error().decode())
+
+    def close(self):
+        if self._h:
+            lib().rfx_close(self._h)
+            self._h = None
+
+    def sync(self):
+        _check(lib().rfx_sync(self._h), "rfx_sync")
+
+    def prof(self, on: bool):
+        _check(lib().rfx_prof_enable(self._h, int(on)), "rfx_prof_enable")
+
+    def prof_reset(self):
+        _check(lib().rfx_prof_reset(self._h), "rfx_prof_reset")
+
+    def prof_dict(self) -> dict:
+        buf = C.create_string_buffer(8192)
+        _check(lib().rfx_prof_names(self._h, buf, len(buf)), "rfx_prof_names")
+        out = {}
+        for name in buf.value.decode().split("\n"):
+            if not name:
+                continue
+            ms, n = C.c_double(0), C.c_uint64(0)
+            _check(lib().rfx_prof_query(self._h, name.encode(), C.byref(ms), C.byref(n)), "rfx_prof_query")
+            out[name] = (ms.value, n.value)
+        return out
+
+    def upload(self, p: PackedReads) -> "ReadBlock":
+        return ReadBlock(self, p)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class ReadBlock:
+    def __init__(self, ctx: Context, p: PackedReads):
+        self.ctx = ctx
+        self._h = lib().rfx_reads_upload(ctx._h, _p(p.codes, u64p), _p(p.acgt, u32p), _p(p.good, u32p),
+                                         _p(p.word_off, u32p), _p(p.len, u32p), p.n)
+        if not self._h:
+            raise RufusError("rfx_reads_upload failed: " + lib().rfx_last_error().decode())
+        self.n = p.n
+
+    @property
+    def bases(self) -> int:
+        return int(lib().rfx_reads_bases(self._h))
+
+    def free(self):
+        if self._h:
+            lib().rfx_reads_free(self._h)
+            self._h = None
+
+
+class Records:
+    def __init__(self, ctx: Context, handle):
+        if not handle:
+            raise RufusError("records: " + lib().rfx_last_error().decode())
+        self.ctx, self._h = ctx, handle
+
+    def __len__(self):
+        return int(lib().rfx_records_size(self._h))
+
+    @property
+    def k(self):
+        return lib().rfx_records_k(self._h)
+
+    @property
+    def lsize(self):
+        return lib().rfx_records_lsize(self._h)
+
+    def payload(self, counter_len: int = 4) -> bytes:
+        n = len(self) * ((2 * self.k + 7) // 8 + counter_len)
+        buf = np.zeros(max(n, 1), dtype=np.uint8)
+        _check(lib().rfx_records_payload(self._h, buf.ctypes.data, n, counter_len), "rfx_records_payload")
+        return buf[:n].tobytes()
+
+    def get(self):
+        n = len(self)
+        keys, counts, pos = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint64)
+        _check(lib().rfx_records_get(self._h, _p(keys, u64p), _p(counts, u32p), _p(pos, u64p)), "rfx_records_get")
+        return keys, counts, pos
+
+    def histo(self) -> np.ndarray:
+        h = np.zeros(HISTO_BINS, dtype=np.uint64)
+        _check(lib().rfx_records_histo(self._h, _p(h, u64p)), "rfx_records_histo")
+        return h
+
+    def query(self, keys: np.ndarray) -> np.ndarray:
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.zeros(len(keys), dtype=np.uint32)
+        _check(lib().rfx_query(self._h, _p(keys, u64p), len(keys), _p(out, u32p)), "rfx_query")
+        return out
+
+    def dev_ptrs(self):
+        L = lib()
+        return L.rfx_records_dev_keys(self._h), L.rfx_records_dev_counts(self._h), L.rfx_records_dev_pos(self._h)
+
+    @classmethod
+    def load(cls, ctx: Context, k: int, lsize: int, cols: np.ndarray, payload: bytes, counter_len: int = 4):
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        rl = (2 * k + 7) // 8 + counter_len
+        n = len(payload) // rl
+        buf = np.frombuffer(payload, dtype=np.uint8)
+        h = lib().rfx_records_load(ctx._h, k, lsize, _p(cols, u64p), buf.ctypes.data if n else None, n, counter_len)
+        return cls(ctx, h)
+
+    @classmethod
+    def from_dev(cls, ctx: Context, k: int, lsize: int, cols: np.ndarray, d_keys: int, d_counts: int, n: int):
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        return cls(ctx, lib().rfx_records_from_dev(ctx._h, k, lsize, _p(cols, u64p), d_keys, d_counts, n))
+
+    def free(self):
+        if self._h:
+            lib().rfx_records_free(self._h)
+            self._h = None
+
+
+class CountTable:
+    """``jellyfish count`` state: exact canonical k-mer counts in an HBM hash table."""
+
+    def __init__(self, ctx: Context, k: int, size: int, canonical: bool = True, capacity: int = 0, pos_lo: int = 0,
+                 pos_hi: int = 0):
+        self.ctx, self.k, self.lsize, self.canonical = ctx, k, ceil_log2(size), canonical
+        self._h = lib().rfx_count_begin(ctx._h, k, int(canonical), self.lsize, capacity, pos_lo, pos_hi)
+        if not self._h:
+            raise RufusError("rfx_count_begin failed: " + lib().rfx_last_error().decode())
+
+    def add(self, reads: ReadBlock):
+        _check(lib().rfx_count_add(self._h, reads._h), "rfx_count_add")
+
+    def add_pairs_dev(self, d_keys: int, d_counts: int, n: int):
+        _check(lib().rfx_count_add_pairs_dev(self._h, d_keys, d_counts, n), "rfx_count_add_pairs_dev")
+
+    def stats(self):
+        d, c, m = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().rfx_count_stats(self._h, C.byref(d), C.byref(c), C.byref(m)), "rfx_count_stats")
+        return {"distinct": d.value, "capacity": c.value, "max_displacement": m.value}
+
+    def finish(self, lower: int = 0, upper: int = 2**64 - 1, want_histo: bool = False):
+        h = np.zeros(HISTO_BINS, dtype=np.uint64) if want_histo else None
+        rec = Records(self.ctx, lib().rfx_count_finish(self._h, lower, upper, _p(h, u64p)))
+        return (rec, h) if want_histo else rec
+
+    def free(self):
+        if self._h:
+            lib().rfx_count_free(self._h)
+            self._h = None
+
+
+def merge_unique(ctx: Context, files, min_count: int = 5):
+    arr = (C.c_void_p * len(files))(*[f._h for f in files])
+    n = C.c_uint64(0)
+    rc = lib().rfx_merge_unique(ctx._h, arr, len(files), min_count, None, None, 0, C.byref(n))
+    if rc not in (0, E_RANGE):
+        _check(rc, "rfx_merge_unique")
+    keys, counts = np.zeros(max(n.value, 1), np.uint64), np.zeros(max(n.value, 1), np.uint32)
+    _check(lib().rfx_merge_unique(ctx._h, arr, len(files), min_count, _p(keys, u64p), _p(counts, u32p), len(keys),
+                                  C.byref(n)), "rfx_merge_unique")
+    return keys[:n.value], counts[:n.value]
+
+
+def unique_to_subject(ctx: Context, subject: Records, others, min_cov: int, max_cov: int, min_count: int = 5):
+    arr = (C.c_void_p * max(1, len(others)))(*[f._h for f in others])
+    cap = len(subject)
+    keys, counts = np.zeros(max(cap, 1), np.uint64), np.zeros(max(cap, 1), np.uint32)
+    n = C.c_uint64(0)
+    _check(lib().rfx_unique_to_subject(ctx._h, subject._h, arr, len(others), min_count, min_cov, max_cov,
+                                       _p(keys, u64p), _p(counts, u32p), len(keys), C.byref(n)),
+           "rfx_unique_to_subject")
+    return keys[:n.value].copy(), counts[:n.value].copy()
+
+
+class MutantSet:
+    def __init__(self, ctx: Context, fwd_keys: np.ndarray, k: int):
+        fwd_keys = np.ascontiguousarray(fwd_keys, dtype=np.uint64)
+        self.ctx, self.k = ctx, k
+        self._h = lib().rfx_set_build(ctx._h, _p(fwd_keys, u64p), len(fwd_keys), k)
+        if not self._h:
+            raise RufusError("rfx_set_build failed: " + lib().rfx_last_error().decode())
+
+    def filter(self, reads: ReadBlock, thresh: int = 1, last_base_skipped: bool = True, want_hits: bool = True,
+               want_mask: bool = True):
+        hits = np.zeros(max(reads.n, 1), np.uint32) if want_hits else None
+        mask = np.zeros((reads.n + 63) // 64 or 1, np.uint64) if want_mask else None
+        n = C.c_uint64(0)
+        _check(lib().rfx_filter(self._h, reads._h, thresh, int(last_base_skipped), _p(hits, u32p), _p(mask, u64p),
+                                C.byref(n)), "rfx_filter")
+        return (hits[:reads.n] if want_hits else None), mask, n.value
+
+    def free(self):
+        if self._h:
+            lib().rfx_set_free(self._h)
+            self._h = None

@@ -1,0 +1,803 @@
+// Device half of the C-ABI (include/rufus_hip.h): context, memory, orchestration of the kernels in
+// rfx_kernels.hip.  No CPU fallback: rfx_open() fails when no gfx950 device is visible and every
+// other entry point needs a ctx.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <queue>
+
+#include "rfx_internal.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int hip_fail(hipError_t e, const char* what) {
+  snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+  return RFX_E_HIP;
+}
+#define HIPCHK(x)                                   \
+  do {                                              \
+    hipError_t e_ = (x);                            \
+    if (e_ != hipSuccess) return hip_fail(e_, #x);  \
+  } while (0)
+#define HIPCHKP(x)                        \
+  do {                                    \
+    hipError_t e_ = (x);                  \
+    if (e_ != hipSuccess) {               \
+      hip_fail(e_, #x);                   \
+      return nullptr;                     \
+    }                                     \
+  } while (0)
+
+void* dmalloc(rfx_ctx* c, size_t bytes) {
+  if (bytes == 0) bytes = 8;
+  if (c->budget && c->used + bytes > c->budget) {
+    snprintf(g_err, sizeof g_err, "hbm budget exceeded: %zu + %zu > %zu", c->used, bytes, c->budget);
+    return nullptr;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    hip_fail(e, "hipMalloc");
+    return nullptr;
+  }
+  c->used += bytes;
+  c->allocs[p] = bytes;
+  return p;
+}
+
+void dfree(rfx_ctx* c, void* p) {
+  if (!p) return;
+  auto it = c->allocs.find(p);
+  if (it != c->allocs.end()) {
+    c->used -= it->second;
+    c->allocs.erase(it);
+  }
+  hipFree(p);
+}
+
+int ceil_log2(uint64_t x) {
+  int l = 0;
+  while (l < 63 && (1ull << l) < x) ++l;
+  return l;
+}
+
+void build_lut(const uint64_t* cols, int k, std::vector<uint64_t>& lut, int& ntab) {
+  const int c = 2 * k;
+  ntab = (c + 7) / 8;
+  lut.assign((size_t)ntab * 256, 0);
+  for (int t = 0; t < ntab; ++t)
+    for (int v = 0; v < 256; ++v) {
+      uint64_t r = 0;
+      for (int j = 0; j < 8; ++j) {
+        const int bit = 8 * t + j;
+        if (((v >> j) & 1) && bit < c) r ^= cols[c - 1 - bit];
+      }
+      lut[(size_t)t * 256 + v] = r;
+    }
+}
+
+rfx_table_view view_of(const rfx_table* t) {
+  rfx_table_view v;
+  v.keys = t->keys;
+  v.counts = t->counts;
+  v.cap = t->cap;
+  v.slots = t->cap + RFX_TABLE_MARGIN;
+  v.rshift = t->lsize >= t->tbits ? t->lsize - t->tbits : 0;
+  v.lshift = t->lsize >= t->tbits ? 0 : t->tbits - t->lsize;
+  v.pos_lo = t->pos_lo;
+  v.pos_hi = t->pos_hi;
+  v.ntab = t->ntab;
+  v.kshift = 2 * t->k - v.lshift;
+  return v;
+}
+
+int alloc_table_arrays(rfx_ctx* c, uint64_t cap, uint64_t** keys, uint32_t** counts) {
+  const uint64_t slots = cap + RFX_TABLE_MARGIN;
+  *keys = (uint64_t*)dmalloc(c, slots * 8);
+  if (!*keys) return RFX_E_NOMEM;
+  *counts = (uint32_t*)dmalloc(c, slots * 4);
+  if (!*counts) {
+    dfree(c, *keys);
+    *keys = nullptr;
+    return RFX_E_NOMEM;
+  }
+  HIPCHK(hipMemsetAsync(*keys, 0xFF, slots * 8, c->stream));
+  HIPCHK(hipMemsetAsync(*counts, 0, slots * 4, c->stream));
+  return RFX_OK;
+}
+
+int read_stats(rfx_table* t, rfx_table_stats* out) {
+  HIPCHK(hipMemcpyAsync(out, t->d_stats, sizeof(*out), hipMemcpyDeviceToHost, t->ctx->stream));
+  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  return RFX_OK;
+}
+
+// Rehash into a table of new_cap slots.
+int table_grow(rfx_table* t, uint64_t new_cap) {
+  rfx_ctx* c = t->ctx;
+  rfx_table_stats st;
+  int rc = read_stats(t, &st);
+  if (rc) return rc;
+  uint64_t* pk = (uint64_t*)dmalloc(c, (st.distinct + 1) * 8);
+  uint32_t* pc = (uint32_t*)dmalloc(c, (st.distinct + 1) * 4);
+  unsigned long long* d_n = (unsigned long long*)dmalloc(c, 8);
+  if (!pk || !pc || !d_n) {
+    dfree(c, pk); dfree(c, pc); dfree(c, d_n);
+    return RFX_E_FULL;
+  }
+  HIPCHK(hipMemsetAsync(d_n, 0, 8, c->stream));
+  rfxk::table_pairs(c, view_of(t), pk, pc, d_n);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  dfree(c, t->keys);
+  dfree(c, t->counts);
+  t->keys = nullptr;
+  t->counts = nullptr;
+  rc = alloc_table_arrays(c, new_cap, &t->keys, &t->counts);
+  if (rc) {
+    dfree(c, pk); dfree(c, pc); dfree(c, d_n);
+    return RFX_E_FULL;
+  }
+  t->cap = new_cap;
+  t->tbits = ceil_log2(new_cap);
+  HIPCHK(hipMemsetAsync(t->d_stats, 0, sizeof(rfx_table_stats), c->stream));
+  // the pairs already passed the pos range; widen it for the re-insert
+  rfx_table_view v = view_of(t);
+  rfxk::count_pairs(c, pk, pc, st.distinct, v, t->lut, t->d_stats);
+  HIPCHK(hipStreamSynchronize(c->stream));
+  dfree(c, pk); dfree(c, pc); dfree(c, d_n);
+  return RFX_OK;
+}
+
+rfx_records* records_alloc(rfx_ctx* c, int k, int lsize, const uint64_t* cols, uint64_t n) {
+  rfx_records* r = new rfx_records();
+  r->ctx = c;
+  r->k = k;
+  r->lsize = lsize;
+  r->n = n;
+  memcpy(r->cols, cols, sizeof(uint64_t) * 2 * k);
+  std::vector<uint64_t> lut;
+  build_lut(cols, k, lut, r->ntab);
+  r->keys = (uint64_t*)dmalloc(c, n * 8);
+  r->counts = (uint32_t*)dmalloc(c, n * 4);
+  r->pos = (uint64_t*)dmalloc(c, n * 8);
+  r->lut = (uint64_t*)dmalloc(c, lut.size() * 8);
+  if (!r->keys || !r->counts || !r->pos || !r->lut) {
+    rfx_records_free(r);
+    return nullptr;
+  }
+  if (hipMemcpyAsync(r->lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) {
+    rfx_records_free(r);
+    return nullptr;
+  }
+  return r;
+}
+
+struct HostRun {
+  std::vector<uint64_t> keys, pos;
+  std::vector<uint32_t> counts;
+};
+
+// flags = count in [lo,hi] and key absent from every other file; compacted (order kept) to the host.
+int unique_run(rfx_ctx* c, const rfx_records* f, const rfx_records* const* all, int n_all, uint32_t lo, uint32_t hi,
+               HostRun& out) {
+  out.keys.clear(); out.pos.clear(); out.counts.clear();
+  if (f->n == 0) return RFX_OK;
+  const uint64_t nblk = (f->n + 2047) / 2048;
+  uint8_t* flags = (uint8_t*)dmalloc(c, f->n);
+  uint64_t* ok = (uint64_t*)dmalloc(c, f->n * 8);
+  uint64_t* op = (uint64_t*)dmalloc(c, f->n * 8);
+  uint32_t* oc = (uint32_t*)dmalloc(c, f->n * 4);
+  uint64_t* boff = (uint64_t*)dmalloc(c, nblk * 8);
+  unsigned long long* d_tot = (unsigned long long*)dmalloc(c, 8);
+  auto cleanup = [&] { dfree(c, flags); dfree(c, ok); dfree(c, op); dfree(c, oc); dfree(c, boff); dfree(c, d_tot); };
+  if (!flags || !ok || !op || !oc || !boff || !d_tot) { cleanup(); return RFX_E_NOMEM; }
+  rfxk::flag_range(c, f->counts, f->n, lo, hi, flags);
+  for (int j = 0; j < n_all; ++j) {
+    if (all[j] == f) continue;
+    rfxk::flag_absent(c, f->keys, f->pos, f->n, all[j]->keys, all[j]->pos, all[j]->n, flags);
+  }
+  rfxk::compact(c, flags, f->keys, f->counts, f->pos, f->n, ok, oc, op, boff, d_tot);
+  unsigned long long tot = 0;
+  hipError_t e = hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && tot) {
+    out.keys.resize(tot); out.pos.resize(tot); out.counts.resize(tot);
+    e = hipMemcpy(out.keys.data(), ok, tot * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out.pos.data(), op, tot * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out.counts.data(), oc, tot * 4, hipMemcpyDeviceToHost);
+  }
+  cleanup();
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "unique_run");
+}
+
+void resolve_spans(rfx_ctx* c) {
+  for (auto& s : c->spans) {
+    hipEventSynchronize(s.e1);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.e0, s.e1) == hipSuccess) {
+      auto& a = c->acc[s.name];
+      a.ms += ms;
+      a.launches += 1;
+    }
+    hipEventDestroy(s.e0);
+    hipEventDestroy(s.e1);
+  }
+  c->spans.clear();
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rfx_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+rfx_ctx* rfx_open(int device, size_t hbm_budget_bytes) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0 || device < 0 || device >= n) {
+    snprintf(g_err, sizeof g_err, "no HIP device (count=%d, %s)", n, hipGetErrorString(e));
+    return nullptr;
+  }
+  hipDeviceProp_t prop;
+  HIPCHKP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    snprintf(g_err, sizeof g_err, "device %d is %s, this library is built for gfx950 only", device, prop.gcnArchName);
+    return nullptr;
+  }
+  HIPCHKP(hipSetDevice(device));
+  rfx_ctx* c = new rfx_ctx();
+  c->device = device;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  c->budget = hbm_budget_bytes;
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  return c;
+}
+
+void rfx_close(rfx_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  resolve_spans(c);
+  for (auto& kv : c->allocs) hipFree(kv.first);
+  hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int rfx_sync(rfx_ctx* c) {
+  if (!c) return RFX_E_NODEVICE;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return RFX_OK;
+}
+
+void* rfx_stream(rfx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int rfx_prof_enable(rfx_ctx* c, int on) {
+  if (!c) return RFX_E_NODEVICE;
+  c->prof = on != 0;
+  return RFX_OK;
+}
+int rfx_prof_reset(rfx_ctx* c) {
+  if (!c) return RFX_E_NODEVICE;
+  resolve_spans(c);
+  c->acc.clear();
+  return RFX_OK;
+}
+int rfx_prof_query(rfx_ctx* c, const char* kernel, double* total_ms, uint64_t* launches) {
+  if (!c || !kernel) return RFX_E_INVAL;
+  resolve_spans(c);
+  auto it = c->acc.find(kernel);
+  if (total_ms) *total_ms = it == c->acc.end() ? 0.0 : it->second.ms;
+  if (launches) *launches = it == c->acc.end() ? 0 : it->second.launches;
+  return RFX_OK;
+}
+int rfx_prof_names(rfx_ctx* c, char* buf, size_t cap) {
+  if (!c || !buf || cap == 0) return RFX_E_INVAL;
+  resolve_spans(c);
+  std::string s;
+  for (auto& kv : c->acc) {
+    s += kv.first;
+    s += '\n';
+  }
+  if (s.size() + 1 > cap) return RFX_E_RANGE;
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return RFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+rfx_reads* rfx_reads_upload(rfx_ctx* c, const uint64_t* codes, const uint32_t* acgt, const uint32_t* good,
+                            const uint32_t* word_off, const uint32_t* len, uint32_t n_reads) {
+  if (!c || !word_off || !len || (!codes && n_reads)) return nullptr;
+  (void)hipSetDevice(c->device);
+  rfx_reads* r = new rfx_reads();
+  memset(r, 0, sizeof *r);
+  r->ctx = c;
+  r->n = n_reads;
+  r->n_words = word_off[n_reads];
+  for (uint32_t i = 0; i < n_reads; ++i) {
+    r->n_bases += len[i];
+    r->max_len = std::max(r->max_len, len[i]);
+  }
+  r->codes = (uint64_t*)dmalloc(c, r->n_words * 8);
+  r->word_off = (uint32_t*)dmalloc(c, ((size_t)n_reads + 1) * 4);
+  r->len = (uint32_t*)dmalloc(c, (size_t)n_reads * 4);
+  if (acgt) r->acgt = (uint32_t*)dmalloc(c, r->n_words * 4);
+  if (good) r->good = (uint32_t*)dmalloc(c, r->n_words * 4);
+  bool ok = r->codes && r->word_off && r->len && (!acgt || r->acgt) && (!good || r->good);
+  if (ok) {
+    hipError_t e = hipMemcpyAsync(r->codes, codes, r->n_words * 8, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(r->word_off, word_off, ((size_t)n_reads + 1) * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->len, len, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && acgt) e = hipMemcpyAsync(r->acgt, acgt, r->n_words * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && good) e = hipMemcpyAsync(r->good, good, r->n_words * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) {
+      hip_fail(e, "rfx_reads_upload");
+      ok = false;
+    }
+  }
+  if (!ok) {
+    rfx_reads_free(r);
+    return nullptr;
+  }
+  return r;
+}
+
+void rfx_reads_free(rfx_reads* r) {
+  if (!r) return;
+  dfree(r->ctx, r->codes); dfree(r->ctx, r->acgt); dfree(r->ctx, r->good);
+  dfree(r->ctx, r->word_off); dfree(r->ctx, r->len);
+  delete r;
+}
+uint32_t rfx_reads_count(const rfx_reads* r) { return r ? r->n : 0; }
+uint64_t rfx_reads_bases(const rfx_reads* r) { return r ? r->n_bases : 0; }
+
+// ---------------------------------------------------------------------------------------------
+rfx_table* rfx_count_begin(rfx_ctx* c, int k, int canonical, int lsize, uint64_t capacity_slots, uint64_t pos_lo,
+                           uint64_t pos_hi) {
+  if (!c) return nullptr;
+  if (k < 1 || k > 32 || (k == 32 && !canonical) || lsize < 1 || lsize > 63 || lsize > 2 * k) {
+    snprintf(g_err, sizeof g_err, "rfx_count_begin: unsupported k=%d canonical=%d lsize=%d", k, canonical, lsize);
+    return nullptr;
+  }
+  (void)hipSetDevice(c->device);
+  rfx_table* t = new rfx_table();
+  memset(t, 0, sizeof *t);
+  t->ctx = c;
+  t->k = k;
+  t->canonical = canonical != 0;
+  t->lsize = lsize;
+  uint64_t cap = capacity_slots ? capacity_slots : (1ull << 22);
+  if (cap < (1ull << 16)) cap = 1ull << 16;
+  t->tbits = ceil_log2(cap);
+  t->cap = 1ull << t->tbits;
+  t->pos_lo = pos_lo;
+  t->pos_hi = pos_hi ? pos_hi : (1ull << lsize);
+  if (rfx_jf_matrix(lsize, k, t->cols) != RFX_OK) {
+    delete t;
+    return nullptr;
+  }
+  std::vector<uint64_t> lut;
+  build_lut(t->cols, k, lut, t->ntab);
+  t->lut = (uint64_t*)dmalloc(c, lut.size() * 8);
+  t->d_stats = (rfx_table_stats*)dmalloc(c, sizeof(rfx_table_stats));
+  t->d_ctl = (rfx_count_ctl*)dmalloc(c, sizeof(rfx_count_ctl));
+  bool ok = t->lut && t->d_stats && t->d_ctl && alloc_table_arrays(c, t->cap, &t->keys, &t->counts) == RFX_OK;
+  if (ok) ok = hipMemcpyAsync(t->lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+               hipMemsetAsync(t->d_stats, 0, sizeof(rfx_table_stats), c->stream) == hipSuccess &&
+               hipStreamSynchronize(c->stream) == hipSuccess;
+  if (!ok) {
+    rfx_count_free(t);
+    return nullptr;
+  }
+  return t;
+}
+
+void rfx_count_free(rfx_table* t) {
+  if (!t) return;
+  dfree(t->ctx, t->keys); dfree(t->ctx, t->counts); dfree(t->ctx, t->lut); dfree(t->ctx, t->d_stats);
+  dfree(t->ctx, t->d_ctl); dfree(t->ctx, t->ovf_keys);
+  delete t;
+}
+
+// Table load (distinct / cap) above which the count kernel stops taking chunks and the host grows
+// the table.  Linear probing stays short below it and finish tiles stay sparse enough to sort in LDS.
+static const double kLoadLimit = 0.55;
+
+static int grow_for(rfx_table* t, uint64_t distinct_after) {
+  uint64_t target = t->cap;
+  while ((double)target * kLoadLimit < (double)distinct_after) target <<= 1;
+  return target > t->cap ? table_grow(t, target) : RFX_OK;
+}
+
+int rfx_count_add(rfx_table* t, const rfx_reads* r) {
+  if (!t || !r || t->ctx != r->ctx) return RFX_E_INVAL;
+  if (!r->acgt) return RFX_E_INVAL;
+  rfx_ctx* c = t->ctx;
+  (void)hipSetDevice(c->device);
+  if (r->n == 0) return RFX_OK;
+  // Overflow list: every thread in flight could divert all of its windows after the stop flag is up.
+  const uint64_t in_flight = (uint64_t)rfxk::count_reads_grid(c, r->n) * rfxk::count_reads_block();
+  const uint64_t need = in_flight * (r->max_len ? r->max_len : 1);
+  if (need > t->ovf_cap) {
+    dfree(c, t->ovf_keys);
+    t->ovf_keys = (uint64_t*)dmalloc(c, need * 8);
+    t->ovf_cap = t->ovf_keys ? need : 0;
+    if (!t->ovf_keys) return RFX_E_NOMEM;
+  }
+  HIPCHK(hipMemsetAsync(t->d_ctl, 0, sizeof(rfx_count_ctl), c->stream));
+  const uint32_t n_chunks = (r->n + rfxk::count_reads_block() - 1) / rfxk::count_reads_block();
+  const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+  for (;;) {
+    const uint64_t limit = (uint64_t)((double)t->cap * kLoadLimit);
+    rfxk::count_reads(c, rv, view_of(t), t->lut, t->k, t->canonical, t->d_stats, t->d_ctl, t->ovf_keys, t->ovf_cap,
+                      limit);
+    rfx_count_ctl ctl;
+    rfx_table_stats st;
+    HIPCHK(hipMemcpyAsync(&ctl, t->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(&st, t->d_stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ctl.lost || st.overflow) {
+      snprintf(g_err, sizeof g_err, "count table overflow list exhausted; counts are not exact");
+      return RFX_E_FULL;
+    }
+    if (ctl.ticket >= n_chunks && ctl.ovf_n == 0) return RFX_OK;
+    // Stopped early: grow (at least x2) so that the keys seen so far sit below the load limit,
+    // put the diverted keys back, clear the stop flag and resume from the ticket.
+    int rc = table_grow(t, t->cap * 2);
+    if (rc == RFX_OK) rc = grow_for(t, st.distinct + ctl.ovf_n);
+    if (rc) return rc;
+    if (ctl.ovf_n) {
+      rfxk::count_pairs(c, t->ovf_keys, nullptr, ctl.ovf_n, view_of(t), t->lut, t->d_stats);
+      HIPCHK(hipMemcpyAsync(&st, t->d_stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(hipStreamSynchronize(c->stream));
+      if (st.overflow) return RFX_E_FULL;
+    }
+    ctl.stop = 0;
+    ctl.ovf_n = 0;
+    HIPCHK(hipMemcpyAsync(t->d_ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (ctl.ticket >= n_chunks) return RFX_OK;
+  }
+}
+
+int rfx_count_add_pairs_dev(rfx_table* t, const uint64_t* d_keys, const uint32_t* d_counts, uint64_t n) {
+  if (!t || (n && (!d_keys || !d_counts))) return RFX_E_INVAL;
+  rfx_ctx* c = t->ctx;
+  (void)hipSetDevice(c->device);
+  rfx_table_stats st;
+  int rc = read_stats(t, &st);
+  if (rc) return rc;
+  rc = grow_for(t, st.distinct + n);  // worst case every pair is a new key
+  if (rc) return rc;
+  rfxk::count_pairs(c, d_keys, d_counts, n, view_of(t), t->lut, t->d_stats);
+  return RFX_OK;
+}
+
+int rfx_count_stats(rfx_table* t, uint64_t* distinct, uint64_t* capacity, uint64_t* max_displacement) {
+  if (!t) return RFX_E_INVAL;
+  (void)hipSetDevice(t->ctx->device);
+  rfx_table_stats st;
+  int rc = read_stats(t, &st);
+  if (rc) return rc;
+  if (distinct) *distinct = st.distinct;
+  if (capacity) *capacity = t->cap;
+  if (max_displacement) *max_displacement = st.max_disp;
+  return st.overflow ? RFX_E_FULL : RFX_OK;
+}
+
+rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {
+  if (!t) return nullptr;
+  rfx_ctx* c = t->ctx;
+  (void)hipSetDevice(c->device);
+  rfx_table_stats st;
+  if (read_stats(t, &st)) return nullptr;
+  if (st.overflow) {
+    snprintf(g_err, sizeof g_err, "count table overflowed its probe margin; counts are not exact");
+    return nullptr;
+  }
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    const uint64_t n_tiles = t->cap / RFX_TILE;
+    uint32_t* tile_counts = (uint32_t*)dmalloc(c, n_tiles * 4);
+    uint64_t* tile_off = (uint64_t*)dmalloc(c, (n_tiles + 1) * 8);
+    uint32_t* d_max = (uint32_t*)dmalloc(c, 4);
+    auto cleanup = [&] { dfree(c, tile_counts); dfree(c, tile_off); dfree(c, d_max); };
+    if (!tile_counts || !tile_off || !d_max) { cleanup(); return nullptr; }
+    const rfx_table_view tv = view_of(t);
+    const uint32_t halo = st.max_disp;
+    rfxk::tile_count(c, tv, t->lut, halo, lower, upper, tile_counts, n_tiles);
+    rfxk::tile_scan(c, tile_counts, n_tiles, tile_off, d_max);
+    uint64_t total = 0;
+    uint32_t mx = 0;
+    hipError_t e = hipMemcpyAsync(&total, tile_off + n_tiles, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { hip_fail(e, "rfx_count_finish"); cleanup(); return nullptr; }
+    uint32_t sort_cap = 64;
+    while (sort_cap < mx) sort_cap <<= 1;
+    if (sort_cap > 4096) {
+      // tiles too dense for the LDS sort: halve the density by doubling the table
+      cleanup();
+      if (table_grow(t, t->cap * 2) != RFX_OK || read_stats(t, &st)) return nullptr;
+      continue;
+    }
+    rfx_records* r = records_alloc(c, t->k, t->lsize, t->cols, total);
+    if (!r) { cleanup(); return nullptr; }
+    rfxk::tile_emit(c, tv, t->lut, halo, lower, upper, tile_off, n_tiles, sort_cap, r->keys, r->counts, r->pos);
+    e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) { hip_fail(e, "tile_emit"); rfx_records_free(r); return nullptr; }
+    if (histo && rfx_records_histo(r, histo) != RFX_OK) { rfx_records_free(r); return nullptr; }
+    return r;
+  }
+  snprintf(g_err, sizeof g_err, "rfx_count_finish: tiles stay too dense after growing");
+  return nullptr;
+}
+
+// ---------------------------------------------------------------------------------------------
+uint64_t rfx_records_size(const rfx_records* r) { return r ? r->n : 0; }
+int rfx_records_k(const rfx_records* r) { return r ? r->k : 0; }
+int rfx_records_lsize(const rfx_records* r) { return r ? r->lsize : 0; }
+const uint64_t* rfx_records_dev_keys(const rfx_records* r) { return r ? r->keys : nullptr; }
+const uint32_t* rfx_records_dev_counts(const rfx_records* r) { return r ? r->counts : nullptr; }
+const uint64_t* rfx_records_dev_pos(const rfx_records* r) { return r ? r->pos : nullptr; }
+
+void rfx_records_free(rfx_records* r) {
+  if (!r) return;
+  dfree(r->ctx, r->keys); dfree(r->ctx, r->counts); dfree(r->ctx, r->pos); dfree(r->ctx, r->lut);
+  delete r;
+}
+
+int rfx_records_payload(const rfx_records* r, void* out, size_t cap_bytes, int counter_len) {
+  if (!r || counter_len < 1 || counter_len > 8) return RFX_E_INVAL;
+  rfx_ctx* c = r->ctx;
+  (void)hipSetDevice(c->device);
+  const int kb = (2 * r->k + 7) / 8;
+  const size_t bytes = (size_t)r->n * (kb + counter_len);
+  if (bytes > cap_bytes) return RFX_E_RANGE;
+  if (bytes == 0) return RFX_OK;
+  if (!out) return RFX_E_INVAL;
+  uint8_t* d = (uint8_t*)dmalloc(c, bytes + 4);
+  if (!d) return RFX_E_NOMEM;
+  rfxk::format_records(c, r->keys, r->counts, r->n, kb, counter_len, d);
+  hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  dfree(c, d);
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_payload");
+}
+
+int rfx_records_get(const rfx_records* r, uint64_t* keys, uint32_t* counts, uint64_t* pos) {
+  if (!r) return RFX_E_INVAL;
+  (void)hipSetDevice(r->ctx->device);
+  if (r->n == 0) return RFX_OK;
+  if (keys) HIPCHK(hipMemcpy(keys, r->keys, r->n * 8, hipMemcpyDeviceToHost));
+  if (counts) HIPCHK(hipMemcpy(counts, r->counts, r->n * 4, hipMemcpyDeviceToHost));
+  if (pos) HIPCHK(hipMemcpy(pos, r->pos, r->n * 8, hipMemcpyDeviceToHost));
+  return RFX_OK;
+}
+
+rfx_records* rfx_records_load(rfx_ctx* c, int k, int lsize, const uint64_t* cols, const void* payload, uint64_t n,
+                              int counter_len) {
+  if (!c || !cols || k < 1 || k > 32 || counter_len < 1 || counter_len > 8 || (n && !payload)) return nullptr;
+  (void)hipSetDevice(c->device);
+  rfx_records* r = records_alloc(c, k, lsize, cols, n);
+  if (!r || n == 0) return r;
+  const int kb = (2 * k + 7) / 8;
+  const size_t bytes = (size_t)n * (kb + counter_len);
+  uint8_t* d = (uint8_t*)dmalloc(c, bytes);
+  unsigned int* d_bad = (unsigned int*)dmalloc(c, 4);
+  unsigned int bad = 0;
+  bool ok = d && d_bad;
+  if (ok) ok = hipMemcpyAsync(d, payload, bytes, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+               hipMemsetAsync(d_bad, 0, 4, c->stream) == hipSuccess;
+  if (ok) {
+    rfxk::parse_records(c, d, n, kb, counter_len, r->keys, r->counts);
+    rfxk::compute_pos(c, r->keys, n, r->lut, r->ntab, r->pos);
+    rfxk::check_sorted(c, r->keys, r->pos, n, d_bad);
+    ok = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+         hipStreamSynchronize(c->stream) == hipSuccess;
+  }
+  dfree(c, d);
+  dfree(c, d_bad);
+  if (ok && bad) {
+    snprintf(g_err, sizeof g_err, "records are not in (pos,key) order for this matrix");
+    ok = false;
+  }
+  if (!ok) {
+    rfx_records_free(r);
+    return nullptr;
+  }
+  return r;
+}
+
+rfx_records* rfx_records_from_dev(rfx_ctx* c, int k, int lsize, const uint64_t* cols, const uint64_t* d_keys,
+                                  const uint32_t* d_counts, uint64_t n) {
+  if (!c || !cols || (n && (!d_keys || !d_counts))) return nullptr;
+  (void)hipSetDevice(c->device);
+  rfx_records* r = records_alloc(c, k, lsize, cols, n);
+  if (!r || n == 0) return r;
+  bool ok = hipMemcpyAsync(r->keys, d_keys, n * 8, hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+            hipMemcpyAsync(r->counts, d_counts, n * 4, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+  if (ok) {
+    rfxk::compute_pos(c, r->keys, n, r->lut, r->ntab, r->pos);
+    ok = hipStreamSynchronize(c->stream) == hipSuccess;
+  }
+  if (!ok) {
+    rfx_records_free(r);
+    return nullptr;
+  }
+  return r;
+}
+
+int rfx_records_histo(const rfx_records* r, uint64_t* histo) {
+  if (!r || !histo) return RFX_E_INVAL;
+  rfx_ctx* c = r->ctx;
+  (void)hipSetDevice(c->device);
+  unsigned long long* d = (unsigned long long*)dmalloc(c, RFX_HISTO_BINS * 8);
+  if (!d) return RFX_E_NOMEM;
+  hipError_t e = hipMemsetAsync(d, 0, RFX_HISTO_BINS * 8, c->stream);
+  if (e == hipSuccess) {
+    rfxk::histo(c, r->counts, r->n, d);
+    e = hipMemcpyAsync(histo, d, RFX_HISTO_BINS * 8, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  dfree(c, d);
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_histo");
+}
+
+// ---------------------------------------------------------------------------------------------
+static int same_function(const rfx_records* a, const rfx_records* b) {
+  return a->k == b->k && a->lsize == b->lsize && memcmp(a->cols, b->cols, sizeof(uint64_t) * 2 * a->k) == 0;
+}
+
+int rfx_merge_unique(rfx_ctx* c, const rfx_records* const* files, int n_files, uint32_t min_count,
+                     uint64_t* keys_out, uint32_t* counts_out, uint64_t cap, uint64_t* n_out) {
+  if (!c || !files || n_files < 1 || !n_out) return RFX_E_INVAL;
+  (void)hipSetDevice(c->device);
+  for (int i = 0; i < n_files; ++i) {
+    if (!files[i] || files[i]->ctx != c) return RFX_E_INVAL;
+    // jf/jellyfish/merge_files.cc:193-203: same key length, size and matrix or refuse
+    if (!same_function(files[0], files[i])) return RFX_E_FORMAT;
+  }
+  std::vector<HostRun> runs(n_files);
+  for (int i = 0; i < n_files; ++i) {
+    int rc = unique_run(c, files[i], files, n_files, min_count, 0xFFFFFFFFu, runs[i]);
+    if (rc) return rc;
+  }
+  // k-way merge of the per-file runs by (pos, key): each run is already sorted.
+  struct Head { uint64_t pos, key; int f; size_t i; };
+  auto gt = [](const Head& a, const Head& b) { return a.pos != b.pos ? a.pos > b.pos : a.key > b.key; };
+  std::priority_queue<Head, std::vector<Head>, decltype(gt)> pq(gt);
+  uint64_t total = 0;
+  for (int f = 0; f < n_files; ++f) {
+    total += runs[f].keys.size();
+    if (!runs[f].keys.empty()) pq.push(Head{runs[f].pos[0], runs[f].keys[0], f, 0});
+  }
+  *n_out = total;
+  if (total > cap) return RFX_E_RANGE;
+  uint64_t o = 0;
+  while (!pq.empty()) {
+    Head h = pq.top();
+    pq.pop();
+    if (keys_out) keys_out[o] = h.key;
+    if (counts_out) counts_out[o] = runs[h.f].counts[h.i];
+    ++o;
+    if (h.i + 1 < runs[h.f].keys.size()) pq.push(Head{runs[h.f].pos[h.i + 1], runs[h.f].keys[h.i + 1], h.f, h.i + 1});
+  }
+  return RFX_OK;
+}
+
+int rfx_query(const rfx_records* db, const uint64_t* keys, uint64_t n, uint32_t* counts_out) {
+  if (!db || (n && (!keys || !counts_out))) return RFX_E_INVAL;
+  rfx_ctx* c = db->ctx;
+  (void)hipSetDevice(c->device);
+  if (n == 0) return RFX_OK;
+  uint64_t* dq = (uint64_t*)dmalloc(c, n * 8);
+  uint32_t* dout = (uint32_t*)dmalloc(c, n * 4);
+  if (!dq || !dout) { dfree(c, dq); dfree(c, dout); return RFX_E_NOMEM; }
+  hipError_t e = hipMemcpyAsync(dq, keys, n * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    rfxk::query(c, dq, n, db->lut, db->ntab, db->keys, db->pos, db->counts, db->n, dout);
+    e = hipMemcpyAsync(counts_out, dout, n * 4, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  dfree(c, dq); dfree(c, dout);
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_query");
+}
+
+int rfx_unique_to_subject(rfx_ctx* c, const rfx_records* subject, const rfx_records* const* others, int n_others,
+                          uint32_t min_count, uint32_t min_cov, uint32_t max_cov, uint64_t* keys_out,
+                          uint32_t* counts_out, uint64_t cap, uint64_t* n_out) {
+  if (!c || !subject || n_others < 0 || (n_others && !others) || !n_out) return RFX_E_INVAL;
+  (void)hipSetDevice(c->device);
+  std::vector<const rfx_records*> all{subject};
+  for (int i = 0; i < n_others; ++i) {
+    if (!others[i] || !same_function(subject, others[i])) return RFX_E_FORMAT;
+    all.push_back(others[i]);
+  }
+  HostRun run;
+  const uint32_t lo = std::max(min_count, min_cov);
+  int rc = unique_run(c, subject, all.data(), (int)all.size(), lo, max_cov, run);
+  if (rc) return rc;
+  *n_out = run.keys.size();
+  if (run.keys.size() > cap) return RFX_E_RANGE;
+  if (keys_out) memcpy(keys_out, run.keys.data(), run.keys.size() * 8);
+  if (counts_out) memcpy(counts_out, run.counts.data(), run.counts.size() * 4);
+  return RFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) {
+  if (!c || k < 1 || k > 32 || (n && !fwd_keys)) return nullptr;
+  (void)hipSetDevice(c->device);
+  rfx_set* s = new rfx_set();
+  memset(s, 0, sizeof *s);
+  s->ctx = c;
+  s->k = k;
+  s->n = n;
+  s->bits = std::max(6, ceil_log2(n * 2 + 1));
+  if (s->bits > 31) {
+    delete s;
+    return nullptr;
+  }
+  s->cap = 1ull << s->bits;
+  for (uint64_t i = 0; i < n; ++i)
+    if (fwd_keys[i] == RFX_EMPTY) s->has_all_ones = 1;
+  s->slots = (uint64_t*)dmalloc(c, s->cap * 8);
+  uint64_t* dk = (uint64_t*)dmalloc(c, n * 8);
+  bool ok = s->slots && dk;
+  if (ok) ok = hipMemsetAsync(s->slots, 0xFF, s->cap * 8, c->stream) == hipSuccess;
+  if (ok && n) ok = hipMemcpyAsync(dk, fwd_keys, n * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+  if (ok) {
+    rfxk::set_insert(c, dk, n, s->slots, s->bits);
+    ok = hipStreamSynchronize(c->stream) == hipSuccess;
+  }
+  dfree(c, dk);
+  if (!ok) {
+    rfx_set_free(s);
+    return nullptr;
+  }
+  return s;
+}
+uint64_t rfx_set_size(const rfx_set* s) { return s ? s->n : 0; }
+void rfx_set_free(rfx_set* s) {
+  if (!s) return;
+  dfree(s->ctx, s->slots);
+  delete s;
+}
+
+int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped, uint32_t* hits_out,
+               uint64_t* hitmask_out, uint64_t* n_hit_reads) {
+  if (!s || !r || s->ctx != r->ctx || !r->good) return RFX_E_INVAL;
+  rfx_ctx* c = s->ctx;
+  (void)hipSetDevice(c->device);
+  if (n_hit_reads) *n_hit_reads = 0;
+  if (r->n == 0) return RFX_OK;
+  const uint64_t nmask = ((uint64_t)r->n + 63) / 64;
+  uint32_t* d_hits = hits_out ? (uint32_t*)dmalloc(c, (size_t)r->n * 4) : nullptr;
+  uint64_t* d_mask = (uint64_t*)dmalloc(c, nmask * 8);
+  unsigned long long* d_n = (unsigned long long*)dmalloc(c, 8);
+  auto cleanup = [&] { dfree(c, d_hits); dfree(c, d_mask); dfree(c, d_n); };
+  if ((hits_out && !d_hits) || !d_mask || !d_n) { cleanup(); return RFX_E_NOMEM; }
+  hipError_t e = hipMemsetAsync(d_n, 0, 8, c->stream);
+  if (e == hipSuccess) {
+    rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+    rfxk::filter(c, rv, s->slots, s->bits, s->has_all_ones, s->k, thresh, last_base_skipped, d_hits, d_mask, d_n);
+    unsigned long long nh = 0;
+    e = hipMemcpyAsync(&nh, d_n, 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && hits_out) e = hipMemcpyAsync(hits_out, d_hits, (size_t)r->n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && hitmask_out) e = hipMemcpyAsync(hitmask_out, d_mask, nmask * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && n_hit_reads) *n_hit_reads = nh;
+  }
+  cleanup();
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_filter");
+}
+
+}  // extern "C"

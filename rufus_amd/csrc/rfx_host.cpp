@@ -1,0 +1,338 @@
+// Host-only half of the C-ABI: jellyfish hash matrix, read packing, hash-list loader, .Jhash header.
+// No device code here; everything is callable on a machine without a GPU.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include <unistd.h>
+#include <sys/utsname.h>
+
+#include "../../include/rufus_hip.h"
+
+namespace {
+
+// glibc's default random(): TYPE_3 additive feedback generator x[i] = x[i-3] + x[i-31], seeded
+// with 1 when the program never calls srandom() -- which jellyfish never does
+// (jf/lib/misc.cc:74-80 calls random() directly).  Re-implemented so the matrix does not depend on
+// the process-wide libc state of whoever loads this library.
+struct GlibcRandom {
+  uint32_t st[31];
+  int f, r;  // front / rear cursors of the 31-word ring (separation 3)
+  explicit GlibcRandom(uint32_t seed = 1) : f(3), r(0) {
+    int32_t w = (int32_t)(seed ? seed : 1);
+    st[0] = (uint32_t)w;
+    for (int i = 1; i < 31; ++i) {
+      // 16807 * w mod (2^31 - 1) by Schrage's method, as srandom_r does
+      const int32_t hi = w / 127773, lo = w % 127773;
+      w = 16807 * lo - 2836 * hi;
+      if (w < 0) w += 2147483647;
+      st[i] = (uint32_t)w;
+    }
+    for (int i = 0; i < 310; ++i) next();  // srandom_r discards 10 * 31 outputs
+  }
+  uint32_t next() {
+    st[f] += st[r];
+    const uint32_t out = st[f] >> 1;
+    f = (f + 1) % 31;
+    r = (r + 1) % 31;
+    return out;
+  }
+};
+
+// jf/lib/misc.cc:74-80 with ConstFloorLog2<RAND_MAX>::val == 30.
+uint64_t random_bits64(GlibcRandom& g) {
+  uint64_t res = 0;
+  for (int i = 0; i < 64; i += 30) res ^= (uint64_t)g.next() << i;
+  return res;
+}
+
+// Column-wise Gauss-Jordan of the r x c matrix whose top (c-r) rows are an implicit identity;
+// returns false if singular.  jf/lib/rectangular_binary_matrix.cc:138-186.
+bool pseudo_inverse(std::vector<uint64_t> piv, int r, int c, std::vector<uint64_t>& inv) {
+  inv.assign(c, 0);
+  const int first = c - r;
+  for (int i = first; i < c; ++i) inv[i] = 1ull << (r - 1 - (i - first));
+  for (int i = first; i < c; ++i) {
+    const uint64_t bit = 1ull << (r - 1 - (i - first));
+    if (!(piv[i] & bit)) {
+      int j = i + 1;
+      while (j < c && !(piv[j] & bit)) ++j;
+      if (j == c) return false;
+      piv[i] ^= piv[j];
+      inv[i] ^= inv[j];
+    }
+    for (int j = i + 1; j < c; ++j)
+      if (piv[j] & bit) {
+        piv[j] ^= piv[i];
+        inv[j] ^= inv[i];
+      }
+  }
+  for (int i = first; i < c; ++i) {
+    const uint64_t bit = 1ull << (r - 1 - (i - first));
+    for (int j = 0; j < i; ++j)
+      if (piv[j] & bit) {
+        piv[j] ^= piv[i];
+        inv[j] ^= inv[i];
+      }
+  }
+  return true;
+}
+
+inline int jf_code(unsigned char ch) {
+  switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return -1;
+  }
+}
+
+// Util::Split (src/Util.cpp:24-33): std::getline tokens, no trailing empty token.
+std::vector<std::string> split(const std::string& s, char d) {
+  std::vector<std::string> t;
+  size_t i = 0;
+  while (i < s.size()) {
+    const size_t j = s.find(d, i);
+    if (j == std::string::npos) {
+      t.push_back(s.substr(i));
+      break;
+    }
+    t.push_back(s.substr(i, j - i));
+    i = j + 1;
+  }
+  return t;
+}
+
+// Util::HashToLong (src/Util.cpp:51-84) of `s`, returned as a forward jellyfish key of k bases:
+// base i contributes its code at bits 2(k-1-i); unknown characters and missing positions are A.
+uint64_t rufus_key(const std::string& s, int k) {
+  uint64_t key = 0;
+  for (int i = 0; i < k; ++i) {
+    uint64_t code = 0;
+    if (i < (int)s.size()) {
+      switch (s[i]) {
+        case 'C': code = 1; break;
+        case 'G': code = 2; break;
+        case 'T': code = 3; break;
+        default: break;
+      }
+    }
+    key |= code << (2 * (k - 1 - i));
+  }
+  return key;
+}
+
+// Util::RevComp (src/Util.cpp:187-210): ACGTN complemented, everything else dropped.
+std::string rufus_revcomp(const std::string& s) {
+  std::string o;
+  for (size_t i = s.size(); i-- > 0;) {
+    switch (s[i]) {
+      case 'A': o += 'T'; break;
+      case 'C': o += 'G'; break;
+      case 'G': o += 'C'; break;
+      case 'T': o += 'A'; break;
+      case 'N': o += 'N'; break;
+      default: break;
+    }
+  }
+  return o;
+}
+
+void json_escape(std::string& out, const char* s) {
+  out += '"';
+  for (; *s; ++s) {
+    const unsigned char ch = (unsigned char)*s;
+    if (ch == '"' || ch == '\\') { out += '\\'; out += (char)ch; }
+    else if (ch == '\n') out += "\\n";
+    else if (ch == '\t') out += "\\t";
+    else if (ch < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", ch); out += b; }
+    else out += (char)ch;
+  }
+  out += '"';
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rfx_version(void) { return "rufus_amd 0.1 (gfx950)"; }
+
+const char* rfx_strerror(int code) {
+  switch (code) {
+    case RFX_OK: return "ok";
+    case RFX_E_NODEVICE: return "no usable gfx950 device";
+    case RFX_E_INVAL: return "invalid argument";
+    case RFX_E_NOMEM: return "out of memory / hbm budget exceeded";
+    case RFX_E_FULL: return "count table full";
+    case RFX_E_HIP: return "HIP runtime error";
+    case RFX_E_MIXEDCASE: return "lower-case bases: pack count and filter blocks separately";
+    case RFX_E_RANGE: return "output buffer too small";
+    case RFX_E_FORMAT: return "malformed input";
+    default: return "unknown error";
+  }
+}
+
+int rfx_jf_matrix(int lsize, int k, uint64_t* cols) {
+  const int r = lsize, c = 2 * k;
+  if (r < 1 || r > 64 || k < 1 || c < r || !cols) return RFX_E_INVAL;
+  GlibcRandom rng(1);
+  const uint64_t cmask = ~0ull >> (64 - r);
+  std::vector<uint64_t> m(c), inv;
+  do {
+    for (int i = 0; i < c; ++i) m[i] = random_bits64(rng) & cmask;
+  } while (!pseudo_inverse(m, r, c, inv));
+  memcpy(cols, inv.data(), sizeof(uint64_t) * c);
+  return RFX_OK;
+}
+
+uint64_t rfx_jf_pos(const uint64_t* cols, int k, int lsize, uint64_t key) {
+  const int c = 2 * k;
+  uint64_t res = 0;
+  for (int b = 0; b < c && b < 64; ++b)
+    if ((key >> b) & 1) res ^= cols[c - 1 - b];
+  return lsize >= 64 ? res : res & ((1ull << lsize) - 1);
+}
+
+uint64_t rfx_pack_words(const uint64_t* off, uint32_t n_reads) {
+  uint64_t w = 0;
+  for (uint32_t i = 0; i < n_reads; ++i) w += (off[i + 1] - off[i] + 31) / 32;
+  return w;
+}
+
+int rfx_pack_reads(const char* seq, const char* qual, const uint64_t* off, uint32_t n_reads, int min_q, int flags,
+                   uint64_t* codes, uint32_t* acgt, uint32_t* good, uint32_t* word_off, uint32_t* len) {
+  if (!seq || !off || !codes || !word_off || !len) return RFX_E_INVAL;
+  const bool want_count = flags & RFX_PACK_COUNT, want_filter = flags & RFX_PACK_FILTER;
+  if ((want_count && !acgt) || (want_filter && !good) || (!want_count && !want_filter)) return RFX_E_INVAL;
+  uint64_t w = 0;
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    const uint64_t b0 = off[r], L = off[r + 1] - off[r];
+    if (L > 0xFFFFFFFFull || w > 0xFFFFFFFFull) return RFX_E_RANGE;
+    word_off[r] = (uint32_t)w;
+    len[r] = (uint32_t)L;
+    for (uint64_t i = 0; i < L; i += 32) {
+      uint64_t cw = 0;
+      uint32_t ma = 0, mg = 0;
+      const uint64_t nb = std::min<uint64_t>(32, L - i);
+      for (uint64_t b = 0; b < nb; ++b) {
+        const unsigned char ch = (unsigned char)seq[b0 + i + b];
+        const int jc = jf_code(ch);
+        uint64_t code = 0;
+        if (want_filter) {
+          // src/Util.cpp:51-84: only upper-case ACGT carry bits
+          if (ch == 'C') code = 1;
+          else if (ch == 'G') code = 2;
+          else if (ch == 'T') code = 3;
+          if (want_count && jc > 0 && ch >= 'a') return RFX_E_MIXEDCASE;
+          const int q = qual ? (int)(signed char)qual[b0 + i + b] : 0;
+          if (!(q - 33 < min_q || ch == 'N')) mg |= 1u << b;  // src/RUFUS.Filter.cpp:205
+        } else {
+          code = jc < 0 ? 0 : (uint64_t)jc;
+        }
+        if (want_count && jc >= 0) ma |= 1u << b;
+        cw |= code << (2 * b);
+      }
+      codes[w] = cw;
+      if (acgt) acgt[w] = ma;
+      if (good) good[w] = mg;
+      ++w;
+    }
+  }
+  if (w > 0xFFFFFFFFull) return RFX_E_RANGE;
+  word_off[n_reads] = (uint32_t)w;
+  return RFX_OK;
+}
+
+long rfx_hashlist_keys(const char* text, size_t n, int k, int single_end, uint64_t* keys_out, size_t cap) {
+  if (!text || k < 1 || k > 32) return RFX_E_INVAL;
+  const char first = single_end ? '\t' : ' ', second = single_end ? ' ' : '\t';
+  long count = 0;
+  const char *p = text, *end = text + n;
+  while (p < end) {
+    const char* nl = (const char*)memchr(p, '\n', end - p);
+    const std::string line(p, nl ? nl : end);
+    p = nl ? nl + 1 : end;
+    std::vector<std::string> t = split(line, first);
+    std::string kmer;
+    bool have = false;
+    if (t.size() == 2) { kmer = t[0]; have = true; }
+    else if (t.size() == 4) { kmer = t[3]; have = true; }
+    if (t.size() == 1) {
+      t = split(line, second);
+      if (!t.empty()) { kmer = t[0]; have = true; }
+    }
+    if (!have) continue;
+    const uint64_t fw = rufus_key(kmer, k), rv = rufus_key(rufus_revcomp(kmer), k);
+    if (keys_out) {
+      if ((size_t)count + 2 > cap) return RFX_E_RANGE;
+      keys_out[count] = fw;
+      keys_out[count + 1] = rv;
+    }
+    count += 2;
+  }
+  return count;
+}
+
+long rfx_jhash_header(int k, int lsize, const uint64_t* cols, int canonical, int counter_len, int argc,
+                      const char* const* argv, char* buf, size_t cap) {
+  if (!cols || !buf || k < 1 || lsize < 1 || lsize > 63) return RFX_E_INVAL;
+  // jf/include/jellyfish/large_hash_array.hpp:37-48: the reprobe limit shrinks until its offset fits the table.
+  auto reprobe = [](int i) -> uint64_t { return i == 0 ? 1 : (uint64_t)i * (i + 1) / 2; };
+  int max_reprobe = 126;  // jf/sub_commands/count_main_cmdline.hpp:361-369 default
+  const uint64_t size = 1ull << lsize;
+  while (max_reprobe >= 1 && reprobe(max_reprobe) >= size) --max_reprobe;
+
+  char tmp[4096];
+  struct utsname un;
+  std::string host = uname(&un) == 0 ? un.nodename : "";
+  std::string pwd = getcwd(tmp, sizeof tmp) ? tmp : "";
+  ssize_t l = readlink("/proc/self/exe", tmp, sizeof tmp - 1);
+  std::string exe = l > 0 ? std::string(tmp, (size_t)l) : "";
+  time_t now = time(nullptr);
+  std::string when = ctime_r(&now, tmp) ? tmp : "";
+  while (!when.empty() && (when.back() == '\n' || when.back() == ' ')) when.pop_back();
+
+  // Keys in std::map (alphabetical) order like Json::FastWriter (generic_file_header.hpp:96-121).
+  std::string js = "{\"alignment\":8,\"canonical\":";
+  js += canonical ? "true" : "false";
+  js += ",\"cmdline\":[";
+  for (int i = 0; i < argc; ++i) {
+    if (i) js += ',';
+    json_escape(js, argv[i]);
+  }
+  js += "],\"counter_len\":" + std::to_string(counter_len);
+  js += ",\"exe_path\":"; json_escape(js, exe.c_str());
+  js += ",\"format\":\"binary/sorted\",\"hostname\":"; json_escape(js, host.c_str());
+  js += ",\"key_len\":" + std::to_string(2 * k);
+  js += ",\"matrix1\":{\"c\":" + std::to_string(2 * k) + ",\"columns\":[";
+  for (int i = 0; i < 2 * k; ++i) {
+    if (i) js += ',';
+    js += std::to_string((unsigned long long)cols[i]);
+  }
+  js += "],\"r\":" + std::to_string(lsize) + "}";
+  js += ",\"max_reprobe\":" + std::to_string(max_reprobe);
+  js += ",\"pwd\":"; json_escape(js, pwd.c_str());
+  js += ",\"reprobes\":[";
+  for (int i = 0; i <= max_reprobe; ++i) {
+    if (i) js += ',';
+    js += std::to_string((unsigned long long)reprobe(i));
+  }
+  js += "],\"size\":" + std::to_string((unsigned long long)size);
+  js += ",\"time\":"; json_escape(js, when.c_str());
+  js += ",\"val_len\":7}";
+
+  size_t hlen = js.size();
+  const size_t rem = (9 + js.size()) % 8;
+  if (rem) hlen += 8 - rem;
+  if (9 + hlen > cap) return RFX_E_RANGE;
+  snprintf(buf, 10, "%09zu", hlen);
+  memcpy(buf + 9, js.data(), js.size());
+  memset(buf + 9 + js.size(), 0, hlen - js.size());
+  return (long)(9 + hlen);
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// Internal structures shared by the C-ABI layer (rfx_api.hip) and the kernels (rfx_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rufus_hip.h"
+
+#define RFX_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define RFX_TILE 1024u          // table slots per finish tile
+#define RFX_TABLE_MARGIN 65536u // probe run-off slots behind the last home slot (no wrap-around)
+#define RFX_PROBE_LIMIT 2048u   // longer probes divert the key to the overflow list and stop the launch
+
+struct rfx_prof_span {
+  std::string name;
+  hipEvent_t e0, e1;
+};
+struct rfx_prof_acc {
+  double ms = 0;
+  uint64_t launches = 0;
+};
+
+struct rfx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  size_t budget = 0, used = 0;
+  int n_cu = 256;
+  bool prof = false;
+  std::vector<rfx_prof_span> spans;
+  std::map<std::string, rfx_prof_acc> acc;
+  std::map<void*, size_t> allocs;
+};
+
+// Device-side statistics of a count table.
+struct rfx_table_stats {
+  unsigned long long distinct;  // occupied slots
+  unsigned int max_disp;        // largest (slot - home) of any occupied slot
+  unsigned int overflow;        // a probe ran past the margin: the table content is NOT exact
+};
+
+// Launch control of the read-count kernel: chunks of reads are handed out by ticket so a launch can
+// stop early (table getting full) and be resumed exactly after the host has grown the table.
+struct rfx_count_ctl {
+  unsigned int ticket;          // next chunk to hand out; chunks below it are fully processed
+  unsigned int stop;            // set by the first block that sees the load limit or diverts a key
+  unsigned int lost;            // overflow list itself overflowed: counts are NOT exact (fatal)
+  unsigned int pad;
+  unsigned long long ovf_n;     // keys diverted to the overflow list (each stands for one instance)
+};
+
+// What kernels see of a table.  home(pos) = pos >> rshift (or << lshift): monotone in pos, so a
+// linear-probed slot array is "almost" in (pos,key) order and finish only sorts inside tiles.
+struct rfx_table_view {
+  uint64_t* keys;
+  uint32_t* counts;
+  uint64_t slots;  // cap + margin
+  uint64_t cap;
+  int rshift, lshift;
+  uint64_t pos_lo, pos_hi;
+  int ntab;    // byte-indexed GF(2) lookup tables in use (ceil(2k/8))
+  int kshift;  // 2k - lshift: top key bits order equal-pos entries when the table is finer than pos
+};
+
+struct rfx_reads_view {
+  const uint64_t* codes;
+  const uint32_t* acgt;
+  const uint32_t* good;
+  const uint32_t* word_off;
+  const uint32_t* len;
+  uint32_t n;
+};
+
+struct rfx_reads {
+  rfx_ctx* ctx;
+  uint32_t n;
+  uint64_t n_words, n_bases;
+  uint32_t max_len;
+  uint64_t* codes;
+  uint32_t *acgt, *good, *word_off, *len;
+};
+
+struct rfx_table {
+  rfx_ctx* ctx;
+  int k, canonical, lsize;
+  uint64_t cap;  // power of two
+  int tbits;
+  uint64_t pos_lo, pos_hi;
+  uint64_t* keys;
+  uint32_t* counts;
+  uint64_t* lut;  // device: ntab x 256 uint64
+  int ntab;
+  rfx_table_stats* d_stats;
+  rfx_count_ctl* d_ctl;
+  uint64_t* ovf_keys;
+  uint64_t ovf_cap;
+  uint64_t cols[64];
+};
+
+struct rfx_records {
+  rfx_ctx* ctx;
+  int k, lsize, ntab;
+  uint64_t n;
+  uint64_t* keys;
+  uint32_t* counts;
+  uint64_t* pos;
+  uint64_t* lut;
+  uint64_t cols[64];
+};
+
+struct rfx_set {
+  rfx_ctx* ctx;
+  int k, bits;
+  uint64_t n, cap;
+  uint64_t* slots;
+  int has_all_ones;  // K = 32 poly-T collides with the empty sentinel
+};
+
+// ---- kernel launchers (rfx_kernels.hip) -------------------------------------------------------
+namespace rfxk {
+int count_reads_grid(rfx_ctx*, uint32_t n_reads);
+int count_reads_block();
+void count_reads(rfx_ctx*, const rfx_reads_view&, const rfx_table_view&, const uint64_t* lut, int k, int canonical,
+                 rfx_table_stats* stats, rfx_count_ctl* ctl, uint64_t* ovf_keys, uint64_t ovf_cap,
+                 uint64_t load_limit);
+// counts == nullptr: every key stands for one instance (overflow list re-insert)
+void count_pairs(rfx_ctx*, const uint64_t* keys, const uint32_t* counts, uint64_t n, const rfx_table_view&,
+                 const uint64_t* lut, rfx_table_stats* stats);
+void table_pairs(rfx_ctx*, const rfx_table_view&, uint64_t* out_keys, uint32_t* out_counts,
+                 unsigned long long* d_n);  // every occupied slot, unordered
+void tile_count(rfx_ctx*, const rfx_table_view&, const uint64_t* lut, uint32_t halo, uint64_t lower, uint64_t upper,
+                uint32_t* tile_counts, uint64_t n_tiles);
+void tile_scan(rfx_ctx*, const uint32_t* tile_counts, uint64_t n_tiles, uint64_t* tile_off /* n_tiles+1 */,
+               uint32_t* d_max);
+void tile_emit(rfx_ctx*, const rfx_table_view&, const uint64_t* lut, uint32_t halo, uint64_t lower, uint64_t upper,
+               const uint64_t* tile_off, uint64_t n_tiles, uint32_t sort_cap, uint64_t* out_keys, uint32_t* out_counts,
+               uint64_t* out_pos);
+void histo(rfx_ctx*, const uint32_t* counts, uint64_t n, unsigned long long* d_histo);
+void format_records(rfx_ctx*, const uint64_t* keys, const uint32_t* counts, uint64_t n, int key_bytes, int counter_len,
+                    uint8_t* out);
+void parse_records(rfx_ctx*, const uint8_t* in, uint64_t n, int key_bytes, int counter_len, uint64_t* keys,
+                   uint32_t* counts);
+void compute_pos(rfx_ctx*, const uint64_t* keys, uint64_t n, const uint64_t* lut, int ntab, uint64_t* pos);
+void check_sorted(rfx_ctx*, const uint64_t* keys, const uint64_t* pos, uint64_t n, unsigned int* d_bad);
+void flag_range(rfx_ctx*, const uint32_t* counts, uint64_t n, uint32_t lo, uint32_t hi, uint8_t* flags);
+void flag_absent(rfx_ctx*, const uint64_t* keys, const uint64_t* pos, uint64_t n, const uint64_t* bkeys,
+                 const uint64_t* bpos, uint64_t nb, uint8_t* flags);
+void compact(rfx_ctx*, const uint8_t* flags, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos,
+             uint64_t n, uint64_t* out_keys, uint32_t* out_counts, uint64_t* out_pos, uint64_t* block_off,
+             unsigned long long* d_total);
+void query(rfx_ctx*, const uint64_t* qkeys, uint64_t nq, const uint64_t* lut, int ntab, const uint64_t* keys,
+           const uint64_t* pos, const uint32_t* counts, uint64_t n, uint32_t* out);
+void set_insert(rfx_ctx*, const uint64_t* keys, uint64_t n, uint64_t* slots, int bits);
+void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, int k, int thresh,
+            int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit);
+}  // namespace rfxk
+
+// Launch bracket: records a HIP-event span on the ctx stream when profiling is on.
+struct rfx_span {
+  rfx_ctx* c;
+  rfx_prof_span s;
+  bool on;
+  rfx_span(rfx_ctx* ctx, const char* name) : c(ctx), on(ctx->prof) {
+    if (on) {
+      s.name = name;
+      hipEventCreate(&s.e0);
+      hipEventCreate(&s.e1);
+      hipEventRecord(s.e0, c->stream);
+    }
+  }
+  ~rfx_span() {
+    if (on) {
+      hipEventRecord(s.e1, c->stream);
+      c->spans.push_back(s);
+    }
+  }
+};

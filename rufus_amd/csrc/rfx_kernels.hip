@@ -1,0 +1,846 @@
+// CDNA4 (gfx950) kernels of the RUFUS hot path.  Integer / hash work: no MFMA anywhere; the
+// levers are coalesced 16-byte streaming of the packed reads through LDS, an LDS-resident GF(2)
+// lookup for jellyfish's matrix hash, 64-wide wave ballots for hit compaction, and a table layout
+// whose slot order already is (almost) the output order.
+//
+// Kernel  | replaces (reference file:line)
+// K2 count_reads  jf/include/jellyfish/mer_iterator.hpp:59-88 + large_hash_array.hpp:298-302,:513-744
+// K3 tile_*       jf/include/jellyfish/sorted_dumper.hpp:80-112, mer_heap.hpp:34-38, histo_main.cc:33-89
+// K4 flag_*/query jf/jellyfish/merge_files.cc:69-155, jf/include/jellyfish/binary_dumper.hpp:156-203
+// K5 filter       src/RUFUS.Filter.cpp:196-277, src/RUFUS.Filter.ss.cpp:164-203
+#include "rfx_internal.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+
+// ---------------------------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------------------------
+// pos = M * key over GF(2): XOR of one 256-entry table per key byte
+// (jf/include/jellyfish/rectangular_binary_matrix.hpp:206-243 computes the same product bit by bit).
+__device__ __forceinline__ uint64_t gf2_pos(const uint64_t* __restrict__ lut, uint64_t key, int ntab) {
+  uint64_t r = 0;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    if (t < ntab) r ^= lut[t * 256 + (uint32_t)((key >> (8 * t)) & 255u)];
+  return r;
+}
+
+// Home slot: monotone in (pos, key) so that slot order is (almost) the output order.
+__device__ __forceinline__ uint64_t home_of(const rfx_table_view& tv, uint64_t pos, uint64_t key) {
+  return tv.lshift ? ((pos << tv.lshift) | (key >> tv.kshift)) : (pos >> tv.rshift);
+}
+
+__device__ __forceinline__ void load_lut(uint64_t* s_lut, const uint64_t* g_lut, int ntab) {
+  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
+}
+
+// Linear-probe insert.  The plain load is only a hint: keys never change once written, so a
+// non-empty value is final; a stale "empty" is corrected by the CAS.  Returns false when the probe
+// ran longer than RFX_PROBE_LIMIT (or off the end): the caller diverts the key.
+__device__ __forceinline__ bool table_add(const rfx_table_view& tv, uint64_t key, uint32_t inc, uint64_t home,
+                                          uint32_t& n_new, uint32_t& max_disp) {
+  uint64_t slot = home;
+  const uint64_t last = min(tv.slots, home + RFX_PROBE_LIMIT);
+  for (; slot < last; ++slot) {
+    uint64_t cur = tv.keys[slot];
+    if (cur == RFX_EMPTY) {
+      cur = atomicCAS((unsigned long long*)&tv.keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+      if (cur == RFX_EMPTY) {
+        ++n_new;
+        uint32_t d = (uint32_t)(slot - home);
+        max_disp = d > max_disp ? d : max_disp;
+        cur = key;
+      }
+    }
+    if (cur == key) {
+      atomicAdd(&tv.counts[slot], inc);
+      return true;
+    }
+  }
+  return false;
+}
+
+__device__ __forceinline__ void flush_stats(rfx_table_stats* stats, uint32_t n_new, uint32_t max_disp,
+                                            uint32_t overflow) {
+  for (int off = WAVE / 2; off > 0; off >>= 1) {
+    n_new += __shfl_down(n_new, off);
+    uint32_t o = __shfl_down(max_disp, off);
+    max_disp = o > max_disp ? o : max_disp;
+    overflow |= __shfl_down(overflow, off);
+  }
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    if (n_new) atomicAdd(&stats->distinct, (unsigned long long)n_new);
+    if (max_disp) atomicMax(&stats->max_disp, max_disp);
+    if (overflow) atomicOr(&stats->overflow, 1u);
+  }
+}
+
+// Stage the code and mask words of reads [r0, r0+nr) into LDS with coalesced loads.  Returns false
+// (nothing staged) when the chunk is larger than the staging area.
+template <int STAGE_WORDS>
+__device__ __forceinline__ bool stage_chunk(const uint64_t* __restrict__ codes, const uint32_t* __restrict__ mask,
+                                            uint32_t w0, uint32_t w1, uint64_t* s_codes, uint32_t* s_mask) {
+  uint32_t nw = w1 - w0;
+  if (nw > (uint32_t)STAGE_WORDS) return false;
+  for (uint32_t i = threadIdx.x; i < nw; i += blockDim.x) {
+    s_codes[i] = codes[w0 + i];
+    s_mask[i] = mask[w0 + i];
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: count canonical k-mers of a read block
+// ---------------------------------------------------------------------------------------------
+constexpr int K2_BLOCK = 512;
+constexpr int K2_STAGE = K2_BLOCK * 6;  // words: reads up to 192 bases on average are staged
+
+// Chunks of K2_BLOCK reads are handed out by ticket.  A block stops asking for chunks as soon as
+// the table passes its load limit or any key had to be diverted; the host then grows the table,
+// re-inserts the diverted keys and relaunches from the ticket -- nothing is lost or double counted.
+template <bool CANON>
+__global__ __launch_bounds__(K2_BLOCK) void k_count_reads(rfx_reads_view rv, rfx_table_view tv,
+                                                           const uint64_t* __restrict__ g_lut, int k,
+                                                           rfx_table_stats* stats, rfx_count_ctl* ctl,
+                                                           uint64_t* __restrict__ ovf_keys, uint64_t ovf_cap,
+                                                           uint64_t load_limit) {
+  __shared__ uint64_t s_lut[8 * 256];
+  __shared__ uint64_t s_codes[K2_STAGE];
+  __shared__ uint32_t s_mask[K2_STAGE];
+  __shared__ uint32_t s_chunk;
+  load_lut(s_lut, g_lut, tv.ntab);
+
+  const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+  const int rcshift = 2 * (k - 1);
+  const uint32_t n_chunks = (rv.n + K2_BLOCK - 1) / K2_BLOCK;
+
+  for (;;) {
+    __syncthreads();  // previous chunk fully consumed (and LUT visible on the first trip)
+    if (threadIdx.x == 0) {
+      uint32_t c = 0xFFFFFFFFu;
+      const unsigned int stop = __hip_atomic_load(&ctl->stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long d = __hip_atomic_load(&stats->distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!stop && d > load_limit) atomicExch(&ctl->stop, 1u);
+      else if (!stop) {
+        // never hand out a ticket past the end: the ticket then equals the number of chunks done
+        c = atomicAdd(&ctl->ticket, 1u);
+        if (c >= n_chunks) {
+          atomicSub(&ctl->ticket, 1u);
+          c = 0xFFFFFFFFu;
+        }
+      }
+      s_chunk = c;
+    }
+    __syncthreads();
+    const uint32_t chunk = s_chunk;
+    if (chunk == 0xFFFFFFFFu) break;
+
+    const uint32_t r0 = chunk * K2_BLOCK;
+    const uint32_t r1 = min(rv.n, r0 + K2_BLOCK);
+    const uint32_t w0 = rv.word_off[r0], w1 = rv.word_off[r1];
+    const bool staged = stage_chunk<K2_STAGE>(rv.codes, rv.acgt, w0, w1, s_codes, s_mask);
+    __syncthreads();
+
+    uint32_t n_new = 0, max_disp = 0;
+    const uint32_t r = r0 + threadIdx.x;
+    if (r < r1) {
+      const uint32_t wr = rv.word_off[r];
+      const uint32_t len = rv.len[r];
+      const uint64_t* cw = staged ? s_codes + (wr - w0) : rv.codes + wr;
+      const uint32_t* cm = staged ? s_mask + (wr - w0) : rv.acgt + wr;
+      uint64_t fwd = 0, rc = 0;
+      int filled = 0;
+      const uint32_t nw = (len + 31) >> 5;
+      for (uint32_t wi = 0; wi < nw; ++wi) {
+        uint64_t w = cw[wi];
+        uint32_t m = cm[wi];
+        const int nb = min(32u, len - (wi << 5));
+        for (int b = 0; b < nb; ++b) {
+          const uint32_t code = (uint32_t)w & 3u;
+          w >>= 2;
+          const bool valid = m & 1u;
+          m >>= 1;
+          fwd = ((fwd << 2) | code) & kmask;
+          if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - code) << rcshift);
+          filled = valid ? filled + 1 : 0;
+          if (filled >= k) {
+            const uint64_t key = CANON ? (rc < fwd ? rc : fwd) : fwd;
+            const uint64_t pos = gf2_pos(s_lut, key, tv.ntab);
+            if (pos >= tv.pos_lo && pos < tv.pos_hi &&
+                !table_add(tv, key, 1u, home_of(tv, pos, key), n_new, max_disp)) {
+              const unsigned long long o = atomicAdd(&ctl->ovf_n, 1ull);
+              if (o < ovf_cap) ovf_keys[o] = key;
+              else atomicExch(&ctl->lost, 1u);
+              atomicExch(&ctl->stop, 1u);
+            }
+          }
+        }
+      }
+    }
+    flush_stats(stats, n_new, max_disp, 0u);
+  }
+}
+
+// Merge pre-aggregated pairs (multi-GPU owner reduce, rehash, overflow re-insert).  The host sizes
+// the table first, so a diverted key here is an error (stats->overflow).
+__global__ __launch_bounds__(256) void k_count_pairs(const uint64_t* __restrict__ keys,
+                                                      const uint32_t* __restrict__ counts, uint64_t n,
+                                                      rfx_table_view tv, const uint64_t* __restrict__ g_lut,
+                                                      rfx_table_stats* stats) {
+  __shared__ uint64_t s_lut[8 * 256];
+  load_lut(s_lut, g_lut, tv.ntab);
+  __syncthreads();
+  uint32_t n_new = 0, max_disp = 0, overflow = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i];
+    const uint32_t c = counts ? counts[i] : 1u;
+    if (c == 0) continue;
+    const uint64_t pos = gf2_pos(s_lut, key, tv.ntab);
+    if (pos >= tv.pos_lo && pos < tv.pos_hi && !table_add(tv, key, c, home_of(tv, pos, key), n_new, max_disp))
+      overflow = 1;
+  }
+  flush_stats(stats, n_new, max_disp, overflow);
+}
+
+// Every occupied slot as an unordered (key,count) pair (rehash source).
+__global__ __launch_bounds__(256) void k_table_pairs(rfx_table_view tv, uint64_t* out_keys, uint32_t* out_counts,
+                                                      unsigned long long* d_n) {
+  for (uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; s < tv.slots;
+       s += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = tv.keys[s];
+    const bool live = key != RFX_EMPTY;
+    const unsigned long long m = __ballot(live);
+    unsigned long long base = 0;
+    const int lane = threadIdx.x & (WAVE - 1);
+    if (lane == 0 && m) base = atomicAdd(d_n, (unsigned long long)__popcll(m));
+    base = __shfl(base, 0);
+    if (live) {
+      const uint64_t o = base + __popcll(m & ((1ull << lane) - 1));
+      out_keys[o] = key;
+      out_counts[o] = tv.counts[s];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: table -> (pos,key)-sorted records
+// A tile owns the RFX_TILE home slots [a, a+T).  Linear probing only moves an entry forward by at
+// most max_disp slots, so every entry whose home is in the tile lives in [a, a+T+halo).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool tile_take(const rfx_table_view& tv, const uint64_t* s_lut, uint64_t s, uint64_t a,
+                                          uint64_t lower, uint64_t upper, uint64_t& key, uint32_t& cnt,
+                                          uint64_t& pos) {
+  key = tv.keys[s];
+  if (key == RFX_EMPTY) return false;
+  cnt = tv.counts[s];
+  if (cnt < lower || cnt > upper) return false;
+  pos = gf2_pos(s_lut, key, tv.ntab);
+  const uint64_t h = home_of(tv, pos, key);
+  return h >= a && h < a + RFX_TILE;
+}
+
+__global__ __launch_bounds__(256) void k_tile_count(rfx_table_view tv, const uint64_t* __restrict__ g_lut,
+                                                     uint32_t halo, uint64_t lower, uint64_t upper,
+                                                     uint32_t* __restrict__ tile_counts, uint64_t n_tiles) {
+  __shared__ uint64_t s_lut[8 * 256];
+  __shared__ uint32_t s_n;
+  load_lut(s_lut, g_lut, tv.ntab);
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t a = t * RFX_TILE;
+    const uint64_t end = min(tv.slots, a + RFX_TILE + halo);
+    uint32_t mine = 0;
+    for (uint64_t s = a + threadIdx.x; s < end; s += blockDim.x) {
+      uint64_t key, pos;
+      uint32_t cnt;
+      mine += tile_take(tv, s_lut, s, a, lower, upper, key, cnt, pos);
+    }
+    for (int off = WAVE / 2; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) tile_counts[t] = s_n;
+    __syncthreads();
+  }
+}
+
+// Exclusive scan of the tile counts (one block; n_tiles is small next to the table).
+__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t* __restrict__ tile_counts, uint64_t n_tiles,
+                                                     uint64_t* __restrict__ tile_off, uint32_t* d_max) {
+  __shared__ uint64_t s_part[1024];
+  __shared__ uint64_t s_carry;
+  __shared__ uint32_t s_max;
+  if (threadIdx.x == 0) {
+    s_carry = 0;
+    s_max = 0;
+  }
+  __syncthreads();
+  uint32_t mx = 0;
+  for (uint64_t base = 0; base < n_tiles; base += 1024) {
+    const uint64_t i = base + threadIdx.x;
+    const uint32_t v = i < n_tiles ? tile_counts[i] : 0;
+    mx = v > mx ? v : mx;
+    s_part[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint64_t add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const uint64_t incl = s_part[threadIdx.x];
+    if (i < n_tiles) tile_off[i] = s_carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry += incl;
+    __syncthreads();
+  }
+  atomicMax(&s_max, mx);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tile_off[n_tiles] = s_carry;
+    *d_max = s_max;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_tile_emit(rfx_table_view tv, const uint64_t* __restrict__ g_lut,
+                                                    uint32_t halo, uint64_t lower, uint64_t upper,
+                                                    const uint64_t* __restrict__ tile_off, uint64_t n_tiles,
+                                                    uint32_t sort_cap, uint64_t* __restrict__ out_keys,
+                                                    uint32_t* __restrict__ out_counts, uint64_t* __restrict__ out_pos) {
+  extern __shared__ uint64_t s_dyn[];  // [lut 2048][pos sort_cap][key sort_cap][cnt sort_cap (u32)]
+  uint64_t* s_lut = s_dyn;
+  uint64_t* s_pos = s_dyn + 8 * 256;
+  uint64_t* s_key = s_pos + sort_cap;
+  uint32_t* s_cnt = (uint32_t*)(s_key + sort_cap);
+  __shared__ uint32_t s_n;
+  load_lut(s_lut, g_lut, tv.ntab);
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t off = tile_off[t];
+    const uint32_t n_t = (uint32_t)(tile_off[t + 1] - off);
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (n_t == 0) continue;
+    const uint64_t a = t * RFX_TILE;
+    const uint64_t end = min(tv.slots, a + RFX_TILE + halo);
+    for (uint64_t s = a + threadIdx.x; s < end; s += blockDim.x) {
+      uint64_t key, pos;
+      uint32_t cnt;
+      if (tile_take(tv, s_lut, s, a, lower, upper, key, cnt, pos)) {
+        const uint32_t i = atomicAdd(&s_n, 1u);
+        s_pos[i] = pos;
+        s_key[i] = key;
+        s_cnt[i] = cnt;
+      }
+    }
+    uint32_t P = 1;
+    while (P < n_t) P <<= 1;
+    for (uint32_t i = n_t + threadIdx.x; i < P; i += blockDim.x) {
+      s_pos[i] = ~0ull;
+      s_key[i] = ~0ull;
+      s_cnt[i] = 0;
+    }
+    __syncthreads();
+    // bitonic sort by (pos, key)
+    for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+      for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+        for (uint32_t i = threadIdx.x; i < P; i += blockDim.x) {
+          const uint32_t x = i ^ j;
+          if (x > i) {
+            const uint64_t pa = s_pos[i], pb = s_pos[x], ka = s_key[i], kb = s_key[x];
+            const bool gt = pa > pb || (pa == pb && ka > kb);
+            const bool up = (i & kk) == 0;
+            if (gt == up) {
+              s_pos[i] = pb;
+              s_pos[x] = pa;
+              s_key[i] = kb;
+              s_key[x] = ka;
+              const uint32_t ca = s_cnt[i];
+              s_cnt[i] = s_cnt[x];
+              s_cnt[x] = ca;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+    for (uint32_t i = threadIdx.x; i < n_t; i += blockDim.x) {
+      out_keys[off + i] = s_key[i];
+      out_counts[off + i] = s_cnt[i];
+      out_pos[off + i] = s_pos[i];
+    }
+    __syncthreads();
+  }
+}
+
+// Count-of-counts: bin = min(count, 10001) (jf/sub_commands/histo_main.cc:40-49 with base 0, ceil 10001).
+__global__ __launch_bounds__(256) void k_histo(const uint32_t* __restrict__ counts, uint64_t n,
+                                                unsigned long long* __restrict__ g_histo) {
+  __shared__ uint32_t s_h[RFX_HISTO_BINS];
+  for (int i = threadIdx.x; i < RFX_HISTO_BINS; i += blockDim.x) s_h[i] = 0;
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    uint32_t c = counts[i];
+    atomicAdd(&s_h[c > 10001u ? 10001u : c], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RFX_HISTO_BINS; i += blockDim.x)
+    if (s_h[i]) atomicAdd(&g_histo[i], (unsigned long long)s_h[i]);
+}
+
+// SoA -> file records through an LDS byte buffer so the global stores are whole dwords.
+__global__ __launch_bounds__(256) void k_format_records(const uint64_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ counts, uint64_t n,
+                                                         int key_bytes, int counter_len, uint8_t* __restrict__ out) {
+  __shared__ uint32_t s_buf[256 * 16 / 4];
+  uint8_t* sb = (uint8_t*)s_buf;
+  const int rl = key_bytes + counter_len;
+  const uint64_t n_blocks = (n + 255) / 256;
+  for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const uint64_t i = blk * 256 + threadIdx.x;
+    if (i < n) {
+      const uint64_t key = keys[i];
+      uint64_t c = counts[i];
+      if (counter_len < 4) {
+        const uint64_t cap = (1ull << (8 * counter_len)) - 1;
+        c = c > cap ? cap : c;
+      }
+      uint8_t* p = sb + threadIdx.x * rl;
+      for (int b = 0; b < key_bytes; ++b) p[b] = (uint8_t)(key >> (8 * b));
+      for (int b = 0; b < counter_len; ++b) p[key_bytes + b] = (uint8_t)(c >> (8 * b));
+    }
+    __syncthreads();
+    const uint64_t nrec = min((uint64_t)256, n - blk * 256);
+    const uint64_t nbytes = nrec * rl;
+    uint8_t* o = out + blk * 256 * rl;  // 256*rl is a multiple of 4
+    const uint64_t ndw = nbytes / 4;
+    for (uint64_t d = threadIdx.x; d < ndw; d += blockDim.x) ((uint32_t*)o)[d] = s_buf[d];
+    for (uint64_t b = ndw * 4 + threadIdx.x; b < nbytes; b += blockDim.x) o[b] = sb[b];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_parse_records(const uint8_t* __restrict__ in, uint64_t n, int key_bytes,
+                                                        int counter_len, uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ counts) {
+  const int rl = key_bytes + counter_len;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint8_t* p = in + i * rl;
+    uint64_t key = 0, c = 0;
+    for (int b = 0; b < key_bytes; ++b) key |= (uint64_t)p[b] << (8 * b);
+    for (int b = 0; b < counter_len; ++b) c |= (uint64_t)p[key_bytes + b] << (8 * b);
+    keys[i] = key;
+    counts[i] = c > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)c;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_compute_pos(const uint64_t* __restrict__ keys, uint64_t n,
+                                                      const uint64_t* __restrict__ g_lut, int ntab,
+                                                      uint64_t* __restrict__ pos) {
+  __shared__ uint64_t s_lut[8 * 256];
+  load_lut(s_lut, g_lut, ntab);
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    pos[i] = gf2_pos(s_lut, keys[i], ntab);
+}
+
+__global__ __launch_bounds__(256) void k_check_sorted(const uint64_t* __restrict__ keys,
+                                                       const uint64_t* __restrict__ pos, uint64_t n,
+                                                       unsigned int* d_bad) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i + 1 < n;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const bool ok = pos[i] < pos[i + 1] || (pos[i] == pos[i + 1] && keys[i] < keys[i + 1]);
+    if (!ok) atomicOr(d_bad, 1u);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: set difference on sorted records
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_flag_range(const uint32_t* __restrict__ counts, uint64_t n, uint32_t lo,
+                                                     uint32_t hi, uint8_t* __restrict__ flags) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t c = counts[i];
+    flags[i] = c >= lo && c <= hi;
+  }
+}
+
+__device__ __forceinline__ uint64_t lower_bound(const uint64_t* __restrict__ bkeys, const uint64_t* __restrict__ bpos,
+                                                uint64_t nb, uint64_t p, uint64_t k) {
+  uint64_t lo = 0, hi = nb;
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    const uint64_t mp = bpos[mid];
+    const bool less = mp < p || (mp == p && bkeys[mid] < k);
+    if (less) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// Clear the flag of every record that also occurs in B (binary search by (pos,key)).
+__global__ __launch_bounds__(256) void k_flag_absent(const uint64_t* __restrict__ keys,
+                                                      const uint64_t* __restrict__ pos, uint64_t n,
+                                                      const uint64_t* __restrict__ bkeys,
+                                                      const uint64_t* __restrict__ bpos, uint64_t nb,
+                                                      uint8_t* __restrict__ flags) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    if (!flags[i]) continue;
+    const uint64_t k = keys[i], p = pos[i];
+    const uint64_t lo = lower_bound(bkeys, bpos, nb, p, k);
+    if (lo < nb && bkeys[lo] == k) flags[i] = 0;
+  }
+}
+
+constexpr int CP_ITEMS = 2048;  // elements per compaction block
+
+__global__ __launch_bounds__(256) void k_compact_count(const uint8_t* __restrict__ flags, uint64_t n,
+                                                        uint64_t* __restrict__ block_cnt) {
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * CP_ITEMS;
+  uint32_t mine = 0;
+  for (uint32_t j = threadIdx.x; j < CP_ITEMS; j += blockDim.x)
+    if (base + j < n) mine += flags[base + j] != 0;
+  for (int off = WAVE / 2; off > 0; off >>= 1) mine += __shfl_down(mine, off);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && mine) atomicAdd(&s_n, mine);
+  __syncthreads();
+  if (threadIdx.x == 0) block_cnt[blockIdx.x] = s_n;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_u64(uint64_t* __restrict__ v, uint64_t n,
+                                                    unsigned long long* d_total) {
+  // in-place exclusive scan, one block
+  __shared__ uint64_t s_part[1024];
+  __shared__ uint64_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < n; base += 1024) {
+    const uint64_t i = base + threadIdx.x;
+    const uint64_t x = i < n ? v[i] : 0;
+    s_part[threadIdx.x] = x;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint64_t add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const uint64_t incl = s_part[threadIdx.x];
+    if (i < n) v[i] = s_carry + incl - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *d_total = s_carry;
+}
+
+// Order-preserving scatter: each wave owns a contiguous run of 64*32 flags of its block.
+__global__ __launch_bounds__(64) void k_compact_scatter(const uint8_t* __restrict__ flags,
+                                                         const uint64_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ counts,
+                                                         const uint64_t* __restrict__ pos, uint64_t n,
+                                                         const uint64_t* __restrict__ block_off,
+                                                         uint64_t* __restrict__ out_keys,
+                                                         uint32_t* __restrict__ out_counts,
+                                                         uint64_t* __restrict__ out_pos) {
+  const uint64_t base = (uint64_t)blockIdx.x * CP_ITEMS;
+  uint64_t o = block_off[blockIdx.x];
+  const int lane = threadIdx.x;
+  for (uint32_t j = 0; j < CP_ITEMS; j += WAVE) {
+    const uint64_t i = base + j + lane;
+    const bool f = i < n && flags[i] != 0;
+    const unsigned long long m = __ballot(f);
+    if (f) {
+      const uint64_t d = o + __popcll(m & ((1ull << lane) - 1));
+      out_keys[d] = keys[i];
+      out_counts[d] = counts[i];
+      if (out_pos) out_pos[d] = pos[i];
+    }
+    o += __popcll(m);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_query(const uint64_t* __restrict__ qkeys, uint64_t nq,
+                                                const uint64_t* __restrict__ g_lut, int ntab,
+                                                const uint64_t* __restrict__ keys, const uint64_t* __restrict__ pos,
+                                                const uint32_t* __restrict__ counts, uint64_t n,
+                                                uint32_t* __restrict__ out) {
+  __shared__ uint64_t s_lut[8 * 256];
+  load_lut(s_lut, g_lut, ntab);
+  __syncthreads();
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t k = qkeys[i];
+    const uint64_t p = gf2_pos(s_lut, k, ntab);
+    const uint64_t lo = lower_bound(keys, pos, n, p, k);
+    out[i] = (lo < n && keys[lo] == k) ? counts[lo] : 0u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5: read filter
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t set_hash(uint64_t key, int bits) {
+  uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+  uint32_t h = (lo ^ (hi * 0x9E3779B1u)) * 0x85EBCA6Bu;
+  h ^= h >> 15;
+  h *= 0xC2B2AE35u;
+  return h >> (32 - bits);
+}
+
+__global__ __launch_bounds__(256) void k_set_insert(const uint64_t* __restrict__ keys, uint64_t n,
+                                                     uint64_t* __restrict__ slots, int bits) {
+  const uint32_t mask = (1u << bits) - 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i];
+    if (key == RFX_EMPTY) continue;  // carried by has_all_ones
+    uint32_t s = set_hash(key, bits);
+    for (;;) {
+      const uint64_t cur =
+          atomicCAS((unsigned long long*)&slots[s], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+      if (cur == RFX_EMPTY || cur == key) break;
+      s = (s + 1) & mask;
+    }
+  }
+}
+
+constexpr int K5_BLOCK = 256;
+constexpr int K5_STAGE = K5_BLOCK * 6;
+constexpr int K5_LDS_SET = 4096;  // slots: sets up to this size are probed from LDS
+
+__device__ __forceinline__ bool set_has(const uint64_t* __restrict__ slots, int bits, uint64_t key) {
+  const uint32_t mask = (1u << bits) - 1;
+  uint32_t s = set_hash(key, bits);
+  for (;;) {
+    const uint64_t cur = slots[s];
+    if (cur == key) return true;
+    if (cur == RFX_EMPTY) return false;
+    s = (s + 1) & mask;
+  }
+}
+
+__global__ __launch_bounds__(K5_BLOCK) void k_filter(rfx_reads_view rv, const uint64_t* __restrict__ g_slots, int bits,
+                                                      int has_all_ones, int k, int thresh, int last_base_skipped,
+                                                      uint32_t* __restrict__ hits_out,
+                                                      uint64_t* __restrict__ hitmask,
+                                                      unsigned long long* __restrict__ d_nhit) {
+  __shared__ uint64_t s_codes[K5_STAGE];
+  __shared__ uint32_t s_mask[K5_STAGE];
+  __shared__ uint64_t s_set[K5_LDS_SET];
+  const bool lds_set = (1u << bits) <= (uint32_t)K5_LDS_SET;
+  if (lds_set)
+    for (uint32_t i = threadIdx.x; i < (1u << bits); i += blockDim.x) s_set[i] = g_slots[i];
+  const uint64_t* slots = lds_set ? s_set : g_slots;
+  const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+
+  const uint32_t n_chunks = (rv.n + K5_BLOCK - 1) / K5_BLOCK;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t r0 = chunk * K5_BLOCK;
+    const uint32_t r1 = min(rv.n, r0 + K5_BLOCK);
+    const uint32_t w0 = rv.word_off[r0], w1 = rv.word_off[r1];
+    __syncthreads();
+    const bool staged = stage_chunk<K5_STAGE>(rv.codes, rv.good, w0, w1, s_codes, s_mask);
+    __syncthreads();
+
+    const uint32_t r = r0 + threadIdx.x;
+    uint32_t found = 0;
+    if (r < r1) {
+      const uint32_t wr = rv.word_off[r];
+      const uint32_t len = rv.len[r];
+      const uint64_t* cw = staged ? s_codes + (wr - w0) : rv.codes + wr;
+      const uint32_t* cm = staged ? s_mask + (wr - w0) : rv.good + wr;
+      // src/RUFUS.Filter.cpp:203: `i < length()-1` -- the last base is never examined.
+      const uint32_t stop = last_base_skipped ? (len ? len - 1 : 0) : len;
+      uint64_t fwd = 0;
+      int streak = 0;
+      const uint32_t nw = (stop + 31) >> 5;
+      for (uint32_t wi = 0; wi < nw; ++wi) {
+        uint64_t w = cw[wi];
+        uint32_t m = cm[wi];
+        const int nb = min(32u, stop - (wi << 5));
+        for (int b = 0; b < nb; ++b) {
+          const uint32_t code = (uint32_t)w & 3u;
+          w >>= 2;
+          const bool good = m & 1u;
+          m >>= 1;
+          fwd = ((fwd << 2) | code) & kmask;
+          streak = good ? streak + 1 : 0;
+          if (streak >= k) {
+            const bool hit = fwd == RFX_EMPTY ? has_all_ones != 0 : set_has(slots, bits, fwd);
+            found += hit;
+          }
+        }
+      }
+      if (hits_out) hits_out[r] = found;
+    }
+    // wave ballot -> one 64-bit word of the hit mask per 64 reads
+    const bool pass = r < r1 && (int)found >= thresh;
+    const unsigned long long m = __ballot(pass);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && r < r1) {
+      if (hitmask) hitmask[r >> 6] = m;
+      if (m) atomicAdd(d_nhit, (unsigned long long)__popcll(m));
+    }
+  }
+}
+
+inline int grid_for(rfx_ctx* c, uint64_t work_items, int block, int per_cu) {
+  uint64_t blocks = (work_items + block - 1) / block;
+  uint64_t cap = (uint64_t)c->n_cu * per_cu;
+  if (blocks < 1) blocks = 1;
+  return (int)(blocks < cap ? blocks : cap);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+namespace rfxk {
+
+int count_reads_block() { return K2_BLOCK; }
+int count_reads_grid(rfx_ctx* c, uint32_t n_reads) { return grid_for(c, (n_reads + K2_BLOCK - 1) / K2_BLOCK, 1, 3); }
+
+void count_reads(rfx_ctx* c, const rfx_reads_view& rv, const rfx_table_view& tv, const uint64_t* lut, int k,
+                 int canonical, rfx_table_stats* stats, rfx_count_ctl* ctl, uint64_t* ovf_keys, uint64_t ovf_cap,
+                 uint64_t load_limit) {
+  if (rv.n == 0) return;
+  const int grid = count_reads_grid(c, rv.n);
+  rfx_span sp(c, "k_count_reads");
+  if (canonical)
+    hipLaunchKernelGGL(k_count_reads<true>, dim3(grid), dim3(K2_BLOCK), 0, c->stream, rv, tv, lut, k, stats, ctl,
+                       ovf_keys, ovf_cap, load_limit);
+  else
+    hipLaunchKernelGGL(k_count_reads<false>, dim3(grid), dim3(K2_BLOCK), 0, c->stream, rv, tv, lut, k, stats, ctl,
+                       ovf_keys, ovf_cap, load_limit);
+}
+
+void count_pairs(rfx_ctx* c, const uint64_t* keys, const uint32_t* counts, uint64_t n, const rfx_table_view& tv,
+                 const uint64_t* lut, rfx_table_stats* stats) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_count_pairs");
+  hipLaunchKernelGGL(k_count_pairs, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, counts, n, tv, lut,
+                     stats);
+}
+
+void table_pairs(rfx_ctx* c, const rfx_table_view& tv, uint64_t* out_keys, uint32_t* out_counts,
+                 unsigned long long* d_n) {
+  rfx_span sp(c, "k_table_pairs");
+  hipLaunchKernelGGL(k_table_pairs, dim3(grid_for(c, tv.slots, 256, 8)), dim3(256), 0, c->stream, tv, out_keys,
+                     out_counts, d_n);
+}
+
+void tile_count(rfx_ctx* c, const rfx_table_view& tv, const uint64_t* lut, uint32_t halo, uint64_t lower,
+                uint64_t upper, uint32_t* tile_counts, uint64_t n_tiles) {
+  rfx_span sp(c, "k_tile_count");
+  hipLaunchKernelGGL(k_tile_count, dim3(grid_for(c, n_tiles, 1, 8)), dim3(256), 0, c->stream, tv, lut, halo, lower,
+                     upper, tile_counts, n_tiles);
+}
+
+void tile_scan(rfx_ctx* c, const uint32_t* tile_counts, uint64_t n_tiles, uint64_t* tile_off, uint32_t* d_max) {
+  rfx_span sp(c, "k_tile_scan");
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, c->stream, tile_counts, n_tiles, tile_off, d_max);
+}
+
+void tile_emit(rfx_ctx* c, const rfx_table_view& tv, const uint64_t* lut, uint32_t halo, uint64_t lower,
+               uint64_t upper, const uint64_t* tile_off, uint64_t n_tiles, uint32_t sort_cap, uint64_t* out_keys,
+               uint32_t* out_counts, uint64_t* out_pos) {
+  const size_t lds = (size_t)8 * 256 * 8 + (size_t)sort_cap * 20;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)k_tile_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    attr_set = true;
+  }
+  rfx_span sp(c, "k_tile_emit");
+  hipLaunchKernelGGL(k_tile_emit, dim3(grid_for(c, n_tiles, 1, 8)), dim3(256), lds, c->stream, tv, lut, halo, lower,
+                     upper, tile_off, n_tiles, sort_cap, out_keys, out_counts, out_pos);
+}
+
+void histo(rfx_ctx* c, const uint32_t* counts, uint64_t n, unsigned long long* d_histo) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_histo");
+  hipLaunchKernelGGL(k_histo, dim3(grid_for(c, n, 256 * 16, 2)), dim3(256), 0, c->stream, counts, n, d_histo);
+}
+
+void format_records(rfx_ctx* c, const uint64_t* keys, const uint32_t* counts, uint64_t n, int key_bytes,
+                    int counter_len, uint8_t* out) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_format_records");
+  hipLaunchKernelGGL(k_format_records, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, counts, n,
+                     key_bytes, counter_len, out);
+}
+
+void parse_records(rfx_ctx* c, const uint8_t* in, uint64_t n, int key_bytes, int counter_len, uint64_t* keys,
+                   uint32_t* counts) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_parse_records");
+  hipLaunchKernelGGL(k_parse_records, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, in, n, key_bytes,
+                     counter_len, keys, counts);
+}
+
+void compute_pos(rfx_ctx* c, const uint64_t* keys, uint64_t n, const uint64_t* lut, int ntab, uint64_t* pos) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_compute_pos");
+  hipLaunchKernelGGL(k_compute_pos, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, lut, ntab, pos);
+}
+
+void check_sorted(rfx_ctx* c, const uint64_t* keys, const uint64_t* pos, uint64_t n, unsigned int* d_bad) {
+  if (n < 2) return;
+  rfx_span sp(c, "k_check_sorted");
+  hipLaunchKernelGGL(k_check_sorted, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, pos, n, d_bad);
+}
+
+void flag_range(rfx_ctx* c, const uint32_t* counts, uint64_t n, uint32_t lo, uint32_t hi, uint8_t* flags) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_flag_range");
+  hipLaunchKernelGGL(k_flag_range, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, counts, n, lo, hi, flags);
+}
+
+void flag_absent(rfx_ctx* c, const uint64_t* keys, const uint64_t* pos, uint64_t n, const uint64_t* bkeys,
+                 const uint64_t* bpos, uint64_t nb, uint8_t* flags) {
+  if (n == 0 || nb == 0) return;
+  rfx_span sp(c, "k_flag_absent");
+  hipLaunchKernelGGL(k_flag_absent, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, pos, n, bkeys, bpos,
+                     nb, flags);
+}
+
+void compact(rfx_ctx* c, const uint8_t* flags, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos,
+             uint64_t n, uint64_t* out_keys, uint32_t* out_counts, uint64_t* out_pos, uint64_t* block_off,
+             unsigned long long* d_total) {
+  const uint64_t nblk = (n + CP_ITEMS - 1) / CP_ITEMS;
+  if (nblk == 0) {
+    hipMemsetAsync(d_total, 0, sizeof(unsigned long long), c->stream);
+    return;
+  }
+  rfx_span sp(c, "k_compact");
+  hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, n, block_off);
+  hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, c->stream, block_off, nblk, d_total);
+  hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)nblk), dim3(64), 0, c->stream, flags, keys, counts, pos, n,
+                     block_off, out_keys, out_counts, out_pos);
+}
+
+void query(rfx_ctx* c, const uint64_t* qkeys, uint64_t nq, const uint64_t* lut, int ntab, const uint64_t* keys,
+           const uint64_t* pos, const uint32_t* counts, uint64_t n, uint32_t* out) {
+  if (nq == 0) return;
+  rfx_span sp(c, "k_query");
+  hipLaunchKernelGGL(k_query, dim3(grid_for(c, nq, 256, 8)), dim3(256), 0, c->stream, qkeys, nq, lut, ntab, keys, pos,
+                     counts, n, out);
+}
+
+void set_insert(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint64_t* slots, int bits) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_set_insert");
+  hipLaunchKernelGGL(k_set_insert, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, slots, bits);
+}
+
+void filter(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones, int k, int thresh,
+            int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit) {
+  if (rv.n == 0) return;
+  rfx_span sp(c, "k_filter");
+  const int grid = grid_for(c, (rv.n + K5_BLOCK - 1) / K5_BLOCK, 1, 2);
+  hipLaunchKernelGGL(k_filter, dim3(grid), dim3(K5_BLOCK), 0, c->stream, rv, slots, bits, has_all_ones, k, thresh,
+                     last_base_skipped, hits, hitmask, d_nhit);
+}
+
+}  // namespace rfxk

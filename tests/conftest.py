@@ -1,0 +1,42 @@
+import gzip
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by `pytest -m gpu` on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def testrun():
+    """The reference's own test trio (testRun/*.mate{1,2}.fastq) + expected values (tests/golden/make_golden.py)."""
+    d = os.path.join(GOLDEN, "testRun")
+    data = {s: [gzip.open(f"{d}/{s}.mate{m}.fastq.gz", "rb").read() for m in (1, 2)]
+            for s in ("Child", "Mother", "Father")}
+    data["expected"] = json.load(open(f"{d}/expected.json"))
+    data["hashlist"] = open(f"{d}/Child.k25_c5.HashList").read()
+    data["hashlist_dev"] = open(f"{d}/Child.k25_c8.dev.HashList").read()
+    data["merge"] = open(f"{d}/merge.Child.Mother.Father.txt").read()
+    return data
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    from rufus_amd import capi
+    c = capi.Context(0)   # raises loudly without a gfx950 device: no CPU fallback
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="session")
+def small_trio():
+    from tests.synth import make_trio
+    return make_trio(genome_len=60_000, n_pairs=6_000, n_snv=6, seed=99)

@@ -1,0 +1,337 @@
+"""GPU parity: the HIP path, called through the C-ABI, against the oracle and the golden fixtures.
+Bit-exact everywhere (integer / byte work)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from rufus_amd import capi, tools
+from tests.synth import fastq_bytes, make_trio
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_same_records(jf: tools.JhashFile, orc: oracle.Records):
+    keys, counts, pos = jf.records.get()
+    assert len(keys) == len(orc.keys)
+    assert np.array_equal(keys, orc.keys)
+    assert np.array_equal(counts.astype(np.uint64), np.minimum(orc.counts, np.uint64(0xFFFFFFFF)))
+    assert np.array_equal(pos, orc.pos)
+    assert jf.records.payload() == orc.payload()
+
+
+# ------------------------------------------------------------------------------------------------
+# count + histo + file format
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("label,size", [("s100M", 100_000_000), ("s8G", 8 << 30)])
+def test_testrun_count_matches_golden(ctx, testrun, label, size, tmp_path):
+    for s in ("Child", "Mother", "Father"):
+        e = testrun["expected"]["samples"][s][label]
+        out = str(tmp_path / f"{s}.Jhash")
+        jf = tools.jellyfish_count(ctx, testrun[s], 25, size, lower=2, out=out, argv=["jellyfish", "count"])
+        assert len(jf.records) == e["records"]
+        payload = jf.records.payload()
+        assert hashlib.sha256(payload).hexdigest() == e["payload_sha256"]
+        assert payload[:11].hex() == e["first_record_hex"]
+        full = tools.jellyfish_histo(jf, full=True)
+        assert full.count("\n") == 10002
+        assert hashlib.md5(full.encode()).hexdigest() == e["histo_full_md5"]
+        # the file we wrote parses with the oracle's independent reader and reloads on the device
+        hdr, pl = oracle.parse_jhash(open(out, "rb").read())
+        assert pl == payload and hdr["size"] == 1 << capi.ceil_log2(size) and hdr["canonical"] is True
+        back = tools.JhashFile.read(ctx, out)
+        assert back.records.payload() == payload
+        back.records.free()
+        jf.records.free()
+
+
+@pytest.mark.parametrize("k,size,canonical,lower", [(25, 1 << 22, True, 0), (31, 8 << 30, True, 2),
+                                                     (15, 1 << 16, True, 1), (11, 1 << 10, False, 0),
+                                                     (32, 1 << 30, True, 0), (5, 1 << 8, True, 3)])
+def test_synthetic_count_matches_oracle(ctx, small_trio, k, size, canonical, lower):
+    fq = [fastq_bytes(small_trio["child"], m) for m in (1, 2)]
+    jf = tools.jellyfish_count(ctx, fq, k, size, canonical=canonical, lower=lower)
+    orc = oracle.count(fq, k, size, lower=lower, canonical=canonical)
+    assert_same_records(jf, orc)
+    h = jf.records.histo()
+    assert np.array_equal(h, oracle.histo(orc.counts, full=True)[0])
+    assert tools.jellyfish_histo(jf) == oracle.histo(orc.counts)[1]
+    assert tools.jellyfish_dump(jf) == orc.dump_text()
+    jf.records.free()
+
+
+def test_count_edge_cases(ctx):
+    k, size = 25, 1 << 20
+    reads = [b"", b"ACGT", b"A" * 24, b"A" * 25, b"N" * 40, b"ACGTN" * 30, b"acgtacgtacgtacgtacgtacgtacgtacgt",
+             b"TTTTTTTTTTTTTTTTTTTTTTTTTTTTTT", b"ACGTRYACGT" * 20, b"G" * 1000, b"C" * 31 + b"\r" + b"C" * 31,
+             (b"ACGGTCAAGTCCATGCAAT" * 40)[:733]]
+    fa = b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(reads))
+    jf = tools.jellyfish_count(ctx, [fa], k, size)
+    assert_same_records(jf, oracle.count([fa], k, size))
+    jf.records.free()
+    # empty input, and an input without a single k-mer
+    for data in (b"", b">x\nACGT\n"):
+        jf = tools.jellyfish_count(ctx, [data], k, size)
+        assert len(jf.records) == 0 and jf.records.payload() == b""
+        assert int(jf.records.histo().sum()) == 0
+        jf.records.free()
+    # upper bound and a counter narrower than the counts (saturating, binary_dumper.hpp:44-48)
+    rep = b">x\n" + b"ACGTTGCATGCCGATAGCTAGCTAGGATCCA" * 400 + b"\n"
+    jf = tools.jellyfish_count(ctx, [rep], 21, 1 << 16, lower=2, upper=399)
+    orc = oracle.count([rep], 21, 1 << 16, lower=2, upper=399)
+    assert_same_records(jf, orc)
+    jf2 = tools.jellyfish_count(ctx, [rep], 21, 1 << 16)
+    orc2 = oracle.count([rep], 21, 1 << 16)
+    assert int(orc2.counts.max()) > 255 and jf2.records.payload(1) == orc2.payload(1)
+    jf.records.free()
+    jf2.records.free()
+
+
+def test_count_grows_from_a_tiny_table_and_in_blocks(ctx, small_trio):
+    """Many blocks into one table that starts far too small: exercises early stop, overflow
+    re-insert and rehash; the result must not depend on the capacity or on the block split."""
+    child = small_trio["child"]
+    k, size = 25, 1 << 27
+    seqs = [r.tobytes() for m in (0, 1) for r in child.s[m]]
+    ref = oracle.count(None, k, size, lower=2, reads=seqs)
+    for cap, nblk in ((1 << 16, 7), (1 << 24, 1)):
+        t = capi.CountTable(ctx, k, size, capacity=cap)
+        for part in np.array_split(np.arange(len(seqs)), nblk):
+            blk = ctx.upload(capi.PackedReads.from_reads([seqs[i] for i in part]))
+            t.add(blk)
+            blk.free()
+        st = t.stats()
+        assert st["distinct"] == len(oracle.count(None, k, size, reads=seqs).keys)
+        assert st["distinct"] <= 0.56 * st["capacity"] + 70000
+        rec = t.finish(2)
+        keys, counts, pos = rec.get()
+        assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts.astype(np.uint32))
+        rec.free()
+        t.free()
+
+
+def test_key_range_passes_partition_the_output(ctx, small_trio):
+    """pos-range passes (multi-pass / multi-GPU ownership): concatenating the slices in pos order
+    reproduces the single-pass payload."""
+    fq = [fastq_bytes(small_trio["mother"], m) for m in (1, 2)]
+    k, size = 25, 1 << 27
+    seqs = tools.parse_sequences(fq[0]) + tools.parse_sequences(fq[1])
+    whole = oracle.count(fq, k, size, lower=2).payload()
+    blk = ctx.upload(capi.PackedReads.from_reads(seqs))
+    cuts = [0, 1 << 25, 3 << 25, 1 << 27]
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        t = capi.CountTable(ctx, k, size, pos_lo=lo, pos_hi=hi)
+        t.add(blk)
+        rec = t.finish(2)
+        parts.append(rec.payload())
+        rec.free()
+        t.free()
+    blk.free()
+    assert b"".join(parts) == whole
+
+
+def test_add_pairs_merges_partials(ctx, small_trio):
+    """Owner-side reduce of the multi-GPU exchange: two half-counts merged as (key,count) pairs."""
+    child = small_trio["child"]
+    k, size = 25, 1 << 27
+    halves = [[r.tobytes() for r in child.s[m]] for m in (0, 1)]
+    ref = oracle.count(None, k, size, lower=2, reads=halves[0] + halves[1])
+    owner = capi.CountTable(ctx, k, size)
+    for h in halves:
+        t = capi.CountTable(ctx, k, size)
+        blk = ctx.upload(capi.PackedReads.from_reads(h))
+        t.add(blk)
+        part = t.finish(1)
+        dk, dc, _ = part.dev_ptrs()
+        owner.add_pairs_dev(dk, dc, len(part))
+        ctx.sync()
+        part.free(); blk.free(); t.free()
+    rec = owner.finish(2)
+    assert rec.payload() == ref.payload()
+    rec.free(); owner.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# set difference
+# ------------------------------------------------------------------------------------------------
+def test_testrun_merge_query_hashlist(ctx, testrun):
+    files = {s: tools.jellyfish_count(ctx, testrun[s], 25, 100_000_000, lower=2) for s in ("Child", "Mother", "Father")}
+    trio = [files["Child"], files["Mother"], files["Father"]]
+    merge = tools.rufus_merge(ctx, trio)
+    assert merge == testrun["merge"]
+    assert tools.check_jelly_hash_list(files["Child"], merge, 5, 140) == testrun["hashlist"]
+    assert tools.hash_list(ctx, files["Child"], trio[1:], 5, 140) == testrun["hashlist"]
+    # testRun/runDevTest.sh: an exclude list is one more merge input; -m 8
+    assert tools.hash_list(ctx, files["Child"], trio[1:] + [files["Mother"]], 8, 140) == testrun["hashlist_dev"]
+    # query: absent k-mers print 0, reverse complements are canonicalised
+    q = tools.jellyfish_query(files["Child"], ["A" * 25, "T" * 25, "ACGTACGTACGTACGTACGTACGTC"])
+    assert q.splitlines()[0] == "A" * 25 + " 48" and q.splitlines()[1] == "A" * 25 + " 48"
+    assert q.splitlines()[2].endswith(" 0")
+    # inputs counted with another table size cannot be merged (merge_files.cc:193-203)
+    other = tools.jellyfish_count(ctx, testrun["Mother"], 25, 1 << 20, lower=2)
+    with pytest.raises(capi.RufusError):
+        tools.rufus_merge(ctx, [files["Child"], other])
+    for f in trio + [other]:
+        f.records.free()
+
+
+def test_synthetic_merge_and_hashlist(ctx, small_trio):
+    k, size = 25, 1 << 27
+    fq = {n: [fastq_bytes(small_trio[n], m) for m in (1, 2)] for n in ("child", "mother", "father")}
+    files = {n: tools.jellyfish_count(ctx, fq[n], k, size, lower=2) for n in fq}
+    orc = {n: oracle.count(fq[n], k, size, lower=2) for n in fq}
+    got = tools.rufus_merge(ctx, [files["child"], files["mother"], files["father"]])
+    assert got == oracle.merge_unique_text([orc["child"], orc["mother"], orc["father"]])
+    for lo, hi in ((5, 1200), (2, 9), (8, 8)):
+        assert tools.hash_list(ctx, files["child"], [files["mother"], files["father"]], lo, hi) == \
+            oracle.hash_list(orc["child"], [orc["mother"], orc["father"]], lo, hi)
+    # single input: everything with count >= 5 is "unique"
+    assert tools.rufus_merge(ctx, [files["father"]]) == oracle.merge_unique_text([orc["father"]])
+    for f in files.values():
+        f.records.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# filter
+# ------------------------------------------------------------------------------------------------
+def test_testrun_filter_matches_reference_binary(ctx, testrun, tmp_path):
+    exp = testrun["expected"]
+    hl = tmp_path / "Child.HashList"
+    hl.write_text(testrun["hashlist"])
+    for m in (1, 2):
+        (tmp_path / f"m{m}.fq").write_bytes(testrun["Child"][m - 1])
+    stub = str(tmp_path / "out")
+    n = tools.rufus_filter(ctx, str(hl), str(tmp_path / "m1.fq"), str(tmp_path / "m2.fq"), stub, 25, 15, 1, 4)
+    assert n == 26
+    for m in (1, 2):   # reference at 1 thread writes in input order, as we do: byte-identical files
+        data = open(f"{stub}.Mutations.Mate{m}.fastq", "rb").read()
+        assert hashlib.sha256(data).hexdigest() == exp["filter_paired_sha256"][str(m)]
+    n = tools.rufus_filter_single(ctx, str(hl), str(tmp_path / "m1.fq"), stub, 25, 15, 1)
+    data = open(f"{stub}.Mutations.fastq", "rb").read()
+    assert hashlib.sha256(data).hexdigest() == exp["filter_single_sha256"]
+    assert n == len(exp["filter_single_names"])
+
+
+@pytest.mark.parametrize("k,minq,thresh", [(25, 15, 1), (25, 0, 2), (31, 30, 1), (12, 15, 3)])
+def test_synthetic_filter_matches_oracle(ctx, small_trio, k, minq, thresh):
+    child = small_trio["child"]
+    m1, m2 = fastq_bytes(child, 1), fastq_bytes(child, 2)
+    # hash list: k-mers of a handful of child reads (forward or reverse-complement spelling), mixed line formats
+    rng = np.random.default_rng(k)
+    lines = []
+    for i in rng.integers(0, len(child), 12):
+        s = child.s[int(rng.integers(0, 2))][i].tobytes().decode()
+        j = int(rng.integers(0, len(s) - k))
+        km = s[j:j + k]
+        if "N" in km:
+            continue
+        lines.append(rng.choice([f"{km} 7", f"{km}\t9", f"1 2 3 {km}", km]))
+    text = ("\n".join(lines) + "\n").encode()
+    fs = oracle.FilterSet(text)
+    keys = capi.hashlist_keys(text, k)
+    mset = capi.MutantSet(ctx, keys, k)
+    pulled = np.zeros(len(child), bool)
+    for data, mate in ((m1, 0), (m2, 1)):
+        h, s, p, q = tools.parse_fastq4(data)
+        blk = ctx.upload(capi.PackedReads.from_reads(s, q, minq, capi.PACK_FILTER))
+        hits, mask, nh = mset.filter(blk, thresh, True)
+        want = np.array([fs.scan(a, b, k, minq) for a, b in zip(s, q)], dtype=np.uint32)
+        assert np.array_equal(hits, want)
+        bits = tools._mask_bits(mask, len(s))
+        assert np.array_equal(bits, want >= thresh) and nh == int(bits.sum())
+        # single-end loop bound (last base examined)
+        hits1, _, _ = mset.filter(blk, thresh, False)
+        want1 = np.array([fs.scan(a, b, k, minq, single_end=True) for a, b in zip(s, q)], dtype=np.uint32)
+        assert np.array_equal(hits1, want1)
+        pulled |= bits
+        blk.free()
+    mset.free()
+    assert np.array_equal(np.flatnonzero(pulled), fs.pairs(m1, m2, k, minq, thresh))
+    assert pulled.any()
+
+
+def test_filter_edge_cases(ctx):
+    k = 5
+    text = b"ACGTA 3\nTTTTT 9\n"
+    fs = oracle.FilterSet(text)
+    mset = capi.MutantSet(ctx, capi.hashlist_keys(text, k), k)
+    seqs = [b"ACGTAC", b"ACGTA", b"TACGT", b"ACGT", b"A", b"AAAAANAAAAA", b"TTTTTT", b"ACGTXACGTAA", b"acgtaA",
+            b"ACGTA" * 50, b"TACGTAG", b"ACNTAACGTAT"]
+    quals = [b"JJJJJJ", b"JJJJJ", b"JJJJJ", b"JJJJ", b"J", b"JJJJJJJJJJJ", b"JJJ#JJ", b"JJJJJJJJJJJ", b"JJJJJJ",
+             b"J" * 250, b"JJJ", b"J" * 11]
+    blk = ctx.upload(capi.PackedReads.from_reads(seqs, quals, 15, capi.PACK_FILTER))
+    for skipped, single in ((True, False), (False, True)):
+        hits, mask, _ = mset.filter(blk, 1, skipped)
+        want = [fs.scan(a, b, k, 15, single_end=single) for a, b in zip(seqs, quals)]
+        assert hits.tolist() == want
+    blk.free()
+    # a large set is probed from HBM instead of LDS
+    rng = np.random.default_rng(3)
+    kmers = ["".join(rng.choice(list("ACGT"), 21)) for _ in range(6000)]
+    text = ("\n".join(f"{x} 5" for x in kmers) + "\n").encode()
+    reads = [("".join(rng.choice(list("ACGT"), 40)) + kmers[i] + "ACGTACGT").encode() for i in range(0, 6000, 37)]
+    reads += [("".join(rng.choice(list("ACGT"), 100))).encode() for _ in range(100)]
+    quals = [b"J" * len(r) for r in reads]
+    fs = oracle.FilterSet(text)
+    big = capi.MutantSet(ctx, capi.hashlist_keys(text, 21), 21)
+    blk = ctx.upload(capi.PackedReads.from_reads(reads, quals, 15, capi.PACK_FILTER))
+    hits, _, _ = big.filter(blk, 1, True)
+    assert hits.tolist() == [fs.scan(a, b, 21, 15) for a, b in zip(reads, quals)]
+    blk.free(); big.free(); mset.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json configs[1]: synthetic 1M x 150 bp trio, k=25)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.skipif(os.environ.get("RFX_SKIP_S1") == "1", reason="RFX_SKIP_S1=1")
+def test_s1_full_size_properties(ctx):
+    """At the size the oracle no longer finishes in seconds, check size-independent properties:
+    total = sum over the histogram, the planted SNVs are exactly the mutant k-mers (25 per SNV),
+    records strictly sorted, child-only k-mers absent from both parents, and a 40k-read slice of
+    the same input still matches the oracle bit for bit."""
+    trio = make_trio()   # 5 Mb genome, 0.5 M pairs/sample, 20 SNVs, seed 12345
+    k, size = 25, 8 << 30
+    files = {}
+    for name in ("child", "mother", "father"):
+        s = trio[name]
+        t = capi.CountTable(ctx, k, size, capacity=1 << 26)
+        for m in (0, 1):
+            off = np.arange(len(s) + 1, dtype=np.uint64) * np.uint64(150)
+            blk = ctx.upload(capi.PackedReads(s.s[m].tobytes(), off))
+            t.add(blk)
+            blk.free()
+        rec_all, h_all = t.finish(1, want_histo=True)
+        n_valid_windows = int(sum(int(x) * i for i, x in enumerate(h_all)))   # no count reaches 10001 at 30x
+        # every ACGT-only window was counted exactly once
+        want = 0
+        for m in (0, 1):
+            isn = (s.s[m] == ord("N"))
+            run = np.zeros(len(s), dtype=np.int64)
+            tot = 0
+            for j in range(150):
+                run = np.where(isn[:, j], 0, run + 1)
+                tot += int((run >= k).sum())
+            want += tot
+        assert n_valid_windows == want
+        rec_all.free()
+        rec = t.finish(2)
+        files[name] = tools.JhashFile(rec, capi.jf_matrix(33, k), True)
+        keys, counts, pos = rec.get()
+        assert np.all((pos[1:] > pos[:-1]) | ((pos[1:] == pos[:-1]) & (keys[1:] > keys[:-1])))
+        assert int(counts.min()) >= 2
+        t.free()
+    hl = tools.hash_list(ctx, files["child"], [files["mother"], files["father"]], 5, 1200)
+    kmers = [ln.split()[0] for ln in hl.splitlines()]
+    assert len(kmers) == 25 * 20
+    for other in ("mother", "father"):
+        assert not tools.jellyfish_query(files[other], kmers).replace(" 0\n", "\n").count(" ")
+    # slice parity against the oracle
+    sl = [trio["child"].s[0][i].tobytes() for i in range(40000)]
+    jf = tools.jellyfish_count(ctx, [b"".join(b">r\n" + r + b"\n" for r in sl)], k, size, lower=2)
+    assert jf.records.payload() == oracle.count(None, k, size, lower=2, reads=sl).payload()
+    jf.records.free()
+    for f in files.values():
+        f.records.free()

@@ -224,11 +224,12 @@ def test_synthetic_filter_matches_oracle(ctx, small_trio, k, minq, thresh):
     lines = []
     for i in rng.integers(0, len(child), 12):
         s = child.s[int(rng.integers(0, 2))][i].tobytes().decode()
-        j = int(rng.integers(0, len(s) - k))
-        km = s[j:j + k]
-        if "N" in km:
-            continue
-        lines.append(rng.choice([f"{km} 7", f"{km}\t9", f"1 2 3 {km}", km]))
+        j = int(rng.integers(0, len(s) - k - 3))
+        for d in range(3):   # three consecutive windows so thresholds 2 and 3 can be met
+            km = s[j + d:j + d + k]
+            if "N" in km:
+                continue
+            lines.append(rng.choice([f"{km} 7", f"{km}\t9", f"1 2 3 {km}", km]))
     text = ("\n".join(lines) + "\n").encode()
     fs = oracle.FilterSet(text)
     keys = capi.hashlist_keys(text, k)

@@ -94,6 +94,9 @@ rfx_ctx* rfx_open(int device, size_t hbm_budget_bytes); /* NULL on failure (no C
 void rfx_close(rfx_ctx*);
 int rfx_sync(rfx_ctx*);
 void* rfx_stream(rfx_ctx*); /* the hipStream_t every kernel of this ctx is launched on */
+/* Device-to-device copy on the ctx stream, then stream sync (hand-off to / from buffers another
+ * runtime owns, e.g. the RCCL exchange buffers of the multi-GPU path). */
+int rfx_memcpy_dev(rfx_ctx*, void* d_dst, const void* d_src, size_t bytes);
 
 /* Per-kernel HIP-event timing on the ctx stream (used by bench.py for roofline.achieved). */
 int rfx_prof_enable(rfx_ctx*, int on);

@@ -48,6 +48,7 @@ def lib():
         L.orc_count_total.argtypes = [C.c_void_p]
         L.orc_count_total.restype = C.c_uint64
         L.orc_count_get.argtypes = [C.c_void_p, u64p, u64p, u64p]
+        L.orc_merge_unique.restype = C.c_size_t
         L.orc_hash_to_long.argtypes = [C.c_char_p, C.c_size_t]
         L.orc_hash_to_long.restype = C.c_uint64
         L.orc_revcomp.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
@@ -252,7 +253,7 @@ def histo(counts: np.ndarray, low: int = 1, high: int = 10000, inc: int = 1, ful
 # ------------------------------------------------------------------------------------------------
 # set difference
 # ------------------------------------------------------------------------------------------------
-def merge_unique(files, min_count: int = 5):
+def merge_unique(files, min_count: int = 5, with_file: bool = False):
     """RUFUS's modified ``jellyfish merge`` (jf/jellyfish/merge_files.cc:69-155): k-way merge in
     (pos, key) order; a key present in exactly one input with count >= 5 is printed ``KMER\\tCOUNT``.
     ``files``: list of Records sharing k / lsize / matrix (:193-203)."""
@@ -260,13 +261,20 @@ def merge_unique(files, min_count: int = 5):
     for f in files[1:]:
         if f.k != f0.k or f.lsize != f0.lsize or not np.array_equal(f.cols, f0.cols):
             raise ValueError("Can't merge hash with different hash function")
-    seen = {}
-    for f in files:
-        for key, cnt, pos in zip(f.keys.tolist(), f.counts.tolist(), f.pos.tolist()):
-            seen.setdefault(key, []).append((pos, cnt))
-    out = [(v[0][0], key, v[0][1]) for key, v in seen.items() if len(v) == 1 and v[0][1] >= min_count]
-    out.sort()
-    return [(key, cnt) for _, key, cnt in out]
+    nf = len(files)
+    P = C.POINTER(C.c_uint64)
+    arr = lambda xs: (P * nf)(*[_u64p(np.ascontiguousarray(x, dtype=np.uint64)) for x in xs])
+    keep = [[np.ascontiguousarray(getattr(f, a), dtype=np.uint64) for f in files] for a in ("keys", "counts", "pos")]
+    ns = (C.c_size_t * nf)(*[len(f.keys) for f in files])
+    tot = sum(len(f.keys) for f in files)
+    ok, ov = np.zeros(max(tot, 1), np.uint64), np.zeros(max(tot, 1), np.uint64)
+    of = np.zeros(max(tot, 1), np.int32)
+    n = lib().orc_merge_unique(nf, (P * nf)(*[_u64p(x) for x in keep[0]]), (P * nf)(*[_u64p(x) for x in keep[1]]),
+                               (P * nf)(*[_u64p(x) for x in keep[2]]), ns, C.c_uint64(min_count), _u64p(ok),
+                               _u64p(ov), of.ctypes.data_as(C.POINTER(C.c_int)))
+    if with_file:
+        return ok[:n].tolist(), ov[:n].tolist(), of[:n].tolist()
+    return list(zip(ok[:n].tolist(), ov[:n].tolist()))
 
 
 def merge_unique_text(files, min_count: int = 5) -> str:
@@ -289,10 +297,15 @@ def query(rec: Records, kmers):
 
 def hash_list(subject: Records, others, min_cov: int, max_cov: int) -> str:
     """Net effect of runRufus.sh:925-926 + scripts/CheckJellyHashList.sh:12: merge-unique over
-    [subject]+others, re-query in the subject, keep min_cov <= count <= max_cov; ``KMER COUNT``."""
-    uniq = merge_unique([subject] + list(others))
-    q = query(subject, [jf_decode(k, subject.k) for k, _ in uniq])
-    return "".join(f"{jf_decode(k, subject.k)} {c}\n" for k, c in q if min_cov <= c <= max_cov)
+    [subject]+others, re-query in the subject (keys unique to another input read 0 there), keep
+    min_cov <= count <= max_cov; ``KMER COUNT`` in merge order."""
+    keys, vals, which = merge_unique([subject] + list(others), with_file=True)
+    out = []
+    for key, v, f in zip(keys, vals, which):
+        c = v if f == 0 else 0          # query of the subject database
+        if min_cov <= c <= max_cov:
+            out.append(f"{jf_decode(key, subject.k)} {c}\n")
+    return "".join(out)
 
 
 # ------------------------------------------------------------------------------------------------

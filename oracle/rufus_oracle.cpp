@@ -239,6 +239,38 @@ void orc_count_get(void* h, uint64_t* keys, uint64_t* vals, uint64_t* pos) {
   if (pos) memcpy(pos, c->pos.data(), 8 * c->pos.size());
 }
 
+// ---- set difference -------------------------------------------------------------------------
+// RUFUS's modified merge (jf/jellyfish/merge_files.cc:69-155) as a k-way merge of (pos,key)-sorted
+// record arrays: a key held by exactly one input with count >= min_count is emitted, in merged order.
+// Returns the number emitted (out arrays sized by the caller to the sum of the inputs).
+size_t orc_merge_unique(int n_files, const uint64_t* const* keys, const uint64_t* const* vals,
+                        const uint64_t* const* pos, const size_t* n, uint64_t min_count, uint64_t* out_keys,
+                        uint64_t* out_vals, int* out_file) {
+  std::vector<size_t> cur(n_files, 0);
+  size_t o = 0;
+  for (;;) {
+    int best = -1;
+    for (int f = 0; f < n_files; ++f) {
+      if (cur[f] >= n[f]) continue;
+      if (best < 0 || pos[f][cur[f]] < pos[best][cur[best]] ||
+          (pos[f][cur[f]] == pos[best][cur[best]] && keys[f][cur[f]] < keys[best][cur[best]]))
+        best = f;
+    }
+    if (best < 0) break;
+    const uint64_t key = keys[best][cur[best]], val = vals[best][cur[best]];
+    int holders = 0;
+    for (int f = 0; f < n_files; ++f)
+      if (cur[f] < n[f] && keys[f][cur[f]] == key) { ++holders; ++cur[f]; }
+    if (holders == 1 && val >= min_count) {
+      out_keys[o] = key;
+      out_vals[o] = val;
+      if (out_file) out_file[o] = best;
+      ++o;
+    }
+  }
+  return o;
+}
+
 // ---- RUFUS-side 2-bit codec -----------------------------------------------------------------
 // src/Util.cpp:51-84 HashToLong: base i -> bits (2i, 2i+1); A=(0,0) C=(0,1) G=(1,0) T=(1,1),
 // i.e. value A0 G1 C2 T3 at shift 2i; any other character leaves 00.

@@ -38,6 +38,7 @@ SIGNATURES = {
     "rfx_close": (None, [C.c_void_p]),
     "rfx_sync": (C.c_int, [C.c_void_p]),
     "rfx_stream": (C.c_void_p, [C.c_void_p]),
+    "rfx_memcpy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rfx_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rfx_prof_reset": (C.c_int, [C.c_void_p]),
     "rfx_prof_query": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), u64p]),
@@ -192,6 +193,9 @@ class Context:
 
     def sync(self):
         _check(lib().rfx_sync(self._h), "rfx_sync")
+
+    def memcpy_dev(self, dst: int, src: int, nbytes: int):
+        _check(lib().rfx_memcpy_dev(self._h, dst, src, nbytes), "rfx_memcpy_dev")
 
     def prof(self, on: bool):
         _check(lib().rfx_prof_enable(self._h, int(on)), "rfx_prof_enable")

@@ -30,14 +30,38 @@ int hip_fail(hipError_t e, const char* what) {
     }                                     \
   } while (0)
 
+// Device allocations go through a small size-keyed cache: the count tables and record arrays of
+// consecutive samples have the same sizes, and hipMalloc/hipFree of GB-sized blocks cost
+// milliseconds each.  `used` counts live + cached bytes; the cache is dropped before giving up.
+void pool_release(rfx_ctx* c) {
+  for (auto& kv : c->pool) {
+    c->used -= kv.first;
+    (void)hipFree(kv.second);
+  }
+  c->pool.clear();
+}
+
 void* dmalloc(rfx_ctx* c, size_t bytes) {
-  if (bytes == 0) bytes = 8;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (bytes == 0) bytes = 256;
+  auto it = c->pool.lower_bound(bytes);
+  if (it != c->pool.end() && it->first <= bytes + bytes / 4) {
+    void* p = it->second;
+    c->allocs[p] = it->first;
+    c->pool.erase(it);
+    return p;
+  }
+  if (c->budget && c->used + bytes > c->budget) pool_release(c);
   if (c->budget && c->used + bytes > c->budget) {
     snprintf(g_err, sizeof g_err, "hbm budget exceeded: %zu + %zu > %zu", c->used, bytes, c->budget);
     return nullptr;
   }
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    pool_release(c);
+    e = hipMalloc(&p, bytes);
+  }
   if (e != hipSuccess) {
     hip_fail(e, "hipMalloc");
     return nullptr;
@@ -50,11 +74,15 @@ void* dmalloc(rfx_ctx* c, size_t bytes) {
 void dfree(rfx_ctx* c, void* p) {
   if (!p) return;
   auto it = c->allocs.find(p);
-  if (it != c->allocs.end()) {
-    c->used -= it->second;
-    c->allocs.erase(it);
+  if (it == c->allocs.end()) {
+    (void)hipFree(p);
+    return;
   }
-  hipFree(p);
+  const size_t bytes = it->second;
+  c->allocs.erase(it);
+  // Everything on this ctx runs on one stream, so a cached block is safe to hand out again: work
+  // that still uses it is ordered before any later kernel or copy on that stream.
+  c->pool.emplace(bytes, p);
 }
 
 int ceil_log2(uint64_t x) {
@@ -265,8 +293,9 @@ void rfx_close(rfx_ctx* c) {
   (void)hipSetDevice(c->device);
   hipStreamSynchronize(c->stream);
   resolve_spans(c);
-  for (auto& kv : c->allocs) hipFree(kv.first);
-  hipStreamDestroy(c->stream);
+  for (auto& kv : c->allocs) (void)hipFree(kv.first);
+  pool_release(c);
+  (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
@@ -277,6 +306,14 @@ int rfx_sync(rfx_ctx* c) {
 }
 
 void* rfx_stream(rfx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int rfx_memcpy_dev(rfx_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
+  if (!c || (bytes && (!d_dst || !d_src))) return RFX_E_INVAL;
+  (void)hipSetDevice(c->device);
+  if (bytes) HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return RFX_OK;
+}
 
 int rfx_prof_enable(rfx_ctx* c, int on) {
   if (!c) return RFX_E_NODEVICE;

@@ -32,6 +32,7 @@ struct rfx_ctx {
   std::vector<rfx_prof_span> spans;
   std::map<std::string, rfx_prof_acc> acc;
   std::map<void*, size_t> allocs;
+  std::multimap<size_t, void*> pool;  // freed blocks kept for reuse, keyed by size
 };
 
 // Device-side statistics of a count table.

@@ -1,0 +1,198 @@
+"""Read-block sharding of the trio hot path over the GPUs of one node.
+
+One process per GPU, ``torch.distributed`` for the exchange (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests).  Per sample:
+
+1. every rank counts ITS read block into a local table and drains all (key,count) partials in
+   (pos,key) order (K2 + K3 with lower = 1);
+2. the pos range is cut into ``world`` equal owner slices; because the partials are pos-sorted each
+   destination's share is one contiguous run -> one ``all_to_all_single`` with split sizes (keys,
+   counts);
+3. the owner adds the partials it received into a fresh table (``rfx_count_add_pairs_dev``) and
+   finishes it with the real lower bound: its records are a contiguous slice of the single-GPU
+   ``.Jhash`` payload, so concatenating the slices in rank order reproduces that file;
+4. count-of-counts histograms are additive across owners (keys are disjoint) -> ``all_reduce(SUM)``.
+
+The set difference needs no communication (every rank owns the same pos slice of every sample);
+the per-slice mutant k-mers are all-gathered (small) and every rank filters its own subject block.
+
+The compute is delegated to a *backend* object; the product backend is :class:`HipBackend` (C-ABI ->
+HIP kernels).  The tests drive the same exchange logic on CPU with gloo and a checker backend.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+HISTO_BINS = capi.HISTO_BINS
+
+
+def revcomp_keys(keys: np.ndarray, k: int) -> np.ndarray:
+    keys = np.asarray(keys, dtype=np.uint64)
+    r = np.zeros_like(keys)
+    x = keys.copy()
+    for _ in range(k):
+        r = (r << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
+        x >>= np.uint64(2)
+    return r
+
+
+class HipBackend:
+    """Everything a shard computes, through the C-ABI.  Tensors handed to / taken from
+    torch.distributed live in torch-owned HBM; data moves between them and library-owned buffers
+    with device-to-device copies on the library stream."""
+
+    def __init__(self, ctx: capi.Context, k: int, size: int, capacity: int = 0, device: torch.device | None = None):
+        self.ctx, self.k, self.size, self.capacity = ctx, k, size, capacity
+        self.lsize = capi.ceil_log2(size)
+        self.cols = capi.jf_matrix(self.lsize, k)
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+    # -- single-rank path -------------------------------------------------------------------------
+    def local_count(self, block, lower: int):
+        t = capi.CountTable(self.ctx, self.k, self.size, True, self.capacity)
+        try:
+            t.add(block)
+            return t.finish(lower, want_histo=True)
+        finally:
+            t.free()
+
+    # -- exchange path ----------------------------------------------------------------------------
+    def count_partials(self, block):
+        """(keys int64, counts int32, pos int64) device tensors of every distinct k-mer of the block."""
+        rec, _ = self.local_count(block, 1)
+        n = len(rec)
+        keys = torch.empty(n, dtype=torch.int64, device=self.device)
+        counts = torch.empty(n, dtype=torch.int32, device=self.device)
+        pos = torch.empty(n, dtype=torch.int64, device=self.device)
+        dk, dc, dp = rec.dev_ptrs()
+        torch.cuda.synchronize(self.device)
+        self.ctx.memcpy_dev(keys.data_ptr(), dk, n * 8)
+        self.ctx.memcpy_dev(counts.data_ptr(), dc, n * 4)
+        self.ctx.memcpy_dev(pos.data_ptr(), dp, n * 8)
+        rec.free()
+        return keys, counts, pos
+
+    def reduce_partials(self, keys: torch.Tensor, counts: torch.Tensor, lower: int, pos_lo: int, pos_hi: int):
+        """Owner-side reduce of received partials -> (records slice, histogram)."""
+        t = capi.CountTable(self.ctx, self.k, self.size, True, self.capacity, pos_lo, pos_hi)
+        try:
+            torch.cuda.synchronize(self.device)
+            t.add_pairs_dev(keys.data_ptr(), counts.data_ptr(), keys.numel())
+            self.ctx.sync()
+            return t.finish(lower, want_histo=True)
+        finally:
+            t.free()
+
+    def unique(self, subject, others, min_cov: int, max_cov: int):
+        return capi.unique_to_subject(self.ctx, subject, others, min_cov, max_cov)
+
+    def filter_pairs(self, canon_keys: np.ndarray, block, thresh: int):
+        """Pair i = reads i and i + n/2 of the block (all of mate 1, then all of mate 2)."""
+        keys = np.concatenate([canon_keys, revcomp_keys(canon_keys, self.k)]) if len(canon_keys) else canon_keys
+        mset = capi.MutantSet(self.ctx, keys, self.k)
+        try:
+            _, mask, _ = mset.filter(block, thresh, last_base_skipped=True, want_hits=False)
+        finally:
+            mset.free()
+        bits = np.unpackbits(mask.view(np.uint8), bitorder="little")[:block.n].astype(bool)
+        half = block.n // 2
+        return bits[:half] | bits[half:2 * half]
+
+    def free(self, rec):
+        rec.free()
+
+    def n_records(self, rec) -> int:
+        return len(rec)
+
+
+def owner_bounds(lsize: int, world: int):
+    """pos range [b[g], b[g+1]) owned by rank g."""
+    return [(g << lsize) // world for g in range(world + 1)]
+
+
+def exchange_partials(keys: torch.Tensor, counts: torch.Tensor, pos: torch.Tensor, lsize: int, group):
+    """Send each (pos-sorted) partial to the owner of its pos; returns what this rank received."""
+    world = dist.get_world_size(group)
+    bounds = torch.tensor(owner_bounds(lsize, world), dtype=torch.int64, device=pos.device)
+    cuts = torch.searchsorted(pos, bounds)                 # partials are pos-sorted: contiguous runs
+    send = (cuts[1:] - cuts[:-1]).to(torch.int64)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    send_l, recv_l = send.tolist(), recv.tolist()
+    rk = torch.empty(sum(recv_l), dtype=keys.dtype, device=keys.device)
+    rc = torch.empty(sum(recv_l), dtype=counts.dtype, device=counts.device)
+    dist.all_to_all_single(rk, keys, recv_l, send_l, group=group)
+    dist.all_to_all_single(rc, counts, recv_l, send_l, group=group)
+    return rk, rc
+
+
+def all_gather_keys(keys: np.ndarray, device, group) -> np.ndarray:
+    world = dist.get_world_size(group)
+    n = torch.tensor([len(keys)], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    m = max(sizes + [1])
+    buf = torch.zeros(m, dtype=torch.int64, device=device)
+    buf[:len(keys)] = torch.from_numpy(keys.astype(np.uint64).view(np.int64)).to(device)
+    out = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(out, buf, group=group)
+    return np.concatenate([o[:s].cpu().numpy().view(np.uint64) for o, s in zip(out, sizes)])
+
+
+class TrioShard:
+    """One rank's share of: count x (1 subject + controls) -> histogram -> hash list -> filter."""
+
+    def __init__(self, ctx_or_backend, k: int, size: int, lower: int, min_cov: int, max_cov: int, thresh: int,
+                 capacity: int = 0, group=None):
+        self.be = ctx_or_backend if hasattr(ctx_or_backend, "local_count") else HipBackend(ctx_or_backend, k, size,
+                                                                                           capacity)
+        self.k, self.lsize = k, capi.ceil_log2(size)
+        self.lower, self.min_cov, self.max_cov, self.thresh = lower, min_cov, max_cov, thresh
+        self.group = group
+        self.world = dist.get_world_size(group) if group is not None else 1
+        self.rank = dist.get_rank(group) if group is not None else 0
+
+    def count_sample(self, block):
+        if self.world == 1:
+            return self.be.local_count(block, self.lower)
+        keys, counts, pos = self.be.count_partials(block)
+        rk, rc = exchange_partials(keys, counts, pos, self.lsize, self.group)
+        b = owner_bounds(self.lsize, self.world)
+        rec, histo = self.be.reduce_partials(rk, rc, self.lower, b[self.rank], b[self.rank + 1])
+        h = torch.from_numpy(histo.astype(np.int64)).to(keys.device)
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+        return rec, h.cpu().numpy().astype(np.uint64)
+
+    def run(self, subject_block, control_blocks, keep_records: bool = False):
+        recs, histos = [], []
+        for blk in [subject_block] + list(control_blocks):
+            rec, h = self.count_sample(blk)
+            recs.append(rec)
+            histos.append(h)
+        keys, counts = self.be.unique(recs[0], recs[1:], self.min_cov, self.max_cov)
+        n_rec = [self.be.n_records(r) for r in recs]
+        if self.world > 1:
+            dev = self.be.device
+            keys = all_gather_keys(keys, dev, self.group)
+            t = torch.tensor(n_rec, dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            n_rec = t.tolist()
+        pulled = self.be.filter_pairs(keys, subject_block, self.thresh)
+        n_pulled = int(pulled.sum())
+        if self.world > 1:
+            t = torch.tensor([n_pulled], dtype=torch.int64, device=self.be.device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            n_pulled = int(t.item())
+        out = {"n_mutant": len(keys), "n_pulled": n_pulled, "n_records": n_rec, "histos": histos,
+               "mutant_keys": keys, "pulled": pulled}
+        if keep_records:
+            out["records"] = recs
+        else:
+            for r in recs:
+                self.be.free(r)
+        return out

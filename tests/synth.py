@@ -51,12 +51,16 @@ def _reads_from(genome: np.ndarray, alt: np.ndarray | None, n_pairs: int, L: int
 
 
 def make_trio(genome_len=5_000_000, n_pairs=500_000, n_snv=20, seed=12345, L=150, err=0.005, lowq=0.02,
-              nrate=0.001):
+              nrate=0.001, read_seed=None):
+    """``seed`` fixes the genome and the planted SNVs; ``read_seed`` (default: continue the same
+    stream) draws the reads, so several read blocks of one trio can be generated independently."""
     rng = np.random.default_rng(seed)
     genome = ACGT[rng.integers(0, 4, genome_len)]
     alt = genome.copy()
     pos = np.sort(rng.choice(np.arange(1000, genome_len - 1000), n_snv, replace=False))
     alt[pos] = ACGT[(np.searchsorted(ACGT, genome[pos]) + rng.integers(1, 4, n_snv)) & 3]
+    if read_seed is not None:
+        rng = np.random.default_rng(read_seed)
     trio = {}
     for name, a in (("child", alt), ("mother", None), ("father", None)):
         trio[name] = Sample(name, *_reads_from(genome, a, n_pairs, L, rng, err, lowq, nrate))

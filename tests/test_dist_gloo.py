@@ -1,0 +1,136 @@
+"""CPU, world_size 2, gloo: the exchange logic of rufus_amd.dist (owner split, all-to-all of
+partials, owner reduce, histogram all-reduce, mutant-set all-gather) driven with a checker backend.
+The concatenation of the owner slices must be the single-process result, byte for byte."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle
+from rufus_amd import dist as rdist
+from tests.synth import make_trio
+
+K, SIZE, LOWER, MIN_COV, MAX_COV, THRESH, MINQ = 25, 1 << 27, 2, 5, 1200, 1, 15
+
+
+class Block:
+    def __init__(self, sample):
+        self.seqs = [r.tobytes() for m in (0, 1) for r in sample.s[m]]
+        self.quals = [r.tobytes() for m in (0, 1) for r in sample.q[m]]
+        self.n = len(self.seqs)
+
+
+class OracleBackend:
+    """Stands in for HipBackend on CPU: same interface, oracle arithmetic."""
+    device = torch.device("cpu")
+
+    def __init__(self):
+        self.lsize = oracle.ceil_log2(SIZE)
+        self.cols = oracle.jf_matrix(self.lsize, K)
+
+    def local_count(self, block, lower):
+        r = oracle.count(None, K, SIZE, lower=lower, reads=block.seqs)
+        return r, oracle.histo(r.counts, full=True)[0]
+
+    def count_partials(self, block):
+        r, _ = self.local_count(block, 1)
+        return (torch.from_numpy(r.keys.view(np.int64).copy()), torch.from_numpy(r.counts.astype(np.int32)),
+                torch.from_numpy(r.pos.view(np.int64).copy()))
+
+    def reduce_partials(self, keys, counts, lower, pos_lo, pos_hi):
+        k = keys.numpy().view(np.uint64)
+        uk, inv = np.unique(k, return_inverse=True)
+        c = np.zeros(len(uk), dtype=np.uint64)
+        np.add.at(c, inv, counts.numpy().astype(np.uint64))
+        pos = np.array([oracle.jf_pos(self.cols, int(x), self.lsize) for x in uk], dtype=np.uint64)
+        assert np.all((pos >= pos_lo) & (pos < pos_hi)), "partial routed to the wrong owner"
+        keep = c >= lower
+        uk, c, pos = uk[keep], c[keep], pos[keep]
+        o = np.lexsort((uk, pos))
+        r = oracle.Records(K, self.lsize, self.cols, uk[o], c[o], pos[o])
+        return r, oracle.histo(r.counts, full=True)[0]
+
+    def unique(self, subject, others, min_cov, max_cov):
+        keys, vals, which = oracle.merge_unique([subject] + list(others), with_file=True)
+        sel = [(k, v) for k, v, f in zip(keys, vals, which) if f == 0 and min_cov <= v <= max_cov]
+        return (np.array([k for k, _ in sel], dtype=np.uint64), np.array([v for _, v in sel], dtype=np.uint32))
+
+    def filter_pairs(self, canon_keys, block, thresh):
+        text = "".join(f"{oracle.jf_decode(int(k), K)} 1\n" for k in canon_keys).encode()
+        fs = oracle.FilterSet(text)
+        hit = np.array([fs.scan(s, q, K, MINQ) >= thresh for s, q in zip(block.seqs, block.quals)])
+        half = block.n // 2
+        return hit[:half] | hit[half:2 * half]
+
+    def free(self, rec):
+        pass
+
+    def n_records(self, rec):
+        return len(rec.keys)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        trio = make_trio(genome_len=30_000, n_pairs=1500, n_snv=4, seed=5, read_seed=100 + rank)
+        blocks = {n: Block(trio[n]) for n in ("child", "mother", "father")}
+        shard = rdist.TrioShard(OracleBackend(), K, SIZE, LOWER, MIN_COV, MAX_COV, THRESH, group=dist.group.WORLD)
+        res = shard.run(blocks["child"], [blocks["mother"], blocks["father"]], keep_records=True)
+        q.put((rank, [r.payload() for r in res["records"]], [h.tolist() for h in res["histos"]],
+               res["mutant_keys"].tolist(), res["pulled"].tolist(), res["n_records"], res["n_pulled"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_exchange_matches_single_process():
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+    # single-process truth on the union of both ranks' reads
+    be = OracleBackend()
+    allb = {}
+    for n in ("child", "mother", "father"):
+        parts = [Block(make_trio(genome_len=30_000, n_pairs=1500, n_snv=4, seed=5, read_seed=100 + r)[n])
+                 for r in range(world)]
+        allb[n] = parts
+    recs = [oracle.count(None, K, SIZE, lower=LOWER, reads=sum((b.seqs for b in allb[n]), []))
+            for n in ("child", "mother", "father")]
+    for i in range(3):
+        assert b"".join(g[1][i] for g in got) == recs[i].payload()          # slices concatenate to the file
+        assert got[0][2][i] == got[1][2][i] == oracle.histo(recs[i].counts, full=True)[0].tolist()
+    keys, _ = be.unique(recs[0], recs[1:], MIN_COV, MAX_COV)
+    assert got[0][3] == got[1][3] == keys.tolist() and len(keys) > 0
+    assert got[0][5] == got[1][5] == [len(r.keys) for r in recs]
+    n_pulled = 0
+    for r in range(world):
+        want = be.filter_pairs(keys, allb["child"][r], THRESH)
+        assert got[r][4] == want.tolist()
+        n_pulled += int(want.sum())
+    assert got[0][6] == got[1][6] == n_pulled and n_pulled > 0
+
+
+def test_owner_bounds_cover_the_range():
+    for lsize in (10, 27, 33):
+        for world in (1, 2, 3, 8):
+            b = rdist.owner_bounds(lsize, world)
+            assert b[0] == 0 and b[-1] == 1 << lsize and all(x < y for x, y in zip(b, b[1:]))
+    k = np.array([0, 1, 0x3FFFFFFFFFFFF, 12345678901234], dtype=np.uint64)
+    assert rdist.revcomp_keys(rdist.revcomp_keys(k, 25), 25).tolist() == k.tolist()
+    assert rdist.revcomp_keys(np.array([0], dtype=np.uint64), 3).tolist() == [63]

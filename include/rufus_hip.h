@@ -124,6 +124,15 @@ uint64_t rfx_reads_bases(const rfx_reads*);
  * capacity_slots == 0 picks an initial size; the table grows by rehash inside the ctx budget. */
 rfx_table* rfx_count_begin(rfx_ctx*, int k, int canonical, int lsize, uint64_t capacity_slots, uint64_t pos_lo,
                            uint64_t pos_hi);
+/* Two exact implementations sit behind rfx_count_add(): RFX_COUNT_P2L partitions the k-mer instances
+ * by (pos,key) prefix and counts every bin in LDS (fast path: no global atomics), RFX_COUNT_TABLE
+ * inserts into an open-addressed table in HBM (any size, grows by rehash; also what
+ * rfx_count_add_pairs_dev uses).  RFX_COUNT_AUTO (default) takes P2L while its transient buffers fit
+ * the budget and falls back to the table.  Results are identical. */
+#define RFX_COUNT_AUTO 0
+#define RFX_COUNT_TABLE 1
+#define RFX_COUNT_P2L 2
+int rfx_count_set_mode(rfx_table*, int mode);
 int rfx_count_add(rfx_table*, const rfx_reads*);
 /* Merge pre-aggregated (key,count) pairs (device pointers): owner-side reduce of the multi-GPU
  * exchange, and the rehash path. */

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "librufus_hip.so")
 
 HISTO_BINS = 10002
 PACK_COUNT, PACK_FILTER = 1, 2
+COUNT_AUTO, COUNT_TABLE, COUNT_P2L = 0, 1, 2
 E_FULL, E_RANGE, E_MIXEDCASE = -4, -7, -6
 
 u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
@@ -48,6 +49,7 @@ SIGNATURES = {
     "rfx_reads_count": (C.c_uint32, [C.c_void_p]),
     "rfx_reads_bases": (C.c_uint64, [C.c_void_p]),
     "rfx_count_begin": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]),
+    "rfx_count_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "rfx_count_add": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rfx_count_add_pairs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "rfx_count_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
@@ -312,11 +314,13 @@ class CountTable:
     """``jellyfish count`` state: exact canonical k-mer counts in an HBM hash table."""
 
     def __init__(self, ctx: Context, k: int, size: int, canonical: bool = True, capacity: int = 0, pos_lo: int = 0,
-                 pos_hi: int = 0):
+                 pos_hi: int = 0, mode: int = COUNT_AUTO):
         self.ctx, self.k, self.lsize, self.canonical = ctx, k, ceil_log2(size), canonical
         self._h = lib().rfx_count_begin(ctx._h, k, int(canonical), self.lsize, capacity, pos_lo, pos_hi)
         if not self._h:
             raise RufusError("rfx_count_begin failed: " + lib().rfx_last_error().decode())
+        if mode != COUNT_AUTO:
+            _check(lib().rfx_count_set_mode(self._h, mode), "rfx_count_set_mode")
 
     def add(self, reads: ReadBlock):
         _check(lib().rfx_count_add(self._h, reads._h), "rfx_count_add")

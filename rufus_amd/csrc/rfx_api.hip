@@ -425,7 +425,8 @@ rfx_table* rfx_count_begin(rfx_ctx* c, int k, int canonical, int lsize, uint64_t
   t->lut = (uint64_t*)dmalloc(c, lut.size() * 8);
   t->d_stats = (rfx_table_stats*)dmalloc(c, sizeof(rfx_table_stats));
   t->d_ctl = (rfx_count_ctl*)dmalloc(c, sizeof(rfx_count_ctl));
-  bool ok = t->lut && t->d_stats && t->d_ctl && alloc_table_arrays(c, t->cap, &t->keys, &t->counts) == RFX_OK;
+  t->segs = new std::vector<rfx_segment>();
+  bool ok = t->lut && t->d_stats && t->d_ctl;  // the slot arrays are allocated on first use (ensure_table)
   if (ok) ok = hipMemcpyAsync(t->lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
                hipMemsetAsync(t->d_stats, 0, sizeof(rfx_table_stats), c->stream) == hipSuccess &&
                hipStreamSynchronize(c->stream) == hipSuccess;
@@ -440,7 +441,134 @@ void rfx_count_free(rfx_table* t) {
   if (!t) return;
   dfree(t->ctx, t->keys); dfree(t->ctx, t->counts); dfree(t->ctx, t->lut); dfree(t->ctx, t->d_stats);
   dfree(t->ctx, t->d_ctl); dfree(t->ctx, t->ovf_keys);
+  if (t->segs) {
+    for (auto& sg : *t->segs) {
+      dfree(t->ctx, sg.inst);
+      dfree(t->ctx, sg.bin_start);
+    }
+    delete t->segs;
+  }
   delete t;
+}
+
+static int ensure_table(rfx_table* t) {
+  if (t->keys) return RFX_OK;
+  return alloc_table_arrays(t->ctx, t->cap, &t->keys, &t->counts);
+}
+
+// ---- P2L path ----------------------------------------------------------------------------------
+static rfx_ord_cfg ord_cfg(const rfx_table* t, int bin_bits) {
+  rfx_ord_cfg c;
+  c.pshl = 64 - t->lsize;
+  if (2 * t->k >= c.pshl) {
+    c.kshr = 2 * t->k - c.pshl;
+    c.kshl = 0;
+  } else {
+    c.kshr = -1;
+    c.kshl = c.pshl - 2 * t->k;
+  }
+  c.bin_shift = 64 - bin_bits;
+  return c;
+}
+
+static int p2l_add(rfx_table* t, const rfx_reads* r) {
+  rfx_ctx* c = t->ctx;
+  const uint64_t windows = r->n_bases > (uint64_t)(t->k - 1) * r->n ? r->n_bases - (uint64_t)(t->k - 1) * r->n : 0;
+  if (windows >= (1ull << 32)) return RFX_E_RANGE;  // a segment indexes its instances with 32 bits
+  if (!t->p2l_bins) {
+    // ~16 K instances per bin: a few thousand distinct keys at sequencing depth, well inside the
+    // 6144-key LDS table of k_leaf; denser bins are split into rounds there.
+    uint32_t P = 256;
+    while (P < 8192 && (uint64_t)P * 16384 < windows) P <<= 1;
+    t->p2l_bins = P;
+  }
+  const uint32_t P = t->p2l_bins;
+  const int bin_bits = ceil_log2(P);
+  const rfx_ord_cfg cfg = ord_cfg(t, bin_bits);
+  // transient + resident need of this path: 8 B per instance now, 12 B more per instance at finish
+  uint64_t held = 0;
+  for (auto& sg : *t->segs) held += sg.n;
+  if (c->budget && c->used + (held + windows) * 20 > c->budget) return RFX_E_NOMEM;
+  const int G = rfxk::p2l_grid(c, r->n);
+  uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)G * P * 4);
+  uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
+  if (!cnt || !bin_start) { dfree(c, cnt); dfree(c, bin_start); return RFX_E_NOMEM; }
+  const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+  rfxk::bin_count(c, rv, t->lut, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt);
+  rfxk::bin_offsets(c, cnt, (uint32_t)G, P, bin_start);
+  uint64_t total = 0;
+  hipError_t e = hipMemcpyAsync(&total, bin_start + P, 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) { dfree(c, cnt); dfree(c, bin_start); return hip_fail(e, "p2l_add"); }
+  if (total == 0) { dfree(c, cnt); dfree(c, bin_start); return RFX_OK; }
+  uint64_t* inst = (uint64_t*)dmalloc(c, total * 8);
+  if (!inst) { dfree(c, cnt); dfree(c, bin_start); return RFX_E_NOMEM; }
+  rfxk::bin_scatter(c, rv, t->lut, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt, bin_start, inst);
+  dfree(c, cnt);
+  t->segs->push_back(rfx_segment{inst, total, bin_start});
+  return RFX_OK;
+}
+
+// Count every bin in LDS and emit the records with lower <= count <= upper in (pos,key) order.
+static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
+  rfx_ctx* c = t->ctx;
+  const uint32_t P = t->p2l_bins;
+  const int bin_bits = ceil_log2(P);
+  const rfx_ord_cfg cfg = ord_cfg(t, bin_bits);
+  const int nseg = (int)t->segs->size();
+  std::vector<const uint64_t*> h_inst(nseg), h_bs(nseg);
+  uint64_t total_inst = 0;
+  for (int i = 0; i < nseg; ++i) {
+    h_inst[i] = (*t->segs)[i].inst;
+    h_bs[i] = (*t->segs)[i].bin_start;
+    total_inst += (*t->segs)[i].n;
+  }
+  const uint64_t** d_inst = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
+  const uint64_t** d_bs = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
+  uint64_t* tmp_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
+  uint64_t* n_surv = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
+  uint64_t* tmp_keys = (uint64_t*)dmalloc(c, total_inst * 8);
+  uint32_t* tmp_counts = (uint32_t*)dmalloc(c, total_inst * 4);
+  unsigned int* d_err = (unsigned int*)dmalloc(c, 4);
+  auto cleanup = [&] {
+    dfree(c, d_inst); dfree(c, d_bs); dfree(c, tmp_start); dfree(c, n_surv); dfree(c, tmp_keys); dfree(c, tmp_counts);
+    dfree(c, d_err);
+  };
+  if (!d_inst || !d_bs || !tmp_start || !n_surv || !tmp_keys || !tmp_counts || !d_err) { cleanup(); return nullptr; }
+  hipError_t e = hipMemcpyAsync(d_inst, h_inst.data(), nseg * sizeof(void*), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_bs, h_bs.data(), nseg * sizeof(void*), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 4, c->stream);
+  if (e != hipSuccess) { hip_fail(e, "p2l_emit"); cleanup(); return nullptr; }
+  rfxk::tmp_start(c, d_bs, nseg, P, tmp_start);
+  rfxk::leaf(c, d_inst, d_bs, nseg, P, bin_bits, t->lut, t->ntab, cfg, lower, upper, tmp_start, tmp_keys, tmp_counts,
+             n_surv, d_err);
+  rfxk::scan_tail(c, n_surv, P);
+  uint64_t total_out = 0;
+  unsigned int err = 0;
+  e = hipMemcpyAsync(&total_out, n_surv + P, 8, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // h_inst / h_bs stay alive until here
+  if (e != hipSuccess || err) {
+    if (e != hipSuccess) hip_fail(e, "p2l_emit");
+    else snprintf(g_err, sizeof g_err, "P2L: a bin could not be split far enough to fit LDS");
+    cleanup();
+    return nullptr;
+  }
+  rfx_records* rec = records_alloc(c, t->k, t->lsize, t->cols, total_out);
+  if (!rec) { cleanup(); return nullptr; }
+  rfxk::leaf_compact(c, tmp_keys, tmp_counts, tmp_start, n_surv, P, t->lut, t->ntab, rec->keys, rec->counts, rec->pos);
+  e = hipStreamSynchronize(c->stream);
+  cleanup();
+  if (e != hipSuccess) { hip_fail(e, "leaf_compact"); rfx_records_free(rec); return nullptr; }
+  return rec;
+}
+
+static void p2l_drop_segments(rfx_table* t) {
+  for (auto& sg : *t->segs) {
+    dfree(t->ctx, sg.inst);
+    dfree(t->ctx, sg.bin_start);
+  }
+  t->segs->clear();
 }
 
 // Table load (distinct / cap) above which the count kernel stops taking chunks and the host grows
@@ -459,6 +587,16 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
   if (r->n == 0) return RFX_OK;
+  if (t->mode != RFX_COUNT_TABLE && !t->table_active) {
+    const int rc = p2l_add(t, r);
+    if (rc == RFX_OK || t->mode == RFX_COUNT_P2L) return rc;
+    if (rc != RFX_E_NOMEM && rc != RFX_E_RANGE) return rc;  // auto: no room for the instance lists
+  }
+  {
+    const int rc = ensure_table(t);
+    if (rc) return rc;
+    t->table_active = 1;
+  }
   // Overflow list: every thread in flight could divert all of its windows after the stop flag is up.
   const uint64_t in_flight = (uint64_t)rfxk::count_reads_grid(c, r->n) * rfxk::count_reads_block();
   const uint64_t need = in_flight * (r->max_len ? r->max_len : 1);
@@ -504,12 +642,21 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   }
 }
 
+int rfx_count_set_mode(rfx_table* t, int mode) {
+  if (!t || mode < RFX_COUNT_AUTO || mode > RFX_COUNT_P2L) return RFX_E_INVAL;
+  t->mode = mode;
+  return RFX_OK;
+}
+
 int rfx_count_add_pairs_dev(rfx_table* t, const uint64_t* d_keys, const uint32_t* d_counts, uint64_t n) {
   if (!t || (n && (!d_keys || !d_counts))) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
+  int rc = ensure_table(t);
+  if (rc) return rc;
+  t->table_active = 1;
   rfx_table_stats st;
-  int rc = read_stats(t, &st);
+  rc = read_stats(t, &st);
   if (rc) return rc;
   rc = grow_for(t, st.distinct + n);  // worst case every pair is a new key
   if (rc) return rc;
@@ -521,7 +668,7 @@ int rfx_count_stats(rfx_table* t, uint64_t* distinct, uint64_t* capacity, uint64
   if (!t) return RFX_E_INVAL;
   (void)hipSetDevice(t->ctx->device);
   rfx_table_stats st;
-  int rc = read_stats(t, &st);
+  int rc = read_stats(t, &st);  // describes the table path; P2L instance lists are counted at finish
   if (rc) return rc;
   if (distinct) *distinct = st.distinct;
   if (capacity) *capacity = t->cap;
@@ -533,6 +680,21 @@ rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint
   if (!t) return nullptr;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
+  if (!t->segs->empty()) {
+    if (!t->table_active) {
+      rfx_records* r = p2l_emit(t, lower, upper);
+      if (r && histo && rfx_records_histo(r, histo) != RFX_OK) { rfx_records_free(r); return nullptr; }
+      return r;
+    }
+    // both paths hold data: fold the instance lists into the table as (key,count) pairs
+    rfx_records* part = p2l_emit(t, 1, ~0ull);
+    if (!part) return nullptr;
+    const int rc = rfx_count_add_pairs_dev(t, part->keys, part->counts, part->n);
+    rfx_records_free(part);
+    if (rc) return nullptr;
+    p2l_drop_segments(t);
+  }
+  if (ensure_table(t)) return nullptr;
   rfx_table_stats st;
   if (read_stats(t, &st)) return nullptr;
   if (st.overflow) {

@@ -65,6 +65,19 @@ struct rfx_table_view {
   int kshift;  // 2k - lshift: top key bits order equal-pos entries when the table is finer than pos
 };
 
+// Layout of the 64-bit order proxy ord = (pos << pshl) | leading key bits (P2L count path).
+struct rfx_ord_cfg {
+  int pshl;       // 64 - lsize
+  int kshr, kshl; // key >> kshr when kshr >= 0, else key << kshl
+  int bin_shift;  // 64 - log2(number of bins)
+};
+
+struct rfx_segment {  // the k-mer instances of one rfx_count_add call, grouped by bin
+  uint64_t* inst;
+  uint64_t n;
+  uint64_t* bin_start;  // device, P+1 entries
+};
+
 struct rfx_reads_view {
   const uint64_t* codes;
   const uint32_t* acgt;
@@ -98,6 +111,11 @@ struct rfx_table {
   uint64_t* ovf_keys;
   uint64_t ovf_cap;
   uint64_t cols[64];
+  // P2L path (rfx_p2l.hip): instances partitioned by bin, counted in LDS at finish
+  int mode;           // 0 auto, 1 global table only, 2 P2L only
+  int table_active;   // the global table holds data
+  uint32_t p2l_bins;  // 0 until the first P2L add
+  std::vector<rfx_segment>* segs;
 };
 
 struct rfx_records {
@@ -156,6 +174,21 @@ void query(rfx_ctx*, const uint64_t* qkeys, uint64_t nq, const uint64_t* lut, in
 void set_insert(rfx_ctx*, const uint64_t* keys, uint64_t n, uint64_t* slots, int bits);
 void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, int k, int thresh,
             int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit);
+int p2l_grid(rfx_ctx*, uint32_t n_reads);
+void bin_count(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical,
+               const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, uint32_t* cnt);
+void bin_offsets(rfx_ctx*, uint32_t* cnt, uint32_t G, uint32_t P, uint64_t* bin_start /* P+1 */);
+void bin_scatter(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical,
+                 const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel,
+                 const uint64_t* bin_start, uint64_t* inst);
+void tmp_start(rfx_ctx*, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out /* P+1 */);
+void leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, uint32_t P, int bin_bits,
+          const uint64_t* lut, int ntab, const rfx_ord_cfg&, uint64_t lower, uint64_t upper, const uint64_t* tmp_start,
+          uint64_t* tmp_keys, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err);
+void scan_tail(rfx_ctx*, uint64_t* v, uint64_t n);  // exclusive scan in place, v[n] = total
+void leaf_compact(rfx_ctx*, const uint64_t* tmp_keys, const uint32_t* tmp_counts, const uint64_t* tmp_start,
+                  const uint64_t* out_off, uint32_t P, const uint64_t* lut, int ntab, uint64_t* out_keys,
+                  uint32_t* out_counts, uint64_t* out_pos);
 }  // namespace rfxk
 
 // Launch bracket: records a HIP-event span on the ctx stream when profiling is on.

@@ -1,0 +1,402 @@
+// "P2L" count path: partition -> LDS count -> sorted emit.  No global atomics per k-mer.
+//
+// Measured on MI355X (scratch/ubench_atomics.hip): device-scope global atomics top out at ~27 G/s
+// whatever the working set (even L2-resident), LDS CAS64+add32 inserts run at ~1 T/s.  So a k-mer
+// instance is written ONCE to HBM as an 8-byte key into the bin of its (pos,key) order prefix,
+// and each bin is then counted entirely in LDS, sorted there, and emitted in output order:
+//
+//   k_bin_count    reads -> canonical k-mers -> bin histogram per block           (LDS atomics)
+//   k_bin_offsets  per-bin exclusive offsets, block runs grouped by XCD           (tiny)
+//   k_bin_scatter  recompute the k-mers, store each key at its reserved slot      (8 B/k-mer write)
+//   k_leaf         one workgroup per bin: LDS hash count, survivors sorted in LDS (8 B/k-mer read)
+//   k_leaf_compact bins -> dense (pos,key)-sorted records
+//
+// replaces jf/include/jellyfish/large_hash_array.hpp:298-302,:513-744 (hash insert) and
+// jf/include/jellyfish/sorted_dumper.hpp:80-112 (sorted dump) in one go.
+#include "rfx_internal.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int P2_BLOCK = 512;     // threads = reads per chunk in the partition kernels
+constexpr int LEAF_BLOCK = 1024;
+constexpr int LEAF_TBL = 8192;    // LDS hash slots per bin round
+constexpr int LEAF_FILL = 6144;   // distinct keys allowed before the bin is split into more rounds
+constexpr int LEAF_SORT = 2048;   // survivors sorted per round
+constexpr int LEAF_RMAX = 20;
+
+__device__ __forceinline__ uint64_t gf2_pos(const uint64_t* __restrict__ lut, uint64_t key, int ntab) {
+  uint64_t r = 0;
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+    if (t < ntab) r ^= lut[t * 256 + (uint32_t)((key >> (8 * t)) & 255u)];
+  return r;
+}
+
+// 64-bit proxy of the (pos,key) output order: pos in the top lsize bits, then as many leading key
+// bits as fit.  (ord,key) orders exactly like (pos,key); bins and rounds are prefixes of ord.
+__device__ __forceinline__ uint64_t ord_of(const rfx_ord_cfg& c, uint64_t pos, uint64_t key) {
+  return (pos << c.pshl) | (c.kshr >= 0 ? (key >> c.kshr) : (key << c.kshl));
+}
+
+// Visit every counted window of read r: f(key, pos).
+template <bool CANON, typename F>
+__device__ __forceinline__ void for_each_kmer(const rfx_reads_view& rv, uint32_t r, int k, const uint64_t* s_lut,
+                                              int ntab, uint64_t pos_lo, uint64_t pos_hi, F&& f) {
+  const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+  const int rcshift = 2 * (k - 1);
+  const uint32_t wr = rv.word_off[r];
+  const uint32_t len = rv.len[r];
+  const uint64_t* cw = rv.codes + wr;
+  const uint32_t* cm = rv.acgt + wr;
+  uint64_t fwd = 0, rc = 0;
+  int filled = 0;
+  const uint32_t nw = (len + 31) >> 5;
+  for (uint32_t wi = 0; wi < nw; ++wi) {
+    uint64_t w = cw[wi];
+    uint32_t m = cm[wi];
+    const int nb = min(32u, len - (wi << 5));
+    for (int b = 0; b < nb; ++b) {
+      const uint32_t code = (uint32_t)w & 3u;
+      w >>= 2;
+      const bool valid = m & 1u;
+      m >>= 1;
+      fwd = ((fwd << 2) | code) & kmask;
+      if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - code) << rcshift);
+      filled = valid ? filled + 1 : 0;
+      if (filled >= k) {
+        const uint64_t key = CANON ? (rc < fwd ? rc : fwd) : fwd;
+        const uint64_t pos = gf2_pos(s_lut, key, ntab);
+        if (pos >= pos_lo && pos < pos_hi) f(key, pos);
+      }
+    }
+  }
+}
+
+template <bool CANON>
+__global__ __launch_bounds__(P2_BLOCK) void k_bin_count(rfx_reads_view rv, const uint64_t* __restrict__ g_lut, int ntab,
+                                                         int k, rfx_ord_cfg cfg, uint32_t P, uint64_t pos_lo,
+                                                         uint64_t pos_hi, uint32_t* __restrict__ cnt) {
+  extern __shared__ uint64_t s_dyn[];
+  uint64_t* s_lut = s_dyn;
+  uint32_t* s_hist = (uint32_t*)(s_dyn + 8 * 256);
+  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
+  for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) s_hist[b] = 0;
+  __syncthreads();
+  const uint32_t n_chunks = (rv.n + P2_BLOCK - 1) / P2_BLOCK;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t r = chunk * P2_BLOCK + threadIdx.x;
+    if (r < rv.n)
+      for_each_kmer<CANON>(rv, r, k, s_lut, ntab, pos_lo, pos_hi, [&](uint64_t key, uint64_t pos) {
+        atomicAdd(&s_hist[(uint32_t)(ord_of(cfg, pos, key) >> cfg.bin_shift)], 1u);
+      });
+  }
+  __syncthreads();
+  for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) cnt[(uint64_t)blockIdx.x * P + b] = s_hist[b];
+}
+
+// cnt[g][b] (instances of bin b seen by block g) -> start of block g's run inside bin b, in place.
+// Runs of one bin are ordered by (g % 8, g / 8): blocks that share an XCD (observed dispatch: block
+// g runs on XCD g % 8) write neighbouring runs, so partially written lines meet in ONE L2.
+__global__ __launch_bounds__(256) void k_bin_offsets(uint32_t* __restrict__ cnt, uint32_t G, uint32_t P,
+                                                      uint64_t* __restrict__ bin_tot) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= P) return;
+  uint32_t run = 0;
+  for (uint32_t x = 0; x < 8; ++x)
+    for (uint32_t g = x; g < G; g += 8) {
+      const uint64_t i = (uint64_t)g * P + b;
+      const uint32_t c = cnt[i];
+      cnt[i] = run;
+      run += c;
+    }
+  bin_tot[b] = run;
+}
+
+template <bool CANON>
+__global__ __launch_bounds__(P2_BLOCK) void k_bin_scatter(rfx_reads_view rv, const uint64_t* __restrict__ g_lut,
+                                                           int ntab, int k, rfx_ord_cfg cfg, uint32_t P, uint64_t pos_lo,
+                                                           uint64_t pos_hi, const uint32_t* __restrict__ rel,
+                                                           const uint64_t* __restrict__ bin_start,
+                                                           uint64_t* __restrict__ inst) {
+  extern __shared__ uint64_t s_dyn[];
+  uint64_t* s_lut = s_dyn;
+  uint32_t* s_cur = (uint32_t*)(s_dyn + 8 * 256);
+  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
+  for (uint32_t b = threadIdx.x; b < P; b += blockDim.x)
+    s_cur[b] = (uint32_t)bin_start[b] + rel[(uint64_t)blockIdx.x * P + b];  // a segment holds < 2^32 instances
+  __syncthreads();
+  const uint32_t n_chunks = (rv.n + P2_BLOCK - 1) / P2_BLOCK;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t r = chunk * P2_BLOCK + threadIdx.x;
+    if (r < rv.n)
+      for_each_kmer<CANON>(rv, r, k, s_lut, ntab, pos_lo, pos_hi, [&](uint64_t key, uint64_t pos) {
+        const uint32_t i = atomicAdd(&s_cur[(uint32_t)(ord_of(cfg, pos, key) >> cfg.bin_shift)], 1u);
+        inst[i] = key;
+      });
+  }
+}
+
+__global__ __launch_bounds__(256) void k_tmp_start(const uint64_t* const* __restrict__ seg_bs, int nseg, uint32_t P,
+                                                    uint64_t* __restrict__ tmp_start) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > P) return;
+  uint64_t s = 0;
+  for (int i = 0; i < nseg; ++i) s += seg_bs[i][b];
+  tmp_start[b] = s;
+}
+
+__device__ __forceinline__ uint32_t leaf_hash(uint64_t key) {
+  uint32_t h = (uint32_t)key ^ (uint32_t)(key >> 23) ^ (uint32_t)(key >> 41);
+  h *= 0x9E3779B1u;
+  return h >> (32 - 13);  // LEAF_TBL = 2^13
+}
+
+// One workgroup per bin.  If a bin holds more distinct keys than the LDS table (or more survivors
+// than the sort area) it is re-run split into 2^r sub-ranges of ord, in order -- exact for any input.
+__global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __restrict__ seg_inst,
+                                                      const uint64_t* const* __restrict__ seg_bs, int nseg, uint32_t P,
+                                                      int bin_bits, const uint64_t* __restrict__ g_lut, int ntab,
+                                                      rfx_ord_cfg cfg, uint64_t lower, uint64_t upper,
+                                                      const uint64_t* __restrict__ tmp_start,
+                                                      uint64_t* __restrict__ tmp_keys, uint32_t* __restrict__ tmp_counts,
+                                                      uint64_t* __restrict__ n_surv, unsigned int* __restrict__ err) {
+  __shared__ unsigned long long s_keys[LEAF_TBL];
+  __shared__ uint32_t s_cnt[LEAF_TBL];
+  __shared__ uint64_t s_ord[LEAF_SORT];
+  __shared__ uint64_t s_skey[LEAF_SORT];
+  __shared__ uint32_t s_scnt[LEAF_SORT];
+  __shared__ uint32_t s_nd, s_ns, s_ovf;
+
+  for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
+    const uint64_t out0 = tmp_start[bin];
+    uint64_t emitted = 0;
+    bool done = false;
+    for (int r = 0; r <= LEAF_RMAX && !done; ++r) {
+      emitted = 0;
+      bool ok = true;
+      for (uint32_t j = 0; j < (1u << r) && ok; ++j) {
+        for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
+          s_keys[i] = RFX_EMPTY;
+          s_cnt[i] = 0;
+        }
+        if (threadIdx.x == 0) {
+          s_nd = 0;
+          s_ns = 0;
+          s_ovf = 0;
+        }
+        __syncthreads();
+        for (int sg = 0; sg < nseg; ++sg) {
+          const uint64_t a = seg_bs[sg][bin], e = seg_bs[sg][bin + 1];
+          const uint64_t* __restrict__ src = seg_inst[sg];
+          for (uint64_t i = a + threadIdx.x; i < e; i += LEAF_BLOCK) {
+            const uint64_t key = src[i];
+            if (r > 0) {
+              const uint64_t ord = ord_of(cfg, gf2_pos(g_lut, key, ntab), key);
+              if ((uint32_t)((ord << bin_bits) >> (64 - r)) != j) continue;
+            }
+            if (*(volatile uint32_t*)&s_ovf) break;
+            uint32_t slot = leaf_hash(key);
+            for (;;) {
+              unsigned long long cur = s_keys[slot];
+              if (cur == RFX_EMPTY) {
+                cur = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+                if (cur == RFX_EMPTY) {
+                  cur = key;
+                  if (atomicAdd(&s_nd, 1u) >= (uint32_t)LEAF_FILL) s_ovf = 1;
+                }
+              }
+              if (cur == key) {
+                atomicAdd(&s_cnt[slot], 1u);
+                break;
+              }
+              slot = (slot + 1) & (LEAF_TBL - 1);
+            }
+          }
+        }
+        __syncthreads();
+        if (s_ovf) {
+          ok = false;
+          break;
+        }
+        // survivors -> sort area
+        for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
+          const uint64_t key = s_keys[i];
+          if (key == RFX_EMPTY) continue;
+          const uint32_t c = s_cnt[i];
+          if (c < lower || c > upper) continue;
+          const uint32_t o = atomicAdd(&s_ns, 1u);
+          if (o < (uint32_t)LEAF_SORT) {
+            s_ord[o] = ord_of(cfg, gf2_pos(g_lut, key, ntab), key);
+            s_skey[o] = key;
+            s_scnt[o] = c;
+          }
+        }
+        __syncthreads();
+        const uint32_t ns = s_ns;
+        if (ns > (uint32_t)LEAF_SORT) {
+          ok = false;
+          break;
+        }
+        uint32_t Pw = 1;
+        while (Pw < ns) Pw <<= 1;
+        for (uint32_t i = ns + threadIdx.x; i < Pw; i += LEAF_BLOCK) {
+          s_ord[i] = ~0ull;
+          s_skey[i] = ~0ull;
+          s_scnt[i] = 0;
+        }
+        __syncthreads();
+        for (uint32_t kk = 2; kk <= Pw; kk <<= 1)
+          for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
+            for (uint32_t i = threadIdx.x; i < Pw; i += LEAF_BLOCK) {
+              const uint32_t x = i ^ jj;
+              if (x > i) {
+                const uint64_t oa = s_ord[i], ob = s_ord[x], ka = s_skey[i], kb = s_skey[x];
+                const bool gt = oa > ob || (oa == ob && ka > kb);
+                if (gt == ((i & kk) == 0)) {
+                  s_ord[i] = ob;
+                  s_ord[x] = oa;
+                  s_skey[i] = kb;
+                  s_skey[x] = ka;
+                  const uint32_t ca = s_scnt[i];
+                  s_scnt[i] = s_scnt[x];
+                  s_scnt[x] = ca;
+                }
+              }
+            }
+            __syncthreads();
+          }
+        for (uint32_t i = threadIdx.x; i < ns; i += LEAF_BLOCK) {
+          tmp_keys[out0 + emitted + i] = s_skey[i];
+          tmp_counts[out0 + emitted + i] = s_scnt[i];
+        }
+        emitted += ns;
+        __syncthreads();
+      }
+      if (ok) done = true;
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      n_surv[bin] = done ? emitted : 0;
+      if (!done) atomicExch(err, 1u);
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void k_leaf_compact(const uint64_t* __restrict__ tmp_keys,
+                                                       const uint32_t* __restrict__ tmp_counts,
+                                                       const uint64_t* __restrict__ tmp_start,
+                                                       const uint64_t* __restrict__ out_off, uint32_t P,
+                                                       const uint64_t* __restrict__ g_lut, int ntab,
+                                                       uint64_t* __restrict__ out_keys, uint32_t* __restrict__ out_counts,
+                                                       uint64_t* __restrict__ out_pos) {
+  __shared__ uint64_t s_lut[8 * 256];
+  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
+  __syncthreads();
+  for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
+    const uint64_t src = tmp_start[bin], dst = out_off[bin], n = out_off[bin + 1] - dst;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+      const uint64_t key = tmp_keys[src + i];
+      out_keys[dst + i] = key;
+      out_counts[dst + i] = tmp_counts[src + i];
+      out_pos[dst + i] = gf2_pos(s_lut, key, ntab);
+    }
+  }
+}
+
+// exclusive scan of v[0..n) in place, v[n] = total (one block)
+__global__ __launch_bounds__(1024) void k_scan_tail(uint64_t* __restrict__ v, uint64_t n) {
+  __shared__ uint64_t s_part[1024];
+  __shared__ uint64_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (uint64_t base = 0; base < n; base += 1024) {
+    const uint64_t i = base + threadIdx.x;
+    const uint64_t x = i < n ? v[i] : 0;
+    s_part[threadIdx.x] = x;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      uint64_t add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
+      __syncthreads();
+      s_part[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const uint64_t incl = s_part[threadIdx.x];
+    if (i < n) v[i] = s_carry + incl - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) v[n] = s_carry;
+}
+
+}  // namespace
+
+namespace rfxk {
+
+int p2l_grid(rfx_ctx* c, uint32_t n_reads) {
+  const uint32_t n_chunks = (n_reads + P2_BLOCK - 1) / P2_BLOCK;
+  uint32_t g = (uint32_t)c->n_cu * 3;
+  if (n_chunks < g) g = n_chunks;
+  g = (g + 7) & ~7u;  // whole XCD groups
+  return (int)(g < 8 ? 8 : g);
+}
+
+void bin_count(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int ntab, int k, int canonical,
+               const rfx_ord_cfg& cfg, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, uint32_t* cnt) {
+  const size_t lds = 8 * 256 * 8 + (size_t)P * 4;
+  rfx_span sp(c, "k_bin_count");
+  if (canonical)
+    hipLaunchKernelGGL(k_bin_count<true>, dim3(grid), dim3(P2_BLOCK), lds, c->stream, rv, lut, ntab, k, cfg, P, pos_lo,
+                       pos_hi, cnt);
+  else
+    hipLaunchKernelGGL(k_bin_count<false>, dim3(grid), dim3(P2_BLOCK), lds, c->stream, rv, lut, ntab, k, cfg, P, pos_lo,
+                       pos_hi, cnt);
+}
+
+void bin_offsets(rfx_ctx* c, uint32_t* cnt, uint32_t G, uint32_t P, uint64_t* bin_start) {
+  rfx_span sp(c, "k_bin_offsets");
+  hipLaunchKernelGGL(k_bin_offsets, dim3((P + 255) / 256), dim3(256), 0, c->stream, cnt, G, P, bin_start);
+  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, c->stream, bin_start, (uint64_t)P);
+}
+
+void bin_scatter(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int ntab, int k, int canonical,
+                 const rfx_ord_cfg& cfg, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel,
+                 const uint64_t* bin_start, uint64_t* inst) {
+  const size_t lds = 8 * 256 * 8 + (size_t)P * 4;
+  rfx_span sp(c, "k_bin_scatter");
+  if (canonical)
+    hipLaunchKernelGGL(k_bin_scatter<true>, dim3(grid), dim3(P2_BLOCK), lds, c->stream, rv, lut, ntab, k, cfg, P,
+                       pos_lo, pos_hi, rel, bin_start, inst);
+  else
+    hipLaunchKernelGGL(k_bin_scatter<false>, dim3(grid), dim3(P2_BLOCK), lds, c->stream, rv, lut, ntab, k, cfg, P,
+                       pos_lo, pos_hi, rel, bin_start, inst);
+}
+
+void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out) {
+  hipLaunchKernelGGL(k_tmp_start, dim3((P + 1 + 255) / 256), dim3(256), 0, c->stream, seg_bs, nseg, P, out);
+}
+
+void leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, uint32_t P,
+          int bin_bits, const uint64_t* lut, int ntab, const rfx_ord_cfg& cfg, uint64_t lower, uint64_t upper,
+          const uint64_t* tmp_start_, uint64_t* tmp_keys, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err) {
+  rfx_span sp(c, "k_leaf");
+  hipLaunchKernelGGL(k_leaf, dim3(P), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, P, bin_bits, lut, ntab,
+                     cfg, lower, upper, tmp_start_, tmp_keys, tmp_counts, n_surv, err);
+}
+
+void scan_tail(rfx_ctx* c, uint64_t* v, uint64_t n) {
+  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, c->stream, v, n);
+}
+
+void leaf_compact(rfx_ctx* c, const uint64_t* tmp_keys, const uint32_t* tmp_counts, const uint64_t* tmp_start_,
+                  const uint64_t* out_off, uint32_t P, const uint64_t* lut, int ntab, uint64_t* out_keys,
+                  uint32_t* out_counts, uint64_t* out_pos) {
+  rfx_span sp(c, "k_leaf_compact");
+  const uint32_t grid = P < (uint32_t)c->n_cu * 8 ? P : (uint32_t)c->n_cu * 8;
+  hipLaunchKernelGGL(k_leaf_compact, dim3(grid), dim3(256), 0, c->stream, tmp_keys, tmp_counts, tmp_start_, out_off, P,
+                     lut, ntab, out_keys, out_counts, out_pos);
+}
+
+}  // namespace rfxk

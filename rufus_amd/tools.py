@@ -164,9 +164,10 @@ class JhashFile:
 
 
 def jellyfish_count(ctx: capi.Context, inputs, k: int, size: int, canonical: bool = True, lower: int = 0,
-                    upper: int = 2**64 - 1, out: str | None = None, capacity: int = 0, argv=()) -> JhashFile:
+                    upper: int = 2**64 - 1, out: str | None = None, capacity: int = 0, argv=(),
+                    mode: int = capi.COUNT_AUTO) -> JhashFile:
     """Count the k-mers of FASTA/FASTQ files (paths or bytes)."""
-    table = capi.CountTable(ctx, k, size, canonical, capacity)
+    table = capi.CountTable(ctx, k, size, canonical, capacity, mode=mode)
     try:
         for src in inputs:
             data = src if isinstance(src, (bytes, bytearray)) else open(src, "rb").read()

@@ -47,12 +47,13 @@ def test_testrun_count_matches_golden(ctx, testrun, label, size, tmp_path):
         jf.records.free()
 
 
+@pytest.mark.parametrize("mode", [capi.COUNT_P2L, capi.COUNT_TABLE])
 @pytest.mark.parametrize("k,size,canonical,lower", [(25, 1 << 22, True, 0), (31, 8 << 30, True, 2),
                                                      (15, 1 << 16, True, 1), (11, 1 << 10, False, 0),
                                                      (32, 1 << 30, True, 0), (5, 1 << 8, True, 3)])
-def test_synthetic_count_matches_oracle(ctx, small_trio, k, size, canonical, lower):
+def test_synthetic_count_matches_oracle(ctx, small_trio, k, size, canonical, lower, mode):
     fq = [fastq_bytes(small_trio["child"], m) for m in (1, 2)]
-    jf = tools.jellyfish_count(ctx, fq, k, size, canonical=canonical, lower=lower)
+    jf = tools.jellyfish_count(ctx, fq, k, size, canonical=canonical, lower=lower, mode=mode)
     orc = oracle.count(fq, k, size, lower=lower, canonical=canonical)
     assert_same_records(jf, orc)
     h = jf.records.histo()
@@ -68,9 +69,10 @@ def test_count_edge_cases(ctx):
              b"TTTTTTTTTTTTTTTTTTTTTTTTTTTTTT", b"ACGTRYACGT" * 20, b"G" * 1000, b"C" * 31 + b"\r" + b"C" * 31,
              (b"ACGGTCAAGTCCATGCAAT" * 40)[:733]]
     fa = b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(reads))
-    jf = tools.jellyfish_count(ctx, [fa], k, size)
-    assert_same_records(jf, oracle.count([fa], k, size))
-    jf.records.free()
+    for mode in (capi.COUNT_P2L, capi.COUNT_TABLE):
+        jf = tools.jellyfish_count(ctx, [fa], k, size, mode=mode)
+        assert_same_records(jf, oracle.count([fa], k, size))
+        jf.records.free()
     # empty input, and an input without a single k-mer
     for data in (b"", b">x\nACGT\n"):
         jf = tools.jellyfish_count(ctx, [data], k, size)
@@ -97,7 +99,7 @@ def test_count_grows_from_a_tiny_table_and_in_blocks(ctx, small_trio):
     seqs = [r.tobytes() for m in (0, 1) for r in child.s[m]]
     ref = oracle.count(None, k, size, lower=2, reads=seqs)
     for cap, nblk in ((1 << 16, 7), (1 << 24, 1)):
-        t = capi.CountTable(ctx, k, size, capacity=cap)
+        t = capi.CountTable(ctx, k, size, capacity=cap, mode=capi.COUNT_TABLE)
         for part in np.array_split(np.arange(len(seqs)), nblk):
             blk = ctx.upload(capi.PackedReads.from_reads([seqs[i] for i in part]))
             t.add(blk)
@@ -110,6 +112,43 @@ def test_count_grows_from_a_tiny_table_and_in_blocks(ctx, small_trio):
         assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts.astype(np.uint32))
         rec.free()
         t.free()
+
+
+def test_p2l_dense_bins_split_into_rounds_and_many_blocks(ctx):
+    """Unrelated random reads: almost every window is a new key, so bins hold more distinct keys than
+    the LDS table and k_leaf must split them into ord sub-ranges; several add() calls = several
+    instance segments per bin.  Also the mixed case: P2L segments folded into the table path."""
+    rng = np.random.default_rng(11)
+    seqs = [bytes(r) for r in np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (36000, 150))]]
+    seqs += seqs[:3000]                                   # some repeats so that lower=2 keeps something
+    k, size = 25, 8 << 30
+    ref1 = oracle.count(None, k, size, lower=1, reads=seqs)
+    ref2 = oracle.count(None, k, size, lower=2, reads=seqs)
+    assert len(ref1.keys) > 4_000_000
+    t = capi.CountTable(ctx, k, size, mode=capi.COUNT_P2L)
+    for part in np.array_split(np.arange(len(seqs)), 3):
+        blk = ctx.upload(capi.PackedReads.from_reads([seqs[i] for i in part]))
+        t.add(blk)
+        blk.free()
+    for lower, ref in ((1, ref1), (2, ref2)):
+        rec = t.finish(lower)
+        keys, counts, pos = rec.get()
+        assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts.astype(np.uint32))
+        assert np.array_equal(pos, ref.pos)
+        rec.free()
+    # fold into the table path: add the first 1000 reads again as pre-aggregated pairs
+    extra = capi.CountTable(ctx, k, size, mode=capi.COUNT_P2L)
+    blk = ctx.upload(capi.PackedReads.from_reads(seqs[:1000]))
+    extra.add(blk)
+    part = extra.finish(1)
+    dk, dc, _ = part.dev_ptrs()
+    t.add_pairs_dev(dk, dc, len(part))
+    ctx.sync()
+    rec = t.finish(2)
+    ref3 = oracle.count(None, k, size, lower=2, reads=seqs + seqs[:1000])
+    assert rec.payload() == ref3.payload()
+    for x in (rec, part, blk, extra, t):
+        x.free()
 
 
 def test_key_range_passes_partition_the_output(ctx, small_trio):

@@ -3,6 +3,7 @@
 // other entry point needs a ctx.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <queue>
 
@@ -258,6 +259,9 @@ void resolve_spans(rfx_ctx* c) {
 
 }  // namespace
 
+static bool build_sort_transform(const uint64_t* cols, int r, int c, uint64_t* img_t, uint64_t* img_inv);
+static void lut_from_images(const uint64_t* img, int nbits, std::vector<uint64_t>& lut, int& ntab);
+
 extern "C" {
 
 const char* rfx_last_error(void) { return g_err; }
@@ -426,6 +430,25 @@ rfx_table* rfx_count_begin(rfx_ctx* c, int k, int canonical, int lsize, uint64_t
   t->d_stats = (rfx_table_stats*)dmalloc(c, sizeof(rfx_table_stats));
   t->d_ctl = (rfx_count_ctl*)dmalloc(c, sizeof(rfx_count_ctl));
   t->segs = new std::vector<rfx_segment>();
+  {
+    uint64_t img_t[64], img_inv[64];
+    if (build_sort_transform(t->cols, lsize, 2 * k, img_t, img_inv)) {
+      std::vector<uint64_t> lt, li;
+      int nt = 0;
+      lut_from_images(img_t, 2 * k, lt, nt);
+      lut_from_images(img_inv, 2 * k, li, nt);
+      t->lut_t = (uint64_t*)dmalloc(c, lt.size() * 8);
+      t->lut_tinv = (uint64_t*)dmalloc(c, li.size() * 8);
+      if (!t->lut_t || !t->lut_tinv ||
+          hipMemcpyAsync(t->lut_t, lt.data(), lt.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+          hipMemcpyAsync(t->lut_tinv, li.data(), li.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+          hipStreamSynchronize(c->stream) != hipSuccess) {
+        dfree(c, t->lut_t);
+        dfree(c, t->lut_tinv);
+        t->lut_t = t->lut_tinv = nullptr;
+      }
+    }
+  }
   bool ok = t->lut && t->d_stats && t->d_ctl;  // the slot arrays are allocated on first use (ensure_table)
   if (ok) ok = hipMemcpyAsync(t->lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
                hipMemsetAsync(t->d_stats, 0, sizeof(rfx_table_stats), c->stream) == hipSuccess &&
@@ -441,6 +464,7 @@ void rfx_count_free(rfx_table* t) {
   if (!t) return;
   dfree(t->ctx, t->keys); dfree(t->ctx, t->counts); dfree(t->ctx, t->lut); dfree(t->ctx, t->d_stats);
   dfree(t->ctx, t->d_ctl); dfree(t->ctx, t->ovf_keys);
+  dfree(t->ctx, t->lut_t); dfree(t->ctx, t->lut_tinv);
   if (t->segs) {
     for (auto& sg : *t->segs) {
       dfree(t->ctx, sg.inst);
@@ -459,22 +483,98 @@ static int ensure_table(rfx_table* t) {
 // ---- P2L path ----------------------------------------------------------------------------------
 static rfx_ord_cfg ord_cfg(const rfx_table* t, int bin_bits) {
   rfx_ord_cfg c;
-  c.pshl = 64 - t->lsize;
-  if (2 * t->k >= c.pshl) {
-    c.kshr = 2 * t->k - c.pshl;
-    c.kshl = 0;
-  } else {
-    c.kshr = -1;
-    c.kshl = c.pshl - 2 * t->k;
-  }
-  c.bin_shift = 64 - bin_bits;
+  c.c_bits = 2 * t->k;
+  c.sel_bits = 2 * t->k - t->lsize;
+  c.bin_shift = c.c_bits - bin_bits;
   return c;
+}
+
+// Sortable-word transform of the P2L path.  M (r x c, r = lsize, c = 2k) has kernel dimension c - r;
+// reduce M to row echelon form taking pivots from key bit 0 upward: every kernel vector then has its
+// HIGHEST set bit at a free column f and is zero at all other free columns.  Two keys with equal pos
+// differ by a kernel vector, so they first differ (from the top) at a free column: comparing the
+// free-column bits high to low orders them like the full keys.  T = [M ; e_f for free f, descending]
+// is invertible and w = T*key = (pos << (c-r)) | free bits sorts exactly like (pos,key)
+// (jf/include/jellyfish/mer_heap.hpp:34-38).  Fills img_t[b] = T*e_b and img_inv[b] = T^-1*e_b;
+// returns false when M is rank deficient (P2L then stays off).
+static bool build_sort_transform(const uint64_t* cols, int r, int c, uint64_t* img_t, uint64_t* img_inv) {
+  if (c > 62 || r > c) return false;
+  // rows of M as masks over key bits: pos bit i = parity(row[i] & key); key bit b selects cols[c-1-b]
+  std::vector<uint64_t> row(r, 0);
+  for (int b = 0; b < c; ++b)
+    for (int i = 0; i < r; ++i)
+      if ((cols[c - 1 - b] >> i) & 1) row[i] |= 1ull << b;
+  std::vector<uint64_t> e(row);
+  std::vector<bool> is_pivot(c, false);
+  int rank = 0;
+  for (int b = 0; b < c && rank < r; ++b) {
+    int p = -1;
+    for (int i = rank; i < r; ++i)
+      if ((e[i] >> b) & 1) { p = i; break; }
+    if (p < 0) continue;
+    std::swap(e[rank], e[p]);
+    for (int i = 0; i < r; ++i)
+      if (i != rank && ((e[i] >> b) & 1)) e[i] ^= e[rank];
+    is_pivot[b] = true;
+    ++rank;
+  }
+  if (rank != r) return false;
+  std::vector<int> freec;
+  for (int b = c - 1; b >= 0; --b)
+    if (!is_pivot[b]) freec.push_back(b);  // descending
+  // T as c row masks over key bits, row 0 = most significant bit of w
+  std::vector<uint64_t> trow(c);
+  for (int i = 0; i < r; ++i) trow[i] = row[r - 1 - i];          // w bit c-1-i = pos bit r-1-i
+  for (int j = 0; j < c - r; ++j) trow[r + j] = 1ull << freec[j];  // then the free key bits, high to low
+  for (int b = 0; b < c; ++b) {
+    uint64_t w = 0;
+    for (int i = 0; i < c; ++i)
+      if ((trow[i] >> b) & 1) w |= 1ull << (c - 1 - i);
+    img_t[b] = w;
+  }
+  // invert: Gauss-Jordan on [A | I] where A[i] = row mask producing w bit (c-1-i)
+  std::vector<uint64_t> a(trow), inv(c);
+  for (int i = 0; i < c; ++i) inv[i] = 1ull << i;  // inv[i]: combination of original rows, bit j = row j
+  for (int col = 0; col < c; ++col) {
+    int p = -1;
+    for (int i = col; i < c; ++i)
+      if ((a[i] >> col) & 1) { p = i; break; }
+    if (p < 0) return false;
+    std::swap(a[col], a[p]);
+    std::swap(inv[col], inv[p]);
+    for (int i = 0; i < c; ++i)
+      if (i != col && ((a[i] >> col) & 1)) { a[i] ^= a[col]; inv[i] ^= inv[col]; }
+  }
+  // now a = I: key bit `col` = XOR over rows j in inv[col] of (w bit c-1-j)
+  for (int wb = 0; wb < c; ++wb) {       // image of unit word e_wb
+    const int j = c - 1 - wb;             // the T row that produces w bit wb
+    uint64_t key = 0;
+    for (int col = 0; col < c; ++col)
+      if ((inv[col] >> j) & 1) key |= 1ull << col;
+    img_inv[wb] = key;
+  }
+  return true;
+}
+
+static void lut_from_images(const uint64_t* img, int nbits, std::vector<uint64_t>& lut, int& ntab) {
+  ntab = (nbits + 7) / 8;
+  lut.assign((size_t)ntab * 256, 0);
+  for (int t = 0; t < ntab; ++t)
+    for (int v = 0; v < 256; ++v) {
+      uint64_t r = 0;
+      for (int j = 0; j < 8; ++j)
+        if (((v >> j) & 1) && 8 * t + j < nbits) r ^= img[8 * t + j];
+      lut[(size_t)t * 256 + v] = r;
+    }
 }
 
 static int p2l_add(rfx_table* t, const rfx_reads* r) {
   rfx_ctx* c = t->ctx;
   const uint64_t windows = r->n_bases > (uint64_t)(t->k - 1) * r->n ? r->n_bases - (uint64_t)(t->k - 1) * r->n : 0;
   if (windows >= (1ull << 32)) return RFX_E_RANGE;  // a segment indexes its instances with 32 bits
+  if (!t->p2l_bins) {
+    if (const char* ev = getenv("RFX_P2L_BINS")) t->p2l_bins = (uint32_t)atoi(ev);  // tuning experiments
+  }
   if (!t->p2l_bins) {
     // ~16 K instances per bin: a few thousand distinct keys at sequencing depth, well inside the
     // 6144-key LDS table of k_leaf; denser bins are split into rounds there.
@@ -494,7 +594,7 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
   uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
   if (!cnt || !bin_start) { dfree(c, cnt); dfree(c, bin_start); return RFX_E_NOMEM; }
   const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
-  rfxk::bin_count(c, rv, t->lut, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt);
+  rfxk::bin_count(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt);
   rfxk::bin_offsets(c, cnt, (uint32_t)G, P, bin_start);
   uint64_t total = 0;
   hipError_t e = hipMemcpyAsync(&total, bin_start + P, 8, hipMemcpyDeviceToHost, c->stream);
@@ -503,7 +603,8 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
   if (total == 0) { dfree(c, cnt); dfree(c, bin_start); return RFX_OK; }
   uint64_t* inst = (uint64_t*)dmalloc(c, total * 8);
   if (!inst) { dfree(c, cnt); dfree(c, bin_start); return RFX_E_NOMEM; }
-  rfxk::bin_scatter(c, rv, t->lut, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt, bin_start, inst);
+  rfxk::bin_scatter(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt, bin_start,
+                    inst);
   dfree(c, cnt);
   t->segs->push_back(rfx_segment{inst, total, bin_start});
   return RFX_OK;
@@ -540,8 +641,7 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
   if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 4, c->stream);
   if (e != hipSuccess) { hip_fail(e, "p2l_emit"); cleanup(); return nullptr; }
   rfxk::tmp_start(c, d_bs, nseg, P, tmp_start);
-  rfxk::leaf(c, d_inst, d_bs, nseg, P, bin_bits, t->lut, t->ntab, cfg, lower, upper, tmp_start, tmp_keys, tmp_counts,
-             n_surv, d_err);
+  rfxk::leaf(c, d_inst, d_bs, nseg, P, cfg, lower, upper, tmp_start, tmp_keys, tmp_counts, n_surv, d_err);
   rfxk::scan_tail(c, n_surv, P);
   uint64_t total_out = 0;
   unsigned int err = 0;
@@ -556,7 +656,8 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
   }
   rfx_records* rec = records_alloc(c, t->k, t->lsize, t->cols, total_out);
   if (!rec) { cleanup(); return nullptr; }
-  rfxk::leaf_compact(c, tmp_keys, tmp_counts, tmp_start, n_surv, P, t->lut, t->ntab, rec->keys, rec->counts, rec->pos);
+  rfxk::leaf_compact(c, tmp_keys, tmp_counts, tmp_start, n_surv, P, t->lut_tinv, t->ntab, cfg.sel_bits, rec->keys,
+                     rec->counts, rec->pos);
   e = hipStreamSynchronize(c->stream);
   cleanup();
   if (e != hipSuccess) { hip_fail(e, "leaf_compact"); rfx_records_free(rec); return nullptr; }
@@ -587,7 +688,7 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
   if (r->n == 0) return RFX_OK;
-  if (t->mode != RFX_COUNT_TABLE && !t->table_active) {
+  if (t->mode != RFX_COUNT_TABLE && !t->table_active && t->lut_t) {  // P2L needs 2k <= 62 and full-rank M
     const int rc = p2l_add(t, r);
     if (rc == RFX_OK || t->mode == RFX_COUNT_P2L) return rc;
     if (rc != RFX_E_NOMEM && rc != RFX_E_RANGE) return rc;  // auto: no room for the instance lists

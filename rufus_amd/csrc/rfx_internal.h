@@ -65,11 +65,11 @@ struct rfx_table_view {
   int kshift;  // 2k - lshift: top key bits order equal-pos entries when the table is finer than pos
 };
 
-// Layout of the 64-bit order proxy ord = (pos << pshl) | leading key bits (P2L count path).
+// Geometry of the sortable word w = T * key of the P2L count path (rfx_p2l.hip).
 struct rfx_ord_cfg {
-  int pshl;       // 64 - lsize
-  int kshr, kshl; // key >> kshr when kshr >= 0, else key << kshl
-  int bin_shift;  // 64 - log2(number of bins)
+  int c_bits;     // 2k: width of w
+  int sel_bits;   // 2k - lsize: pos = w >> sel_bits
+  int bin_shift;  // bin = w >> bin_shift  (= c_bits - log2(number of bins))
 };
 
 struct rfx_segment {  // the k-mer instances of one rfx_count_add call, grouped by bin
@@ -116,6 +116,8 @@ struct rfx_table {
   int table_active;   // the global table holds data
   uint32_t p2l_bins;  // 0 until the first P2L add
   std::vector<rfx_segment>* segs;
+  uint64_t* lut_t;     // device LUT of T (key -> sortable word), null when M is rank deficient
+  uint64_t* lut_tinv;  // device LUT of T^-1
 };
 
 struct rfx_records {
@@ -182,13 +184,13 @@ void bin_scatter(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab,
                  const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel,
                  const uint64_t* bin_start, uint64_t* inst);
 void tmp_start(rfx_ctx*, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out /* P+1 */);
-void leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, uint32_t P, int bin_bits,
-          const uint64_t* lut, int ntab, const rfx_ord_cfg&, uint64_t lower, uint64_t upper, const uint64_t* tmp_start,
-          uint64_t* tmp_keys, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err);
+void leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, uint32_t P,
+          const rfx_ord_cfg&, uint64_t lower, uint64_t upper, const uint64_t* tmp_start, uint64_t* tmp_w,
+          uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err);
 void scan_tail(rfx_ctx*, uint64_t* v, uint64_t n);  // exclusive scan in place, v[n] = total
-void leaf_compact(rfx_ctx*, const uint64_t* tmp_keys, const uint32_t* tmp_counts, const uint64_t* tmp_start,
-                  const uint64_t* out_off, uint32_t P, const uint64_t* lut, int ntab, uint64_t* out_keys,
-                  uint32_t* out_counts, uint64_t* out_pos);
+void leaf_compact(rfx_ctx*, const uint64_t* tmp_w, const uint32_t* tmp_counts, const uint64_t* tmp_start,
+                  const uint64_t* out_off, uint32_t P, const uint64_t* lut_inv, int ntab, int sel_bits,
+                  uint64_t* out_keys, uint32_t* out_counts, uint64_t* out_pos);
 }  // namespace rfxk
 
 // Launch bracket: records a HIP-event span on the ctx stream when profiling is on.

@@ -17,7 +17,6 @@
 
 namespace {
 
-constexpr int WAVE = 64;
 constexpr int P2_BLOCK = 512;     // threads = reads per chunk in the partition kernels
 constexpr int LEAF_BLOCK = 1024;
 constexpr int LEAF_TBL = 8192;    // LDS hash slots per bin round
@@ -25,7 +24,7 @@ constexpr int LEAF_FILL = 6144;   // distinct keys allowed before the bin is spl
 constexpr int LEAF_SORT = 2048;   // survivors sorted per round
 constexpr int LEAF_RMAX = 20;
 
-__device__ __forceinline__ uint64_t gf2_pos(const uint64_t* __restrict__ lut, uint64_t key, int ntab) {
+__device__ __forceinline__ uint64_t gf2_mul(const uint64_t* __restrict__ lut, uint64_t key, int ntab) {
   uint64_t r = 0;
 #pragma unroll
   for (int t = 0; t < 8; ++t)
@@ -33,16 +32,16 @@ __device__ __forceinline__ uint64_t gf2_pos(const uint64_t* __restrict__ lut, ui
   return r;
 }
 
-// 64-bit proxy of the (pos,key) output order: pos in the top lsize bits, then as many leading key
-// bits as fit.  (ord,key) orders exactly like (pos,key); bins and rounds are prefixes of ord.
-__device__ __forceinline__ uint64_t ord_of(const rfx_ord_cfg& c, uint64_t pos, uint64_t key) {
-  return (pos << c.pshl) | (c.kshr >= 0 ? (key >> c.kshr) : (key << c.kshl));
-}
+// Sortable word w = T * key (GF(2), 2k bits): the top lsize bits are pos = M * key, the low 2k-lsize
+// bits are the key bits at the free columns of M taken high to low.  T is invertible and numeric
+// order of w IS the (pos,key) output order (host side: build_sort_transform in rfx_api.hip), so
+// bins and rounds are prefixes of w, survivors sort on one 64-bit compare, and the key comes back
+// as Tinv * w for the few records that are emitted.
 
 // Visit every counted window of read r: f(key, pos).
 template <bool CANON, typename F>
 __device__ __forceinline__ void for_each_kmer(const rfx_reads_view& rv, uint32_t r, int k, const uint64_t* s_lut,
-                                              int ntab, uint64_t pos_lo, uint64_t pos_hi, F&& f) {
+                                              int ntab, int sel_bits, uint64_t pos_lo, uint64_t pos_hi, F&& f) {
   const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
   const int rcshift = 2 * (k - 1);
   const uint32_t wr = rv.word_off[r];
@@ -66,8 +65,9 @@ __device__ __forceinline__ void for_each_kmer(const rfx_reads_view& rv, uint32_t
       filled = valid ? filled + 1 : 0;
       if (filled >= k) {
         const uint64_t key = CANON ? (rc < fwd ? rc : fwd) : fwd;
-        const uint64_t pos = gf2_pos(s_lut, key, ntab);
-        if (pos >= pos_lo && pos < pos_hi) f(key, pos);
+        const uint64_t w = gf2_mul(s_lut, key, ntab);
+        const uint64_t pos = w >> sel_bits;
+        if (pos >= pos_lo && pos < pos_hi) f(w);
       }
     }
   }
@@ -87,9 +87,8 @@ __global__ __launch_bounds__(P2_BLOCK) void k_bin_count(rfx_reads_view rv, const
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t r = chunk * P2_BLOCK + threadIdx.x;
     if (r < rv.n)
-      for_each_kmer<CANON>(rv, r, k, s_lut, ntab, pos_lo, pos_hi, [&](uint64_t key, uint64_t pos) {
-        atomicAdd(&s_hist[(uint32_t)(ord_of(cfg, pos, key) >> cfg.bin_shift)], 1u);
-      });
+      for_each_kmer<CANON>(rv, r, k, s_lut, ntab, cfg.sel_bits, pos_lo, pos_hi,
+                           [&](uint64_t w) { atomicAdd(&s_hist[(uint32_t)(w >> cfg.bin_shift)], 1u); });
   }
   __syncthreads();
   for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) cnt[(uint64_t)blockIdx.x * P + b] = s_hist[b];
@@ -130,9 +129,9 @@ __global__ __launch_bounds__(P2_BLOCK) void k_bin_scatter(rfx_reads_view rv, con
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t r = chunk * P2_BLOCK + threadIdx.x;
     if (r < rv.n)
-      for_each_kmer<CANON>(rv, r, k, s_lut, ntab, pos_lo, pos_hi, [&](uint64_t key, uint64_t pos) {
-        const uint32_t i = atomicAdd(&s_cur[(uint32_t)(ord_of(cfg, pos, key) >> cfg.bin_shift)], 1u);
-        inst[i] = key;
+      for_each_kmer<CANON>(rv, r, k, s_lut, ntab, cfg.sel_bits, pos_lo, pos_hi, [&](uint64_t w) {
+        const uint32_t i = atomicAdd(&s_cur[(uint32_t)(w >> cfg.bin_shift)], 1u);
+        inst[i] = w;
       });
   }
 }
@@ -146,35 +145,35 @@ __global__ __launch_bounds__(256) void k_tmp_start(const uint64_t* const* __rest
   tmp_start[b] = s;
 }
 
-__device__ __forceinline__ uint32_t leaf_hash(uint64_t key) {
-  uint32_t h = (uint32_t)key ^ (uint32_t)(key >> 23) ^ (uint32_t)(key >> 41);
+__device__ __forceinline__ uint32_t leaf_hash(uint64_t w) {
+  uint32_t h = (uint32_t)w ^ (uint32_t)(w >> 19) ^ (uint32_t)(w >> 37);
   h *= 0x9E3779B1u;
   return h >> (32 - 13);  // LEAF_TBL = 2^13
 }
 
-// One workgroup per bin.  If a bin holds more distinct keys than the LDS table (or more survivors
-// than the sort area) it is re-run split into 2^r sub-ranges of ord, in order -- exact for any input.
+// One workgroup per bin.  If a bin holds more distinct words than the LDS table (or more survivors
+// than the sort area) it is re-run split into 2^r sub-ranges of w, in order -- exact for any input.
 __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __restrict__ seg_inst,
                                                       const uint64_t* const* __restrict__ seg_bs, int nseg, uint32_t P,
-                                                      int bin_bits, const uint64_t* __restrict__ g_lut, int ntab,
                                                       rfx_ord_cfg cfg, uint64_t lower, uint64_t upper,
                                                       const uint64_t* __restrict__ tmp_start,
-                                                      uint64_t* __restrict__ tmp_keys, uint32_t* __restrict__ tmp_counts,
+                                                      uint64_t* __restrict__ tmp_w, uint32_t* __restrict__ tmp_counts,
                                                       uint64_t* __restrict__ n_surv, unsigned int* __restrict__ err) {
   __shared__ unsigned long long s_keys[LEAF_TBL];
   __shared__ uint32_t s_cnt[LEAF_TBL];
-  __shared__ uint64_t s_ord[LEAF_SORT];
-  __shared__ uint64_t s_skey[LEAF_SORT];
-  __shared__ uint32_t s_scnt[LEAF_SORT];
+  __shared__ uint64_t s_w[LEAF_SORT];
+  __shared__ uint32_t s_c[LEAF_SORT];
   __shared__ uint32_t s_nd, s_ns, s_ovf;
+  const int bin_bits = cfg.c_bits - cfg.bin_shift;  // bins are the top bits of the c-bit word
 
   for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
     const uint64_t out0 = tmp_start[bin];
     uint64_t emitted = 0;
     bool done = false;
-    for (int r = 0; r <= LEAF_RMAX && !done; ++r) {
+    for (int r = 0; r <= LEAF_RMAX && !done && bin_bits + r <= cfg.c_bits; ++r) {
       emitted = 0;
       bool ok = true;
+      const int sub_shift = cfg.c_bits - bin_bits - r;
       for (uint32_t j = 0; j < (1u << r) && ok; ++j) {
         for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
           s_keys[i] = RFX_EMPTY;
@@ -189,28 +188,37 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
         for (int sg = 0; sg < nseg; ++sg) {
           const uint64_t a = seg_bs[sg][bin], e = seg_bs[sg][bin + 1];
           const uint64_t* __restrict__ src = seg_inst[sg];
-          for (uint64_t i = a + threadIdx.x; i < e; i += LEAF_BLOCK) {
-            const uint64_t key = src[i];
-            if (r > 0) {
-              const uint64_t ord = ord_of(cfg, gf2_pos(g_lut, key, ntab), key);
-              if ((uint32_t)((ord << bin_bits) >> (64 - r)) != j) continue;
+          for (uint64_t base = a; base < e; base += 4 * LEAF_BLOCK) {
+            uint64_t w[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {  // four independent loads in flight per lane
+              const uint64_t i = base + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
+              w[u] = i < e ? src[i] : RFX_EMPTY;
             }
-            if (*(volatile uint32_t*)&s_ovf) break;
-            uint32_t slot = leaf_hash(key);
-            for (;;) {
-              unsigned long long cur = s_keys[slot];
-              if (cur == RFX_EMPTY) {
-                cur = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const uint64_t key = w[u];
+              // re-check before EVERY insert: at most one insert per thread can follow the flag, which
+              // the LEAF_TBL - LEAF_FILL spare slots absorb -- the probe loop below always terminates
+              if (*(volatile uint32_t*)&s_ovf) break;
+              if (key == RFX_EMPTY) continue;
+              if (r > 0 && (uint32_t)((key >> sub_shift) & ((1u << r) - 1)) != j) continue;
+              uint32_t slot = leaf_hash(key);
+              for (;;) {
+                unsigned long long cur = s_keys[slot];
                 if (cur == RFX_EMPTY) {
-                  cur = key;
-                  if (atomicAdd(&s_nd, 1u) >= (uint32_t)LEAF_FILL) s_ovf = 1;
+                  cur = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+                  if (cur == RFX_EMPTY) {
+                    cur = key;
+                    if (atomicAdd(&s_nd, 1u) >= (uint32_t)LEAF_FILL) s_ovf = 1;
+                  }
                 }
+                if (cur == key) {
+                  atomicAdd(&s_cnt[slot], 1u);
+                  break;
+                }
+                slot = (slot + 1) & (LEAF_TBL - 1);
               }
-              if (cur == key) {
-                atomicAdd(&s_cnt[slot], 1u);
-                break;
-              }
-              slot = (slot + 1) & (LEAF_TBL - 1);
             }
           }
         }
@@ -227,9 +235,8 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
           if (c < lower || c > upper) continue;
           const uint32_t o = atomicAdd(&s_ns, 1u);
           if (o < (uint32_t)LEAF_SORT) {
-            s_ord[o] = ord_of(cfg, gf2_pos(g_lut, key, ntab), key);
-            s_skey[o] = key;
-            s_scnt[o] = c;
+            s_w[o] = key;
+            s_c[o] = c;
           }
         }
         __syncthreads();
@@ -238,37 +245,13 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
           ok = false;
           break;
         }
-        uint32_t Pw = 1;
-        while (Pw < ns) Pw <<= 1;
-        for (uint32_t i = ns + threadIdx.x; i < Pw; i += LEAF_BLOCK) {
-          s_ord[i] = ~0ull;
-          s_skey[i] = ~0ull;
-          s_scnt[i] = 0;
-        }
-        __syncthreads();
-        for (uint32_t kk = 2; kk <= Pw; kk <<= 1)
-          for (uint32_t jj = kk >> 1; jj > 0; jj >>= 1) {
-            for (uint32_t i = threadIdx.x; i < Pw; i += LEAF_BLOCK) {
-              const uint32_t x = i ^ jj;
-              if (x > i) {
-                const uint64_t oa = s_ord[i], ob = s_ord[x], ka = s_skey[i], kb = s_skey[x];
-                const bool gt = oa > ob || (oa == ob && ka > kb);
-                if (gt == ((i & kk) == 0)) {
-                  s_ord[i] = ob;
-                  s_ord[x] = oa;
-                  s_skey[i] = kb;
-                  s_skey[x] = ka;
-                  const uint32_t ca = s_scnt[i];
-                  s_scnt[i] = s_scnt[x];
-                  s_scnt[x] = ca;
-                }
-              }
-            }
-            __syncthreads();
-          }
+        // rank sort: the words are distinct, rank = number of smaller words (broadcast LDS reads)
         for (uint32_t i = threadIdx.x; i < ns; i += LEAF_BLOCK) {
-          tmp_keys[out0 + emitted + i] = s_skey[i];
-          tmp_counts[out0 + emitted + i] = s_scnt[i];
+          const uint64_t wi = s_w[i];
+          uint32_t rank = 0;
+          for (uint32_t q = 0; q < ns; ++q) rank += s_w[q] < wi;
+          tmp_w[out0 + emitted + rank] = wi;
+          tmp_counts[out0 + emitted + rank] = s_c[i];
         }
         emitted += ns;
         __syncthreads();
@@ -284,23 +267,23 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
   }
 }
 
-__global__ __launch_bounds__(256) void k_leaf_compact(const uint64_t* __restrict__ tmp_keys,
+__global__ __launch_bounds__(256) void k_leaf_compact(const uint64_t* __restrict__ tmp_w,
                                                        const uint32_t* __restrict__ tmp_counts,
                                                        const uint64_t* __restrict__ tmp_start,
                                                        const uint64_t* __restrict__ out_off, uint32_t P,
-                                                       const uint64_t* __restrict__ g_lut, int ntab,
+                                                       const uint64_t* __restrict__ g_lut_inv, int ntab, int sel_bits,
                                                        uint64_t* __restrict__ out_keys, uint32_t* __restrict__ out_counts,
                                                        uint64_t* __restrict__ out_pos) {
   __shared__ uint64_t s_lut[8 * 256];
-  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
+  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut_inv[i];
   __syncthreads();
   for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
     const uint64_t src = tmp_start[bin], dst = out_off[bin], n = out_off[bin + 1] - dst;
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-      const uint64_t key = tmp_keys[src + i];
-      out_keys[dst + i] = key;
+      const uint64_t w = tmp_w[src + i];
+      out_keys[dst + i] = gf2_mul(s_lut, w, ntab);
       out_counts[dst + i] = tmp_counts[src + i];
-      out_pos[dst + i] = gf2_pos(s_lut, key, ntab);
+      out_pos[dst + i] = w >> sel_bits;
     }
   }
 }
@@ -379,24 +362,24 @@ void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, 
 }
 
 void leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, uint32_t P,
-          int bin_bits, const uint64_t* lut, int ntab, const rfx_ord_cfg& cfg, uint64_t lower, uint64_t upper,
-          const uint64_t* tmp_start_, uint64_t* tmp_keys, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err) {
+          const rfx_ord_cfg& cfg, uint64_t lower, uint64_t upper, const uint64_t* tmp_start_, uint64_t* tmp_w,
+          uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err) {
   rfx_span sp(c, "k_leaf");
-  hipLaunchKernelGGL(k_leaf, dim3(P), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, P, bin_bits, lut, ntab,
-                     cfg, lower, upper, tmp_start_, tmp_keys, tmp_counts, n_surv, err);
+  hipLaunchKernelGGL(k_leaf, dim3(P), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, P, cfg, lower, upper,
+                     tmp_start_, tmp_w, tmp_counts, n_surv, err);
 }
 
 void scan_tail(rfx_ctx* c, uint64_t* v, uint64_t n) {
   hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, c->stream, v, n);
 }
 
-void leaf_compact(rfx_ctx* c, const uint64_t* tmp_keys, const uint32_t* tmp_counts, const uint64_t* tmp_start_,
-                  const uint64_t* out_off, uint32_t P, const uint64_t* lut, int ntab, uint64_t* out_keys,
-                  uint32_t* out_counts, uint64_t* out_pos) {
+void leaf_compact(rfx_ctx* c, const uint64_t* tmp_w, const uint32_t* tmp_counts, const uint64_t* tmp_start_,
+                  const uint64_t* out_off, uint32_t P, const uint64_t* lut_inv, int ntab, int sel_bits,
+                  uint64_t* out_keys, uint32_t* out_counts, uint64_t* out_pos) {
   rfx_span sp(c, "k_leaf_compact");
   const uint32_t grid = P < (uint32_t)c->n_cu * 8 ? P : (uint32_t)c->n_cu * 8;
-  hipLaunchKernelGGL(k_leaf_compact, dim3(grid), dim3(256), 0, c->stream, tmp_keys, tmp_counts, tmp_start_, out_off, P,
-                     lut, ntab, out_keys, out_counts, out_pos);
+  hipLaunchKernelGGL(k_leaf_compact, dim3(grid), dim3(256), 0, c->stream, tmp_w, tmp_counts, tmp_start_, out_off, P,
+                     lut_inv, ntab, sel_bits, out_keys, out_counts, out_pos);
 }
 
 }  // namespace rfxk

@@ -592,10 +592,12 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
   const int G = rfxk::p2l_grid(c, r->n);
   uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)G * P * 4);
   uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
-  if (!cnt || !bin_start) { dfree(c, cnt); dfree(c, bin_start); return RFX_E_NOMEM; }
+  uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
+  if (!cnt || !bin_start || !gsum) { dfree(c, cnt); dfree(c, bin_start); dfree(c, gsum); return RFX_E_NOMEM; }
   const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
   rfxk::bin_count(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt);
-  rfxk::bin_offsets(c, cnt, (uint32_t)G, P, bin_start);
+  rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
+  dfree(c, gsum);
   uint64_t total = 0;
   hipError_t e = hipMemcpyAsync(&total, bin_start + P, 8, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -1049,13 +1051,22 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
   s->cap = 1ull << s->bits;
   for (uint64_t i = 0; i < n; ++i)
     if (fwd_keys[i] == RFX_EMPTY) s->has_all_ones = 1;
+  // window bitmap: 8x more bits than slots (floor 2^16 = the LDS-resident size, cap 2^26 = 8 MB),
+  // indexed by the bits of the word just above its two newest bases
+  s->bm_bits = std::min(26, std::max(16, s->bits + 3));
+  if (s->bm_bits > 2 * k) s->bm_bits = 2 * k;
+  s->bm_shift = 2 * k >= s->bm_bits + 4 ? 4 : 0;
+  const size_t bm_words = (size_t)1 << (s->bm_bits > 5 ? s->bm_bits - 5 : 0);
   s->slots = (uint64_t*)dmalloc(c, s->cap * 8);
+  s->bitmap = (uint32_t*)dmalloc(c, std::max<size_t>(bm_words, 2048) * 4);
   uint64_t* dk = (uint64_t*)dmalloc(c, n * 8);
-  bool ok = s->slots && dk;
-  if (ok) ok = hipMemsetAsync(s->slots, 0xFF, s->cap * 8, c->stream) == hipSuccess;
+  bool ok = s->slots && dk && s->bitmap;
+  if (ok) ok = hipMemsetAsync(s->slots, 0xFF, s->cap * 8, c->stream) == hipSuccess &&
+               hipMemsetAsync(s->bitmap, 0, std::max<size_t>(bm_words, 2048) * 4, c->stream) == hipSuccess;
   if (ok && n) ok = hipMemcpyAsync(dk, fwd_keys, n * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess;
   if (ok) {
     rfxk::set_insert(c, dk, n, s->slots, s->bits);
+    rfxk::set_bitmap(c, dk, n, s->bitmap, s->bm_bits, s->bm_shift);
     ok = hipStreamSynchronize(c->stream) == hipSuccess;
   }
   dfree(c, dk);
@@ -1069,6 +1080,7 @@ uint64_t rfx_set_size(const rfx_set* s) { return s ? s->n : 0; }
 void rfx_set_free(rfx_set* s) {
   if (!s) return;
   dfree(s->ctx, s->slots);
+  dfree(s->ctx, s->bitmap);
   delete s;
 }
 
@@ -1088,7 +1100,8 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
   hipError_t e = hipMemsetAsync(d_n, 0, 8, c->stream);
   if (e == hipSuccess) {
     rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
-    rfxk::filter(c, rv, s->slots, s->bits, s->has_all_ones, s->k, thresh, last_base_skipped, d_hits, d_mask, d_n);
+    rfxk::filter(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap, s->bm_bits, s->bm_shift, s->k, thresh,
+                 last_base_skipped, d_hits, d_mask, d_n);
     unsigned long long nh = 0;
     e = hipMemcpyAsync(&nh, d_n, 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess && hits_out) e = hipMemcpyAsync(hits_out, d_hits, (size_t)r->n * 4, hipMemcpyDeviceToHost, c->stream);

@@ -137,6 +137,8 @@ struct rfx_set {
   uint64_t n, cap;
   uint64_t* slots;
   int has_all_ones;  // K = 32 poly-T collides with the empty sentinel
+  uint32_t* bitmap;  // 2^bm_bits bits indexed by (fwd >> bm_shift): pre-filter of the probe
+  int bm_bits, bm_shift;
 };
 
 // ---- kernel launchers (rfx_kernels.hip) -------------------------------------------------------
@@ -174,12 +176,15 @@ void compact(rfx_ctx*, const uint8_t* flags, const uint64_t* keys, const uint32_
 void query(rfx_ctx*, const uint64_t* qkeys, uint64_t nq, const uint64_t* lut, int ntab, const uint64_t* keys,
            const uint64_t* pos, const uint32_t* counts, uint64_t n, uint32_t* out);
 void set_insert(rfx_ctx*, const uint64_t* keys, uint64_t n, uint64_t* slots, int bits);
-void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, int k, int thresh,
-            int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit);
+void set_bitmap(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm, int bm_bits, int bm_shift);
+void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
+            int bm_bits, int bm_shift, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
+            unsigned long long* d_nhit);
 int p2l_grid(rfx_ctx*, uint32_t n_reads);
 void bin_count(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical,
                const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, uint32_t* cnt);
-void bin_offsets(rfx_ctx*, uint32_t* cnt, uint32_t G, uint32_t P, uint64_t* bin_start /* P+1 */);
+void bin_offsets(rfx_ctx*, uint32_t* cnt, uint32_t G, uint32_t P, uint32_t* gsum /* 8*P */,
+                 uint64_t* bin_start /* P+1 */);
 void bin_scatter(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical,
                  const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel,
                  const uint64_t* bin_start, uint64_t* inst);

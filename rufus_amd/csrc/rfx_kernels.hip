@@ -607,8 +607,7 @@ __global__ __launch_bounds__(256) void k_set_insert(const uint64_t* __restrict__
 }
 
 constexpr int K5_BLOCK = 256;
-constexpr int K5_STAGE = K5_BLOCK * 6;
-constexpr int K5_LDS_SET = 4096;  // slots: sets up to this size are probed from LDS
+constexpr int K5_LDS_BM_BITS = 16;  // a 2^16-bit (8 KB) window bitmap is copied to LDS
 
 __device__ __forceinline__ bool set_has(const uint64_t* __restrict__ slots, int bits, uint64_t key) {
   const uint32_t mask = (1u << bits) - 1;
@@ -621,36 +620,44 @@ __device__ __forceinline__ bool set_has(const uint64_t* __restrict__ slots, int 
   }
 }
 
+// One bit per value of bm_bits window bits of the forward word (no hashing: the rolling word IS the
+// index).  A clear bit proves the window is not in the set; only set bits pay for the real probe.
+__global__ __launch_bounds__(256) void k_set_bitmap(const uint64_t* __restrict__ keys, uint64_t n,
+                                                     uint32_t* __restrict__ bm, int bm_bits, int bm_shift) {
+  const uint32_t mask = (1u << bm_bits) - 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t idx = (uint32_t)(keys[i] >> bm_shift) & mask;
+    atomicOr(&bm[idx >> 5], 1u << (idx & 31));
+  }
+}
+
+// Thread per read, words straight from HBM/L2 (a wave's 64 reads are one contiguous 2.5 KB span),
+// 32 waves per CU.  Per base: roll the forward word, roll the good streak, test one bitmap bit.
 __global__ __launch_bounds__(K5_BLOCK) void k_filter(rfx_reads_view rv, const uint64_t* __restrict__ g_slots, int bits,
-                                                      int has_all_ones, int k, int thresh, int last_base_skipped,
+                                                      int has_all_ones, const uint32_t* __restrict__ g_bm, int bm_bits,
+                                                      int bm_shift, int k, int thresh, int last_base_skipped,
                                                       uint32_t* __restrict__ hits_out,
                                                       uint64_t* __restrict__ hitmask,
                                                       unsigned long long* __restrict__ d_nhit) {
-  __shared__ uint64_t s_codes[K5_STAGE];
-  __shared__ uint32_t s_mask[K5_STAGE];
-  __shared__ uint64_t s_set[K5_LDS_SET];
-  const bool lds_set = (1u << bits) <= (uint32_t)K5_LDS_SET;
-  if (lds_set)
-    for (uint32_t i = threadIdx.x; i < (1u << bits); i += blockDim.x) s_set[i] = g_slots[i];
-  const uint64_t* slots = lds_set ? s_set : g_slots;
+  __shared__ uint32_t s_bm[1 << (K5_LDS_BM_BITS - 5)];
+  const bool lds_bm = bm_bits == K5_LDS_BM_BITS;
+  if (lds_bm) {
+    for (uint32_t i = threadIdx.x; i < (1u << (K5_LDS_BM_BITS - 5)); i += blockDim.x) s_bm[i] = g_bm[i];
+    __syncthreads();
+  }
+  const uint32_t* __restrict__ bm = lds_bm ? s_bm : g_bm;
+  const uint32_t bm_mask = (1u << bm_bits) - 1;
   const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
 
   const uint32_t n_chunks = (rv.n + K5_BLOCK - 1) / K5_BLOCK;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const uint32_t r0 = chunk * K5_BLOCK;
-    const uint32_t r1 = min(rv.n, r0 + K5_BLOCK);
-    const uint32_t w0 = rv.word_off[r0], w1 = rv.word_off[r1];
-    __syncthreads();
-    const bool staged = stage_chunk<K5_STAGE>(rv.codes, rv.good, w0, w1, s_codes, s_mask);
-    __syncthreads();
-
-    const uint32_t r = r0 + threadIdx.x;
+    const uint32_t r = chunk * K5_BLOCK + threadIdx.x;
     uint32_t found = 0;
-    if (r < r1) {
+    if (r < rv.n) {
       const uint32_t wr = rv.word_off[r];
       const uint32_t len = rv.len[r];
-      const uint64_t* cw = staged ? s_codes + (wr - w0) : rv.codes + wr;
-      const uint32_t* cm = staged ? s_mask + (wr - w0) : rv.good + wr;
+      const uint64_t* __restrict__ cw = rv.codes + wr;
+      const uint32_t* __restrict__ cm = rv.good + wr;
       // src/RUFUS.Filter.cpp:203: `i < length()-1` -- the last base is never examined.
       const uint32_t stop = last_base_skipped ? (len ? len - 1 : 0) : len;
       uint64_t fwd = 0;
@@ -661,26 +668,25 @@ __global__ __launch_bounds__(K5_BLOCK) void k_filter(rfx_reads_view rv, const ui
         uint32_t m = cm[wi];
         const int nb = min(32u, stop - (wi << 5));
         for (int b = 0; b < nb; ++b) {
-          const uint32_t code = (uint32_t)w & 3u;
+          fwd = ((fwd << 2) | (w & 3u)) & kmask;
           w >>= 2;
-          const bool good = m & 1u;
+          streak = (m & 1u) ? streak + 1 : 0;
           m >>= 1;
-          fwd = ((fwd << 2) | code) & kmask;
-          streak = good ? streak + 1 : 0;
           if (streak >= k) {
-            const bool hit = fwd == RFX_EMPTY ? has_all_ones != 0 : set_has(slots, bits, fwd);
-            found += hit;
+            const uint32_t idx = (uint32_t)(fwd >> bm_shift) & bm_mask;
+            if ((bm[idx >> 5] >> (idx & 31)) & 1u)
+              found += fwd == RFX_EMPTY ? (has_all_ones != 0) : set_has(g_slots, bits, fwd);
           }
         }
       }
       if (hits_out) hits_out[r] = found;
     }
     // wave ballot -> one 64-bit word of the hit mask per 64 reads
-    const bool pass = r < r1 && (int)found >= thresh;
-    const unsigned long long m = __ballot(pass);
-    if ((threadIdx.x & (WAVE - 1)) == 0 && r < r1) {
-      if (hitmask) hitmask[r >> 6] = m;
-      if (m) atomicAdd(d_nhit, (unsigned long long)__popcll(m));
+    const bool pass = r < rv.n && (int)found >= thresh;
+    const unsigned long long mm = __ballot(pass);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && r < rv.n) {
+      if (hitmask) hitmask[r >> 6] = mm;
+      if (mm) atomicAdd(d_nhit, (unsigned long long)__popcll(mm));
     }
   }
 }
@@ -834,13 +840,21 @@ void set_insert(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint64_t* slots, i
   hipLaunchKernelGGL(k_set_insert, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, slots, bits);
 }
 
-void filter(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones, int k, int thresh,
-            int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit) {
+void set_bitmap(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* bm, int bm_bits, int bm_shift) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_set_bitmap");
+  hipLaunchKernelGGL(k_set_bitmap, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, bm, bm_bits,
+                     bm_shift);
+}
+
+void filter(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
+            int bm_bits, int bm_shift, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
+            unsigned long long* d_nhit) {
   if (rv.n == 0) return;
   rfx_span sp(c, "k_filter");
-  const int grid = grid_for(c, (rv.n + K5_BLOCK - 1) / K5_BLOCK, 1, 2);
-  hipLaunchKernelGGL(k_filter, dim3(grid), dim3(K5_BLOCK), 0, c->stream, rv, slots, bits, has_all_ones, k, thresh,
-                     last_base_skipped, hits, hitmask, d_nhit);
+  const int grid = grid_for(c, (rv.n + K5_BLOCK - 1) / K5_BLOCK, 1, 8);
+  hipLaunchKernelGGL(k_filter, dim3(grid), dim3(K5_BLOCK), 0, c->stream, rv, slots, bits, has_all_ones, bm, bm_bits,
+                     bm_shift, k, thresh, last_base_skipped, hits, hitmask, d_nhit);
 }
 
 }  // namespace rfxk

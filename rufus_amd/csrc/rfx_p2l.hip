@@ -96,20 +96,37 @@ __global__ __launch_bounds__(P2_BLOCK) void k_bin_count(rfx_reads_view rv, const
 
 // cnt[g][b] (instances of bin b seen by block g) -> start of block g's run inside bin b, in place.
 // Runs of one bin are ordered by (g % 8, g / 8): blocks that share an XCD (observed dispatch: block
-// g runs on XCD g % 8) write neighbouring runs, so partially written lines meet in ONE L2.
+// g runs on XCD g % 8) write neighbouring runs.  Two passes, thread = (XCD group x, bin b) with b
+// fastest so every load is coalesced: group sums, then offsets.
+__global__ __launch_bounds__(256) void k_bin_group_sums(const uint32_t* __restrict__ cnt, uint32_t G, uint32_t P,
+                                                         uint32_t* __restrict__ gsum /* [8][P] */) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 8 * P) return;
+  const uint32_t x = t / P, b = t - x * P;
+  uint32_t s = 0;
+  for (uint32_t g = x; g < G; g += 8) s += cnt[(uint64_t)g * P + b];
+  gsum[t] = s;
+}
+
 __global__ __launch_bounds__(256) void k_bin_offsets(uint32_t* __restrict__ cnt, uint32_t G, uint32_t P,
+                                                      const uint32_t* __restrict__ gsum,
                                                       uint64_t* __restrict__ bin_tot) {
-  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= P) return;
-  uint32_t run = 0;
-  for (uint32_t x = 0; x < 8; ++x)
-    for (uint32_t g = x; g < G; g += 8) {
-      const uint64_t i = (uint64_t)g * P + b;
-      const uint32_t c = cnt[i];
-      cnt[i] = run;
-      run += c;
-    }
-  bin_tot[b] = run;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 8 * P) return;
+  const uint32_t x = t / P, b = t - x * P;
+  uint32_t run = 0, tot = 0;
+  for (uint32_t y = 0; y < 8; ++y) {
+    const uint32_t v = gsum[y * P + b];
+    if (y < x) run += v;
+    tot += v;
+  }
+  if (x == 0) bin_tot[b] = tot;
+  for (uint32_t g = x; g < G; g += 8) {
+    const uint64_t i = (uint64_t)g * P + b;
+    const uint32_t c = cnt[i];
+    cnt[i] = run;
+    run += c;
+  }
 }
 
 template <bool CANON>
@@ -151,6 +168,9 @@ __device__ __forceinline__ uint32_t leaf_hash(uint64_t w) {
   return h >> (32 - 13);  // LEAF_TBL = 2^13
 }
 
+constexpr int LEAF_ILP = 16;      // words loaded per lane before the first insert (128 KB in flight per CU)
+constexpr int LEAF_BUCKETS = 256;  // survivors are bucketed on the next 8 bits of w, then ranked inside the bucket
+
 // One workgroup per bin.  If a bin holds more distinct words than the LDS table (or more survivors
 // than the sort area) it is re-run split into 2^r sub-ranges of w, in order -- exact for any input.
 __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __restrict__ seg_inst,
@@ -159,10 +179,11 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
                                                       const uint64_t* __restrict__ tmp_start,
                                                       uint64_t* __restrict__ tmp_w, uint32_t* __restrict__ tmp_counts,
                                                       uint64_t* __restrict__ n_surv, unsigned int* __restrict__ err) {
-  __shared__ unsigned long long s_keys[LEAF_TBL];
-  __shared__ uint32_t s_cnt[LEAF_TBL];
+  __shared__ unsigned long long s_keys[LEAF_TBL];  // hash table keys; reused as the bucketed survivor words
+  __shared__ uint32_t s_cnt[LEAF_TBL];             // hash table counts; reused as the bucketed survivor counts
   __shared__ uint64_t s_w[LEAF_SORT];
   __shared__ uint32_t s_c[LEAF_SORT];
+  __shared__ uint32_t s_bstart[LEAF_BUCKETS + 1], s_bfill[LEAF_BUCKETS];
   __shared__ uint32_t s_nd, s_ns, s_ovf;
   const int bin_bits = cfg.c_bits - cfg.bin_shift;  // bins are the top bits of the c-bit word
 
@@ -173,12 +194,13 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
     for (int r = 0; r <= LEAF_RMAX && !done && bin_bits + r <= cfg.c_bits; ++r) {
       emitted = 0;
       bool ok = true;
-      const int sub_shift = cfg.c_bits - bin_bits - r;
+      const int sub_shift = cfg.c_bits - bin_bits - r;  // bits of w below the (bin, round) prefix
       for (uint32_t j = 0; j < (1u << r) && ok; ++j) {
         for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
           s_keys[i] = RFX_EMPTY;
           s_cnt[i] = 0;
         }
+        if (threadIdx.x < LEAF_BUCKETS) s_bfill[threadIdx.x] = 0;
         if (threadIdx.x == 0) {
           s_nd = 0;
           s_ns = 0;
@@ -188,15 +210,15 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
         for (int sg = 0; sg < nseg; ++sg) {
           const uint64_t a = seg_bs[sg][bin], e = seg_bs[sg][bin + 1];
           const uint64_t* __restrict__ src = seg_inst[sg];
-          for (uint64_t base = a; base < e; base += 4 * LEAF_BLOCK) {
-            uint64_t w[4];
+          for (uint64_t base = a; base < e; base += (uint64_t)LEAF_ILP * LEAF_BLOCK) {
+            uint64_t w[LEAF_ILP];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {  // four independent loads in flight per lane
+            for (int u = 0; u < LEAF_ILP; ++u) {  // independent loads, all in flight before the first insert
               const uint64_t i = base + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
               w[u] = i < e ? src[i] : RFX_EMPTY;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < LEAF_ILP; ++u) {
               const uint64_t key = w[u];
               // re-check before EVERY insert: at most one insert per thread can follow the flag, which
               // the LEAF_TBL - LEAF_FILL spare slots absorb -- the probe loop below always terminates
@@ -227,7 +249,8 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
           ok = false;
           break;
         }
-        // survivors -> sort area
+        // survivors -> staging area, counting them per bucket (next bits of w below the prefix)
+        const int bsh = sub_shift > 8 ? sub_shift - 8 : 0;
         for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
           const uint64_t key = s_keys[i];
           if (key == RFX_EMPTY) continue;
@@ -237,6 +260,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
           if (o < (uint32_t)LEAF_SORT) {
             s_w[o] = key;
             s_c[o] = c;
+            atomicAdd(&s_bfill[(uint32_t)(key >> bsh) & (LEAF_BUCKETS - 1)], 1u);
           }
         }
         __syncthreads();
@@ -245,13 +269,43 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
           ok = false;
           break;
         }
-        // rank sort: the words are distinct, rank = number of smaller words (broadcast LDS reads)
+        // exclusive scan of the 256 bucket sizes by one wave (4 buckets per lane)
+        if (threadIdx.x < 64) {
+          const uint32_t l = threadIdx.x;
+          const uint32_t c0 = s_bfill[4 * l], c1 = s_bfill[4 * l + 1], c2 = s_bfill[4 * l + 2], c3 = s_bfill[4 * l + 3];
+          uint32_t sum = c0 + c1 + c2 + c3, inc = sum;
+          for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(inc, off);
+            if ((int)l >= off) inc += o;
+          }
+          const uint32_t ex = inc - sum;
+          s_bstart[4 * l] = ex;
+          s_bstart[4 * l + 1] = ex + c0;
+          s_bstart[4 * l + 2] = ex + c0 + c1;
+          s_bstart[4 * l + 3] = ex + c0 + c1 + c2;
+          if (l == 63) s_bstart[LEAF_BUCKETS] = inc;
+          s_bfill[4 * l] = s_bfill[4 * l + 1] = s_bfill[4 * l + 2] = s_bfill[4 * l + 3] = 0;
+        }
+        __syncthreads();
+        // group by bucket (the table arrays are free now), then rank inside the bucket
+        uint64_t* s_w2 = (uint64_t*)s_keys;
+        uint32_t* s_c2 = s_cnt;
         for (uint32_t i = threadIdx.x; i < ns; i += LEAF_BLOCK) {
           const uint64_t wi = s_w[i];
-          uint32_t rank = 0;
-          for (uint32_t q = 0; q < ns; ++q) rank += s_w[q] < wi;
+          const uint32_t bk = (uint32_t)(wi >> bsh) & (LEAF_BUCKETS - 1);
+          const uint32_t p = s_bstart[bk] + atomicAdd(&s_bfill[bk], 1u);
+          s_w2[p] = wi;
+          s_c2[p] = s_c[i];
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < ns; i += LEAF_BLOCK) {
+          const uint64_t wi = s_w2[i];
+          const uint32_t bk = (uint32_t)(wi >> bsh) & (LEAF_BUCKETS - 1);
+          const uint32_t b0 = s_bstart[bk], b1 = s_bstart[bk + 1];
+          uint32_t rank = b0;
+          for (uint32_t q = b0; q < b1; ++q) rank += s_w2[q] < wi;  // the words are distinct
           tmp_w[out0 + emitted + rank] = wi;
-          tmp_counts[out0 + emitted + rank] = s_c[i];
+          tmp_counts[out0 + emitted + rank] = s_c2[i];
         }
         emitted += ns;
         __syncthreads();
@@ -338,9 +392,11 @@ void bin_count(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int nt
                        pos_hi, cnt);
 }
 
-void bin_offsets(rfx_ctx* c, uint32_t* cnt, uint32_t G, uint32_t P, uint64_t* bin_start) {
+void bin_offsets(rfx_ctx* c, uint32_t* cnt, uint32_t G, uint32_t P, uint32_t* gsum, uint64_t* bin_start) {
   rfx_span sp(c, "k_bin_offsets");
-  hipLaunchKernelGGL(k_bin_offsets, dim3((P + 255) / 256), dim3(256), 0, c->stream, cnt, G, P, bin_start);
+  const uint32_t nb = (8 * P + 255) / 256;
+  hipLaunchKernelGGL(k_bin_group_sums, dim3(nb), dim3(256), 0, c->stream, cnt, G, P, gsum);
+  hipLaunchKernelGGL(k_bin_offsets, dim3(nb), dim3(256), 0, c->stream, cnt, G, P, gsum, bin_start);
   hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, c->stream, bin_start, (uint64_t)P);
 }
 

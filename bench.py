@@ -160,10 +160,12 @@ def main():
 
     if rank == 0:
         reads_per_step = 3 * n_reads * world
-        # K2 (count) is the dominant stage.  On the P2L path it is three launches per read block
-        # (histogram of bins, scatter of the 8-byte keys, LDS count + sort of every bin); the
-        # algorithmic bytes of SURVEY 8(d) cover the whole stage, so its time is their sum.
-        k2 = [n for n in ("k_bin_count", "k_bin_offsets", "k_bin_scatter", "k_leaf") if n in prof] or ["k_count_reads"]
+        # K2+K3 (count -> sorted records) is the dominant stage.  On the P2L path it is a chain of
+        # launches per read block (bin histogram, two-level partition of the 8-byte words, LDS count +
+        # sort of every bin, compaction); the algorithmic bytes of SURVEY 8(d) K2 cover the stage as a
+        # whole, so the time used for roofline.achieved is the SUM of their average durations.
+        k2 = [n for n in ("k_bin_count", "k_bin_offsets", "k_bin_scatter", "k_part1", "k_part2", "k_leaf",
+                         "k_leaf_compact") if n in prof] or ["k_count_reads"]
         n_count = max(prof[n][1] for n in k2)
         parts = {n: prof[n][0] / max(prof[n][1], 1) for n in k2}
         avg_ms = sum(parts.values())
@@ -191,6 +193,15 @@ def main():
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(prof.items())},
         }
+        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+        # (profiles/summarize_pmc.py; 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes), default workload only.
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pmc_path) and args.pairs == 500_000 and args.genome == 5_000_000:
+            pmc = json.load(open(pmc_path))
+            if all(n in pmc for n in k2):
+                line["roofline"]["traffic"] = sum(pmc[n]["hbm_bytes_per_launch"] * (2 if n == "k_bin_offsets" else 1)
+                                                  for n in k2)
+                line["roofline"]["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_pairs * 10)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a
+pass on gfx950: TCC has 4 slots, FETCH_SIZE takes 3 and WRITE_SIZE 2 -- MI355X_MICROARCH.md).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline
+    python profiles/summarize_pmc.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/r01_pmc.json
+
+Units/corrections as the guide prescribes: the counters are in KB (bytes = value * 1024) and on gfx950
+FETCH_SIZE reports exactly half of the bytes of a wide coalesced streaming read, so
+hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  (Calibration inside this profile: k_part2 and
+k_leaf each stream the 1 008 000 000-byte word array once; FETCH_SIZE reads 483 582 KB / 481 417 KB.)
+"""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def kname(s):
+    m = re.search(r"(k_[a-z0-9_]+|__amd_rocclr_[A-Za-z]+)", s)
+    return m.group(1) if m else s[:40]
+
+
+def load(path, counter):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            a = agg[kname(r["Kernel_Name"])]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return {k: (n, v / n) for k, (n, v) in agg.items()}
+
+
+def main():
+    f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(f) | set(w)):
+        fn, fv = f.get(k, (0, 0.0))
+        wn, wv = w.get(k, (0, 0.0))
+        out[k] = {"launches": max(fn, wn), "FETCH_SIZE_KB_avg": round(fv, 1), "WRITE_SIZE_KB_avg": round(wv, 1),
+                  "hbm_bytes_per_launch": int((2 * fv + wv) * 1024)}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        print(f"{k:26s} {v['launches']:4d} {v['FETCH_SIZE_KB_avg']:14.1f} {v['WRITE_SIZE_KB_avg']:14.1f} "
+              f"{v['hbm_bytes_per_launch'] / 1e6:10.1f} MB")
+
+
+if __name__ == "__main__":
+    main()

@@ -179,6 +179,117 @@ int table_grow(rfx_table* t, uint64_t new_cap) {
   return RFX_OK;
 }
 
+// Sortable-word transform of the P2L path.  M (r x c, r = lsize, c = 2k) has kernel dimension c - r;
+// reduce M to row echelon form taking pivots from key bit 0 upward: every kernel vector then has its
+// HIGHEST set bit at a free column f and is zero at all other free columns.  Two keys with equal pos
+// differ by a kernel vector, so they first differ (from the top) at a free column: comparing the
+// free-column bits high to low orders them like the full keys.  T = [M ; e_f for free f, descending]
+// is invertible and w = T*key = (pos << (c-r)) | free bits sorts exactly like (pos,key)
+// (jf/include/jellyfish/mer_heap.hpp:34-38).  Fills img_t[b] = T*e_b and img_inv[b] = T^-1*e_b;
+// returns false when M is rank deficient (P2L then stays off).
+bool build_sort_transform(const uint64_t* cols, int r, int c, uint64_t* img_t, uint64_t* img_inv) {
+  if (c > 62 || r > c) return false;
+  // rows of M as masks over key bits: pos bit i = parity(row[i] & key); key bit b selects cols[c-1-b]
+  std::vector<uint64_t> row(r, 0);
+  for (int b = 0; b < c; ++b)
+    for (int i = 0; i < r; ++i)
+      if ((cols[c - 1 - b] >> i) & 1) row[i] |= 1ull << b;
+  std::vector<uint64_t> e(row);
+  std::vector<bool> is_pivot(c, false);
+  int rank = 0;
+  for (int b = 0; b < c && rank < r; ++b) {
+    int p = -1;
+    for (int i = rank; i < r; ++i)
+      if ((e[i] >> b) & 1) { p = i; break; }
+    if (p < 0) continue;
+    std::swap(e[rank], e[p]);
+    for (int i = 0; i < r; ++i)
+      if (i != rank && ((e[i] >> b) & 1)) e[i] ^= e[rank];
+    is_pivot[b] = true;
+    ++rank;
+  }
+  if (rank != r) return false;
+  std::vector<int> freec;
+  for (int b = c - 1; b >= 0; --b)
+    if (!is_pivot[b]) freec.push_back(b);  // descending
+  // T as c row masks over key bits, row 0 = most significant bit of w
+  std::vector<uint64_t> trow(c);
+  for (int i = 0; i < r; ++i) trow[i] = row[r - 1 - i];          // w bit c-1-i = pos bit r-1-i
+  for (int j = 0; j < c - r; ++j) trow[r + j] = 1ull << freec[j];  // then the free key bits, high to low
+  for (int b = 0; b < c; ++b) {
+    uint64_t w = 0;
+    for (int i = 0; i < c; ++i)
+      if ((trow[i] >> b) & 1) w |= 1ull << (c - 1 - i);
+    img_t[b] = w;
+  }
+  // invert: Gauss-Jordan on [A | I] where A[i] = row mask producing w bit (c-1-i)
+  std::vector<uint64_t> a(trow), inv(c);
+  for (int i = 0; i < c; ++i) inv[i] = 1ull << i;  // inv[i]: combination of original rows, bit j = row j
+  for (int col = 0; col < c; ++col) {
+    int p = -1;
+    for (int i = col; i < c; ++i)
+      if ((a[i] >> col) & 1) { p = i; break; }
+    if (p < 0) return false;
+    std::swap(a[col], a[p]);
+    std::swap(inv[col], inv[p]);
+    for (int i = 0; i < c; ++i)
+      if (i != col && ((a[i] >> col) & 1)) { a[i] ^= a[col]; inv[i] ^= inv[col]; }
+  }
+  // now a = I: key bit `col` = XOR over rows j in inv[col] of (w bit c-1-j)
+  for (int wb = 0; wb < c; ++wb) {       // image of unit word e_wb
+    const int j = c - 1 - wb;             // the T row that produces w bit wb
+    uint64_t key = 0;
+    for (int col = 0; col < c; ++col)
+      if ((inv[col] >> j) & 1) key |= 1ull << col;
+    img_inv[wb] = key;
+  }
+  return true;
+}
+
+void lut_from_images(const uint64_t* img, int nbits, std::vector<uint64_t>& lut, int& ntab) {
+  ntab = (nbits + 7) / 8;
+  lut.assign((size_t)ntab * 256, 0);
+  for (int t = 0; t < ntab; ++t)
+    for (int v = 0; v < 256; ++v) {
+      uint64_t r = 0;
+      for (int j = 0; j < 8; ++j)
+        if (((v >> j) & 1) && 8 * t + j < nbits) r ^= img[8 * t + j];
+      lut[(size_t)t * 256 + v] = r;
+    }
+}
+
+// Matrix + device lookup tables of (k, lsize), built on first use and kept for the life of the ctx.
+const rfx_hash_consts* get_consts(rfx_ctx* c, int k, int lsize, const uint64_t* cols_in) {
+  rfx_hash_consts hc;
+  memset(hc.cols, 0, sizeof hc.cols);
+  if (cols_in) memcpy(hc.cols, cols_in, sizeof(uint64_t) * 2 * k);
+  else if (rfx_jf_matrix(lsize, k, hc.cols) != RFX_OK) return nullptr;
+  uint64_t digest = 0xcbf29ce484222325ull;
+  for (int i = 0; i < 2 * k; ++i) digest = (digest ^ hc.cols[i]) * 0x100000001b3ull;
+  auto key = std::make_pair(k * 64 + lsize, digest);
+  auto it = c->consts.find(key);
+  if (it != c->consts.end()) return &it->second;
+  std::vector<uint64_t> lut, lt, li;
+  build_lut(hc.cols, k, lut, hc.ntab);
+  hc.lut = (uint64_t*)dmalloc(c, lut.size() * 8);
+  if (!hc.lut || hipMemcpyAsync(hc.lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+    return nullptr;
+  uint64_t img_t[64], img_inv[64];
+  if (build_sort_transform(hc.cols, lsize, 2 * k, img_t, img_inv)) {
+    int nt = 0;
+    lut_from_images(img_t, 2 * k, lt, nt);
+    lut_from_images(img_inv, 2 * k, li, nt);
+    hc.lut_t = (uint64_t*)dmalloc(c, lt.size() * 8);
+    hc.lut_tinv = (uint64_t*)dmalloc(c, li.size() * 8);
+    if (!hc.lut_t || !hc.lut_tinv ||
+        hipMemcpyAsync(hc.lut_t, lt.data(), lt.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+        hipMemcpyAsync(hc.lut_tinv, li.data(), li.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
+      hc.lut_t = hc.lut_tinv = nullptr;
+  }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;  // host vectors die at return
+  return &(c->consts[key] = hc);
+}
+
 rfx_records* records_alloc(rfx_ctx* c, int k, int lsize, const uint64_t* cols, uint64_t n) {
   rfx_records* r = new rfx_records();
   r->ctx = c;
@@ -186,21 +297,16 @@ rfx_records* records_alloc(rfx_ctx* c, int k, int lsize, const uint64_t* cols, u
   r->lsize = lsize;
   r->n = n;
   memcpy(r->cols, cols, sizeof(uint64_t) * 2 * k);
-  std::vector<uint64_t> lut;
-  build_lut(cols, k, lut, r->ntab);
+  const rfx_hash_consts* hc = get_consts(c, k, lsize, cols);
   r->keys = (uint64_t*)dmalloc(c, n * 8);
   r->counts = (uint32_t*)dmalloc(c, n * 4);
   r->pos = (uint64_t*)dmalloc(c, n * 8);
-  r->lut = (uint64_t*)dmalloc(c, lut.size() * 8);
-  if (!r->keys || !r->counts || !r->pos || !r->lut) {
+  if (!hc || !r->keys || !r->counts || !r->pos) {
     rfx_records_free(r);
     return nullptr;
   }
-  if (hipMemcpyAsync(r->lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-      hipStreamSynchronize(c->stream) != hipSuccess) {
-    rfx_records_free(r);
-    return nullptr;
-  }
+  r->lut = hc->lut;  // owned by the ctx
+  r->ntab = hc->ntab;
   return r;
 }
 
@@ -258,9 +364,6 @@ void resolve_spans(rfx_ctx* c) {
 }
 
 }  // namespace
-
-static bool build_sort_transform(const uint64_t* cols, int r, int c, uint64_t* img_t, uint64_t* img_inv);
-static void lut_from_images(const uint64_t* img, int nbits, std::vector<uint64_t>& lut, int& ntab);
 
 extern "C" {
 
@@ -420,39 +523,21 @@ rfx_table* rfx_count_begin(rfx_ctx* c, int k, int canonical, int lsize, uint64_t
   t->cap = 1ull << t->tbits;
   t->pos_lo = pos_lo;
   t->pos_hi = pos_hi ? pos_hi : (1ull << lsize);
-  if (rfx_jf_matrix(lsize, k, t->cols) != RFX_OK) {
+  const rfx_hash_consts* hc = get_consts(c, k, lsize, nullptr);
+  if (!hc) {
     delete t;
     return nullptr;
   }
-  std::vector<uint64_t> lut;
-  build_lut(t->cols, k, lut, t->ntab);
-  t->lut = (uint64_t*)dmalloc(c, lut.size() * 8);
+  memcpy(t->cols, hc->cols, sizeof t->cols);
+  t->lut = hc->lut;  // the lookup tables are owned by the ctx
+  t->lut_t = hc->lut_t;
+  t->lut_tinv = hc->lut_tinv;
+  t->ntab = hc->ntab;
+  t->segs = new std::vector<rfx_segment>();
   t->d_stats = (rfx_table_stats*)dmalloc(c, sizeof(rfx_table_stats));
   t->d_ctl = (rfx_count_ctl*)dmalloc(c, sizeof(rfx_count_ctl));
-  t->segs = new std::vector<rfx_segment>();
-  {
-    uint64_t img_t[64], img_inv[64];
-    if (build_sort_transform(t->cols, lsize, 2 * k, img_t, img_inv)) {
-      std::vector<uint64_t> lt, li;
-      int nt = 0;
-      lut_from_images(img_t, 2 * k, lt, nt);
-      lut_from_images(img_inv, 2 * k, li, nt);
-      t->lut_t = (uint64_t*)dmalloc(c, lt.size() * 8);
-      t->lut_tinv = (uint64_t*)dmalloc(c, li.size() * 8);
-      if (!t->lut_t || !t->lut_tinv ||
-          hipMemcpyAsync(t->lut_t, lt.data(), lt.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-          hipMemcpyAsync(t->lut_tinv, li.data(), li.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-          hipStreamSynchronize(c->stream) != hipSuccess) {
-        dfree(c, t->lut_t);
-        dfree(c, t->lut_tinv);
-        t->lut_t = t->lut_tinv = nullptr;
-      }
-    }
-  }
-  bool ok = t->lut && t->d_stats && t->d_ctl;  // the slot arrays are allocated on first use (ensure_table)
-  if (ok) ok = hipMemcpyAsync(t->lut, lut.data(), lut.size() * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
-               hipMemsetAsync(t->d_stats, 0, sizeof(rfx_table_stats), c->stream) == hipSuccess &&
-               hipStreamSynchronize(c->stream) == hipSuccess;
+  const bool ok = t->d_stats && t->d_ctl &&
+                  hipMemsetAsync(t->d_stats, 0, sizeof(rfx_table_stats), c->stream) == hipSuccess;
   if (!ok) {
     rfx_count_free(t);
     return nullptr;
@@ -462,9 +547,8 @@ rfx_table* rfx_count_begin(rfx_ctx* c, int k, int canonical, int lsize, uint64_t
 
 void rfx_count_free(rfx_table* t) {
   if (!t) return;
-  dfree(t->ctx, t->keys); dfree(t->ctx, t->counts); dfree(t->ctx, t->lut); dfree(t->ctx, t->d_stats);
+  dfree(t->ctx, t->keys); dfree(t->ctx, t->counts); dfree(t->ctx, t->d_stats);
   dfree(t->ctx, t->d_ctl); dfree(t->ctx, t->ovf_keys);
-  dfree(t->ctx, t->lut_t); dfree(t->ctx, t->lut_tinv);
   if (t->segs) {
     for (auto& sg : *t->segs) {
       dfree(t->ctx, sg.inst);
@@ -487,85 +571,6 @@ static rfx_ord_cfg ord_cfg(const rfx_table* t, int bin_bits) {
   c.sel_bits = 2 * t->k - t->lsize;
   c.bin_shift = c.c_bits - bin_bits;
   return c;
-}
-
-// Sortable-word transform of the P2L path.  M (r x c, r = lsize, c = 2k) has kernel dimension c - r;
-// reduce M to row echelon form taking pivots from key bit 0 upward: every kernel vector then has its
-// HIGHEST set bit at a free column f and is zero at all other free columns.  Two keys with equal pos
-// differ by a kernel vector, so they first differ (from the top) at a free column: comparing the
-// free-column bits high to low orders them like the full keys.  T = [M ; e_f for free f, descending]
-// is invertible and w = T*key = (pos << (c-r)) | free bits sorts exactly like (pos,key)
-// (jf/include/jellyfish/mer_heap.hpp:34-38).  Fills img_t[b] = T*e_b and img_inv[b] = T^-1*e_b;
-// returns false when M is rank deficient (P2L then stays off).
-static bool build_sort_transform(const uint64_t* cols, int r, int c, uint64_t* img_t, uint64_t* img_inv) {
-  if (c > 62 || r > c) return false;
-  // rows of M as masks over key bits: pos bit i = parity(row[i] & key); key bit b selects cols[c-1-b]
-  std::vector<uint64_t> row(r, 0);
-  for (int b = 0; b < c; ++b)
-    for (int i = 0; i < r; ++i)
-      if ((cols[c - 1 - b] >> i) & 1) row[i] |= 1ull << b;
-  std::vector<uint64_t> e(row);
-  std::vector<bool> is_pivot(c, false);
-  int rank = 0;
-  for (int b = 0; b < c && rank < r; ++b) {
-    int p = -1;
-    for (int i = rank; i < r; ++i)
-      if ((e[i] >> b) & 1) { p = i; break; }
-    if (p < 0) continue;
-    std::swap(e[rank], e[p]);
-    for (int i = 0; i < r; ++i)
-      if (i != rank && ((e[i] >> b) & 1)) e[i] ^= e[rank];
-    is_pivot[b] = true;
-    ++rank;
-  }
-  if (rank != r) return false;
-  std::vector<int> freec;
-  for (int b = c - 1; b >= 0; --b)
-    if (!is_pivot[b]) freec.push_back(b);  // descending
-  // T as c row masks over key bits, row 0 = most significant bit of w
-  std::vector<uint64_t> trow(c);
-  for (int i = 0; i < r; ++i) trow[i] = row[r - 1 - i];          // w bit c-1-i = pos bit r-1-i
-  for (int j = 0; j < c - r; ++j) trow[r + j] = 1ull << freec[j];  // then the free key bits, high to low
-  for (int b = 0; b < c; ++b) {
-    uint64_t w = 0;
-    for (int i = 0; i < c; ++i)
-      if ((trow[i] >> b) & 1) w |= 1ull << (c - 1 - i);
-    img_t[b] = w;
-  }
-  // invert: Gauss-Jordan on [A | I] where A[i] = row mask producing w bit (c-1-i)
-  std::vector<uint64_t> a(trow), inv(c);
-  for (int i = 0; i < c; ++i) inv[i] = 1ull << i;  // inv[i]: combination of original rows, bit j = row j
-  for (int col = 0; col < c; ++col) {
-    int p = -1;
-    for (int i = col; i < c; ++i)
-      if ((a[i] >> col) & 1) { p = i; break; }
-    if (p < 0) return false;
-    std::swap(a[col], a[p]);
-    std::swap(inv[col], inv[p]);
-    for (int i = 0; i < c; ++i)
-      if (i != col && ((a[i] >> col) & 1)) { a[i] ^= a[col]; inv[i] ^= inv[col]; }
-  }
-  // now a = I: key bit `col` = XOR over rows j in inv[col] of (w bit c-1-j)
-  for (int wb = 0; wb < c; ++wb) {       // image of unit word e_wb
-    const int j = c - 1 - wb;             // the T row that produces w bit wb
-    uint64_t key = 0;
-    for (int col = 0; col < c; ++col)
-      if ((inv[col] >> j) & 1) key |= 1ull << col;
-    img_inv[wb] = key;
-  }
-  return true;
-}
-
-static void lut_from_images(const uint64_t* img, int nbits, std::vector<uint64_t>& lut, int& ntab) {
-  ntab = (nbits + 7) / 8;
-  lut.assign((size_t)ntab * 256, 0);
-  for (int t = 0; t < ntab; ++t)
-    for (int v = 0; v < 256; ++v) {
-      uint64_t r = 0;
-      for (int j = 0; j < 8; ++j)
-        if (((v >> j) & 1) && 8 * t + j < nbits) r ^= img[8 * t + j];
-      lut[(size_t)t * 256 + v] = r;
-    }
 }
 
 static int p2l_add(rfx_table* t, const rfx_reads* r) {
@@ -595,19 +600,44 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
   uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
   if (!cnt || !bin_start || !gsum) { dfree(c, cnt); dfree(c, bin_start); dfree(c, gsum); return RFX_E_NOMEM; }
   const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+  const uint32_t P1 = (uint32_t)rfxk::p1_bins();
+  const bool two_level = P >= 2048 && !getenv("RFX_P2L_ONE_LEVEL");
+  const uint32_t P2 = P / P1;
+  uint32_t *cnt1 = nullptr, *gsum1 = nullptr, *fine_cur = nullptr;
+  uint64_t* tot1 = nullptr;
+  auto drop = [&] { dfree(c, cnt); dfree(c, gsum); dfree(c, cnt1); dfree(c, gsum1); dfree(c, fine_cur); dfree(c, tot1); };
   rfxk::bin_count(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt);
+  if (two_level) {
+    cnt1 = (uint32_t*)dmalloc(c, (size_t)G * P1 * 4);
+    gsum1 = (uint32_t*)dmalloc(c, (size_t)8 * P1 * 4);
+    tot1 = (uint64_t*)dmalloc(c, ((size_t)P1 + 1) * 8);
+    fine_cur = (uint32_t*)dmalloc(c, (size_t)P * 4);
+    if (!cnt1 || !gsum1 || !tot1 || !fine_cur) { drop(); dfree(c, bin_start); return RFX_E_NOMEM; }
+    rfxk::coarse_counts(c, cnt, (uint32_t)G, P, P2, cnt1);   // before bin_offsets rewrites cnt in place
+  }
   rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
-  dfree(c, gsum);
+  if (two_level) rfxk::bin_offsets(c, cnt1, (uint32_t)G, P1, gsum1, tot1);
   uint64_t total = 0;
   hipError_t e = hipMemcpyAsync(&total, bin_start + P, 8, hipMemcpyDeviceToHost, c->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e != hipSuccess) { dfree(c, cnt); dfree(c, bin_start); return hip_fail(e, "p2l_add"); }
-  if (total == 0) { dfree(c, cnt); dfree(c, bin_start); return RFX_OK; }
+  if (e != hipSuccess) { drop(); dfree(c, bin_start); return hip_fail(e, "p2l_add"); }
+  if (total == 0) { drop(); dfree(c, bin_start); return RFX_OK; }
   uint64_t* inst = (uint64_t*)dmalloc(c, total * 8);
-  if (!inst) { dfree(c, cnt); dfree(c, bin_start); return RFX_E_NOMEM; }
-  rfxk::bin_scatter(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt, bin_start,
-                    inst);
-  dfree(c, cnt);
+  if (!inst) { drop(); dfree(c, bin_start); return RFX_E_NOMEM; }
+  if (two_level) {
+    uint64_t* buf_a = (uint64_t*)dmalloc(c, total * 8);
+    if (!buf_a || hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream) != hipSuccess) {
+      dfree(c, buf_a); dfree(c, inst); drop(); dfree(c, bin_start);
+      return RFX_E_NOMEM;
+    }
+    rfxk::part1(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P2, t->pos_lo, t->pos_hi, G, cnt1, bin_start, buf_a);
+    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P, P2, cfg);
+    dfree(c, buf_a);
+  } else {
+    rfxk::bin_scatter(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt, bin_start,
+                      inst);
+  }
+  drop();
   t->segs->push_back(rfx_segment{inst, total, bin_start});
   return RFX_OK;
 }
@@ -852,7 +882,7 @@ const uint64_t* rfx_records_dev_pos(const rfx_records* r) { return r ? r->pos : 
 
 void rfx_records_free(rfx_records* r) {
   if (!r) return;
-  dfree(r->ctx, r->keys); dfree(r->ctx, r->counts); dfree(r->ctx, r->pos); dfree(r->ctx, r->lut);
+  dfree(r->ctx, r->keys); dfree(r->ctx, r->counts); dfree(r->ctx, r->pos);
   delete r;
 }
 

@@ -23,6 +23,15 @@ struct rfx_prof_acc {
   uint64_t launches = 0;
 };
 
+// Per (k, lsize) constants: jellyfish matrix and the byte-indexed GF(2) lookup tables on the device.
+struct rfx_hash_consts {
+  uint64_t cols[64];
+  int ntab = 0;
+  uint64_t* lut = nullptr;       // M:      key -> pos
+  uint64_t* lut_t = nullptr;     // T:      key -> sortable word (null if M is rank deficient / 2k > 62)
+  uint64_t* lut_tinv = nullptr;  // T^-1:   sortable word -> key
+};
+
 struct rfx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -33,6 +42,7 @@ struct rfx_ctx {
   std::map<std::string, rfx_prof_acc> acc;
   std::map<void*, size_t> allocs;
   std::multimap<size_t, void*> pool;  // freed blocks kept for reuse, keyed by size
+  std::map<std::pair<int, uint64_t>, rfx_hash_consts> consts;  // (k*64+lsize, matrix digest) -> device tables
 };
 
 // Device-side statistics of a count table.
@@ -188,6 +198,13 @@ void bin_offsets(rfx_ctx*, uint32_t* cnt, uint32_t G, uint32_t P, uint32_t* gsum
 void bin_scatter(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical,
                  const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel,
                  const uint64_t* bin_start, uint64_t* inst);
+int p1_bins();
+void coarse_counts(rfx_ctx*, const uint32_t* cnt, uint32_t G, uint32_t P, uint32_t P2, uint32_t* cnt1);
+void part1(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical, const rfx_ord_cfg&,
+           uint32_t P2, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel1, const uint64_t* fine_start,
+           uint64_t* buf_a);
+void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur, uint32_t P,
+           uint32_t P2, const rfx_ord_cfg&);
 void tmp_start(rfx_ctx*, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out /* P+1 */);
 void leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, uint32_t P,
           const rfx_ord_cfg&, uint64_t lower, uint64_t upper, const uint64_t* tmp_start, uint64_t* tmp_w,

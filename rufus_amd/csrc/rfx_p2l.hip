@@ -153,6 +153,205 @@ __global__ __launch_bounds__(P2_BLOCK) void k_bin_scatter(rfx_reads_view rv, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Two-level partition (used when there are >= 2048 bins).  Scattered 8-byte stores into thousands of
+// bins are partial-line writes (measured 0.6-1.1 TB/s); instead the words are reordered in LDS so
+// that every global store instruction writes whole runs:
+//   k_part1  reads -> words -> P1 = 128 coarse bins, phase by phase (8 bases of 512 reads = up to
+//            4096 words per phase, ~32-word runs per coarse bin);
+//   k_part2  coarse bin -> its P/P1 fine bins, 8192-word tiles, ~128-word runs.
+// Fine bin sizes are exact (k_bin_count), so both levels write into exactly sized regions.
+// ---------------------------------------------------------------------------------------------
+constexpr int P1_BINS = 128;
+constexpr int P1_S = 8;                       // bases per phase
+constexpr int P1_STAGE = P2_BLOCK * P1_S;     // words staged per phase
+constexpr int L2_BLOCK = 1024;
+constexpr int L2_PER = 8;                     // words per lane per tile
+constexpr int L2_TILE = L2_BLOCK * L2_PER;
+
+// cnt[g][f] over fine bins -> cnt1[g][cb] over coarse bins (P2 consecutive fine bins each)
+__global__ __launch_bounds__(256) void k_coarse_counts(const uint32_t* __restrict__ cnt, uint32_t G, uint32_t P,
+                                                        uint32_t P2, uint32_t* __restrict__ cnt1) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t P1 = P / P2;
+  if (t >= G * P1) return;
+  const uint32_t g = t / P1, cb = t - g * P1;
+  const uint32_t* p = cnt + (uint64_t)g * P + (uint64_t)cb * P2;
+  uint32_t s = 0;
+  for (uint32_t i = 0; i < P2; ++i) s += p[i];
+  cnt1[t] = s;
+}
+
+// exclusive scan of up to 256 LDS counters by wave 0 (4 per lane); returns the total in s_start[n]
+__device__ __forceinline__ void wave_scan256(const uint32_t* s_cnt, uint32_t* s_start, uint32_t n) {
+  const uint32_t l = threadIdx.x;  // caller guarantees l < 64
+  uint32_t c[4], sum = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    c[i] = 4 * l + i < n ? s_cnt[4 * l + i] : 0;
+    sum += c[i];
+  }
+  uint32_t inc = sum;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(inc, off);
+    if ((int)l >= off) inc += o;
+  }
+  uint32_t ex = inc - sum;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (4 * l + i < n) s_start[4 * l + i] = ex;
+    ex += c[i];
+  }
+  if (l == 63) s_start[n] = inc;
+}
+
+template <bool CANON>
+__global__ __launch_bounds__(P2_BLOCK) void k_part1(rfx_reads_view rv, const uint64_t* __restrict__ g_lut, int ntab,
+                                                     int k, rfx_ord_cfg cfg, uint32_t P2, uint64_t pos_lo,
+                                                     uint64_t pos_hi, const uint32_t* __restrict__ rel1,
+                                                     const uint64_t* __restrict__ fine_start,
+                                                     uint64_t* __restrict__ buf_a) {
+  __shared__ uint64_t s_lut[8 * 256];
+  __shared__ uint64_t s_stage[P1_STAGE];
+  __shared__ uint8_t s_sbin[P1_STAGE];
+  __shared__ uint32_t s_cnt[P1_BINS], s_start[P1_BINS + 1], s_gcur[P1_BINS], s_gbase[P1_BINS];
+  __shared__ uint32_t s_maxlen;
+  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
+  if (threadIdx.x < P1_BINS) {
+    s_gcur[threadIdx.x] =
+        (uint32_t)fine_start[(uint64_t)threadIdx.x * P2] + rel1[(uint64_t)blockIdx.x * P1_BINS + threadIdx.x];
+    s_cnt[threadIdx.x] = 0;
+  }
+  const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+  const int rcshift = 2 * (k - 1);
+  const int shift1 = cfg.c_bits - 7;  // log2(P1_BINS) = 7
+  const uint32_t n_chunks = (rv.n + P2_BLOCK - 1) / P2_BLOCK;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t r = chunk * P2_BLOCK + threadIdx.x;
+    const bool live = r < rv.n;
+    const uint32_t len = live ? rv.len[r] : 0;
+    const uint64_t* cw = rv.codes + (live ? rv.word_off[r] : 0);
+    const uint32_t* cm = rv.acgt + (live ? rv.word_off[r] : 0);
+    if (threadIdx.x == 0) s_maxlen = 0;
+    __syncthreads();
+    if (len) atomicMax(&s_maxlen, len);
+    __syncthreads();
+    const uint32_t n_phase = (s_maxlen + P1_S - 1) / P1_S;
+    uint64_t fwd = 0, rc = 0, cur_w = 0;
+    uint32_t cur_m = 0;
+    int filled = 0;
+    for (uint32_t ph = 0; ph < n_phase; ++ph) {
+      uint64_t wv[P1_S];
+      uint32_t br[P1_S];  // (bin << 16) | rank, or ~0 when this base yields no word
+      const uint32_t p0 = ph * P1_S;
+      if ((ph & 3) == 0 && p0 < len) {  // 32 bases per code word = 4 phases
+        cur_w = cw[p0 >> 5];
+        cur_m = cm[p0 >> 5];
+      }
+#pragma unroll
+      for (int b = 0; b < P1_S; ++b) {
+        br[b] = ~0u;
+        if (p0 + b < len) {
+          const uint32_t code = (uint32_t)cur_w & 3u;
+          cur_w >>= 2;
+          const bool valid = cur_m & 1u;
+          cur_m >>= 1;
+          fwd = ((fwd << 2) | code) & kmask;
+          if (CANON) rc = (rc >> 2) | ((uint64_t)(3u - code) << rcshift);
+          filled = valid ? filled + 1 : 0;
+          if (filled >= k) {
+            const uint64_t key = CANON ? (rc < fwd ? rc : fwd) : fwd;
+            const uint64_t w = gf2_mul(s_lut, key, ntab);
+            const uint64_t pos = w >> cfg.sel_bits;
+            if (pos >= pos_lo && pos < pos_hi) {
+              const uint32_t bin = (uint32_t)(w >> shift1);
+              wv[b] = w;
+              br[b] = (bin << 16) | atomicAdd(&s_cnt[bin], 1u);
+            }
+          }
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < 64) wave_scan256(s_cnt, s_start, P1_BINS);
+      __syncthreads();
+      if (threadIdx.x < P1_BINS) {
+        s_gbase[threadIdx.x] = s_gcur[threadIdx.x];
+        s_gcur[threadIdx.x] += s_cnt[threadIdx.x];
+        s_cnt[threadIdx.x] = 0;
+      }
+#pragma unroll
+      for (int b = 0; b < P1_S; ++b)
+        if (br[b] != ~0u) {
+          const uint32_t bin = br[b] >> 16, e = s_start[bin] + (br[b] & 0xFFFFu);
+          s_stage[e] = wv[b];
+          s_sbin[e] = (uint8_t)bin;
+        }
+      __syncthreads();
+      const uint32_t total = s_start[P1_BINS];
+      for (uint32_t e = threadIdx.x; e < total; e += P2_BLOCK) {
+        const uint32_t bin = s_sbin[e];
+        buf_a[s_gbase[bin] + (e - s_start[bin])] = s_stage[e];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Coarse bin cb of A -> its P2 fine bins in B.  W workgroups share a coarse bin (tiles strided).
+__global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__ buf_a, uint64_t* __restrict__ buf_b,
+                                                     const uint64_t* __restrict__ fine_start,
+                                                     uint32_t* __restrict__ fine_cur, uint32_t P2, int shift2,
+                                                     uint32_t W) {
+  __shared__ uint64_t s_stage[L2_TILE];
+  __shared__ uint8_t s_sbin[L2_TILE];
+  __shared__ uint32_t s_cnt[256], s_start[257];
+  __shared__ uint64_t s_gbase[256];
+  const uint32_t cb = blockIdx.x / W, j = blockIdx.x - cb * W;
+  const uint64_t a = fine_start[(uint64_t)cb * P2], e = fine_start[(uint64_t)(cb + 1) * P2];
+  if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t base = a + (uint64_t)j * L2_TILE; base < e; base += (uint64_t)W * L2_TILE) {
+    uint64_t wv[L2_PER];
+    uint32_t br[L2_PER];
+#pragma unroll
+    for (int u = 0; u < L2_PER; ++u) {
+      const uint64_t i = base + threadIdx.x + (uint64_t)u * L2_BLOCK;
+      wv[u] = i < e ? buf_a[i] : RFX_EMPTY;
+    }
+#pragma unroll
+    for (int u = 0; u < L2_PER; ++u) {
+      br[u] = ~0u;
+      if (wv[u] != RFX_EMPTY) {
+        const uint32_t sub = (uint32_t)(wv[u] >> shift2) & (P2 - 1);
+        br[u] = (sub << 16) | atomicAdd(&s_cnt[sub], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) wave_scan256(s_cnt, s_start, P2);
+    __syncthreads();
+    if (threadIdx.x < P2) {
+      const uint32_t c = s_cnt[threadIdx.x];
+      const uint64_t f = (uint64_t)cb * P2 + threadIdx.x;
+      s_gbase[threadIdx.x] = fine_start[f] + (c ? atomicAdd(&fine_cur[f], c) : 0u);
+      s_cnt[threadIdx.x] = 0;
+    }
+#pragma unroll
+    for (int u = 0; u < L2_PER; ++u)
+      if (br[u] != ~0u) {
+        const uint32_t sub = br[u] >> 16, x = s_start[sub] + (br[u] & 0xFFFFu);
+        s_stage[x] = wv[u];
+        s_sbin[x] = (uint8_t)sub;
+      }
+    __syncthreads();
+    const uint32_t total = s_start[P2];
+    for (uint32_t x = threadIdx.x; x < total; x += L2_BLOCK) {
+      const uint32_t sub = s_sbin[x];
+      buf_b[s_gbase[sub] + (x - s_start[sub])] = s_stage[x];
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void k_tmp_start(const uint64_t* const* __restrict__ seg_bs, int nseg, uint32_t P,
                                                     uint64_t* __restrict__ tmp_start) {
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,6 +610,33 @@ void bin_scatter(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int 
   else
     hipLaunchKernelGGL(k_bin_scatter<false>, dim3(grid), dim3(P2_BLOCK), lds, c->stream, rv, lut, ntab, k, cfg, P,
                        pos_lo, pos_hi, rel, bin_start, inst);
+}
+
+int p1_bins() { return P1_BINS; }
+
+void coarse_counts(rfx_ctx* c, const uint32_t* cnt, uint32_t G, uint32_t P, uint32_t P2, uint32_t* cnt1) {
+  const uint32_t n = G * (P / P2);
+  hipLaunchKernelGGL(k_coarse_counts, dim3((n + 255) / 256), dim3(256), 0, c->stream, cnt, G, P, P2, cnt1);
+}
+
+void part1(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int ntab, int k, int canonical,
+           const rfx_ord_cfg& cfg, uint32_t P2, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel1,
+           const uint64_t* fine_start, uint64_t* buf_a) {
+  rfx_span sp(c, "k_part1");
+  if (canonical)
+    hipLaunchKernelGGL(k_part1<true>, dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, lut, ntab, k, cfg, P2, pos_lo,
+                       pos_hi, rel1, fine_start, buf_a);
+  else
+    hipLaunchKernelGGL(k_part1<false>, dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, lut, ntab, k, cfg, P2, pos_lo,
+                       pos_hi, rel1, fine_start, buf_a);
+}
+
+void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur,
+           uint32_t P, uint32_t P2, const rfx_ord_cfg& cfg) {
+  rfx_span sp(c, "k_part2");
+  const uint32_t W = 16;
+  hipLaunchKernelGGL(k_part2, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start, fine_cur, P2,
+                     cfg.bin_shift, W);
 }
 
 void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out) {

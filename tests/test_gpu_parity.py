@@ -151,6 +151,32 @@ def test_p2l_dense_bins_split_into_rounds_and_many_blocks(ctx):
         x.free()
 
 
+@pytest.mark.parametrize("bins", ["2048", "8192"])
+def test_two_level_partition_matches_oracle(ctx, small_trio, bins, monkeypatch):
+    """>= 2048 bins switches the P2L path to its two-level partition (coarse bins through LDS-staged
+    runs, then fine bins); force it on a small input and compare bit for bit, k=25 and k=31."""
+    monkeypatch.setenv("RFX_P2L_BINS", bins)
+    fq = [fastq_bytes(small_trio["father"], m) for m in (1, 2)]
+    for k, size, lower in ((25, 8 << 30, 2), (31, 1 << 20, 1)):
+        jf = tools.jellyfish_count(ctx, fq, k, size, lower=lower, mode=capi.COUNT_P2L)
+        assert_same_records(jf, oracle.count(fq, k, size, lower=lower))
+        jf.records.free()
+    # ragged reads (lengths 0..400) and a pos-range pass through the same kernels
+    rng = np.random.default_rng(5)
+    seqs = [bytes(np.frombuffer(b"ACGTN", np.uint8)[rng.choice(5, int(n), p=[.245, .245, .245, .245, .02])])
+            for n in rng.integers(0, 400, 3000)]
+    t = capi.CountTable(ctx, 25, 1 << 27, mode=capi.COUNT_P2L, pos_lo=1 << 20, pos_hi=100 << 20)
+    blk = ctx.upload(capi.PackedReads.from_reads(seqs))
+    t.add(blk)
+    rec = t.finish(1)
+    ref = oracle.count(None, 25, 1 << 27, lower=1, reads=seqs)
+    sel = (ref.pos >= (1 << 20)) & (ref.pos < (100 << 20))
+    keys, counts, pos = rec.get()
+    assert np.array_equal(keys, ref.keys[sel]) and np.array_equal(counts, ref.counts[sel].astype(np.uint32))
+    for x in (rec, blk, t):
+        x.free()
+
+
 def test_key_range_passes_partition_the_output(ctx, small_trio):
     """pos-range passes (multi-pass / multi-GPU ownership): concatenating the slices in pos order
     reproduces the single-pass payload."""

@@ -1,0 +1,343 @@
+// Shared host-side plumbing of the drop-in executables (text parsing, .Jhash container, k-mer text).
+// All arithmetic of the hot path happens behind the C-ABI (include/rufus_hip.h); nothing here counts,
+// hashes or compares k-mers.
+#pragma once
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/rufus_hip.h"
+
+namespace rfxcli {
+
+[[noreturn]] inline void die(const std::string& msg) {
+  // jellyfish's err::die: message on stderr, non-zero exit (jf/include/jellyfish/err.hpp)
+  fprintf(stderr, "%s\n", msg.c_str());
+  exit(1);
+}
+
+inline rfx_ctx* open_ctx() {
+  const char* dev = getenv("RUFUS_GPU");
+  rfx_ctx* c = rfx_open(dev ? atoi(dev) : 0, 0);
+  if (!c) die(std::string("rufus_amd: no MI355X (gfx950) device: ") + rfx_last_error() + " -- there is no CPU fallback");
+  return c;
+}
+
+// Buffered line reader over a file descriptor; works on regular files and on named pipes.
+class LineReader {
+  int fd_ = -1;
+  std::vector<char> buf_;
+  size_t beg_ = 0, end_ = 0;
+  bool eof_ = false;
+
+  bool fill() {
+    if (eof_) return false;
+    if (beg_ > 0) {
+      memmove(buf_.data(), buf_.data() + beg_, end_ - beg_);
+      end_ -= beg_;
+      beg_ = 0;
+    }
+    if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
+    ssize_t n = ::read(fd_, buf_.data() + end_, buf_.size() - end_);
+    if (n <= 0) {
+      eof_ = true;
+      return false;
+    }
+    end_ += (size_t)n;
+    return true;
+  }
+
+ public:
+  explicit LineReader(size_t cap = 1 << 22) : buf_(cap) {}
+  bool open(const char* path) {
+    fd_ = strcmp(path, "stdin") == 0 || strcmp(path, "/dev/stdin") == 0 ? 0 : ::open(path, O_RDONLY);
+    return fd_ >= 0;
+  }
+  void attach(int fd) { fd_ = fd; }
+  ~LineReader() {
+    if (fd_ > 0) ::close(fd_);
+  }
+  // Next line without its '\n' (std::getline semantics: a final unterminated line is returned,
+  // an empty file returns false).  The view is valid until the next call.
+  bool getline(const char*& b, const char*& e) {
+    for (;;) {
+      char* nl = (char*)memchr(buf_.data() + beg_, '\n', end_ - beg_);
+      if (nl) {
+        b = buf_.data() + beg_;
+        e = nl;
+        beg_ = (size_t)(nl - buf_.data()) + 1;
+        return true;
+      }
+      if (!fill()) {
+        if (beg_ == end_) return false;
+        b = buf_.data() + beg_;
+        e = buf_.data() + end_;
+        beg_ = end_;
+        return true;
+      }
+    }
+  }
+  int peek() {  // next byte or -1
+    if (beg_ == end_ && !fill()) return -1;
+    return (unsigned char)buf_[beg_];
+  }
+};
+
+// A batch of reads as the packer wants them.
+struct ReadBatch {
+  std::string seq, qual;
+  std::vector<uint64_t> off{0};
+  void clear() {
+    seq.clear();
+    qual.clear();
+    off.assign(1, 0);
+  }
+  uint32_t n() const { return (uint32_t)(off.size() - 1); }
+  void add(const char* s, size_t ls, const char* q = nullptr, size_t lq = 0, bool want_qual = false) {
+    seq.append(s, ls);
+    if (want_qual) {  // a quality string shorter than its read reads as '\0' (bad) past its end
+      const size_t m = lq < ls ? lq : ls;
+      if (q) qual.append(q, m);
+      qual.append(ls - m, '\0');
+    }
+    off.push_back(seq.size());
+  }
+};
+
+struct PackedBatch {
+  std::vector<uint64_t> codes;
+  std::vector<uint32_t> acgt, good, word_off, len;
+  int pack(const ReadBatch& b, int flags, int min_q) {
+    const uint32_t n = b.n();
+    const uint64_t nw = rfx_pack_words(b.off.data(), n);
+    codes.assign(nw + 1, 0);
+    if (flags & RFX_PACK_COUNT) acgt.assign(nw + 1, 0);
+    if (flags & RFX_PACK_FILTER) good.assign(nw + 1, 0);
+    word_off.assign((size_t)n + 1, 0);
+    len.assign((size_t)n + 1, 0);
+    return rfx_pack_reads(b.seq.data(), (flags & RFX_PACK_FILTER) ? b.qual.data() : nullptr, b.off.data(), n, min_q, flags,
+                          codes.data(), (flags & RFX_PACK_COUNT) ? acgt.data() : nullptr,
+                          (flags & RFX_PACK_FILTER) ? good.data() : nullptr, word_off.data(), len.data());
+  }
+  rfx_reads* upload(rfx_ctx* c, uint32_t n, int flags) {
+    return rfx_reads_upload(c, codes.data(), (flags & RFX_PACK_COUNT) ? acgt.data() : nullptr,
+                            (flags & RFX_PACK_FILTER) ? good.data() : nullptr, word_off.data(), len.data(), n);
+  }
+};
+
+// Sequences of a FASTA/FASTQ stream the way jellyfish's parser sees them
+// (jf/include/jellyfish/mer_overlap_sequence_parser.hpp:124-251): type sniffed from the first byte,
+// multi-line records joined, as many quality characters skipped as there were sequence characters.
+// cb(seq, len) is called once per read.  Returns false on an unsupported / malformed file.
+template <typename F>
+bool parse_sequences(LineReader& in, F&& cb) {
+  const int first = in.peek();
+  if (first < 0) return true;  // empty file
+  const char *b, *e;
+  std::string seq;
+  if (first == '>') {
+    bool have = false;
+    while (in.getline(b, e)) {
+      if (b < e && *b == '>') {
+        if (have) cb(seq.data(), seq.size());
+        seq.clear();
+        have = true;
+      } else {
+        seq.append(b, e);
+      }
+    }
+    if (have) cb(seq.data(), seq.size());
+    return true;
+  }
+  if (first != '@') return false;
+  while (in.getline(b, e)) {
+    if (b == e) continue;
+    if (*b != '@') return false;
+    seq.clear();
+    bool plus = false;
+    while (in.getline(b, e)) {
+      if (b < e && *b == '+') {
+        plus = true;
+        break;
+      }
+      seq.append(b, e);
+    }
+    size_t quals = 0;
+    while (plus && quals < seq.size() && in.getline(b, e)) quals += (size_t)(e - b);
+    if (quals != seq.size()) return false;
+    cb(seq.data(), seq.size());
+  }
+  return true;
+}
+
+// ---- k-mer text <-> key (jf/include/jellyfish/mer_dna.hpp: first base most significant) -----------
+inline std::string key_to_text(uint64_t key, int k) {
+  std::string s((size_t)k, 'A');
+  for (int i = 0; i < k; ++i) s[(size_t)i] = "ACGT"[(key >> (2 * (k - 1 - i))) & 3];
+  return s;
+}
+inline bool text_to_key(const char* s, size_t n, uint64_t& key) {
+  key = 0;
+  for (size_t i = 0; i < n; ++i) {
+    uint64_t c;
+    switch (s[i]) {
+      case 'A': case 'a': c = 0; break;
+      case 'C': case 'c': c = 1; break;
+      case 'G': case 'g': c = 2; break;
+      case 'T': case 't': c = 3; break;
+      default: return false;
+    }
+    key = (key << 2) | c;
+  }
+  return true;
+}
+inline uint64_t revcomp_key(uint64_t key, int k) {
+  uint64_t r = 0;
+  for (int i = 0; i < k; ++i) {
+    r = (r << 2) | (3 - (key & 3));
+    key >>= 2;
+  }
+  return r;
+}
+
+// ---- .Jhash container ----------------------------------------------------------------------------
+struct JhashHeader {
+  int k = 0, lsize = 0, counter_len = 4;
+  bool canonical = false;
+  std::string format;
+  std::vector<uint64_t> cols;
+  size_t payload_offset = 0;
+};
+
+// Just enough JSON for the terse header jellyfish writes (Json::FastWriter) and the one we write.
+inline bool json_find(const std::string& js, const std::string& key, size_t& pos) {
+  const std::string pat = "\"" + key + "\"";
+  size_t p = 0;
+  while ((p = js.find(pat, p)) != std::string::npos) {
+    size_t q = p + pat.size();
+    while (q < js.size() && (js[q] == ' ' || js[q] == '\t' || js[q] == '\n')) ++q;
+    if (q < js.size() && js[q] == ':') {
+      pos = q + 1;
+      while (pos < js.size() && (js[pos] == ' ' || js[pos] == '\n')) ++pos;
+      return true;
+    }
+    p = q;
+  }
+  return false;
+}
+inline bool json_u64(const std::string& js, const std::string& key, uint64_t& v) {
+  size_t p;
+  if (!json_find(js, key, p)) return false;
+  char* end;
+  v = strtoull(js.c_str() + p, &end, 10);
+  return end != js.c_str() + p;
+}
+
+inline bool read_jhash(const char* path, JhashHeader& h, std::vector<char>& payload) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  char digits[10] = {0};
+  if (fread(digits, 1, 9, f) != 9) { fclose(f); return false; }
+  for (int i = 0; i < 9; ++i)
+    if (digits[i] < '0' || digits[i] > '9') { fclose(f); return false; }
+  const size_t hlen = (size_t)atol(digits);
+  std::string js(hlen, '\0');
+  if (hlen < 2 || fread(&js[0], 1, hlen, f) != hlen || js[0] != '{') { fclose(f); return false; }
+  while (!js.empty() && js.back() == '\0') js.pop_back();
+  uint64_t key_len = 0, size = 0, clen = 4;
+  if (!json_u64(js, "key_len", key_len) || !json_u64(js, "size", size)) { fclose(f); return false; }
+  json_u64(js, "counter_len", clen);
+  h.k = (int)(key_len / 2);
+  h.lsize = 0;
+  while ((1ull << h.lsize) < size) ++h.lsize;
+  h.counter_len = (int)clen;
+  size_t p;
+  h.canonical = json_find(js, "canonical", p) && js.compare(p, 4, "true") == 0;
+  if (json_find(js, "format", p) && js[p] == '"') h.format = js.substr(p + 1, js.find('"', p + 1) - p - 1);
+  h.cols.clear();
+  size_t m;
+  if (json_find(js, "matrix1", m)) {
+    const std::string sub = js.substr(m);
+    size_t cp;
+    if (json_find(sub, "columns", cp) && sub[cp] == '[') {
+      const char* s = sub.c_str() + cp + 1;
+      while (*s && *s != ']') {
+        char* end;
+        const uint64_t v = strtoull(s, &end, 10);
+        if (end == s) break;
+        h.cols.push_back(v);
+        s = end;
+        while (*s == ',' || *s == ' ') ++s;
+      }
+    }
+  }
+  if ((int)h.cols.size() != 2 * h.k) { fclose(f); return false; }
+  h.payload_offset = 9 + hlen;
+  payload.clear();
+  char buf[1 << 16];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) payload.insert(payload.end(), buf, buf + n);
+  fclose(f);
+  return true;
+}
+
+inline rfx_records* load_records(rfx_ctx* c, const char* path, JhashHeader& h) {
+  std::vector<char> payload;
+  if (!read_jhash(path, h, payload)) die(std::string("Failed to parse header of file '") + path + "'");
+  if (h.format != "binary/sorted") die("Unknown format '" + h.format + "'");
+  const size_t rl = (size_t)(2 * h.k + 7) / 8 + (size_t)h.counter_len;
+  if (payload.size() % rl != 0)
+    die("Size of database (" + std::to_string(payload.size()) + ") must be a multiple of the length of a record (" +
+        std::to_string(rl) + ")");
+  rfx_records* r = rfx_records_load(c, h.k, h.lsize, h.cols.data(), payload.data(), payload.size() / rl, h.counter_len);
+  if (!r) die(std::string("rufus_amd: cannot load '") + path + "': " + rfx_last_error());
+  return r;
+}
+
+inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols, bool canonical, int counter_len,
+                        int argc, char** argv) {
+  const int k = rfx_records_k(rec), lsize = rfx_records_lsize(rec);
+  std::vector<char> hdr(1 << 16);
+  const long hl = rfx_jhash_header(k, lsize, cols, canonical, counter_len, argc, argv, hdr.data(), hdr.size());
+  if (hl < 0) die("rufus_amd: header too large");
+  const uint64_t n = rfx_records_size(rec);
+  const size_t bytes = (size_t)n * ((size_t)(2 * k + 7) / 8 + (size_t)counter_len);
+  std::vector<char> payload(bytes ? bytes : 1);
+  if (rfx_records_payload(rec, payload.data(), bytes, counter_len) != RFX_OK)
+    die(std::string("rufus_amd: drain failed: ") + rfx_last_error());
+  FILE* f = fopen(path, "wb");
+  if (!f) die(std::string("Can't open output file '") + path + "'");
+  fwrite(hdr.data(), 1, (size_t)hl, f);
+  fwrite(payload.data(), 1, bytes, f);
+  fclose(f);
+}
+
+// yaggo's SI suffixes (jf/sub_commands/count_main_cmdline.hpp:104-109): k M G T P E are powers of 1000.
+inline bool parse_si(const char* s, uint64_t& v) {
+  char* end;
+  const unsigned long long x = strtoull(s, &end, 10);
+  if (end == s) return false;
+  uint64_t mul = 1;
+  switch (*end) {
+    case 0: break;
+    case 'k': mul = 1000ull; ++end; break;
+    case 'M': mul = 1000000ull; ++end; break;
+    case 'G': mul = 1000000000ull; ++end; break;
+    case 'T': mul = 1000000000000ull; ++end; break;
+    case 'P': mul = 1000000000000000ull; ++end; break;
+    case 'E': mul = 1000000000000000000ull; ++end; break;
+    default: return false;
+  }
+  if (*end) return false;
+  v = x * mul;
+  return true;
+}
+
+}  // namespace rfxcli

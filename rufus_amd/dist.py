@@ -114,24 +114,34 @@ def owner_bounds(lsize: int, world: int):
     return [(g << lsize) // world for g in range(world + 1)]
 
 
+def _wire(t: torch.Tensor, group) -> torch.Tensor:
+    """Tensor as the collective backend wants it: gloo moves host memory (used by the tests, which can
+    put two ranks on one GPU), nccl/RCCL moves HBM directly over xGMI."""
+    return t.cpu() if dist.get_backend(group) == "gloo" and t.is_cuda else t
+
+
 def exchange_partials(keys: torch.Tensor, counts: torch.Tensor, pos: torch.Tensor, lsize: int, group):
     """Send each (pos-sorted) partial to the owner of its pos; returns what this rank received."""
     world = dist.get_world_size(group)
+    dev = keys.device
     bounds = torch.tensor(owner_bounds(lsize, world), dtype=torch.int64, device=pos.device)
     cuts = torch.searchsorted(pos, bounds)                 # partials are pos-sorted: contiguous runs
-    send = (cuts[1:] - cuts[:-1]).to(torch.int64)
+    send = _wire((cuts[1:] - cuts[:-1]).to(torch.int64), group)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
     send_l, recv_l = send.tolist(), recv.tolist()
-    rk = torch.empty(sum(recv_l), dtype=keys.dtype, device=keys.device)
-    rc = torch.empty(sum(recv_l), dtype=counts.dtype, device=counts.device)
-    dist.all_to_all_single(rk, keys, recv_l, send_l, group=group)
-    dist.all_to_all_single(rc, counts, recv_l, send_l, group=group)
-    return rk, rc
+    wk, wc = _wire(keys, group), _wire(counts, group)
+    rk = torch.empty(sum(recv_l), dtype=keys.dtype, device=wk.device)
+    rc = torch.empty(sum(recv_l), dtype=counts.dtype, device=wc.device)
+    dist.all_to_all_single(rk, wk, recv_l, send_l, group=group)
+    dist.all_to_all_single(rc, wc, recv_l, send_l, group=group)
+    return rk.to(dev), rc.to(dev)
 
 
 def all_gather_keys(keys: np.ndarray, device, group) -> np.ndarray:
     world = dist.get_world_size(group)
+    if dist.get_backend(group) == "gloo":
+        device = torch.device("cpu")
     n = torch.tensor([len(keys)], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
@@ -164,7 +174,7 @@ class TrioShard:
         rk, rc = exchange_partials(keys, counts, pos, self.lsize, self.group)
         b = owner_bounds(self.lsize, self.world)
         rec, histo = self.be.reduce_partials(rk, rc, self.lower, b[self.rank], b[self.rank + 1])
-        h = torch.from_numpy(histo.astype(np.int64)).to(keys.device)
+        h = _wire(torch.from_numpy(histo.astype(np.int64)).to(keys.device), self.group)
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
         return rec, h.cpu().numpy().astype(np.uint64)
 
@@ -177,7 +187,7 @@ class TrioShard:
         keys, counts = self.be.unique(recs[0], recs[1:], self.min_cov, self.max_cov)
         n_rec = [self.be.n_records(r) for r in recs]
         if self.world > 1:
-            dev = self.be.device
+            dev = torch.device("cpu") if dist.get_backend(self.group) == "gloo" else self.be.device
             keys = all_gather_keys(keys, dev, self.group)
             t = torch.tensor(n_rec, dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
@@ -185,7 +195,8 @@ class TrioShard:
         pulled = self.be.filter_pairs(keys, subject_block, self.thresh)
         n_pulled = int(pulled.sum())
         if self.world > 1:
-            t = torch.tensor([n_pulled], dtype=torch.int64, device=self.be.device)
+            t = torch.tensor([n_pulled], dtype=torch.int64,
+                             device="cpu" if dist.get_backend(self.group) == "gloo" else self.be.device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             n_pulled = int(t.item())
         out = {"n_mutant": len(keys), "n_pulled": n_pulled, "n_records": n_rec, "histos": histos,

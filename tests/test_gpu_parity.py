@@ -401,3 +401,68 @@ def test_s1_full_size_properties(ctx):
     jf.records.free()
     for f in files.values():
         f.records.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-GPU path on the real HIP backend: two ranks share the one GPU, exchange over gloo
+# ------------------------------------------------------------------------------------------------
+def _dist_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from rufus_amd import dist as rdist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.synth import flat_reads
+        c = capi.Context(0)
+        trio = make_trio(genome_len=40_000, n_pairs=3000, n_snv=5, seed=8, read_seed=50 + rank)
+        blocks = {}
+        for n in ("child", "mother", "father"):
+            seq, qual, off = flat_reads(trio[n])
+            blocks[n] = c.upload(capi.PackedReads(seq, off, qual, 15, capi.PACK_COUNT | capi.PACK_FILTER))
+        shard = rdist.TrioShard(c, 25, 8 << 30, 2, 5, 1200, 1, group=dist.group.WORLD)
+        res = shard.run(blocks["child"], [blocks["mother"], blocks["father"]], keep_records=True)
+        q.put((rank, [r.payload() for r in res["records"]], [h.tolist() for h in res["histos"]],
+               res["mutant_keys"].tolist(), res["pulled"].tolist(), res["n_pulled"]))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_exchange_on_the_hip_backend():
+    import socket
+    import torch.multiprocessing as mp
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_dist_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    parts = [make_trio(genome_len=40_000, n_pairs=3000, n_snv=5, seed=8, read_seed=50 + r) for r in range(world)]
+    recs = []
+    for n in ("child", "mother", "father"):
+        reads = [x.tobytes() for t in parts for m in (0, 1) for x in t[n].s[m]]
+        recs.append(oracle.count(None, 25, 8 << 30, lower=2, reads=reads))
+    for i in range(3):
+        assert b"".join(g[1][i] for g in got) == recs[i].payload()       # owner slices concatenate to the file
+        assert got[0][2][i] == got[1][2][i] == oracle.histo(recs[i].counts, full=True)[0].tolist()
+    hl = oracle.hash_list(recs[0], recs[1:], 5, 1200)
+    want_keys = [oracle.jf_encode(ln.split()[0]) for ln in hl.splitlines()]
+    assert got[0][3] == got[1][3] == want_keys and want_keys
+    fs = oracle.FilterSet(hl.encode())
+    tot = 0
+    for r in range(world):
+        c = parts[r]["child"]
+        from tests.synth import fastq_bytes as fqb
+        want = np.zeros(len(c), bool)
+        want[fs.pairs(fqb(c, 1), fqb(c, 2), 25, 15, 1)] = True
+        assert got[r][4] == want.tolist()
+        tot += int(want.sum())
+    assert got[0][5] == got[1][5] == tot and tot > 0

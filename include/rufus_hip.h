@@ -194,6 +194,29 @@ void rfx_set_free(rfx_set*);
 int rfx_filter(rfx_set*, const rfx_reads*, int thresh, int last_base_skipped, uint32_t* hits_out,
                uint64_t* hitmask_out, uint64_t* n_hit_reads);
 
+/* ---------------------------------------------------------------------------------------------
+ * K6: overlap scoring of the greedy assemblers; K7: per-base mutant k-mer coverage of contigs
+ * ------------------------------------------------------------------------------------------- */
+/* Align3 of OverlapSam / Overlap / OverlapRegion (src/OverlapSam.cpp:33-241, src/Overlap.cpp:169-360,
+ * src/OverlapRegion.cpp:31-231) for ONE query `a` against `nb` candidates: every offset of the three
+ * alignment phases is scored on the device and reduced in the reference's loop order (first offset
+ * with the strictly greatest accepted score).  Per candidate j, out[5j..5j+4] =
+ *   { phase-1 best score, its overlap, perfect flag (score == window),
+ *     best score over all three phases (== phase 1 when perfect), its overlap };
+ * a score equal to RFX_OVL_NONE_* (the variant's initial LocalBestScore) means "nothing accepted".
+ * The caller applies the reference's cross-candidate rules (shared PerfectMatch, first-best wins).
+ * variant: RFX_OVL_SAM / RFX_OVL_REGION (LocalBestScore starts at 0, '>=' in every phase) or
+ * RFX_OVL_CONTIG (Overlap.cpp: starts at -1, phase 3 accepts with a strict '>'). */
+#define RFX_OVL_SAM 0
+#define RFX_OVL_CONTIG 1
+#define RFX_OVL_REGION 2
+int rfx_overlap_score(rfx_ctx*, const char* a, int alen, const char* const* b, const int* blen, int nb, float min_pct,
+                      int min_ovl, int variant, int* out /* nb x 5 */);
+/* AnnotateOverlap (src/AnnotateOverlap.cpp:88-134): for each packed contig of the block (good mask =
+ * base != 'N' && qual-33 >= 3, i.e. RFX_PACK_FILTER with min_q 3) the number of mutant windows that
+ * cover every base; cov_out holds rfx_reads_bases() counters, contig after contig. */
+int rfx_annotate(rfx_set*, const rfx_reads*, uint32_t* cov_out);
+
 #ifdef __cplusplus
 }
 #endif

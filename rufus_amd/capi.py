@@ -76,6 +76,9 @@ SIGNATURES = {
     "rfx_set_size": (C.c_uint64, [C.c_void_p]),
     "rfx_set_free": (None, [C.c_void_p]),
     "rfx_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, u32p, u64p, u64p]),
+    "rfx_overlap_score": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
+                                    C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "rfx_annotate": (C.c_int, [C.c_void_p, C.c_void_p, u32p]),
 }
 
 
@@ -367,6 +370,20 @@ def unique_to_subject(ctx: Context, subject: Records, others, min_cov: int, max_
     return keys[:n.value].copy(), counts[:n.value].copy()
 
 
+OVL_SAM, OVL_CONTIG, OVL_REGION = 0, 1, 2
+
+
+def overlap_score(ctx: Context, a: bytes, cands, min_pct: float, min_ovl: int, variant: int = OVL_SAM) -> np.ndarray:
+    """rows of (phase-1 score, overlap, perfect, full score, overlap) per candidate."""
+    nb = len(cands)
+    arr = (C.c_char_p * max(nb, 1))(*cands)
+    lens = (C.c_int * max(nb, 1))(*[len(x) for x in cands])
+    out = np.zeros((max(nb, 1), 5), dtype=np.int32)
+    _check(lib().rfx_overlap_score(ctx._h, a, len(a), arr, lens, nb, min_pct, min_ovl, variant,
+                                   out.ctypes.data_as(C.POINTER(C.c_int))), "rfx_overlap_score")
+    return out[:nb]
+
+
 class MutantSet:
     def __init__(self, ctx: Context, fwd_keys: np.ndarray, k: int):
         fwd_keys = np.ascontiguousarray(fwd_keys, dtype=np.uint64)
@@ -383,6 +400,11 @@ class MutantSet:
         _check(lib().rfx_filter(self._h, reads._h, thresh, int(last_base_skipped), _p(hits, u32p), _p(mask, u64p),
                                 C.byref(n)), "rfx_filter")
         return (hits[:reads.n] if want_hits else None), mask, n.value
+
+    def annotate(self, reads: ReadBlock) -> np.ndarray:
+        cov = np.zeros(max(reads.bases, 1), dtype=np.uint32)
+        _check(lib().rfx_annotate(self._h, reads._h, _p(cov, u32p)), "rfx_annotate")
+        return cov[:reads.bases]
 
     def free(self):
         if self._h:

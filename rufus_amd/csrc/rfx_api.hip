@@ -1143,4 +1143,65 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_filter");
 }
 
+// ---------------------------------------------------------------------------------------------
+int rfx_overlap_score(rfx_ctx* c, const char* a, int alen, const char* const* b, const int* blen, int nb,
+                      float min_pct, int min_ovl, int variant, int* out) {
+  if (!c || !a || alen < 0 || nb < 0 || (nb && (!b || !blen || !out))) return RFX_E_INVAL;
+  (void)hipSetDevice(c->device);
+  if (nb == 0) return RFX_OK;
+  std::vector<uint32_t> off((size_t)nb + 1, 0);
+  int max_blen = 0;
+  for (int j = 0; j < nb; ++j) {
+    if (blen[j] < 0) return RFX_E_INVAL;
+    off[(size_t)j + 1] = off[(size_t)j] + (uint32_t)blen[j];
+    max_blen = std::max(max_blen, blen[j]);
+  }
+  if ((size_t)alen + (size_t)max_blen + 16 > 150 * 1024) return RFX_E_RANGE;  // both strings live in LDS
+  std::string cat;
+  cat.reserve(off[(size_t)nb]);
+  for (int j = 0; j < nb; ++j) cat.append(b[j], (size_t)blen[j]);
+  char* d_a = (char*)dmalloc(c, (size_t)alen + 1);
+  char* d_b = (char*)dmalloc(c, cat.size() + 1);
+  uint32_t* d_off = (uint32_t*)dmalloc(c, off.size() * 4);
+  int* d_out = (int*)dmalloc(c, (size_t)nb * 5 * sizeof(int));
+  auto cleanup = [&] { dfree(c, d_a); dfree(c, d_b); dfree(c, d_off); dfree(c, d_out); };
+  if (!d_a || !d_b || !d_off || !d_out) { cleanup(); return RFX_E_NOMEM; }
+  hipError_t e = hipMemcpyAsync(d_a, a, (size_t)alen, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess && !cat.empty()) e = hipMemcpyAsync(d_b, cat.data(), cat.size(), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) {
+    rfxk::overlap_score(c, d_a, alen, d_b, d_off, nb, max_blen, min_pct, min_ovl, variant == RFX_OVL_CONTIG,
+                        variant == RFX_OVL_CONTIG ? -1 : 0, d_out);
+    e = hipMemcpyAsync(out, d_out, (size_t)nb * 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  cleanup();
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_overlap_score");
+}
+
+int rfx_annotate(rfx_set* s, const rfx_reads* r, uint32_t* cov_out) {
+  if (!s || !r || s->ctx != r->ctx || !r->good || !cov_out) return RFX_E_INVAL;
+  rfx_ctx* c = s->ctx;
+  (void)hipSetDevice(c->device);
+  if (r->n == 0 || r->n_bases == 0) return RFX_OK;
+  std::vector<uint32_t> len(r->n);
+  hipError_t e = hipMemcpy(len.data(), r->len, (size_t)r->n * 4, hipMemcpyDeviceToHost);
+  std::vector<uint64_t> off((size_t)r->n + 1, 0);
+  for (uint32_t i = 0; i < r->n; ++i) off[(size_t)i + 1] = off[i] + len[i];
+  uint64_t* d_off = (uint64_t*)dmalloc(c, off.size() * 8);
+  uint32_t* d_cov = (uint32_t*)dmalloc(c, r->n_bases * 4);
+  if (!d_off || !d_cov) { dfree(c, d_off); dfree(c, d_cov); return RFX_E_NOMEM; }
+  if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(d_cov, 0, r->n_bases * 4, c->stream);
+  if (e == hipSuccess) {
+    rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+    rfxk::annotate(c, rv, s->slots, s->bits, s->has_all_ones, s->k, d_off, d_cov);
+    e = hipMemcpyAsync(cov_out, d_cov, r->n_bases * 4, hipMemcpyDeviceToHost, c->stream);
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  dfree(c, d_off);
+  dfree(c, d_cov);
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_annotate");
+}
+
 }  // extern "C"

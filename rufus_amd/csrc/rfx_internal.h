@@ -190,6 +190,10 @@ void set_bitmap(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm, int bm
 void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
             int bm_bits, int bm_shift, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
             unsigned long long* d_nhit);
+void overlap_score(rfx_ctx*, const char* d_a, int alen, const char* d_bcat, const uint32_t* d_boff, int nb, int max_blen,
+                   float min_pct, int min_ovl, int strict3, int local_init, int* d_out /* nb x 5 */);
+void annotate(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, int k,
+              const uint64_t* base_off, uint32_t* cov);
 int p2l_grid(rfx_ctx*, uint32_t n_reads);
 void bin_count(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical,
                const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, uint32_t* cnt);

@@ -15,9 +15,10 @@ for a, b in zip(b"ACGTN", b"TGCAN"):
 class Sample:
     """Mate matrices: seq/qual are uint8 arrays of shape (n_pairs, L) per mate."""
 
-    def __init__(self, name, s1, q1, s2, q2):
+    def __init__(self, name, s1, q1, s2, q2, pos1=None, pos2=None):
         self.name, self.s = name, (s1, s2)
         self.q = (q1, q2)
+        self.pos = (pos1, pos2)    # 0-based leftmost genome coordinate of each mate
 
     def __len__(self):
         return self.s[0].shape[0]
@@ -47,7 +48,7 @@ def _reads_from(genome: np.ndarray, alt: np.ndarray | None, n_pairs: int, L: int
         q = np.full(s.shape, ord("J"), dtype=np.uint8)
         q[rng.random(s.shape) < lowq] = ord("#")
         out.append((s, q))
-    return out[0][0], out[0][1], out[1][0], out[1][1]
+    return out[0][0], out[0][1], out[1][0], out[1][1], start, start + insert - L
 
 
 def make_trio(genome_len=5_000_000, n_pairs=500_000, n_snv=20, seed=12345, L=150, err=0.005, lowq=0.02,

@@ -1,0 +1,157 @@
+"""GPU: the assembly chain against the REAL reference binaries under
+oracle/_ref run with Threads = 1: OverlapSam -> ReplaceQwithDinFASTQD -> ConvertFASTqD.to.FASTQ ->
+AnnotateOverlap, byte-identical files; plus the scoring kernel against a direct restatement."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from rufus_amd import capi
+from tests.conftest import ROOT
+from tests.synth import make_trio
+
+pytestmark = pytest.mark.gpu
+BIN = os.path.join(ROOT, "rufus_amd", "bin")
+REF = os.path.join(ROOT, "oracle", "_ref")
+needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "OverlapSam")), reason="oracle/_ref not built")
+
+
+def align3_one(a: bytes, b: bytes, min_pct: float, min_ovl: int, strict3: bool, init: int):
+    """Per-candidate body of Align3 (src/OverlapSam.cpp:47-229 / src/Overlap.cpp:176-340), float32 as the
+    reference: returns (p1 score, p1 overlap, perfect, full score, full overlap)."""
+    f = np.float32
+    al, bl = len(a), len(b)
+    asm = not (bl > al)
+    window, longest = (bl, al) if asm else (al, bl)
+    mm = int(f(window) - f(window) * f(min_pct))
+    best, ovl, perfect = init, 0, False
+    ac = bc = 0
+    for i in range(longest - window + 1):
+        score = f(0)
+        for k in range(window):
+            if a[k + ac] == b[k + bc] and b[k + bc] != ord("N"):
+                score += f(1)
+            if f(k) - score > mm:
+                score = f(-1)
+                break
+        if asm:
+            ac += 1
+        else:
+            bc += 1
+        if window and f(score / f(window)) >= f(min_pct):
+            if best < score:
+                best, ovl = int(score), (-i if asm else i)
+            if score == window:
+                perfect = True
+                break
+    p1 = (best, ovl, perfect)
+    if not perfect:
+        for phase in (2, 3):
+            for i in range(window - 1, min_ovl - 1, -1):
+                score, k = f(0), 0
+                for k in range(i + 1):
+                    x, y = (a[al - i + k - 1], b[k]) if phase == 2 else (b[bl - i + k - 1], a[k])
+                    if x == y and y != ord("N"):
+                        score += f(1)
+                    if f(k) - score > mm:
+                        score = f(-1)
+                        break
+                else:
+                    k = i + 1
+                pct = f(score / f(k)) if k else f(0)
+                ok = pct > f(min_pct) if (phase == 3 and strict3) else pct >= f(min_pct)
+                if ok and best < score:
+                    best, ovl = int(score), (i - al + 1 if phase == 2 else bl - i - 1)
+                    if score == i:
+                        break
+    return p1[0], p1[1], int(p1[2]), best, ovl
+
+
+def test_overlap_score_kernel_matches_restatement(ctx):
+    rng = np.random.default_rng(17)
+    base = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 600)].tobytes()
+
+    def mutate(s, n_sub, n_n):
+        s = bytearray(s)
+        for p in rng.integers(0, len(s), n_sub):
+            s[p] = b"ACGT"[int(rng.integers(0, 4))]
+        for p in rng.integers(0, len(s), n_n):
+            s[p] = ord("N")
+        return bytes(s)
+
+    a = base[100:250]
+    cands = [base[100:250], base[130:280], base[60:210], mutate(base[120:270], 3, 2), mutate(base[90:240], 12, 0),
+             base[150:200], base[50:400], b"moved", b"", mutate(base[245:395], 1, 1), base[300:450], a[:149],
+             mutate(base[100:250], 2, 0), b"N" * 150, base[101:251]]
+    for variant, strict3, init, pct, movl in ((capi.OVL_SAM, False, 0, 0.95, 20), (capi.OVL_CONTIG, True, -1, 0.98, 50),
+                                              (capi.OVL_REGION, False, 0, 0.98, 50), (capi.OVL_CONTIG, True, -1, 0.9, 5)):
+        got = capi.overlap_score(ctx, a, cands, pct, movl, variant)
+        for j, b in enumerate(cands):
+            want = align3_one(a, b, pct, movl, strict3, init)
+            assert tuple(int(x) for x in got[j]) == want, (variant, j, got[j], want)
+
+
+def fabricate_sam(seed=31):
+    """Position-sorted SAM (flags 99/147 + a few unmapped, duplicate-flagged, short and low-quality records)
+    of the child read pairs that carry a mutant k-mer, as bwa + samtools sort would hand them over."""
+    trio = make_trio(genome_len=30_000, n_pairs=4000, n_snv=3, seed=seed)
+    k = 25
+    reads = {n: [r.tobytes() for m in (0, 1) for r in trio[n].s[m]] for n in ("child", "mother", "father")}
+    recs = {n: oracle.count(None, k, 1 << 27, lower=2, reads=reads[n]) for n in reads}
+    hl = oracle.hash_list(recs["child"], [recs["mother"], recs["father"]], 5, 1200)
+    fs = oracle.FilterSet(hl.encode())
+    c = trio["child"]
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    rows = []
+    rng = np.random.default_rng(seed)
+    for i in range(len(c)):
+        s1, q1, s2, q2 = c.s[0][i].tobytes(), c.q[0][i].tobytes(), c.s[1][i].tobytes(), c.q[1][i].tobytes()
+        if fs.scan(s1, q1, k, 15) < 1 and fs.scan(s2, q2, k, 15) < 1:
+            continue
+        name = f"c{i}"
+        rows.append((int(c.pos[0][i]), name, 99, s1, q1))
+        rows.append((int(c.pos[1][i]), name, 147, s2.translate(comp)[::-1], q2[::-1]))
+        if rng.random() < 0.1:
+            rows.append((int(c.pos[0][i]) + 1, name + "u", 77, s1, q1))                 # unmapped
+        if rng.random() < 0.05:
+            rows.append((int(c.pos[0][i]) + 2, name + "d", 1024 + 99, s1, q1))          # duplicate: rejected
+        if rng.random() < 0.05:
+            rows.append((int(c.pos[0][i]) + 3, name + "s", 0, s1[:40], q1[:40]))        # too short: rejected
+        if rng.random() < 0.05:
+            rows.append((int(c.pos[0][i]) + 4, name + "q", 16, s1, b"#" * 70 + q1[70:]))  # > 33 % low quality
+    rows.sort(key=lambda r: r[0])
+    sam = b"".join(b"\t".join([n.encode(), str(f).encode(), b"chr1", str(p + 1).encode(), b"60", b"150M", b"=",
+                               b"1", b"0", s, q, b"NM:i:0"]) + b"\n" for p, n, f, s, q in rows)
+    return sam, hl, len(rows)
+
+
+@needs_ref
+@pytest.mark.parametrize("mincov", ["1", "2"])
+def test_overlapsam_and_tail_match_reference(tmp_path, mincov):
+    sam, hl, n = fabricate_sam()
+    assert n > 60
+    d = str(tmp_path)
+    open(f"{d}/in.sam", "wb").write(sam)
+    open(f"{d}/hl", "w").write(hl)
+
+    def run(exe, args, stdout=None):
+        r = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode in (0,), (exe, r.stderr[-500:])
+        if stdout:
+            open(f"{d}/{stdout}", "wb").write(r.stdout)
+        return r
+
+    for tag, where in (("ours", BIN), ("ref", REF)):
+        run(f"{where}/OverlapSam", ["in.sam", ".95", "20", mincov, f"{tag}.sam", "N", "1", "hl", "1"])
+        run(f"{where}/ReplaceQwithDinFASTQD", [f"{tag}.sam.fastqd"], f"{tag}.overlap.fastqd")
+        run(f"{where}/ConvertFASTqD.to.FASTQ", [f"{tag}.overlap.fastqd"], f"{tag}.overlap.fastq")
+        run(f"{where}/AnnotateOverlap", ["hl", f"{tag}.overlap.fastq", f"{tag}.hash.fastq"], f"{tag}.hashcount.fastq")
+    for f in ("sam.fastq", "sam.fastqd", "overlap.fastqd", "overlap.fastq", "hashcount.fastq", "hash.fastq"):
+        a, b = open(f"{d}/ours.{f}", "rb").read(), open(f"{d}/ref.{f}", "rb").read()
+        assert a == b, f
+        assert len(a) > 500, f
+    # the contigs carry mutant k-mer coverage: some quality characters above '!'
+    q = open(f"{d}/ours.hashcount.fastq", "rb").read().split(b"\n")[3::4]
+    assert any(max(x) > 33 for x in q if x)

@@ -155,3 +155,39 @@ def test_overlapsam_and_tail_match_reference(tmp_path, mincov):
     # the contigs carry mutant k-mer coverage: some quality characters above '!'
     q = open(f"{d}/ours.hashcount.fastq", "rb").read().split(b"\n")[3::4]
     assert any(max(x) > 33 for x in q if x)
+
+
+@needs_ref
+def test_full_assembly_chain_matches_reference(tmp_path):
+    """scripts/Overlap.shorter.sh:127-194 with the reference's own arguments, every stage fed by the
+    previous stage of its own side (ours / reference), Threads = 1."""
+    sam, hl, n = fabricate_sam(seed=77)
+    d = str(tmp_path)
+    open(f"{d}/in.sam", "wb").write(sam)
+    open(f"{d}/hl", "w").write(hl)
+
+    def run(exe, args, stdout=None):
+        r = subprocess.run([exe] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, (exe, r.stderr[-500:])
+        if stdout:
+            open(f"{d}/{stdout}", "wb").write(r.stdout)
+
+    sizes = {}
+    for t, w in (("ours", BIN), ("ref", REF)):
+        run(f"{w}/OverlapSam", ["in.sam", ".95", "20", "1", f"{t}.sam", "NS", "1", "hl", "1"])
+        run(f"{w}/Overlap", [f"{t}.sam.fastqd", ".98", "100", "1", "FP", "20", "1", f"{t}.1", "0", "1"])
+        run(f"{w}/Overlap", [f"{t}.1.fastqd", ".98", "75", "2", "FP", "20", "1", f"{t}.2", "1", "1"])
+        run(f"{w}/Overlap", [f"{t}.2.fastqd", ".98", "50", "2", "NS", "20", "1", f"{t}.3", "1", "1"])
+        run(f"{w}/OverlapRegion", [f"{t}.3.fastqd", ".98", "50", "2", f"{t}.4", "NS", "1", "1"])
+        run(f"{w}/ReplaceQwithDinFASTQD", [f"{t}.4.fastqd"], f"{t}.overlap.fastqd")
+        run(f"{w}/ConvertFASTqD.to.FASTQ", [f"{t}.overlap.fastqd"], f"{t}.overlap.fastq")
+        run(f"{w}/AnnotateOverlap", ["hl", f"{t}.overlap.fastq", f"{t}.asm.hash.fastq"], f"{t}.hashcount.fastq")
+    stages = ["sam.fastqd", "1.fastqd", "1.fastq", "1.fastqgood.fastq", "1.fastqbad.fastq", "2.fastqd", "3.fastqd",
+              "4.fastqd", "4.fastq", "overlap.fastqd", "overlap.fastq", "hashcount.fastq", "asm.hash.fastq"]
+    for f in stages:
+        a, b = open(f"{d}/ours.{f}", "rb").read(), open(f"{d}/ref.{f}", "rb").read()
+        sizes[f] = a.count(b"\n")
+        assert a == b, (f, sizes)
+    # the chain really assembles: node counts shrink stage by stage and something comes out
+    nodes = [sizes[f] // 6 for f in ("sam.fastqd", "1.fastqd", "2.fastqd", "3.fastqd", "4.fastqd")]
+    assert nodes[0] > nodes[-1] >= 1, nodes

@@ -100,6 +100,9 @@ int rfx_memcpy_dev(rfx_ctx*, void* d_dst, const void* d_src, size_t bytes);
 
 /* Per-kernel HIP-event timing on the ctx stream (used by bench.py for roofline.achieved). */
 int rfx_prof_enable(rfx_ctx*, int on);
+/* Restrict the brackets to a comma-separated list of kernel names (NULL or "" = every launch): an
+ * event pair per launch costs ~10 us of host time, which matters when a step is ~100 launches. */
+int rfx_prof_filter(rfx_ctx*, const char* kernel_names);
 int rfx_prof_reset(rfx_ctx*);
 int rfx_prof_query(rfx_ctx*, const char* kernel, double* total_ms, uint64_t* launches);
 int rfx_prof_names(rfx_ctx*, char* buf, size_t cap); /* '\n'-separated kernel names seen so far */

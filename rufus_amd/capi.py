@@ -41,6 +41,7 @@ SIGNATURES = {
     "rfx_stream": (C.c_void_p, [C.c_void_p]),
     "rfx_memcpy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rfx_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "rfx_prof_filter": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rfx_prof_reset": (C.c_int, [C.c_void_p]),
     "rfx_prof_query": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), u64p]),
     "rfx_prof_names": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
@@ -204,6 +205,9 @@ class Context:
 
     def prof(self, on: bool):
         _check(lib().rfx_prof_enable(self._h, int(on)), "rfx_prof_enable")
+
+    def prof_filter(self, names=()):
+        _check(lib().rfx_prof_filter(self._h, ",".join(names).encode()), "rfx_prof_filter")
 
     def prof_reset(self):
         _check(lib().rfx_prof_reset(self._h), "rfx_prof_reset")

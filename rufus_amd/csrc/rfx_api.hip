@@ -86,6 +86,44 @@ void dfree(rfx_ctx* c, void* p) {
   c->pool.emplace(bytes, p);
 }
 
+// ---- pinned scratch -------------------------------------------------------------------------------
+// Stream sync + delivery of the queued read-backs; every synchronisation of the API goes through here.
+hipError_t ctx_sync(rfx_ctx* c) {
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess)
+    for (auto& r : c->pin_reads) memcpy(r.dst, c->pin + r.off, r.n);
+  c->pin_reads.clear();
+  c->pin_used = 0;
+  return e;
+}
+
+// Device -> host copy that lands in `dst` at the next ctx_sync().
+hipError_t queue_read(rfx_ctx* c, void* dst, const void* d_src, size_t n) {
+  if (n == 0) return hipSuccess;
+  const size_t need = (n + 63) & ~(size_t)63;
+  if (c->pin && c->pin_used + need <= c->pin_cap) {
+    const size_t off = c->pin_used;
+    c->pin_used += need;
+    c->pin_reads.push_back({dst, off, n});
+    return hipMemcpyAsync(c->pin + off, d_src, n, hipMemcpyDeviceToHost, c->stream);
+  }
+  return hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, c->stream);
+}
+
+// Host -> device copy of a buffer the caller may free right away (staged in the pinned scratch when it fits).
+hipError_t upload(rfx_ctx* c, void* d_dst, const void* src, size_t n) {
+  if (n == 0) return hipSuccess;
+  const size_t need = (n + 63) & ~(size_t)63;
+  if (c->pin && c->pin_used + need <= c->pin_cap) {
+    char* stage = c->pin + c->pin_used;
+    c->pin_used += need;
+    memcpy(stage, src, n);
+    return hipMemcpyAsync(d_dst, stage, n, hipMemcpyHostToDevice, c->stream);
+  }
+  const hipError_t e = hipMemcpyAsync(d_dst, src, n, hipMemcpyHostToDevice, c->stream);
+  return e == hipSuccess ? ctx_sync(c) : e;  // pageable source: make it safe to free
+}
+
 int ceil_log2(uint64_t x) {
   int l = 0;
   while (l < 63 && (1ull << l) < x) ++l;
@@ -138,8 +176,8 @@ int alloc_table_arrays(rfx_ctx* c, uint64_t cap, uint64_t** keys, uint32_t** cou
 }
 
 int read_stats(rfx_table* t, rfx_table_stats* out) {
-  HIPCHK(hipMemcpyAsync(out, t->d_stats, sizeof(*out), hipMemcpyDeviceToHost, t->ctx->stream));
-  HIPCHK(hipStreamSynchronize(t->ctx->stream));
+  HIPCHK(queue_read(t->ctx, out, t->d_stats, sizeof(*out)));
+  HIPCHK(ctx_sync(t->ctx));
   return RFX_OK;
 }
 
@@ -158,7 +196,7 @@ int table_grow(rfx_table* t, uint64_t new_cap) {
   }
   HIPCHK(hipMemsetAsync(d_n, 0, 8, c->stream));
   rfxk::table_pairs(c, view_of(t), pk, pc, d_n);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(ctx_sync(c));
   dfree(c, t->keys);
   dfree(c, t->counts);
   t->keys = nullptr;
@@ -174,7 +212,7 @@ int table_grow(rfx_table* t, uint64_t new_cap) {
   // the pairs already passed the pos range; widen it for the re-insert
   rfx_table_view v = view_of(t);
   rfxk::count_pairs(c, pk, pc, st.distinct, v, t->lut, t->d_stats);
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(ctx_sync(c));
   dfree(c, pk); dfree(c, pc); dfree(c, d_n);
   return RFX_OK;
 }
@@ -286,7 +324,7 @@ const rfx_hash_consts* get_consts(rfx_ctx* c, int k, int lsize, const uint64_t* 
         hipMemcpyAsync(hc.lut_tinv, li.data(), li.size() * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess)
       hc.lut_t = hc.lut_tinv = nullptr;
   }
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return nullptr;  // host vectors die at return
+  if (ctx_sync(c) != hipSuccess) return nullptr;  // host vectors die at return
   return &(c->consts[key] = hc);
 }
 
@@ -336,13 +374,14 @@ int unique_run(rfx_ctx* c, const rfx_records* f, const rfx_records* const* all, 
   }
   rfxk::compact(c, flags, f->keys, f->counts, f->pos, f->n, ok, oc, op, boff, d_tot);
   unsigned long long tot = 0;
-  hipError_t e = hipMemcpyAsync(&tot, d_tot, 8, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipError_t e = queue_read(c, &tot, d_tot, 8);
+  if (e == hipSuccess) e = ctx_sync(c);
   if (e == hipSuccess && tot) {
     out.keys.resize(tot); out.pos.resize(tot); out.counts.resize(tot);
-    e = hipMemcpy(out.keys.data(), ok, tot * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(out.pos.data(), op, tot * 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(out.counts.data(), oc, tot * 4, hipMemcpyDeviceToHost);
+    e = queue_read(c, out.keys.data(), ok, tot * 8);
+    if (e == hipSuccess) e = queue_read(c, out.pos.data(), op, tot * 8);
+    if (e == hipSuccess) e = queue_read(c, out.counts.data(), oc, tot * 4);
+    if (e == hipSuccess) e = ctx_sync(c);
   }
   cleanup();
   return e == hipSuccess ? RFX_OK : hip_fail(e, "unique_run");
@@ -357,8 +396,8 @@ void resolve_spans(rfx_ctx* c) {
       a.ms += ms;
       a.launches += 1;
     }
-    hipEventDestroy(s.e0);
-    hipEventDestroy(s.e1);
+    c->free_events.push_back(s.e0);
+    c->free_events.push_back(s.e1);
   }
   c->spans.clear();
 }
@@ -392,23 +431,27 @@ rfx_ctx* rfx_open(int device, size_t hbm_budget_bytes) {
     delete c;
     return nullptr;
   }
+  if (hipHostMalloc((void**)&c->pin, 4u << 20, hipHostMallocDefault) == hipSuccess) c->pin_cap = 4u << 20;
+  else c->pin = nullptr;
   return c;
 }
 
 void rfx_close(rfx_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  ctx_sync(c);
   resolve_spans(c);
   for (auto& kv : c->allocs) (void)hipFree(kv.first);
   pool_release(c);
+  for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+  if (c->pin) (void)hipHostFree(c->pin);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
 
 int rfx_sync(rfx_ctx* c) {
   if (!c) return RFX_E_NODEVICE;
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(ctx_sync(c));
   return RFX_OK;
 }
 
@@ -418,13 +461,18 @@ int rfx_memcpy_dev(rfx_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
   if (!c || (bytes && (!d_dst || !d_src))) return RFX_E_INVAL;
   (void)hipSetDevice(c->device);
   if (bytes) HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
-  HIPCHK(hipStreamSynchronize(c->stream));
+  HIPCHK(ctx_sync(c));
   return RFX_OK;
 }
 
 int rfx_prof_enable(rfx_ctx* c, int on) {
   if (!c) return RFX_E_NODEVICE;
   c->prof = on != 0;
+  return RFX_OK;
+}
+int rfx_prof_filter(rfx_ctx* c, const char* names) {
+  if (!c) return RFX_E_NODEVICE;
+  c->prof_filter = (names && *names) ? std::string(",") + names + "," : std::string();
   return RFX_OK;
 }
 int rfx_prof_reset(rfx_ctx* c) {
@@ -480,7 +528,7 @@ rfx_reads* rfx_reads_upload(rfx_ctx* c, const uint64_t* codes, const uint32_t* a
     if (e == hipSuccess && n_reads) e = hipMemcpyAsync(r->len, len, (size_t)n_reads * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && acgt) e = hipMemcpyAsync(r->acgt, acgt, r->n_words * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && good) e = hipMemcpyAsync(r->good, good, r->n_words * 4, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess) e = ctx_sync(c);
     if (e != hipSuccess) {
       hip_fail(e, "rfx_reads_upload");
       ok = false;
@@ -617,10 +665,9 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
   }
   rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
   if (two_level) rfxk::bin_offsets(c, cnt1, (uint32_t)G, P1, gsum1, tot1);
-  uint64_t total = 0;
-  hipError_t e = hipMemcpyAsync(&total, bin_start + P, 8, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-  if (e != hipSuccess) { drop(); dfree(c, bin_start); return hip_fail(e, "p2l_add"); }
+  // No read-back: the number of instances is bounded by the number of windows, which the host
+  // knows; the exact per-bin extents stay on the device (bin_start) where the leaf reads them.
+  const uint64_t total = windows;
   if (total == 0) { drop(); dfree(c, bin_start); return RFX_OK; }
   uint64_t* inst = (uint64_t*)dmalloc(c, total * 8);
   if (!inst) { drop(); dfree(c, bin_start); return RFX_E_NOMEM; }
@@ -668,8 +715,8 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
     dfree(c, d_err);
   };
   if (!d_inst || !d_bs || !tmp_start || !n_surv || !tmp_keys || !tmp_counts || !d_err) { cleanup(); return nullptr; }
-  hipError_t e = hipMemcpyAsync(d_inst, h_inst.data(), nseg * sizeof(void*), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_bs, h_bs.data(), nseg * sizeof(void*), hipMemcpyHostToDevice, c->stream);
+  hipError_t e = upload(c, d_inst, h_inst.data(), nseg * sizeof(void*));
+  if (e == hipSuccess) e = upload(c, d_bs, h_bs.data(), nseg * sizeof(void*));
   if (e == hipSuccess) e = hipMemsetAsync(d_err, 0, 4, c->stream);
   if (e != hipSuccess) { hip_fail(e, "p2l_emit"); cleanup(); return nullptr; }
   rfxk::tmp_start(c, d_bs, nseg, P, tmp_start);
@@ -677,9 +724,9 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
   rfxk::scan_tail(c, n_surv, P);
   uint64_t total_out = 0;
   unsigned int err = 0;
-  e = hipMemcpyAsync(&total_out, n_surv + P, 8, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(&err, d_err, 4, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // h_inst / h_bs stay alive until here
+  e = queue_read(c, &total_out, n_surv + P, 8);
+  if (e == hipSuccess) e = queue_read(c, &err, d_err, 4);
+  if (e == hipSuccess) e = ctx_sync(c);  // h_inst / h_bs stay alive until here
   if (e != hipSuccess || err) {
     if (e != hipSuccess) hip_fail(e, "p2l_emit");
     else snprintf(g_err, sizeof g_err, "P2L: a bin could not be split far enough to fit LDS");
@@ -690,9 +737,7 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
   if (!rec) { cleanup(); return nullptr; }
   rfxk::leaf_compact(c, tmp_keys, tmp_counts, tmp_start, n_surv, P, t->lut_tinv, t->ntab, cfg.sel_bits, rec->keys,
                      rec->counts, rec->pos);
-  e = hipStreamSynchronize(c->stream);
-  cleanup();
-  if (e != hipSuccess) { hip_fail(e, "leaf_compact"); rfx_records_free(rec); return nullptr; }
+  cleanup();  // stream-ordered: the pool hands these blocks out again only to later work of this stream
   return rec;
 }
 
@@ -748,9 +793,9 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
                       limit);
     rfx_count_ctl ctl;
     rfx_table_stats st;
-    HIPCHK(hipMemcpyAsync(&ctl, t->d_ctl, sizeof ctl, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(&st, t->d_stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(queue_read(c, &ctl, t->d_ctl, sizeof ctl));
+    HIPCHK(queue_read(c, &st, t->d_stats, sizeof st));
+    HIPCHK(ctx_sync(c));
     if (ctl.lost || st.overflow) {
       snprintf(g_err, sizeof g_err, "count table overflow list exhausted; counts are not exact");
       return RFX_E_FULL;
@@ -763,14 +808,14 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
     if (rc) return rc;
     if (ctl.ovf_n) {
       rfxk::count_pairs(c, t->ovf_keys, nullptr, ctl.ovf_n, view_of(t), t->lut, t->d_stats);
-      HIPCHK(hipMemcpyAsync(&st, t->d_stats, sizeof st, hipMemcpyDeviceToHost, c->stream));
-      HIPCHK(hipStreamSynchronize(c->stream));
+      HIPCHK(queue_read(c, &st, t->d_stats, sizeof st));
+      HIPCHK(ctx_sync(c));
       if (st.overflow) return RFX_E_FULL;
     }
     ctl.stop = 0;
     ctl.ovf_n = 0;
     HIPCHK(hipMemcpyAsync(t->d_ctl, &ctl, sizeof ctl, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(ctx_sync(c));
     if (ctl.ticket >= n_chunks) return RFX_OK;
   }
 }
@@ -847,9 +892,9 @@ rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint
     rfxk::tile_scan(c, tile_counts, n_tiles, tile_off, d_max);
     uint64_t total = 0;
     uint32_t mx = 0;
-    hipError_t e = hipMemcpyAsync(&total, tile_off + n_tiles, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&mx, d_max, 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipError_t e = queue_read(c, &total, tile_off + n_tiles, 8);
+    if (e == hipSuccess) e = queue_read(c, &mx, d_max, 4);
+    if (e == hipSuccess) e = ctx_sync(c);
     if (e != hipSuccess) { hip_fail(e, "rfx_count_finish"); cleanup(); return nullptr; }
     uint32_t sort_cap = 64;
     while (sort_cap < mx) sort_cap <<= 1;
@@ -862,7 +907,7 @@ rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint
     rfx_records* r = records_alloc(c, t->k, t->lsize, t->cols, total);
     if (!r) { cleanup(); return nullptr; }
     rfxk::tile_emit(c, tv, t->lut, halo, lower, upper, tile_off, n_tiles, sort_cap, r->keys, r->counts, r->pos);
-    e = hipStreamSynchronize(c->stream);
+    e = ctx_sync(c);
     cleanup();
     if (e != hipSuccess) { hip_fail(e, "tile_emit"); rfx_records_free(r); return nullptr; }
     if (histo && rfx_records_histo(r, histo) != RFX_OK) { rfx_records_free(r); return nullptr; }
@@ -899,7 +944,7 @@ int rfx_records_payload(const rfx_records* r, void* out, size_t cap_bytes, int c
   if (!d) return RFX_E_NOMEM;
   rfxk::format_records(c, r->keys, r->counts, r->n, kb, counter_len, d);
   hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = ctx_sync(c);
   dfree(c, d);
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_payload");
 }
@@ -908,9 +953,11 @@ int rfx_records_get(const rfx_records* r, uint64_t* keys, uint32_t* counts, uint
   if (!r) return RFX_E_INVAL;
   (void)hipSetDevice(r->ctx->device);
   if (r->n == 0) return RFX_OK;
-  if (keys) HIPCHK(hipMemcpy(keys, r->keys, r->n * 8, hipMemcpyDeviceToHost));
-  if (counts) HIPCHK(hipMemcpy(counts, r->counts, r->n * 4, hipMemcpyDeviceToHost));
-  if (pos) HIPCHK(hipMemcpy(pos, r->pos, r->n * 8, hipMemcpyDeviceToHost));
+  rfx_ctx* c = r->ctx;  // copies ride the ctx stream: the records may still be in flight on it
+  if (keys) HIPCHK(hipMemcpyAsync(keys, r->keys, r->n * 8, hipMemcpyDeviceToHost, c->stream));
+  if (counts) HIPCHK(hipMemcpyAsync(counts, r->counts, r->n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (pos) HIPCHK(hipMemcpyAsync(pos, r->pos, r->n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(ctx_sync(c));
   return RFX_OK;
 }
 
@@ -932,8 +979,8 @@ rfx_records* rfx_records_load(rfx_ctx* c, int k, int lsize, const uint64_t* cols
     rfxk::parse_records(c, d, n, kb, counter_len, r->keys, r->counts);
     rfxk::compute_pos(c, r->keys, n, r->lut, r->ntab, r->pos);
     rfxk::check_sorted(c, r->keys, r->pos, n, d_bad);
-    ok = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
-         hipStreamSynchronize(c->stream) == hipSuccess;
+    ok = queue_read(c, &bad, d_bad, 4) == hipSuccess &&
+         ctx_sync(c) == hipSuccess;
   }
   dfree(c, d);
   dfree(c, d_bad);
@@ -958,7 +1005,7 @@ rfx_records* rfx_records_from_dev(rfx_ctx* c, int k, int lsize, const uint64_t* 
             hipMemcpyAsync(r->counts, d_counts, n * 4, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
   if (ok) {
     rfxk::compute_pos(c, r->keys, n, r->lut, r->ntab, r->pos);
-    ok = hipStreamSynchronize(c->stream) == hipSuccess;
+    ok = ctx_sync(c) == hipSuccess;
   }
   if (!ok) {
     rfx_records_free(r);
@@ -976,9 +1023,9 @@ int rfx_records_histo(const rfx_records* r, uint64_t* histo) {
   hipError_t e = hipMemsetAsync(d, 0, RFX_HISTO_BINS * 8, c->stream);
   if (e == hipSuccess) {
     rfxk::histo(c, r->counts, r->n, d);
-    e = hipMemcpyAsync(histo, d, RFX_HISTO_BINS * 8, hipMemcpyDeviceToHost, c->stream);
+    e = queue_read(c, histo, d, RFX_HISTO_BINS * 8);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = ctx_sync(c);
   dfree(c, d);
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_histo");
 }
@@ -1033,12 +1080,12 @@ int rfx_query(const rfx_records* db, const uint64_t* keys, uint64_t n, uint32_t*
   uint64_t* dq = (uint64_t*)dmalloc(c, n * 8);
   uint32_t* dout = (uint32_t*)dmalloc(c, n * 4);
   if (!dq || !dout) { dfree(c, dq); dfree(c, dout); return RFX_E_NOMEM; }
-  hipError_t e = hipMemcpyAsync(dq, keys, n * 8, hipMemcpyHostToDevice, c->stream);
+  hipError_t e = upload(c, dq, keys, n * 8);
   if (e == hipSuccess) {
     rfxk::query(c, dq, n, db->lut, db->ntab, db->keys, db->pos, db->counts, db->n, dout);
-    e = hipMemcpyAsync(counts_out, dout, n * 4, hipMemcpyDeviceToHost, c->stream);
+    e = queue_read(c, counts_out, dout, n * 4);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = ctx_sync(c);
   dfree(c, dq); dfree(c, dout);
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_query");
 }
@@ -1093,11 +1140,11 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
   bool ok = s->slots && dk && s->bitmap;
   if (ok) ok = hipMemsetAsync(s->slots, 0xFF, s->cap * 8, c->stream) == hipSuccess &&
                hipMemsetAsync(s->bitmap, 0, std::max<size_t>(bm_words, 2048) * 4, c->stream) == hipSuccess;
-  if (ok && n) ok = hipMemcpyAsync(dk, fwd_keys, n * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess;
+  if (ok && n) ok = upload(c, dk, fwd_keys, n * 8) == hipSuccess;
   if (ok) {
     rfxk::set_insert(c, dk, n, s->slots, s->bits);
     rfxk::set_bitmap(c, dk, n, s->bitmap, s->bm_bits, s->bm_shift);
-    ok = hipStreamSynchronize(c->stream) == hipSuccess;
+    ok = ctx_sync(c) == hipSuccess;
   }
   dfree(c, dk);
   if (!ok) {
@@ -1133,10 +1180,10 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
     rfxk::filter(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap, s->bm_bits, s->bm_shift, s->k, thresh,
                  last_base_skipped, d_hits, d_mask, d_n);
     unsigned long long nh = 0;
-    e = hipMemcpyAsync(&nh, d_n, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && hits_out) e = hipMemcpyAsync(hits_out, d_hits, (size_t)r->n * 4, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess && hitmask_out) e = hipMemcpyAsync(hitmask_out, d_mask, nmask * 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    e = queue_read(c, &nh, d_n, 8);
+    if (e == hipSuccess && hits_out) e = queue_read(c, hits_out, d_hits, (size_t)r->n * 4);
+    if (e == hipSuccess && hitmask_out) e = queue_read(c, hitmask_out, d_mask, nmask * 8);
+    if (e == hipSuccess) e = ctx_sync(c);
     if (e == hipSuccess && n_hit_reads) *n_hit_reads = nh;
   }
   cleanup();
@@ -1166,15 +1213,15 @@ int rfx_overlap_score(rfx_ctx* c, const char* a, int alen, const char* const* b,
   int* d_out = (int*)dmalloc(c, (size_t)nb * 5 * sizeof(int));
   auto cleanup = [&] { dfree(c, d_a); dfree(c, d_b); dfree(c, d_off); dfree(c, d_out); };
   if (!d_a || !d_b || !d_off || !d_out) { cleanup(); return RFX_E_NOMEM; }
-  hipError_t e = hipMemcpyAsync(d_a, a, (size_t)alen, hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess && !cat.empty()) e = hipMemcpyAsync(d_b, cat.data(), cat.size(), hipMemcpyHostToDevice, c->stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), off.size() * 4, hipMemcpyHostToDevice, c->stream);
+  hipError_t e = upload(c, d_a, a, (size_t)alen);
+  if (e == hipSuccess && !cat.empty()) e = upload(c, d_b, cat.data(), cat.size());
+  if (e == hipSuccess) e = upload(c, d_off, off.data(), off.size() * 4);
   if (e == hipSuccess) {
     rfxk::overlap_score(c, d_a, alen, d_b, d_off, nb, max_blen, min_pct, min_ovl, variant == RFX_OVL_CONTIG,
                         variant == RFX_OVL_CONTIG ? -1 : 0, d_out);
-    e = hipMemcpyAsync(out, d_out, (size_t)nb * 5 * sizeof(int), hipMemcpyDeviceToHost, c->stream);
+    e = queue_read(c, out, d_out, (size_t)nb * 5 * sizeof(int));
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = ctx_sync(c);
   cleanup();
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_overlap_score");
 }
@@ -1185,7 +1232,8 @@ int rfx_annotate(rfx_set* s, const rfx_reads* r, uint32_t* cov_out) {
   (void)hipSetDevice(c->device);
   if (r->n == 0 || r->n_bases == 0) return RFX_OK;
   std::vector<uint32_t> len(r->n);
-  hipError_t e = hipMemcpy(len.data(), r->len, (size_t)r->n * 4, hipMemcpyDeviceToHost);
+  hipError_t e = hipMemcpyAsync(len.data(), r->len, (size_t)r->n * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = ctx_sync(c);
   std::vector<uint64_t> off((size_t)r->n + 1, 0);
   for (uint32_t i = 0; i < r->n; ++i) off[(size_t)i + 1] = off[i] + len[i];
   uint64_t* d_off = (uint64_t*)dmalloc(c, off.size() * 8);
@@ -1198,7 +1246,7 @@ int rfx_annotate(rfx_set* s, const rfx_reads* r, uint32_t* cov_out) {
     rfxk::annotate(c, rv, s->slots, s->bits, s->has_all_ones, s->k, d_off, d_cov);
     e = hipMemcpyAsync(cov_out, d_cov, r->n_bases * 4, hipMemcpyDeviceToHost, c->stream);
   }
-  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess) e = ctx_sync(c);
   dfree(c, d_off);
   dfree(c, d_cov);
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_annotate");

@@ -38,10 +38,18 @@ struct rfx_ctx {
   size_t budget = 0, used = 0;
   int n_cu = 256;
   bool prof = false;
+  std::string prof_filter;  // ",name1,name2," -- when non-empty only these kernels are bracketed
   std::vector<rfx_prof_span> spans;
+  std::vector<hipEvent_t> free_events;  // recycled: creating two events per launch costs more than recording them
   std::map<std::string, rfx_prof_acc> acc;
   std::map<void*, size_t> allocs;
   std::multimap<size_t, void*> pool;  // freed blocks kept for reuse, keyed by size
+  // pinned host scratch: small read-backs and uploads go through it (pageable copies cost a
+  // staging round trip each); a bump allocator that is reset at every stream synchronisation
+  char* pin = nullptr;
+  size_t pin_cap = 0, pin_used = 0;
+  struct pin_read { void* dst; size_t off, n; };
+  std::vector<pin_read> pin_reads;
   std::map<std::pair<int, uint64_t>, rfx_hash_consts> consts;  // (k*64+lsize, matrix digest) -> device tables
 };
 
@@ -224,17 +232,27 @@ struct rfx_span {
   rfx_ctx* c;
   rfx_prof_span s;
   bool on;
-  rfx_span(rfx_ctx* ctx, const char* name) : c(ctx), on(ctx->prof) {
+  rfx_span(rfx_ctx* ctx, const char* name)
+      : c(ctx),
+        on(ctx->prof && (ctx->prof_filter.empty() ||
+                         ctx->prof_filter.find(std::string(",") + name + ",") != std::string::npos)) {
     if (on) {
       s.name = name;
-      hipEventCreate(&s.e0);
-      hipEventCreate(&s.e1);
-      hipEventRecord(s.e0, c->stream);
+      auto get = [&](hipEvent_t& e) {
+        if (c->free_events.empty()) (void)hipEventCreate(&e);
+        else {
+          e = c->free_events.back();
+          c->free_events.pop_back();
+        }
+      };
+      get(s.e0);
+      get(s.e1);
+      (void)hipEventRecord(s.e0, c->stream);
     }
   }
   ~rfx_span() {
     if (on) {
-      hipEventRecord(s.e1, c->stream);
+      (void)hipEventRecord(s.e1, c->stream);
       c->spans.push_back(s);
     }
   }

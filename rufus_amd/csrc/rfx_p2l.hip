@@ -18,8 +18,13 @@
 namespace {
 
 constexpr int P2_BLOCK = 512;     // threads = reads per chunk in the partition kernels
+// Leaf geometry: 8192-slot LDS table + 2048-entry sort area = 120 KB, one 1024-thread workgroup per CU.
+// (Measured alternative: 4096 slots / 512 threads / 16 K bins gives two workgroups per CU and a 12 %
+// faster leaf, but the finer bins cost more than that in k_bin_count and k_part2.)  The next bin's
+// words are prefetched into registers while the current bin is being sorted and emitted.
 constexpr int LEAF_BLOCK = 1024;
-constexpr int LEAF_TBL = 8192;    // LDS hash slots per bin round
+constexpr int LEAF_TBL_LOG2 = 13;
+constexpr int LEAF_TBL = 1 << LEAF_TBL_LOG2;  // LDS hash slots per bin round
 constexpr int LEAF_FILL = 6144;   // distinct keys allowed before the bin is split into more rounds
 constexpr int LEAF_SORT = 2048;   // survivors sorted per round
 constexpr int LEAF_RMAX = 20;
@@ -364,16 +369,18 @@ __global__ __launch_bounds__(256) void k_tmp_start(const uint64_t* const* __rest
 __device__ __forceinline__ uint32_t leaf_hash(uint64_t w) {
   uint32_t h = (uint32_t)w ^ (uint32_t)(w >> 19) ^ (uint32_t)(w >> 37);
   h *= 0x9E3779B1u;
-  return h >> (32 - 13);  // LEAF_TBL = 2^13
+  return h >> (32 - LEAF_TBL_LOG2);
 }
 
-constexpr int LEAF_ILP = 16;      // words loaded per lane before the first insert (128 KB in flight per CU)
+constexpr int LEAF_ILP = 8;       // words loaded per lane before the first insert (64 KB in flight per workgroup)
 constexpr int LEAF_BUCKETS = 256;  // survivors are bucketed on the next 8 bits of w, then ranked inside the bucket
 
 // One workgroup per bin.  If a bin holds more distinct words than the LDS table (or more survivors
 // than the sort area) it is re-run split into 2^r sub-ranges of w, in order -- exact for any input.
 __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __restrict__ seg_inst,
-                                                      const uint64_t* const* __restrict__ seg_bs, int nseg, uint32_t P,
+                                                      const uint64_t* const* __restrict__ seg_bs, int nseg,
+                                                      const uint64_t* __restrict__ inst0,
+                                                      const uint64_t* __restrict__ bs0, uint32_t P,
                                                       rfx_ord_cfg cfg, uint64_t lower, uint64_t upper,
                                                       const uint64_t* __restrict__ tmp_start,
                                                       uint64_t* __restrict__ tmp_w, uint32_t* __restrict__ tmp_counts,
@@ -386,8 +393,26 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
   __shared__ uint32_t s_nd, s_ns, s_ovf;
   const int bin_bits = cfg.c_bits - cfg.bin_shift;  // bins are the top bits of the c-bit word
 
+  // First batch of segment 0 of a bin (inst0/bs0 are segment 0's arrays passed by value, no pointer
+  // chase).  Issued one bin ahead so the HBM latency hides behind the previous bin's sort and emit.
+  uint64_t pre[LEAF_ILP];
+  uint64_t pre_a = 0, pre_e = 0, pre_out0 = 0;
+  auto prefetch = [&](uint32_t b) {
+    if (b >= P) return;
+    pre_a = bs0[b];
+    pre_e = bs0[b + 1];
+    pre_out0 = tmp_start[b];
+#pragma unroll
+    for (int u = 0; u < LEAF_ILP; ++u) {
+      const uint64_t i = pre_a + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
+      pre[u] = i < pre_e ? inst0[i] : RFX_EMPTY;
+    }
+  };
+  prefetch(blockIdx.x);
+
   for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
-    const uint64_t out0 = tmp_start[bin];
+    const uint64_t out0 = pre_out0, a0 = pre_a, e0 = pre_e;
+    bool prefetched_next = false;  // until then `pre` holds this bin's first batch
     uint64_t emitted = 0;
     bool done = false;
     for (int r = 0; r <= LEAF_RMAX && !done && bin_bits + r <= cfg.c_bits; ++r) {
@@ -407,14 +432,19 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
         }
         __syncthreads();
         for (int sg = 0; sg < nseg; ++sg) {
-          const uint64_t a = seg_bs[sg][bin], e = seg_bs[sg][bin + 1];
-          const uint64_t* __restrict__ src = seg_inst[sg];
+          const uint64_t a = sg == 0 ? a0 : seg_bs[sg][bin], e = sg == 0 ? e0 : seg_bs[sg][bin + 1];
+          const uint64_t* __restrict__ src = sg == 0 ? inst0 : seg_inst[sg];
           for (uint64_t base = a; base < e; base += (uint64_t)LEAF_ILP * LEAF_BLOCK) {
             uint64_t w[LEAF_ILP];
+            if (sg == 0 && base == a && !prefetched_next) {  // first pass over the bin: already in registers
 #pragma unroll
-            for (int u = 0; u < LEAF_ILP; ++u) {  // independent loads, all in flight before the first insert
-              const uint64_t i = base + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
-              w[u] = i < e ? src[i] : RFX_EMPTY;
+              for (int u = 0; u < LEAF_ILP; ++u) w[u] = pre[u];
+            } else {
+#pragma unroll
+              for (int u = 0; u < LEAF_ILP; ++u) {  // independent loads, all in flight before the first insert
+                const uint64_t i = base + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
+                w[u] = i < e ? src[i] : RFX_EMPTY;
+              }
             }
 #pragma unroll
             for (int u = 0; u < LEAF_ILP; ++u) {
@@ -442,6 +472,10 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
               }
             }
           }
+        }
+        if (!prefetched_next) {  // the next bin's loads fly while this bin is ranked and written out
+          prefetch(bin + gridDim.x);
+          prefetched_next = true;
         }
         __syncthreads();
         if (s_ovf) {
@@ -582,6 +616,12 @@ int p2l_grid(rfx_ctx* c, uint32_t n_reads) {
 void bin_count(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int ntab, int k, int canonical,
                const rfx_ord_cfg& cfg, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, uint32_t* cnt) {
   const size_t lds = 8 * 256 * 8 + (size_t)P * 4;
+  static bool attr_set = false;
+  if (!attr_set) {  // 16 K bins: 80 KB of dynamic LDS
+    (void)hipFuncSetAttribute((const void*)k_bin_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute((const void*)k_bin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
   rfx_span sp(c, "k_bin_count");
   if (canonical)
     hipLaunchKernelGGL(k_bin_count<true>, dim3(grid), dim3(P2_BLOCK), lds, c->stream, rv, lut, ntab, k, cfg, P, pos_lo,
@@ -643,12 +683,14 @@ void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, 
   hipLaunchKernelGGL(k_tmp_start, dim3((P + 1 + 255) / 256), dim3(256), 0, c->stream, seg_bs, nseg, P, out);
 }
 
-void leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, uint32_t P,
-          const rfx_ord_cfg& cfg, uint64_t lower, uint64_t upper, const uint64_t* tmp_start_, uint64_t* tmp_w,
+void leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, const uint64_t* inst0,
+          const uint64_t* bs0, uint32_t P, const rfx_ord_cfg& cfg, uint64_t lower, uint64_t upper, const uint64_t* tmp_start_, uint64_t* tmp_w,
           uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err) {
   rfx_span sp(c, "k_leaf");
-  hipLaunchKernelGGL(k_leaf, dim3(P), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, P, cfg, lower, upper,
-                     tmp_start_, tmp_w, tmp_counts, n_surv, err);
+  // a few bins per workgroup so that the one-bin-ahead prefetch has something to overlap with
+  const uint32_t grid = P < (uint32_t)c->n_cu * 4 ? P : (uint32_t)c->n_cu * 4;
+  hipLaunchKernelGGL(k_leaf, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0, P, cfg,
+                     lower, upper, tmp_start_, tmp_w, tmp_counts, n_surv, err);
 }
 
 void scan_tail(rfx_ctx* c, uint64_t* v, uint64_t n) {

@@ -94,8 +94,8 @@ def revcomp_keys(keys, k):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--cpu-pairs", type=int, default=200_000, help="pairs per sample of the CPU baseline sample")
     ap.add_argument("--pairs", type=int, default=500_000, help="read pairs per sample per GPU")
     ap.add_argument("--genome", type=int, default=5_000_000)

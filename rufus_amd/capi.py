@@ -363,15 +363,25 @@ def merge_unique(ctx: Context, files, min_count: int = 5):
     return keys[:n.value], counts[:n.value]
 
 
+_uniq_buf = {}
+
+
 def unique_to_subject(ctx: Context, subject: Records, others, min_cov: int, max_cov: int, min_count: int = 5):
     arr = (C.c_void_p * max(1, len(others)))(*[f._h for f in others])
-    cap = len(subject)
-    keys, counts = np.zeros(max(cap, 1), np.uint64), np.zeros(max(cap, 1), np.uint32)
-    n = C.c_uint64(0)
-    _check(lib().rfx_unique_to_subject(ctx._h, subject._h, arr, len(others), min_count, min_cov, max_cov,
-                                       _p(keys, u64p), _p(counts, u32p), len(keys), C.byref(n)),
-           "rfx_unique_to_subject")
-    return keys[:n.value].copy(), counts[:n.value].copy()
+    # mutant lists are tiny next to the record arrays: start from a reused 64 K buffer, enlarge on demand
+    cap = _uniq_buf.get("cap", 1 << 16)
+    while True:
+        if _uniq_buf.get("cap") != cap or "k" not in _uniq_buf:
+            _uniq_buf.update(cap=cap, k=np.zeros(cap, np.uint64), c=np.zeros(cap, np.uint32))
+        keys, counts = _uniq_buf["k"], _uniq_buf["c"]
+        n = C.c_uint64(0)
+        rc = lib().rfx_unique_to_subject(ctx._h, subject._h, arr, len(others), min_count, min_cov, max_cov,
+                                         _p(keys, u64p), _p(counts, u32p), cap, C.byref(n))
+        if rc == E_RANGE and n.value > cap:
+            cap = int(n.value)
+            continue
+        _check(rc, "rfx_unique_to_subject")
+        return keys[:n.value].copy(), counts[:n.value].copy()
 
 
 OVL_SAM, OVL_CONTIG, OVL_REGION = 0, 1, 2

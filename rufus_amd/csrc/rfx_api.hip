@@ -301,7 +301,14 @@ const rfx_hash_consts* get_consts(rfx_ctx* c, int k, int lsize, const uint64_t* 
   rfx_hash_consts hc;
   memset(hc.cols, 0, sizeof hc.cols);
   if (cols_in) memcpy(hc.cols, cols_in, sizeof(uint64_t) * 2 * k);
-  else if (rfx_jf_matrix(lsize, k, hc.cols) != RFX_OK) return nullptr;
+  else {
+    std::vector<uint64_t>& sc = c->std_cols[k * 64 + lsize];  // generating it costs a Gaussian elimination
+    if (sc.empty()) {
+      sc.assign(2 * (size_t)k, 0);
+      if (rfx_jf_matrix(lsize, k, sc.data()) != RFX_OK) { c->std_cols.erase(k * 64 + lsize); return nullptr; }
+    }
+    memcpy(hc.cols, sc.data(), sizeof(uint64_t) * 2 * k);
+  }
   uint64_t digest = 0xcbf29ce484222325ull;
   for (int i = 0; i < 2 * k; ++i) digest = (digest ^ hc.cols[i]) * 0x100000001b3ull;
   auto key = std::make_pair(k * 64 + lsize, digest);

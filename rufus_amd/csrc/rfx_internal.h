@@ -51,6 +51,7 @@ struct rfx_ctx {
   struct pin_read { void* dst; size_t off, n; };
   std::vector<pin_read> pin_reads;
   std::map<std::pair<int, uint64_t>, rfx_hash_consts> consts;  // (k*64+lsize, matrix digest) -> device tables
+  std::map<int, std::vector<uint64_t>> std_cols;                // k*64+lsize -> jellyfish's own matrix
 };
 
 // Device-side statistics of a count table.

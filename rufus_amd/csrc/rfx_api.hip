@@ -661,6 +661,36 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
   uint32_t *cnt1 = nullptr, *gsum1 = nullptr, *fine_cur = nullptr;
   uint64_t* tot1 = nullptr;
   auto drop = [&] { dfree(c, cnt); dfree(c, gsum); dfree(c, cnt1); dfree(c, gsum1); dfree(c, fine_cur); dfree(c, tot1); };
+  // Optimistic two-level path: the sizing pass is folded into the first partition pass (fixed-capacity
+  // coarse bins, 16-bit per-block fine histogram).  If either assumption fails the device raises a flag
+  // and the block is redone on the exact path below.  RFX_P2L_EXACT=1 forces the exact path.
+  if (two_level && P <= 8192 && !getenv("RFX_P2L_EXACT")) {
+    const uint64_t cap64 = windows / P1 + windows / (4ull * P1) + 65536;
+    const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
+    uint32_t* coarse_cur = (uint32_t*)dmalloc(c, (ncur + 1) * 4);  // [ncur] = overflow flag
+    fine_cur = (uint32_t*)dmalloc(c, (size_t)P * 4);
+    uint64_t* buf_a = cap64 < (1ull << 32) / P1 ? (uint64_t*)dmalloc(c, cap64 * P1 * 8) : nullptr;
+    uint64_t* inst = windows ? (uint64_t*)dmalloc(c, windows * 8) : nullptr;
+    unsigned int flag = 1;
+    if (coarse_cur && fine_cur && buf_a && inst &&
+        hipMemsetAsync(coarse_cur, 0, (ncur + 1) * 4, c->stream) == hipSuccess &&
+        hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream) == hipSuccess) {
+      rfxk::part1_fused(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P2, t->pos_lo, t->pos_hi, G, buf_a, coarse_cur,
+                        (uint32_t)cap64, cnt, coarse_cur + ncur);
+      rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
+      rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P, P2, cfg, coarse_cur, (uint32_t)cap64);
+      if (queue_read(c, &flag, coarse_cur + ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) flag = 1;
+    }
+    dfree(c, coarse_cur); dfree(c, buf_a); dfree(c, fine_cur);
+    fine_cur = nullptr;
+    if (!flag) {
+      drop();
+      t->segs->push_back(rfx_segment{inst, windows, bin_start});
+      return RFX_OK;
+    }
+    dfree(c, inst);
+    if (hipGetLastError() != hipSuccess) { drop(); dfree(c, bin_start); return RFX_E_HIP; }
+  }
   rfxk::bin_count(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt);
   if (two_level) {
     cnt1 = (uint32_t*)dmalloc(c, (size_t)G * P1 * 4);
@@ -685,7 +715,7 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
       return RFX_E_NOMEM;
     }
     rfxk::part1(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P2, t->pos_lo, t->pos_hi, G, cnt1, bin_start, buf_a);
-    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P, P2, cfg);
+    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P, P2, cfg, nullptr, 0);
     dfree(c, buf_a);
   } else {
     rfxk::bin_scatter(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt, bin_start,

@@ -212,12 +212,16 @@ void bin_scatter(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab,
                  const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel,
                  const uint64_t* bin_start, uint64_t* inst);
 int p1_bins();
+int p1_cur_stride();
 void coarse_counts(rfx_ctx*, const uint32_t* cnt, uint32_t G, uint32_t P, uint32_t P2, uint32_t* cnt1);
 void part1(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical, const rfx_ord_cfg&,
            uint32_t P2, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel1, const uint64_t* fine_start,
            uint64_t* buf_a);
+void part1_fused(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical,
+                 const rfx_ord_cfg&, uint32_t P2, uint64_t pos_lo, uint64_t pos_hi, int grid, uint64_t* buf_a,
+                 uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows, unsigned int* flag);
 void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur, uint32_t P,
-           uint32_t P2, const rfx_ord_cfg&);
+           uint32_t P2, const rfx_ord_cfg&, const uint32_t* coarse_cur, uint32_t cap_a);
 void tmp_start(rfx_ctx*, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out /* P+1 */);
 void leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, const uint64_t* inst0,
           const uint64_t* bs0, uint32_t P, const rfx_ord_cfg&, uint64_t lower, uint64_t upper, const uint64_t* tmp_start, uint64_t* tmp_w,

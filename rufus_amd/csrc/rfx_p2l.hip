@@ -170,6 +170,8 @@ __global__ __launch_bounds__(P2_BLOCK) void k_bin_scatter(rfx_reads_view rv, con
 constexpr int P1_BINS = 128;
 constexpr int P1_S = 8;                       // bases per phase
 constexpr int P1_STAGE = P2_BLOCK * P1_S;     // words staged per phase
+constexpr int P1_CUR_STRIDE = 64;             // fused path: one 256 B line per coarse-bin cursor (L2 atomics
+                                              // on one line serialise; 128 cursors in 4 lines cost 0.2 ms)
 constexpr int L2_BLOCK = 1024;
 constexpr int L2_PER = 8;                     // words per lane per tile
 constexpr int L2_TILE = L2_BLOCK * L2_PER;
@@ -210,21 +212,35 @@ __device__ __forceinline__ void wave_scan256(const uint32_t* s_cnt, uint32_t* s_
   if (l == 63) s_start[n] = inc;
 }
 
-template <bool CANON>
+// FUSED = true: the sizing pass (k_bin_count) is folded in.  Coarse bins then have a fixed capacity
+// `cap_a` and every phase reserves its runs with one global atomic per coarse bin; the exact fine-bin
+// histogram that k_part2 / k_leaf need falls out of a 16-bit LDS histogram (P must be <= 8192).  Both
+// shortcuts can fail on pathological input (one k-mer family holding > 20 % of a coarse bin, or
+// > 65535 instances of one fine bin inside one block): *flag is raised, nothing is written out of
+// bounds, and the host redoes the block on the exact path.
+template <bool CANON, bool FUSED>
 __global__ __launch_bounds__(P2_BLOCK) void k_part1(rfx_reads_view rv, const uint64_t* __restrict__ g_lut, int ntab,
                                                      int k, rfx_ord_cfg cfg, uint32_t P2, uint64_t pos_lo,
                                                      uint64_t pos_hi, const uint32_t* __restrict__ rel1,
                                                      const uint64_t* __restrict__ fine_start,
-                                                     uint64_t* __restrict__ buf_a) {
+                                                     uint64_t* __restrict__ buf_a, uint32_t* __restrict__ coarse_cur,
+                                                     uint32_t cap_a, uint32_t* __restrict__ cnt_rows,
+                                                     unsigned int* __restrict__ flag) {
   __shared__ uint64_t s_lut[8 * 256];
   __shared__ uint64_t s_stage[P1_STAGE];
   __shared__ uint8_t s_sbin[P1_STAGE];
   __shared__ uint32_t s_cnt[P1_BINS], s_start[P1_BINS + 1], s_gcur[P1_BINS], s_gbase[P1_BINS];
   __shared__ uint32_t s_maxlen;
+  __shared__ uint32_t s_fine[FUSED ? 4096 : 1];  // two 16-bit counters per word: fine bins 2i, 2i+1
+  const uint32_t P = P2 * P1_BINS;
+  uint32_t blk_total = 0;  // words this block produced (uniform)
   for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
+  if (FUSED)
+    for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) s_fine[i] = 0;
   if (threadIdx.x < P1_BINS) {
-    s_gcur[threadIdx.x] =
-        (uint32_t)fine_start[(uint64_t)threadIdx.x * P2] + rel1[(uint64_t)blockIdx.x * P1_BINS + threadIdx.x];
+    if (!FUSED)
+      s_gcur[threadIdx.x] =
+          (uint32_t)fine_start[(uint64_t)threadIdx.x * P2] + rel1[(uint64_t)blockIdx.x * P1_BINS + threadIdx.x];
     s_cnt[threadIdx.x] = 0;
   }
   const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
@@ -272,16 +288,29 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part1(rfx_reads_view rv, const uin
               const uint32_t bin = (uint32_t)(w >> shift1);
               wv[b] = w;
               br[b] = (bin << 16) | atomicAdd(&s_cnt[bin], 1u);
+              if (FUSED) {  // no-return LDS atomic; a wrapped 16-bit counter shows up in the sum check below
+                const uint32_t fb = (uint32_t)(w >> cfg.bin_shift);
+                atomicAdd(&s_fine[fb >> 1], 1u << ((fb & 1u) * 16));
+              }
             }
           }
         }
       }
       __syncthreads();
+      // FUSED: reserve this phase's runs now; the round trip of the global atomic hides behind the
+      // scan and the staging, its result is only needed for the write-out.
+      uint32_t cn = 0, at = 0;
+      if (FUSED && threadIdx.x < P1_BINS) {
+        cn = s_cnt[threadIdx.x];
+        if (cn) at = atomicAdd(&coarse_cur[threadIdx.x * P1_CUR_STRIDE], cn);
+      }
       if (threadIdx.x < 64) wave_scan256(s_cnt, s_start, P1_BINS);
       __syncthreads();
       if (threadIdx.x < P1_BINS) {
-        s_gbase[threadIdx.x] = s_gcur[threadIdx.x];
-        s_gcur[threadIdx.x] += s_cnt[threadIdx.x];
+        if (!FUSED) {
+          s_gbase[threadIdx.x] = s_gcur[threadIdx.x];
+          s_gcur[threadIdx.x] += s_cnt[threadIdx.x];
+        }
         s_cnt[threadIdx.x] = 0;
       }
 #pragma unroll
@@ -291,14 +320,39 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part1(rfx_reads_view rv, const uin
           s_stage[e] = wv[b];
           s_sbin[e] = (uint8_t)bin;
         }
+      if (FUSED && threadIdx.x < P1_BINS) {
+        if (at + cn > cap_a) {  // bin over its capacity: drop the run (the block is redone exactly)
+          atomicExch(flag, 1u);
+          s_gbase[threadIdx.x] = 0xFFFFFFFFu;
+        } else {
+          s_gbase[threadIdx.x] = threadIdx.x * cap_a + at;
+        }
+      }
       __syncthreads();
       const uint32_t total = s_start[P1_BINS];
+      if (FUSED) blk_total += total;
       for (uint32_t e = threadIdx.x; e < total; e += P2_BLOCK) {
         const uint32_t bin = s_sbin[e];
-        buf_a[s_gbase[bin] + (e - s_start[bin])] = s_stage[e];
+        if (!FUSED || s_gbase[bin] != 0xFFFFFFFFu) buf_a[(uint64_t)s_gbase[bin] + (e - s_start[bin])] = s_stage[e];
       }
       __syncthreads();
     }
+  }
+  if (FUSED) {  // this block's row of the exact fine-bin histogram
+    __syncthreads();
+    if (threadIdx.x == 0) s_maxlen = 0;
+    __syncthreads();
+    uint32_t sum = 0;
+    for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) {
+      const uint32_t v = (s_fine[b >> 1] >> ((b & 1u) * 16)) & 0xFFFFu;
+      cnt_rows[(uint64_t)blockIdx.x * P + b] = v;
+      sum += v;
+    }
+    // A wrapped low half carries into its neighbour (sum - 65535), a wrapped high half carries out
+    // of the word (sum - 65536): any wrap leaves the sum short of the words this block produced.
+    atomicAdd(&s_maxlen, sum);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_maxlen != blk_total) atomicExch(flag, 1u);
   }
 }
 
@@ -306,13 +360,16 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part1(rfx_reads_view rv, const uin
 __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__ buf_a, uint64_t* __restrict__ buf_b,
                                                      const uint64_t* __restrict__ fine_start,
                                                      uint32_t* __restrict__ fine_cur, uint32_t P2, int shift2,
-                                                     uint32_t W) {
+                                                     uint32_t W, const uint32_t* __restrict__ coarse_cur,
+                                                     uint32_t cap_a) {
   __shared__ uint64_t s_stage[L2_TILE];
   __shared__ uint8_t s_sbin[L2_TILE];
   __shared__ uint32_t s_cnt[256], s_start[257];
   __shared__ uint64_t s_gbase[256];
   const uint32_t cb = blockIdx.x / W, j = blockIdx.x - cb * W;
-  const uint64_t a = fine_start[(uint64_t)cb * P2], e = fine_start[(uint64_t)(cb + 1) * P2];
+  // coarse bin cb of A: exactly sized (same extents as its fine bins in B) or fixed-capacity (fused path)
+  const uint64_t a = coarse_cur ? (uint64_t)cb * cap_a : fine_start[(uint64_t)cb * P2];
+  const uint64_t e = coarse_cur ? a + min(coarse_cur[cb * P1_CUR_STRIDE], cap_a) : fine_start[(uint64_t)(cb + 1) * P2];
   if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   for (uint64_t base = a + (uint64_t)j * L2_TILE; base < e; base += (uint64_t)W * L2_TILE) {
@@ -337,7 +394,9 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
     if (threadIdx.x < P2) {
       const uint32_t c = s_cnt[threadIdx.x];
       const uint64_t f = (uint64_t)cb * P2 + threadIdx.x;
-      s_gbase[threadIdx.x] = fine_start[f] + (c ? atomicAdd(&fine_cur[f], c) : 0u);
+      const uint32_t at = c ? atomicAdd(&fine_cur[f], c) : 0u;
+      // never write past the fine bin (only possible after the fused part1 raised its flag)
+      s_gbase[threadIdx.x] = fine_start[f] + at + c <= fine_start[f + 1] ? fine_start[f] + at : ~0ull;
       s_cnt[threadIdx.x] = 0;
     }
 #pragma unroll
@@ -351,7 +410,7 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
     const uint32_t total = s_start[P2];
     for (uint32_t x = threadIdx.x; x < total; x += L2_BLOCK) {
       const uint32_t sub = s_sbin[x];
-      buf_b[s_gbase[sub] + (x - s_start[sub])] = s_stage[x];
+      if (s_gbase[sub] != ~0ull) buf_b[s_gbase[sub] + (x - s_start[sub])] = s_stage[x];
     }
     __syncthreads();
   }
@@ -653,6 +712,7 @@ void bin_scatter(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int 
 }
 
 int p1_bins() { return P1_BINS; }
+int p1_cur_stride() { return P1_CUR_STRIDE; }
 
 void coarse_counts(rfx_ctx* c, const uint32_t* cnt, uint32_t G, uint32_t P, uint32_t P2, uint32_t* cnt1) {
   const uint32_t n = G * (P / P2);
@@ -664,19 +724,35 @@ void part1(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int ntab, 
            const uint64_t* fine_start, uint64_t* buf_a) {
   rfx_span sp(c, "k_part1");
   if (canonical)
-    hipLaunchKernelGGL(k_part1<true>, dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, lut, ntab, k, cfg, P2, pos_lo,
-                       pos_hi, rel1, fine_start, buf_a);
+    hipLaunchKernelGGL((k_part1<true, false>), dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, lut, ntab, k, cfg, P2,
+                       pos_lo, pos_hi, rel1, fine_start, buf_a, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr,
+                       (unsigned int*)nullptr);
   else
-    hipLaunchKernelGGL(k_part1<false>, dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, lut, ntab, k, cfg, P2, pos_lo,
-                       pos_hi, rel1, fine_start, buf_a);
+    hipLaunchKernelGGL((k_part1<false, false>), dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, lut, ntab, k, cfg, P2,
+                       pos_lo, pos_hi, rel1, fine_start, buf_a, (uint32_t*)nullptr, 0u, (uint32_t*)nullptr,
+                       (unsigned int*)nullptr);
+}
+
+void part1_fused(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int ntab, int k, int canonical,
+                 const rfx_ord_cfg& cfg, uint32_t P2, uint64_t pos_lo, uint64_t pos_hi, int grid, uint64_t* buf_a,
+                 uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows, unsigned int* flag) {
+  rfx_span sp(c, "k_part1");
+  if (canonical)
+    hipLaunchKernelGGL((k_part1<true, true>), dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, lut, ntab, k, cfg, P2,
+                       pos_lo, pos_hi, (const uint32_t*)nullptr, (const uint64_t*)nullptr, buf_a, coarse_cur, cap_a,
+                       cnt_rows, flag);
+  else
+    hipLaunchKernelGGL((k_part1<false, true>), dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, lut, ntab, k, cfg, P2,
+                       pos_lo, pos_hi, (const uint32_t*)nullptr, (const uint64_t*)nullptr, buf_a, coarse_cur, cap_a,
+                       cnt_rows, flag);
 }
 
 void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur,
-           uint32_t P, uint32_t P2, const rfx_ord_cfg& cfg) {
+           uint32_t P, uint32_t P2, const rfx_ord_cfg& cfg, const uint32_t* coarse_cur, uint32_t cap_a) {
   rfx_span sp(c, "k_part2");
   const uint32_t W = 16;
   hipLaunchKernelGGL(k_part2, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start, fine_cur, P2,
-                     cfg.bin_shift, W);
+                     cfg.bin_shift, W, coarse_cur, cap_a);
 }
 
 void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out) {

@@ -151,11 +151,15 @@ def test_p2l_dense_bins_split_into_rounds_and_many_blocks(ctx):
         x.free()
 
 
+@pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("bins", ["2048", "8192"])
-def test_two_level_partition_matches_oracle(ctx, small_trio, bins, monkeypatch):
+def test_two_level_partition_matches_oracle(ctx, small_trio, bins, exact, monkeypatch):
     """>= 2048 bins switches the P2L path to its two-level partition (coarse bins through LDS-staged
-    runs, then fine bins); force it on a small input and compare bit for bit, k=25 and k=31."""
+    runs, then fine bins); force it on a small input and compare bit for bit, k=25 and k=31.  Both
+    flavours: sizing pass fused into the first partition pass (default) and the exact-size passes."""
     monkeypatch.setenv("RFX_P2L_BINS", bins)
+    if exact:
+        monkeypatch.setenv("RFX_P2L_EXACT", "1")
     fq = [fastq_bytes(small_trio["father"], m) for m in (1, 2)]
     for k, size, lower in ((25, 8 << 30, 2), (31, 1 << 20, 1)):
         jf = tools.jellyfish_count(ctx, fq, k, size, lower=lower, mode=capi.COUNT_P2L)
@@ -175,6 +179,36 @@ def test_two_level_partition_matches_oracle(ctx, small_trio, bins, monkeypatch):
     assert np.array_equal(keys, ref.keys[sel]) and np.array_equal(counts, ref.counts[sel].astype(np.uint32))
     for x in (rec, blk, t):
         x.free()
+
+
+def test_skewed_input_falls_back_to_the_exact_partition(ctx, monkeypatch):
+    """The fused partition pass assumes coarse bins within 25 % of even and < 65536 instances of a
+    fine bin per workgroup.  Homopolymer reads break both: the device raises its flag and the block
+    is redone on the exact path (visible as a k_bin_count launch); the result is still bit-exact."""
+    monkeypatch.setenv("RFX_P2L_BINS", "2048")
+    rng = np.random.default_rng(3)
+    seqs = [b"A" * 150] * 2500 + [b"AC" * 75] * 700
+    seqs += [bytes(r) for r in np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (500, 150))]]
+    k, size = 25, 1 << 24
+    ref = oracle.count(None, k, size, lower=1, reads=seqs)
+    for skew, reads in ((True, seqs), (False, seqs[-500:])):
+        ctx.prof(True)
+        ctx.prof_reset()
+        t = capi.CountTable(ctx, k, size, mode=capi.COUNT_P2L)
+        blk = ctx.upload(capi.PackedReads.from_reads(reads))
+        t.add(blk)
+        rec = t.finish(1)
+        launched = ctx.prof_dict()
+        ctx.prof(False)
+        assert ("k_bin_count" in launched) == skew, launched
+        assert "k_part1" in launched and "k_part2" in launched
+        if skew:
+            keys, counts, pos = rec.get()
+            assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts.astype(np.uint32))
+            assert np.array_equal(pos, ref.pos)
+            assert int(counts.max()) == 2500 * 126
+        for x in (rec, blk, t):
+            x.free()
 
 
 def test_key_range_passes_partition_the_output(ctx, small_trio):

@@ -135,6 +135,7 @@ rfx_table* rfx_count_begin(rfx_ctx*, int k, int canonical, int lsize, uint64_t c
 #define RFX_COUNT_AUTO 0
 #define RFX_COUNT_TABLE 1
 #define RFX_COUNT_P2L 2
+#define RFX_COUNT_MSP 3
 int rfx_count_set_mode(rfx_table*, int mode);
 int rfx_count_add(rfx_table*, const rfx_reads*);
 /* Merge pre-aggregated (key,count) pairs (device pointers): owner-side reduce of the multi-GPU

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "librufus_hip.so")
 
 HISTO_BINS = 10002
 PACK_COUNT, PACK_FILTER = 1, 2
-COUNT_AUTO, COUNT_TABLE, COUNT_P2L = 0, 1, 2
+COUNT_AUTO, COUNT_TABLE, COUNT_P2L, COUNT_MSP = 0, 1, 2, 3
 E_FULL, E_RANGE, E_MIXEDCASE = -4, -7, -6
 
 u8p, u32p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)

@@ -678,14 +678,16 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
       rfxk::part1_fused(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P2, t->pos_lo, t->pos_hi, G, buf_a, coarse_cur,
                         (uint32_t)cap64, cnt, coarse_cur + ncur);
       rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
-      rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P, P2, cfg, coarse_cur, (uint32_t)cap64);
+      rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, cfg.bin_shift, coarse_cur, (uint32_t)cap64, nullptr, nullptr,
+                  ~0ull, "k_part2");
       if (queue_read(c, &flag, coarse_cur + ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) flag = 1;
     }
     dfree(c, coarse_cur); dfree(c, buf_a); dfree(c, fine_cur);
     fine_cur = nullptr;
     if (!flag) {
       drop();
-      t->segs->push_back(rfx_segment{inst, windows, bin_start});
+      t->segs->push_back(rfx_segment{inst, windows, bin_start, windows});
+      t->seg_kind = RFX_COUNT_P2L;
       return RFX_OK;
     }
     dfree(c, inst);
@@ -715,14 +717,15 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
       return RFX_E_NOMEM;
     }
     rfxk::part1(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P2, t->pos_lo, t->pos_hi, G, cnt1, bin_start, buf_a);
-    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P, P2, cfg, nullptr, 0);
+    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, cfg.bin_shift, nullptr, 0, nullptr, nullptr, ~0ull, "k_part2");
     dfree(c, buf_a);
   } else {
     rfxk::bin_scatter(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt, bin_start,
                       inst);
   }
   drop();
-  t->segs->push_back(rfx_segment{inst, total, bin_start});
+  t->segs->push_back(rfx_segment{inst, total, bin_start, total});
+  t->seg_kind = RFX_COUNT_P2L;
   return RFX_OK;
 }
 
@@ -758,7 +761,7 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
   if (e != hipSuccess) { hip_fail(e, "p2l_emit"); cleanup(); return nullptr; }
   rfxk::tmp_start(c, d_bs, nseg, P, tmp_start);
   rfxk::leaf(c, d_inst, d_bs, nseg, h_inst[0], h_bs[0], P, cfg, lower, upper, tmp_start, tmp_keys, tmp_counts, n_surv,
-             d_err);
+             d_err, nullptr);
   rfxk::scan_tail(c, n_surv, P);
   uint64_t total_out = 0;
   unsigned int err = 0;
@@ -779,12 +782,190 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
   return rec;
 }
 
+// ---- MSP path (rfx_msp.hip) ---------------------------------------------------------------------
+// Partition one read block into super-k-mer records grouped by minimizer bin.  The sizes of the
+// intermediate buffers are estimates (records per k-mer depend on the sequence); the device reports
+// when one did not hold and the block is redone with exact sizes.
+static int msp_add(rfx_table* t, const rfx_reads* r) {
+  rfx_ctx* c = t->ctx;
+  const uint64_t windows = r->n_bases > (uint64_t)(t->k - 1) * r->n ? r->n_bases - (uint64_t)(t->k - 1) * r->n : 0;
+  if (windows >= (1ull << 32)) return RFX_E_RANGE;
+  if (windows == 0) return RFX_OK;
+  if (!t->p2l_bins) {
+    if (const char* ev = getenv("RFX_P2L_BINS")) t->p2l_bins = (uint32_t)atoi(ev);
+    uint32_t P = 256;
+    while (P < 8192 && (uint64_t)P * 16384 < windows) P <<= 1;
+    if (!t->p2l_bins) t->p2l_bins = P;
+    if (t->p2l_bins < 256) t->p2l_bins = 256;    // 128 coarse bins x >= 2 sub-bins
+    if (t->p2l_bins > 8192) t->p2l_bins = 8192;  // 6-bit sub-bin field, 16-bit LDS histogram
+  }
+  const uint32_t P = t->p2l_bins, P1 = (uint32_t)rfxk::p1_bins(), P2 = P / P1;
+  const int bin_bits = ceil_log2(P);
+  const int G = rfxk::p2l_grid(c, r->n);
+  const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
+  const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+  uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)G * P * 4);
+  uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
+  uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
+  uint32_t* fine_cur = (uint32_t*)dmalloc(c, (size_t)P * 4);
+  uint32_t* cur = (uint32_t*)dmalloc(c, (ncur + 1) * 4);  // [ncur] = flag
+  uint64_t *buf_a = nullptr, *inst = nullptr;
+  auto drop = [&] { dfree(c, cnt); dfree(c, gsum); dfree(c, fine_cur); dfree(c, cur); dfree(c, buf_a); };
+  auto fail = [&](int rc) { drop(); dfree(c, bin_start); dfree(c, inst); return rc; };
+  if (!cnt || !gsum || !bin_start || !fine_cur || !cur) return fail(RFX_E_NOMEM);
+
+  // ~3.2 k-mers per record on ordinary sequence: room for 2.5, coarse bins 25 % above even
+  uint64_t cap_b = windows * 2 / 5 + 65536;
+  if (cap_b > windows) cap_b = windows;
+  uint64_t cap_a = cap_b / P1 + cap_b / (4ull * P1) + 16384;
+  unsigned int flag = 1;
+  uint64_t total = 0;
+  if (!getenv("RFX_P2L_EXACT")) {
+    buf_a = (uint64_t*)dmalloc(c, cap_a * P1 * 8);
+    inst = (uint64_t*)dmalloc(c, cap_b * 8);
+    if (!buf_a || !inst) return fail(RFX_E_NOMEM);
+    HIPCHK(hipMemsetAsync(cur, 0, (ncur + 1) * 4, c->stream));
+    HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
+    rfxk::msp_part1(c, rv, t->k, t->canonical, bin_bits, 0, G, buf_a, cur, (uint32_t)cap_a, cnt, cur + ncur);
+    rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
+    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
+    if (queue_read(c, &flag, cur + ncur, 4) != hipSuccess || queue_read(c, &total, bin_start + P, 8) != hipSuccess ||
+        ctx_sync(c) != hipSuccess)
+      return fail(RFX_E_HIP);
+    if (total > cap_b) flag = 1;
+  }
+  if (flag) {  // exact redo: 32-bit histogram, then scatter into coarse bins as large as the fullest one
+    dfree(c, buf_a);
+    dfree(c, inst);
+    buf_a = inst = nullptr;
+    rfxk::msp_part1(c, rv, t->k, t->canonical, bin_bits, 1, G, nullptr, nullptr, 0, cnt, nullptr);
+    rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
+    std::vector<uint64_t> bs((size_t)P + 1);
+    if (queue_read(c, bs.data(), bin_start, ((size_t)P + 1) * 8) != hipSuccess || ctx_sync(c) != hipSuccess)
+      return fail(RFX_E_HIP);
+    total = bs[P];
+    cap_a = 1;
+    for (uint32_t cb = 0; cb < P1; ++cb) cap_a = std::max<uint64_t>(cap_a, bs[(size_t)(cb + 1) * P2] - bs[(size_t)cb * P2]);
+    cap_b = total ? total : 1;
+    buf_a = (uint64_t*)dmalloc(c, cap_a * P1 * 8);
+    inst = (uint64_t*)dmalloc(c, cap_b * 8);
+    if (!buf_a || !inst) return fail(RFX_E_NOMEM);
+    HIPCHK(hipMemsetAsync(cur, 0, (ncur + 1) * 4, c->stream));
+    HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
+    rfxk::msp_part1(c, rv, t->k, t->canonical, bin_bits, 2, G, buf_a, cur, (uint32_t)cap_a, nullptr, cur + ncur);
+    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
+    if (queue_read(c, &flag, cur + ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) return fail(RFX_E_HIP);
+    if (flag) {
+      snprintf(g_err, sizeof g_err, "MSP: exact partition overflowed (internal error)");
+      return fail(RFX_E_HIP);
+    }
+  }
+  drop();
+  t->segs->push_back(rfx_segment{inst, total, bin_start, windows});
+  t->seg_kind = RFX_COUNT_MSP;
+  return RFX_OK;
+}
+
+// Count every minimizer bin in LDS, then put the survivors in (pos,key) order.
+static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
+  rfx_ctx* c = t->ctx;
+  const uint32_t P = t->p2l_bins, P1 = (uint32_t)rfxk::p1_bins();
+  const int nseg = (int)t->segs->size();
+  std::vector<const uint64_t*> h_inst(nseg), h_bs(nseg);
+  uint64_t kmers = 0;
+  for (int i = 0; i < nseg; ++i) {
+    h_inst[i] = (*t->segs)[i].inst;
+    h_bs[i] = (*t->segs)[i].bin_start;
+    kmers += (*t->segs)[i].kmers;
+  }
+  const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
+  const uint64_t** d_inst = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
+  const uint64_t** d_bs = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
+  uint32_t* cur = (uint32_t*)dmalloc(c, (ncur + 2) * 4);  // [ncur] = capacity flag, [ncur+1] = error
+  std::vector<uint32_t> h_cur(ncur + 2);
+  uint64_t *aw = nullptr, *bw = nullptr, *tmp_w = nullptr, *bsq = nullptr, *n_surv = nullptr;
+  uint32_t *ac = nullptr, *bc = nullptr, *tmp_c = nullptr, *fcur = nullptr;
+  auto drop_try = [&] {
+    dfree(c, aw); dfree(c, ac); dfree(c, bw); dfree(c, bc); dfree(c, tmp_w); dfree(c, tmp_c); dfree(c, bsq);
+    dfree(c, n_surv); dfree(c, fcur);
+    aw = bw = tmp_w = bsq = n_surv = nullptr;
+    ac = bc = tmp_c = fcur = nullptr;
+  };
+  auto cleanup = [&] { drop_try(); dfree(c, d_inst); dfree(c, d_bs); dfree(c, cur); };
+  if (!d_inst || !d_bs || !cur) { cleanup(); return nullptr; }
+  hipError_t e = upload(c, d_inst, h_inst.data(), nseg * sizeof(void*));
+  if (e == hipSuccess) e = upload(c, d_bs, h_bs.data(), nseg * sizeof(void*));
+  if (e != hipSuccess) { hip_fail(e, "msp_emit"); cleanup(); return nullptr; }
+
+  // Survivors per coarse pos bin: a guess first (a quarter of the instances when singletons are
+  // dropped, else 60 %); if a bin overflows, the cursors of that run say exactly what is needed.
+  double frac = lower >= 2 ? 0.25 : 0.6;
+  if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
+  uint64_t cap = (uint64_t)((double)kmers * frac) / P1;
+  cap += cap / 8 + 4096;
+  rfx_records* rec = nullptr;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
+    const uint64_t room = cap * P1;
+    uint32_t Pq = 256;
+    while (Pq < 32768 && (uint64_t)Pq * 1536 < room) Pq <<= 1;
+    const uint32_t P2q = Pq / P1;
+    const rfx_ord_cfg cfg = ord_cfg(t, ceil_log2(Pq));
+    aw = (uint64_t*)dmalloc(c, room * 8);
+    ac = (uint32_t*)dmalloc(c, room * 4);
+    bsq = (uint64_t*)dmalloc(c, ((size_t)Pq + 1) * 8);
+    fcur = (uint32_t*)dmalloc(c, (size_t)Pq * 4);
+    if (!aw || !ac || !bsq || !fcur) break;
+    e = hipMemsetAsync(cur, 0, (ncur + 2) * 4, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(bsq, 0, ((size_t)Pq + 1) * 8, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(fcur, 0, (size_t)Pq * 4, c->stream);
+    if (e != hipSuccess) { hip_fail(e, "msp_emit"); break; }
+    rfxk::msp_leaf(c, d_inst, d_bs, nseg, h_inst[0], h_bs[0], P, t->k, t->canonical, t->lut_t, t->ntab, cfg.sel_bits,
+                   cfg.c_bits - 7, t->pos_lo, t->pos_hi, lower, upper, aw, ac, cur, (uint32_t)cap, cur + ncur,
+                   cur + ncur + 1);
+    rfxk::surv_hist(c, aw, cur, (uint32_t)cap, P2q, cfg.bin_shift, bsq);
+    rfxk::scan_tail(c, bsq, Pq);
+    bw = (uint64_t*)dmalloc(c, room * 8);
+    bc = (uint32_t*)dmalloc(c, room * 4);
+    if (!bw || !bc) break;
+    rfxk::part2(c, aw, bw, bsq, fcur, P2q, cfg.bin_shift, cur, (uint32_t)cap, ac, bc, ~0ull, "k_surv_part2");
+    uint64_t total_out = 0;
+    e = queue_read(c, &total_out, bsq + Pq, 8);
+    if (e == hipSuccess) e = queue_read(c, h_cur.data(), cur, (ncur + 2) * 4);
+    if (e == hipSuccess) e = ctx_sync(c);  // h_inst / h_bs stay alive until here
+    if (e != hipSuccess) { hip_fail(e, "msp_emit"); break; }
+    if (h_cur[ncur + 1]) {
+      snprintf(g_err, sizeof g_err, "MSP: a bin could not be split far enough to fit LDS");
+      break;
+    }
+    if (h_cur[ncur]) {  // a coarse pos bin overflowed: rerun with what the fullest one needs
+      if (attempt == 1) {
+        snprintf(g_err, sizeof g_err, "MSP: survivor bins overflowed twice (internal error)");
+        break;
+      }
+      cap = 1;
+      for (uint32_t cb = 0; cb < P1; ++cb) cap = std::max<uint64_t>(cap, h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
+      drop_try();
+      continue;
+    }
+    // every survivor is kept and fine bins are exact, so the sort writes the records in place
+    rec = records_alloc(c, t->k, t->lsize, t->cols, total_out);
+    if (rec)
+      rfxk::surv_sort(c, bw, bc, bsq, Pq, cfg.bin_shift, t->lut_tinv, t->ntab, cfg.sel_bits, rec->keys, rec->counts,
+                      rec->pos);
+    break;
+  }
+  cleanup();
+  return rec;
+}
+
 static void p2l_drop_segments(rfx_table* t) {
   for (auto& sg : *t->segs) {
     dfree(t->ctx, sg.inst);
     dfree(t->ctx, sg.bin_start);
   }
   t->segs->clear();
+  t->seg_kind = 0;
 }
 
 // Table load (distinct / cap) above which the count kernel stops taking chunks and the host grows
@@ -804,8 +985,15 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   (void)hipSetDevice(c->device);
   if (r->n == 0) return RFX_OK;
   if (t->mode != RFX_COUNT_TABLE && !t->table_active && t->lut_t) {  // P2L needs 2k <= 62 and full-rank M
-    const int rc = p2l_add(t, r);
-    if (rc == RFX_OK || t->mode == RFX_COUNT_P2L) return rc;
+    // segments of one table are of one kind; MSP where the record format allows it
+    const bool msp = t->seg_kind ? t->seg_kind == RFX_COUNT_MSP
+                                 : (t->mode != RFX_COUNT_P2L && rfxk::msp_k_ok(t->k) && !getenv("RFX_NO_MSP"));
+    if (t->mode == RFX_COUNT_MSP && !msp) {
+      snprintf(g_err, sizeof g_err, "RFX_COUNT_MSP needs 23 <= k <= 25");
+      return RFX_E_INVAL;
+    }
+    const int rc = msp ? msp_add(t, r) : p2l_add(t, r);
+    if (rc == RFX_OK || t->mode == RFX_COUNT_P2L || t->mode == RFX_COUNT_MSP) return rc;
     if (rc != RFX_E_NOMEM && rc != RFX_E_RANGE) return rc;  // auto: no room for the instance lists
   }
   {
@@ -859,7 +1047,7 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
 }
 
 int rfx_count_set_mode(rfx_table* t, int mode) {
-  if (!t || mode < RFX_COUNT_AUTO || mode > RFX_COUNT_P2L) return RFX_E_INVAL;
+  if (!t || mode < RFX_COUNT_AUTO || mode > RFX_COUNT_MSP) return RFX_E_INVAL;
   t->mode = mode;
   return RFX_OK;
 }
@@ -898,12 +1086,12 @@ rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint
   (void)hipSetDevice(c->device);
   if (!t->segs->empty()) {
     if (!t->table_active) {
-      rfx_records* r = p2l_emit(t, lower, upper);
+      rfx_records* r = t->seg_kind == RFX_COUNT_MSP ? msp_emit(t, lower, upper) : p2l_emit(t, lower, upper);
       if (r && histo && rfx_records_histo(r, histo) != RFX_OK) { rfx_records_free(r); return nullptr; }
       return r;
     }
     // both paths hold data: fold the instance lists into the table as (key,count) pairs
-    rfx_records* part = p2l_emit(t, 1, ~0ull);
+    rfx_records* part = t->seg_kind == RFX_COUNT_MSP ? msp_emit(t, 1, ~0ull) : p2l_emit(t, 1, ~0ull);
     if (!part) return nullptr;
     const int rc = rfx_count_add_pairs_dev(t, part->keys, part->counts, part->n);
     rfx_records_free(part);

@@ -92,9 +92,10 @@ struct rfx_ord_cfg {
 };
 
 struct rfx_segment {  // the k-mer instances of one rfx_count_add call, grouped by bin
-  uint64_t* inst;
-  uint64_t n;
+  uint64_t* inst;       // P2L: sortable words; MSP: super-k-mer records
+  uint64_t n;           // entries of inst
   uint64_t* bin_start;  // device, P+1 entries
+  uint64_t kmers;       // upper bound of the k-mer instances represented (P2L: n)
 };
 
 struct rfx_reads_view {
@@ -133,7 +134,8 @@ struct rfx_table {
   // P2L path (rfx_p2l.hip): instances partitioned by bin, counted in LDS at finish
   int mode;           // 0 auto, 1 global table only, 2 P2L only
   int table_active;   // the global table holds data
-  uint32_t p2l_bins;  // 0 until the first P2L add
+  uint32_t p2l_bins;  // 0 until the first P2L / MSP add
+  int seg_kind;       // what the segments hold: 0 nothing yet, RFX_COUNT_P2L words, RFX_COUNT_MSP records
   std::vector<rfx_segment>* segs;
   uint64_t* lut_t;     // device LUT of T (key -> sortable word), null when M is rank deficient
   uint64_t* lut_tinv;  // device LUT of T^-1
@@ -220,12 +222,29 @@ void part1(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k
 void part1_fused(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical,
                  const rfx_ord_cfg&, uint32_t P2, uint64_t pos_lo, uint64_t pos_hi, int grid, uint64_t* buf_a,
                  uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows, unsigned int* flag);
-void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur, uint32_t P,
-           uint32_t P2, const rfx_ord_cfg&, const uint32_t* coarse_cur, uint32_t cap_a);
+// coarse_cur != null: coarse bins are fixed-capacity (cap_a) with their fill in coarse_cur (padded cursors);
+// pay_a != null: 32-bit payload per word moves along.  sub-bin of a word = (w >> shift2) & (P2 - 1).
+void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur,
+           uint32_t P2, int shift2, const uint32_t* coarse_cur, uint32_t cap_a, const uint32_t* pay_a,
+           uint32_t* pay_b, uint64_t cap_b /* entries buf_b can hold */, const char* span);
+// MSP path (rfx_msp.hip)
+int msp_k_ok(int k);
+void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bits, int hmode, int grid,
+               uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows, unsigned int* flag);
+void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
+              const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
+              int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
+              uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err);
+void surv_hist(rfx_ctx*, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,
+               uint64_t* fine_tot);
+void surv_sort(rfx_ctx*, const uint64_t* bw, const uint32_t* bc, const uint64_t* bs, uint32_t P, int bin_shift,
+               const uint64_t* lut_inv, int ntab, int sel_bits, uint64_t* out_keys, uint32_t* out_counts,
+               uint64_t* out_pos);
 void tmp_start(rfx_ctx*, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out /* P+1 */);
 void leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, const uint64_t* inst0,
-          const uint64_t* bs0, uint32_t P, const rfx_ord_cfg&, uint64_t lower, uint64_t upper, const uint64_t* tmp_start, uint64_t* tmp_w,
-          uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err);
+          const uint64_t* bs0, uint32_t P, const rfx_ord_cfg&, uint64_t lower, uint64_t upper,
+          const uint64_t* tmp_start, uint64_t* tmp_w, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err,
+          const uint32_t* pay0 /* null: every word counts 1 */);
 void scan_tail(rfx_ctx*, uint64_t* v, uint64_t n);  // exclusive scan in place, v[n] = total
 void leaf_compact(rfx_ctx*, const uint64_t* tmp_w, const uint32_t* tmp_counts, const uint64_t* tmp_start,
                   const uint64_t* out_off, uint32_t P, const uint64_t* lut_inv, int ntab, int sel_bits,

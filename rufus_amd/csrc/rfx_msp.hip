@@ -1,0 +1,540 @@
+// "MSP" count path (minimizer super-k-mer partition), the default for 23 <= k <= 25.
+//
+// The P2L path writes every k-mer instance to HBM as an 8-byte sortable word (twice: coarse and fine
+// partition) and reads it back once: 32 B of traffic per instance, and one GF(2) LUT multiply per
+// instance.  Consecutive k-mers of a read overlap in k-1 bases, so here they travel together:
+//
+//   k_msp_part1  reads -> for every k-mer the minimum of hash(canonical m-mer) over its 15 m-mers
+//                (m = k-14); the minimizer picks one of P bins.  Runs of <= 4 consecutive k-mers with
+//                the same bin become ONE 8-byte record (k+3 bases, run length, fine sub-bin).
+//                ~3.2 k-mers per record -> 2.5 B per instance.  128 coarse bins, LDS-staged runs.
+//   k_part2      coarse -> fine bins (same kernel as P2L; the sub-bin is in the record)
+//   k_msp_leaf   one workgroup per fine bin: expand the records, count canonical k-mers in an LDS
+//                hash table; every instance of a k-mer has the same minimizer, so counts are final.
+//                Only the survivors (lower <= count <= upper) get w = T * key and leave, appended to
+//                128 coarse pos bins.
+//   k_surv_hist, k_part2<payload>, k_leaf<payload>, k_leaf_compact
+//                the (few) survivors are put in (pos,key) order by the P2L machinery.
+//
+// The result is the same sorted record list (jf/include/jellyfish/sorted_dumper.hpp:80-112 order).
+#include "rfx_devutil.h"
+#include "rfx_internal.h"
+
+namespace {
+
+constexpr int MSP_WL = 15;    // m-mers per k-mer (window of the sliding minimum); m = k - (MSP_WL - 1)
+constexpr int MSP_NMAX = 4;   // k-mers per record: k + 3 <= 28 bases = 56 bits
+constexpr uint64_t MSP_EMPTY = 1ull << 55;  // no record looks like this: a 1-k-mer record uses 2k <= 50 bits
+
+__device__ __forceinline__ uint32_t mmer_hash(uint32_t c) {
+  c *= 0x9E3779B1u;
+  c ^= c >> 15;
+  c *= 0x85EBCA77u;
+  c ^= c >> 13;
+  return c;
+}
+
+// The minimum of 15 hashes crowds towards 0: remix before taking the top bits.
+__device__ __forceinline__ uint32_t msp_bin(uint32_t minh, int bin_bits) {
+  uint32_t x = minh * 0xC2B2AE3Du;
+  x ^= x >> 16;
+  x *= 0x27D4EB2Fu;
+  return x >> (32 - bin_bits);
+}
+
+// HMODE 0: scatter into fixed-capacity coarse bins + 16-bit fine histogram (one pass, optimistic)
+//       1: 32-bit fine histogram only            } the exact redo after HMODE 0 raised its flag;
+//       2: scatter only                          } cap_a then comes from the cursors of the failed run
+template <bool CANON, int HMODE>
+__global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k, int bin_bits,
+                                                         uint64_t* __restrict__ buf_a,
+                                                         uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
+                                                         uint32_t* __restrict__ cnt_rows,
+                                                         unsigned int* __restrict__ flag) {
+  __shared__ uint64_t s_stage[HMODE == 1 ? 1 : P1_STAGE];
+  __shared__ uint8_t s_sbin[HMODE == 1 ? 1 : P1_STAGE];
+  __shared__ uint32_t s_cnt[P1_BINS], s_start[P1_BINS + 1], s_gbase[P1_BINS];
+  __shared__ uint32_t s_fine[HMODE == 0 ? 4096 : HMODE == 1 ? 8192 : 1];
+  __shared__ uint32_t s_maxlen;
+  const uint32_t P = 1u << bin_bits;
+  const int sub_bits = bin_bits - 7;  // P1_BINS = 2^7 coarse bins
+  const int m = k - (MSP_WL - 1);
+  const uint32_t mmask = (1u << (2 * m)) - 1;
+  const int rmshift = 2 * (m - 1);
+  uint32_t blk_total = 0;
+  if (HMODE == 0)
+    for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) s_fine[i] = 0;
+  if (HMODE == 1)
+    for (uint32_t i = threadIdx.x; i < 8192; i += blockDim.x) s_fine[i] = 0;
+  if (threadIdx.x < P1_BINS) s_cnt[threadIdx.x] = 0;
+  const uint32_t n_chunks = (rv.n + P2_BLOCK - 1) / P2_BLOCK;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t r = chunk * P2_BLOCK + threadIdx.x;
+    const bool live = r < rv.n;
+    const uint32_t len = live ? rv.len[r] : 0;
+    const uint32_t lenp = live ? len + 1 : 0;  // one virtual invalid base closes the last run
+    const uint64_t* cw = rv.codes + (live ? rv.word_off[r] : 0);
+    const uint32_t* cm = rv.acgt + (live ? rv.word_off[r] : 0);
+    if (threadIdx.x == 0) s_maxlen = 0;
+    __syncthreads();
+    atomicMax(&s_maxlen, lenp);
+    __syncthreads();
+    const uint32_t n_phase = (s_maxlen + P1_S - 1) / P1_S;
+    uint32_t fm = 0, rm = 0, cur_m = 0, run_bin = 0;
+    uint64_t hist = 0, cur_w = 0;
+    int filled = 0, run_n = 0;
+    uint32_t a[MSP_WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-14 .. p0+7
+#pragma unroll
+    for (int i = 0; i < MSP_WL - 1 + P1_S; ++i) a[i] = ~0u;
+    for (uint32_t ph = 0; ph < n_phase; ++ph) {
+      uint64_t wv[P1_S];
+      uint32_t br[P1_S];  // (coarse bin << 16) | rank, or ~0: no record closed at this base
+      const uint32_t p0 = ph * P1_S;
+      if ((ph & 3) == 0 && p0 < len) {
+        cur_w = cw[p0 >> 5];
+        cur_m = cm[p0 >> 5];
+      }
+      // window minimum = min(suffix minimum of the 14 old hashes, prefix minimum of the new ones)
+      uint32_t sfx[MSP_WL - 1];
+      sfx[MSP_WL - 2] = a[MSP_WL - 2];
+#pragma unroll
+      for (int i = MSP_WL - 3; i >= 0; --i) sfx[i] = min(a[i], sfx[i + 1]);
+      uint32_t pm = ~0u;
+#pragma unroll
+      for (int b = 0; b < P1_S; ++b) {
+        br[b] = ~0u;
+        if (p0 + b < lenp) {
+          const bool real = p0 + b < len;
+          const uint32_t code = real ? (uint32_t)cur_w & 3u : 0u;
+          const bool valid = real && (cur_m & 1u);
+          cur_w >>= 2;
+          cur_m >>= 1;
+          fm = ((fm << 2) | code) & mmask;
+          rm = (rm >> 2) | ((3u - code) << rmshift);
+          const uint32_t h = mmer_hash(CANON ? min(fm, rm) : fm);
+          a[MSP_WL - 1 + b] = h;
+          pm = min(pm, h);
+          filled = valid ? filled + 1 : 0;
+          const bool kvalid = filled >= k;
+          const uint32_t bin = msp_bin(min(sfx[b], pm), bin_bits);
+          if (run_n && (!kvalid || bin != run_bin || run_n == MSP_NMAX)) {
+            // close the run that ended at the previous base: `hist` still ends there
+            if (HMODE != 1) {
+              const int L = k + run_n - 1;
+              const uint32_t coarse = run_bin >> sub_bits;
+              wv[b] = (hist & ((1ull << (2 * L)) - 1)) | ((uint64_t)(run_n - 1) << 56) |
+                      ((uint64_t)(run_bin & ((1u << sub_bits) - 1)) << 58);
+              br[b] = (coarse << 16) | atomicAdd(&s_cnt[coarse], 1u);
+            }
+            if (HMODE == 0) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
+            if (HMODE == 1) atomicAdd(&s_fine[run_bin], 1u);
+            run_n = 0;
+          }
+          if (kvalid) {
+            if (!run_n) run_bin = bin;
+            ++run_n;
+          }
+          hist = (hist << 2) | code;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < MSP_WL - 1; ++i) a[i] = a[i + P1_S];
+      if (HMODE == 1) continue;
+      __syncthreads();
+      // reserve this phase's runs now; the round trip of the global atomic hides behind scan + staging
+      uint32_t cn = 0, at = 0;
+      if (threadIdx.x < P1_BINS) {
+        cn = s_cnt[threadIdx.x];
+        if (cn) at = atomicAdd(&coarse_cur[threadIdx.x * P1_CUR_STRIDE], cn);
+      }
+      if (threadIdx.x < 64) wave_scan256(s_cnt, s_start, P1_BINS);
+      __syncthreads();
+      if (threadIdx.x < P1_BINS) s_cnt[threadIdx.x] = 0;
+#pragma unroll
+      for (int b = 0; b < P1_S; ++b)
+        if (br[b] != ~0u) {
+          const uint32_t cb = br[b] >> 16, e = s_start[cb] + (br[b] & 0xFFFFu);
+          s_stage[e] = wv[b];
+          s_sbin[e] = (uint8_t)cb;
+        }
+      if (threadIdx.x < P1_BINS) {
+        if ((uint64_t)at + cn > cap_a) {  // over capacity: the run is dropped, the host redoes the block
+          atomicExch(flag, 1u);
+          s_gbase[threadIdx.x] = 0xFFFFFFFFu;
+        } else {
+          s_gbase[threadIdx.x] = threadIdx.x * cap_a + at;
+        }
+      }
+      __syncthreads();
+      const uint32_t total = s_start[P1_BINS];
+      blk_total += total;
+      for (uint32_t e = threadIdx.x; e < total; e += P2_BLOCK) {
+        const uint32_t cb = s_sbin[e];
+        if (s_gbase[cb] != 0xFFFFFFFFu) buf_a[(uint64_t)s_gbase[cb] + (e - s_start[cb])] = s_stage[e];
+      }
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  if (HMODE == 0) {
+    if (threadIdx.x == 0) s_maxlen = 0;
+    __syncthreads();
+    uint32_t sum = 0;
+    for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) {
+      const uint32_t v = (s_fine[b >> 1] >> ((b & 1u) * 16)) & 0xFFFFu;
+      cnt_rows[(uint64_t)blockIdx.x * P + b] = v;
+      sum += v;
+    }
+    // a wrapped 16-bit counter (carry into the neighbour or out of the word) leaves the sum short
+    atomicAdd(&s_maxlen, sum);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_maxlen != blk_total) atomicExch(flag, 1u);
+  }
+  if (HMODE == 1)
+    for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) cnt_rows[(uint64_t)blockIdx.x * P + b] = s_fine[b];
+}
+
+__device__ __forceinline__ uint64_t revcomp_bases(uint64_t s, int nbases) {
+  uint64_t y = __brevll(~s);  // complement, then reverse: bit pairs end up swapped inside
+  y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+  return y >> (64 - 2 * nbases);
+}
+
+__device__ __forceinline__ uint32_t split_hash(uint64_t key) {
+  return (uint32_t)((key * 0xD6E8FEB86659FD93ull) >> 32);
+}
+
+constexpr int MSP_ILP = 8;
+
+// One workgroup per fine minimizer bin.  A bin (or part of it) whose distinct k-mers overflow the LDS
+// table is split in two by a hash bit and each half retried -- results already appended stay valid.
+template <bool CANON>
+__global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
+    const uint64_t* const* __restrict__ seg_inst, const uint64_t* const* __restrict__ seg_bs, int nseg,
+    const uint64_t* __restrict__ inst0, const uint64_t* __restrict__ bs0, uint32_t P, int k,
+    const uint64_t* __restrict__ g_lut, int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi,
+    uint64_t lower, uint64_t upper, uint64_t* __restrict__ out_w, uint32_t* __restrict__ out_c,
+    uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err,
+    int dbg) {
+  __shared__ __attribute__((aligned(16))) unsigned long long s_keys[LEAF_TBL];
+  __shared__ uint32_t s_cnt[LEAF_TBL];
+  __shared__ uint64_t s_lut[8 * 256];
+  __shared__ uint32_t s_pc[P1_BINS];
+  __shared__ uint64_t s_pbase[P1_BINS];
+  __shared__ uint32_t s_nd, s_ovf;
+  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
+  const uint64_t kmask = (1ull << (2 * k)) - 1;
+  const ulonglong2* s_bkt = (const ulonglong2*)s_keys;
+
+  uint64_t pre[MSP_ILP];
+  uint64_t pre_a = 0, pre_e = 0;
+  auto prefetch = [&](uint32_t b) {
+    if (b >= P) return;
+    pre_a = bs0[b];
+    pre_e = bs0[b + 1];
+#pragma unroll
+    for (int u = 0; u < MSP_ILP; ++u) {
+      const uint64_t i = pre_a + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
+      pre[u] = i < pre_e ? inst0[i] : MSP_EMPTY;
+    }
+  };
+  prefetch(blockIdx.x);
+
+  for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
+    const uint64_t a0 = pre_a, e0 = pre_e;
+    bool prefetched_next = false;
+    // sub-range (r, j): k-mers whose top r bits of split_hash equal j; depth-first over the halves
+    int r = 0;
+    uint32_t j = 0;
+    bool failed = false;
+    for (;;) {
+      for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
+        s_keys[i] = RFX_EMPTY;
+        s_cnt[i] = 0;
+      }
+      if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
+      if (threadIdx.x == 0) {
+        s_nd = 0;
+        s_ovf = 0;
+      }
+      __syncthreads();
+      for (int sg = 0; sg < nseg; ++sg) {
+        const uint64_t a = sg == 0 ? a0 : seg_bs[sg][bin], e = sg == 0 ? e0 : seg_bs[sg][bin + 1];
+        const uint64_t* __restrict__ src = sg == 0 ? inst0 : seg_inst[sg];
+        for (uint64_t base = a; base < e; base += (uint64_t)MSP_ILP * LEAF_BLOCK) {
+          uint64_t rec[MSP_ILP];
+          if (sg == 0 && base == a && !prefetched_next) {
+#pragma unroll
+            for (int u = 0; u < MSP_ILP; ++u) rec[u] = pre[u];
+          } else {
+#pragma unroll
+            for (int u = 0; u < MSP_ILP; ++u) {
+              const uint64_t i = base + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
+              rec[u] = i < e ? src[i] : MSP_EMPTY;
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < MSP_ILP; ++u) {
+            if (rec[u] == MSP_EMPTY) continue;
+            const int n = (int)((rec[u] >> 56) & 3u) + 1;
+            const uint64_t S = rec[u] & ((1ull << 56) - 1);
+            const uint64_t R = CANON ? revcomp_bases(S, k + n - 1) : 0;
+            for (int q = 0; q < n; ++q) {
+              const uint64_t fwd = (S >> (2 * (n - 1 - q))) & kmask;
+              uint64_t key = fwd;
+              if (CANON) {
+                const uint64_t rc = (R >> (2 * q)) & kmask;
+                key = rc < fwd ? rc : fwd;
+              }
+              if (r > 0 && (split_hash(key) >> (32 - r)) != j) continue;
+              if (dbg == 1) { if (key == 12345) atomicAdd(&s_cnt[0], 1u); continue; }
+              // Two-slot buckets read with one 16-byte LDS load: ~95 % of the probes end in the first
+              // bucket, so a wave rarely loops more than twice (it waits for its slowest lane).
+              uint32_t bkt = leaf_hash(key) >> 1;
+              for (;;) {
+                const ulonglong2 b2 = s_bkt[bkt];
+                uint32_t slot = 2 * bkt;
+                unsigned long long cur_k = b2.x;
+                if (b2.x != key && b2.x != RFX_EMPTY) {
+                  cur_k = b2.y;
+                  ++slot;
+                }
+                if (cur_k == RFX_EMPTY) {
+                  // A ticket per attempted new key keeps the table at <= LEAF_FILL keys, so probing always
+                  // ends.  One LDS atomic per wave hands them out (same-address LDS atomics serialise
+                  // lane by lane: 64 of them cost more than the rest of the insert).  A lane that then
+                  // loses its slot keeps the ticket: the count runs a little high, never low.
+                  const uint64_t want = __ballot(1);
+                  const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)want) - 1;
+                  uint32_t base = 0;
+                  if (lane == leader) base = atomicAdd(&s_nd, (uint32_t)__popcll(want));
+                  base = __shfl(base, leader);
+                  if (base + (uint32_t)__popcll(want & ((1ull << lane) - 1)) >= (uint32_t)LEAF_FILL) {
+                    s_ovf = 1;  // this pass is void
+                    break;
+                  }
+                  cur_k = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+                  if (cur_k == RFX_EMPTY) cur_k = key;
+                  else if (cur_k != key) continue;  // someone else's key took the slot: look at the bucket again
+                }
+                if (cur_k == key) {
+                  atomicAdd(&s_cnt[slot], 1u);
+                  break;
+                }
+                bkt = (bkt + 1) & (LEAF_TBL / 2 - 1);
+              }
+            }
+          }
+        }
+      }
+      if (!prefetched_next) {  // the next bin's loads fly while this one is emitted
+        prefetch(bin + gridDim.x);
+        prefetched_next = true;
+      }
+      __syncthreads();
+      const bool ovf = s_ovf != 0;
+      if (!ovf && dbg != 2) {
+        // survivors: key -> w in place, counted per coarse pos bin
+        for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
+          const uint64_t key = s_keys[i];
+          if (key == RFX_EMPTY) continue;
+          const uint32_t c = s_cnt[i];
+          uint64_t w = RFX_EMPTY;
+          if (c >= lower && c <= upper) {
+            w = gf2_mul(s_lut, key, ntab);
+            const uint64_t pos = w >> sel_bits;
+            if (pos >= pos_lo && pos < pos_hi) atomicAdd(&s_pc[(uint32_t)(w >> shift1)], 1u);
+            else w = RFX_EMPTY;
+          }
+          s_keys[i] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x < P1_BINS) {
+          const uint32_t cn = s_pc[threadIdx.x];
+          const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
+          if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
+            atomicExch(flag, 1u);
+            s_pbase[threadIdx.x] = ~0ull;
+          } else {
+            s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at;
+          }
+          s_pc[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
+          const uint64_t w = s_keys[i];
+          if (w == RFX_EMPTY) continue;
+          const uint32_t cb = (uint32_t)(w >> shift1);
+          const uint32_t o = atomicAdd(&s_pc[cb], 1u);
+          if (s_pbase[cb] != ~0ull) {
+            out_w[s_pbase[cb] + o] = w;
+            out_c[s_pbase[cb] + o] = s_cnt[i];
+          }
+        }
+      }
+      __syncthreads();
+      if (ovf) {  // split this sub-range
+        if (r >= LEAF_RMAX) {
+          failed = true;
+          break;
+        }
+        ++r;
+        j <<= 1;
+      } else {  // next sub-range in depth-first order
+        while (r > 0 && (j & 1u)) {
+          j >>= 1;
+          --r;
+        }
+        if (r == 0) break;
+        ++j;
+      }
+    }
+    if (failed && threadIdx.x == 0) atomicExch(err, 1u);
+    __syncthreads();
+  }
+}
+
+// Fine pos-bin sizes of the survivors: fine_tot[cb * P2 + sub] += ...  (64-bit counters, scanned later)
+__global__ __launch_bounds__(L2_BLOCK) void k_surv_hist(const uint64_t* __restrict__ buf_a,
+                                                         const uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
+                                                         uint32_t P2, int shift2, uint32_t W,
+                                                         unsigned long long* __restrict__ fine_tot) {
+  __shared__ uint32_t s_cnt[256];
+  const uint32_t cb = blockIdx.x / W, jj = blockIdx.x - cb * W;
+  const uint64_t a = (uint64_t)cb * cap_a, e = a + min(coarse_cur[cb * P1_CUR_STRIDE], cap_a);
+  if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint64_t i = a + (uint64_t)jj * L2_BLOCK + threadIdx.x; i < e; i += (uint64_t)W * L2_BLOCK)
+    atomicAdd(&s_cnt[(uint32_t)(buf_a[i] >> shift2) & (P2 - 1)], 1u);
+  __syncthreads();
+  if (threadIdx.x < P2 && s_cnt[threadIdx.x])
+    atomicAdd(&fine_tot[(uint64_t)cb * P2 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+}
+
+constexpr int SS_BLOCK = 512;
+constexpr int SS_CAP = 2048;
+
+// Final step: one fine pos bin of survivors (distinct words, all kept) -> its slice of the output
+// records in w order.  Bucket on the 8 bits below the bin prefix, rank inside the bucket.
+__global__ __launch_bounds__(SS_BLOCK) void k_surv_sort(const uint64_t* __restrict__ bw,
+                                                         const uint32_t* __restrict__ bc,
+                                                         const uint64_t* __restrict__ bs, uint32_t P, int bin_shift,
+                                                         const uint64_t* __restrict__ g_lut_inv, int ntab, int sel_bits,
+                                                         uint64_t* __restrict__ out_keys,
+                                                         uint32_t* __restrict__ out_counts,
+                                                         uint64_t* __restrict__ out_pos) {
+  __shared__ uint64_t s_lut[8 * 256];
+  __shared__ uint64_t s_w[SS_CAP], s_w2[SS_CAP];
+  __shared__ uint32_t s_c[SS_CAP], s_c2[SS_CAP];
+  __shared__ uint32_t s_bstart[LEAF_BUCKETS + 1], s_bfill[LEAF_BUCKETS];
+  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut_inv[i];
+  const int bsh = bin_shift > 8 ? bin_shift - 8 : 0;
+  for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
+    const uint64_t a = bs[bin];
+    const uint64_t n = bs[bin + 1] - a;
+    __syncthreads();
+    if (n == 0) continue;
+    if (n > (uint64_t)SS_CAP) {  // oversize bin (only adversarial input gets here): rank against the whole bin
+      for (uint64_t i = threadIdx.x; i < n; i += SS_BLOCK) {
+        const uint64_t wi = bw[a + i];
+        uint64_t rank = 0;
+        for (uint64_t q = 0; q < n; ++q) rank += bw[a + q] < wi;
+        out_keys[a + rank] = gf2_mul(s_lut, wi, ntab);
+        out_counts[a + rank] = bc[a + i];
+        out_pos[a + rank] = wi >> sel_bits;
+      }
+      continue;
+    }
+    if (threadIdx.x < LEAF_BUCKETS) s_bfill[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += SS_BLOCK) {
+      const uint64_t wi = bw[a + i];
+      s_w[i] = wi;
+      s_c[i] = bc[a + i];
+      atomicAdd(&s_bfill[(uint32_t)(wi >> bsh) & (LEAF_BUCKETS - 1)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) wave_scan256(s_bfill, s_bstart, LEAF_BUCKETS);
+    __syncthreads();
+    if (threadIdx.x < LEAF_BUCKETS) s_bfill[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += SS_BLOCK) {
+      const uint64_t wi = s_w[i];
+      const uint32_t bk = (uint32_t)(wi >> bsh) & (LEAF_BUCKETS - 1);
+      const uint32_t p = s_bstart[bk] + atomicAdd(&s_bfill[bk], 1u);
+      s_w2[p] = wi;
+      s_c2[p] = s_c[i];
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < (uint32_t)n; i += SS_BLOCK) {
+      const uint64_t wi = s_w2[i];
+      const uint32_t bk = (uint32_t)(wi >> bsh) & (LEAF_BUCKETS - 1);
+      const uint32_t b0 = s_bstart[bk], b1 = s_bstart[bk + 1];
+      uint32_t rank = b0;
+      for (uint32_t q = b0; q < b1; ++q) rank += s_w2[q] < wi;
+      out_keys[a + rank] = gf2_mul(s_lut, wi, ntab);
+      out_counts[a + rank] = s_c2[i];
+      out_pos[a + rank] = wi >> sel_bits;
+    }
+  }
+}
+
+}  // namespace
+
+namespace rfxk {
+
+int msp_k_ok(int k) { return k >= 23 && k <= 25; }  // m = k-14 in 9..11; k+3 bases fit 56 bits
+
+void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, int hmode, int grid,
+               uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows, unsigned int* flag) {
+  rfx_span sp(c, hmode == 1 ? "k_msp_count" : "k_msp_part1");
+#define RFX_MSP_P1(CANON, HM)                                                                                      \
+  hipLaunchKernelGGL((k_msp_part1<CANON, HM>), dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, k, bin_bits, buf_a, \
+                     coarse_cur, cap_a, cnt_rows, flag)
+  if (canonical) {
+    if (hmode == 0) RFX_MSP_P1(true, 0);
+    else if (hmode == 1) RFX_MSP_P1(true, 1);
+    else RFX_MSP_P1(true, 2);
+  } else {
+    if (hmode == 0) RFX_MSP_P1(false, 0);
+    else if (hmode == 1) RFX_MSP_P1(false, 1);
+    else RFX_MSP_P1(false, 2);
+  }
+#undef RFX_MSP_P1
+}
+
+void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
+              const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
+              int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
+              uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err) {
+  rfx_span sp(c, "k_msp_leaf");
+  const int dbg = getenv("RFX_MSP_DBG") ? atoi(getenv("RFX_MSP_DBG")) : 0;
+  const uint32_t grid = P < (uint32_t)c->n_cu * 4 ? P : (uint32_t)c->n_cu * 4;
+  if (canonical)
+    hipLaunchKernelGGL(k_msp_leaf<true>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0,
+                       P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w, out_c, cur, cap, flag,
+                       err, dbg);
+  else
+    hipLaunchKernelGGL(k_msp_leaf<false>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0,
+                       bs0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w, out_c, cur, cap,
+                       flag, err, dbg);
+}
+
+void surv_hist(rfx_ctx* c, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,
+               uint64_t* fine_tot) {
+  rfx_span sp(c, "k_surv_hist");
+  const uint32_t W = 8;
+  hipLaunchKernelGGL(k_surv_hist, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, coarse_cur, cap_a, P2, shift2,
+                     W, (unsigned long long*)fine_tot);
+}
+
+void surv_sort(rfx_ctx* c, const uint64_t* bw, const uint32_t* bc, const uint64_t* bs, uint32_t P, int bin_shift,
+               const uint64_t* lut_inv, int ntab, int sel_bits, uint64_t* out_keys, uint32_t* out_counts,
+               uint64_t* out_pos) {
+  rfx_span sp(c, "k_surv_sort");
+  const uint32_t grid = P < (uint32_t)c->n_cu * 8 ? P : (uint32_t)c->n_cu * 8;
+  hipLaunchKernelGGL(k_surv_sort, dim3(grid), dim3(SS_BLOCK), 0, c->stream, bw, bc, bs, P, bin_shift, lut_inv, ntab,
+                     sel_bits, out_keys, out_counts, out_pos);
+}
+
+}  // namespace rfxk

@@ -14,28 +14,9 @@
 // replaces jf/include/jellyfish/large_hash_array.hpp:298-302,:513-744 (hash insert) and
 // jf/include/jellyfish/sorted_dumper.hpp:80-112 (sorted dump) in one go.
 #include "rfx_internal.h"
+#include "rfx_devutil.h"
 
 namespace {
-
-constexpr int P2_BLOCK = 512;     // threads = reads per chunk in the partition kernels
-// Leaf geometry: 8192-slot LDS table + 2048-entry sort area = 120 KB, one 1024-thread workgroup per CU.
-// (Measured alternative: 4096 slots / 512 threads / 16 K bins gives two workgroups per CU and a 12 %
-// faster leaf, but the finer bins cost more than that in k_bin_count and k_part2.)  The next bin's
-// words are prefetched into registers while the current bin is being sorted and emitted.
-constexpr int LEAF_BLOCK = 1024;
-constexpr int LEAF_TBL_LOG2 = 13;
-constexpr int LEAF_TBL = 1 << LEAF_TBL_LOG2;  // LDS hash slots per bin round
-constexpr int LEAF_FILL = 6144;   // distinct keys allowed before the bin is split into more rounds
-constexpr int LEAF_SORT = 2048;   // survivors sorted per round
-constexpr int LEAF_RMAX = 20;
-
-__device__ __forceinline__ uint64_t gf2_mul(const uint64_t* __restrict__ lut, uint64_t key, int ntab) {
-  uint64_t r = 0;
-#pragma unroll
-  for (int t = 0; t < 8; ++t)
-    if (t < ntab) r ^= lut[t * 256 + (uint32_t)((key >> (8 * t)) & 255u)];
-  return r;
-}
 
 // Sortable word w = T * key (GF(2), 2k bits): the top lsize bits are pos = M * key, the low 2k-lsize
 // bits are the key bits at the free columns of M taken high to low.  T is invertible and numeric
@@ -167,15 +148,6 @@ __global__ __launch_bounds__(P2_BLOCK) void k_bin_scatter(rfx_reads_view rv, con
 //   k_part2  coarse bin -> its P/P1 fine bins, 8192-word tiles, ~128-word runs.
 // Fine bin sizes are exact (k_bin_count), so both levels write into exactly sized regions.
 // ---------------------------------------------------------------------------------------------
-constexpr int P1_BINS = 128;
-constexpr int P1_S = 8;                       // bases per phase
-constexpr int P1_STAGE = P2_BLOCK * P1_S;     // words staged per phase
-constexpr int P1_CUR_STRIDE = 64;             // fused path: one 256 B line per coarse-bin cursor (L2 atomics
-                                              // on one line serialise; 128 cursors in 4 lines cost 0.2 ms)
-constexpr int L2_BLOCK = 1024;
-constexpr int L2_PER = 8;                     // words per lane per tile
-constexpr int L2_TILE = L2_BLOCK * L2_PER;
-
 // cnt[g][f] over fine bins -> cnt1[g][cb] over coarse bins (P2 consecutive fine bins each)
 __global__ __launch_bounds__(256) void k_coarse_counts(const uint32_t* __restrict__ cnt, uint32_t G, uint32_t P,
                                                         uint32_t P2, uint32_t* __restrict__ cnt1) {
@@ -187,29 +159,6 @@ __global__ __launch_bounds__(256) void k_coarse_counts(const uint32_t* __restric
   uint32_t s = 0;
   for (uint32_t i = 0; i < P2; ++i) s += p[i];
   cnt1[t] = s;
-}
-
-// exclusive scan of up to 256 LDS counters by wave 0 (4 per lane); returns the total in s_start[n]
-__device__ __forceinline__ void wave_scan256(const uint32_t* s_cnt, uint32_t* s_start, uint32_t n) {
-  const uint32_t l = threadIdx.x;  // caller guarantees l < 64
-  uint32_t c[4], sum = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    c[i] = 4 * l + i < n ? s_cnt[4 * l + i] : 0;
-    sum += c[i];
-  }
-  uint32_t inc = sum;
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t o = __shfl_up(inc, off);
-    if ((int)l >= off) inc += o;
-  }
-  uint32_t ex = inc - sum;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (4 * l + i < n) s_start[4 * l + i] = ex;
-    ex += c[i];
-  }
-  if (l == 63) s_start[n] = inc;
 }
 
 // FUSED = true: the sizing pass (k_bin_count) is folded in.  Coarse bins then have a fixed capacity
@@ -357,33 +306,40 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part1(rfx_reads_view rv, const uin
 }
 
 // Coarse bin cb of A -> its P2 fine bins in B.  W workgroups share a coarse bin (tiles strided).
+// PAYLOAD: every word carries a 32-bit count that moves with it (survivors of the MSP leaf).
+template <bool PAYLOAD>
 __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__ buf_a, uint64_t* __restrict__ buf_b,
                                                      const uint64_t* __restrict__ fine_start,
                                                      uint32_t* __restrict__ fine_cur, uint32_t P2, int shift2,
                                                      uint32_t W, const uint32_t* __restrict__ coarse_cur,
-                                                     uint32_t cap_a) {
+                                                     uint32_t cap_a, const uint32_t* __restrict__ pay_a,
+                                                     uint32_t* __restrict__ pay_b, uint64_t cap_b) {
   __shared__ uint64_t s_stage[L2_TILE];
+  __shared__ uint32_t s_pay[PAYLOAD ? L2_TILE : 1];
   __shared__ uint8_t s_sbin[L2_TILE];
   __shared__ uint32_t s_cnt[256], s_start[257];
   __shared__ uint64_t s_gbase[256];
   const uint32_t cb = blockIdx.x / W, j = blockIdx.x - cb * W;
   // coarse bin cb of A: exactly sized (same extents as its fine bins in B) or fixed-capacity (fused path)
   const uint64_t a = coarse_cur ? (uint64_t)cb * cap_a : fine_start[(uint64_t)cb * P2];
-  const uint64_t e = coarse_cur ? a + min(coarse_cur[cb * P1_CUR_STRIDE], cap_a) : fine_start[(uint64_t)(cb + 1) * P2];
+  const uint64_t e =
+      coarse_cur ? a + min(coarse_cur[cb * P1_CUR_STRIDE], cap_a) : fine_start[(uint64_t)(cb + 1) * P2];
   if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   for (uint64_t base = a + (uint64_t)j * L2_TILE; base < e; base += (uint64_t)W * L2_TILE) {
     uint64_t wv[L2_PER];
+    uint32_t pv[PAYLOAD ? L2_PER : 1];
     uint32_t br[L2_PER];
 #pragma unroll
     for (int u = 0; u < L2_PER; ++u) {
       const uint64_t i = base + threadIdx.x + (uint64_t)u * L2_BLOCK;
-      wv[u] = i < e ? buf_a[i] : RFX_EMPTY;
+      wv[u] = i < e ? buf_a[i] : 0;
+      if (PAYLOAD) pv[u] = i < e ? pay_a[i] : 0;
     }
 #pragma unroll
     for (int u = 0; u < L2_PER; ++u) {
       br[u] = ~0u;
-      if (wv[u] != RFX_EMPTY) {
+      if (base + threadIdx.x + (uint64_t)u * L2_BLOCK < e) {
         const uint32_t sub = (uint32_t)(wv[u] >> shift2) & (P2 - 1);
         br[u] = (sub << 16) | atomicAdd(&s_cnt[sub], 1u);
       }
@@ -396,7 +352,9 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
       const uint64_t f = (uint64_t)cb * P2 + threadIdx.x;
       const uint32_t at = c ? atomicAdd(&fine_cur[f], c) : 0u;
       // never write past the fine bin (only possible after the fused part1 raised its flag)
-      s_gbase[threadIdx.x] = fine_start[f] + at + c <= fine_start[f + 1] ? fine_start[f] + at : ~0ull;
+      s_gbase[threadIdx.x] = fine_start[f] + at + c <= fine_start[f + 1] && fine_start[f + 1] <= cap_b
+                                 ? fine_start[f] + at
+                                 : ~0ull;
       s_cnt[threadIdx.x] = 0;
     }
 #pragma unroll
@@ -404,13 +362,17 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
       if (br[u] != ~0u) {
         const uint32_t sub = br[u] >> 16, x = s_start[sub] + (br[u] & 0xFFFFu);
         s_stage[x] = wv[u];
+        if (PAYLOAD) s_pay[x] = pv[u];
         s_sbin[x] = (uint8_t)sub;
       }
     __syncthreads();
     const uint32_t total = s_start[P2];
     for (uint32_t x = threadIdx.x; x < total; x += L2_BLOCK) {
       const uint32_t sub = s_sbin[x];
-      if (s_gbase[sub] != ~0ull) buf_b[s_gbase[sub] + (x - s_start[sub])] = s_stage[x];
+      if (s_gbase[sub] != ~0ull) {
+        buf_b[s_gbase[sub] + (x - s_start[sub])] = s_stage[x];
+        if (PAYLOAD) pay_b[s_gbase[sub] + (x - s_start[sub])] = s_pay[x];
+      }
     }
     __syncthreads();
   }
@@ -425,17 +387,10 @@ __global__ __launch_bounds__(256) void k_tmp_start(const uint64_t* const* __rest
   tmp_start[b] = s;
 }
 
-__device__ __forceinline__ uint32_t leaf_hash(uint64_t w) {
-  uint32_t h = (uint32_t)w ^ (uint32_t)(w >> 19) ^ (uint32_t)(w >> 37);
-  h *= 0x9E3779B1u;
-  return h >> (32 - LEAF_TBL_LOG2);
-}
-
-constexpr int LEAF_ILP = 8;       // words loaded per lane before the first insert (64 KB in flight per workgroup)
-constexpr int LEAF_BUCKETS = 256;  // survivors are bucketed on the next 8 bits of w, then ranked inside the bucket
-
 // One workgroup per bin.  If a bin holds more distinct words than the LDS table (or more survivors
 // than the sort area) it is re-run split into 2^r sub-ranges of w, in order -- exact for any input.
+// PAYLOAD: the words of segment 0 carry a 32-bit count each (pay0), added instead of 1 (nseg == 1).
+template <bool PAYLOAD>
 __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __restrict__ seg_inst,
                                                       const uint64_t* const* __restrict__ seg_bs, int nseg,
                                                       const uint64_t* __restrict__ inst0,
@@ -443,7 +398,8 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
                                                       rfx_ord_cfg cfg, uint64_t lower, uint64_t upper,
                                                       const uint64_t* __restrict__ tmp_start,
                                                       uint64_t* __restrict__ tmp_w, uint32_t* __restrict__ tmp_counts,
-                                                      uint64_t* __restrict__ n_surv, unsigned int* __restrict__ err) {
+                                                      uint64_t* __restrict__ n_surv, unsigned int* __restrict__ err,
+                                                      const uint32_t* __restrict__ pay0) {
   __shared__ unsigned long long s_keys[LEAF_TBL];  // hash table keys; reused as the bucketed survivor words
   __shared__ uint32_t s_cnt[LEAF_TBL];             // hash table counts; reused as the bucketed survivor counts
   __shared__ uint64_t s_w[LEAF_SORT];
@@ -455,6 +411,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
   // First batch of segment 0 of a bin (inst0/bs0 are segment 0's arrays passed by value, no pointer
   // chase).  Issued one bin ahead so the HBM latency hides behind the previous bin's sort and emit.
   uint64_t pre[LEAF_ILP];
+  uint32_t pre_c[PAYLOAD ? LEAF_ILP : 1];
   uint64_t pre_a = 0, pre_e = 0, pre_out0 = 0;
   auto prefetch = [&](uint32_t b) {
     if (b >= P) return;
@@ -465,6 +422,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
     for (int u = 0; u < LEAF_ILP; ++u) {
       const uint64_t i = pre_a + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
       pre[u] = i < pre_e ? inst0[i] : RFX_EMPTY;
+      if (PAYLOAD) pre_c[u] = i < pre_e ? pay0[i] : 0;
     }
   };
   prefetch(blockIdx.x);
@@ -495,14 +453,19 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
           const uint64_t* __restrict__ src = sg == 0 ? inst0 : seg_inst[sg];
           for (uint64_t base = a; base < e; base += (uint64_t)LEAF_ILP * LEAF_BLOCK) {
             uint64_t w[LEAF_ILP];
+            uint32_t wc[PAYLOAD ? LEAF_ILP : 1];
             if (sg == 0 && base == a && !prefetched_next) {  // first pass over the bin: already in registers
 #pragma unroll
-              for (int u = 0; u < LEAF_ILP; ++u) w[u] = pre[u];
+              for (int u = 0; u < LEAF_ILP; ++u) {
+                w[u] = pre[u];
+                if (PAYLOAD) wc[u] = pre_c[u];
+              }
             } else {
 #pragma unroll
               for (int u = 0; u < LEAF_ILP; ++u) {  // independent loads, all in flight before the first insert
                 const uint64_t i = base + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
                 w[u] = i < e ? src[i] : RFX_EMPTY;
+                if (PAYLOAD) wc[u] = i < e ? pay0[i] : 0;
               }
             }
 #pragma unroll
@@ -524,7 +487,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
                   }
                 }
                 if (cur == key) {
-                  atomicAdd(&s_cnt[slot], 1u);
+                  atomicAdd(&s_cnt[slot], PAYLOAD ? wc[u] : 1u);
                   break;
                 }
                 slot = (slot + 1) & (LEAF_TBL - 1);
@@ -748,11 +711,16 @@ void part1_fused(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int 
 }
 
 void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur,
-           uint32_t P, uint32_t P2, const rfx_ord_cfg& cfg, const uint32_t* coarse_cur, uint32_t cap_a) {
-  rfx_span sp(c, "k_part2");
+           uint32_t P2, int shift2, const uint32_t* coarse_cur, uint32_t cap_a, const uint32_t* pay_a,
+           uint32_t* pay_b, uint64_t cap_b, const char* span) {
+  rfx_span sp(c, span);
   const uint32_t W = 16;
-  hipLaunchKernelGGL(k_part2, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start, fine_cur, P2,
-                     cfg.bin_shift, W, coarse_cur, cap_a);
+  if (pay_a)
+    hipLaunchKernelGGL(k_part2<true>, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start,
+                       fine_cur, P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b);
+  else
+    hipLaunchKernelGGL(k_part2<false>, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start,
+                       fine_cur, P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b);
 }
 
 void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out) {
@@ -760,13 +728,18 @@ void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, 
 }
 
 void leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, const uint64_t* inst0,
-          const uint64_t* bs0, uint32_t P, const rfx_ord_cfg& cfg, uint64_t lower, uint64_t upper, const uint64_t* tmp_start_, uint64_t* tmp_w,
-          uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err) {
-  rfx_span sp(c, "k_leaf");
+          const uint64_t* bs0, uint32_t P, const rfx_ord_cfg& cfg, uint64_t lower, uint64_t upper,
+          const uint64_t* tmp_start_, uint64_t* tmp_w, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err,
+          const uint32_t* pay0) {
+  rfx_span sp(c, pay0 ? "k_leaf_sort" : "k_leaf");
   // a few bins per workgroup so that the one-bin-ahead prefetch has something to overlap with
   const uint32_t grid = P < (uint32_t)c->n_cu * 4 ? P : (uint32_t)c->n_cu * 4;
-  hipLaunchKernelGGL(k_leaf, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0, P, cfg,
-                     lower, upper, tmp_start_, tmp_w, tmp_counts, n_surv, err);
+  if (pay0)
+    hipLaunchKernelGGL(k_leaf<true>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0, P,
+                       cfg, lower, upper, tmp_start_, tmp_w, tmp_counts, n_surv, err, pay0);
+  else
+    hipLaunchKernelGGL(k_leaf<false>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0,
+                       P, cfg, lower, upper, tmp_start_, tmp_w, tmp_counts, n_surv, err, pay0);
 }
 
 void scan_tail(rfx_ctx* c, uint64_t* v, uint64_t n) {

@@ -211,6 +211,139 @@ def test_skewed_input_falls_back_to_the_exact_partition(ctx, monkeypatch):
             x.free()
 
 
+# ------------------------------------------------------------------------------------------------
+# MSP path (minimizer super-k-mer partition; default for 23 <= k <= 25)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("k,size,canonical,lower", [(25, 8 << 30, True, 2), (25, 1 << 22, True, 1), (24, 1 << 20, True, 0),
+                                                     (23, 1 << 27, False, 1), (25, 1 << 30, False, 3)])
+def test_msp_count_matches_oracle(ctx, small_trio, k, size, canonical, lower):
+    fq = [fastq_bytes(small_trio["mother"], m) for m in (1, 2)]
+    jf = tools.jellyfish_count(ctx, fq, k, size, canonical=canonical, lower=lower, mode=capi.COUNT_MSP)
+    orc = oracle.count(fq, k, size, lower=lower, canonical=canonical)
+    assert_same_records(jf, orc)
+    assert np.array_equal(jf.records.histo(), oracle.histo(orc.counts, full=True)[0])
+    jf.records.free()
+    # the default mode takes the same path for these k
+    ctx.prof(True)
+    ctx.prof_reset()
+    jf = tools.jellyfish_count(ctx, fq, k, size, canonical=canonical, lower=lower)
+    names = ctx.prof_dict()
+    ctx.prof(False)
+    assert "k_msp_part1" in names and "k_msp_leaf" in names and "k_part1" not in names, names
+    assert jf.records.payload() == orc.payload()
+    jf.records.free()
+
+
+def test_msp_rejects_k_outside_its_record_format(ctx):
+    t = capi.CountTable(ctx, 31, 1 << 20, mode=capi.COUNT_MSP)
+    blk = ctx.upload(capi.PackedReads.from_reads([b"ACGT" * 20]))
+    with pytest.raises(capi.RufusError):
+        t.add(blk)
+    blk.free()
+    t.free()
+
+
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("bins", ["256", "2048", "8192"])
+def test_msp_bins_ragged_reads_and_pos_range(ctx, bins, exact, monkeypatch):
+    """Every bin count the path supports, fused and exact sizing, reads of length 0..400 with N,
+    a pos-range pass, and several add() calls (= several record segments per bin)."""
+    monkeypatch.setenv("RFX_P2L_BINS", bins)
+    if exact:
+        monkeypatch.setenv("RFX_P2L_EXACT", "1")
+    rng = np.random.default_rng(int(bins) + exact)
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 30000)]
+    seqs = []
+    for n in rng.integers(0, 400, 4000):
+        s0 = int(rng.integers(0, len(genome) - 400))
+        r = genome[s0:s0 + int(n)].copy()
+        r[rng.random(len(r)) < 0.01] = ord("N")
+        seqs.append(bytes(r))
+    seqs += [b"", b"A" * 24, b"ACGTN" * 30, b"T" * 28, b"T" * 300, b"G" * 25]
+    k, size = 25, 1 << 27
+    for lo, hi in ((0, 0), (1 << 20, 100 << 20)):
+        t = capi.CountTable(ctx, k, size, mode=capi.COUNT_MSP, pos_lo=lo, pos_hi=hi)
+        for part in np.array_split(np.arange(len(seqs)), 3):
+            blk = ctx.upload(capi.PackedReads.from_reads([seqs[i] for i in part]))
+            t.add(blk)
+            blk.free()
+        for lower in (1, 3):
+            rec = t.finish(lower)
+            ref = oracle.count(None, k, size, lower=lower, reads=seqs)
+            sel = (ref.pos >= lo) & (ref.pos < (hi or 1 << 27))
+            keys, counts, pos = rec.get()
+            assert np.array_equal(keys, ref.keys[sel]) and np.array_equal(counts, ref.counts[sel].astype(np.uint32))
+            assert np.array_equal(pos, ref.pos[sel])
+            rec.free()
+        t.free()
+
+
+def test_msp_dense_bins_split_and_survivor_capacity_retry(ctx, monkeypatch):
+    """Unrelated random reads: a minimizer bin holds far more distinct k-mers than the LDS table, so
+    k_msp_leaf splits it by hash bits; the survivor estimate (60 % of the instances at lower = 1, here
+    forced to 0.1 %) is too small, so the emit is rerun with the capacity the device asked for; then
+    pre-aggregated pairs are folded in through the table path."""
+    monkeypatch.setenv("RFX_P2L_BINS", "256")
+    rng = np.random.default_rng(12)
+    seqs = [bytes(r) for r in np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (30000, 150))]]
+    seqs += seqs[:2500]
+    k, size = 25, 8 << 30
+    t = capi.CountTable(ctx, k, size, mode=capi.COUNT_MSP)
+    blk = ctx.upload(capi.PackedReads.from_reads(seqs))
+    t.add(blk)
+    for lower, frac in ((1, None), (2, "0.001"), (1, "0.001")):
+        if frac:
+            monkeypatch.setenv("RFX_MSP_SURV_FRAC", frac)
+        ref = oracle.count(None, k, size, lower=lower, reads=seqs)
+        rec = t.finish(lower)
+        keys, counts, pos = rec.get()
+        assert len(keys) == len(ref.keys)
+        assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts.astype(np.uint32))
+        assert np.array_equal(pos, ref.pos)
+        rec.free()
+    monkeypatch.delenv("RFX_MSP_SURV_FRAC")
+    extra = capi.CountTable(ctx, k, size, mode=capi.COUNT_MSP)
+    blk2 = ctx.upload(capi.PackedReads.from_reads(seqs[:1000]))
+    extra.add(blk2)
+    part = extra.finish(1)
+    dk, dc, _ = part.dev_ptrs()
+    t.add_pairs_dev(dk, dc, len(part))
+    ctx.sync()
+    rec = t.finish(2)
+    assert rec.payload() == oracle.count(None, k, size, lower=2, reads=seqs + seqs[:1000]).payload()
+    for x in (rec, part, blk, blk2, extra, t):
+        x.free()
+
+
+def test_msp_skewed_input_is_redone_with_exact_sizes(ctx, monkeypatch):
+    """Homopolymer / dinucleotide reads put almost every record into one bin: the fixed-capacity
+    coarse bins and the 16-bit histogram of the one-pass partition both give up, the block is redone
+    with the exact two-pass sizing (visible as a k_msp_count launch); ordinary reads are not."""
+    monkeypatch.setenv("RFX_P2L_BINS", "2048")
+    rng = np.random.default_rng(3)
+    seqs = [b"A" * 150] * 2500 + [b"AC" * 75] * 700
+    seqs += [bytes(r) for r in np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (500, 150))]]
+    k, size = 25, 1 << 24
+    ref = oracle.count(None, k, size, lower=1, reads=seqs)
+    for skew, reads in ((True, seqs), (False, seqs[-500:])):
+        ctx.prof(True)
+        ctx.prof_reset()
+        t = capi.CountTable(ctx, k, size, mode=capi.COUNT_MSP)
+        blk = ctx.upload(capi.PackedReads.from_reads(reads))
+        t.add(blk)
+        rec = t.finish(1)
+        launched = ctx.prof_dict()
+        ctx.prof(False)
+        assert ("k_msp_count" in launched) == skew, launched
+        if skew:
+            keys, counts, pos = rec.get()
+            assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts.astype(np.uint32))
+            assert np.array_equal(pos, ref.pos)
+            assert int(counts.max()) == 2500 * 126
+        for x in (rec, blk, t):
+            x.free()
+
+
 def test_key_range_passes_partition_the_output(ctx, small_trio):
     """pos-range passes (multi-pass / multi-GPU ownership): concatenating the slices in pos order
     reproduces the single-pass payload."""

@@ -141,7 +141,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    K2_CHAIN = ("k_bin_count", "k_bin_offsets", "k_bin_scatter", "k_part1", "k_part2", "k_leaf", "k_leaf_compact",
+    # every launch of the count -> sorted-records stage, whichever path rfx_count_add/finish took
+    K2_CHAIN = ("k_msp_part1", "k_msp_count", "k_msp_leaf", "k_surv_hist", "k_surv_part2", "k_surv_sort",
+                "k_bin_count", "k_bin_offsets", "k_bin_scatter", "k_part1", "k_part2", "k_leaf", "k_leaf_compact",
                 "k_count_reads")
     ctx.prof(True)          # warm the profiling path too (event pool)
     for _ in range(args.warmup):
@@ -176,13 +178,11 @@ def main():
 
     if rank == 0:
         reads_per_step = 3 * n_reads * world
-        # K2+K3 (count -> sorted records) is the dominant stage.  On the P2L path it is a chain of
-        # launches per read block (bin histogram, two-level partition of the 8-byte words, LDS count +
-        # sort of every bin, compaction); the algorithmic bytes of SURVEY 8(d) K2 cover the stage as a
-        # whole, so the time used for roofline.achieved is the SUM of their average durations.
-        k2 = [n for n in ("k_bin_count", "k_bin_offsets", "k_bin_scatter", "k_part1", "k_part2", "k_leaf",
-                         "k_leaf_compact") if n in prof] or ["k_count_reads"]
-        k2 = [n for n in k2 if n in prof]
+        # K2+K3 (count -> sorted records) is the dominant stage.  It is a chain of launches per read
+        # block (MSP path: super-k-mer partition in two levels, LDS count of every minimizer bin,
+        # partition + sort of the survivors); the algorithmic bytes of SURVEY 8(d) K2 cover the stage as
+        # a whole, so the time used for roofline.achieved is the SUM of their average durations.
+        k2 = [n for n in K2_CHAIN if n in prof]
         n_count = max([prof[n][1] for n in k2] or [0])
         parts = {n: prof[n][0] / max(prof[n][1], 1) for n in k2}
         avg_ms = sum(parts.values())

@@ -205,6 +205,7 @@ __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
 }
 
 constexpr int MSP_ILP = 8;
+constexpr int MSP_LIST = 3072;  // dense survivor list of k_msp_leaf (flushed when two more scan rounds might not fit)
 
 // One workgroup per fine minimizer bin.  A bin (or part of it) whose distinct k-mers overflow the LDS
 // table is split in two by a hash bit and each half retried -- results already appended stay valid.
@@ -214,17 +215,17 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
     const uint64_t* __restrict__ inst0, const uint64_t* __restrict__ bs0, uint32_t P, int k,
     const uint64_t* __restrict__ g_lut, int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi,
     uint64_t lower, uint64_t upper, uint64_t* __restrict__ out_w, uint32_t* __restrict__ out_c,
-    uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err,
-    int dbg) {
+    uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err) {
   __shared__ __attribute__((aligned(16))) unsigned long long s_keys[LEAF_TBL];
   __shared__ uint32_t s_cnt[LEAF_TBL];
   __shared__ uint64_t s_lut[8 * 256];
   __shared__ uint32_t s_pc[P1_BINS];
   __shared__ uint64_t s_pbase[P1_BINS];
-  __shared__ uint32_t s_nd, s_ovf;
+  __shared__ uint64_t s_lk[MSP_LIST];
+  __shared__ uint32_t s_lc[MSP_LIST];
+  __shared__ uint32_t s_nd, s_ovf, s_nl;
   for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
   const uint64_t kmask = (1ull << (2 * k)) - 1;
-  const ulonglong2* s_bkt = (const ulonglong2*)s_keys;
 
   uint64_t pre[MSP_ILP];
   uint64_t pre_a = 0, pre_e = 0;
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
       if (threadIdx.x == 0) {
         s_nd = 0;
         s_ovf = 0;
+        s_nl = 0;
       }
       __syncthreads();
       for (int sg = 0; sg < nseg; ++sg) {
@@ -287,41 +289,24 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
                 key = rc < fwd ? rc : fwd;
               }
               if (r > 0 && (split_hash(key) >> (32 - r)) != j) continue;
-              if (dbg == 1) { if (key == 12345) atomicAdd(&s_cnt[0], 1u); continue; }
-              // Two-slot buckets read with one 16-byte LDS load: ~95 % of the probes end in the first
-              // bucket, so a wave rarely loops more than twice (it waits for its slowest lane).
-              uint32_t bkt = leaf_hash(key) >> 1;
+              // The kernel is instruction-issue bound (~240 wave instructions per 64 inserts measured), so
+              // the probe is ONE returning CAS: it yields "was empty, now mine", "already mine" or
+              // "someone else's" without a separate read-and-branch for the new-key case.
+              // s_ovf is looked at before every insert: at most one insert per thread can follow the
+              // flag, which the LEAF_TBL - LEAF_FILL spare slots absorb -- probing always terminates.
+              if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+              uint32_t slot = leaf_hash(key);
               for (;;) {
-                const ulonglong2 b2 = s_bkt[bkt];
-                uint32_t slot = 2 * bkt;
-                unsigned long long cur_k = b2.x;
-                if (b2.x != key && b2.x != RFX_EMPTY) {
-                  cur_k = b2.y;
-                  ++slot;
+                unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+                if (old == RFX_EMPTY) {
+                  if (atomicAdd(&s_nd, 1u) >= (uint32_t)LEAF_FILL) s_ovf = 1;
+                  old = key;
                 }
-                if (cur_k == RFX_EMPTY) {
-                  // A ticket per attempted new key keeps the table at <= LEAF_FILL keys, so probing always
-                  // ends.  One LDS atomic per wave hands them out (same-address LDS atomics serialise
-                  // lane by lane: 64 of them cost more than the rest of the insert).  A lane that then
-                  // loses its slot keeps the ticket: the count runs a little high, never low.
-                  const uint64_t want = __ballot(1);
-                  const int lane = threadIdx.x & 63, leader = __ffsll((unsigned long long)want) - 1;
-                  uint32_t base = 0;
-                  if (lane == leader) base = atomicAdd(&s_nd, (uint32_t)__popcll(want));
-                  base = __shfl(base, leader);
-                  if (base + (uint32_t)__popcll(want & ((1ull << lane) - 1)) >= (uint32_t)LEAF_FILL) {
-                    s_ovf = 1;  // this pass is void
-                    break;
-                  }
-                  cur_k = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
-                  if (cur_k == RFX_EMPTY) cur_k = key;
-                  else if (cur_k != key) continue;  // someone else's key took the slot: look at the bucket again
-                }
-                if (cur_k == key) {
+                if (old == key) {
                   atomicAdd(&s_cnt[slot], 1u);
                   break;
                 }
-                bkt = (bkt + 1) & (LEAF_TBL / 2 - 1);
+                slot = (slot + 1) & (LEAF_TBL - 1);
               }
             }
           }
@@ -333,44 +318,64 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
       }
       __syncthreads();
       const bool ovf = s_ovf != 0;
-      if (!ovf && dbg != 2) {
-        // survivors: key -> w in place, counted per coarse pos bin
-        for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
-          const uint64_t key = s_keys[i];
-          if (key == RFX_EMPTY) continue;
-          const uint32_t c = s_cnt[i];
-          uint64_t w = RFX_EMPTY;
-          if (c >= lower && c <= upper) {
-            w = gf2_mul(s_lut, key, ntab);
+      if (!ovf) {
+        // Survivors are few (a twelfth of the slots on 30x data): gather them into a dense list first so
+        // that w = T * key (7 LDS table reads) and the scattered store run on full waves, not on the
+        // odd lane of every wave that scans the table.
+        auto flush = [&]() {
+          __syncthreads();
+          const uint32_t nl = s_nl;
+          for (uint32_t i = threadIdx.x; i < nl; i += LEAF_BLOCK) {
+            uint64_t w = gf2_mul(s_lut, s_lk[i], ntab);
             const uint64_t pos = w >> sel_bits;
             if (pos >= pos_lo && pos < pos_hi) atomicAdd(&s_pc[(uint32_t)(w >> shift1)], 1u);
             else w = RFX_EMPTY;
+            s_lk[i] = w;
           }
-          s_keys[i] = w;
-        }
-        __syncthreads();
-        if (threadIdx.x < P1_BINS) {
-          const uint32_t cn = s_pc[threadIdx.x];
-          const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
-          if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
-            atomicExch(flag, 1u);
-            s_pbase[threadIdx.x] = ~0ull;
-          } else {
-            s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at;
+          __syncthreads();
+          if (threadIdx.x < P1_BINS) {
+            const uint32_t cn = s_pc[threadIdx.x];
+            const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
+            if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
+              atomicExch(flag, 1u);
+              s_pbase[threadIdx.x] = ~0ull;
+            } else {
+              s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at;
+            }
+            s_pc[threadIdx.x] = 0;
           }
-          s_pc[threadIdx.x] = 0;
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
-          const uint64_t w = s_keys[i];
-          if (w == RFX_EMPTY) continue;
-          const uint32_t cb = (uint32_t)(w >> shift1);
-          const uint32_t o = atomicAdd(&s_pc[cb], 1u);
-          if (s_pbase[cb] != ~0ull) {
-            out_w[s_pbase[cb] + o] = w;
-            out_c[s_pbase[cb] + o] = s_cnt[i];
+          __syncthreads();
+          for (uint32_t i = threadIdx.x; i < nl; i += LEAF_BLOCK) {
+            const uint64_t w = s_lk[i];
+            if (w == RFX_EMPTY) continue;
+            const uint32_t cb = (uint32_t)(w >> shift1);
+            const uint32_t o = atomicAdd(&s_pc[cb], 1u);
+            if (s_pbase[cb] != ~0ull) {
+              out_w[s_pbase[cb] + o] = w;
+              out_c[s_pbase[cb] + o] = s_lc[i];
+            }
           }
+          __syncthreads();
+          if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
+          if (threadIdx.x == 0) s_nl = 0;
+          __syncthreads();
+        };
+        for (int base = 0; base < LEAF_TBL; base += 2 * LEAF_BLOCK) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int i = base + h * LEAF_BLOCK + threadIdx.x;
+            const uint64_t key = s_keys[i];
+            const uint32_t c = s_cnt[i];
+            if (key != RFX_EMPTY && c >= lower && c <= upper) {
+              const uint32_t o = atomicAdd(&s_nl, 1u);
+              s_lk[o] = key;
+              s_lc[o] = c;
+            }
+          }
+          __syncthreads();
+          if (s_nl > MSP_LIST - 2 * LEAF_BLOCK) flush();  // the next two rounds might not fit
         }
+        flush();
       }
       __syncthreads();
       if (ovf) {  // split this sub-range
@@ -508,16 +513,15 @@ void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err) {
   rfx_span sp(c, "k_msp_leaf");
-  const int dbg = getenv("RFX_MSP_DBG") ? atoi(getenv("RFX_MSP_DBG")) : 0;
   const uint32_t grid = P < (uint32_t)c->n_cu * 4 ? P : (uint32_t)c->n_cu * 4;
   if (canonical)
     hipLaunchKernelGGL(k_msp_leaf<true>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0,
                        P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w, out_c, cur, cap, flag,
-                       err, dbg);
+                       err);
   else
     hipLaunchKernelGGL(k_msp_leaf<false>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0,
                        bs0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w, out_c, cur, cap,
-                       flag, err, dbg);
+                       flag, err);
 }
 
 void surv_hist(rfx_ctx* c, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,

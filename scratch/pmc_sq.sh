@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/pmc_sq -o s -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_sq.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d gpurun_out/pmc_sq -o s -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > gpurun_out/pmc_sq.log 2>&1
 python - <<'PY'
 import csv,collections,re,glob
 f=glob.glob('gpurun_out/pmc_sq/**/s_counter_collection.csv',recursive=True)[0]

@@ -205,7 +205,10 @@ __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
 }
 
 constexpr int MSP_ILP = 8;
-constexpr int MSP_LIST = 3072;  // dense survivor list of k_msp_leaf (flushed when two more scan rounds might not fit)
+constexpr int MSP_RC_LOG2 = 12;
+constexpr int MSP_RC = 1 << MSP_RC_LOG2;  // record cache slots (aliases the survivor list)
+constexpr int MSP_RC_PROBES = 8;
+constexpr int MSP_LIST = 4096;  // dense survivor list of k_msp_leaf (flushed when two more scan rounds might not fit)
 
 // One workgroup per fine minimizer bin.  A bin (or part of it) whose distinct k-mers overflow the LDS
 // table is split in two by a hash bit and each half retried -- results already appended stay valid.
@@ -218,13 +221,13 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
     uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err) {
   __shared__ __attribute__((aligned(16))) unsigned long long s_keys[LEAF_TBL];
   __shared__ uint32_t s_cnt[LEAF_TBL];
-  __shared__ uint64_t s_lut[8 * 256];
   __shared__ uint32_t s_pc[P1_BINS];
   __shared__ uint64_t s_pbase[P1_BINS];
   __shared__ uint64_t s_lk[MSP_LIST];
   __shared__ uint32_t s_lc[MSP_LIST];
   __shared__ uint32_t s_nd, s_ovf, s_nl;
-  for (int i = threadIdx.x; i < ntab * 256; i += blockDim.x) s_lut[i] = g_lut[i];
+  unsigned long long* s_rk = (unsigned long long*)s_lk;  // the record cache lives in the (then idle) survivor list
+  uint32_t* s_rc = s_lc;
   const uint64_t kmask = (1ull << (2 * k)) - 1;
 
   uint64_t pre[MSP_ILP];
@@ -253,6 +256,10 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
         s_keys[i] = RFX_EMPTY;
         s_cnt[i] = 0;
       }
+      for (int i = threadIdx.x; i < MSP_RC; i += LEAF_BLOCK) {
+        s_rk[i] = MSP_EMPTY;
+        s_rc[i] = 0;
+      }
       if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
       if (threadIdx.x == 0) {
         s_nd = 0;
@@ -260,6 +267,45 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
         s_nl = 0;
       }
       __syncthreads();
+      // k-mer q of record x into the table, counted `mult` times.
+      auto insert_kmer = [&](uint64_t x, int q, uint32_t mult) {
+        const int n = (int)((x >> 56) & 3u) + 1;
+        if (q >= n) return;
+        const uint64_t S = x & ((1ull << 56) - 1);
+        const uint64_t fwd = (S >> (2 * (n - 1 - q))) & kmask;
+        uint64_t key = fwd;
+        if (CANON) {
+          const uint64_t rc = (revcomp_bases(S, k + n - 1) >> (2 * q)) & kmask;
+          key = rc < fwd ? rc : fwd;
+        }
+        if (r > 0 && (split_hash(key) >> (32 - r)) != j) return;
+        // The probe is ONE returning CAS: it yields "was empty, now mine", "already mine" or "someone
+        // else's" without a separate read-and-branch for the new-key case.  s_ovf is looked at before
+        // every insert: at most one insert per thread can follow the flag, which the LEAF_TBL -
+        // LEAF_FILL spare slots absorb -- probing always terminates.
+        if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+        uint32_t slot = leaf_hash(key);
+        for (;;) {
+          unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+          if (old == RFX_EMPTY) {
+            if (atomicAdd(&s_nd, 1u) >= (uint32_t)LEAF_FILL) s_ovf = 1;
+            old = key;
+          }
+          if (old == key) {
+            atomicAdd(&s_cnt[slot], mult);
+            break;
+          }
+          slot = (slot + 1) & (LEAF_TBL - 1);
+        }
+      };
+      auto insert_record = [&](uint64_t x, uint32_t mult) {
+        for (int q = 0; q < MSP_NMAX; ++q) insert_kmer(x, q, mult);
+      };
+      // Phase A: identical records first.  Reads that cover the same stretch of genome cut it into the
+      // same records (run boundaries follow the minimizers, not the read), so at sequencing depth most
+      // records of a bin are copies: one cheap insert of the 8-byte record into a small cache, and only
+      // the distinct ones pay for k-mer extraction and up to four table inserts (phase B).  The cache is
+      // best effort: a record that finds no slot within MSP_RC_PROBES goes straight to the table.
       for (int sg = 0; sg < nseg; ++sg) {
         const uint64_t a = sg == 0 ? a0 : seg_bs[sg][bin], e = sg == 0 ? e0 : seg_bs[sg][bin + 1];
         const uint64_t* __restrict__ src = sg == 0 ? inst0 : seg_inst[sg];
@@ -277,44 +323,53 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
           }
 #pragma unroll
           for (int u = 0; u < MSP_ILP; ++u) {
-            if (rec[u] == MSP_EMPTY) continue;
-            const int n = (int)((rec[u] >> 56) & 3u) + 1;
-            const uint64_t S = rec[u] & ((1ull << 56) - 1);
-            const uint64_t R = CANON ? revcomp_bases(S, k + n - 1) : 0;
-            for (int q = 0; q < n; ++q) {
-              const uint64_t fwd = (S >> (2 * (n - 1 - q))) & kmask;
-              uint64_t key = fwd;
-              if (CANON) {
-                const uint64_t rc = (R >> (2 * q)) & kmask;
-                key = rc < fwd ? rc : fwd;
+            const uint64_t x = rec[u];
+            if (x == MSP_EMPTY) continue;
+            uint32_t h = (uint32_t)x ^ (uint32_t)(x >> 23) ^ (uint32_t)(x >> 41);
+            h = (h * 0x9E3779B1u) >> (32 - MSP_RC_LOG2);
+            bool cached = false;
+            for (int p = 0; p < MSP_RC_PROBES; ++p) {
+              const unsigned long long old = atomicCAS(&s_rk[h], (unsigned long long)MSP_EMPTY, (unsigned long long)x);
+              if (old == MSP_EMPTY || old == x) {
+                atomicAdd(&s_rc[h], 1u);
+                cached = true;
+                break;
               }
-              if (r > 0 && (split_hash(key) >> (32 - r)) != j) continue;
-              // The kernel is instruction-issue bound (~240 wave instructions per 64 inserts measured), so
-              // the probe is ONE returning CAS: it yields "was empty, now mine", "already mine" or
-              // "someone else's" without a separate read-and-branch for the new-key case.
-              // s_ovf is looked at before every insert: at most one insert per thread can follow the
-              // flag, which the LEAF_TBL - LEAF_FILL spare slots absorb -- probing always terminates.
-              if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
-              uint32_t slot = leaf_hash(key);
-              for (;;) {
-                unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
-                if (old == RFX_EMPTY) {
-                  if (atomicAdd(&s_nd, 1u) >= (uint32_t)LEAF_FILL) s_ovf = 1;
-                  old = key;
-                }
-                if (old == key) {
-                  atomicAdd(&s_cnt[slot], 1u);
-                  break;
-                }
-                slot = (slot + 1) & (LEAF_TBL - 1);
-              }
+              h = (h + 1) & (MSP_RC - 1);
             }
+            if (!cached) insert_record(x, 1u);
           }
         }
       }
       if (!prefetched_next) {  // the next bin's loads fly while this one is emitted
         prefetch(bin + gridDim.x);
         prefetched_next = true;
+      }
+      __syncthreads();
+      {  // Phase B: pack the cache (in place, through registers), then one dense pass over the distinct records
+        uint64_t ex[MSP_RC / LEAF_BLOCK];
+        uint32_t ec[MSP_RC / LEAF_BLOCK];
+#pragma unroll
+        for (int h = 0; h < MSP_RC / LEAF_BLOCK; ++h) {
+          ex[h] = s_rk[h * LEAF_BLOCK + threadIdx.x];
+          ec[h] = s_rc[h * LEAF_BLOCK + threadIdx.x];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < MSP_RC / LEAF_BLOCK; ++h)
+          if (ex[h] != MSP_EMPTY) {
+            const uint32_t o = atomicAdd(&s_nl, 1u);
+            s_rk[o] = ex[h];
+            s_rc[o] = ec[h];
+          }
+        __syncthreads();
+        const uint32_t nrec = s_nl;
+        // one k-mer per thread: four times the parallelism of one record per thread, and the table
+        // round trips of a record's k-mers overlap instead of queueing in one lane
+        for (uint32_t i = threadIdx.x; i < MSP_NMAX * nrec; i += LEAF_BLOCK)
+          insert_kmer(s_rk[i >> 2], (int)(i & 3u), s_rc[i >> 2]);
+        __syncthreads();
+        if (threadIdx.x == 0) s_nl = 0;
       }
       __syncthreads();
       const bool ovf = s_ovf != 0;
@@ -326,7 +381,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
           __syncthreads();
           const uint32_t nl = s_nl;
           for (uint32_t i = threadIdx.x; i < nl; i += LEAF_BLOCK) {
-            uint64_t w = gf2_mul(s_lut, s_lk[i], ntab);
+            uint64_t w = gf2_mul(g_lut, s_lk[i], ntab);  // 14 KB table, L1-resident; only survivors get here
             const uint64_t pos = w >> sel_bits;
             if (pos >= pos_lo && pos < pos_hi) atomicAdd(&s_pc[(uint32_t)(w >> shift1)], 1u);
             else w = RFX_EMPTY;

@@ -548,8 +548,12 @@ rfx_reads* rfx_reads_upload(rfx_ctx* c, const uint64_t* codes, const uint32_t* a
   return r;
 }
 
+static void msp_forget_pending(rfx_table* t);
+static void rfx_reads_release_pending(const rfx_reads* r);
+
 void rfx_reads_free(rfx_reads* r) {
   if (!r) return;
+  rfx_reads_release_pending(r);  // a count table may still need these reads to redo its partition
   dfree(r->ctx, r->codes); dfree(r->ctx, r->acgt); dfree(r->ctx, r->good);
   dfree(r->ctx, r->word_off); dfree(r->ctx, r->len);
   delete r;
@@ -589,6 +593,7 @@ rfx_table* rfx_count_begin(rfx_ctx* c, int k, int canonical, int lsize, uint64_t
   t->lut_tinv = hc->lut_tinv;
   t->ntab = hc->ntab;
   t->segs = new std::vector<rfx_segment>();
+  t->pend = new std::vector<rfx_pending_add>();
   t->d_stats = (rfx_table_stats*)dmalloc(c, sizeof(rfx_table_stats));
   t->d_ctl = (rfx_count_ctl*)dmalloc(c, sizeof(rfx_count_ctl));
   const bool ok = t->d_stats && t->d_ctl &&
@@ -604,6 +609,10 @@ void rfx_count_free(rfx_table* t) {
   if (!t) return;
   dfree(t->ctx, t->keys); dfree(t->ctx, t->counts); dfree(t->ctx, t->d_stats);
   dfree(t->ctx, t->d_ctl); dfree(t->ctx, t->ovf_keys);
+  if (t->pend) {
+    msp_forget_pending(t);
+    delete t->pend;
+  }
   if (t->segs) {
     for (auto& sg : *t->segs) {
       dfree(t->ctx, sg.inst);
@@ -784,182 +793,301 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
 
 // ---- MSP path (rfx_msp.hip) ---------------------------------------------------------------------
 // Partition one read block into super-k-mer records grouped by minimizer bin.  The sizes of the
-// intermediate buffers are estimates (records per k-mer depend on the sequence); the device reports
-// when one did not hold and the block is redone with exact sizes.
-static int msp_add(rfx_table* t, const rfx_reads* r) {
+// intermediate buffers are estimates (records per k-mer depend on the sequence); the device raises a
+// flag when one did not hold and the block is redone with exact sizes.  The flag is NOT waited for
+// here: it is read with the next synchronisation the table needs anyway (finish), or when the read
+// block is about to be freed -- the redo needs the reads.
+struct msp_geom {
+  uint32_t P, P1, P2;
+  int bin_bits, G;
+  size_t ncur;
+  uint64_t windows;
+};
+
+static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   rfx_ctx* c = t->ctx;
-  const uint64_t windows = r->n_bases > (uint64_t)(t->k - 1) * r->n ? r->n_bases - (uint64_t)(t->k - 1) * r->n : 0;
-  if (windows >= (1ull << 32)) return RFX_E_RANGE;
-  if (windows == 0) return RFX_OK;
+  g.windows = r->n_bases > (uint64_t)(t->k - 1) * r->n ? r->n_bases - (uint64_t)(t->k - 1) * r->n : 0;
   if (!t->p2l_bins) {
     if (const char* ev = getenv("RFX_P2L_BINS")) t->p2l_bins = (uint32_t)atoi(ev);
     uint32_t P = 256;
-    while (P < 8192 && (uint64_t)P * 16384 < windows) P <<= 1;
+    while (P < 8192 && (uint64_t)P * 16384 < g.windows) P <<= 1;
     if (!t->p2l_bins) t->p2l_bins = P;
     if (t->p2l_bins < 256) t->p2l_bins = 256;    // 128 coarse bins x >= 2 sub-bins
     if (t->p2l_bins > 8192) t->p2l_bins = 8192;  // 6-bit sub-bin field, 16-bit LDS histogram
   }
-  const uint32_t P = t->p2l_bins, P1 = (uint32_t)rfxk::p1_bins(), P2 = P / P1;
-  const int bin_bits = ceil_log2(P);
-  const int G = rfxk::p2l_grid(c, r->n);
-  const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
+  g.P = t->p2l_bins;
+  g.P1 = (uint32_t)rfxk::p1_bins();
+  g.P2 = g.P / g.P1;
+  g.bin_bits = ceil_log2(g.P);
+  g.G = rfxk::p2l_grid(c, r->n);
+  g.ncur = (size_t)g.P1 * rfxk::p1_cur_stride();
+  return true;
+}
+
+static void msp_forget_pending(rfx_table* t) {
+  rfx_ctx* c = t->ctx;
+  for (auto& p : *t->pend) dfree(c, p.cur);
+  t->pend->clear();
+  c->pend_tables.erase(std::remove(c->pend_tables.begin(), c->pend_tables.end(), t), c->pend_tables.end());
+}
+
+// Exact two-pass sizing (32-bit histogram, then scatter into coarse bins as large as the fullest one).
+static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* seg) {
+  rfx_ctx* c = t->ctx;
+  msp_geom g;
+  msp_geometry(t, r, g);
+  const uint32_t P = g.P, P1 = g.P1, P2 = g.P2;
   const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
-  uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)G * P * 4);
+  uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
   uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
   uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
   uint32_t* fine_cur = (uint32_t*)dmalloc(c, (size_t)P * 4);
-  uint32_t* cur = (uint32_t*)dmalloc(c, (ncur + 1) * 4);  // [ncur] = flag
+  uint32_t* cur = (uint32_t*)dmalloc(c, (g.ncur + 1) * 4);
   uint64_t *buf_a = nullptr, *inst = nullptr;
   auto drop = [&] { dfree(c, cnt); dfree(c, gsum); dfree(c, fine_cur); dfree(c, cur); dfree(c, buf_a); };
   auto fail = [&](int rc) { drop(); dfree(c, bin_start); dfree(c, inst); return rc; };
   if (!cnt || !gsum || !bin_start || !fine_cur || !cur) return fail(RFX_E_NOMEM);
-
-  // ~3.2 k-mers per record on ordinary sequence: room for 2.5, coarse bins 25 % above even
-  uint64_t cap_b = windows * 2 / 5 + 65536;
-  if (cap_b > windows) cap_b = windows;
-  uint64_t cap_a = cap_b / P1 + cap_b / (4ull * P1) + 16384;
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 1, g.G, nullptr, nullptr, 0, cnt, nullptr);
+  rfxk::bin_offsets(c, cnt, (uint32_t)g.G, P, gsum, bin_start);
+  std::vector<uint64_t> bs((size_t)P + 1);
+  if (queue_read(c, bs.data(), bin_start, ((size_t)P + 1) * 8) != hipSuccess || ctx_sync(c) != hipSuccess)
+    return fail(RFX_E_HIP);
+  const uint64_t total = bs[P];
+  uint64_t cap_a = 1;
+  for (uint32_t cb = 0; cb < P1; ++cb) cap_a = std::max<uint64_t>(cap_a, bs[(size_t)(cb + 1) * P2] - bs[(size_t)cb * P2]);
+  const uint64_t cap_b = total ? total : 1;
+  buf_a = (uint64_t*)dmalloc(c, cap_a * P1 * 8);
+  inst = (uint64_t*)dmalloc(c, cap_b * 8);
+  if (!buf_a || !inst) return fail(RFX_E_NOMEM);
+  HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1) * 4, c->stream));
+  HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 2, g.G, buf_a, cur, (uint32_t)cap_a, nullptr, cur + g.ncur);
+  rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
   unsigned int flag = 1;
-  uint64_t total = 0;
-  if (!getenv("RFX_P2L_EXACT")) {
-    buf_a = (uint64_t*)dmalloc(c, cap_a * P1 * 8);
-    inst = (uint64_t*)dmalloc(c, cap_b * 8);
-    if (!buf_a || !inst) return fail(RFX_E_NOMEM);
-    HIPCHK(hipMemsetAsync(cur, 0, (ncur + 1) * 4, c->stream));
-    HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
-    rfxk::msp_part1(c, rv, t->k, t->canonical, bin_bits, 0, G, buf_a, cur, (uint32_t)cap_a, cnt, cur + ncur);
-    rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
-    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
-    if (queue_read(c, &flag, cur + ncur, 4) != hipSuccess || queue_read(c, &total, bin_start + P, 8) != hipSuccess ||
-        ctx_sync(c) != hipSuccess)
-      return fail(RFX_E_HIP);
-    if (total > cap_b) flag = 1;
-  }
-  if (flag) {  // exact redo: 32-bit histogram, then scatter into coarse bins as large as the fullest one
-    dfree(c, buf_a);
-    dfree(c, inst);
-    buf_a = inst = nullptr;
-    rfxk::msp_part1(c, rv, t->k, t->canonical, bin_bits, 1, G, nullptr, nullptr, 0, cnt, nullptr);
-    rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
-    std::vector<uint64_t> bs((size_t)P + 1);
-    if (queue_read(c, bs.data(), bin_start, ((size_t)P + 1) * 8) != hipSuccess || ctx_sync(c) != hipSuccess)
-      return fail(RFX_E_HIP);
-    total = bs[P];
-    cap_a = 1;
-    for (uint32_t cb = 0; cb < P1; ++cb) cap_a = std::max<uint64_t>(cap_a, bs[(size_t)(cb + 1) * P2] - bs[(size_t)cb * P2]);
-    cap_b = total ? total : 1;
-    buf_a = (uint64_t*)dmalloc(c, cap_a * P1 * 8);
-    inst = (uint64_t*)dmalloc(c, cap_b * 8);
-    if (!buf_a || !inst) return fail(RFX_E_NOMEM);
-    HIPCHK(hipMemsetAsync(cur, 0, (ncur + 1) * 4, c->stream));
-    HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
-    rfxk::msp_part1(c, rv, t->k, t->canonical, bin_bits, 2, G, buf_a, cur, (uint32_t)cap_a, nullptr, cur + ncur);
-    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
-    if (queue_read(c, &flag, cur + ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) return fail(RFX_E_HIP);
-    if (flag) {
-      snprintf(g_err, sizeof g_err, "MSP: exact partition overflowed (internal error)");
-      return fail(RFX_E_HIP);
-    }
+  if (queue_read(c, &flag, cur + g.ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) return fail(RFX_E_HIP);
+  if (flag) {
+    snprintf(g_err, sizeof g_err, "MSP: exact partition overflowed (internal error)");
+    return fail(RFX_E_HIP);
   }
   drop();
-  t->segs->push_back(rfx_segment{inst, total, bin_start, windows});
-  t->seg_kind = RFX_COUNT_MSP;
+  *seg = rfx_segment{inst, total, bin_start, g.windows};
   return RFX_OK;
 }
 
-// Count every minimizer bin in LDS, then put the survivors in (pos,key) order.
-static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
+static int msp_add(rfx_table* t, const rfx_reads* r) {
+  rfx_ctx* c = t->ctx;
+  msp_geom g;
+  msp_geometry(t, r, g);
+  if (g.windows >= (1ull << 32)) return RFX_E_RANGE;
+  if (g.windows == 0) return RFX_OK;
+  if (getenv("RFX_P2L_EXACT")) {
+    rfx_segment seg;
+    const int rc = msp_partition_exact(t, r, &seg);
+    if (rc) return rc;
+    t->segs->push_back(seg);
+    t->seg_kind = RFX_COUNT_MSP;
+    return RFX_OK;
+  }
+  const uint32_t P = g.P, P1 = g.P1, P2 = g.P2;
+  const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+  uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
+  uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
+  uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
+  uint32_t* fine_cur = (uint32_t*)dmalloc(c, (size_t)P * 4);
+  uint32_t* cur = (uint32_t*)dmalloc(c, (g.ncur + 1) * 4);  // [ncur] = flag
+  // ~3.4 k-mers per record on ordinary sequence: room for 2.5, coarse bins 25 % above even
+  uint64_t cap_b = g.windows * 2 / 5 + 65536;
+  if (cap_b > g.windows) cap_b = g.windows;
+  const uint64_t cap_a = cap_b / P1 + cap_b / (4ull * P1) + 16384;
+  uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * P1 * 8);
+  uint64_t* inst = (uint64_t*)dmalloc(c, cap_b * 8);
+  auto drop = [&] { dfree(c, cnt); dfree(c, gsum); dfree(c, fine_cur); dfree(c, buf_a); };
+  if (!cnt || !gsum || !bin_start || !fine_cur || !cur || !buf_a || !inst) {
+    drop(); dfree(c, cur); dfree(c, bin_start); dfree(c, inst);
+    return RFX_E_NOMEM;
+  }
+  HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1) * 4, c->stream));
+  HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 0, g.G, buf_a, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
+  rfxk::bin_offsets(c, cnt, (uint32_t)g.G, P, gsum, bin_start);
+  rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
+  rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
+  drop();
+  t->segs->push_back(rfx_segment{inst, cap_b, bin_start, g.windows});
+  t->seg_kind = RFX_COUNT_MSP;
+  if (t->pend->empty()) c->pend_tables.push_back(t);
+  t->pend->push_back(rfx_pending_add{r, cur, t->segs->size() - 1, g.ncur});
+  return RFX_OK;
+}
+
+// Redo the flagged blocks of `flags` (one per pending add, in order) exactly; forget all pending adds.
+static int msp_settle(rfx_table* t, const std::vector<unsigned int>& flags) {
+  rfx_ctx* c = t->ctx;
+  int rc = RFX_OK;
+  for (size_t i = 0; i < t->pend->size() && rc == RFX_OK; ++i) {
+    if (!flags[i]) continue;
+    const rfx_pending_add& p = (*t->pend)[i];
+    rfx_segment& sg = (*t->segs)[p.seg];
+    dfree(c, sg.inst);
+    dfree(c, sg.bin_start);
+    sg.inst = sg.bin_start = nullptr;
+    rfx_segment fresh{};
+    rc = msp_partition_exact(t, p.r, &fresh);
+    if (rc == RFX_OK) sg = fresh;
+  }
+  msp_forget_pending(t);
+  return rc;
+}
+
+// Wait for the flags of the pending adds and settle them (used when a read block goes away first).
+static int msp_resolve(rfx_table* t) {
+  rfx_ctx* c = t->ctx;
+  if (t->pend->empty()) return RFX_OK;
+  std::vector<unsigned int> flags(t->pend->size(), 1u);
+  for (size_t i = 0; i < t->pend->size(); ++i)
+    if (queue_read(c, &flags[i], (*t->pend)[i].cur + (*t->pend)[i].ncur, 4) != hipSuccess) return RFX_E_HIP;
+  if (ctx_sync(c) != hipSuccess) return RFX_E_HIP;
+  return msp_settle(t, flags);
+}
+
+static void rfx_reads_release_pending(const rfx_reads* r) {
+  rfx_ctx* c = r->ctx;
+  std::vector<rfx_table*> hit;
+  for (rfx_table* t : c->pend_tables)
+    for (auto& p : *t->pend)
+      if (p.r == r) {
+        hit.push_back(t);
+        break;
+      }
+  for (rfx_table* t : hit) {
+    const int rc = msp_resolve(t);
+    if (rc) t->pend_error = rc;
+  }
+}
+
+// Count every minimizer bin in LDS, then put the survivors in (pos,key) order.  One synchronisation:
+// everything is queued (the records array is sized by what the survivor bins can hold), then the
+// totals, the capacity flags of this emit AND of the pending adds, and the histogram come back together.
+static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {
   rfx_ctx* c = t->ctx;
   const uint32_t P = t->p2l_bins, P1 = (uint32_t)rfxk::p1_bins();
-  const int nseg = (int)t->segs->size();
-  std::vector<const uint64_t*> h_inst(nseg), h_bs(nseg);
-  uint64_t kmers = 0;
-  for (int i = 0; i < nseg; ++i) {
-    h_inst[i] = (*t->segs)[i].inst;
-    h_bs[i] = (*t->segs)[i].bin_start;
-    kmers += (*t->segs)[i].kmers;
-  }
   const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
-  const uint64_t** d_inst = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
-  const uint64_t** d_bs = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
-  uint32_t* cur = (uint32_t*)dmalloc(c, (ncur + 2) * 4);  // [ncur] = capacity flag, [ncur+1] = error
-  std::vector<uint32_t> h_cur(ncur + 2);
-  uint64_t *aw = nullptr, *bw = nullptr, *tmp_w = nullptr, *bsq = nullptr, *n_surv = nullptr;
-  uint32_t *ac = nullptr, *bc = nullptr, *tmp_c = nullptr, *fcur = nullptr;
-  auto drop_try = [&] {
-    dfree(c, aw); dfree(c, ac); dfree(c, bw); dfree(c, bc); dfree(c, tmp_w); dfree(c, tmp_c); dfree(c, bsq);
-    dfree(c, n_surv); dfree(c, fcur);
-    aw = bw = tmp_w = bsq = n_surv = nullptr;
-    ac = bc = tmp_c = fcur = nullptr;
-  };
-  auto cleanup = [&] { drop_try(); dfree(c, d_inst); dfree(c, d_bs); dfree(c, cur); };
-  if (!d_inst || !d_bs || !cur) { cleanup(); return nullptr; }
-  hipError_t e = upload(c, d_inst, h_inst.data(), nseg * sizeof(void*));
-  if (e == hipSuccess) e = upload(c, d_bs, h_bs.data(), nseg * sizeof(void*));
-  if (e != hipSuccess) { hip_fail(e, "msp_emit"); cleanup(); return nullptr; }
-
-  // Survivors per coarse pos bin: a guess first (a quarter of the instances when singletons are
-  // dropped, else 60 %); if a bin overflows, the cursors of that run say exactly what is needed.
   double frac = lower >= 2 ? 0.25 : 0.6;
   if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
-  uint64_t cap = (uint64_t)((double)kmers * frac) / P1;
-  cap += cap / 8 + 4096;
+  uint64_t cap = 0;  // survivors per coarse pos bin; 0 = guess from the instance count
   rfx_records* rec = nullptr;
-  for (int attempt = 0; attempt < 2; ++attempt) {
+  for (int attempt = 0; attempt < 4 && !rec; ++attempt) {
+    const int nseg = (int)t->segs->size();
+    std::vector<const uint64_t*> h_inst(nseg), h_bs(nseg);
+    uint64_t kmers = 0;
+    for (int i = 0; i < nseg; ++i) {
+      h_inst[i] = (*t->segs)[i].inst;
+      h_bs[i] = (*t->segs)[i].bin_start;
+      kmers += (*t->segs)[i].kmers;
+    }
+    if (!cap) {
+      // a guess first (a quarter of the instances when singletons are dropped, else 60 %); if a bin
+      // overflows, the cursors of that run say exactly what is needed
+      cap = (uint64_t)((double)kmers * frac) / P1;
+      cap += cap / 8 + 4096;
+    }
     if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
     const uint64_t room = cap * P1;
     uint32_t Pq = 256;
     while (Pq < 32768 && (uint64_t)Pq * 1536 < room) Pq <<= 1;
     const uint32_t P2q = Pq / P1;
     const rfx_ord_cfg cfg = ord_cfg(t, ceil_log2(Pq));
-    aw = (uint64_t*)dmalloc(c, room * 8);
-    ac = (uint32_t*)dmalloc(c, room * 4);
-    bsq = (uint64_t*)dmalloc(c, ((size_t)Pq + 1) * 8);
-    fcur = (uint32_t*)dmalloc(c, (size_t)Pq * 4);
-    if (!aw || !ac || !bsq || !fcur) break;
-    e = hipMemsetAsync(cur, 0, (ncur + 2) * 4, c->stream);
+    const uint64_t** d_inst = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
+    const uint64_t** d_bs = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
+    uint32_t* cur = (uint32_t*)dmalloc(c, (ncur + 2) * 4);  // [ncur] = capacity flag, [ncur+1] = error
+    uint64_t* aw = (uint64_t*)dmalloc(c, room * 8);
+    uint32_t* ac = (uint32_t*)dmalloc(c, room * 4);
+    uint64_t* bw = (uint64_t*)dmalloc(c, room * 8);
+    uint32_t* bc = (uint32_t*)dmalloc(c, room * 4);
+    uint64_t* bsq = (uint64_t*)dmalloc(c, ((size_t)Pq + 1) * 8);
+    uint32_t* fcur = (uint32_t*)dmalloc(c, (size_t)Pq * 4);
+    unsigned long long* d_histo = histo ? (unsigned long long*)dmalloc(c, RFX_HISTO_BINS * 8) : nullptr;
+    rfx_records* big = records_alloc(c, t->k, t->lsize, t->cols, room);
+    auto drop = [&] {
+      dfree(c, d_inst); dfree(c, d_bs); dfree(c, cur); dfree(c, aw); dfree(c, ac); dfree(c, bw); dfree(c, bc);
+      dfree(c, bsq); dfree(c, fcur); dfree(c, d_histo);
+    };
+    if (!d_inst || !d_bs || !cur || !aw || !ac || !bw || !bc || !bsq || !fcur || (histo && !d_histo) || !big) {
+      drop();
+      rfx_records_free(big);
+      return nullptr;
+    }
+    hipError_t e = upload(c, d_inst, h_inst.data(), nseg * sizeof(void*));
+    if (e == hipSuccess) e = upload(c, d_bs, h_bs.data(), nseg * sizeof(void*));
+    if (e == hipSuccess) e = hipMemsetAsync(cur, 0, (ncur + 2) * 4, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(bsq, 0, ((size_t)Pq + 1) * 8, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(fcur, 0, (size_t)Pq * 4, c->stream);
-    if (e != hipSuccess) { hip_fail(e, "msp_emit"); break; }
+    if (e == hipSuccess && histo) e = hipMemsetAsync(d_histo, 0, RFX_HISTO_BINS * 8, c->stream);
+    if (e != hipSuccess) { hip_fail(e, "msp_emit"); drop(); rfx_records_free(big); return nullptr; }
     rfxk::msp_leaf(c, d_inst, d_bs, nseg, h_inst[0], h_bs[0], P, t->k, t->canonical, t->lut_t, t->ntab, cfg.sel_bits,
                    cfg.c_bits - 7, t->pos_lo, t->pos_hi, lower, upper, aw, ac, cur, (uint32_t)cap, cur + ncur,
                    cur + ncur + 1);
+    if (histo) rfxk::histo_bins(c, ac, cur, (uint32_t)cap, d_histo);  // count-of-counts of exactly the survivors
     rfxk::surv_hist(c, aw, cur, (uint32_t)cap, P2q, cfg.bin_shift, bsq);
     rfxk::scan_tail(c, bsq, Pq);
-    bw = (uint64_t*)dmalloc(c, room * 8);
-    bc = (uint32_t*)dmalloc(c, room * 4);
-    if (!bw || !bc) break;
     rfxk::part2(c, aw, bw, bsq, fcur, P2q, cfg.bin_shift, cur, (uint32_t)cap, ac, bc, ~0ull, "k_surv_part2");
+    // every survivor is kept and fine bins are exact, so the sort writes the records in place
+    rfxk::surv_sort(c, bw, bc, bsq, Pq, cfg.bin_shift, t->lut_tinv, t->ntab, cfg.sel_bits, big->keys, big->counts,
+                    big->pos);
     uint64_t total_out = 0;
+    std::vector<uint32_t> h_cur(ncur + 2);
+    std::vector<unsigned int> pflags(t->pend->size(), 1u);
     e = queue_read(c, &total_out, bsq + Pq, 8);
     if (e == hipSuccess) e = queue_read(c, h_cur.data(), cur, (ncur + 2) * 4);
+    for (size_t i = 0; i < pflags.size() && e == hipSuccess; ++i)
+      e = queue_read(c, &pflags[i], (*t->pend)[i].cur + (*t->pend)[i].ncur, 4);
+    if (e == hipSuccess && histo) e = queue_read(c, histo, d_histo, RFX_HISTO_BINS * 8);
     if (e == hipSuccess) e = ctx_sync(c);  // h_inst / h_bs stay alive until here
-    if (e != hipSuccess) { hip_fail(e, "msp_emit"); break; }
-    if (h_cur[ncur + 1]) {
-      snprintf(g_err, sizeof g_err, "MSP: a bin could not be split far enough to fit LDS");
-      break;
-    }
-    if (h_cur[ncur]) {  // a coarse pos bin overflowed: rerun with what the fullest one needs
-      if (attempt == 1) {
-        snprintf(g_err, sizeof g_err, "MSP: survivor bins overflowed twice (internal error)");
-        break;
-      }
-      cap = 1;
-      for (uint32_t cb = 0; cb < P1; ++cb) cap = std::max<uint64_t>(cap, h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
-      drop_try();
+    drop();
+    if (e != hipSuccess) { hip_fail(e, "msp_emit"); rfx_records_free(big); return nullptr; }
+    bool redo = false;
+    for (unsigned int f : pflags) redo |= f != 0;
+    if (!t->pend->empty() && msp_settle(t, pflags) != RFX_OK) { rfx_records_free(big); return nullptr; }
+    if (redo) {  // a block was re-partitioned: count again
+      rfx_records_free(big);
       continue;
     }
-    // every survivor is kept and fine bins are exact, so the sort writes the records in place
-    rec = records_alloc(c, t->k, t->lsize, t->cols, total_out);
-    if (rec)
-      rfxk::surv_sort(c, bw, bc, bsq, Pq, cfg.bin_shift, t->lut_tinv, t->ntab, cfg.sel_bits, rec->keys, rec->counts,
-                      rec->pos);
-    break;
+    if (h_cur[ncur + 1]) {
+      snprintf(g_err, sizeof g_err, "MSP: a bin could not be split far enough to fit LDS");
+      rfx_records_free(big);
+      return nullptr;
+    }
+    if (h_cur[ncur]) {  // a coarse pos bin overflowed: rerun with what the fullest one needs
+      cap = 1;
+      for (uint32_t cb = 0; cb < P1; ++cb) cap = std::max<uint64_t>(cap, h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
+      rfx_records_free(big);
+      continue;
+    }
+    big->n = total_out;
+    rec = big;
+    // Give a large slack back (exact arrays, device copies); a small one is not worth the 40 B/record of
+    // copy traffic -- the arrays return to the pool with the records anyway.
+    if ((room - total_out) * 20 > (2ull << 30)) {
+      rfx_records* fit = records_alloc(c, t->k, t->lsize, t->cols, total_out);
+      if (fit) {
+        e = hipMemcpyAsync(fit->keys, big->keys, total_out * 8, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(fit->counts, big->counts, total_out * 4, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(fit->pos, big->pos, total_out * 8, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) {
+          rfx_records_free(big);  // stream-ordered pool: reused only by later work of this stream
+          rec = fit;
+        } else {
+          rfx_records_free(fit);
+        }
+      }
+    }
   }
-  cleanup();
+  if (!rec && !g_err[0]) snprintf(g_err, sizeof g_err, "MSP: emit did not converge (internal error)");
   return rec;
 }
 
 static void p2l_drop_segments(rfx_table* t) {
+  msp_forget_pending(t);
   for (auto& sg : *t->segs) {
     dfree(t->ctx, sg.inst);
     dfree(t->ctx, sg.bin_start);
@@ -1084,14 +1212,19 @@ rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint
   if (!t) return nullptr;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
+  if (t->pend_error) {
+    snprintf(g_err, sizeof g_err, "a deferred MSP re-partition failed (%s); the table is incomplete", rfx_strerror(t->pend_error));
+    return nullptr;
+  }
   if (!t->segs->empty()) {
     if (!t->table_active) {
-      rfx_records* r = t->seg_kind == RFX_COUNT_MSP ? msp_emit(t, lower, upper) : p2l_emit(t, lower, upper);
+      if (t->seg_kind == RFX_COUNT_MSP) return msp_emit(t, lower, upper, histo);
+      rfx_records* r = p2l_emit(t, lower, upper);
       if (r && histo && rfx_records_histo(r, histo) != RFX_OK) { rfx_records_free(r); return nullptr; }
       return r;
     }
     // both paths hold data: fold the instance lists into the table as (key,count) pairs
-    rfx_records* part = t->seg_kind == RFX_COUNT_MSP ? msp_emit(t, 1, ~0ull) : p2l_emit(t, 1, ~0ull);
+    rfx_records* part = t->seg_kind == RFX_COUNT_MSP ? msp_emit(t, 1, ~0ull, nullptr) : p2l_emit(t, 1, ~0ull);
     if (!part) return nullptr;
     const int rc = rfx_count_add_pairs_dev(t, part->keys, part->counts, part->n);
     rfx_records_free(part);

@@ -44,6 +44,7 @@ struct rfx_ctx {
   std::map<std::string, rfx_prof_acc> acc;
   std::map<void*, size_t> allocs;
   std::multimap<size_t, void*> pool;  // freed blocks kept for reuse, keyed by size
+  std::vector<struct rfx_table*> pend_tables;  // tables with unread MSP capacity flags
   // pinned host scratch: small read-backs and uploads go through it (pageable copies cost a
   // staging round trip each); a bump allocator that is reset at every stream synchronisation
   char* pin = nullptr;
@@ -98,6 +99,14 @@ struct rfx_segment {  // the k-mer instances of one rfx_count_add call, grouped 
   uint64_t kmers;       // upper bound of the k-mer instances represented (P2L: n)
 };
 
+struct rfx_reads;
+struct rfx_pending_add {  // an MSP partition whose capacity flag has not been read back yet
+  const rfx_reads* r;    // needed for the exact redo, so rfx_reads_free settles the add first
+  uint32_t* cur;         // device: coarse cursors, flag at cur[ncur]
+  size_t seg;            // index into rfx_table::segs
+  size_t ncur;
+};
+
 struct rfx_reads_view {
   const uint64_t* codes;
   const uint32_t* acgt;
@@ -136,6 +145,8 @@ struct rfx_table {
   int table_active;   // the global table holds data
   uint32_t p2l_bins;  // 0 until the first P2L / MSP add
   int seg_kind;       // what the segments hold: 0 nothing yet, RFX_COUNT_P2L words, RFX_COUNT_MSP records
+  std::vector<rfx_pending_add>* pend;
+  int pend_error;     // a deferred redo failed: the table cannot be finished
   std::vector<rfx_segment>* segs;
   uint64_t* lut_t;     // device LUT of T (key -> sortable word), null when M is rank deficient
   uint64_t* lut_tinv;  // device LUT of T^-1
@@ -237,6 +248,9 @@ void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* 
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err);
 void surv_hist(rfx_ctx*, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,
                uint64_t* fine_tot);
+void flag_if_gt(rfx_ctx*, const uint64_t* d_value, uint64_t limit, unsigned int* d_flag);
+// count-of-counts over the filled part of fixed-capacity coarse bins
+void histo_bins(rfx_ctx*, const uint32_t* counts, const uint32_t* coarse_cur, uint32_t cap, unsigned long long* d_histo);
 void surv_sort(rfx_ctx*, const uint64_t* bw, const uint32_t* bc, const uint64_t* bs, uint32_t P, int bin_shift,
                const uint64_t* lut_inv, int ntab, int sel_bits, uint64_t* out_keys, uint32_t* out_counts,
                uint64_t* out_pos);

@@ -471,6 +471,29 @@ __global__ __launch_bounds__(L2_BLOCK) void k_surv_hist(const uint64_t* __restri
     atomicAdd(&fine_tot[(uint64_t)cb * P2 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
 }
 
+__global__ void k_flag_if_gt(const uint64_t* __restrict__ v, uint64_t limit, unsigned int* __restrict__ flag) {
+  if (*v > limit) atomicExch(flag, 1u);
+}
+
+// Count-of-counts (jf/sub_commands/histo_main.cc:40-49: bin = min(count, 10001)) of the survivors as the
+// leaf left them: the filled part of each fixed-capacity coarse bin.
+__global__ __launch_bounds__(256) void k_histo_bins(const uint32_t* __restrict__ counts,
+                                                     const uint32_t* __restrict__ coarse_cur, uint32_t cap, uint32_t W,
+                                                     unsigned long long* __restrict__ g_histo) {
+  __shared__ uint32_t s_h[RFX_HISTO_BINS];
+  for (int i = threadIdx.x; i < RFX_HISTO_BINS; i += blockDim.x) s_h[i] = 0;
+  __syncthreads();
+  const uint32_t cb = blockIdx.x / W, jj = blockIdx.x - cb * W;
+  const uint64_t a = (uint64_t)cb * cap, e = a + min(coarse_cur[cb * P1_CUR_STRIDE], cap);
+  for (uint64_t i = a + (uint64_t)jj * blockDim.x + threadIdx.x; i < e; i += (uint64_t)W * blockDim.x) {
+    const uint32_t c = counts[i];
+    atomicAdd(&s_h[c > 10001u ? 10001u : c], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RFX_HISTO_BINS; i += blockDim.x)
+    if (s_h[i]) atomicAdd(&g_histo[i], (unsigned long long)s_h[i]);
+}
+
 constexpr int SS_BLOCK = 512;
 constexpr int SS_CAP = 2048;
 
@@ -585,6 +608,17 @@ void surv_hist(rfx_ctx* c, const uint64_t* buf_a, const uint32_t* coarse_cur, ui
   const uint32_t W = 8;
   hipLaunchKernelGGL(k_surv_hist, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, coarse_cur, cap_a, P2, shift2,
                      W, (unsigned long long*)fine_tot);
+}
+
+void flag_if_gt(rfx_ctx* c, const uint64_t* d_value, uint64_t limit, unsigned int* d_flag) {
+  hipLaunchKernelGGL(k_flag_if_gt, dim3(1), dim3(1), 0, c->stream, d_value, limit, d_flag);
+}
+
+void histo_bins(rfx_ctx* c, const uint32_t* counts, const uint32_t* coarse_cur, uint32_t cap,
+                unsigned long long* d_histo) {
+  rfx_span sp(c, "k_histo");
+  const uint32_t W = 4;
+  hipLaunchKernelGGL(k_histo_bins, dim3(P1_BINS * W), dim3(256), 0, c->stream, counts, coarse_cur, cap, W, d_histo);
 }
 
 void surv_sort(rfx_ctx* c, const uint64_t* bw, const uint32_t* bc, const uint64_t* bs, uint32_t P, int bin_shift,

@@ -31,13 +31,24 @@ HISTO_BINS = capi.HISTO_BINS
 
 
 def revcomp_keys(keys: np.ndarray, k: int) -> np.ndarray:
-    keys = np.asarray(keys, dtype=np.uint64)
-    r = np.zeros_like(keys)
-    x = keys.copy()
-    for _ in range(k):
-        r = (r << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
-        x >>= np.uint64(2)
-    return r
+    """Reverse complement of 2-bit packed k-mers: complement every base, reverse the 32 base slots of
+    the word (pairs inside nibbles, nibbles inside bytes, then the bytes), shift the k bases down."""
+    x = ~np.asarray(keys, dtype=np.uint64)
+    m2, m4 = np.uint64(0x3333333333333333), np.uint64(0x0F0F0F0F0F0F0F0F)
+    x = ((x >> np.uint64(2)) & m2) | ((x & m2) << np.uint64(2))
+    x = ((x >> np.uint64(4)) & m4) | ((x & m4) << np.uint64(4))
+    return x.byteswap() >> np.uint64(64 - 2 * k)
+
+
+class _ShardResult(dict):
+    """Result of TrioShard.run; the per-pair boolean vector is unpacked from the hit mask on first use."""
+
+    def __missing__(self, key):
+        if key != "pulled":
+            raise KeyError(key)
+        v = self["_pulled_fn"]()
+        self[key] = v
+        return v
 
 
 class HipBackend:
@@ -98,9 +109,18 @@ class HipBackend:
             _, mask, _ = mset.filter(block, thresh, last_base_skipped=True, want_hits=False)
         finally:
             mset.free()
-        bits = np.unpackbits(mask.view(np.uint8), bitorder="little")[:block.n].astype(bool)
         half = block.n // 2
-        return bits[:half] | bits[half:2 * half]
+        m8 = mask.view(np.uint8)
+
+        def unpack():
+            bits = np.unpackbits(m8, bitorder="little")[:block.n].astype(bool)
+            return bits[:half] | bits[half:2 * half]
+
+        if half % 8 == 0:   # the two mates' bits line up byte for byte: OR and popcount the packed mask
+            n_pulled = int(np.bitwise_count(m8[:half // 8] | m8[half // 8:half // 4]).sum())
+        else:
+            n_pulled = int(unpack().sum())
+        return n_pulled, unpack
 
     def free(self, rec):
         rec.free()
@@ -192,15 +212,18 @@ class TrioShard:
             t = torch.tensor(n_rec, dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             n_rec = t.tolist()
-        pulled = self.be.filter_pairs(keys, subject_block, self.thresh)
-        n_pulled = int(pulled.sum())
+        res = self.be.filter_pairs(keys, subject_block, self.thresh)
+        if isinstance(res, tuple):       # (count, unpack-on-demand): the HIP backend keeps the mask packed
+            n_pulled, pulled_fn = res
+        else:                            # a plain boolean vector (checker backends)
+            n_pulled, pulled_fn = int(res.sum()), (lambda: res)
         if self.world > 1:
             t = torch.tensor([n_pulled], dtype=torch.int64,
                              device="cpu" if dist.get_backend(self.group) == "gloo" else self.be.device)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             n_pulled = int(t.item())
-        out = {"n_mutant": len(keys), "n_pulled": n_pulled, "n_records": n_rec, "histos": histos,
-               "mutant_keys": keys, "pulled": pulled}
+        out = _ShardResult({"n_mutant": len(keys), "n_pulled": n_pulled, "n_records": n_rec, "histos": histos,
+                            "mutant_keys": keys, "_pulled_fn": pulled_fn})
         if keep_records:
             out["records"] = recs
         else:

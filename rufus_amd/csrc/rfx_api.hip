@@ -972,7 +972,11 @@ static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper, uint6
   rfx_ctx* c = t->ctx;
   const uint32_t P = t->p2l_bins, P1 = (uint32_t)rfxk::p1_bins();
   const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
-  double frac = lower >= 2 ? 0.25 : 0.6;
+  // Survivors per instance: unknown before counting.  Samples of one run look alike, so the ratio the
+  // last emit on this ctx saw (+30 %) is the guess; the first emit assumes a quarter (singletons
+  // dropped) or 60 %.  A guess that is too small costs one rerun with exact capacities.
+  double& seen = c->msp_surv_frac[lower >= 2 ? 1 : 0];
+  double frac = seen > 0 ? seen * 1.3 : (lower >= 2 ? 0.25 : 0.6);
   if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
   uint64_t cap = 0;  // survivors per coarse pos bin; 0 = guess from the instance count
   rfx_records* rec = nullptr;
@@ -1065,6 +1069,7 @@ static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper, uint6
     }
     big->n = total_out;
     rec = big;
+    if (kmers) seen = (double)total_out / (double)kmers;
     // Give a large slack back (exact arrays, device copies); a small one is not worth the 40 B/record of
     // copy traffic -- the arrays return to the pool with the records anyway.
     if ((room - total_out) * 20 > (2ull << 30)) {

@@ -45,6 +45,7 @@ struct rfx_ctx {
   std::map<void*, size_t> allocs;
   std::multimap<size_t, void*> pool;  // freed blocks kept for reuse, keyed by size
   std::vector<struct rfx_table*> pend_tables;  // tables with unread MSP capacity flags
+  double msp_surv_frac[2] = {0, 0};            // survivors / instances seen by the last MSP emit ([lower >= 2])
   // pinned host scratch: small read-backs and uploads go through it (pageable copies cost a
   // staging round trip each); a bump allocator that is reset at every stream synchronisation
   char* pin = nullptr;

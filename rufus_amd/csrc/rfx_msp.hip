@@ -26,20 +26,16 @@ constexpr int MSP_WL = 15;    // m-mers per k-mer (window of the sliding minimum
 constexpr int MSP_NMAX = 4;   // k-mers per record: k + 3 <= 28 bases = 56 bits
 constexpr uint64_t MSP_EMPTY = 1ull << 55;  // no record looks like this: a 1-k-mer record uses 2k <= 50 bits
 
+// One multiply each: 32-bit integer multiplies are quarter rate, and k_msp_part1 hashes every base.
+// The xor keeps the all-A m-mer (c = 0) from hashing to 0 = always the minimum.
 __device__ __forceinline__ uint32_t mmer_hash(uint32_t c) {
-  c *= 0x9E3779B1u;
-  c ^= c >> 15;
-  c *= 0x85EBCA77u;
-  c ^= c >> 13;
-  return c;
+  c = (c ^ 0x5BD1E995u) * 0x9E3779B1u;
+  return c ^ (c >> 15);
 }
 
-// The minimum of 15 hashes crowds towards 0: remix before taking the top bits.
+// The minimum of 15 hashes crowds towards 0: spread it again before taking the top bits.
 __device__ __forceinline__ uint32_t msp_bin(uint32_t minh, int bin_bits) {
-  uint32_t x = minh * 0xC2B2AE3Du;
-  x ^= x >> 16;
-  x *= 0x27D4EB2Fu;
-  return x >> (32 - bin_bits);
+  return (minh * 0xC2B2AE3Du) >> (32 - bin_bits);
 }
 
 // HMODE 0: scatter into fixed-capacity coarse bins + 16-bit fine histogram (one pass, optimistic)

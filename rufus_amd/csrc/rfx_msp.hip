@@ -276,15 +276,19 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
         }
         if (r > 0 && (split_hash(key) >> (32 - r)) != j) return;
         // The probe is ONE returning CAS: it yields "was empty, now mine", "already mine" or "someone
-        // else's" without a separate read-and-branch for the new-key case.  s_ovf is looked at before
-        // every insert: at most one insert per thread can follow the flag, which the LEAF_TBL -
-        // LEAF_FILL spare slots absorb -- probing always terminates.
-        if (__hip_atomic_load(&s_ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+        // else's" without a separate read-and-branch for the new-key case.  New keys are only counted
+        // (no returned ticket: one wave-aggregated LDS add); the count is looked at before every
+        // insert, so at most one key per thread can follow LEAF_FILL, which the LEAF_TBL - LEAF_FILL
+        // spare slots absorb -- probing always terminates.  A skipped insert voids the pass.
+        if (__hip_atomic_load(&s_nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)LEAF_FILL) {
+          s_ovf = 1;
+          return;
+        }
         uint32_t slot = leaf_hash(key);
         for (;;) {
           unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
           if (old == RFX_EMPTY) {
-            if (atomicAdd(&s_nd, 1u) >= (uint32_t)LEAF_FILL) s_ovf = 1;
+            atomicAdd(&s_nd, 1u);
             old = key;
           }
           if (old == key) {

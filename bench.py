@@ -216,10 +216,10 @@ def main():
         pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
         if os.path.exists(pmc_path) and args.pairs == 500_000 and args.genome == 5_000_000:
             pmc = json.load(open(pmc_path))
-            if all(n in pmc for n in k2):
-                line["roofline"]["traffic"] = sum(pmc[n]["hbm_bytes_per_launch"] * (2 if n == "k_bin_offsets" else 1)
-                                                  for n in k2)
-                line["roofline"]["traffic_source"] = "profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+            if "_chain" in pmc and "k_msp_part1" in k2 and "k_msp_part1" in pmc:
+                line["roofline"]["traffic"] = pmc["_chain"]["hbm_bytes_per_sample"]
+                line["roofline"]["traffic_source"] = ("profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                                      "all launches of the chain, per sample)")
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_pairs * 10)

@@ -41,8 +41,21 @@ def main():
         wn, wv = w.get(k, (0, 0.0))
         out[k] = {"launches": max(fn, wn), "FETCH_SIZE_KB_avg": round(fv, 1), "WRITE_SIZE_KB_avg": round(wv, 1),
                   "hbm_bytes_per_launch": int((2 * fv + wv) * 1024)}
+    # The count -> sorted-records chain of one sample (what bench.py prices against the roofline): every
+    # launch between two k_msp_part1 launches that belongs to rfx_count_add / rfx_count_finish.
+    chain = ["k_msp_part1", "k_msp_count", "k_bin_group_sums", "k_bin_offsets", "k_scan_tail", "k_part2", "k_flag_if_gt",
+             "k_msp_leaf", "k_surv_hist", "k_surv_sort", "k_bin_count", "k_part1", "k_leaf", "k_leaf_compact",
+             "k_bin_scatter", "k_tmp_start"]
+    samples = max(out.get("k_msp_part1", {}).get("launches", 0), out.get("k_part1", {}).get("launches", 0),
+                  out.get("k_bin_scatter", {}).get("launches", 0))
+    if samples:
+        tot = sum(out[k]["hbm_bytes_per_launch"] * out[k]["launches"] for k in chain if k in out)
+        out["_chain"] = {"kernels": [k for k in chain if k in out], "samples": samples,
+                         "hbm_bytes_per_sample": int(tot / samples)}
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
-    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+    if "_chain" in out:
+        print(f"count chain: {out['_chain']['hbm_bytes_per_sample'] / 1e6:.1f} MB per sample over {samples} samples")
+    for k, v in sorted(((k, v) for k, v in out.items() if k != "_chain"), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{k:26s} {v['launches']:4d} {v['FETCH_SIZE_KB_avg']:14.1f} {v['WRITE_SIZE_KB_avg']:14.1f} "
               f"{v['hbm_bytes_per_launch'] / 1e6:10.1f} MB")
 

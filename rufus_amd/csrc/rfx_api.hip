@@ -893,21 +893,21 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
   uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
   uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
-  uint32_t* fine_cur = (uint32_t*)dmalloc(c, (size_t)P * 4);
-  uint32_t* cur = (uint32_t*)dmalloc(c, (g.ncur + 1) * 4);  // [ncur] = flag
+  // one zeroed block: coarse cursors, [ncur] = flag, then the fine-bin cursors of k_part2
+  uint32_t* cur = (uint32_t*)dmalloc(c, (g.ncur + 1 + (size_t)P) * 4);
+  uint32_t* fine_cur = cur ? cur + g.ncur + 1 : nullptr;
   // ~3.4 k-mers per record on ordinary sequence: room for 2.5, coarse bins 25 % above even
   uint64_t cap_b = g.windows * 2 / 5 + 65536;
   if (cap_b > g.windows) cap_b = g.windows;
   const uint64_t cap_a = cap_b / P1 + cap_b / (4ull * P1) + 16384;
   uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * P1 * 8);
   uint64_t* inst = (uint64_t*)dmalloc(c, cap_b * 8);
-  auto drop = [&] { dfree(c, cnt); dfree(c, gsum); dfree(c, fine_cur); dfree(c, buf_a); };
-  if (!cnt || !gsum || !bin_start || !fine_cur || !cur || !buf_a || !inst) {
+  auto drop = [&] { dfree(c, cnt); dfree(c, gsum); dfree(c, buf_a); };
+  if (!cnt || !gsum || !bin_start || !cur || !buf_a || !inst) {
     drop(); dfree(c, cur); dfree(c, bin_start); dfree(c, inst);
     return RFX_E_NOMEM;
   }
-  HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1) * 4, c->stream));
-  HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
+  HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
   rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 0, g.G, buf_a, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
   rfxk::bin_offsets(c, cnt, (uint32_t)g.G, P, gsum, bin_start);
   rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
@@ -1001,32 +1001,32 @@ static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper, uint6
     while (Pq < 32768 && (uint64_t)Pq * 1536 < room) Pq <<= 1;
     const uint32_t P2q = Pq / P1;
     const rfx_ord_cfg cfg = ord_cfg(t, ceil_log2(Pq));
-    const uint64_t** d_inst = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
-    const uint64_t** d_bs = (const uint64_t**)dmalloc(c, nseg * sizeof(void*));
-    uint32_t* cur = (uint32_t*)dmalloc(c, (ncur + 2) * 4);  // [ncur] = capacity flag, [ncur+1] = error
+    std::vector<const uint64_t*> h_ptrs(h_inst);
+    h_ptrs.insert(h_ptrs.end(), h_bs.begin(), h_bs.end());
+    const uint64_t** d_inst = (const uint64_t**)dmalloc(c, 2 * nseg * sizeof(void*));
+    const uint64_t** d_bs = d_inst ? d_inst + nseg : nullptr;
     uint64_t* aw = (uint64_t*)dmalloc(c, room * 8);
     uint32_t* ac = (uint32_t*)dmalloc(c, room * 4);
     uint64_t* bw = (uint64_t*)dmalloc(c, room * 8);
     uint32_t* bc = (uint32_t*)dmalloc(c, room * 4);
-    uint64_t* bsq = (uint64_t*)dmalloc(c, ((size_t)Pq + 1) * 8);
-    uint32_t* fcur = (uint32_t*)dmalloc(c, (size_t)Pq * 4);
-    unsigned long long* d_histo = histo ? (unsigned long long*)dmalloc(c, RFX_HISTO_BINS * 8) : nullptr;
+    // one zeroed block: fine pos-bin sizes, histogram, coarse cursors ([ncur] = capacity flag,
+    // [ncur+1] = error), fine cursors
+    const size_t zero_bytes = ((size_t)Pq + 1 + RFX_HISTO_BINS) * 8 + (ncur + 2 + (size_t)Pq) * 4;
+    uint64_t* bsq = (uint64_t*)dmalloc(c, zero_bytes);
+    unsigned long long* d_histo = bsq ? (unsigned long long*)(bsq + Pq + 1) : nullptr;
+    uint32_t* cur = bsq ? (uint32_t*)(d_histo + RFX_HISTO_BINS) : nullptr;
+    uint32_t* fcur = bsq ? cur + ncur + 2 : nullptr;
     rfx_records* big = records_alloc(c, t->k, t->lsize, t->cols, room);
     auto drop = [&] {
-      dfree(c, d_inst); dfree(c, d_bs); dfree(c, cur); dfree(c, aw); dfree(c, ac); dfree(c, bw); dfree(c, bc);
-      dfree(c, bsq); dfree(c, fcur); dfree(c, d_histo);
+      dfree(c, d_inst); dfree(c, aw); dfree(c, ac); dfree(c, bw); dfree(c, bc); dfree(c, bsq);
     };
-    if (!d_inst || !d_bs || !cur || !aw || !ac || !bw || !bc || !bsq || !fcur || (histo && !d_histo) || !big) {
+    if (!d_inst || !aw || !ac || !bw || !bc || !bsq || !big) {
       drop();
       rfx_records_free(big);
       return nullptr;
     }
-    hipError_t e = upload(c, d_inst, h_inst.data(), nseg * sizeof(void*));
-    if (e == hipSuccess) e = upload(c, d_bs, h_bs.data(), nseg * sizeof(void*));
-    if (e == hipSuccess) e = hipMemsetAsync(cur, 0, (ncur + 2) * 4, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(bsq, 0, ((size_t)Pq + 1) * 8, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(fcur, 0, (size_t)Pq * 4, c->stream);
-    if (e == hipSuccess && histo) e = hipMemsetAsync(d_histo, 0, RFX_HISTO_BINS * 8, c->stream);
+    hipError_t e = upload(c, d_inst, h_ptrs.data(), 2 * nseg * sizeof(void*));
+    if (e == hipSuccess) e = hipMemsetAsync(bsq, 0, zero_bytes, c->stream);
     if (e != hipSuccess) { hip_fail(e, "msp_emit"); drop(); rfx_records_free(big); return nullptr; }
     rfxk::msp_leaf(c, d_inst, d_bs, nseg, h_inst[0], h_bs[0], P, t->k, t->canonical, t->lut_t, t->ntab, cfg.sel_bits,
                    cfg.c_bits - 7, t->pos_lo, t->pos_hi, lower, upper, aw, ac, cur, (uint32_t)cap, cur + ncur,

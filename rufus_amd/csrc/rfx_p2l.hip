@@ -597,30 +597,39 @@ __global__ __launch_bounds__(256) void k_leaf_compact(const uint64_t* __restrict
   }
 }
 
-// exclusive scan of v[0..n) in place, v[n] = total (one block)
+// exclusive scan of v[0..n) in place, v[n] = total (one block): every thread owns a contiguous chunk,
+// the 1024 chunk sums are scanned with wave shuffles (two levels) -- a handful of barriers for any n
 __global__ __launch_bounds__(1024) void k_scan_tail(uint64_t* __restrict__ v, uint64_t n) {
-  __shared__ uint64_t s_part[1024];
-  __shared__ uint64_t s_carry;
-  if (threadIdx.x == 0) s_carry = 0;
-  __syncthreads();
-  for (uint64_t base = 0; base < n; base += 1024) {
-    const uint64_t i = base + threadIdx.x;
-    const uint64_t x = i < n ? v[i] : 0;
-    s_part[threadIdx.x] = x;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      uint64_t add = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0;
-      __syncthreads();
-      s_part[threadIdx.x] += add;
-      __syncthreads();
-    }
-    const uint64_t incl = s_part[threadIdx.x];
-    if (i < n) v[i] = s_carry + incl - x;
-    __syncthreads();
-    if (threadIdx.x == 1023) s_carry += incl;
-    __syncthreads();
+  __shared__ uint64_t s_wave[16];
+  const uint64_t per = (n + 1023) / 1024;
+  const uint64_t a = threadIdx.x * per, e = a + per < n ? a + per : n;
+  uint64_t sum = 0;
+  for (uint64_t i = a; i < e; ++i) sum += v[i];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint64_t inc = sum;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
   }
-  if (threadIdx.x == 0) v[n] = s_carry;
+  if (lane == 63) s_wave[wv] = inc;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint64_t w = lane < 16 ? s_wave[lane] : 0;
+    uint64_t winc = w;
+    for (int off = 1; off < 16; off <<= 1) {
+      const uint64_t o = __shfl_up(winc, off);
+      if (lane >= off) winc += o;
+    }
+    if (lane < 16) s_wave[lane] = winc - w;  // exclusive prefix of the wave totals
+    if (lane == 15) v[n] = winc;
+  }
+  __syncthreads();
+  uint64_t run = s_wave[wv] + inc - sum;
+  for (uint64_t i = a; i < e; ++i) {
+    const uint64_t x = v[i];
+    v[i] = run;
+    run += x;
+  }
 }
 
 }  // namespace

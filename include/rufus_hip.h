@@ -127,11 +127,18 @@ uint64_t rfx_reads_bases(const rfx_reads*);
  * capacity_slots == 0 picks an initial size; the table grows by rehash inside the ctx budget. */
 rfx_table* rfx_count_begin(rfx_ctx*, int k, int canonical, int lsize, uint64_t capacity_slots, uint64_t pos_lo,
                            uint64_t pos_hi);
-/* Two exact implementations sit behind rfx_count_add(): RFX_COUNT_P2L partitions the k-mer instances
- * by (pos,key) prefix and counts every bin in LDS (fast path: no global atomics), RFX_COUNT_TABLE
- * inserts into an open-addressed table in HBM (any size, grows by rehash; also what
- * rfx_count_add_pairs_dev uses).  RFX_COUNT_AUTO (default) takes P2L while its transient buffers fit
- * the budget and falls back to the table.  Results are identical. */
+/* Three exact implementations sit behind rfx_count_add(); results are identical.
+ *  RFX_COUNT_MSP   (23 <= k <= 25) cuts reads into super-k-mers (runs of consecutive k-mers sharing a
+ *                  minimizer bin, 8 bytes per <= 4 k-mers), partitions those, counts every bin in LDS and
+ *                  sorts only the surviving (key,count) pairs into (pos,key) order.  Fastest, least HBM.
+ *  RFX_COUNT_P2L   (2k <= 62) partitions one 8-byte sortable word per k-mer instance by (pos,key) prefix
+ *                  and counts + sorts every bin in LDS.
+ *  RFX_COUNT_TABLE inserts into an open-addressed table in HBM (any k, grows by rehash; also what
+ *                  rfx_count_add_pairs_dev uses).
+ * RFX_COUNT_AUTO (default) takes MSP where it applies, else P2L, and falls back to the table when the
+ * transient buffers do not fit the budget.  MSP sizes its buffers optimistically; if the device reports
+ * that one did not hold, the affected read block is partitioned again with exact sizes -- at
+ * rfx_count_finish, or inside rfx_reads_free if the block is freed first (the redo needs the reads). */
 #define RFX_COUNT_AUTO 0
 #define RFX_COUNT_TABLE 1
 #define RFX_COUNT_P2L 2

@@ -770,7 +770,7 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
   if (e != hipSuccess) { hip_fail(e, "p2l_emit"); cleanup(); return nullptr; }
   rfxk::tmp_start(c, d_bs, nseg, P, tmp_start);
   rfxk::leaf(c, d_inst, d_bs, nseg, h_inst[0], h_bs[0], P, cfg, lower, upper, tmp_start, tmp_keys, tmp_counts, n_surv,
-             d_err, nullptr);
+             d_err);
   rfxk::scan_tail(c, n_surv, P);
   uint64_t total_out = 0;
   unsigned int err = 0;

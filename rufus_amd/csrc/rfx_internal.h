@@ -258,8 +258,7 @@ void surv_sort(rfx_ctx*, const uint64_t* bw, const uint32_t* bc, const uint64_t*
 void tmp_start(rfx_ctx*, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out /* P+1 */);
 void leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, const uint64_t* inst0,
           const uint64_t* bs0, uint32_t P, const rfx_ord_cfg&, uint64_t lower, uint64_t upper,
-          const uint64_t* tmp_start, uint64_t* tmp_w, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err,
-          const uint32_t* pay0 /* null: every word counts 1 */);
+          const uint64_t* tmp_start, uint64_t* tmp_w, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err);
 void scan_tail(rfx_ctx*, uint64_t* v, uint64_t n);  // exclusive scan in place, v[n] = total
 void leaf_compact(rfx_ctx*, const uint64_t* tmp_w, const uint32_t* tmp_counts, const uint64_t* tmp_start,
                   const uint64_t* out_off, uint32_t P, const uint64_t* lut_inv, int ntab, int sel_bits,

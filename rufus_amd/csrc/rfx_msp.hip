@@ -10,11 +10,13 @@
 //                ~3.2 k-mers per record -> 2.5 B per instance.  128 coarse bins, LDS-staged runs.
 //   k_part2      coarse -> fine bins (same kernel as P2L; the sub-bin is in the record)
 //   k_msp_leaf   one workgroup per fine bin: expand the records, count canonical k-mers in an LDS
-//                hash table; every instance of a k-mer has the same minimizer, so counts are final.
+//                hash table (identical records are merged in a small cache first); every instance of
+//                a k-mer has the same minimizer, so counts are final.
 //                Only the survivors (lower <= count <= upper) get w = T * key and leave, appended to
 //                128 coarse pos bins.
-//   k_surv_hist, k_part2<payload>, k_leaf<payload>, k_leaf_compact
-//                the (few) survivors are put in (pos,key) order by the P2L machinery.
+//   k_surv_hist, k_part2<payload>, k_surv_sort
+//                the (few) survivors are partitioned by pos prefix and sorted in LDS straight into the
+//                output records (sizes are exact: no compaction pass).
 //
 // The result is the same sorted record list (jf/include/jellyfish/sorted_dumper.hpp:80-112 order).
 #include "rfx_devutil.h"

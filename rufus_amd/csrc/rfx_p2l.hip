@@ -389,8 +389,6 @@ __global__ __launch_bounds__(256) void k_tmp_start(const uint64_t* const* __rest
 
 // One workgroup per bin.  If a bin holds more distinct words than the LDS table (or more survivors
 // than the sort area) it is re-run split into 2^r sub-ranges of w, in order -- exact for any input.
-// PAYLOAD: the words of segment 0 carry a 32-bit count each (pay0), added instead of 1 (nseg == 1).
-template <bool PAYLOAD>
 __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __restrict__ seg_inst,
                                                       const uint64_t* const* __restrict__ seg_bs, int nseg,
                                                       const uint64_t* __restrict__ inst0,
@@ -398,8 +396,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
                                                       rfx_ord_cfg cfg, uint64_t lower, uint64_t upper,
                                                       const uint64_t* __restrict__ tmp_start,
                                                       uint64_t* __restrict__ tmp_w, uint32_t* __restrict__ tmp_counts,
-                                                      uint64_t* __restrict__ n_surv, unsigned int* __restrict__ err,
-                                                      const uint32_t* __restrict__ pay0) {
+                                                      uint64_t* __restrict__ n_surv, unsigned int* __restrict__ err) {
   __shared__ unsigned long long s_keys[LEAF_TBL];  // hash table keys; reused as the bucketed survivor words
   __shared__ uint32_t s_cnt[LEAF_TBL];             // hash table counts; reused as the bucketed survivor counts
   __shared__ uint64_t s_w[LEAF_SORT];
@@ -411,7 +408,6 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
   // First batch of segment 0 of a bin (inst0/bs0 are segment 0's arrays passed by value, no pointer
   // chase).  Issued one bin ahead so the HBM latency hides behind the previous bin's sort and emit.
   uint64_t pre[LEAF_ILP];
-  uint32_t pre_c[PAYLOAD ? LEAF_ILP : 1];
   uint64_t pre_a = 0, pre_e = 0, pre_out0 = 0;
   auto prefetch = [&](uint32_t b) {
     if (b >= P) return;
@@ -422,7 +418,6 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
     for (int u = 0; u < LEAF_ILP; ++u) {
       const uint64_t i = pre_a + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
       pre[u] = i < pre_e ? inst0[i] : RFX_EMPTY;
-      if (PAYLOAD) pre_c[u] = i < pre_e ? pay0[i] : 0;
     }
   };
   prefetch(blockIdx.x);
@@ -453,19 +448,14 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
           const uint64_t* __restrict__ src = sg == 0 ? inst0 : seg_inst[sg];
           for (uint64_t base = a; base < e; base += (uint64_t)LEAF_ILP * LEAF_BLOCK) {
             uint64_t w[LEAF_ILP];
-            uint32_t wc[PAYLOAD ? LEAF_ILP : 1];
             if (sg == 0 && base == a && !prefetched_next) {  // first pass over the bin: already in registers
 #pragma unroll
-              for (int u = 0; u < LEAF_ILP; ++u) {
-                w[u] = pre[u];
-                if (PAYLOAD) wc[u] = pre_c[u];
-              }
+              for (int u = 0; u < LEAF_ILP; ++u) w[u] = pre[u];
             } else {
 #pragma unroll
               for (int u = 0; u < LEAF_ILP; ++u) {  // independent loads, all in flight before the first insert
                 const uint64_t i = base + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
                 w[u] = i < e ? src[i] : RFX_EMPTY;
-                if (PAYLOAD) wc[u] = i < e ? pay0[i] : 0;
               }
             }
 #pragma unroll
@@ -487,7 +477,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
                   }
                 }
                 if (cur == key) {
-                  atomicAdd(&s_cnt[slot], PAYLOAD ? wc[u] : 1u);
+                  atomicAdd(&s_cnt[slot], 1u);
                   break;
                 }
                 slot = (slot + 1) & (LEAF_TBL - 1);
@@ -738,17 +728,12 @@ void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, 
 
 void leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, const uint64_t* inst0,
           const uint64_t* bs0, uint32_t P, const rfx_ord_cfg& cfg, uint64_t lower, uint64_t upper,
-          const uint64_t* tmp_start_, uint64_t* tmp_w, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err,
-          const uint32_t* pay0) {
-  rfx_span sp(c, pay0 ? "k_leaf_sort" : "k_leaf");
+          const uint64_t* tmp_start_, uint64_t* tmp_w, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err) {
+  rfx_span sp(c, "k_leaf");
   // a few bins per workgroup so that the one-bin-ahead prefetch has something to overlap with
   const uint32_t grid = P < (uint32_t)c->n_cu * 4 ? P : (uint32_t)c->n_cu * 4;
-  if (pay0)
-    hipLaunchKernelGGL(k_leaf<true>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0, P,
-                       cfg, lower, upper, tmp_start_, tmp_w, tmp_counts, n_surv, err, pay0);
-  else
-    hipLaunchKernelGGL(k_leaf<false>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0,
-                       P, cfg, lower, upper, tmp_start_, tmp_w, tmp_counts, n_surv, err, pay0);
+  hipLaunchKernelGGL(k_leaf, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0, P, cfg,
+                     lower, upper, tmp_start_, tmp_w, tmp_counts, n_surv, err);
 }
 
 void scan_tail(rfx_ctx* c, uint64_t* v, uint64_t n) {

@@ -695,7 +695,7 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
     fine_cur = nullptr;
     if (!flag) {
       drop();
-      t->segs->push_back(rfx_segment{inst, windows, bin_start, windows});
+      t->segs->push_back(rfx_segment{inst, windows, bin_start, windows, P});
       t->seg_kind = RFX_COUNT_P2L;
       return RFX_OK;
     }
@@ -733,7 +733,7 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
                       inst);
   }
   drop();
-  t->segs->push_back(rfx_segment{inst, total, bin_start, total});
+  t->segs->push_back(rfx_segment{inst, total, bin_start, total, P});
   t->seg_kind = RFX_COUNT_P2L;
   return RFX_OK;
 }
@@ -870,7 +870,7 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
     return fail(RFX_E_HIP);
   }
   drop();
-  *seg = rfx_segment{inst, total, bin_start, g.windows};
+  *seg = rfx_segment{inst, total, bin_start, g.windows, P};
   return RFX_OK;
 }
 
@@ -913,7 +913,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
   rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
   drop();
-  t->segs->push_back(rfx_segment{inst, cap_b, bin_start, g.windows});
+  t->segs->push_back(rfx_segment{inst, cap_b, bin_start, g.windows, P});
   t->seg_kind = RFX_COUNT_MSP;
   if (t->pend->empty()) c->pend_tables.push_back(t);
   t->pend->push_back(rfx_pending_add{r, cur, t->segs->size() - 1, g.ncur});
@@ -950,6 +950,52 @@ static int msp_resolve(rfx_table* t) {
   return msp_settle(t, flags);
 }
 
+// Bring every segment to 2^to_bits bins: segments of one bin count are refined together into ONE
+// new segment (slice tag + histogram, scan, third partition pass), at most 6 bits per step.
+static int msp_refine(rfx_table* t, int to_bits) {
+  rfx_ctx* c = t->ctx;
+  for (;;) {
+    uint32_t b = 0;  // the smallest bin count still below the target
+    for (auto& sg : *t->segs)
+      if (sg.bins < (1u << to_bits) && (b == 0 || sg.bins < b)) b = sg.bins;
+    if (!b) return RFX_OK;
+    const int from_bits = ceil_log2(b);
+    const int step = std::min(6, to_bits - from_bits);
+    const uint32_t Pn = b << step;
+    uint64_t total = 0, kmers = 0;
+    for (auto& sg : *t->segs)
+      if (sg.bins == b) {
+        total += sg.n;
+        kmers += sg.kmers;
+      }
+    uint64_t* fine = (uint64_t*)dmalloc(c, ((size_t)Pn + 1) * 8);
+    uint32_t* fine_cur = (uint32_t*)dmalloc(c, (size_t)Pn * 4);
+    uint64_t* out = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
+    if (!fine || !fine_cur || !out) { dfree(c, fine); dfree(c, fine_cur); dfree(c, out); return RFX_E_NOMEM; }
+    HIPCHK(hipMemsetAsync(fine, 0, ((size_t)Pn + 1) * 8, c->stream));
+    HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)Pn * 4, c->stream));
+    for (auto& sg : *t->segs)
+      if (sg.bins == b) rfxk::slice_tag(c, sg.inst, sg.bin_start, t->k, t->canonical, from_bits, from_bits + step, fine);
+    rfxk::scan_tail(c, fine, Pn);
+    for (auto& sg : *t->segs)
+      if (sg.bins == b)
+        rfxk::part2(c, sg.inst, out, fine, fine_cur, 1u << step, 58, nullptr, 0, nullptr, nullptr, total, "k_part3",
+                    sg.bin_start, b);
+    dfree(c, fine_cur);
+    std::vector<rfx_segment> keep;
+    for (auto& sg : *t->segs) {
+      if (sg.bins == b) {
+        dfree(c, sg.inst);  // stream-ordered pool: reused only by later work of this stream
+        dfree(c, sg.bin_start);
+      } else {
+        keep.push_back(sg);
+      }
+    }
+    keep.push_back(rfx_segment{out, total, fine, kmers, Pn});
+    *t->segs = keep;
+  }
+}
+
 static void rfx_reads_release_pending(const rfx_reads* r) {
   rfx_ctx* c = r->ctx;
   std::vector<rfx_table*> hit;
@@ -970,8 +1016,27 @@ static void rfx_reads_release_pending(const rfx_reads* r) {
 // totals, the capacity flags of this emit AND of the pending adds, and the histogram come back together.
 static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {
   rfx_ctx* c = t->ctx;
-  const uint32_t P = t->p2l_bins, P1 = (uint32_t)rfxk::p1_bins();
+  const uint32_t P1 = (uint32_t)rfxk::p1_bins();
   const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
+  // One bin count for all segments; more bins when the table holds more than ~1.5 x 16 K instances per
+  // bin (several read blocks, or blocks far beyond 1 M reads) -- the LDS table of the leaf is fixed.
+  {
+    uint64_t kmers = 0;
+    uint32_t pmax = 0, pmin = ~0u;
+    for (auto& sg : *t->segs) {
+      kmers += sg.kmers;
+      pmax = std::max(pmax, sg.bins);
+      pmin = std::min(pmin, sg.bins);
+    }
+    int to_bits = ceil_log2(pmax);
+    while (to_bits < 24 && (kmers >> to_bits) > 24576) ++to_bits;
+    if (getenv("RFX_MSP_REFINE_BITS")) to_bits = std::max(to_bits, atoi(getenv("RFX_MSP_REFINE_BITS")));
+    if (pmin < (1u << to_bits)) {
+      if (msp_resolve(t) != RFX_OK) return nullptr;  // refinement replaces segments: settle the adds first
+      if (msp_refine(t, to_bits) != RFX_OK) return nullptr;
+    }
+  }
+  const uint32_t P = t->segs->front().bins;
   // Survivors per instance: unknown before counting.  Samples of one run look alike, so the ratio the
   // last emit on this ctx saw (+30 %) is the guess; the first emit assumes a quarter (singletons
   // dropped) or 60 %.  A guess that is too small costs one rerun with exact capacities.

@@ -98,6 +98,7 @@ struct rfx_segment {  // the k-mer instances of one rfx_count_add call, grouped 
   uint64_t n;           // entries of inst
   uint64_t* bin_start;  // device, P+1 entries
   uint64_t kmers;       // upper bound of the k-mer instances represented (P2L: n)
+  uint32_t bins;        // MSP: bins of THIS segment (segments are brought to a common count before the leaf)
 };
 
 struct rfx_reads;
@@ -238,7 +239,8 @@ void part1_fused(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab,
 // pay_a != null: 32-bit payload per word moves along.  sub-bin of a word = (w >> shift2) & (P2 - 1).
 void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur,
            uint32_t P2, int shift2, const uint32_t* coarse_cur, uint32_t cap_a, const uint32_t* pay_a,
-           uint32_t* pay_b, uint64_t cap_b /* entries buf_b can hold */, const char* span);
+           uint32_t* pay_b, uint64_t cap_b /* entries buf_b can hold */, const char* span,
+           const uint64_t* coarse_start = nullptr /* n_coarse+1 explicit coarse extents */, uint32_t n_coarse = 0);
 // MSP path (rfx_msp.hip)
 int msp_k_ok(int k);
 void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bits, int hmode, int grid,
@@ -247,6 +249,10 @@ void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* 
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err);
+// refinement of a record partition from 2^from_bits to 2^to_bits bins: writes each record's slice (the
+// next to_bits-from_bits bits of its minimizer hash) into the record's sub-bin field and counts the new bins
+void slice_tag(rfx_ctx*, uint64_t* inst, const uint64_t* bin_start, int k, int canonical, int from_bits, int to_bits,
+               uint64_t* fine_tot);
 void surv_hist(rfx_ctx*, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,
                uint64_t* fine_tot);
 void flag_if_gt(rfx_ctx*, const uint64_t* d_value, uint64_t limit, unsigned int* d_flag);

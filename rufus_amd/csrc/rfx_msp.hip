@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t mmer_hash(uint32_t c) {
 
 // The minimum of 15 hashes crowds towards 0: spread it again before taking the top bits.
 __device__ __forceinline__ uint32_t msp_bin(uint32_t minh, int bin_bits) {
-  return (minh * 0xC2B2AE3Du) >> (32 - bin_bits);
+  return (minh * 0xC2B2AE3Du) >> (32 - bin_bits);  // record_bin_hash() repeats this product
 }
 
 // HMODE 0: scatter into fixed-capacity coarse bins + 16-bit fine histogram (one pass, optimistic)
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
     atomicMax(&s_maxlen, lenp);
     __syncthreads();
     const uint32_t n_phase = (s_maxlen + P1_S - 1) / P1_S;
-    uint32_t fm = 0, rm = 0, cur_m = 0, run_bin = 0;
+    uint32_t fm = 0, rm = 0, cur_m = 0, run_h = 0;
     uint64_t hist = 0, cur_w = 0;
     int filled = 0, run_n = 0;
     uint32_t a[MSP_WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-14 .. p0+7
@@ -114,9 +114,13 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
           pm = min(pm, h);
           filled = valid ? filled + 1 : 0;
           const bool kvalid = filled >= k;
-          const uint32_t bin = msp_bin(min(sfx[b], pm), bin_bits);
-          if (run_n && (!kvalid || bin != run_bin || run_n == MSP_NMAX)) {
+          // A run = consecutive k-mers with the same minimizer HASH (not merely the same bin): every
+          // further bit of that hash is then common to the record's k-mers, which is what lets
+          // k_slice_tag refine the partition later without separating instances of a k-mer.
+          const uint32_t mh = min(sfx[b], pm);
+          if (run_n && (!kvalid || mh != run_h || run_n == MSP_NMAX)) {
             // close the run that ended at the previous base: `hist` still ends there
+            const uint32_t run_bin = msp_bin(run_h, bin_bits);
             if (HMODE != 1) {
               const int L = k + run_n - 1;
               const uint32_t coarse = run_bin >> sub_bits;
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
             run_n = 0;
           }
           if (kvalid) {
-            if (!run_n) run_bin = bin;
+            if (!run_n) run_h = mh;
             ++run_n;
           }
           hist = (hist << 2) | code;
@@ -200,6 +204,54 @@ __device__ __forceinline__ uint64_t revcomp_bases(uint64_t s, int nbases) {
 
 __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
   return (uint32_t)((key * 0xD6E8FEB86659FD93ull) >> 32);
+}
+
+// msp_bin's pre-shift value for a record: the minimizer hash of its first k-mer (= of all its k-mers),
+// recomputed exactly as k_msp_part1 does.
+template <bool CANON>
+__device__ __forceinline__ uint32_t record_bin_hash(uint64_t x, int k) {
+  const int n = (int)((x >> 56) & 3u) + 1;
+  const uint64_t S = x & ((1ull << 56) - 1);
+  const uint64_t kmask = (1ull << (2 * k)) - 1;
+  const uint64_t fwd = (S >> (2 * (n - 1))) & kmask;
+  const uint64_t rck = CANON ? revcomp_bases(fwd, k) : 0;
+  const int m = k - (MSP_WL - 1);
+  const uint32_t mmask = (1u << (2 * m)) - 1;
+  uint32_t minh = ~0u;
+#pragma unroll
+  for (int i = 0; i < MSP_WL; ++i) {
+    const uint32_t f = (uint32_t)(fwd >> (2 * (MSP_WL - 1 - i))) & mmask;
+    const uint32_t c = CANON ? min(f, (uint32_t)(rck >> (2 * i)) & mmask) : f;
+    minh = min(minh, mmer_hash(c));
+  }
+  return minh * 0xC2B2AE3Du;
+}
+
+// Too many k-mers per bin for the LDS table (many read blocks in one table, or blocks far beyond 1 M
+// reads): refine the partition.  All k-mers of a record share the minimizer, so the next bits of the
+// same hash split every bin into slices without separating instances of a k-mer.  The slice goes into
+// the record's sub-bin field (free after k_part2), k_part2 then moves the records a third time.
+template <bool CANON>
+__global__ __launch_bounds__(256) void k_slice_tag(uint64_t* __restrict__ inst, const uint64_t* __restrict__ bin_start,
+                                                    uint32_t P, int k, int from_bits, int to_bits,
+                                                    unsigned long long* __restrict__ fine_tot) {
+  __shared__ uint32_t s_cnt[64];
+  const int sbits = to_bits - from_bits;
+  for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t a = bin_start[bin], e = bin_start[bin + 1];
+    for (uint64_t i = a + threadIdx.x; i < e; i += blockDim.x) {
+      const uint64_t x = inst[i];
+      const uint32_t sl = (record_bin_hash<CANON>(x, k) >> (32 - to_bits)) & ((1u << sbits) - 1);
+      inst[i] = (x & ((1ull << 58) - 1)) | ((uint64_t)sl << 58);
+      atomicAdd(&s_cnt[sl], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < (1u << sbits) && s_cnt[threadIdx.x])
+      atomicAdd(&fine_tot[((uint64_t)bin << sbits) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    __syncthreads();
+  }
 }
 
 constexpr int MSP_ILP = 8;
@@ -602,6 +654,19 @@ void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const
     hipLaunchKernelGGL(k_msp_leaf<false>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0,
                        bs0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w, out_c, cur, cap,
                        flag, err);
+}
+
+void slice_tag(rfx_ctx* c, uint64_t* inst, const uint64_t* bin_start, int k, int canonical, int from_bits, int to_bits,
+               uint64_t* fine_tot) {
+  rfx_span sp(c, "k_slice_tag");
+  const uint32_t P = 1u << from_bits;
+  const uint32_t grid = P < (uint32_t)c->n_cu * 16 ? P : (uint32_t)c->n_cu * 16;
+  if (canonical)
+    hipLaunchKernelGGL(k_slice_tag<true>, dim3(grid), dim3(256), 0, c->stream, inst, bin_start, P, k, from_bits, to_bits,
+                       (unsigned long long*)fine_tot);
+  else
+    hipLaunchKernelGGL(k_slice_tag<false>, dim3(grid), dim3(256), 0, c->stream, inst, bin_start, P, k, from_bits,
+                       to_bits, (unsigned long long*)fine_tot);
 }
 
 void surv_hist(rfx_ctx* c, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,

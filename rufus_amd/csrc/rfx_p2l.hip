@@ -313,17 +313,20 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
                                                      uint32_t* __restrict__ fine_cur, uint32_t P2, int shift2,
                                                      uint32_t W, const uint32_t* __restrict__ coarse_cur,
                                                      uint32_t cap_a, const uint32_t* __restrict__ pay_a,
-                                                     uint32_t* __restrict__ pay_b, uint64_t cap_b) {
+                                                     uint32_t* __restrict__ pay_b, uint64_t cap_b,
+                                                     const uint64_t* __restrict__ coarse_start) {
   __shared__ uint64_t s_stage[L2_TILE];
   __shared__ uint32_t s_pay[PAYLOAD ? L2_TILE : 1];
   __shared__ uint8_t s_sbin[L2_TILE];
   __shared__ uint32_t s_cnt[256], s_start[257];
   __shared__ uint64_t s_gbase[256];
   const uint32_t cb = blockIdx.x / W, j = blockIdx.x - cb * W;
-  // coarse bin cb of A: exactly sized (same extents as its fine bins in B) or fixed-capacity (fused path)
-  const uint64_t a = coarse_cur ? (uint64_t)cb * cap_a : fine_start[(uint64_t)cb * P2];
-  const uint64_t e =
-      coarse_cur ? a + min(coarse_cur[cb * P1_CUR_STRIDE], cap_a) : fine_start[(uint64_t)(cb + 1) * P2];
+  // coarse bin cb of A: given extents (refinement of an existing partition), fixed-capacity with a fill
+  // cursor (fused path), or exactly sized = the extents of its fine bins in B
+  const uint64_t a = coarse_start ? coarse_start[cb] : coarse_cur ? (uint64_t)cb * cap_a : fine_start[(uint64_t)cb * P2];
+  const uint64_t e = coarse_start ? coarse_start[cb + 1]
+                     : coarse_cur ? a + min(coarse_cur[cb * P1_CUR_STRIDE], cap_a)
+                                  : fine_start[(uint64_t)(cb + 1) * P2];
   if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   for (uint64_t base = a + (uint64_t)j * L2_TILE; base < e; base += (uint64_t)W * L2_TILE) {
@@ -711,15 +714,17 @@ void part1_fused(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int 
 
 void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur,
            uint32_t P2, int shift2, const uint32_t* coarse_cur, uint32_t cap_a, const uint32_t* pay_a,
-           uint32_t* pay_b, uint64_t cap_b, const char* span) {
+           uint32_t* pay_b, uint64_t cap_b, const char* span, const uint64_t* coarse_start, uint32_t n_coarse) {
   rfx_span sp(c, span);
-  const uint32_t W = 16;
+  // 128 coarse bins: 16 workgroups share one; thousands (refinement): one each
+  const uint32_t nc = coarse_start ? n_coarse : (uint32_t)P1_BINS;
+  const uint32_t W = nc >= 2048 ? 1 : 16;
   if (pay_a)
-    hipLaunchKernelGGL(k_part2<true>, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start,
-                       fine_cur, P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b);
+    hipLaunchKernelGGL(k_part2<true>, dim3(nc * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start, fine_cur,
+                       P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b, coarse_start);
   else
-    hipLaunchKernelGGL(k_part2<false>, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start,
-                       fine_cur, P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b);
+    hipLaunchKernelGGL(k_part2<false>, dim3(nc * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start, fine_cur,
+                       P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b, coarse_start);
 }
 
 void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out) {

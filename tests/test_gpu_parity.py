@@ -315,6 +315,43 @@ def test_msp_dense_bins_split_and_survivor_capacity_retry(ctx, monkeypatch):
         x.free()
 
 
+@pytest.mark.parametrize("force_bits", [None, "15"])
+def test_msp_refines_the_partition_when_bins_get_dense(ctx, force_bits, monkeypatch):
+    """Four read blocks into one table with 256 bins: > 24 K instances per bin, so finish refines the
+    record partition by further minimizer-hash bits (k_slice_tag + a third k_part2 pass, all segments
+    merged into one) before the LDS count; forced to 2^15 bins it takes two refinement steps.  A block
+    added after a finish joins at the coarse bin count and is refined at the next finish."""
+    monkeypatch.setenv("RFX_P2L_BINS", "256")
+    if force_bits:
+        monkeypatch.setenv("RFX_MSP_REFINE_BITS", force_bits)
+    rng = np.random.default_rng(21)
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 400_000)]
+    starts = rng.integers(0, len(genome) - 150, 64_000)
+    seqs = [bytes(genome[s0:s0 + 150]) for s0 in starts]
+    k, size = 25, 1 << 30
+    ctx.prof(True)
+    ctx.prof_reset()
+    t = capi.CountTable(ctx, k, size, mode=capi.COUNT_MSP)
+    parts = np.array_split(np.arange(len(seqs)), 5)
+    for part in parts[:4]:
+        blk = ctx.upload(capi.PackedReads.from_reads([seqs[i] for i in part]))
+        t.add(blk)
+        blk.free()
+    n4 = sum(len(p) for p in parts[:4])
+    rec = t.finish(2)
+    names = ctx.prof_dict()
+    ctx.prof(False)
+    assert "k_slice_tag" in names and "k_part3" in names, names
+    assert rec.payload() == oracle.count(None, k, size, lower=2, reads=seqs[:n4]).payload()
+    rec.free()
+    blk = ctx.upload(capi.PackedReads.from_reads([seqs[i] for i in parts[4]]))
+    t.add(blk)
+    rec = t.finish(1)
+    assert rec.payload() == oracle.count(None, k, size, lower=1, reads=seqs).payload()
+    for x in (rec, blk, t):
+        x.free()
+
+
 def test_msp_skewed_input_is_redone_with_exact_sizes(ctx, monkeypatch):
     """Homopolymer / dinucleotide reads put almost every record into one bin: the fixed-capacity
     coarse bins and the 16-bit histogram of the one-pass partition both give up, the block is redone

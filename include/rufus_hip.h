@@ -149,6 +149,24 @@ int rfx_count_add(rfx_table*, const rfx_reads*);
  * exchange, and the rehash path. */
 int rfx_count_add_pairs_dev(rfx_table*, const uint64_t* d_keys, const uint32_t* d_counts, uint64_t n);
 int rfx_count_stats(rfx_table*, uint64_t* distinct, uint64_t* capacity, uint64_t* max_displacement);
+
+/* Multi-GPU sharding of the MSP path (rufus_amd/dist.py): the super-k-mer records of a read block are
+ * grouped by minimizer bin, and every instance of a canonical k-mer lives in the same bin on every
+ * rank.  So ranks exchange RECORDS by bin owner (contiguous runs of the record array) and each owner
+ * counts complete bins: no partial counts, no reduce.
+ *   rfx_count_segments       number of record segments held (one per rfx_count_add), after settling
+ *                            any pending capacity check; < 0 on error, 0 if the table is not on the MSP path.
+ *   rfx_count_segment_get    device pointers of segment i: records grouped by bin, bin_start[bins+1].
+ *                            Valid until the next add/finish/free on the table.
+ *   rfx_count_add_records_dev  append a copy of records grouped the same way (bin b = bin_start[b]..
+ *                            bin_start[b+1]); `bins` is a power of two >= 256 and the table must be MSP
+ *                            capable (23 <= k <= 25).  All segments of a table must come from the same
+ *                            k / canonical setting; bins may differ (finish refines to a common count). */
+int rfx_count_segments(rfx_table*);
+int rfx_count_segment_get(rfx_table*, int i, const uint64_t** d_records, const uint64_t** d_bin_start, uint32_t* bins,
+                          uint64_t* n_records);
+int rfx_count_add_records_dev(rfx_table*, const uint64_t* d_records, uint64_t n_records, const uint64_t* d_bin_start,
+                              uint32_t bins);
 void rfx_count_free(rfx_table*);
 
 /* K3: table -> records with lower <= count <= upper in (pos,key) order (jf/include/jellyfish/

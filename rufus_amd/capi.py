@@ -54,6 +54,10 @@ SIGNATURES = {
     "rfx_count_add": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rfx_count_add_pairs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "rfx_count_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "rfx_count_segments": (C.c_int, [C.c_void_p]),
+    "rfx_count_segment_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_uint32), u64p]),
+    "rfx_count_add_records_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
     "rfx_count_free": (None, [C.c_void_p]),
     "rfx_count_finish": (C.c_void_p, [C.c_void_p, C.c_uint64, C.c_uint64, u64p]),
     "rfx_records_size": (C.c_uint64, [C.c_void_p]),
@@ -334,6 +338,23 @@ class CountTable:
 
     def add_pairs_dev(self, d_keys: int, d_counts: int, n: int):
         _check(lib().rfx_count_add_pairs_dev(self._h, d_keys, d_counts, n), "rfx_count_add_pairs_dev")
+
+    def segments(self):
+        """[(d_records, d_bin_start, bins, n_records)] of the MSP record segments held (device pointers)."""
+        n = lib().rfx_count_segments(self._h)
+        if n < 0:
+            _check(n, "rfx_count_segments")
+        out = []
+        for i in range(n):
+            dr, db, bins, nr = C.c_void_p(0), C.c_void_p(0), C.c_uint32(0), C.c_uint64(0)
+            _check(lib().rfx_count_segment_get(self._h, i, C.byref(dr), C.byref(db), C.byref(bins), C.byref(nr)),
+                   "rfx_count_segment_get")
+            out.append((dr.value or 0, db.value or 0, bins.value, nr.value))
+        return out
+
+    def add_records_dev(self, d_records: int, n_records: int, d_bin_start: int, bins: int):
+        _check(lib().rfx_count_add_records_dev(self._h, d_records, n_records, d_bin_start, bins),
+               "rfx_count_add_records_dev")
 
     def stats(self):
         d, c, m = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

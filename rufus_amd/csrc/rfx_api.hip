@@ -1266,6 +1266,55 @@ int rfx_count_add_pairs_dev(rfx_table* t, const uint64_t* d_keys, const uint32_t
   return RFX_OK;
 }
 
+int rfx_count_segments(rfx_table* t) {
+  if (!t) return RFX_E_INVAL;
+  (void)hipSetDevice(t->ctx->device);
+  if (t->seg_kind != RFX_COUNT_MSP) return 0;
+  const int rc = msp_resolve(t);
+  if (rc) return rc;
+  return (int)t->segs->size();
+}
+
+int rfx_count_segment_get(rfx_table* t, int i, const uint64_t** d_records, const uint64_t** d_bin_start, uint32_t* bins,
+                          uint64_t* n_records) {
+  if (!t || t->seg_kind != RFX_COUNT_MSP || i < 0 || i >= (int)t->segs->size()) return RFX_E_INVAL;
+  rfx_ctx* c = t->ctx;
+  (void)hipSetDevice(c->device);
+  int rc = msp_resolve(t);
+  if (rc) return rc;
+  rfx_segment& sg = (*t->segs)[(size_t)i];
+  uint64_t total = 0;  // the exact record count lives on the device (segments are sized optimistically)
+  HIPCHK(queue_read(c, &total, sg.bin_start + sg.bins, 8));
+  HIPCHK(ctx_sync(c));
+  if (d_records) *d_records = sg.inst;
+  if (d_bin_start) *d_bin_start = sg.bin_start;
+  if (bins) *bins = sg.bins;
+  if (n_records) *n_records = total;
+  return RFX_OK;
+}
+
+int rfx_count_add_records_dev(rfx_table* t, const uint64_t* d_records, uint64_t n_records, const uint64_t* d_bin_start,
+                              uint32_t bins) {
+  if (!t || !d_bin_start || (n_records && !d_records) || bins < 256 || (bins & (bins - 1))) return RFX_E_INVAL;
+  rfx_ctx* c = t->ctx;
+  (void)hipSetDevice(c->device);
+  if (!rfxk::msp_k_ok(t->k) || !t->lut_t || t->table_active || (t->seg_kind && t->seg_kind != RFX_COUNT_MSP)) {
+    snprintf(g_err, sizeof g_err, "rfx_count_add_records_dev: the table is not on the MSP path");
+    return RFX_E_INVAL;
+  }
+  uint64_t* inst = (uint64_t*)dmalloc(c, (n_records ? n_records : 1) * 8);
+  uint64_t* bs = (uint64_t*)dmalloc(c, ((size_t)bins + 1) * 8);
+  if (!inst || !bs) { dfree(c, inst); dfree(c, bs); return RFX_E_NOMEM; }
+  hipError_t e = hipMemcpyAsync(bs, d_bin_start, ((size_t)bins + 1) * 8, hipMemcpyDeviceToDevice, c->stream);
+  if (e == hipSuccess && n_records)
+    e = hipMemcpyAsync(inst, d_records, n_records * 8, hipMemcpyDeviceToDevice, c->stream);
+  if (e != hipSuccess) { dfree(c, inst); dfree(c, bs); return hip_fail(e, "rfx_count_add_records_dev"); }
+  if (!t->p2l_bins) t->p2l_bins = bins > 8192 ? 8192 : bins;  // geometry of later rfx_count_add calls
+  t->segs->push_back(rfx_segment{inst, n_records, bs, n_records * 4, bins});  // <= 4 k-mers per record
+  t->seg_kind = RFX_COUNT_MSP;
+  return RFX_OK;
+}
+
 int rfx_count_stats(rfx_table* t, uint64_t* distinct, uint64_t* capacity, uint64_t* max_displacement) {
   if (!t) return RFX_E_INVAL;
   (void)hipSetDevice(t->ctx->device);

@@ -16,6 +16,22 @@ GPU box, "gloo" in the CPU tests).  Per sample:
 The set difference needs no communication (every rank owns the same pos slice of every sample);
 the per-slice mutant k-mers are all-gathered (small) and every rank filters its own subject block.
 
+**Minimizer sharding** (default where the MSP count path applies, 23 <= k <= 25).  The scheme above
+ships (key,count) partials -- 12 B per distinct k-mer per rank, and the owner has to reduce them.  The
+MSP path offers a cheaper cut: a read block becomes 8-byte super-k-mer records grouped by minimizer
+bin, and every instance of a canonical k-mer is in the same bin on every rank.  So
+
+1. every rank partitions ITS read block into records (``rfx_count_add``; no counting yet);
+2. bins are dealt to owners in equal contiguous ranges (of 256 virtual top-level bins, so ranks with
+   different bin counts agree); a destination's share is one contiguous run of the record array ->
+   one ``all_to_all_single`` for the records (2.4 B per k-mer instance) and one for the bin offsets;
+3. the owner imports the runs (``rfx_count_add_records_dev``) and finishes: complete counts of the
+   k-mers of its bins, sorted by (pos,key).  No reduce, no partial counts.
+4. The shard is a function of the k-mer, the same for every sample: histograms add up
+   (``all_reduce``), the set difference is local to the shard, mutant k-mers are all-gathered and put
+   back into (pos,key) order.  (A rank's records are NOT a slice of the ``.Jhash`` payload in this mode;
+   ``merge_shards`` interleaves them when the file is wanted.)
+
 The compute is delegated to a *backend* object; the product backend is :class:`HipBackend` (C-ABI ->
 HIP kernels).  The tests drive the same exchange logic on CPU with gloo and a checker backend.
 """
@@ -98,6 +114,47 @@ class HipBackend:
         finally:
             t.free()
 
+    # -- minimizer-shard path ----------------------------------------------------------------------
+    def msp_capable(self) -> bool:
+        return 23 <= self.k <= 25
+
+    def partition(self, block):
+        """(records int64[n], bin_start int64[bins+1]) device tensors: the block's super-k-mer records
+        grouped by minimizer bin."""
+        t = capi.CountTable(self.ctx, self.k, self.size, True, self.capacity, mode=capi.COUNT_MSP)
+        try:
+            t.add(block)
+            segs = t.segments()
+            if not segs:                         # no k-mer at all
+                return (torch.empty(0, dtype=torch.int64, device=self.device),
+                        torch.zeros(257, dtype=torch.int64, device=self.device))
+            d_rec, d_bs, bins, n = segs[0]
+            rec = torch.empty(n, dtype=torch.int64, device=self.device)
+            bs = torch.empty(bins + 1, dtype=torch.int64, device=self.device)
+            torch.cuda.synchronize(self.device)
+            self.ctx.memcpy_dev(rec.data_ptr(), d_rec, n * 8)
+            self.ctx.memcpy_dev(bs.data_ptr(), d_bs, (bins + 1) * 8)
+            self.ctx.sync()
+            return rec, bs
+        finally:
+            t.free()
+
+    def count_records(self, runs, lower: int):
+        """runs: [(records, bin_start)] received from every rank for this owner's bins -> (records of
+        the shard in (pos,key) order, histogram)."""
+        t = capi.CountTable(self.ctx, self.k, self.size, True, self.capacity, mode=capi.COUNT_MSP)
+        try:
+            torch.cuda.synchronize(self.device)
+            for rec, bs in runs:
+                t.add_records_dev(rec.data_ptr(), rec.numel(), bs.data_ptr(), bs.numel() - 1)
+            self.ctx.sync()                      # the copies are done: the tensors may go
+            return t.finish(lower, want_histo=True)
+        finally:
+            t.free()
+
+    def pos_of(self, keys: np.ndarray) -> np.ndarray:
+        return np.array([capi.jf_pos(self.cols, self.k, self.lsize, int(x)) for x in keys], dtype=np.uint64)
+
     def unique(self, subject, others, min_cov: int, max_cov: int):
         return capi.unique_to_subject(self.ctx, subject, others, min_cov, max_cov)
 
@@ -134,6 +191,13 @@ def owner_bounds(lsize: int, world: int):
     return [(g << lsize) // world for g in range(world + 1)]
 
 
+def bin_owner_bounds(bins: int, world: int):
+    """bin range [b[g], b[g+1]) owned by rank g.  Cut on 256 virtual top-level bins (the top 8 bits of
+    the minimizer hash) so that ranks / samples partitioned into different bin counts agree."""
+    assert bins >= 256 and bins % 256 == 0 and world <= 256
+    return [-(-g * 256 // world) * (bins // 256) for g in range(world + 1)]
+
+
 def _wire(t: torch.Tensor, group) -> torch.Tensor:
     """Tensor as the collective backend wants it: gloo moves host memory (used by the tests, which can
     put two ranks on one GPU), nccl/RCCL moves HBM directly over xGMI."""
@@ -158,6 +222,60 @@ def exchange_partials(keys: torch.Tensor, counts: torch.Tensor, pos: torch.Tenso
     return rk.to(dev), rc.to(dev)
 
 
+def exchange_records(records: torch.Tensor, bin_start: torch.Tensor, group):
+    """Deal the bins to their owners.  Returns [(records_from_rank, bin_start_full)] for this rank's bins,
+    one entry per source rank; bin_start_full has the sender's bin count + 1 entries (empty outside the
+    owned range) so that the run can be imported as it is."""
+    world, me = dist.get_world_size(group), dist.get_rank(group)
+    dev = records.device
+    bins = bin_start.numel() - 1
+    b = bin_owner_bounds(bins, world)
+    bs_host = bin_start.cpu()
+    cuts = bs_host[torch.tensor(b)]
+    send_l = (cuts[1:] - cuts[:-1]).tolist()
+    send = _wire(torch.tensor(send_l, dtype=torch.int64, device=dev), group)
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    recv_l = recv.tolist()
+    wr = _wire(records[:int(cuts[-1])], group)
+    rr = torch.empty(sum(recv_l), dtype=records.dtype, device=wr.device)
+    dist.all_to_all_single(rr, wr, recv_l, send_l, group=group)
+    # bin offsets of every destination's range, relative to the start of its run.  Bin counts may differ
+    # between ranks (they follow the block size), so the lengths travel first.
+    parts = [bs_host[b[d]:b[d + 1] + 1] - bs_host[b[d]] for d in range(world)]
+    len_s = _wire(torch.tensor([p.numel() for p in parts], dtype=torch.int64, device=dev), group)
+    len_r = torch.empty_like(len_s)
+    dist.all_to_all_single(len_r, len_s, group=group)
+    len_sl, len_rl = len_s.tolist(), len_r.tolist()
+    sb = _wire(torch.cat(parts).to(dev), group)
+    rb = torch.empty(sum(len_rl), dtype=torch.int64, device=sb.device)
+    dist.all_to_all_single(rb, sb, len_rl, len_sl, group=group)
+    v0, v1 = -(-me * 256 // world), -(-(me + 1) * 256 // world)   # my range in virtual bins
+    runs, ro, bo = [], 0, 0
+    for src in range(world):
+        loc = rb[bo:bo + len_rl[src]].cpu()
+        nb = len_rl[src] - 1                      # bins of my range at the SENDER's resolution
+        sbins = nb * 256 // (v1 - v0)             # hence the sender's bin count
+        lo = v0 * (sbins // 256)
+        full = torch.zeros(sbins + 1, dtype=torch.int64)
+        full[lo:lo + nb + 1] = loc
+        full[lo + nb + 1:] = loc[-1]
+        runs.append((rr[ro:ro + recv_l[src]].to(dev), full.to(dev)))
+        ro += recv_l[src]
+        bo += len_rl[src]
+    return runs
+
+
+def merge_shards(shards):
+    """[(keys, counts, pos)] of the ranks' minimizer shards -> one (pos,key)-ordered triple (the .Jhash
+    payload order); host-side, for callers that want the file."""
+    keys = np.concatenate([s[0] for s in shards])
+    counts = np.concatenate([s[1] for s in shards])
+    pos = np.concatenate([s[2] for s in shards])
+    o = np.lexsort((keys, pos))
+    return keys[o], counts[o], pos[o]
+
+
 def all_gather_keys(keys: np.ndarray, device, group) -> np.ndarray:
     world = dist.get_world_size(group)
     if dist.get_backend(group) == "gloo":
@@ -178,7 +296,7 @@ class TrioShard:
     """One rank's share of: count x (1 subject + controls) -> histogram -> hash list -> filter."""
 
     def __init__(self, ctx_or_backend, k: int, size: int, lower: int, min_cov: int, max_cov: int, thresh: int,
-                 capacity: int = 0, group=None):
+                 capacity: int = 0, group=None, shard_by: str | None = None):
         self.be = ctx_or_backend if hasattr(ctx_or_backend, "local_count") else HipBackend(ctx_or_backend, k, size,
                                                                                            capacity)
         self.k, self.lsize = k, capi.ceil_log2(size)
@@ -186,10 +304,21 @@ class TrioShard:
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
+        capable = getattr(self.be, "msp_capable", lambda: False)()
+        self.shard_by = shard_by or ("minimizer" if capable else "pos")   # what a rank's records are a shard of
+        if self.shard_by == "minimizer" and not capable:
+            raise ValueError("minimizer sharding needs the MSP count path (23 <= k <= 25)")
 
     def count_sample(self, block):
         if self.world == 1:
             return self.be.local_count(block, self.lower)
+        if self.shard_by == "minimizer":
+            records, bin_start = self.be.partition(block)
+            runs = exchange_records(records, bin_start, self.group)
+            rec, histo = self.be.count_records(runs, self.lower)
+            h = _wire(torch.from_numpy(histo.astype(np.int64)).to(records.device), self.group)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            return rec, h.cpu().numpy().astype(np.uint64)
         keys, counts, pos = self.be.count_partials(block)
         rk, rc = exchange_partials(keys, counts, pos, self.lsize, self.group)
         b = owner_bounds(self.lsize, self.world)
@@ -209,6 +338,8 @@ class TrioShard:
         if self.world > 1:
             dev = torch.device("cpu") if dist.get_backend(self.group) == "gloo" else self.be.device
             keys = all_gather_keys(keys, dev, self.group)
+            if self.shard_by == "minimizer" and len(keys):   # shard lists interleave in (pos,key) order
+                keys = keys[np.lexsort((keys, self.be.pos_of(keys)))]
             t = torch.tensor(n_rec, dtype=torch.int64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             n_rec = t.tolist()

@@ -1,6 +1,7 @@
-"""CPU, world_size 2, gloo: the exchange logic of rufus_amd.dist (owner split, all-to-all of
-partials, owner reduce, histogram all-reduce, mutant-set all-gather) driven with a checker backend.
-The concatenation of the owner slices must be the single-process result, byte for byte."""
+"""CPU, world_size 2 and 3, gloo: the exchange logic of rufus_amd.dist driven with a checker backend --
+both sharding schemes: by pos (all-to-all of (key,count) partials, owner reduce; owner slices concatenate
+to the single-process result) and by minimizer bin (all-to-all of records, owners count complete bins;
+shards interleave to the single-process result).  Histogram all-reduce, mutant-set all-gather, filter."""
 import os
 import socket
 
@@ -22,6 +23,28 @@ class Block:
         self.seqs = [r.tobytes() for m in (0, 1) for r in sample.s[m]]
         self.quals = [r.tobytes() for m in (0, 1) for r in sample.q[m]]
         self.n = len(self.seqs)
+
+
+_CODE = np.full(256, 4, dtype=np.uint8)
+for _i, _c in enumerate(b"ACGT"):
+    _CODE[_c] = _i
+_POW = (np.uint64(1) << (np.uint64(2) * np.arange(K - 1, -1, -1, dtype=np.uint64)))
+
+
+def kmer_instances(seqs, k=K):
+    """Canonical key of every window without a non-ACGT character (what jellyfish -C counts)."""
+    out = []
+    for s in seqs:
+        c = _CODE[np.frombuffer(s, dtype=np.uint8)]
+        if len(c) < k:
+            continue
+        w = np.lib.stride_tricks.sliding_window_view(c, k)
+        ok = (w < 4).all(axis=1)
+        w = w[ok].astype(np.uint64)
+        fwd = (w * _POW).sum(axis=1, dtype=np.uint64)
+        rc = ((np.uint64(3) - w[:, ::-1]) * _POW).sum(axis=1, dtype=np.uint64)
+        out.append(np.minimum(fwd, rc))
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.uint64)
 
 
 class OracleBackend:
@@ -54,6 +77,48 @@ class OracleBackend:
         r = oracle.Records(K, self.lsize, self.cols, uk[o], c[o], pos[o])
         return r, oracle.histo(r.counts, full=True)[0]
 
+    # minimizer-shard interface: here a "record" is one canonical k-mer instance and its bin any fixed
+    # function of the k-mer -- enough to exercise the exchange (splits, offsets, import) on CPU
+    BINS = 512
+
+    def msp_capable(self):
+        return True
+
+    def _bin(self, keys):
+        return ((keys * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(64 - 9)).astype(np.int64)
+
+    def partition(self, block):
+        keys = kmer_instances(block.seqs)                    # canonical key of every valid window
+        b = self._bin(keys)
+        o = np.argsort(b, kind="stable")
+        bs = np.zeros(self.BINS + 1, dtype=np.int64)
+        np.cumsum(np.bincount(b, minlength=self.BINS), out=bs[1:])
+        return torch.from_numpy(keys[o].view(np.int64).copy()), torch.from_numpy(bs)
+
+    def count_records(self, runs, lower):
+        me, world = dist.get_rank(), dist.get_world_size()
+        own = rdist.bin_owner_bounds(self.BINS, world)
+        chunks = []
+        for rec, bs in runs:
+            bs = bs.numpy()
+            assert len(bs) == self.BINS + 1 and bs[own[me]] == 0 and bs[own[me + 1]] == len(rec) == bs[-1]
+            k = rec.numpy().view(np.uint64)
+            assert np.all(np.repeat(np.arange(self.BINS), np.diff(bs)) == self._bin(k)), "record in the wrong bin"
+            chunks.append(k)
+        k = np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint64)
+        uk, c = np.unique(k, return_counts=True)
+        assert np.all((self._bin(uk) >= own[me]) & (self._bin(uk) < own[me + 1]))
+        c = c.astype(np.uint64)
+        keep = c >= lower
+        uk, c = uk[keep], c[keep]
+        pos = self.pos_of(uk)
+        o = np.lexsort((uk, pos))
+        r = oracle.Records(K, self.lsize, self.cols, uk[o], c[o], pos[o])
+        return r, oracle.histo(r.counts, full=True)[0]
+
+    def pos_of(self, keys):
+        return np.array([oracle.jf_pos(self.cols, int(x), self.lsize) for x in keys], dtype=np.uint64)
+
     def unique(self, subject, others, min_cov, max_cov):
         keys, vals, which = oracle.merge_unique([subject] + list(others), with_file=True)
         sel = [(k, v) for k, v, f in zip(keys, vals, which) if f == 0 and min_cov <= v <= max_cov]
@@ -73,29 +138,31 @@ class OracleBackend:
         return len(rec.keys)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, shard_by):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         trio = make_trio(genome_len=30_000, n_pairs=1500, n_snv=4, seed=5, read_seed=100 + rank)
         blocks = {n: Block(trio[n]) for n in ("child", "mother", "father")}
-        shard = rdist.TrioShard(OracleBackend(), K, SIZE, LOWER, MIN_COV, MAX_COV, THRESH, group=dist.group.WORLD)
+        shard = rdist.TrioShard(OracleBackend(), K, SIZE, LOWER, MIN_COV, MAX_COV, THRESH, group=dist.group.WORLD,
+                                shard_by=shard_by)
         res = shard.run(blocks["child"], [blocks["mother"], blocks["father"]], keep_records=True)
-        q.put((rank, [r.payload() for r in res["records"]], [h.tolist() for h in res["histos"]],
+        q.put((rank, [(r.keys.tolist(), r.counts.tolist(), r.pos.tolist()) for r in res["records"]],
+               [h.tolist() for h in res["histos"]],
                res["mutant_keys"].tolist(), res["pulled"].tolist(), res["n_records"], res["n_pulled"]))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_exchange_matches_single_process():
-    world = 2
+@pytest.mark.parametrize("world,shard_by", [(2, "pos"), (2, "minimizer"), (3, "minimizer")])
+def test_exchange_matches_single_process(world, shard_by):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, shard_by)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=300) for _ in range(world))
@@ -113,17 +180,24 @@ def test_two_rank_exchange_matches_single_process():
     recs = [oracle.count(None, K, SIZE, lower=LOWER, reads=sum((b.seqs for b in allb[n]), []))
             for n in ("child", "mother", "father")]
     for i in range(3):
-        assert b"".join(g[1][i] for g in got) == recs[i].payload()          # slices concatenate to the file
-        assert got[0][2][i] == got[1][2][i] == oracle.histo(recs[i].counts, full=True)[0].tolist()
+        shards = [tuple(np.array(x, dtype=np.uint64) for x in g[1][i]) for g in got]
+        if shard_by == "pos":      # owner slices concatenate to the file
+            keys_, counts_, pos_ = (np.concatenate([s_[j] for s_ in shards]) for j in range(3))
+        else:                      # minimizer shards are disjoint and interleave to the file
+            assert all(len(s_[0]) for s_ in shards)
+            keys_, counts_, pos_ = rdist.merge_shards(shards)
+        assert keys_.tolist() == recs[i].keys.tolist() and counts_.tolist() == recs[i].counts.tolist()
+        assert pos_.tolist() == recs[i].pos.tolist()
+        assert all(g[2][i] == oracle.histo(recs[i].counts, full=True)[0].tolist() for g in got)
     keys, _ = be.unique(recs[0], recs[1:], MIN_COV, MAX_COV)
-    assert got[0][3] == got[1][3] == keys.tolist() and len(keys) > 0
-    assert got[0][5] == got[1][5] == [len(r.keys) for r in recs]
+    assert all(g[3] == keys.tolist() for g in got) and len(keys) > 0
+    assert all(g[5] == [len(r.keys) for r in recs] for g in got)
     n_pulled = 0
     for r in range(world):
         want = be.filter_pairs(keys, allb["child"][r], THRESH)
         assert got[r][4] == want.tolist()
         n_pulled += int(want.sum())
-    assert got[0][6] == got[1][6] == n_pulled and n_pulled > 0
+    assert all(g[6] == n_pulled for g in got) and n_pulled > 0
 
 
 def test_owner_bounds_cover_the_range():

@@ -610,7 +610,7 @@ def test_s1_full_size_properties(ctx):
 # ------------------------------------------------------------------------------------------------
 # multi-GPU path on the real HIP backend: two ranks share the one GPU, exchange over gloo
 # ------------------------------------------------------------------------------------------------
-def _dist_worker(rank, world, port, q):
+def _dist_worker(rank, world, port, q, shard_by):
     import torch.distributed as dist
     from rufus_amd import dist as rdist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -623,18 +623,23 @@ def _dist_worker(rank, world, port, q):
         for n in ("child", "mother", "father"):
             seq, qual, off = flat_reads(trio[n])
             blocks[n] = c.upload(capi.PackedReads(seq, off, qual, 15, capi.PACK_COUNT | capi.PACK_FILTER))
-        shard = rdist.TrioShard(c, 25, 8 << 30, 2, 5, 1200, 1, group=dist.group.WORLD)
+        shard = rdist.TrioShard(c, 25, 8 << 30, 2, 5, 1200, 1, group=dist.group.WORLD, shard_by=shard_by)
         res = shard.run(blocks["child"], [blocks["mother"], blocks["father"]], keep_records=True)
-        q.put((rank, [r.payload() for r in res["records"]], [h.tolist() for h in res["histos"]],
+        q.put((rank, [tuple(x.tolist() for x in r.get()) for r in res["records"]], [h.tolist() for h in res["histos"]],
                res["mutant_keys"].tolist(), res["pulled"].tolist(), res["n_pulled"]))
         c.close()
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_exchange_on_the_hip_backend():
+@pytest.mark.parametrize("shard_by", ["minimizer", "pos"])
+def test_two_ranks_exchange_on_the_hip_backend(shard_by):
+    """minimizer: ranks exchange super-k-mer records by bin owner and count complete bins (shards
+    interleave to the single-GPU result); pos: ranks exchange (key,count) partials by pos owner (slices
+    concatenate to it)."""
     import socket
     import torch.multiprocessing as mp
+    from rufus_amd import dist as rdist
     world = 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -642,7 +647,7 @@ def test_two_ranks_exchange_on_the_hip_backend():
     s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_dist_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [mpc.Process(target=_dist_worker, args=(r, world, port, q, shard_by)) for r in range(world)]
     for p in procs:
         p.start()
     got = sorted(q.get(timeout=240) for _ in range(world))
@@ -655,7 +660,15 @@ def test_two_ranks_exchange_on_the_hip_backend():
         reads = [x.tobytes() for t in parts for m in (0, 1) for x in t[n].s[m]]
         recs.append(oracle.count(None, 25, 8 << 30, lower=2, reads=reads))
     for i in range(3):
-        assert b"".join(g[1][i] for g in got) == recs[i].payload()       # owner slices concatenate to the file
+        shards = [(np.array(g[1][i][0], np.uint64), np.array(g[1][i][1], np.uint64), np.array(g[1][i][2], np.uint64))
+                  for g in got]
+        if shard_by == "pos":
+            keys_, counts_, pos_ = (np.concatenate([s_[j] for s_ in shards]) for j in range(3))
+        else:
+            assert all(len(s_[0]) > 0 for s_ in shards)
+            keys_, counts_, pos_ = rdist.merge_shards(shards)
+        assert np.array_equal(keys_, recs[i].keys) and np.array_equal(counts_, recs[i].counts)
+        assert np.array_equal(pos_, recs[i].pos)
         assert got[0][2][i] == got[1][2][i] == oracle.histo(recs[i].counts, full=True)[0].tolist()
     hl = oracle.hash_list(recs[0], recs[1:], 5, 1200)
     want_keys = [oracle.jf_encode(ln.split()[0]) for ln in hl.splitlines()]

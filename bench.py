@@ -200,7 +200,8 @@ def main():
                                    f"(genome {args.genome} bp, 20 SNVs, seed 12345), k={K}, -s 8G -L {LOWER}, "
                                    f"MinCov {MIN_COV}, MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}",
                        "reads_counted_per_step": reads_per_step, "reads_filtered_per_step": n_reads * world,
-                       "parallelism": f"read-block shard x{world}" + (", all-to-all by pos owner" if world > 1 else ""),
+                       "parallelism": f"read-block shard x{world}" + (
+                           f", all-to-all of super-k-mer records by {shard.shard_by}-bin owner" if world > 1 else ""),
                        "mutant_kmers": int(res["n_mutant"]), "pulled_pairs": int(res["n_pulled"]),
                        "records_subject": int(res["n_records"][0])},
             "roofline": {"bound": "hbm", "kernel": "+".join(k2), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -101,6 +102,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(or `make -C rufus_amd/csrc`)")
+        # PyTorch-ROCm ships its own copy of the HIP runtime.  If it is loaded AFTER librufus_hip.so has
+        # pulled in /opt/rocm's, the process ends up with two runtimes and torch sees no GPU; loaded first,
+        # ours binds to the runtime that is already there.  torch is optional for this module.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

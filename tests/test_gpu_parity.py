@@ -352,6 +352,63 @@ def test_msp_refines_the_partition_when_bins_get_dense(ctx, force_bits, monkeypa
         x.free()
 
 
+def test_msp_record_segments_export_and_import(ctx, small_trio, monkeypatch):
+    """The multi-GPU building blocks on one GPU: the record segments of two tables (different bin counts)
+    are exported, split at an owner boundary, imported into two fresh tables and finished -- each result
+    holds exactly the k-mers of its bin range, together they are the direct count."""
+    import torch
+    from rufus_amd import dist as rdist
+    k, size = 25, 1 << 28
+    fq = {n: [fastq_bytes(small_trio[n], m) for m in (1, 2)] for n in ("child", "mother")}
+    reads = {n: [r for f in fq[n] for r in tools.parse_sequences(f)] for n in fq}
+    exported = []
+    for n, bins in (("child", "256"), ("mother", "1024")):
+        monkeypatch.setenv("RFX_P2L_BINS", bins)
+        t = capi.CountTable(ctx, k, size, mode=capi.COUNT_MSP)
+        blk = ctx.upload(capi.PackedReads.from_reads(reads[n]))
+        t.add(blk)
+        (d_rec, d_bs, nb, nrec), = t.segments()
+        assert nb == int(bins) and nrec > 0
+        rec = torch.empty(nrec, dtype=torch.int64, device="cuda")
+        bs = torch.empty(nb + 1, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        ctx.memcpy_dev(rec.data_ptr(), d_rec, nrec * 8)
+        ctx.memcpy_dev(bs.data_ptr(), d_bs, (nb + 1) * 8)
+        ctx.sync()
+        assert int(bs[-1]) == nrec and bool((bs[1:] >= bs[:-1]).all())
+        exported.append((rec, bs.cpu()))
+        blk.free()
+        t.free()
+    monkeypatch.delenv("RFX_P2L_BINS")
+    ref = oracle.count(None, k, size, lower=1, reads=reads["child"] + reads["mother"])
+    got = []
+    for owner in range(2):
+        t = capi.CountTable(ctx, k, size, mode=capi.COUNT_MSP)
+        for rec, bs in exported:
+            nb = len(bs) - 1
+            b = rdist.bin_owner_bounds(nb, 2)
+            lo, hi = int(bs[b[owner]]), int(bs[b[owner + 1]])
+            full = torch.zeros(nb + 1, dtype=torch.int64)
+            full[b[owner]:b[owner + 1] + 1] = bs[b[owner]:b[owner + 1] + 1] - lo
+            full[b[owner + 1] + 1:] = hi - lo
+            run, full = rec[lo:hi].clone(), full.cuda()
+            torch.cuda.synchronize()
+            t.add_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), nb)
+            ctx.sync()
+        out = t.finish(1)
+        got.append(out.get())
+        out.free()
+        t.free()
+    assert len(got[0][0]) and len(got[1][0]) and not set(got[0][0].tolist()) & set(got[1][0].tolist())
+    keys, counts, pos = rdist.merge_shards([(g[0], g[1].astype(np.uint64), g[2]) for g in got])
+    assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts) and np.array_equal(pos, ref.pos)
+    # a table that is not on the MSP path refuses records
+    t = capi.CountTable(ctx, 31, size)
+    with pytest.raises(capi.RufusError):
+        t.add_records_dev(exported[0][0].data_ptr(), 1, exported[0][1].cuda().data_ptr(), 256)
+    t.free()
+
+
 def test_msp_skewed_input_is_redone_with_exact_sizes(ctx, monkeypatch):
     """Homopolymer / dinucleotide reads put almost every record into one bin: the fixed-capacity
     coarse bins and the 16-bit histogram of the one-pass partition both give up, the block is redone

@@ -377,7 +377,7 @@ int unique_run(rfx_ctx* c, const rfx_records* f, const rfx_records* const* all, 
   rfxk::flag_range(c, f->counts, f->n, lo, hi, flags);
   for (int j = 0; j < n_all; ++j) {
     if (all[j] == f) continue;
-    rfxk::flag_absent(c, f->keys, f->pos, f->n, all[j]->keys, all[j]->pos, all[j]->n, flags);
+    rfxk::flag_absent(c, f->keys, f->pos, f->n, all[j]->keys, all[j]->pos, all[j]->n, f->lsize, flags);
   }
   rfxk::compact(c, flags, f->keys, f->counts, f->pos, f->n, ok, oc, op, boff, d_tot);
   unsigned long long tot = 0;

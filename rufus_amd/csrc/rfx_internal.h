@@ -203,7 +203,7 @@ void compute_pos(rfx_ctx*, const uint64_t* keys, uint64_t n, const uint64_t* lut
 void check_sorted(rfx_ctx*, const uint64_t* keys, const uint64_t* pos, uint64_t n, unsigned int* d_bad);
 void flag_range(rfx_ctx*, const uint32_t* counts, uint64_t n, uint32_t lo, uint32_t hi, uint8_t* flags);
 void flag_absent(rfx_ctx*, const uint64_t* keys, const uint64_t* pos, uint64_t n, const uint64_t* bkeys,
-                 const uint64_t* bpos, uint64_t nb, uint8_t* flags);
+                 const uint64_t* bpos, uint64_t nb, int lsize, uint8_t* flags);
 void compact(rfx_ctx*, const uint8_t* flags, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos,
              uint64_t n, uint64_t* out_keys, uint32_t* out_counts, uint64_t* out_pos, uint64_t* block_off,
              unsigned long long* d_total);

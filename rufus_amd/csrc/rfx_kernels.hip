@@ -479,16 +479,60 @@ __device__ __forceinline__ uint64_t lower_bound(const uint64_t* __restrict__ bke
   return lo;
 }
 
-// Clear the flag of every record that also occurs in B (binary search by (pos,key)).
+// lower_bound with a starting guess: pos is a hash, so record number pos * nb / 2^lsize is within a few
+// sqrt(nb) of the answer.  Gallop out from there until the target is bracketed, then bisect the bracket:
+// ~14 probes inside a few KB instead of log2(nb) ~ 23 probes across the whole array.
+__device__ __forceinline__ uint64_t lower_bound_near(const uint64_t* __restrict__ bkeys,
+                                                     const uint64_t* __restrict__ bpos, uint64_t nb, uint64_t p,
+                                                     uint64_t k, int lsize) {
+  auto less_at = [&](uint64_t i) {
+    const uint64_t mp = bpos[i];
+    return mp < p || (mp == p && bkeys[i] < k);
+  };
+  uint64_t g = (uint64_t)(((unsigned __int128)p * nb) >> lsize);
+  if (g >= nb) g = nb - 1;
+  uint64_t lo, hi;  // invariant: every index < lo is less, every index >= hi is not
+  if (less_at(g)) {
+    lo = g + 1;
+    hi = nb;
+    for (uint64_t step = 256; lo < nb; step <<= 1) {
+      const uint64_t j = lo + step - 1 < nb ? lo + step - 1 : nb - 1;
+      if (less_at(j)) lo = j + 1;
+      else {
+        hi = j;
+        break;
+      }
+    }
+  } else {
+    hi = g;
+    lo = 0;
+    for (uint64_t step = 256; hi > 0; step <<= 1) {
+      const uint64_t j = hi >= step ? hi - step : 0;
+      if (less_at(j)) {
+        lo = j + 1;
+        break;
+      }
+      hi = j;
+    }
+  }
+  while (lo < hi) {
+    const uint64_t mid = (lo + hi) >> 1;
+    if (less_at(mid)) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// Clear the flag of every record that also occurs in B (search by (pos,key)).
 __global__ __launch_bounds__(256) void k_flag_absent(const uint64_t* __restrict__ keys,
                                                       const uint64_t* __restrict__ pos, uint64_t n,
                                                       const uint64_t* __restrict__ bkeys,
-                                                      const uint64_t* __restrict__ bpos, uint64_t nb,
+                                                      const uint64_t* __restrict__ bpos, uint64_t nb, int lsize,
                                                       uint8_t* __restrict__ flags) {
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     if (!flags[i]) continue;
     const uint64_t k = keys[i], p = pos[i];
-    const uint64_t lo = lower_bound(bkeys, bpos, nb, p, k);
+    const uint64_t lo = lower_bound_near(bkeys, bpos, nb, p, k, lsize);
     if (lo < nb && bkeys[lo] == k) flags[i] = 0;
   }
 }
@@ -804,11 +848,11 @@ void flag_range(rfx_ctx* c, const uint32_t* counts, uint64_t n, uint32_t lo, uin
 }
 
 void flag_absent(rfx_ctx* c, const uint64_t* keys, const uint64_t* pos, uint64_t n, const uint64_t* bkeys,
-                 const uint64_t* bpos, uint64_t nb, uint8_t* flags) {
+                 const uint64_t* bpos, uint64_t nb, int lsize, uint8_t* flags) {
   if (n == 0 || nb == 0) return;
   rfx_span sp(c, "k_flag_absent");
   hipLaunchKernelGGL(k_flag_absent, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, pos, n, bkeys, bpos,
-                     nb, flags);
+                     nb, lsize, flags);
 }
 
 void compact(rfx_ctx* c, const uint8_t* flags, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos,

@@ -522,6 +522,7 @@ rfx_reads* rfx_reads_upload(rfx_ctx* c, const uint64_t* codes, const uint32_t* a
   for (uint32_t i = 0; i < n_reads; ++i) {
     r->n_bases += len[i];
     r->max_len = std::max(r->max_len, len[i]);
+    if (len[i] < 32) ++r->short_cnt[len[i]];
   }
   r->codes = (uint64_t*)dmalloc(c, r->n_words * 8);
   r->word_off = (uint32_t*)dmalloc(c, ((size_t)n_reads + 1) * 4);
@@ -639,7 +640,7 @@ static rfx_ord_cfg ord_cfg(const rfx_table* t, int bin_bits) {
 
 static int p2l_add(rfx_table* t, const rfx_reads* r) {
   rfx_ctx* c = t->ctx;
-  const uint64_t windows = r->n_bases > (uint64_t)(t->k - 1) * r->n ? r->n_bases - (uint64_t)(t->k - 1) * r->n : 0;
+  const uint64_t windows = r->windows_of(t->k);  // exact: the instance arrays below are sized by it
   if (windows >= (1ull << 32)) return RFX_E_RANGE;  // a segment indexes its instances with 32 bits
   if (!t->p2l_bins) {
     if (const char* ev = getenv("RFX_P2L_BINS")) t->p2l_bins = (uint32_t)atoi(ev);  // tuning experiments
@@ -806,7 +807,7 @@ struct msp_geom {
 
 static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   rfx_ctx* c = t->ctx;
-  g.windows = r->n_bases > (uint64_t)(t->k - 1) * r->n ? r->n_bases - (uint64_t)(t->k - 1) * r->n : 0;
+  g.windows = r->windows_of(t->k);
   if (!t->p2l_bins) {
     if (const char* ev = getenv("RFX_P2L_BINS")) t->p2l_bins = (uint32_t)atoi(ev);
     uint32_t P = 256;

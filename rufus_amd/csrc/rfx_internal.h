@@ -125,6 +125,16 @@ struct rfx_reads {
   uint32_t max_len;
   uint64_t* codes;
   uint32_t *acgt, *good, *word_off, *len;
+  uint32_t short_cnt[32];  // reads of length 0..31: they have no window for k > length, see windows_of()
+  // exact number of length-k windows of the block: sum over reads of max(0, len - k + 1)
+  uint64_t windows_of(int k) const {
+    uint64_t bases = n_bases, reads = n;
+    for (int l = 0; l < k - 1 && l < 32; ++l) {  // a read shorter than k-1 must not subtract k-1
+      bases -= (uint64_t)l * short_cnt[l];
+      reads -= short_cnt[l];
+    }
+    return bases - (uint64_t)(k - 1) * reads;
+  }
 };
 
 struct rfx_table {

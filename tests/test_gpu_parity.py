@@ -352,6 +352,46 @@ def test_msp_refines_the_partition_when_bins_get_dense(ctx, force_bits, monkeypa
         x.free()
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_three_count_paths_agree_on_random_configurations(ctx, seed, monkeypatch):
+    """Randomised cross-check: MSP, P2L and the table path must give identical bytes for random k in the
+    MSP range, table size, canonical flag, bounds, bin count, block split and read shapes (repeats,
+    homopolymers, N, short reads) -- and match the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    k = int(rng.choice([23, 24, 25]))
+    size = 1 << int(rng.integers(2 * k - 30 if 2 * k > 40 else 10, min(2 * k, 40)))
+    canonical = bool(rng.integers(0, 2))
+    lower = int(rng.choice([0, 1, 2, 3]))
+    upper = [2**64 - 1, 2**64 - 1, 40][int(rng.integers(0, 3))]   # (rng.choice would round 2^64-1 to a float)
+    monkeypatch.setenv("RFX_P2L_BINS", str(int(rng.choice([256, 512, 4096, 8192]))))
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(2000, 60000)))]
+    seqs = []
+    for _ in range(int(rng.integers(500, 6000))):
+        n = int(rng.choice([0, 10, k - 1, k, k + 1, 60, 150, 151, 300]))
+        s0 = int(rng.integers(0, max(1, len(genome) - n)))
+        r = genome[s0:s0 + n].copy()
+        if rng.random() < 0.1 and len(r):
+            r[rng.integers(0, len(r))] = ord("N")
+        if rng.random() < 0.03:
+            r[:] = ord("ACGT"[int(rng.integers(0, 4))])
+        if rng.random() < 0.3:
+            r = r[::-1].copy()
+        seqs.append(bytes(r))
+    splits = sorted(set([0, len(seqs)] + [int(x) for x in rng.integers(0, len(seqs), int(rng.integers(0, 3)))]))
+    ref = oracle.count(None, k, size, lower=lower, upper=upper, canonical=canonical, reads=seqs)
+    for mode in (capi.COUNT_MSP, capi.COUNT_P2L, capi.COUNT_TABLE, capi.COUNT_AUTO):
+        t = capi.CountTable(ctx, k, size, canonical, mode=mode)
+        for a, b in zip(splits, splits[1:]):
+            blk = ctx.upload(capi.PackedReads.from_reads(seqs[a:b]))
+            t.add(blk)
+            blk.free()
+        rec, h = t.finish(lower, upper, want_histo=True)
+        assert rec.payload() == ref.payload(), (mode, k, size, canonical, lower, upper)
+        assert np.array_equal(h, oracle.histo(ref.counts, full=True)[0])
+        rec.free()
+        t.free()
+
+
 def test_msp_record_segments_export_and_import(ctx, small_trio, monkeypatch):
     """The multi-GPU building blocks on one GPU: the record segments of two tables (different bin counts)
     are exported, split at an owner boundary, imported into two fresh tables and finished -- each result

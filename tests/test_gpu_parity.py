@@ -620,6 +620,47 @@ def test_synthetic_filter_matches_oracle(ctx, small_trio, k, minq, thresh):
     assert pulled.any()
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15])
+def test_filter_matches_oracle_on_random_configurations(ctx, seed):
+    """Randomised: k, MinQ, threshold, set size (LDS bitmap vs HBM probe), read shapes (short, N, low
+    quality, lower case, homopolymer), both loop bounds -- per-read hit counts against the oracle."""
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([5, 12, 19, 21, 25, 31, 32]))
+    minq = int(rng.choice([0, 2, 15, 30]))
+    thresh = int(rng.choice([1, 1, 2, 5]))
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(500, 20000)))]
+    reads, quals = [], []
+    for _ in range(int(rng.integers(50, 1500))):
+        n = int(rng.choice([1, k - 1, k, k + 1, 2 * k, 101, 150, 251]))
+        s0 = int(rng.integers(0, max(1, len(genome) - n)))
+        r = genome[s0:s0 + n].copy()
+        q = rng.choice(np.frombuffer(b"#(5?IJ", np.uint8), len(r), p=[.03, .03, .04, .1, .3, .5])
+        if rng.random() < 0.15 and len(r):
+            r[rng.integers(0, len(r))] = rng.choice(np.frombuffer(b"NnRacgt", np.uint8))
+        if rng.random() < 0.03:
+            r[:] = ord("ACGT"[int(rng.integers(0, 4))])
+        reads.append(bytes(r))
+        quals.append(bytes(q))
+    n_set = int(rng.choice([1, 20, 400, 8000]))
+    kmers = []
+    for _ in range(n_set):
+        s0 = int(rng.integers(0, len(genome) - k)) if len(genome) > k else 0
+        km = bytes(genome[s0:s0 + k]).decode()
+        kmers.append(km if rng.random() < 0.7 else "".join(rng.choice(list("ACGT"), k)))
+    text = ("\n".join(f"{x} {int(rng.integers(1, 99))}" for x in kmers) + "\n").encode()
+    fs = oracle.FilterSet(text)
+    mset = capi.MutantSet(ctx, capi.hashlist_keys(text, k), k)
+    blk = ctx.upload(capi.PackedReads.from_reads(reads, quals, minq, capi.PACK_FILTER))
+    for skipped, single in ((True, False), (False, True)):
+        hits, mask, nh = mset.filter(blk, thresh, skipped)
+        want = np.array([fs.scan(a, b, k, minq, single_end=single) for a, b in zip(reads, quals)], dtype=np.uint32)
+        assert np.array_equal(hits, want), (k, minq, thresh, n_set, np.flatnonzero(hits != want)[:5])
+        bits = tools._mask_bits(mask, len(reads))
+        assert np.array_equal(bits, want >= thresh) and nh == int(bits.sum())
+    blk.free()
+    mset.free()
+
+
 def test_filter_edge_cases(ctx):
     k = 5
     text = b"ACGTA 3\nTTTTT 9\n"

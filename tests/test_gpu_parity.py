@@ -560,6 +560,42 @@ def test_synthetic_merge_and_hashlist(ctx, small_trio):
         f.records.free()
 
 
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_merge_hashlist_query_on_random_configurations(ctx, seed):
+    """Randomised K4 inputs: 2-4 samples of very different sizes drawn from overlapping genomes (so the
+    (pos,key) search starts far from or right at its target, hits and misses both), random k, table
+    size, -L, coverage window; merge text, hash list and query against the oracle."""
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([15, 21, 25, 31]))
+    size = 1 << int(rng.integers(12, min(2 * k, 34)))
+    lower = int(rng.choice([1, 2, 3]))
+    base = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(3000, 30000)))]
+    samples = []
+    for _ in range(int(rng.integers(2, 5))):
+        g = base.copy()
+        mut = rng.integers(0, len(g), int(rng.integers(0, 40)))
+        g[mut] = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, len(mut))]
+        if rng.random() < 0.3:
+            g = g[:int(len(g) * rng.uniform(0.05, 0.6))]          # a much smaller sample
+        cov = int(rng.integers(2, 12))
+        n = max(1, cov * len(g) // 100)
+        reads = [bytes(g[s0:s0 + 100]) for s0 in rng.integers(0, max(1, len(g) - 100), n)]
+        samples.append(b"".join(b">r\n" + r + b"\n" for r in reads))
+    files = [tools.jellyfish_count(ctx, [fa], k, size, lower=lower) for fa in samples]
+    orcs = [oracle.count([fa], k, size, lower=lower) for fa in samples]
+    for f, o in zip(files, orcs):
+        assert f.records.payload() == o.payload()
+    assert tools.rufus_merge(ctx, files) == oracle.merge_unique_text(orcs)
+    for lo, hi in ((1, 10**6), (int(rng.integers(1, 6)), int(rng.integers(6, 40)))):
+        assert tools.hash_list(ctx, files[0], files[1:], lo, hi) == oracle.hash_list(orcs[0], orcs[1:], lo, hi)
+    kmers = [bytes(base[s0:s0 + k]).decode() for s0 in rng.integers(0, len(base) - k, 200)]
+    kmers += ["".join(rng.choice(list("ACGT"), k)) for _ in range(50)]
+    want = "".join(f"{oracle.jf_decode(key, k)} {c}\n" for key, c in oracle.query(orcs[-1], kmers))
+    assert tools.jellyfish_query(files[-1], kmers) == want
+    for f in files:
+        f.records.free()
+
+
 # ------------------------------------------------------------------------------------------------
 # filter
 # ------------------------------------------------------------------------------------------------

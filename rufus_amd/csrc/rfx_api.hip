@@ -687,7 +687,7 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
         hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream) == hipSuccess) {
       rfxk::part1_fused(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P2, t->pos_lo, t->pos_hi, G, buf_a, coarse_cur,
                         (uint32_t)cap64, cnt, coarse_cur + ncur);
-      rfxk::bin_offsets(c, cnt, (uint32_t)G, P, gsum, bin_start);
+      rfxk::bin_totals(c, cnt, (uint32_t)G, P, bin_start);
       rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, cfg.bin_shift, coarse_cur, (uint32_t)cap64, nullptr, nullptr,
                   ~0ull, "k_part2");
       if (queue_read(c, &flag, coarse_cur + ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) flag = 1;
@@ -849,7 +849,7 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   auto fail = [&](int rc) { drop(); dfree(c, bin_start); dfree(c, inst); return rc; };
   if (!cnt || !gsum || !bin_start || !fine_cur || !cur) return fail(RFX_E_NOMEM);
   rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 1, g.G, nullptr, nullptr, 0, cnt, nullptr);
-  rfxk::bin_offsets(c, cnt, (uint32_t)g.G, P, gsum, bin_start);
+  rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
   std::vector<uint64_t> bs((size_t)P + 1);
   if (queue_read(c, bs.data(), bin_start, ((size_t)P + 1) * 8) != hipSuccess || ctx_sync(c) != hipSuccess)
     return fail(RFX_E_HIP);
@@ -910,7 +910,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   }
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
   rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 0, g.G, buf_a, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
-  rfxk::bin_offsets(c, cnt, (uint32_t)g.G, P, gsum, bin_start);
+  rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
   rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
   rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
   drop();

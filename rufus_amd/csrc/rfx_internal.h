@@ -233,6 +233,8 @@ void bin_count(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, i
                const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, uint32_t* cnt);
 void bin_offsets(rfx_ctx*, uint32_t* cnt, uint32_t G, uint32_t P, uint32_t* gsum /* 8*P */,
                  uint64_t* bin_start /* P+1 */);
+// exclusive bin starts from the per-block histogram rows (no per-block offsets)
+void bin_totals(rfx_ctx*, const uint32_t* cnt, uint32_t G, uint32_t P, uint64_t* bin_start /* P+1 */);
 void bin_scatter(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab, int k, int canonical,
                  const rfx_ord_cfg&, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, const uint32_t* rel,
                  const uint64_t* bin_start, uint64_t* inst);

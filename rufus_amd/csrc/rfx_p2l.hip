@@ -115,6 +115,26 @@ __global__ __launch_bounds__(256) void k_bin_offsets(uint32_t* __restrict__ cnt,
   }
 }
 
+// bin_tot[b] = sum over blocks of cnt[g][b]: all the fused partitions need (they reserve their runs
+// with atomics, so the per-block offsets that k_bin_offsets also produces are not used)
+__global__ __launch_bounds__(1024) void k_col_sums(const uint32_t* __restrict__ cnt, uint32_t G, uint32_t P,
+                                                    uint64_t* __restrict__ bin_tot) {
+  __shared__ uint32_t s_part[16][64];
+  const uint32_t lane = threadIdx.x & 63, q = threadIdx.x >> 6;  // 16 row groups x 64 bins
+  const uint32_t b = blockIdx.x * 64 + lane;
+  uint32_t s = 0;
+  if (b < P)
+    for (uint32_t g = q; g < G; g += 16) s += cnt[(uint64_t)g * P + b];
+  s_part[q][lane] = s;
+  __syncthreads();
+  if (q == 0 && b < P) {
+    uint64_t t = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += s_part[i][lane];
+    bin_tot[b] = t;
+  }
+}
+
 template <bool CANON>
 __global__ __launch_bounds__(P2_BLOCK) void k_bin_scatter(rfx_reads_view rv, const uint64_t* __restrict__ g_lut,
                                                            int ntab, int k, rfx_ord_cfg cfg, uint32_t P, uint64_t pos_lo,
@@ -653,6 +673,12 @@ void bin_count(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int nt
   else
     hipLaunchKernelGGL(k_bin_count<false>, dim3(grid), dim3(P2_BLOCK), lds, c->stream, rv, lut, ntab, k, cfg, P, pos_lo,
                        pos_hi, cnt);
+}
+
+void bin_totals(rfx_ctx* c, const uint32_t* cnt, uint32_t G, uint32_t P, uint64_t* bin_start) {
+  rfx_span sp(c, "k_bin_offsets");
+  hipLaunchKernelGGL(k_col_sums, dim3((P + 63) / 64), dim3(1024), 0, c->stream, cnt, G, P, bin_start);
+  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, c->stream, bin_start, (uint64_t)P);
 }
 
 void bin_offsets(rfx_ctx* c, uint32_t* cnt, uint32_t G, uint32_t P, uint32_t* gsum, uint64_t* bin_start) {

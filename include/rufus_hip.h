@@ -173,6 +173,13 @@ void rfx_count_free(rfx_table*);
  * sorted_dumper.hpp:80-112, mer_heap.hpp:34-38; -L/-U at output count_main.cc:318-324) plus the
  * count-of-counts histogram of exactly those records (histo_main.cc:33-89), histo may be NULL. */
 rfx_records* rfx_count_finish(rfx_table*, uint64_t lower, uint64_t upper, uint64_t* histo /* RFX_HISTO_BINS */);
+/* The same in two steps, so that several tables can be queued on the device before the host waits for
+ * the first: _begin launches the work (nothing is waited for on the MSP path; other paths finish inside
+ * _begin), _end waits, returns the records (NULL on error) and frees the handle.  `histo` must stay
+ * valid until _end; the table must not be touched in between. */
+typedef struct rfx_finish rfx_finish;
+rfx_finish* rfx_count_finish_begin(rfx_table*, uint64_t lower, uint64_t upper, uint64_t* histo /* RFX_HISTO_BINS */);
+rfx_records* rfx_count_finish_end(rfx_finish*);
 
 /* ---------------------------------------------------------------------------------------------
  * Records (the .Jhash payload; jf/include/jellyfish/binary_dumper.hpp:44-48)

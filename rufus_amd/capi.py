@@ -55,6 +55,8 @@ SIGNATURES = {
     "rfx_count_add": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rfx_count_add_pairs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "rfx_count_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
+    "rfx_count_finish_begin": (C.c_void_p, [C.c_void_p, C.c_uint64, C.c_uint64, u64p]),
+    "rfx_count_finish_end": (C.c_void_p, [C.c_void_p]),
     "rfx_count_segments": (C.c_int, [C.c_void_p]),
     "rfx_count_segment_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_uint32), u64p]),
@@ -374,6 +376,17 @@ class CountTable:
         h = np.zeros(HISTO_BINS, dtype=np.uint64) if want_histo else None
         rec = Records(self.ctx, lib().rfx_count_finish(self._h, lower, upper, _p(h, u64p)))
         return (rec, h) if want_histo else rec
+
+    def finish_begin(self, lower: int = 0, upper: int = 2**64 - 1, want_histo: bool = False):
+        """Queue the finish; returns a handle for finish_end().  Several tables can be queued before the
+        first finish_end() waits."""
+        h = np.zeros(HISTO_BINS, dtype=np.uint64) if want_histo else None
+        return (lib().rfx_count_finish_begin(self._h, lower, upper, _p(h, u64p)), h)
+
+    def finish_end(self, handle):
+        f, h = handle
+        rec = Records(self.ctx, lib().rfx_count_finish_end(f))
+        return (rec, h) if h is not None else rec
 
     def free(self):
         if self._h:

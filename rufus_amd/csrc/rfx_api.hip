@@ -1015,7 +1015,37 @@ static void rfx_reads_release_pending(const rfx_reads* r) {
 // Count every minimizer bin in LDS, then put the survivors in (pos,key) order.  One synchronisation:
 // everything is queued (the records array is sized by what the survivor bins can hold), then the
 // totals, the capacity flags of this emit AND of the pending adds, and the histogram come back together.
-static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {
+// Queueing and collecting are separate steps so that a caller can queue several tables before it
+// waits for the first (rfx_count_finish_begin / _end).
+struct rfx_finish {
+  rfx_table* t = nullptr;
+  uint64_t lower = 0, upper = 0;
+  uint64_t* histo = nullptr;
+  rfx_records* ready = nullptr;  // result computed at begin (paths without a queued form)
+  bool failed = false;
+  // one queued attempt
+  bool queued = false;
+  uint64_t cap = 0, room = 0, kmers = 0, total_out = 0;
+  const uint64_t** d_inst = nullptr;
+  uint64_t *aw = nullptr, *bw = nullptr, *bsq = nullptr;
+  uint32_t *ac = nullptr, *bc = nullptr;
+  rfx_records* big = nullptr;
+  std::vector<const uint64_t*> h_ptrs;
+  std::vector<uint32_t> h_cur;
+  std::vector<unsigned int> pflags;
+};
+
+static void msp_emit_drop(rfx_finish* f) {
+  rfx_ctx* c = f->t->ctx;
+  dfree(c, f->d_inst); dfree(c, f->aw); dfree(c, f->ac); dfree(c, f->bw); dfree(c, f->bc); dfree(c, f->bsq);
+  f->d_inst = nullptr;
+  f->aw = f->bw = f->bsq = nullptr;
+  f->ac = f->bc = nullptr;
+  f->queued = false;
+}
+
+static int msp_emit_queue(rfx_finish* f) {
+  rfx_table* t = f->t;
   rfx_ctx* c = t->ctx;
   const uint32_t P1 = (uint32_t)rfxk::p1_bins();
   const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
@@ -1033,128 +1063,160 @@ static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper, uint6
     while (to_bits < 24 && (kmers >> to_bits) > 24576) ++to_bits;
     if (getenv("RFX_MSP_REFINE_BITS")) to_bits = std::max(to_bits, atoi(getenv("RFX_MSP_REFINE_BITS")));
     if (pmin < (1u << to_bits)) {
-      if (msp_resolve(t) != RFX_OK) return nullptr;  // refinement replaces segments: settle the adds first
-      if (msp_refine(t, to_bits) != RFX_OK) return nullptr;
+      int rc = msp_resolve(t);  // refinement replaces segments: settle the adds first
+      if (rc == RFX_OK) rc = msp_refine(t, to_bits);
+      if (rc) return rc;
     }
   }
   const uint32_t P = t->segs->front().bins;
-  // Survivors per instance: unknown before counting.  Samples of one run look alike, so the ratio the
-  // last emit on this ctx saw (+30 %) is the guess; the first emit assumes a quarter (singletons
-  // dropped) or 60 %.  A guess that is too small costs one rerun with exact capacities.
-  double& seen = c->msp_surv_frac[lower >= 2 ? 1 : 0];
-  double frac = seen > 0 ? seen * 1.3 : (lower >= 2 ? 0.25 : 0.6);
-  if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
-  uint64_t cap = 0;  // survivors per coarse pos bin; 0 = guess from the instance count
-  rfx_records* rec = nullptr;
-  for (int attempt = 0; attempt < 4 && !rec; ++attempt) {
-    const int nseg = (int)t->segs->size();
-    std::vector<const uint64_t*> h_inst(nseg), h_bs(nseg);
-    uint64_t kmers = 0;
-    for (int i = 0; i < nseg; ++i) {
-      h_inst[i] = (*t->segs)[i].inst;
-      h_bs[i] = (*t->segs)[i].bin_start;
-      kmers += (*t->segs)[i].kmers;
-    }
-    if (!cap) {
-      // a guess first (a quarter of the instances when singletons are dropped, else 60 %); if a bin
-      // overflows, the cursors of that run say exactly what is needed
-      cap = (uint64_t)((double)kmers * frac) / P1;
-      cap += cap / 8 + 4096;
-    }
-    if (cap >= (1ull << 32)) cap = (1ull << 32) - 1;
-    const uint64_t room = cap * P1;
-    uint32_t Pq = 256;
-    while (Pq < 32768 && (uint64_t)Pq * 1536 < room) Pq <<= 1;
-    const uint32_t P2q = Pq / P1;
-    const rfx_ord_cfg cfg = ord_cfg(t, ceil_log2(Pq));
-    std::vector<const uint64_t*> h_ptrs(h_inst);
-    h_ptrs.insert(h_ptrs.end(), h_bs.begin(), h_bs.end());
-    const uint64_t** d_inst = (const uint64_t**)dmalloc(c, 2 * nseg * sizeof(void*));
-    const uint64_t** d_bs = d_inst ? d_inst + nseg : nullptr;
-    uint64_t* aw = (uint64_t*)dmalloc(c, room * 8);
-    uint32_t* ac = (uint32_t*)dmalloc(c, room * 4);
-    uint64_t* bw = (uint64_t*)dmalloc(c, room * 8);
-    uint32_t* bc = (uint32_t*)dmalloc(c, room * 4);
-    // one zeroed block: fine pos-bin sizes, histogram, coarse cursors ([ncur] = capacity flag,
-    // [ncur+1] = error), fine cursors
-    const size_t zero_bytes = ((size_t)Pq + 1 + RFX_HISTO_BINS) * 8 + (ncur + 2 + (size_t)Pq) * 4;
-    uint64_t* bsq = (uint64_t*)dmalloc(c, zero_bytes);
-    unsigned long long* d_histo = bsq ? (unsigned long long*)(bsq + Pq + 1) : nullptr;
-    uint32_t* cur = bsq ? (uint32_t*)(d_histo + RFX_HISTO_BINS) : nullptr;
-    uint32_t* fcur = bsq ? cur + ncur + 2 : nullptr;
-    rfx_records* big = records_alloc(c, t->k, t->lsize, t->cols, room);
-    auto drop = [&] {
-      dfree(c, d_inst); dfree(c, aw); dfree(c, ac); dfree(c, bw); dfree(c, bc); dfree(c, bsq);
-    };
-    if (!d_inst || !aw || !ac || !bw || !bc || !bsq || !big) {
-      drop();
-      rfx_records_free(big);
-      return nullptr;
-    }
-    hipError_t e = upload(c, d_inst, h_ptrs.data(), 2 * nseg * sizeof(void*));
-    if (e == hipSuccess) e = hipMemsetAsync(bsq, 0, zero_bytes, c->stream);
-    if (e != hipSuccess) { hip_fail(e, "msp_emit"); drop(); rfx_records_free(big); return nullptr; }
-    rfxk::msp_leaf(c, d_inst, d_bs, nseg, h_inst[0], h_bs[0], P, t->k, t->canonical, t->lut_t, t->ntab, cfg.sel_bits,
-                   cfg.c_bits - 7, t->pos_lo, t->pos_hi, lower, upper, aw, ac, cur, (uint32_t)cap, cur + ncur,
-                   cur + ncur + 1);
-    if (histo) rfxk::histo_bins(c, ac, cur, (uint32_t)cap, d_histo);  // count-of-counts of exactly the survivors
-    rfxk::surv_hist(c, aw, cur, (uint32_t)cap, P2q, cfg.bin_shift, bsq);
-    rfxk::scan_tail(c, bsq, Pq);
-    rfxk::part2(c, aw, bw, bsq, fcur, P2q, cfg.bin_shift, cur, (uint32_t)cap, ac, bc, ~0ull, "k_surv_part2");
-    // every survivor is kept and fine bins are exact, so the sort writes the records in place
-    rfxk::surv_sort(c, bw, bc, bsq, Pq, cfg.bin_shift, t->lut_tinv, t->ntab, cfg.sel_bits, big->keys, big->counts,
-                    big->pos);
-    uint64_t total_out = 0;
-    std::vector<uint32_t> h_cur(ncur + 2);
-    std::vector<unsigned int> pflags(t->pend->size(), 1u);
-    e = queue_read(c, &total_out, bsq + Pq, 8);
-    if (e == hipSuccess) e = queue_read(c, h_cur.data(), cur, (ncur + 2) * 4);
-    for (size_t i = 0; i < pflags.size() && e == hipSuccess; ++i)
-      e = queue_read(c, &pflags[i], (*t->pend)[i].cur + (*t->pend)[i].ncur, 4);
-    if (e == hipSuccess && histo) e = queue_read(c, histo, d_histo, RFX_HISTO_BINS * 8);
-    if (e == hipSuccess) e = ctx_sync(c);  // h_inst / h_bs stay alive until here
-    drop();
-    if (e != hipSuccess) { hip_fail(e, "msp_emit"); rfx_records_free(big); return nullptr; }
-    bool redo = false;
-    for (unsigned int f : pflags) redo |= f != 0;
-    if (!t->pend->empty() && msp_settle(t, pflags) != RFX_OK) { rfx_records_free(big); return nullptr; }
-    if (redo) {  // a block was re-partitioned: count again
-      rfx_records_free(big);
-      continue;
-    }
-    if (h_cur[ncur + 1]) {
-      snprintf(g_err, sizeof g_err, "MSP: a bin could not be split far enough to fit LDS");
-      rfx_records_free(big);
-      return nullptr;
-    }
-    if (h_cur[ncur]) {  // a coarse pos bin overflowed: rerun with what the fullest one needs
-      cap = 1;
-      for (uint32_t cb = 0; cb < P1; ++cb) cap = std::max<uint64_t>(cap, h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
-      rfx_records_free(big);
-      continue;
-    }
-    big->n = total_out;
-    rec = big;
-    if (kmers) seen = (double)total_out / (double)kmers;
-    // Give a large slack back (exact arrays, device copies); a small one is not worth the 40 B/record of
-    // copy traffic -- the arrays return to the pool with the records anyway.
-    if ((room - total_out) * 20 > (2ull << 30)) {
-      rfx_records* fit = records_alloc(c, t->k, t->lsize, t->cols, total_out);
-      if (fit) {
-        e = hipMemcpyAsync(fit->keys, big->keys, total_out * 8, hipMemcpyDeviceToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(fit->counts, big->counts, total_out * 4, hipMemcpyDeviceToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(fit->pos, big->pos, total_out * 8, hipMemcpyDeviceToDevice, c->stream);
-        if (e == hipSuccess) {
-          rfx_records_free(big);  // stream-ordered pool: reused only by later work of this stream
-          rec = fit;
-        } else {
-          rfx_records_free(fit);
-        }
+  const int nseg = (int)t->segs->size();
+  f->h_ptrs.assign(2 * (size_t)nseg, nullptr);
+  f->kmers = 0;
+  for (int i = 0; i < nseg; ++i) {
+    f->h_ptrs[i] = (*t->segs)[i].inst;
+    f->h_ptrs[nseg + i] = (*t->segs)[i].bin_start;
+    f->kmers += (*t->segs)[i].kmers;
+  }
+  if (!f->cap) {
+    // Survivors per instance: unknown before counting.  Samples of one run look alike, so the ratio the
+    // last emit on this ctx saw (+30 %) is the guess; the first emit assumes a quarter (singletons
+    // dropped) or 60 %.  A guess that is too small costs one rerun with the capacity the cursors report.
+    const double seen = c->msp_surv_frac[f->lower >= 2 ? 1 : 0];
+    double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? 0.25 : 0.6);
+    if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
+    f->cap = (uint64_t)((double)f->kmers * frac) / P1;
+    f->cap += f->cap / 8 + 4096;
+  }
+  if (f->cap >= (1ull << 32)) f->cap = (1ull << 32) - 1;
+  const uint64_t cap = f->cap, room = cap * P1;
+  f->room = room;
+  uint32_t Pq = 256;
+  while (Pq < 32768 && (uint64_t)Pq * 1536 < room) Pq <<= 1;
+  const uint32_t P2q = Pq / P1;
+  const rfx_ord_cfg cfg = ord_cfg(t, ceil_log2(Pq));
+  f->d_inst = (const uint64_t**)dmalloc(c, 2 * nseg * sizeof(void*));
+  const uint64_t** d_bs = f->d_inst ? f->d_inst + nseg : nullptr;
+  f->aw = (uint64_t*)dmalloc(c, room * 8);
+  f->ac = (uint32_t*)dmalloc(c, room * 4);
+  f->bw = (uint64_t*)dmalloc(c, room * 8);
+  f->bc = (uint32_t*)dmalloc(c, room * 4);
+  // one zeroed block: fine pos-bin sizes, histogram, coarse cursors ([ncur] = capacity flag,
+  // [ncur+1] = error), fine cursors
+  const size_t zero_bytes = ((size_t)Pq + 1 + RFX_HISTO_BINS) * 8 + (ncur + 2 + (size_t)Pq) * 4;
+  f->bsq = (uint64_t*)dmalloc(c, zero_bytes);
+  uint64_t* bsq = f->bsq;
+  unsigned long long* d_histo = bsq ? (unsigned long long*)(bsq + Pq + 1) : nullptr;
+  uint32_t* cur = bsq ? (uint32_t*)(d_histo + RFX_HISTO_BINS) : nullptr;
+  uint32_t* fcur = bsq ? cur + ncur + 2 : nullptr;
+  f->big = records_alloc(c, t->k, t->lsize, t->cols, room);
+  auto fail = [&](int rc) {
+    msp_emit_drop(f);
+    rfx_records_free(f->big);
+    f->big = nullptr;
+    return rc;
+  };
+  if (!f->d_inst || !f->aw || !f->ac || !f->bw || !f->bc || !f->bsq || !f->big) return fail(RFX_E_NOMEM);
+  hipError_t e = upload(c, f->d_inst, f->h_ptrs.data(), 2 * nseg * sizeof(void*));
+  if (e == hipSuccess) e = hipMemsetAsync(bsq, 0, zero_bytes, c->stream);
+  if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
+  rfxk::msp_leaf(c, f->d_inst, d_bs, nseg, f->h_ptrs[0], f->h_ptrs[nseg], P, t->k, t->canonical, t->lut_t, t->ntab,
+                 cfg.sel_bits, cfg.c_bits - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur, (uint32_t)cap,
+                 cur + ncur, cur + ncur + 1);
+  if (f->histo) rfxk::histo_bins(c, f->ac, cur, (uint32_t)cap, d_histo);  // count-of-counts of exactly the survivors
+  rfxk::surv_hist(c, f->aw, cur, (uint32_t)cap, P2q, cfg.bin_shift, bsq);
+  rfxk::scan_tail(c, bsq, Pq);
+  rfxk::part2(c, f->aw, f->bw, bsq, fcur, P2q, cfg.bin_shift, cur, (uint32_t)cap, f->ac, f->bc, ~0ull, "k_surv_part2");
+  // every survivor is kept and fine bins are exact, so the sort writes the records in place
+  rfxk::surv_sort(c, f->bw, f->bc, bsq, Pq, cfg.bin_shift, t->lut_tinv, t->ntab, cfg.sel_bits, f->big->keys,
+                  f->big->counts, f->big->pos);
+  f->total_out = 0;
+  f->h_cur.assign(ncur + 2, 0);
+  f->pflags.assign(t->pend->size(), 1u);
+  e = queue_read(c, &f->total_out, bsq + Pq, 8);
+  if (e == hipSuccess) e = queue_read(c, f->h_cur.data(), cur, (ncur + 2) * 4);
+  for (size_t i = 0; i < f->pflags.size() && e == hipSuccess; ++i)
+    e = queue_read(c, &f->pflags[i], (*t->pend)[i].cur + (*t->pend)[i].ncur, 4);
+  if (e == hipSuccess && f->histo) e = queue_read(c, f->histo, d_histo, RFX_HISTO_BINS * 8);
+  if (e != hipSuccess) { hip_fail(e, "msp_emit"); (void)ctx_sync(c); return fail(RFX_E_HIP); }
+  f->queued = true;
+  return RFX_OK;
+}
+
+// Wait for a queued attempt.  0: *out is the result; 1: queue again (capacity or a block was redone); < 0: error.
+static int msp_emit_collect(rfx_finish* f, rfx_records** out) {
+  rfx_table* t = f->t;
+  rfx_ctx* c = t->ctx;
+  const uint32_t P1 = (uint32_t)rfxk::p1_bins();
+  const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
+  const hipError_t e = ctx_sync(c);  // delivers the read-backs of every queued emit of this ctx
+  msp_emit_drop(f);
+  rfx_records* big = f->big;
+  f->big = nullptr;
+  if (e != hipSuccess) { hip_fail(e, "msp_emit"); rfx_records_free(big); return RFX_E_HIP; }
+  bool redo = false;
+  for (unsigned int x : f->pflags) redo |= x != 0;
+  if (!t->pend->empty() && f->pflags.size() == t->pend->size()) {
+    const int rc = msp_settle(t, f->pflags);
+    if (rc) { rfx_records_free(big); return rc; }
+  }
+  if (redo) {  // a block was re-partitioned: count again
+    rfx_records_free(big);
+    return 1;
+  }
+  if (f->h_cur[ncur + 1]) {
+    snprintf(g_err, sizeof g_err, "MSP: a bin could not be split far enough to fit LDS");
+    rfx_records_free(big);
+    return RFX_E_FULL;
+  }
+  if (f->h_cur[ncur]) {  // a coarse pos bin overflowed: rerun with what the fullest one needs
+    f->cap = 1;
+    for (uint32_t cb = 0; cb < P1; ++cb)
+      f->cap = std::max<uint64_t>(f->cap, f->h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
+    rfx_records_free(big);
+    return 1;
+  }
+  const uint64_t total_out = f->total_out;
+  big->n = total_out;
+  if (f->kmers) c->msp_surv_frac[f->lower >= 2 ? 1 : 0] = (double)total_out / (double)f->kmers;
+  // Give a large slack back (exact arrays, device copies); a small one is not worth the 40 B/record of
+  // copy traffic -- the arrays return to the pool with the records anyway.
+  if ((f->room - total_out) * 20 > (2ull << 30)) {
+    rfx_records* fit = records_alloc(c, t->k, t->lsize, t->cols, total_out);
+    if (fit) {
+      hipError_t e2 = hipMemcpyAsync(fit->keys, big->keys, total_out * 8, hipMemcpyDeviceToDevice, c->stream);
+      if (e2 == hipSuccess) e2 = hipMemcpyAsync(fit->counts, big->counts, total_out * 4, hipMemcpyDeviceToDevice, c->stream);
+      if (e2 == hipSuccess) e2 = hipMemcpyAsync(fit->pos, big->pos, total_out * 8, hipMemcpyDeviceToDevice, c->stream);
+      if (e2 == hipSuccess) {
+        rfx_records_free(big);  // stream-ordered pool: reused only by later work of this stream
+        big = fit;
+      } else {
+        rfx_records_free(fit);
       }
     }
   }
-  if (!rec && !g_err[0]) snprintf(g_err, sizeof g_err, "MSP: emit did not converge (internal error)");
-  return rec;
+  *out = big;
+  return 0;
+}
+
+static rfx_records* msp_emit_finish(rfx_finish* f) {  // collect, re-queueing as often as the flags ask
+  rfx_records* rec = nullptr;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (!f->queued && msp_emit_queue(f) != RFX_OK) return nullptr;
+    const int rc = msp_emit_collect(f, &rec);
+    if (rc == 0) return rec;
+    if (rc < 0) return nullptr;
+  }
+  snprintf(g_err, sizeof g_err, "MSP: emit did not converge (internal error)");
+  return nullptr;
+}
+
+static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {
+  rfx_finish f;
+  f.t = t;
+  f.lower = lower;
+  f.upper = upper;
+  f.histo = histo;
+  return msp_emit_finish(&f);
 }
 
 static void p2l_drop_segments(rfx_table* t) {
@@ -1326,6 +1388,36 @@ int rfx_count_stats(rfx_table* t, uint64_t* distinct, uint64_t* capacity, uint64
   if (capacity) *capacity = t->cap;
   if (max_displacement) *max_displacement = st.max_disp;
   return st.overflow ? RFX_E_FULL : RFX_OK;
+}
+
+rfx_finish* rfx_count_finish_begin(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {
+  if (!t) return nullptr;
+  (void)hipSetDevice(t->ctx->device);
+  rfx_finish* f = new rfx_finish();
+  f->t = t;
+  f->lower = lower;
+  f->upper = upper;
+  f->histo = histo;
+  if (!t->pend_error && !t->segs->empty() && !t->table_active && t->seg_kind == RFX_COUNT_MSP) {
+    if (msp_emit_queue(f) != RFX_OK) f->failed = true;  // nothing waited for: the work is only queued
+  } else {
+    f->ready = rfx_count_finish(t, lower, upper, histo);  // paths without a queued form finish here
+    f->failed = f->ready == nullptr;
+  }
+  return f;
+}
+
+rfx_records* rfx_count_finish_end(rfx_finish* f) {
+  if (!f) return nullptr;
+  (void)hipSetDevice(f->t->ctx->device);
+  rfx_records* r = f->failed ? nullptr : (f->ready ? f->ready : msp_emit_finish(f));
+  if (f->queued) {  // an error path left an attempt in flight: let it drain before its buffers go
+    (void)ctx_sync(f->t->ctx);
+    msp_emit_drop(f);
+    rfx_records_free(f->big);
+  }
+  delete f;
+  return r;
 }
 
 rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {

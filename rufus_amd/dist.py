@@ -87,6 +87,23 @@ class HipBackend:
         finally:
             t.free()
 
+    def count_begin(self, block, lower: int):
+        """Queue count + finish of a block without waiting (MSP path); pair with count_end()."""
+        t = capi.CountTable(self.ctx, self.k, self.size, True, self.capacity)
+        try:
+            t.add(block)
+            return t, t.finish_begin(lower, want_histo=True)
+        except Exception:
+            t.free()
+            raise
+
+    def count_end(self, pending):
+        t, handle = pending
+        try:
+            return t.finish_end(handle)
+        finally:
+            t.free()
+
     # -- exchange path ----------------------------------------------------------------------------
     def count_partials(self, block):
         """(keys int64, counts int32, pos int64) device tensors of every distinct k-mer of the block."""
@@ -329,10 +346,19 @@ class TrioShard:
 
     def run(self, subject_block, control_blocks, keep_records: bool = False):
         recs, histos = [], []
-        for blk in [subject_block] + list(control_blocks):
-            rec, h = self.count_sample(blk)
-            recs.append(rec)
-            histos.append(h)
+        blocks = [subject_block] + list(control_blocks)
+        if self.world == 1 and hasattr(self.be, "count_begin"):
+            # queue all samples before waiting for the first: the device never idles between them
+            pending = [self.be.count_begin(blk, self.lower) for blk in blocks]
+            for p in pending:
+                rec, h = self.be.count_end(p)
+                recs.append(rec)
+                histos.append(h)
+        else:
+            for blk in blocks:
+                rec, h = self.count_sample(blk)
+                recs.append(rec)
+                histos.append(h)
         keys, counts = self.be.unique(recs[0], recs[1:], self.min_cov, self.max_cov)
         n_rec = [self.be.n_records(r) for r in recs]
         if self.world > 1:

@@ -234,6 +234,29 @@ def test_msp_count_matches_oracle(ctx, small_trio, k, size, canonical, lower):
     jf.records.free()
 
 
+def test_finish_begin_end_pipelines_several_tables(ctx, small_trio):
+    """Three tables queued before the first is waited for (MSP: nothing blocks in _begin; the k = 31
+    table finishes inside _begin) give the same records and histograms as finish()."""
+    fq = {n: [fastq_bytes(small_trio[n], m) for m in (1, 2)] for n in ("child", "mother", "father")}
+    cfgs = [("child", 25, 8 << 30, 2), ("mother", 25, 8 << 30, 1), ("father", 31, 1 << 26, 2)]
+    tables, blocks, handles = [], [], []
+    for n, k, size, lower in cfgs:
+        t = capi.CountTable(ctx, k, size)
+        blk = ctx.upload(capi.PackedReads.from_reads([r for f in fq[n] for r in tools.parse_sequences(f)]))
+        t.add(blk)
+        handles.append(t.finish_begin(lower, want_histo=True))
+        tables.append(t)
+        blocks.append(blk)
+    for (n, k, size, lower), t, h in zip(cfgs, tables, handles):
+        rec, histo = t.finish_end(h)
+        ref = oracle.count(fq[n], k, size, lower=lower)
+        assert rec.payload() == ref.payload()
+        assert np.array_equal(histo, oracle.histo(ref.counts, full=True)[0])
+        rec.free()
+    for x in blocks + tables:
+        x.free()
+
+
 def test_msp_rejects_k_outside_its_record_format(ctx):
     t = capi.CountTable(ctx, 31, 1 << 20, mode=capi.COUNT_MSP)
     blk = ctx.upload(capi.PackedReads.from_reads([b"ACGT" * 20]))

@@ -200,6 +200,29 @@ def test_exchange_matches_single_process(world, shard_by):
     assert all(g[6] == n_pulled for g in got) and n_pulled > 0
 
 
+def test_bin_owner_bounds_agree_across_bin_counts():
+    """Owner ranges are cut on the top 8 bits of the bin index, so a bin of a 256-bin partition and its
+    refinements in 1024- or 8192-bin partitions have the same owner, for any world size."""
+    for world in (1, 2, 3, 5, 8, 64, 256):
+        owners = {}
+        for bins in (256, 1024, 8192):
+            b = rdist.bin_owner_bounds(bins, world)
+            assert b[0] == 0 and b[-1] == bins and all(x <= y for x, y in zip(b, b[1:]))
+            own = np.searchsorted(np.array(b[1:]), np.arange(bins), side="right")
+            owners[bins] = own[::bins // 256]                     # owner of each virtual (top-8-bit) bin
+            assert np.array_equal(np.repeat(owners[bins], bins // 256), own)   # refinements stay together
+        assert np.array_equal(owners[256], owners[1024]) and np.array_equal(owners[256], owners[8192])
+        if world <= 256:
+            assert len(set(owners[256].tolist())) == world        # every rank owns something
+
+
+def test_merge_shards_interleaves_by_pos_then_key():
+    a = (np.array([5, 9], np.uint64), np.array([1, 2], np.uint64), np.array([0, 7], np.uint64))
+    b = (np.array([3, 4, 1], np.uint64), np.array([3, 4, 5], np.uint64), np.array([0, 7, 9], np.uint64))
+    k, c, p = rdist.merge_shards([a, b])
+    assert k.tolist() == [3, 5, 4, 9, 1] and c.tolist() == [3, 1, 4, 2, 5] and p.tolist() == [0, 0, 7, 7, 9]
+
+
 def test_owner_bounds_cover_the_range():
     for lsize in (10, 27, 33):
         for world in (1, 2, 3, 8):

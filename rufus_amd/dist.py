@@ -239,10 +239,10 @@ def exchange_partials(keys: torch.Tensor, counts: torch.Tensor, pos: torch.Tenso
     return rk.to(dev), rc.to(dev)
 
 
-def exchange_records(records: torch.Tensor, bin_start: torch.Tensor, group):
-    """Deal the bins to their owners.  Returns [(records_from_rank, bin_start_full)] for this rank's bins,
-    one entry per source rank; bin_start_full has the sender's bin count + 1 entries (empty outside the
-    owned range) so that the run can be imported as it is."""
+def exchange_records_begin(records: torch.Tensor, bin_start: torch.Tensor, group):
+    """Deal the bins to their owners: the (small) size and offset exchanges happen here, the record
+    all-to-all is only STARTED (async) -- the caller can partition the next sample meanwhile.  Finish
+    with exchange_records_end()."""
     world, me = dist.get_world_size(group), dist.get_rank(group)
     dev = records.device
     bins = bin_start.numel() - 1
@@ -254,9 +254,6 @@ def exchange_records(records: torch.Tensor, bin_start: torch.Tensor, group):
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
     recv_l = recv.tolist()
-    wr = _wire(records[:int(cuts[-1])], group)
-    rr = torch.empty(sum(recv_l), dtype=records.dtype, device=wr.device)
-    dist.all_to_all_single(rr, wr, recv_l, send_l, group=group)
     # bin offsets of every destination's range, relative to the start of its run.  Bin counts may differ
     # between ranks (they follow the block size), so the lengths travel first.
     parts = [bs_host[b[d]:b[d + 1] + 1] - bs_host[b[d]] for d in range(world)]
@@ -267,6 +264,22 @@ def exchange_records(records: torch.Tensor, bin_start: torch.Tensor, group):
     sb = _wire(torch.cat(parts).to(dev), group)
     rb = torch.empty(sum(len_rl), dtype=torch.int64, device=sb.device)
     dist.all_to_all_single(rb, sb, len_rl, len_sl, group=group)
+    wr = _wire(records[:int(cuts[-1])], group)
+    rr = torch.empty(sum(recv_l), dtype=records.dtype, device=wr.device)
+    work = dist.all_to_all_single(rr, wr, recv_l, send_l, group=group, async_op=True)
+    return {"work": work, "rr": rr, "wr": wr, "rb": rb, "recv_l": recv_l, "len_rl": len_rl, "world": world, "me": me,
+            "dev": dev}
+
+
+def exchange_records_end(st):
+    """Wait for the record all-to-all.  Returns [(records_from_rank, bin_start_full)] for this rank's bins,
+    one entry per source rank; bin_start_full has the sender's bin count + 1 entries (empty outside the
+    owned range) so that the run can be imported as it is."""
+    st["work"].wait()
+    if st["rr"].is_cuda:       # wait() orders torch's stream only; the library runs on its own stream
+        torch.cuda.current_stream(st["rr"].device).synchronize()
+    world, me, dev, rr, rb = st["world"], st["me"], st["dev"], st["rr"], st["rb"]
+    recv_l, len_rl = st["recv_l"], st["len_rl"]
     v0, v1 = -(-me * 256 // world), -(-(me + 1) * 256 // world)   # my range in virtual bins
     runs, ro, bo = [], 0, 0
     for src in range(world):
@@ -281,6 +294,10 @@ def exchange_records(records: torch.Tensor, bin_start: torch.Tensor, group):
         ro += recv_l[src]
         bo += len_rl[src]
     return runs
+
+
+def exchange_records(records: torch.Tensor, bin_start: torch.Tensor, group):
+    return exchange_records_end(exchange_records_begin(records, bin_start, group))
 
 
 def merge_shards(shards):
@@ -347,7 +364,23 @@ class TrioShard:
     def run(self, subject_block, control_blocks, keep_records: bool = False):
         recs, histos = [], []
         blocks = [subject_block] + list(control_blocks)
-        if self.world == 1 and hasattr(self.be, "count_begin"):
+        if self.world > 1 and self.shard_by == "minimizer":
+            # The record all-to-all of a sample travels (RCCL on its own stream) while the next sample is
+            # being partitioned and the previous one counted; histograms are reduced once, at the end.
+            started = []
+            for blk in blocks:
+                records, bin_start = self.be.partition(blk)
+                started.append(exchange_records_begin(records, bin_start, self.group))
+            local = []
+            for st in started:
+                rec, histo = self.be.count_records(exchange_records_end(st), self.lower)
+                recs.append(rec)
+                local.append(histo.astype(np.int64))
+            dev = started[0]["dev"]
+            h = _wire(torch.from_numpy(np.stack(local)).to(dev), self.group)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            histos = [x.astype(np.uint64) for x in h.cpu().numpy()]
+        elif self.world == 1 and hasattr(self.be, "count_begin"):
             # queue all samples before waiting for the first: the device never idles between them
             pending = [self.be.count_begin(blk, self.lower) for blk in blocks]
             for p in pending:

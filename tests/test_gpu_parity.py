@@ -829,6 +829,17 @@ def _dist_worker(rank, world, port, q, shard_by):
         dist.destroy_process_group()
 
 
+def test_collectives_on_a_one_rank_rccl_group():
+    """The exchange code issued against the real RCCL backend (one rank: a 1-GPU box cannot do more):
+    all_to_all_single with device split tensors, the async variant, all_reduce, all_gather."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "rccl_selftest.py")], capture_output=True, text=True,
+                       timeout=240, cwd=os.path.dirname(here))
+    assert r.returncode == 0 and "rccl self-test ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("shard_by", ["minimizer", "pos"])
 def test_two_ranks_exchange_on_the_hip_backend(shard_by):
     """minimizer: ranks exchange super-k-mer records by bin owner and count complete bins (shards

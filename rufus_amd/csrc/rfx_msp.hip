@@ -51,7 +51,8 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
                                                          unsigned int* __restrict__ flag) {
   __shared__ uint64_t s_stage[HMODE == 1 ? 1 : P1_STAGE];
   __shared__ uint8_t s_sbin[HMODE == 1 ? 1 : P1_STAGE];
-  __shared__ uint32_t s_cnt[P1_BINS], s_start[P1_BINS + 1], s_gbase[P1_BINS];
+  __shared__ uint32_t s_cnt[P1_BINS], s_start[P1_BINS + 1];
+  __shared__ uint64_t s_gbase[P1_BINS];  // 64-bit: the exact redo may size a coarse bin by a skewed maximum
   __shared__ uint32_t s_fine[HMODE == 0 ? 4096 : HMODE == 1 ? 8192 : 1];
   __shared__ uint32_t s_maxlen;
   const uint32_t P = 1u << bin_bits;
@@ -162,9 +163,9 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
       if (threadIdx.x < P1_BINS) {
         if ((uint64_t)at + cn > cap_a) {  // over capacity: the run is dropped, the host redoes the block
           atomicExch(flag, 1u);
-          s_gbase[threadIdx.x] = 0xFFFFFFFFu;
+          s_gbase[threadIdx.x] = ~0ull;
         } else {
-          s_gbase[threadIdx.x] = threadIdx.x * cap_a + at;
+          s_gbase[threadIdx.x] = (uint64_t)threadIdx.x * cap_a + at;
         }
       }
       __syncthreads();
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
       blk_total += total;
       for (uint32_t e = threadIdx.x; e < total; e += P2_BLOCK) {
         const uint32_t cb = s_sbin[e];
-        if (s_gbase[cb] != 0xFFFFFFFFu) buf_a[(uint64_t)s_gbase[cb] + (e - s_start[cb])] = s_stage[e];
+        if (s_gbase[cb] != ~0ull) buf_a[s_gbase[cb] + (e - s_start[cb])] = s_stage[e];
       }
       __syncthreads();
     }

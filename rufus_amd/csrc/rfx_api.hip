@@ -1707,14 +1707,19 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
   const size_t bm_words = (size_t)1 << (s->bm_bits > 5 ? s->bm_bits - 5 : 0);
   s->slots = (uint64_t*)dmalloc(c, s->cap * 8);
   s->bitmap = (uint32_t*)dmalloc(c, std::max<size_t>(bm_words, 2048) * 4);
+  // the fast filter's own pre-filters (small sets only: two 2^16-bit bitmaps that live in LDS)
+  const size_t bm2_words = (k >= 16 && n <= 4096) ? 4096 : 0;
+  if (bm2_words) s->bitmap2 = (uint32_t*)dmalloc(c, bm2_words * 4);
   uint64_t* dk = (uint64_t*)dmalloc(c, n * 8);
-  bool ok = s->slots && dk && s->bitmap;
+  bool ok = s->slots && dk && s->bitmap && (!bm2_words || s->bitmap2);
+  if (ok && bm2_words) ok = hipMemsetAsync(s->bitmap2, 0, bm2_words * 4, c->stream) == hipSuccess;
   if (ok) ok = hipMemsetAsync(s->slots, 0xFF, s->cap * 8, c->stream) == hipSuccess &&
                hipMemsetAsync(s->bitmap, 0, std::max<size_t>(bm_words, 2048) * 4, c->stream) == hipSuccess;
   if (ok && n) ok = upload(c, dk, fwd_keys, n * 8) == hipSuccess;
   if (ok) {
     rfxk::set_insert(c, dk, n, s->slots, s->bits);
     rfxk::set_bitmap(c, dk, n, s->bitmap, s->bm_bits, s->bm_shift);
+    if (s->bitmap2) rfxk::set_bitmap_packed(c, dk, n, s->bitmap2);
     ok = ctx_sync(c) == hipSuccess;
   }
   dfree(c, dk);
@@ -1729,6 +1734,7 @@ void rfx_set_free(rfx_set* s) {
   if (!s) return;
   dfree(s->ctx, s->slots);
   dfree(s->ctx, s->bitmap);
+  dfree(s->ctx, s->bitmap2);
   delete s;
 }
 
@@ -1748,8 +1754,12 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
   hipError_t e = hipMemsetAsync(d_n, 0, 8, c->stream);
   if (e == hipSuccess) {
     rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
-    rfxk::filter(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap, s->bm_bits, s->bm_shift, s->k, thresh,
-                 last_base_skipped, d_hits, d_mask, d_n);
+    if (s->bitmap2 && !getenv("RFX_FILTER_GENERIC"))
+      rfxk::filter_fast(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap2, s->k, thresh, last_base_skipped,
+                        d_hits, d_mask, d_n);
+    else
+      rfxk::filter(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap, s->bm_bits, s->bm_shift, s->k, thresh,
+                   last_base_skipped, d_hits, d_mask, d_n);
     unsigned long long nh = 0;
     e = queue_read(c, &nh, d_n, 8);
     if (e == hipSuccess && hits_out) e = queue_read(c, hits_out, d_hits, (size_t)r->n * 4);

@@ -183,6 +183,7 @@ struct rfx_set {
   int has_all_ones;  // K = 32 poly-T collides with the empty sentinel
   uint32_t* bitmap;  // 2^bm_bits bits indexed by (fwd >> bm_shift): pre-filter of the probe
   int bm_bits, bm_shift;
+  uint32_t* bitmap2;  // k >= 16, <= 4096 keys: the two packed-order bitmaps of k_filter_fast (else null)
 };
 
 // ---- kernel launchers (rfx_kernels.hip) -------------------------------------------------------
@@ -221,6 +222,10 @@ void query(rfx_ctx*, const uint64_t* qkeys, uint64_t nq, const uint64_t* lut, in
            const uint64_t* pos, const uint32_t* counts, uint64_t n, uint32_t* out);
 void set_insert(rfx_ctx*, const uint64_t* keys, uint64_t n, uint64_t* slots, int bits);
 void set_bitmap(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm, int bm_bits, int bm_shift);
+// k >= 16 and a small set: two 2^16-bit pre-filter bitmaps (last 8 bases, the 8 before) in packed order
+void set_bitmap_packed(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm /* 4096 words */);
+void filter_fast(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
+                 int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit);
 void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
             int bm_bits, int bm_shift, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
             unsigned long long* d_nhit);

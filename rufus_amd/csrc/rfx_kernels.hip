@@ -735,6 +735,116 @@ __global__ __launch_bounds__(K5_BLOCK) void k_filter(rfx_reads_view rv, const ui
   }
 }
 
+// ---- fast filter (k >= 16, sets of <= 4096 keys) -------------------------------------------------
+// k_filter rolls a 64-bit word and a streak counter base by base: ~60 issue slots per base, a dependent
+// chain.  Here nothing rolls: the packed words ARE the windows.
+//   * V = "a fully good window ends here" for the 32 bases of a word at once, by AND-ing shifted copies
+//     of the good mask (run-length doubling, ~20 instructions per word);
+//   * two pre-filter bitmaps in LDS (2^16 bits each): A over the last 8 bases of the k-mer, B over the 8
+//     bases before those, both indexed by the packed codes as they lie in the word -- a constant-shift
+//     extract once the j loop is unrolled, no 64-bit arithmetic, and the 64 LDS reads of a word are
+//     independent (all in flight).  With ~1000 keys a random window passes both with probability 2e-4;
+//   * a window that passes both is cut out of the two packed words with one 128-bit shift, turned into
+//     the forward key (2-bit groups reversed) and probed exactly.
+constexpr int FF_NB = 8;
+
+__global__ __launch_bounds__(256) void k_set_bitmap_packed(const uint64_t* __restrict__ keys, uint64_t n,
+                                                            uint32_t* __restrict__ bm /* A then B */) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i];  // first base most significant: the last base is bits [1:0]
+    uint32_t ia = 0, ib = 0;
+#pragma unroll
+    for (int b = 0; b < FF_NB; ++b) {  // packed order: the earlier base in the lower bits
+      ia |= (uint32_t)((key >> (2 * b)) & 3u) << (2 * (FF_NB - 1 - b));
+      ib |= (uint32_t)((key >> (2 * (b + FF_NB))) & 3u) << (2 * (FF_NB - 1 - b));
+    }
+    atomicOr(&bm[ia >> 5], 1u << (ia & 31));
+    atomicOr(&bm[2048 + (ib >> 5)], 1u << (ib & 31));
+  }
+}
+
+__global__ __launch_bounds__(K5_BLOCK) void k_filter_fast(rfx_reads_view rv, const uint64_t* __restrict__ g_slots,
+                                                           int bits, int has_all_ones,
+                                                           const uint32_t* __restrict__ g_bm, int k, int thresh,
+                                                           int last_base_skipped, uint32_t* __restrict__ hits_out,
+                                                           uint64_t* __restrict__ hitmask,
+                                                           unsigned long long* __restrict__ d_nhit) {
+  __shared__ uint32_t s_bm[4096];  // A: [0, 2048), B: [2048, 4096)
+  for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) s_bm[i] = g_bm[i];
+  __syncthreads();
+  const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+  const uint32_t n_chunks = (rv.n + K5_BLOCK - 1) / K5_BLOCK;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t r = chunk * K5_BLOCK + threadIdx.x;
+    uint32_t found = 0;
+    if (r < rv.n) {
+      const uint32_t wr = rv.word_off[r];
+      const uint32_t len = rv.len[r];
+      const uint64_t* __restrict__ cw = rv.codes + wr;
+      const uint32_t* __restrict__ cm = rv.good + wr;
+      // src/RUFUS.Filter.cpp:203: `i < length()-1` -- the last base is never examined.
+      const uint32_t stop = last_base_skipped ? (len ? len - 1 : 0) : len;
+      const uint32_t nw = (stop + 31) >> 5;
+      uint64_t prev_c = 0;
+      uint32_t prev_g = 0;
+      for (uint32_t wi = 0; wi < nw; ++wi) {
+        const uint64_t cur_c = cw[wi];
+        uint32_t cur_g = cm[wi];
+        const uint32_t nb = stop - (wi << 5);
+        if (nb < 32) cur_g &= (1u << nb) - 1;  // positions at or beyond `stop` end no window
+        // V bit (32 + j): the k good bits ending at base j of this word are all set (the positions before
+        // the read are zero bits of prev_g, so a window cannot start before the read either)
+        const uint64_t X = ((uint64_t)cur_g << 32) | prev_g;
+        uint64_t acc = ~0ull, run = X;
+        int off = 0;
+        for (int bit = 0; (k >> bit) != 0; ++bit) {
+          if ((k >> bit) & 1) {
+            acc &= run << off;
+            off += 1 << bit;
+          }
+          run &= run << (1 << bit);
+        }
+        const uint32_t V = (uint32_t)(acc >> 32);
+        if (V) {
+          uint32_t cand = 0;
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            // packed codes of bases j-7 .. j and j-15 .. j-8 (may reach into the previous word)
+            const int sa = 2 * (j - FF_NB + 1), sb = 2 * (j - 2 * FF_NB + 1);
+            const uint32_t ia = (uint32_t)(sa >= 0 ? cur_c >> sa : (cur_c << (-sa)) | (prev_c >> (64 + sa))) & 0xFFFFu;
+            const uint32_t ib = (uint32_t)(sb >= 0 ? cur_c >> sb : (cur_c << (-sb)) | (prev_c >> (64 + sb))) & 0xFFFFu;
+            const uint32_t hit = (s_bm[ia >> 5] >> (ia & 31)) & (s_bm[2048 + (ib >> 5)] >> (ib & 31)) & 1u;
+            cand |= hit << j;
+          }
+          cand &= V;
+          while (cand) {  // rare
+            const int j = __ffs(cand) - 1;
+            cand &= cand - 1;
+            // window = bases j-k+1 .. j of (prev word, this word): one 128-bit shift, then the 2-bit groups
+            // reversed to get the forward key (first base most significant)
+            const int sh = 2 * (j - k + 1) + 64;  // 2 .. 126
+            const uint64_t packed = sh >= 64 ? cur_c >> (sh - 64) : (prev_c >> sh) | (cur_c << (64 - sh));
+            uint64_t y = __brevll(packed);  // reverses bits: swap them back inside every pair
+            y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+            const uint64_t fwd = (k == 32 ? y : y >> (64 - 2 * k)) & kmask;
+            found += fwd == RFX_EMPTY ? (has_all_ones != 0) : set_has(g_slots, bits, fwd);
+          }
+        }
+        prev_c = cur_c;
+        prev_g = cur_g;
+      }
+      if (hits_out) hits_out[r] = found;
+    }
+    // wave ballot -> one 64-bit word of the hit mask per 64 reads
+    const bool pass = r < rv.n && (int)found >= thresh;
+    const unsigned long long mm = __ballot(pass);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && r < rv.n) {
+      if (hitmask) hitmask[r >> 6] = mm;
+      if (mm) atomicAdd(d_nhit, (unsigned long long)__popcll(mm));
+    }
+  }
+}
+
 inline int grid_for(rfx_ctx* c, uint64_t work_items, int block, int per_cu) {
   uint64_t blocks = (work_items + block - 1) / block;
   uint64_t cap = (uint64_t)c->n_cu * per_cu;
@@ -889,6 +999,22 @@ void set_bitmap(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* bm, int 
   rfx_span sp(c, "k_set_bitmap");
   hipLaunchKernelGGL(k_set_bitmap, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, bm, bm_bits,
                      bm_shift);
+}
+
+void set_bitmap_packed(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* bm) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_set_bitmap");
+  hipLaunchKernelGGL(k_set_bitmap_packed, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, bm);
+}
+
+void filter_fast(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones,
+                 const uint32_t* bm, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
+                 unsigned long long* d_nhit) {
+  if (rv.n == 0) return;
+  rfx_span sp(c, "k_filter");
+  const int grid = grid_for(c, (rv.n + K5_BLOCK - 1) / K5_BLOCK, 1, 8);
+  hipLaunchKernelGGL(k_filter_fast, dim3(grid), dim3(K5_BLOCK), 0, c->stream, rv, slots, bits, has_all_ones, bm, k,
+                     thresh, last_base_skipped, hits, hitmask, d_nhit);
 }
 
 void filter(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,

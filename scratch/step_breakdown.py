@@ -18,16 +18,13 @@ shard = TrioShard(ctx, bench.K, bench.JF_SIZE, bench.LOWER, bench.MIN_COV, bench
 be = shard.be
 for it in range(4):
     t = [time.perf_counter()]
+    pend = [be.count_begin(blocks[n], bench.LOWER) for n in ("child", "mother", "father")]; t.append(time.perf_counter())
     recs = []
-    for n in ("child", "mother", "father"):
-        tb = capi.CountTable(ctx, be.k, be.size, True, be.capacity)
-        tb.add(blocks[n]); t.append(time.perf_counter())
-        rec, h = tb.finish(bench.LOWER, want_histo=True); t.append(time.perf_counter())
-        tb.free(); recs.append(rec)
+    for p in pend:
+        rec, h = be.count_end(p); recs.append(rec); t.append(time.perf_counter())
     keys, counts = be.unique(recs[0], recs[1:], bench.MIN_COV, bench.MAX_DEPTH); t.append(time.perf_counter())
     pulled = be.filter_pairs(keys, blocks["child"], bench.THRESH); t.append(time.perf_counter())
-    n = pulled[0]; t.append(time.perf_counter())
     for r in recs: r.free()
     t.append(time.perf_counter())
     d = np.diff(np.array(t)) * 1e3
-    print("add/finish x3:", np.round(d[:6], 3), "unique %.3f filter %.3f sum %.3f free %.3f total %.3f" % (d[6], d[7], d[8], d[9], (t[-1] - t[0]) * 1e3))
+    print("begin x3 %.3f | end %.3f %.3f %.3f | unique %.3f filter %.3f free %.3f | total %.3f" % (*d[:7], (t[-1] - t[0]) * 1e3))

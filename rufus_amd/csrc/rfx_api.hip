@@ -380,15 +380,24 @@ int unique_run(rfx_ctx* c, const rfx_records* f, const rfx_records* const* all, 
     rfxk::flag_absent(c, f->keys, f->pos, f->n, all[j]->keys, all[j]->pos, all[j]->n, f->lsize, flags);
   }
   rfxk::compact(c, flags, f->keys, f->counts, f->pos, f->n, ok, oc, op, boff, d_tot);
+  // The result is usually tiny (mutant k-mers): fetch the count AND the first entries with one
+  // synchronisation; only a result beyond the speculative head needs a second round.
   unsigned long long tot = 0;
+  const uint64_t head = std::min<uint64_t>(f->n, 2048);
+  out.keys.resize(head); out.pos.resize(head); out.counts.resize(head);
   hipError_t e = queue_read(c, &tot, d_tot, 8);
+  if (e == hipSuccess) e = queue_read(c, out.keys.data(), ok, head * 8);
+  if (e == hipSuccess) e = queue_read(c, out.pos.data(), op, head * 8);
+  if (e == hipSuccess) e = queue_read(c, out.counts.data(), oc, head * 4);
   if (e == hipSuccess) e = ctx_sync(c);
-  if (e == hipSuccess && tot) {
+  if (e == hipSuccess) {
     out.keys.resize(tot); out.pos.resize(tot); out.counts.resize(tot);
-    e = queue_read(c, out.keys.data(), ok, tot * 8);
-    if (e == hipSuccess) e = queue_read(c, out.pos.data(), op, tot * 8);
-    if (e == hipSuccess) e = queue_read(c, out.counts.data(), oc, tot * 4);
-    if (e == hipSuccess) e = ctx_sync(c);
+    if (tot > head) {
+      e = queue_read(c, out.keys.data() + head, ok + head, (tot - head) * 8);
+      if (e == hipSuccess) e = queue_read(c, out.pos.data() + head, op + head, (tot - head) * 8);
+      if (e == hipSuccess) e = queue_read(c, out.counts.data() + head, oc + head, (tot - head) * 4);
+      if (e == hipSuccess) e = ctx_sync(c);
+    }
   }
   cleanup();
   return e == hipSuccess ? RFX_OK : hip_fail(e, "unique_run");

@@ -1,6 +1,8 @@
 // Host-only half of the C-ABI: jellyfish hash matrix, read packing, hash-list loader, .Jhash header.
 // No device code here; everything is callable on a machine without a GPU.
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
@@ -81,15 +83,6 @@ bool pseudo_inverse(std::vector<uint64_t> piv, int r, int c, std::vector<uint64_
   return true;
 }
 
-inline int jf_code(unsigned char ch) {
-  switch (ch) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: return -1;
-  }
-}
 
 // Util::Split (src/Util.cpp:24-33): std::getline tokens, no trailing empty token.
 std::vector<std::string> split(const std::string& s, char d) {
@@ -203,6 +196,66 @@ uint64_t rfx_pack_words(const uint64_t* off, uint32_t n_reads) {
   return w;
 }
 
+namespace {
+
+// Per character: jellyfish code (either case), "is ACGT/acgt", RUFUS code (upper case only, src/Util.cpp:51-84),
+// and "lower-case c/g/t" (where the two encodings disagree).
+struct PackLut {
+  uint8_t jcode[256], jvalid[256], fcode[256], lower_cgt[256];
+  PackLut() {
+    memset(this, 0, sizeof *this);
+    const char* up = "ACGT";
+    const char* lo = "acgt";
+    for (int i = 0; i < 4; ++i) {
+      jcode[(unsigned char)up[i]] = jcode[(unsigned char)lo[i]] = (uint8_t)i;
+      jvalid[(unsigned char)up[i]] = jvalid[(unsigned char)lo[i]] = 1;
+      fcode[(unsigned char)up[i]] = (uint8_t)i;
+      if (i > 0) lower_cgt[(unsigned char)lo[i]] = 1;
+    }
+  }
+};
+const PackLut g_pack_lut;
+
+// Reads [r0, r1): their word offsets are already in word_off.  Returns RFX_OK or RFX_E_MIXEDCASE.
+int pack_range(const char* seq, const char* qual, const uint64_t* off, uint32_t r0, uint32_t r1, int min_q, bool want_count,
+               bool want_filter, uint64_t* codes, uint32_t* acgt, uint32_t* good, const uint32_t* word_off) {
+  const PackLut& T = g_pack_lut;
+  for (uint32_t r = r0; r < r1; ++r) {
+    const uint64_t b0 = off[r], L = off[r + 1] - off[r];
+    uint64_t w = word_off[r];
+    for (uint64_t i = 0; i < L; i += 32, ++w) {
+      uint64_t cw = 0;
+      uint32_t ma = 0, mg = 0;
+      const uint64_t nb = std::min<uint64_t>(32, L - i);
+      const unsigned char* s = (const unsigned char*)seq + b0 + i;
+      if (!want_filter) {
+        for (uint64_t b = 0; b < nb; ++b) {
+          cw |= (uint64_t)T.jcode[s[b]] << (2 * b);
+          ma |= (uint32_t)T.jvalid[s[b]] << b;
+        }
+      } else {
+        const signed char* q = qual ? (const signed char*)qual + b0 + i : nullptr;
+        for (uint64_t b = 0; b < nb; ++b) {
+          const unsigned char ch = s[b];
+          cw |= (uint64_t)T.fcode[ch] << (2 * b);
+          if (want_count) {
+            if (T.lower_cgt[ch]) return RFX_E_MIXEDCASE;
+            ma |= (uint32_t)T.jvalid[ch] << b;
+          }
+          const int qv = q ? (int)q[b] : 0;
+          mg |= (uint32_t)(!(qv - 33 < min_q || ch == 'N')) << b;  // src/RUFUS.Filter.cpp:205
+        }
+      }
+      codes[w] = cw;
+      if (acgt) acgt[w] = ma;
+      if (good) good[w] = mg;
+    }
+  }
+  return RFX_OK;
+}
+
+}  // namespace
+
 int rfx_pack_reads(const char* seq, const char* qual, const uint64_t* off, uint32_t n_reads, int min_q, int flags,
                    uint64_t* codes, uint32_t* acgt, uint32_t* good, uint32_t* word_off, uint32_t* len) {
   if (!seq || !off || !codes || !word_off || !len) return RFX_E_INVAL;
@@ -210,41 +263,37 @@ int rfx_pack_reads(const char* seq, const char* qual, const uint64_t* off, uint3
   if ((want_count && !acgt) || (want_filter && !good) || (!want_count && !want_filter)) return RFX_E_INVAL;
   uint64_t w = 0;
   for (uint32_t r = 0; r < n_reads; ++r) {
-    const uint64_t b0 = off[r], L = off[r + 1] - off[r];
+    const uint64_t L = off[r + 1] - off[r];
     if (L > 0xFFFFFFFFull || w > 0xFFFFFFFFull) return RFX_E_RANGE;
     word_off[r] = (uint32_t)w;
     len[r] = (uint32_t)L;
-    for (uint64_t i = 0; i < L; i += 32) {
-      uint64_t cw = 0;
-      uint32_t ma = 0, mg = 0;
-      const uint64_t nb = std::min<uint64_t>(32, L - i);
-      for (uint64_t b = 0; b < nb; ++b) {
-        const unsigned char ch = (unsigned char)seq[b0 + i + b];
-        const int jc = jf_code(ch);
-        uint64_t code = 0;
-        if (want_filter) {
-          // src/Util.cpp:51-84: only upper-case ACGT carry bits
-          if (ch == 'C') code = 1;
-          else if (ch == 'G') code = 2;
-          else if (ch == 'T') code = 3;
-          if (want_count && jc > 0 && ch >= 'a') return RFX_E_MIXEDCASE;
-          const int q = qual ? (int)(signed char)qual[b0 + i + b] : 0;
-          if (!(q - 33 < min_q || ch == 'N')) mg |= 1u << b;  // src/RUFUS.Filter.cpp:205
-        } else {
-          code = jc < 0 ? 0 : (uint64_t)jc;
-        }
-        if (want_count && jc >= 0) ma |= 1u << b;
-        cw |= code << (2 * b);
-      }
-      codes[w] = cw;
-      if (acgt) acgt[w] = ma;
-      if (good) good[w] = mg;
-      ++w;
-    }
+    w += (L + 31) / 32;
   }
   if (w > 0xFFFFFFFFull) return RFX_E_RANGE;
   word_off[n_reads] = (uint32_t)w;
-  return RFX_OK;
+  // Packing is a pure per-read map: split the reads into ranges of equal bases over host threads once the
+  // batch is big enough to pay for them (RFX_HOST_THREADS overrides the count; 1 = inline).
+  const uint64_t bases = n_reads ? off[n_reads] - off[0] : 0;
+  unsigned nt = (unsigned)std::min<uint64_t>(bases / (2u << 20), 32);
+  const unsigned hw = std::thread::hardware_concurrency();
+  if (hw && nt > hw) nt = hw;
+  if (const char* ev = getenv("RFX_HOST_THREADS")) nt = (unsigned)atoi(ev);
+  if (nt <= 1 || n_reads < 2 * nt)
+    return pack_range(seq, qual, off, 0, n_reads, min_q, want_count, want_filter, codes, acgt, good, word_off);
+  std::vector<uint32_t> cut(nt + 1, n_reads);
+  cut[0] = 0;
+  for (unsigned t = 1; t < nt; ++t)
+    cut[t] = (uint32_t)(std::lower_bound(off, off + n_reads, off[0] + bases * t / nt) - off);
+  std::atomic<int> err{RFX_OK};
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      const int rc = pack_range(seq, qual, off, cut[t], cut[t + 1], min_q, want_count, want_filter, codes, acgt, good,
+                                word_off);
+      if (rc) err.store(rc);
+    });
+  for (auto& x : th) x.join();
+  return err.load();
 }
 
 long rfx_hashlist_keys(const char* text, size_t n, int k, int single_end, uint64_t* keys_out, size_t cap) {

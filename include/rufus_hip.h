@@ -144,6 +144,12 @@ rfx_table* rfx_count_begin(rfx_ctx*, int k, int canonical, int lsize, uint64_t c
 #define RFX_COUNT_P2L 2
 #define RFX_COUNT_MSP 3
 int rfx_count_set_mode(rfx_table*, int mode);
+/* Shard passes (MSP path only, call before the first add): count only the k-mers whose minimizer bin belongs
+ * to shard `shard` of `n_shards` (<= 256) -- the same cut as the multi-GPU owner ranges.  The shards of a
+ * sample are disjoint and cover it (their records interleave to the full result in (pos,key) order), and
+ * the shard of a k-mer is the same for every sample, so count -> set difference can run shard by shard
+ * when a sample's records do not fit the HBM at once, or on every GPU over all reads without any exchange. */
+int rfx_count_set_shard(rfx_table*, int shard, int n_shards);
 int rfx_count_add(rfx_table*, const rfx_reads*);
 /* Merge pre-aggregated (key,count) pairs (device pointers): owner-side reduce of the multi-GPU
  * exchange, and the rehash path. */

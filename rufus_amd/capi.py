@@ -57,6 +57,7 @@ SIGNATURES = {
     "rfx_count_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "rfx_count_finish_begin": (C.c_void_p, [C.c_void_p, C.c_uint64, C.c_uint64, u64p]),
     "rfx_count_finish_end": (C.c_void_p, [C.c_void_p]),
+    "rfx_count_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "rfx_count_segments": (C.c_int, [C.c_void_p]),
     "rfx_count_segment_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_uint32), u64p]),
@@ -349,6 +350,10 @@ class CountTable:
 
     def add_pairs_dev(self, d_keys: int, d_counts: int, n: int):
         _check(lib().rfx_count_add_pairs_dev(self._h, d_keys, d_counts, n), "rfx_count_add_pairs_dev")
+
+    def set_shard(self, shard: int, n_shards: int):
+        """Count only the k-mers of minimizer shard `shard` of `n_shards` (before the first add)."""
+        _check(lib().rfx_count_set_shard(self._h, shard, n_shards), "rfx_count_set_shard")
 
     def segments(self):
         """[(d_records, d_bin_start, bins, n_records)] of the MSP record segments held (device pointers)."""

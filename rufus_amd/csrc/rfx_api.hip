@@ -808,7 +808,7 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
 // here: it is read with the next synchronisation the table needs anyway (finish), or when the read
 // block is about to be freed -- the redo needs the reads.
 struct msp_geom {
-  uint32_t P, P1, P2;
+  uint32_t P, P1, P2, bin_lo, bin_hi;
   int bin_bits, G;
   size_t ncur;
   uint64_t windows;
@@ -831,6 +831,10 @@ static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   g.bin_bits = ceil_log2(g.P);
   g.G = rfxk::p2l_grid(c, r->n);
   g.ncur = (size_t)g.P1 * rfxk::p1_cur_stride();
+  // shard passes: the same cut as the multi-GPU owner ranges (on the top 8 bits of the bin index)
+  const uint32_t ns = t->n_shards > 1 ? (uint32_t)t->n_shards : 1, sh = t->n_shards > 1 ? (uint32_t)t->shard : 0;
+  g.bin_lo = ((sh * 256 + ns - 1) / ns) * (g.P / 256);
+  g.bin_hi = (((sh + 1) * 256 + ns - 1) / ns) * (g.P / 256);
   return true;
 }
 
@@ -857,7 +861,7 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   auto drop = [&] { dfree(c, cnt); dfree(c, gsum); dfree(c, fine_cur); dfree(c, cur); dfree(c, buf_a); };
   auto fail = [&](int rc) { drop(); dfree(c, bin_start); dfree(c, inst); return rc; };
   if (!cnt || !gsum || !bin_start || !fine_cur || !cur) return fail(RFX_E_NOMEM);
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 1, g.G, nullptr, nullptr, 0, cnt, nullptr);
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 1, g.G, nullptr, nullptr, 0, cnt, nullptr);
   rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
   std::vector<uint64_t> bs((size_t)P + 1);
   if (queue_read(c, bs.data(), bin_start, ((size_t)P + 1) * 8) != hipSuccess || ctx_sync(c) != hipSuccess)
@@ -871,7 +875,7 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   if (!buf_a || !inst) return fail(RFX_E_NOMEM);
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1) * 4, c->stream));
   HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 2, g.G, buf_a, cur, (uint32_t)cap_a, nullptr, cur + g.ncur);
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a, cur, (uint32_t)cap_a, nullptr, cur + g.ncur);
   rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
   unsigned int flag = 1;
   if (queue_read(c, &flag, cur + g.ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) return fail(RFX_E_HIP);
@@ -918,7 +922,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
     return RFX_E_NOMEM;
   }
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 0, g.G, buf_a, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
   rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
   rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
   rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
@@ -1316,8 +1320,25 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   }
 }
 
+int rfx_count_set_shard(rfx_table* t, int shard, int n_shards) {
+  if (!t || n_shards < 1 || n_shards > 256 || shard < 0 || shard >= n_shards) return RFX_E_INVAL;
+  if (!t->segs->empty() || t->table_active) {
+    snprintf(g_err, sizeof g_err, "rfx_count_set_shard: set the shard before the first rfx_count_add");
+    return RFX_E_INVAL;
+  }
+  if (n_shards > 1 && (!rfxk::msp_k_ok(t->k) || !t->lut_t)) {
+    snprintf(g_err, sizeof g_err, "rfx_count_set_shard: minimizer shards need the MSP path (23 <= k <= 25)");
+    return RFX_E_INVAL;
+  }
+  t->shard = shard;
+  t->n_shards = n_shards;
+  if (n_shards > 1) t->mode = RFX_COUNT_MSP;
+  return RFX_OK;
+}
+
 int rfx_count_set_mode(rfx_table* t, int mode) {
   if (!t || mode < RFX_COUNT_AUTO || mode > RFX_COUNT_MSP) return RFX_E_INVAL;
+  if (t->n_shards > 1 && mode != RFX_COUNT_MSP) return RFX_E_INVAL;  // a shard is a set of minimizer bins
   t->mode = mode;
   return RFX_OK;
 }

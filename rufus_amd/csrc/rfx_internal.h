@@ -158,6 +158,7 @@ struct rfx_table {
   uint32_t p2l_bins;  // 0 until the first P2L / MSP add
   int seg_kind;       // what the segments hold: 0 nothing yet, RFX_COUNT_P2L words, RFX_COUNT_MSP records
   std::vector<rfx_pending_add>* pend;
+  int shard, n_shards;  // n_shards > 1: keep only the minimizer bins of this shard (rfx_count_set_shard)
   int pend_error;     // a deferred redo failed: the table cannot be finished
   std::vector<rfx_segment>* segs;
   uint64_t* lut_t;     // device LUT of T (key -> sortable word), null when M is rank deficient
@@ -260,8 +261,9 @@ void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fin
            const uint64_t* coarse_start = nullptr /* n_coarse+1 explicit coarse extents */, uint32_t n_coarse = 0);
 // MSP path (rfx_msp.hip)
 int msp_k_ok(int k);
-void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bits, int hmode, int grid,
-               uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows, unsigned int* flag);
+void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
+               int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
+               unsigned int* flag);
 void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,

@@ -44,8 +44,8 @@ __device__ __forceinline__ uint32_t msp_bin(uint32_t minh, int bin_bits) {
 //       1: 32-bit fine histogram only            } the exact redo after HMODE 0 raised its flag;
 //       2: scatter only                          } cap_a then comes from the cursors of the failed run
 template <bool CANON, int HMODE>
-__global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k, int bin_bits,
-                                                         uint64_t* __restrict__ buf_a,
+__global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k, int bin_bits, uint32_t bin_lo,
+                                                         uint32_t bin_hi, uint64_t* __restrict__ buf_a,
                                                          uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
                                                          uint32_t* __restrict__ cnt_rows,
                                                          unsigned int* __restrict__ flag) {
@@ -122,15 +122,16 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
           if (run_n && (!kvalid || mh != run_h || run_n == MSP_NMAX)) {
             // close the run that ended at the previous base: `hist` still ends there
             const uint32_t run_bin = msp_bin(run_h, bin_bits);
-            if (HMODE != 1) {
+            const bool mine = run_bin >= bin_lo && run_bin < bin_hi;  // shard passes: other bins are not ours
+            if (HMODE != 1 && mine) {
               const int L = k + run_n - 1;
               const uint32_t coarse = run_bin >> sub_bits;
               wv[b] = (hist & ((1ull << (2 * L)) - 1)) | ((uint64_t)(run_n - 1) << 56) |
                       ((uint64_t)(run_bin & ((1u << sub_bits) - 1)) << 58);
               br[b] = (coarse << 16) | atomicAdd(&s_cnt[coarse], 1u);
             }
-            if (HMODE == 0) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
-            if (HMODE == 1) atomicAdd(&s_fine[run_bin], 1u);
+            if (HMODE == 0 && mine) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
+            if (HMODE == 1 && mine) atomicAdd(&s_fine[run_bin], 1u);
             run_n = 0;
           }
           if (kvalid) {
@@ -623,12 +624,13 @@ namespace rfxk {
 
 int msp_k_ok(int k) { return k >= 23 && k <= 25; }  // m = k-14 in 9..11; k+3 bases fit 56 bits
 
-void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, int hmode, int grid,
-               uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows, unsigned int* flag) {
+void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
+               int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
+               unsigned int* flag) {
   rfx_span sp(c, hmode == 1 ? "k_msp_count" : "k_msp_part1");
 #define RFX_MSP_P1(CANON, HM)                                                                                      \
-  hipLaunchKernelGGL((k_msp_part1<CANON, HM>), dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, k, bin_bits, buf_a, \
-                     coarse_cur, cap_a, cnt_rows, flag)
+  hipLaunchKernelGGL((k_msp_part1<CANON, HM>), dim3(grid), dim3(P2_BLOCK), 0, c->stream, rv, k, bin_bits, bin_lo, \
+                     bin_hi, buf_a, coarse_cur, cap_a, cnt_rows, flag)
   if (canonical) {
     if (hmode == 0) RFX_MSP_P1(true, 0);
     else if (hmode == 1) RFX_MSP_P1(true, 1);

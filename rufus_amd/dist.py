@@ -79,9 +79,12 @@ class HipBackend:
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
 
     # -- single-rank path -------------------------------------------------------------------------
-    def local_count(self, block, lower: int):
+    def local_count(self, block, lower: int, shard=None):
+        """shard = (s, S): only the k-mers of minimizer shard s of S (a pass over a sample too big for HBM)."""
         t = capi.CountTable(self.ctx, self.k, self.size, True, self.capacity)
         try:
+            if shard is not None:
+                t.set_shard(*shard)
             t.add(block)
             return t.finish(lower, want_histo=True)
         finally:
@@ -330,7 +333,7 @@ class TrioShard:
     """One rank's share of: count x (1 subject + controls) -> histogram -> hash list -> filter."""
 
     def __init__(self, ctx_or_backend, k: int, size: int, lower: int, min_cov: int, max_cov: int, thresh: int,
-                 capacity: int = 0, group=None, shard_by: str | None = None):
+                 capacity: int = 0, group=None, shard_by: str | None = None, passes: int = 1):
         self.be = ctx_or_backend if hasattr(ctx_or_backend, "local_count") else HipBackend(ctx_or_backend, k, size,
                                                                                            capacity)
         self.k, self.lsize = k, capi.ceil_log2(size)
@@ -338,6 +341,7 @@ class TrioShard:
         self.group = group
         self.world = dist.get_world_size(group) if group is not None else 1
         self.rank = dist.get_rank(group) if group is not None else 0
+        self.passes = passes   # single rank: minimizer-shard passes over the samples (bounded HBM footprint)
         capable = getattr(self.be, "msp_capable", lambda: False)()
         self.shard_by = shard_by or ("minimizer" if capable else "pos")   # what a rank's records are a shard of
         if self.shard_by == "minimizer" and not capable:
@@ -361,9 +365,33 @@ class TrioShard:
         dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
         return rec, h.cpu().numpy().astype(np.uint64)
 
+    def _run_in_passes(self, blocks):
+        """Single rank, S passes: pass s counts minimizer shard s of every sample and takes the set
+        difference on it (the shard of a k-mer is the same in every sample); only one shard of each
+        sample is ever resident.  Returns (mutant keys in (pos,key) order, histograms, record counts)."""
+        keys, histos, n_rec = [], None, np.zeros(len(blocks), dtype=np.int64)
+        for sh in range(self.passes):
+            recs, hs = zip(*[self.be.local_count(blk, self.lower, shard=(sh, self.passes)) for blk in blocks])
+            k_, _ = self.be.unique(recs[0], recs[1:], self.min_cov, self.max_cov)
+            keys.append(k_)
+            histos = [a + b for a, b in zip(histos, hs)] if histos else list(hs)
+            n_rec += [self.be.n_records(r) for r in recs]
+            for r in recs:
+                self.be.free(r)
+        keys = np.concatenate(keys)
+        if len(keys):
+            keys = keys[np.lexsort((keys, self.be.pos_of(keys)))]
+        return keys, histos, n_rec.tolist()
+
     def run(self, subject_block, control_blocks, keep_records: bool = False):
         recs, histos = [], []
         blocks = [subject_block] + list(control_blocks)
+        if self.world == 1 and self.passes > 1:
+            keys, histos, n_rec = self._run_in_passes(blocks)
+            res = self.be.filter_pairs(keys, subject_block, self.thresh)
+            n_pulled, pulled_fn = res if isinstance(res, tuple) else (int(res.sum()), (lambda: res))
+            return _ShardResult({"n_mutant": len(keys), "n_pulled": n_pulled, "n_records": n_rec, "histos": histos,
+                                 "mutant_keys": keys, "_pulled_fn": pulled_fn})
         if self.world > 1 and self.shard_by == "minimizer":
             # The record all-to-all of a sample travels (RCCL on its own stream) while the next sample is
             # being partitioned and the previous one counted; histograms are reduced once, at the end.

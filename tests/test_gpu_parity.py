@@ -415,6 +415,61 @@ def test_three_count_paths_agree_on_random_configurations(ctx, seed, monkeypatch
         t.free()
 
 
+@pytest.mark.parametrize("n_shards", [2, 3, 7])
+def test_msp_shard_passes_partition_the_count(ctx, small_trio, n_shards):
+    """rfx_count_set_shard: every pass counts only the k-mers of its minimizer bins; the passes are
+    disjoint, interleave to the full count, and cut the key space like the multi-GPU owner ranges."""
+    from rufus_amd import dist as rdist
+    k, size = 25, 1 << 28
+    reads = [r for m in (1, 2) for r in tools.parse_sequences(fastq_bytes(small_trio["child"], m))]
+    ref = oracle.count(None, k, size, lower=2, reads=reads)
+    blk = ctx.upload(capi.PackedReads.from_reads(reads))
+    shards, hsum = [], np.zeros(capi.HISTO_BINS, dtype=np.uint64)
+    for sh in range(n_shards):
+        t = capi.CountTable(ctx, k, size)
+        t.set_shard(sh, n_shards)
+        t.add(blk)
+        (d_rec, d_bs, nb, nrec), = t.segments()
+        assert nb >= 256 and nrec > 0
+        rec, h = t.finish(2, want_histo=True)
+        shards.append(tuple(x.astype(np.uint64) for x in rec.get()))
+        hsum += h
+        rec.free()
+        t.free()
+    assert all(len(s_[0]) for s_ in shards)
+    keys, counts, pos = rdist.merge_shards(shards)
+    assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts) and np.array_equal(pos, ref.pos)
+    assert sum(len(s_[0]) for s_ in shards) == len(ref.keys)          # disjoint
+    assert np.array_equal(hsum, oracle.histo(ref.counts, full=True)[0])
+    t = capi.CountTable(ctx, 31, size)
+    with pytest.raises(capi.RufusError):
+        t.set_shard(0, 2)                                             # no minimizer bins outside the MSP path
+    t.free()
+    blk.free()
+
+
+def test_trio_in_shard_passes_equals_one_pass(ctx, small_trio):
+    """The whole hot path (count x3 -> set difference -> filter) in 4 minimizer-shard passes gives the
+    mutant k-mers, histograms, record counts and pulled pairs of the single-pass run."""
+    from rufus_amd import dist as rdist
+    from tests.synth import flat_reads
+    blocks = {}
+    for n in ("child", "mother", "father"):
+        seq, qual, off = flat_reads(small_trio[n])
+        blocks[n] = ctx.upload(capi.PackedReads(seq, off, qual, 15, capi.PACK_COUNT | capi.PACK_FILTER))
+    out = []
+    for passes in (1, 4):
+        shard = rdist.TrioShard(ctx, 25, 8 << 30, 2, 5, 1200, 1, passes=passes)
+        out.append(shard.run(blocks["child"], [blocks["mother"], blocks["father"]]))
+    a, b = out
+    assert len(a["mutant_keys"]) > 0 and np.array_equal(a["mutant_keys"], b["mutant_keys"])
+    assert a["n_records"] == b["n_records"] and a["n_pulled"] == b["n_pulled"] > 0
+    assert all(np.array_equal(x, y) for x, y in zip(a["histos"], b["histos"]))
+    assert np.array_equal(a["pulled"], b["pulled"])
+    for x in blocks.values():
+        x.free()
+
+
 def test_msp_record_segments_export_and_import(ctx, small_trio, monkeypatch):
     """The multi-GPU building blocks on one GPU: the record segments of two tables (different bin counts)
     are exported, split at an owner boundary, imported into two fresh tables and finished -- each result

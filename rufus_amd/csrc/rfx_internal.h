@@ -267,7 +267,8 @@ void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bi
 void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
-              uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err);
+              uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err,
+              int geo /* 0: 1024 threads + 8192 slots, 1: 512 + 4096 (two per CU) */);
 // refinement of a record partition from 2^from_bits to 2^to_bits bins: writes each record's slice (the
 // next to_bits-from_bits bits of its minimizer hash) into the record's sub-bin field and counts the new bins
 void slice_tag(rfx_ctx*, uint64_t* inst, const uint64_t* bin_start, int k, int canonical, int from_bits, int to_bits,

@@ -257,26 +257,27 @@ __global__ __launch_bounds__(256) void k_slice_tag(uint64_t* __restrict__ inst, 
 }
 
 constexpr int MSP_ILP = 8;
-constexpr int MSP_RC_LOG2 = 12;
-constexpr int MSP_RC = 1 << MSP_RC_LOG2;  // record cache slots (aliases the survivor list)
-constexpr int MSP_RC_PROBES = 8;
-constexpr int MSP_LIST = 4096;  // dense survivor list of k_msp_leaf (flushed when two more scan rounds might not fit)
+constexpr int MSP_RC_PROBES = 8;  // a record that finds no cache slot within this many probes bypasses the cache
 
 // One workgroup per fine minimizer bin.  A bin (or part of it) whose distinct k-mers overflow the LDS
 // table is split in two by a hash bit and each half retried -- results already appended stay valid.
-template <bool CANON>
-__global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
+// GEO 0: one 1024-thread workgroup per CU (8192-slot table, 4096-slot record cache);
+// GEO 1: half of everything, two workgroups per CU -- for bins of ~8 K instances.
+template <bool CANON, int GEO>
+__global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     const uint64_t* const* __restrict__ seg_inst, const uint64_t* const* __restrict__ seg_bs, int nseg,
     const uint64_t* __restrict__ inst0, const uint64_t* __restrict__ bs0, uint32_t P, int k,
     const uint64_t* __restrict__ g_lut, int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi,
     uint64_t lower, uint64_t upper, uint64_t* __restrict__ out_w, uint32_t* __restrict__ out_c,
     uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err) {
-  __shared__ __attribute__((aligned(16))) unsigned long long s_keys[LEAF_TBL];
-  __shared__ uint32_t s_cnt[LEAF_TBL];
+  constexpr int TBL_LOG2 = GEO ? 12 : 13, TBL = 1 << TBL_LOG2, BLK = GEO ? 512 : 1024, FILL = TBL * 3 / 4;
+  constexpr int RC_LOG2 = TBL_LOG2 - 1, RC = 1 << RC_LOG2, LIST = RC;
+  __shared__ __attribute__((aligned(16))) unsigned long long s_keys[TBL];
+  __shared__ uint32_t s_cnt[TBL];
   __shared__ uint32_t s_pc[P1_BINS];
   __shared__ uint64_t s_pbase[P1_BINS];
-  __shared__ uint64_t s_lk[MSP_LIST];
-  __shared__ uint32_t s_lc[MSP_LIST];
+  __shared__ uint64_t s_lk[LIST];
+  __shared__ uint32_t s_lc[LIST];
   __shared__ uint32_t s_nd, s_ovf, s_nl;
   unsigned long long* s_rk = (unsigned long long*)s_lk;  // the record cache lives in the (then idle) survivor list
   uint32_t* s_rc = s_lc;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
     pre_e = bs0[b + 1];
 #pragma unroll
     for (int u = 0; u < MSP_ILP; ++u) {
-      const uint64_t i = pre_a + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
+      const uint64_t i = pre_a + threadIdx.x + (uint64_t)u * BLK;
       pre[u] = i < pre_e ? inst0[i] : MSP_EMPTY;
     }
   };
@@ -304,11 +305,11 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
     uint32_t j = 0;
     bool failed = false;
     for (;;) {
-      for (int i = threadIdx.x; i < LEAF_TBL; i += LEAF_BLOCK) {
+      for (int i = threadIdx.x; i < TBL; i += BLK) {
         s_keys[i] = RFX_EMPTY;
         s_cnt[i] = 0;
       }
-      for (int i = threadIdx.x; i < MSP_RC; i += LEAF_BLOCK) {
+      for (int i = threadIdx.x; i < RC; i += BLK) {
         s_rk[i] = MSP_EMPTY;
         s_rc[i] = 0;
       }
@@ -334,13 +335,13 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
         // The probe is ONE returning CAS: it yields "was empty, now mine", "already mine" or "someone
         // else's" without a separate read-and-branch for the new-key case.  New keys are only counted
         // (no returned ticket: one wave-aggregated LDS add); the count is looked at before every
-        // insert, so at most one key per thread can follow LEAF_FILL, which the LEAF_TBL - LEAF_FILL
+        // insert, so at most one key per thread can follow FILL, which the TBL - FILL
         // spare slots absorb -- probing always terminates.  A skipped insert voids the pass.
-        if (__hip_atomic_load(&s_nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)LEAF_FILL) {
+        if (__hip_atomic_load(&s_nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)FILL) {
           s_ovf = 1;
           return;
         }
-        uint32_t slot = leaf_hash(key);
+        uint32_t slot = leaf_hash(key) >> (LEAF_TBL_LOG2 - TBL_LOG2);
         for (;;) {
           unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
           if (old == RFX_EMPTY) {
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
             atomicAdd(&s_cnt[slot], mult);
             break;
           }
-          slot = (slot + 1) & (LEAF_TBL - 1);
+          slot = (slot + 1) & (TBL - 1);
         }
       };
       auto insert_record = [&](uint64_t x, uint32_t mult) {
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
       for (int sg = 0; sg < nseg; ++sg) {
         const uint64_t a = sg == 0 ? a0 : seg_bs[sg][bin], e = sg == 0 ? e0 : seg_bs[sg][bin + 1];
         const uint64_t* __restrict__ src = sg == 0 ? inst0 : seg_inst[sg];
-        for (uint64_t base = a; base < e; base += (uint64_t)MSP_ILP * LEAF_BLOCK) {
+        for (uint64_t base = a; base < e; base += (uint64_t)MSP_ILP * BLK) {
           uint64_t rec[MSP_ILP];
           if (sg == 0 && base == a && !prefetched_next) {
 #pragma unroll
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
           } else {
 #pragma unroll
             for (int u = 0; u < MSP_ILP; ++u) {
-              const uint64_t i = base + threadIdx.x + (uint64_t)u * LEAF_BLOCK;
+              const uint64_t i = base + threadIdx.x + (uint64_t)u * BLK;
               rec[u] = i < e ? src[i] : MSP_EMPTY;
             }
           }
@@ -382,7 +383,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
             const uint64_t x = rec[u];
             if (x == MSP_EMPTY) continue;
             uint32_t h = (uint32_t)x ^ (uint32_t)(x >> 23) ^ (uint32_t)(x >> 41);
-            h = (h * 0x9E3779B1u) >> (32 - MSP_RC_LOG2);
+            h = (h * 0x9E3779B1u) >> (32 - RC_LOG2);
             bool cached = false;
             for (int p = 0; p < MSP_RC_PROBES; ++p) {
               const unsigned long long old = atomicCAS(&s_rk[h], (unsigned long long)MSP_EMPTY, (unsigned long long)x);
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
                 cached = true;
                 break;
               }
-              h = (h + 1) & (MSP_RC - 1);
+              h = (h + 1) & (RC - 1);
             }
             if (!cached) insert_record(x, 1u);
           }
@@ -403,16 +404,16 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
       }
       __syncthreads();
       {  // Phase B: pack the cache (in place, through registers), then one dense pass over the distinct records
-        uint64_t ex[MSP_RC / LEAF_BLOCK];
-        uint32_t ec[MSP_RC / LEAF_BLOCK];
+        uint64_t ex[RC / BLK];
+        uint32_t ec[RC / BLK];
 #pragma unroll
-        for (int h = 0; h < MSP_RC / LEAF_BLOCK; ++h) {
-          ex[h] = s_rk[h * LEAF_BLOCK + threadIdx.x];
-          ec[h] = s_rc[h * LEAF_BLOCK + threadIdx.x];
+        for (int h = 0; h < RC / BLK; ++h) {
+          ex[h] = s_rk[h * BLK + threadIdx.x];
+          ec[h] = s_rc[h * BLK + threadIdx.x];
         }
         __syncthreads();
 #pragma unroll
-        for (int h = 0; h < MSP_RC / LEAF_BLOCK; ++h)
+        for (int h = 0; h < RC / BLK; ++h)
           if (ex[h] != MSP_EMPTY) {
             const uint32_t o = atomicAdd(&s_nl, 1u);
             s_rk[o] = ex[h];
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
         const uint32_t nrec = s_nl;
         // one k-mer per thread: four times the parallelism of one record per thread, and the table
         // round trips of a record's k-mers overlap instead of queueing in one lane
-        for (uint32_t i = threadIdx.x; i < MSP_NMAX * nrec; i += LEAF_BLOCK)
+        for (uint32_t i = threadIdx.x; i < MSP_NMAX * nrec; i += BLK)
           insert_kmer(s_rk[i >> 2], (int)(i & 3u), s_rc[i >> 2]);
         __syncthreads();
         if (threadIdx.x == 0) s_nl = 0;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
         auto flush = [&]() {
           __syncthreads();
           const uint32_t nl = s_nl;
-          for (uint32_t i = threadIdx.x; i < nl; i += LEAF_BLOCK) {
+          for (uint32_t i = threadIdx.x; i < nl; i += BLK) {
             uint64_t w = gf2_mul(g_lut, s_lk[i], ntab);  // 14 KB table, L1-resident; only survivors get here
             const uint64_t pos = w >> sel_bits;
             if (pos >= pos_lo && pos < pos_hi) atomicAdd(&s_pc[(uint32_t)(w >> shift1)], 1u);
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
             s_pc[threadIdx.x] = 0;
           }
           __syncthreads();
-          for (uint32_t i = threadIdx.x; i < nl; i += LEAF_BLOCK) {
+          for (uint32_t i = threadIdx.x; i < nl; i += BLK) {
             const uint64_t w = s_lk[i];
             if (w == RFX_EMPTY) continue;
             const uint32_t cb = (uint32_t)(w >> shift1);
@@ -471,10 +472,10 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
           if (threadIdx.x == 0) s_nl = 0;
           __syncthreads();
         };
-        for (int base = 0; base < LEAF_TBL; base += 2 * LEAF_BLOCK) {
+        for (int base = 0; base < TBL; base += 2 * BLK) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            const int i = base + h * LEAF_BLOCK + threadIdx.x;
+            const int i = base + h * BLK + threadIdx.x;
             const uint64_t key = s_keys[i];
             const uint32_t c = s_cnt[i];
             if (key != RFX_EMPTY && c >= lower && c <= upper) {
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_msp_leaf(
             }
           }
           __syncthreads();
-          if (s_nl > MSP_LIST - 2 * LEAF_BLOCK) flush();  // the next two rounds might not fit
+          if (s_nl > LIST - 2 * BLK) flush();  // the next two rounds might not fit
         }
         flush();
       }
@@ -646,17 +647,23 @@ void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int b
 void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
-              uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err) {
+              uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err,
+              int geo) {
   rfx_span sp(c, "k_msp_leaf");
-  const uint32_t grid = P < (uint32_t)c->n_cu * 4 ? P : (uint32_t)c->n_cu * 4;
-  if (canonical)
-    hipLaunchKernelGGL(k_msp_leaf<true>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0,
-                       P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w, out_c, cur, cap, flag,
-                       err);
-  else
-    hipLaunchKernelGGL(k_msp_leaf<false>, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0,
-                       bs0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w, out_c, cur, cap,
-                       flag, err);
+  const uint32_t per_cu = geo ? 8 : 4;
+  const uint32_t grid = P < (uint32_t)c->n_cu * per_cu ? P : (uint32_t)c->n_cu * per_cu;
+#define RFX_MSP_LEAF(CANON, GEO)                                                                                     \
+  hipLaunchKernelGGL((k_msp_leaf<CANON, GEO>), dim3(grid), dim3(GEO ? 512 : 1024), 0, c->stream, seg_inst, seg_bs, nseg, \
+                     inst0, bs0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w, out_c, cur,  \
+                     cap, flag, err)
+  if (canonical) {
+    if (geo) RFX_MSP_LEAF(true, 1);
+    else RFX_MSP_LEAF(true, 0);
+  } else {
+    if (geo) RFX_MSP_LEAF(false, 1);
+    else RFX_MSP_LEAF(false, 0);
+  }
+#undef RFX_MSP_LEAF
 }
 
 void slice_tag(rfx_ctx* c, uint64_t* inst, const uint64_t* bin_start, int k, int canonical, int from_bits, int to_bits,

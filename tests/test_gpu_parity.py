@@ -387,6 +387,12 @@ def test_three_count_paths_agree_on_random_configurations(ctx, seed, monkeypatch
     lower = int(rng.choice([0, 1, 2, 3]))
     upper = [2**64 - 1, 2**64 - 1, 40][int(rng.integers(0, 3))]   # (rng.choice would round 2^64-1 to a float)
     monkeypatch.setenv("RFX_P2L_BINS", str(int(rng.choice([256, 512, 4096, 8192]))))
+    if rng.random() < 0.4:     # MSP: force a refinement of the partition (one or two steps)
+        monkeypatch.setenv("RFX_MSP_REFINE_BITS", str(int(rng.integers(9, 18))))
+    if rng.random() < 0.5:     # MSP: leaf geometry
+        monkeypatch.setenv("RFX_MSP_GEO", str(int(rng.integers(0, 2))))
+    if rng.random() < 0.2:     # exact two-pass sizing instead of the optimistic one
+        monkeypatch.setenv("RFX_P2L_EXACT", "1")
     genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(2000, 60000)))]
     seqs = []
     for _ in range(int(rng.integers(500, 6000))):

@@ -1142,7 +1142,8 @@ static int msp_emit_queue(rfx_finish* f) {
   if (f->histo) rfxk::histo_bins(c, f->ac, cur, (uint32_t)cap, d_histo);  // count-of-counts of exactly the survivors
   rfxk::surv_hist(c, f->aw, cur, (uint32_t)cap, P2q, cfg.bin_shift, bsq);
   rfxk::scan_tail(c, bsq, Pq);
-  rfxk::part2(c, f->aw, f->bw, bsq, fcur, P2q, cfg.bin_shift, cur, (uint32_t)cap, f->ac, f->bc, ~0ull, "k_surv_part2");
+  rfxk::part2(c, f->aw, f->bw, bsq, fcur, P2q, cfg.bin_shift, cur, (uint32_t)cap, f->ac, f->bc, ~0ull, "k_surv_part2",
+              nullptr, 0, room);
   // every survivor is kept and fine bins are exact, so the sort writes the records in place
   rfxk::surv_sort(c, f->bw, f->bc, bsq, Pq, cfg.bin_shift, t->lut_tinv, t->ntab, cfg.sel_bits, f->big->keys,
                   f->big->counts, f->big->pos);

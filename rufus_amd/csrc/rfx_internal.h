@@ -258,7 +258,8 @@ void part1_fused(rfx_ctx*, const rfx_reads_view&, const uint64_t* lut, int ntab,
 void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur,
            uint32_t P2, int shift2, const uint32_t* coarse_cur, uint32_t cap_a, const uint32_t* pay_a,
            uint32_t* pay_b, uint64_t cap_b /* entries buf_b can hold */, const char* span,
-           const uint64_t* coarse_start = nullptr /* n_coarse+1 explicit coarse extents */, uint32_t n_coarse = 0);
+           const uint64_t* coarse_start = nullptr /* n_coarse+1 explicit coarse extents */, uint32_t n_coarse = 0,
+           uint64_t n_hint = 0 /* expected entries: sizes the grid of a small run */);
 // MSP path (rfx_msp.hip)
 int msp_k_ok(int k);
 void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,

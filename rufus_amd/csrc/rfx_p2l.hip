@@ -740,11 +740,17 @@ void part1_fused(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int 
 
 void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur,
            uint32_t P2, int shift2, const uint32_t* coarse_cur, uint32_t cap_a, const uint32_t* pay_a,
-           uint32_t* pay_b, uint64_t cap_b, const char* span, const uint64_t* coarse_start, uint32_t n_coarse) {
+           uint32_t* pay_b, uint64_t cap_b, const char* span, const uint64_t* coarse_start, uint32_t n_coarse,
+           uint64_t n_hint) {
   rfx_span sp(c, span);
-  // 128 coarse bins: 16 workgroups share one; thousands (refinement): one each
+  // 128 coarse bins: up to 16 workgroups share one (two 8192-entry tiles each when the input is small);
+  // thousands (refinement): one each
   const uint32_t nc = coarse_start ? n_coarse : (uint32_t)P1_BINS;
-  const uint32_t W = nc >= 2048 ? 1 : 16;
+  uint32_t W = nc >= 2048 ? 1 : 16;
+  if (n_hint && nc < 2048) {
+    const uint64_t w = (n_hint / nc + 2 * L2_TILE - 1) / (2 * L2_TILE);
+    W = (uint32_t)(w < 1 ? 1 : w > 16 ? 16 : w);
+  }
   if (pay_a)
     hipLaunchKernelGGL(k_part2<true>, dim3(nc * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start, fine_cur,
                        P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b, coarse_start);

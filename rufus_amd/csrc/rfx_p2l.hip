@@ -746,7 +746,8 @@ void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* f
   // 128 coarse bins: up to 16 workgroups share one (two 8192-entry tiles each when the input is small);
   // thousands (refinement): one each
   const uint32_t nc = coarse_start ? n_coarse : (uint32_t)P1_BINS;
-  uint32_t W = nc >= 2048 ? 1 : 16;
+  // as many workgroups as are resident at once (two per CU): each loops over its share of the tiles
+  uint32_t W = nc >= 2048 ? 1 : std::max(1u, (uint32_t)c->n_cu * 2 / nc);
   if (n_hint && nc < 2048) {
     const uint64_t w = (n_hint / nc + 2 * L2_TILE - 1) / (2 * L2_TILE);
     W = (uint32_t)(w < 1 ? 1 : w > 16 ? 16 : w);

@@ -13,20 +13,41 @@
 
 using namespace rfxcli;
 
-struct Rec {
-  std::string l[4];
-};
-
-static bool read_rec(LineReader& in, Rec& r) {
-  const char *b, *e;
-  if (!in.getline(b, e)) return false;
-  r.l[0].assign(b, e);
-  for (int i = 1; i < 4; ++i) {
-    if (in.getline(b, e)) r.l[i].assign(b, e);
-    else r.l[i].clear();
+// The 4 lines of every record of a batch, back to back in one arena (no per-line allocations: a batch is
+// half a million records).  Line j of record i is text[off[4i+j] .. off[4i+j+1]).
+struct RecBatch {
+  std::string text;
+  std::vector<uint64_t> off{0};
+  void clear() {
+    text.clear();
+    off.assign(1, 0);
   }
-  return true;
-}
+  size_t n() const { return (off.size() - 1) / 4; }
+  const char* line(size_t i, int j) const { return text.data() + off[4 * i + (size_t)j]; }
+  size_t len(size_t i, int j) const { return (size_t)(off[4 * i + (size_t)j + 1] - off[4 * i + (size_t)j]); }
+  // Appends one record; false at end of input.  Missing trailing lines read as empty (the reference's
+  // getline leaves the previous/empty string there; an incomplete last record is garbage in both).
+  bool read(LineReader& in) {
+    const char *b, *e;
+    if (!in.getline(b, e)) return false;
+    text.append(b, e);
+    off.push_back(text.size());
+    for (int j = 1; j < 4; ++j) {
+      if (in.getline(b, e)) text.append(b, e);
+      off.push_back(text.size());
+    }
+    return true;
+  }
+  void write(std::ostream& os, size_t i, const char* header_suffix = nullptr) const {
+    os.write(line(i, 0), (std::streamsize)len(i, 0));
+    if (header_suffix) os << header_suffix;
+    os.put('\n');
+    for (int j = 1; j < 4; ++j) {
+      os.write(line(i, j), (std::streamsize)len(i, j));
+      os.put('\n');
+    }
+  }
+};
 
 int main(int argc, char** argv) {
 #ifdef RFX_SINGLE_END
@@ -97,8 +118,7 @@ int main(int argc, char** argv) {
   if (!set) die(std::string("rufus_amd: ") + rfx_last_error());
 
   const size_t BATCH = 1u << 19;
-  std::vector<Rec> r1, r2;
-  r1.reserve(BATCH);
+  RecBatch r1, r2;
   ReadBatch b1, b2;
   PackedBatch p;
   std::vector<uint64_t> mask1, mask2;
@@ -110,23 +130,22 @@ int main(int argc, char** argv) {
     r2.clear();
     b1.clear();
     b2.clear();
-    while (r1.size() < BATCH) {
-      Rec a1;
-      if (!read_rec(in1, a1)) {
+    while (r1.n() < BATCH) {
+      if (!r1.read(in1)) {
         more = false;
         break;
       }
-      if (a1.l[1].empty()) die("rufus_amd RUFUS.Filter: empty sequence line (undefined behaviour in the reference) -- rejected");
-      b1.add(a1.l[1].data(), a1.l[1].size(), a1.l[3].data(), a1.l[3].size(), true);
-      r1.push_back(std::move(a1));
+      const size_t i = r1.n() - 1;
+      if (r1.len(i, 1) == 0) die("rufus_amd RUFUS.Filter: empty sequence line (undefined behaviour in the reference) -- rejected");
+      b1.add(r1.line(i, 1), r1.len(i, 1), r1.line(i, 3), r1.len(i, 3), true);
 #ifndef RFX_SINGLE_END
-      Rec a2;
-      read_rec(in2, a2);  // lock step: exactly one record of mate 2 per record of mate 1
-      b2.add(a2.l[1].data(), a2.l[1].size(), a2.l[3].data(), a2.l[3].size(), true);
-      r2.push_back(std::move(a2));
+      if (!r2.read(in2)) {  // lock step: exactly one record of mate 2 per record of mate 1
+        r2.off.insert(r2.off.end(), 4, r2.text.size());
+      }
+      b2.add(r2.line(i, 1), r2.len(i, 1), r2.line(i, 3), r2.len(i, 3), true);
 #endif
     }
-    const uint32_t n = (uint32_t)r1.size();
+    const uint32_t n = (uint32_t)r1.n();
     if (n == 0) break;
     total += n;
     auto scan = [&](ReadBatch& b, std::vector<uint64_t>& mask, std::vector<uint32_t>* h) {
@@ -145,7 +164,8 @@ int main(int argc, char** argv) {
     scan(b1, mask1, &hits);
     for (uint32_t i = 0; i < n; ++i)
       if ((mask1[i >> 6] >> (i & 63)) & 1) {
-        out1 << r1[i].l[0] << ":MH" << hits[i] << '\n' << r1[i].l[1] << '\n' << r1[i].l[2] << '\n' << r1[i].l[3] << '\n';
+        const std::string suffix = ":MH" + std::to_string(hits[i]);
+        r1.write(out1, i, suffix.c_str());
         ++found;
       }
 #else
@@ -153,8 +173,8 @@ int main(int argc, char** argv) {
     scan(b2, mask2, nullptr);  // equivalent to the reference's "mate 2 only if mate 1 failed" (:237-277)
     for (uint32_t i = 0; i < n; ++i)
       if (((mask1[i >> 6] | mask2[i >> 6]) >> (i & 63)) & 1) {
-        out1 << r1[i].l[0] << '\n' << r1[i].l[1] << '\n' << r1[i].l[2] << '\n' << r1[i].l[3] << '\n';
-        out2 << r2[i].l[0] << '\n' << r2[i].l[1] << '\n' << r2[i].l[2] << '\n' << r2[i].l[3] << '\n';
+        r1.write(out1, i);
+        r2.write(out2, i);
         ++found;
       }
 #endif

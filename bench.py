@@ -151,7 +151,7 @@ def main():
     # Timed region.  The HIP-event brackets that give roofline.achieved cost ~30 us of pipeline
     # bubble each (measured: 8.5 ms/step with all ~100 launches bracketed, 7.6 ms with none), so they
     # are live on the launches of the dominant stage during the LAST timed step only.
-    ctx.prof_filter(K2_CHAIN)
+    ctx.prof_filter(K2_CHAIN + ("k_filter",))
     ctx.prof(False)
     ctx.prof_reset()
     fence()
@@ -209,6 +209,11 @@ def main():
                          "avg_launch_ms": avg_ms, "avg_launch_ms_by_kernel": {n: round(v, 4) for n, v in parts.items()},
                          "launches": int(n_count), "reads_per_launch": n_reads,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
+            # K5 (read filter) against the same roofline: SURVEY 8(d) prices it at 61 B/read of streaming
+            "roofline_filter": (lambda ms: {"bound": "hbm", "kernel": "k_filter", "achieved": 61.0 * n_reads / (ms * 1e-3) / 1e9,
+                                            "peak": 8000.0, "unit": "GB/s", "frac": 61.0 * n_reads / (ms * 1e-3) / 1e9 / 8000.0,
+                                            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": 61 * n_reads})(
+                prof["k_filter"][0] / max(prof["k_filter"][1], 1)) if "k_filter" in prof and prof["k_filter"][0] > 0 else None,
             "kernels_ms_per_step": {k: round(v[0], 4) for k, v in sorted(prof_all.items())},
             "kernels_ms_per_step_source": "one extra untimed step with every launch bracketed",
         }

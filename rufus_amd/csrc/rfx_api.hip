@@ -668,7 +668,8 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
   uint64_t held = 0;
   for (auto& sg : *t->segs) held += sg.n;
   if (c->budget && c->used + (held + windows) * 20 > c->budget) return RFX_E_NOMEM;
-  const int G = rfxk::p2l_grid(c, r->n);
+  // the partition kernels fit two blocks per CU: a grid of exactly the resident blocks (see msp_geometry)
+  const int G = std::min(rfxk::p2l_grid(c, r->n), c->n_cu * 2);
   uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)G * P * 4);
   uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
   uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
@@ -698,7 +699,7 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
                         (uint32_t)cap64, cnt, coarse_cur + ncur);
       rfxk::bin_totals(c, cnt, (uint32_t)G, P, bin_start);
       rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, cfg.bin_shift, coarse_cur, (uint32_t)cap64, nullptr, nullptr,
-                  ~0ull, "k_part2");
+                  ~0ull, "k_part2", nullptr, 0, windows);
       if (queue_read(c, &flag, coarse_cur + ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) flag = 1;
     }
     dfree(c, coarse_cur); dfree(c, buf_a); dfree(c, fine_cur);
@@ -736,7 +737,8 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
       return RFX_E_NOMEM;
     }
     rfxk::part1(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P2, t->pos_lo, t->pos_hi, G, cnt1, bin_start, buf_a);
-    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, cfg.bin_shift, nullptr, 0, nullptr, nullptr, ~0ull, "k_part2");
+    rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, cfg.bin_shift, nullptr, 0, nullptr, nullptr, ~0ull, "k_part2",
+                nullptr, 0, total);
     dfree(c, buf_a);
   } else {
     rfxk::bin_scatter(c, rv, t->lut_t, t->ntab, t->k, t->canonical, cfg, P, t->pos_lo, t->pos_hi, G, cnt, bin_start,
@@ -878,7 +880,8 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1) * 4, c->stream));
   HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
   rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a, cur, (uint32_t)cap_a, nullptr, cur + g.ncur);
-  rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
+  rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2",
+              nullptr, 0, cap_b);
   unsigned int flag = 1;
   if (queue_read(c, &flag, cur + g.ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) return fail(RFX_E_HIP);
   if (flag) {
@@ -926,7 +929,8 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
   rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
   rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
-  rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2");
+  rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2",
+              nullptr, 0, cap_b);
   rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
   drop();
   t->segs->push_back(rfx_segment{inst, cap_b, bin_start, g.windows, P});

@@ -234,6 +234,36 @@ def test_msp_count_matches_oracle(ctx, small_trio, k, size, canonical, lower):
     jf.records.free()
 
 
+def test_auto_mode_falls_back_to_the_table_when_the_budget_is_small(small_trio):
+    """rfx_open(device, hbm_budget): the partition buffers of the MSP path do not fit 20 MB, so AUTO counts
+    in the open-addressed table (which grows inside the budget) -- same bytes; forcing MSP reports the
+    shortage instead of exceeding the budget."""
+    small = capi.Context(0, hbm_budget=20 << 20)
+    try:
+        fq = [fastq_bytes(small_trio["child"], m) for m in (1, 2)]
+        reads = [r for f in fq for r in tools.parse_sequences(f)][:4000]
+        ref = oracle.count(None, 25, 1 << 24, lower=2, reads=reads)
+        blk = small.upload(capi.PackedReads.from_reads(reads))
+        small.prof(True)
+        small.prof_reset()
+        t = capi.CountTable(small, 25, 1 << 24, capacity=1 << 16)
+        t.add(blk)
+        rec = t.finish(2)
+        names = small.prof_dict()
+        small.prof(False)
+        assert "k_count_reads" in names and "k_msp_leaf" not in names, names
+        assert rec.payload() == ref.payload()
+        rec.free()
+        t.free()
+        t = capi.CountTable(small, 25, 1 << 24, mode=capi.COUNT_MSP)
+        with pytest.raises(capi.RufusError):
+            t.add(blk)
+        t.free()
+        blk.free()
+    finally:
+        small.close()
+
+
 def test_finish_begin_end_pipelines_several_tables(ctx, small_trio):
     """Three tables queued before the first is waited for (MSP: nothing blocks in _begin; the k = 31
     table finishes inside _begin) give the same records and histograms as finish()."""

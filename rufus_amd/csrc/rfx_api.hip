@@ -1761,7 +1761,8 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
     rfxk::set_insert(c, dk, n, s->slots, s->bits);
     rfxk::set_bitmap(c, dk, n, s->bitmap, s->bm_bits, s->bm_shift);
     if (s->bitmap2) rfxk::set_bitmap_packed(c, dk, n, s->bitmap2);
-    ok = ctx_sync(c) == hipSuccess;
+    // no synchronisation: upload() staged the keys, everything else is ordered on the ctx stream, and a
+    // device error surfaces at the first rfx_filter / rfx_annotate (which wait for their results)
   }
   dfree(c, dk);
   if (!ok) {

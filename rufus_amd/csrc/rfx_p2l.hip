@@ -484,22 +484,24 @@ __global__ __launch_bounds__(LEAF_BLOCK) void k_leaf(const uint64_t* const* __re
 #pragma unroll
             for (int u = 0; u < LEAF_ILP; ++u) {
               const uint64_t key = w[u];
-              // re-check before EVERY insert: at most one insert per thread can follow the flag, which
-              // the LEAF_TBL - LEAF_FILL spare slots absorb -- the probe loop below always terminates
-              if (*(volatile uint32_t*)&s_ovf) break;
+              // The count of distinct words is looked at before EVERY insert: at most one word per thread
+              // can follow LEAF_FILL, which the LEAF_TBL - LEAF_FILL spare slots absorb -- the probe loop
+              // below always terminates.  A skipped insert voids the pass (s_ovf).  The probe is one
+              // returning CAS ("was empty, now mine" / "already mine" / "someone else's"), as in k_msp_leaf.
               if (key == RFX_EMPTY) continue;
               if (r > 0 && (uint32_t)((key >> sub_shift) & ((1u << r) - 1)) != j) continue;
+              if (__hip_atomic_load(&s_nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)LEAF_FILL) {
+                s_ovf = 1;
+                break;
+              }
               uint32_t slot = leaf_hash(key);
               for (;;) {
-                unsigned long long cur = s_keys[slot];
-                if (cur == RFX_EMPTY) {
-                  cur = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
-                  if (cur == RFX_EMPTY) {
-                    cur = key;
-                    if (atomicAdd(&s_nd, 1u) >= (uint32_t)LEAF_FILL) s_ovf = 1;
-                  }
+                unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+                if (old == RFX_EMPTY) {
+                  atomicAdd(&s_nd, 1u);
+                  old = key;
                 }
-                if (cur == key) {
+                if (old == key) {
                   atomicAdd(&s_cnt[slot], 1u);
                   break;
                 }

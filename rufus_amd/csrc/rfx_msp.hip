@@ -176,7 +176,8 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
         const uint32_t cb = s_sbin[e];
         if (s_gbase[cb] != ~0ull) buf_a[s_gbase[cb] + (e - s_start[cb])] = s_stage[e];
       }
-      __syncthreads();
+      // no barrier here: the next phase touches only s_cnt / s_fine (atomics) until ITS first barrier, and
+      // nothing of the staging area is rewritten before that barrier has been passed by everyone
     }
   }
   __syncthreads();

@@ -85,6 +85,26 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
     uint32_t a[MSP_WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-14 .. p0+7
 #pragma unroll
     for (int i = 0; i < MSP_WL - 1 + P1_S; ++i) a[i] = ~0u;
+    bool pend = false;        // a staged phase waits for its write-out
+    uint32_t cn = 0, at = 0;  // threads < P1_BINS: size and reserved start of their bin's run of that phase
+    auto flush = [&]() {
+      if (threadIdx.x < P1_BINS) {
+        if ((uint64_t)at + cn > cap_a) {  // over capacity: the run is dropped, the host redoes the block
+          atomicExch(flag, 1u);
+          s_gbase[threadIdx.x] = ~0ull;
+        } else {
+          s_gbase[threadIdx.x] = (uint64_t)threadIdx.x * cap_a + at;
+        }
+      }
+      __syncthreads();  // staging complete, bases known
+      const uint32_t total = s_start[P1_BINS];
+      blk_total += total;
+      for (uint32_t e = threadIdx.x; e < total; e += P2_BLOCK) {
+        const uint32_t cb = s_sbin[e];
+        if (s_gbase[cb] != ~0ull) buf_a[s_gbase[cb] + (e - s_start[cb])] = s_stage[e];
+      }
+      // no barrier after: whoever writes s_start / s_stage / s_gbase next passes a barrier first
+    };
     for (uint32_t ph = 0; ph < n_phase; ++ph) {
       uint64_t wv[P1_S];
       uint32_t br[P1_S];  // (coarse bin << 16) | rank, or ~0: no record closed at this base
@@ -144,12 +164,14 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
 #pragma unroll
       for (int i = 0; i < MSP_WL - 1; ++i) a[i] = a[i + P1_S];
       if (HMODE == 1) continue;
+      // The staged records of the PREVIOUS phase leave now: their reservation (a global atomic, ~1-2 us
+      // round trip, issued one phase ago) has long returned -- waiting for it inside its own phase cost a
+      // third of this kernel.
+      if (pend) flush();
       __syncthreads();
-      // reserve this phase's runs now; the round trip of the global atomic hides behind scan + staging
-      uint32_t cn = 0, at = 0;
-      if (threadIdx.x < P1_BINS) {
+      if (threadIdx.x < P1_BINS) {  // reserve this phase's runs
         cn = s_cnt[threadIdx.x];
-        if (cn) at = atomicAdd(&coarse_cur[threadIdx.x * P1_CUR_STRIDE], cn);
+        at = cn ? atomicAdd(&coarse_cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
       }
       if (threadIdx.x < 64) wave_scan256(s_cnt, s_start, P1_BINS);
       __syncthreads();
@@ -161,24 +183,10 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
           s_stage[e] = wv[b];
           s_sbin[e] = (uint8_t)cb;
         }
-      if (threadIdx.x < P1_BINS) {
-        if ((uint64_t)at + cn > cap_a) {  // over capacity: the run is dropped, the host redoes the block
-          atomicExch(flag, 1u);
-          s_gbase[threadIdx.x] = ~0ull;
-        } else {
-          s_gbase[threadIdx.x] = (uint64_t)threadIdx.x * cap_a + at;
-        }
-      }
-      __syncthreads();
-      const uint32_t total = s_start[P1_BINS];
-      blk_total += total;
-      for (uint32_t e = threadIdx.x; e < total; e += P2_BLOCK) {
-        const uint32_t cb = s_sbin[e];
-        if (s_gbase[cb] != ~0ull) buf_a[s_gbase[cb] + (e - s_start[cb])] = s_stage[e];
-      }
-      // no barrier here: the next phase touches only s_cnt / s_fine (atomics) until ITS first barrier, and
-      // nothing of the staging area is rewritten before that barrier has been passed by everyone
+      pend = true;
     }
+    if (pend) flush();
+    pend = false;
   }
   __syncthreads();
   if (HMODE == 0) {

@@ -831,9 +831,9 @@ static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   g.P1 = (uint32_t)rfxk::p1_bins();
   g.P2 = g.P / g.P1;
   g.bin_bits = ceil_log2(g.P);
-  // k_msp_part1 fits two blocks per CU (LDS): a grid of exactly the resident blocks, each looping over its
-  // share of the chunks, beats a 1.5x larger one whose last half-wave of blocks runs on a half-empty chip
-  g.G = std::min(rfxk::p2l_grid(c, r->n), c->n_cu * 2);
+  // k_msp_part1 fits three blocks per CU (80 VGPRs): a grid of exactly the resident blocks, each looping
+  // over its share of the chunks, beats a larger one whose last wave of blocks runs on a half-empty chip
+  g.G = std::min(rfxk::p2l_grid(c, r->n), c->n_cu * 3);
   g.ncur = (size_t)g.P1 * rfxk::p1_cur_stride();
   // shard passes: the same cut as the multi-GPU owner ranges (on the top 8 bits of the bin index)
   const uint32_t ns = t->n_shards > 1 ? (uint32_t)t->n_shards : 1, sh = t->n_shards > 1 ? (uint32_t)t->shard : 0;

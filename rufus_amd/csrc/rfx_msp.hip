@@ -7,7 +7,8 @@
 //   k_msp_part1  reads -> for every k-mer the minimum of hash(canonical m-mer) over its 15 m-mers
 //                (m = k-14); the minimizer picks one of P bins.  Runs of <= 4 consecutive k-mers with
 //                the same bin become ONE 8-byte record (k+3 bases, run length, fine sub-bin).
-//                ~3.2 k-mers per record -> 2.5 B per instance.  128 coarse bins, LDS-staged runs.
+//                ~3.4 k-mers per record -> 2.4 B per instance.  128 coarse bins; every phase (8 bases of
+//                512 reads) reserves one run per bin and the lanes store their records into it.
 //   k_part2      coarse -> fine bins (same kernel as P2L; the sub-bin is in the record)
 //   k_msp_leaf   one workgroup per fine bin: expand the records, count canonical k-mers in an LDS
 //                hash table (identical records are merged in a small cache first); every instance of
@@ -49,9 +50,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
                                                          uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
                                                          uint32_t* __restrict__ cnt_rows,
                                                          unsigned int* __restrict__ flag) {
-  __shared__ uint64_t s_stage[HMODE == 1 ? 1 : P1_STAGE];
-  __shared__ uint8_t s_sbin[HMODE == 1 ? 1 : P1_STAGE];
-  __shared__ uint32_t s_cnt[P1_BINS], s_start[P1_BINS + 1];
+  __shared__ uint32_t s_cnt[P1_BINS];
   __shared__ uint64_t s_gbase[P1_BINS];  // 64-bit: the exact redo may size a coarse bin by a skewed maximum
   __shared__ uint32_t s_fine[HMODE == 0 ? 4096 : HMODE == 1 ? 8192 : 1];
   __shared__ uint32_t s_maxlen;
@@ -60,7 +59,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
   const int m = k - (MSP_WL - 1);
   const uint32_t mmask = (1u << (2 * m)) - 1;
   const int rmshift = 2 * (m - 1);
-  uint32_t blk_total = 0;
+  uint32_t n_emit = 0;  // records this thread stored (or dropped over capacity)
   if (HMODE == 0)
     for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) s_fine[i] = 0;
   if (HMODE == 1)
@@ -85,26 +84,6 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
     uint32_t a[MSP_WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-14 .. p0+7
 #pragma unroll
     for (int i = 0; i < MSP_WL - 1 + P1_S; ++i) a[i] = ~0u;
-    bool pend = false;        // a staged phase waits for its write-out
-    uint32_t cn = 0, at = 0;  // threads < P1_BINS: size and reserved start of their bin's run of that phase
-    auto flush = [&]() {
-      if (threadIdx.x < P1_BINS) {
-        if ((uint64_t)at + cn > cap_a) {  // over capacity: the run is dropped, the host redoes the block
-          atomicExch(flag, 1u);
-          s_gbase[threadIdx.x] = ~0ull;
-        } else {
-          s_gbase[threadIdx.x] = (uint64_t)threadIdx.x * cap_a + at;
-        }
-      }
-      __syncthreads();  // staging complete, bases known
-      const uint32_t total = s_start[P1_BINS];
-      blk_total += total;
-      for (uint32_t e = threadIdx.x; e < total; e += P2_BLOCK) {
-        const uint32_t cb = s_sbin[e];
-        if (s_gbase[cb] != ~0ull) buf_a[s_gbase[cb] + (e - s_start[cb])] = s_stage[e];
-      }
-      // no barrier after: whoever writes s_start / s_stage / s_gbase next passes a barrier first
-    };
     for (uint32_t ph = 0; ph < n_phase; ++ph) {
       uint64_t wv[P1_S];
       uint32_t br[P1_S];  // (coarse bin << 16) | rank, or ~0: no record closed at this base
@@ -164,33 +143,39 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
 #pragma unroll
       for (int i = 0; i < MSP_WL - 1; ++i) a[i] = a[i + P1_S];
       if (HMODE == 1) continue;
-      // The staged records of the PREVIOUS phase leave now: their reservation (a global atomic, ~1-2 us
-      // round trip, issued one phase ago) has long returned -- waiting for it inside its own phase cost a
-      // third of this kernel.
-      if (pend) flush();
+      // Every lane stores its own records straight into the reserved runs (rank inside the run = the
+      // value its LDS atomic returned).  The stores of one run come from many lanes, but they fall into
+      // the same one or two 128-byte lines within a few hundred cycles and merge in the L2.
       __syncthreads();
-      if (threadIdx.x < P1_BINS) {  // reserve this phase's runs
-        cn = s_cnt[threadIdx.x];
-        at = cn ? atomicAdd(&coarse_cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
+      if (threadIdx.x < P1_BINS) {  // reserve this phase's runs: one global atomic per coarse bin
+        const uint32_t cn = s_cnt[threadIdx.x];
+        const uint32_t at = cn ? atomicAdd(&coarse_cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
+        s_cnt[threadIdx.x] = 0;
+        if ((uint64_t)at + cn > cap_a) {  // over capacity: the run is dropped, the host redoes the block
+          atomicExch(flag, 1u);
+          s_gbase[threadIdx.x] = ~0ull;
+        } else {
+          s_gbase[threadIdx.x] = (uint64_t)threadIdx.x * cap_a + at;
+        }
       }
-      if (threadIdx.x < 64) wave_scan256(s_cnt, s_start, P1_BINS);
       __syncthreads();
-      if (threadIdx.x < P1_BINS) s_cnt[threadIdx.x] = 0;
 #pragma unroll
       for (int b = 0; b < P1_S; ++b)
         if (br[b] != ~0u) {
-          const uint32_t cb = br[b] >> 16, e = s_start[cb] + (br[b] & 0xFFFFu);
-          s_stage[e] = wv[b];
-          s_sbin[e] = (uint8_t)cb;
+          const uint64_t base = s_gbase[br[b] >> 16];
+          if (base != ~0ull) buf_a[base + (br[b] & 0xFFFFu)] = wv[b];
+          ++n_emit;
         }
-      pend = true;
+      // no barrier here: s_gbase is rewritten only after the next phase's first barrier
     }
-    if (pend) flush();
-    pend = false;
   }
   __syncthreads();
   if (HMODE == 0) {
-    if (threadIdx.x == 0) s_maxlen = 0;
+    __shared__ uint32_t s_emit;
+    if (threadIdx.x == 0) {
+      s_maxlen = 0;
+      s_emit = 0;
+    }
     __syncthreads();
     uint32_t sum = 0;
     for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) {
@@ -200,8 +185,9 @@ __global__ __launch_bounds__(P2_BLOCK) void k_msp_part1(rfx_reads_view rv, int k
     }
     // a wrapped 16-bit counter (carry into the neighbour or out of the word) leaves the sum short
     atomicAdd(&s_maxlen, sum);
+    atomicAdd(&s_emit, n_emit);
     __syncthreads();
-    if (threadIdx.x == 0 && s_maxlen != blk_total) atomicExch(flag, 1u);
+    if (threadIdx.x == 0 && s_maxlen != s_emit) atomicExch(flag, 1u);
   }
   if (HMODE == 1)
     for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) cnt_rows[(uint64_t)blockIdx.x * P + b] = s_fine[b];

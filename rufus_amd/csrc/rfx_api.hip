@@ -1372,11 +1372,8 @@ int rfx_count_add_pairs_dev(rfx_table* t, const uint64_t* d_keys, const uint32_t
 
 int rfx_count_segments(rfx_table* t) {
   if (!t) return RFX_E_INVAL;
-  (void)hipSetDevice(t->ctx->device);
-  if (t->seg_kind != RFX_COUNT_MSP) return 0;
-  const int rc = msp_resolve(t);
-  if (rc) return rc;
-  return (int)t->segs->size();
+  if (t->pend_error) return t->pend_error;
+  return t->seg_kind == RFX_COUNT_MSP ? (int)t->segs->size() : 0;
 }
 
 int rfx_count_segment_get(rfx_table* t, int i, const uint64_t** d_records, const uint64_t** d_bin_start, uint32_t* bins,
@@ -1384,17 +1381,29 @@ int rfx_count_segment_get(rfx_table* t, int i, const uint64_t** d_records, const
   if (!t || t->seg_kind != RFX_COUNT_MSP || i < 0 || i >= (int)t->segs->size()) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
-  int rc = msp_resolve(t);
-  if (rc) return rc;
-  rfx_segment& sg = (*t->segs)[(size_t)i];
-  uint64_t total = 0;  // the exact record count lives on the device (segments are sized optimistically)
-  HIPCHK(queue_read(c, &total, sg.bin_start + sg.bins, 8));
-  HIPCHK(ctx_sync(c));
-  if (d_records) *d_records = sg.inst;
-  if (d_bin_start) *d_bin_start = sg.bin_start;
-  if (bins) *bins = sg.bins;
-  if (n_records) *n_records = total;
-  return RFX_OK;
+  // One synchronisation for both: the capacity flags of the pending adds and the exact record count of
+  // the segment (segments are sized optimistically; the count lives on the device).
+  for (int round = 0; round < 2; ++round) {
+    rfx_segment& sg = (*t->segs)[(size_t)i];
+    uint64_t total = 0;
+    std::vector<unsigned int> flags(t->pend->size(), 1u);
+    HIPCHK(queue_read(c, &total, sg.bin_start + sg.bins, 8));
+    for (size_t p = 0; p < flags.size(); ++p) HIPCHK(queue_read(c, &flags[p], (*t->pend)[p].cur + (*t->pend)[p].ncur, 4));
+    HIPCHK(ctx_sync(c));
+    bool redo = false;
+    for (unsigned int f : flags) redo |= f != 0;
+    if (!t->pend->empty()) {
+      const int rc = msp_settle(t, flags);
+      if (rc) return rc;
+    }
+    if (redo) continue;  // a block was re-partitioned: its segment (maybe this one) is new
+    if (d_records) *d_records = sg.inst;
+    if (d_bin_start) *d_bin_start = sg.bin_start;
+    if (bins) *bins = sg.bins;
+    if (n_records) *n_records = total;
+    return RFX_OK;
+  }
+  return RFX_E_HIP;
 }
 
 int rfx_count_add_records_dev(rfx_table* t, const uint64_t* d_records, uint64_t n_records, const uint64_t* d_bin_start,

@@ -139,25 +139,23 @@ class HipBackend:
         return 23 <= self.k <= 25
 
     def partition(self, block):
-        """(records int64[n], bin_start int64[bins+1]) device tensors: the block's super-k-mer records
-        grouped by minimizer bin."""
+        """(records int64[n], bin_start int64[bins+1], keep): the block's super-k-mer records grouped by
+        minimizer bin, as zero-copy views of the library's device memory; `keep` owns that memory --
+        call keep.free() once the tensors are no longer needed (after the exchange)."""
         t = capi.CountTable(self.ctx, self.k, self.size, True, self.capacity, mode=capi.COUNT_MSP)
         try:
             t.add(block)
             segs = t.segments()
-            if not segs:                         # no k-mer at all
-                return (torch.empty(0, dtype=torch.int64, device=self.device),
-                        torch.zeros(257, dtype=torch.int64, device=self.device))
-            d_rec, d_bs, bins, n = segs[0]
-            rec = torch.empty(n, dtype=torch.int64, device=self.device)
-            bs = torch.empty(bins + 1, dtype=torch.int64, device=self.device)
-            torch.cuda.synchronize(self.device)
-            self.ctx.memcpy_dev(rec.data_ptr(), d_rec, n * 8)
-            self.ctx.memcpy_dev(bs.data_ptr(), d_bs, (bins + 1) * 8)
-            self.ctx.sync()
-            return rec, bs
-        finally:
+        except Exception:
             t.free()
+            raise
+        if not segs:                         # no k-mer at all
+            t.free()
+            return (torch.empty(0, dtype=torch.int64, device=self.device),
+                    torch.zeros(257, dtype=torch.int64, device=self.device), None)
+        d_rec, d_bs, bins, n = segs[0]       # segments() has synchronised: the arrays are complete
+        rec = _device_view(d_rec, n, self.device) if n else torch.empty(0, dtype=torch.int64, device=self.device)
+        return rec, _device_view(d_bs, bins + 1, self.device), t
 
     def count_records(self, runs, lower: int):
         """runs: [(records, bin_start)] received from every rank for this owner's bins -> (records of
@@ -209,6 +207,18 @@ class HipBackend:
 def owner_bounds(lsize: int, world: int):
     """pos range [b[g], b[g+1]) owned by rank g."""
     return [(g << lsize) // world for g in range(world + 1)]
+
+
+class _DevMem:
+    """n int64 at a raw device address, for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 3,
+                                         "strides": None}
+
+
+def _device_view(ptr: int, n: int, device) -> torch.Tensor:
+    return torch.as_tensor(_DevMem(ptr, n), device=device)
 
 
 def bin_owner_bounds(bins: int, world: int):
@@ -351,8 +361,11 @@ class TrioShard:
         if self.world == 1:
             return self.be.local_count(block, self.lower)
         if self.shard_by == "minimizer":
-            records, bin_start = self.be.partition(block)
+            part = self.be.partition(block)
+            records, bin_start = part[0], part[1]
             runs = exchange_records(records, bin_start, self.group)
+            if len(part) > 2 and part[2] is not None:
+                part[2].free()
             rec, histo = self.be.count_records(runs, self.lower)
             h = _wire(torch.from_numpy(histo.astype(np.int64)).to(records.device), self.group)
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
@@ -397,14 +410,18 @@ class TrioShard:
             # being partitioned and the previous one counted; histograms are reduced once, at the end.
             started = []
             for blk in blocks:
-                records, bin_start = self.be.partition(blk)
-                started.append(exchange_records_begin(records, bin_start, self.group))
+                part = self.be.partition(blk)          # (records, bin_start[, owner of their memory])
+                keep = part[2] if len(part) > 2 else None
+                started.append((exchange_records_begin(part[0], part[1], self.group), keep))
             local = []
-            for st in started:
-                rec, histo = self.be.count_records(exchange_records_end(st), self.lower)
+            for st, keep in started:
+                runs = exchange_records_end(st)
+                if keep is not None:
+                    keep.free()              # the send buffers were views of this table's memory
+                rec, histo = self.be.count_records(runs, self.lower)
                 recs.append(rec)
                 local.append(histo.astype(np.int64))
-            dev = started[0]["dev"]
+            dev = started[0][0]["dev"]
             h = _wire(torch.from_numpy(np.stack(local)).to(dev), self.group)
             dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
             histos = [x.astype(np.uint64) for x in h.cpu().numpy()]

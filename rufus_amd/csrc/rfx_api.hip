@@ -831,9 +831,13 @@ static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   g.P1 = (uint32_t)rfxk::p1_bins();
   g.P2 = g.P / g.P1;
   g.bin_bits = ceil_log2(g.P);
-  // k_msp_part1 fits three blocks per CU (80 VGPRs): a grid of exactly the resident blocks, each looping
-  // over its share of the chunks, beats a larger one whose last wave of blocks runs on a half-empty chip
-  g.G = std::min(rfxk::p2l_grid(c, r->n), c->n_cu * 3);
+  // k_msp_part1 fits two 768-thread blocks per CU: a grid of exactly the resident blocks, each looping over
+  // its share of the chunks, beats a larger one whose last wave of blocks runs on a half-empty chip
+  {
+    const uint32_t blk = (uint32_t)rfxk::msp_part1_block();
+    const uint32_t chunks = (r->n + blk - 1) / blk;
+    g.G = (int)std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)c->n_cu * 2, (chunks + 7) & ~7u));
+  }
   g.ncur = (size_t)g.P1 * rfxk::p1_cur_stride();
   // shard passes: the same cut as the multi-GPU owner ranges (on the top 8 bits of the bin index)
   const uint32_t ns = t->n_shards > 1 ? (uint32_t)t->n_shards : 1, sh = t->n_shards > 1 ? (uint32_t)t->shard : 0;

@@ -262,6 +262,7 @@ void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fin
            uint64_t n_hint = 0 /* expected entries: sizes the grid of a small run */);
 // MSP path (rfx_msp.hip)
 int msp_k_ok(int k);
+int msp_part1_block();  // threads = reads per chunk of k_msp_part1
 void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
                int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
                unsigned int* flag);

@@ -117,6 +117,37 @@ rfx_reads* rfx_reads_upload(rfx_ctx*, const uint64_t* codes, const uint32_t* acg
 void rfx_reads_free(rfx_reads*);
 uint32_t rfx_reads_count(const rfx_reads*);
 uint64_t rfx_reads_bases(const rfx_reads*);
+uint64_t rfx_reads_words(const rfx_reads*);
+/* D2H copy of a block's arrays (sized by rfx_reads_words / rfx_reads_count; any pointer may be NULL). */
+int rfx_reads_get(const rfx_reads*, uint64_t* codes, uint32_t* acgt, uint32_t* good, uint32_t* word_off, uint32_t* len);
+
+/* Synthetic trio workload (BASELINE.json configs[1]-[4]) -- benchmark and scale-test input,
+ * not a replacement of any reference code.  Every base is a pure function of (parameters, pair, mate, base
+ * index) -- see rufus_amd/csrc/rfx_synth.h -- so a 30x WGS sample (6.2e8 reads) is generated straight into
+ * packed read blocks in HBM, and any slice of it can be regenerated as text on the host for the oracle. */
+typedef struct rfx_synth {
+  uint64_t genome_len;  /* bases, 4000 <= genome_len < 2^32 */
+  uint64_t genome_seed; /* uniform random genome */
+  uint64_t snv_seed;    /* planted SNVs: one per stratum of (genome_len - 2000) / n_snv bases */
+  uint64_t read_seed;   /* one per sample */
+  uint32_t n_snv;       /* (genome_len - 2000) / n_snv must be >= 2 * read_len + 64 */
+  uint32_t read_len;    /* <= 256 */
+  uint32_t insert_lo, insert_span; /* insert = insert_lo + U[0, insert_span), insert_lo >= read_len */
+  uint32_t err_1024;    /* substitution errors per 1024 bases */
+  uint32_t lowq_256;    /* bases with quality '#' (else 'J') per 256 */
+  uint32_t n_1024;      /* 'N' per 1024 bases */
+  uint32_t carrier;     /* 1: pairs of haplotype 1 carry the SNVs (the child); 0: reference only (a parent) */
+} rfx_synth;
+/* Reads 2*first_pair .. 2*(first_pair+n_pairs)-1 of the sample (read 2p = mate 1 of pair p, 2p+1 = mate 2),
+ * packed as rfx_pack_reads(RFX_PACK_COUNT [| RFX_PACK_FILTER with min_q]) would pack their text. */
+rfx_reads* rfx_synth_reads(rfx_ctx*, const rfx_synth*, uint64_t first_pair, uint32_t n_pairs, int min_q,
+                           int want_good);
+/* Host twin: the same reads as text, read after read: seq and qual hold 2*n_pairs*read_len bytes each. */
+int rfx_synth_text(const rfx_synth*, uint64_t first_pair, uint32_t n_pairs, char* seq, char* qual);
+/* SNV i: 0-based genome position, reference and alternative base ('A','C','G','T'). */
+int rfx_synth_snv(const rfx_synth*, uint32_t i, uint64_t* pos, char* ref, char* alt);
+/* Genome bases [first, first+n) as text (host). */
+int rfx_synth_genome(const rfx_synth*, uint64_t first, uint64_t n, char* out);
 
 /* ---------------------------------------------------------------------------------------------
  * K2: canonical k-mer count  (jellyfish count: jf/sub_commands/count_main.cc:148-180;
@@ -177,7 +208,10 @@ void rfx_count_free(rfx_table*);
 
 /* K3: table -> records with lower <= count <= upper in (pos,key) order (jf/include/jellyfish/
  * sorted_dumper.hpp:80-112, mer_heap.hpp:34-38; -L/-U at output count_main.cc:318-324) plus the
- * count-of-counts histogram of exactly those records (histo_main.cc:33-89), histo may be NULL. */
+ * count-of-counts histogram of exactly those records (histo_main.cc:33-89), histo may be NULL.
+ * A table may be finished more than once (different bounds, more reads in between) -- except an MSP table
+ * holding more than 4 GB of super-k-mer records: its finish frees them before the survivors are sorted
+ * (at WGS scale both do not fit side by side), so it can only be freed afterwards. */
 rfx_records* rfx_count_finish(rfx_table*, uint64_t lower, uint64_t upper, uint64_t* histo /* RFX_HISTO_BINS */);
 /* The same in two steps, so that several tables can be queued on the device before the host waits for
  * the first: _begin launches the work (nothing is waited for on the MSP path; other paths finish inside

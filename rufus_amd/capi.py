@@ -50,6 +50,12 @@ SIGNATURES = {
     "rfx_reads_free": (None, [C.c_void_p]),
     "rfx_reads_count": (C.c_uint32, [C.c_void_p]),
     "rfx_reads_bases": (C.c_uint64, [C.c_void_p]),
+    "rfx_reads_words": (C.c_uint64, [C.c_void_p]),
+    "rfx_reads_get": (C.c_int, [C.c_void_p, u64p, u32p, u32p, u32p, u32p]),
+    "rfx_synth_reads": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int]),
+    "rfx_synth_text": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rfx_synth_snv": (C.c_int, [C.c_void_p, C.c_uint32, u64p, C.c_char_p, C.c_char_p]),
+    "rfx_synth_genome": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "rfx_count_begin": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]),
     "rfx_count_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "rfx_count_add": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -169,6 +175,42 @@ def jhash_header(k: int, lsize: int, cols: np.ndarray, canonical: bool = True, c
     return buf.raw[:n]
 
 
+class Synth(C.Structure):
+    """``rfx_synth``: parameters of one sample of the synthetic trio workload."""
+    _fields_ = [("genome_len", C.c_uint64), ("genome_seed", C.c_uint64), ("snv_seed", C.c_uint64),
+                ("read_seed", C.c_uint64), ("n_snv", C.c_uint32), ("read_len", C.c_uint32),
+                ("insert_lo", C.c_uint32), ("insert_span", C.c_uint32), ("err_1024", C.c_uint32),
+                ("lowq_256", C.c_uint32), ("n_1024", C.c_uint32), ("carrier", C.c_uint32)]
+
+    @classmethod
+    def sample(cls, genome_len: int, which: int, n_snv: int = 20, seed: int = 12345, read_len: int = 150):
+        """Sample `which` of a trio on one genome: 0 = child (carrier of the SNVs), 1 / 2 = parents."""
+        return cls(genome_len=genome_len, genome_seed=seed, snv_seed=seed + 7, read_seed=seed * 1000 + which,
+                   n_snv=n_snv, read_len=read_len, insert_lo=250, insert_span=151, err_1024=5, lowq_256=5, n_1024=1,
+                   carrier=1 if which == 0 else 0)
+
+    def text(self, first_pair: int, n_pairs: int):
+        """(seq, qual) uint8 matrices of shape (2*n_pairs, read_len): read 2p = mate 1, 2p+1 = mate 2."""
+        seq = np.zeros((2 * n_pairs, self.read_len), dtype=np.uint8)
+        qual = np.zeros_like(seq)
+        _check(lib().rfx_synth_text(C.byref(self), first_pair, n_pairs, seq.ctypes.data, qual.ctypes.data),
+               "rfx_synth_text")
+        return seq, qual
+
+    def snvs(self):
+        out = []
+        for i in range(self.n_snv):
+            pos, ref, alt = C.c_uint64(0), C.create_string_buffer(1), C.create_string_buffer(1)
+            _check(lib().rfx_synth_snv(C.byref(self), i, C.byref(pos), ref, alt), "rfx_synth_snv")
+            out.append((pos.value, ref.raw, alt.raw))
+        return out
+
+    def genome(self, first: int, n: int) -> bytes:
+        buf = np.zeros(max(n, 1), dtype=np.uint8)
+        _check(lib().rfx_synth_genome(C.byref(self), first, n, buf.ctypes.data), "rfx_synth_genome")
+        return buf[:n].tobytes()
+
+
 class PackedReads:
     """Host-side packed block: 32 bases per 64-bit code word, one mask bit per base."""
 
@@ -243,6 +285,13 @@ class Context:
     def upload(self, p: PackedReads) -> "ReadBlock":
         return ReadBlock(self, p)
 
+    def synth_reads(self, sy: Synth, first_pair: int, n_pairs: int, min_q: int = 15, want_good: bool = True):
+        """Pairs [first_pair, first_pair + n_pairs) of a synthetic sample, generated on the device."""
+        h = lib().rfx_synth_reads(self._h, C.byref(sy), first_pair, n_pairs, min_q, int(want_good))
+        if not h:
+            raise RufusError("rfx_synth_reads failed: " + lib().rfx_last_error().decode())
+        return ReadBlock.from_handle(self, h)
+
     def __enter__(self):
         return self
 
@@ -259,9 +308,30 @@ class ReadBlock:
             raise RufusError("rfx_reads_upload failed: " + lib().rfx_last_error().decode())
         self.n = p.n
 
+    @classmethod
+    def from_handle(cls, ctx: Context, handle):
+        self = cls.__new__(cls)
+        self.ctx, self._h = ctx, handle
+        self.n = int(lib().rfx_reads_count(handle))
+        return self
+
     @property
     def bases(self) -> int:
         return int(lib().rfx_reads_bases(self._h))
+
+    def get(self, want_good: bool = True):
+        """Download the packed arrays: dict codes / acgt / good / word_off / len."""
+        nw = int(lib().rfx_reads_words(self._h))
+        out = {"codes": np.zeros(max(nw, 1), np.uint64), "acgt": np.zeros(max(nw, 1), np.uint32),
+               "good": np.zeros(max(nw, 1), np.uint32) if want_good else None,
+               "word_off": np.zeros(self.n + 1, np.uint32), "len": np.zeros(max(self.n, 1), np.uint32)}
+        _check(lib().rfx_reads_get(self._h, _p(out["codes"], u64p), _p(out["acgt"], u32p), _p(out["good"], u32p),
+                                   _p(out["word_off"], u32p), _p(out["len"], u32p)), "rfx_reads_get")
+        for k_ in ("codes", "acgt", "good"):
+            if out[k_] is not None:
+                out[k_] = out[k_][:nw]
+        out["len"] = out["len"][:self.n]
+        return out
 
     def free(self):
         if self._h:

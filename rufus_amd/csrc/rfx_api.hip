@@ -420,6 +420,14 @@ void resolve_spans(rfx_ctx* c) {
 
 }  // namespace
 
+namespace rfxi {
+void* dmalloc(rfx_ctx* c, size_t bytes) { return ::dmalloc(c, bytes); }
+void dfree(rfx_ctx* c, void* p) { ::dfree(c, p); }
+void set_error(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
+hipError_t sync(rfx_ctx* c) { return ctx_sync(c); }
+hipError_t queue_read(rfx_ctx* c, void* dst, const void* d_src, size_t n) { return ::queue_read(c, dst, d_src, n); }
+}  // namespace rfxi
+
 extern "C" {
 
 const char* rfx_last_error(void) { return g_err; }
@@ -559,6 +567,7 @@ rfx_reads* rfx_reads_upload(rfx_ctx* c, const uint64_t* codes, const uint32_t* a
 }
 
 static void msp_forget_pending(rfx_table* t);
+static void p2l_drop_segments(rfx_table* t);
 static void rfx_reads_release_pending(const rfx_reads* r);
 
 void rfx_reads_free(rfx_reads* r) {
@@ -570,6 +579,21 @@ void rfx_reads_free(rfx_reads* r) {
 }
 uint32_t rfx_reads_count(const rfx_reads* r) { return r ? r->n : 0; }
 uint64_t rfx_reads_bases(const rfx_reads* r) { return r ? r->n_bases : 0; }
+uint64_t rfx_reads_words(const rfx_reads* r) { return r ? r->n_words : 0; }
+
+int rfx_reads_get(const rfx_reads* r, uint64_t* codes, uint32_t* acgt, uint32_t* good, uint32_t* word_off, uint32_t* len) {
+  if (!r) return RFX_E_INVAL;
+  rfx_ctx* c = r->ctx;
+  (void)hipSetDevice(c->device);
+  if ((acgt && !r->acgt) || (good && !r->good)) return RFX_E_INVAL;
+  if (codes && r->n_words) HIPCHK(hipMemcpyAsync(codes, r->codes, r->n_words * 8, hipMemcpyDeviceToHost, c->stream));
+  if (acgt && r->n_words) HIPCHK(hipMemcpyAsync(acgt, r->acgt, r->n_words * 4, hipMemcpyDeviceToHost, c->stream));
+  if (good && r->n_words) HIPCHK(hipMemcpyAsync(good, r->good, r->n_words * 4, hipMemcpyDeviceToHost, c->stream));
+  if (word_off) HIPCHK(hipMemcpyAsync(word_off, r->word_off, ((size_t)r->n + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+  if (len && r->n) HIPCHK(hipMemcpyAsync(len, r->len, (size_t)r->n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(ctx_sync(c));
+  return RFX_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 rfx_table* rfx_count_begin(rfx_ctx* c, int k, int canonical, int lsize, uint64_t capacity_slots, uint64_t pos_lo,
@@ -811,9 +835,11 @@ static rfx_records* p2l_emit(rfx_table* t, uint64_t lower, uint64_t upper) {
 // block is about to be freed -- the redo needs the reads.
 struct msp_geom {
   uint32_t P, P1, P2, bin_lo, bin_hi;
+  uint32_t c_lo, c_n;  // coarse bins the shard's records can fall into: c_lo .. c_lo + c_n - 1
   int bin_bits, G;
   size_t ncur;
   uint64_t windows;
+  int rec_mode;  // rfxk::part2 / bin_hist mode of this table's records
 };
 
 static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
@@ -843,6 +869,9 @@ static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   const uint32_t ns = t->n_shards > 1 ? (uint32_t)t->n_shards : 1, sh = t->n_shards > 1 ? (uint32_t)t->shard : 0;
   g.bin_lo = ((sh * 256 + ns - 1) / ns) * (g.P / 256);
   g.bin_hi = (((sh + 1) * 256 + ns - 1) / ns) * (g.P / 256);
+  g.c_lo = g.bin_lo / g.P2;
+  g.c_n = g.bin_hi > g.bin_lo ? (g.bin_hi - 1) / g.P2 - g.c_lo + 1 : 1;
+  g.rec_mode = t->canonical ? 1 : 2;
   return true;
 }
 
@@ -878,14 +907,18 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   uint64_t cap_a = 1;
   for (uint32_t cb = 0; cb < P1; ++cb) cap_a = std::max<uint64_t>(cap_a, bs[(size_t)(cb + 1) * P2] - bs[(size_t)cb * P2]);
   const uint64_t cap_b = total ? total : 1;
-  buf_a = (uint64_t*)dmalloc(c, cap_a * P1 * 8);
+  if (cap_a >= (1ull << 32)) return fail(RFX_E_RANGE);
+  // only the shard's coarse bins exist: the kernels index coarse bins absolutely, so they get the
+  // address coarse bin 0 would have
+  buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
   inst = (uint64_t*)dmalloc(c, cap_b * 8);
   if (!buf_a || !inst) return fail(RFX_E_NOMEM);
+  uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1) * 4, c->stream));
   HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a, cur, (uint32_t)cap_a, nullptr, cur + g.ncur);
-  rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2",
-              nullptr, 0, cap_b);
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr, cur + g.ncur);
+  rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b,
+              "k_part2", nullptr, 0, cap_b, g.rec_mode, t->k);
   unsigned int flag = 1;
   if (queue_read(c, &flag, cur + g.ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) return fail(RFX_E_HIP);
   if (flag) {
@@ -911,30 +944,63 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
     t->seg_kind = RFX_COUNT_MSP;
     return RFX_OK;
   }
-  const uint32_t P = g.P, P1 = g.P1, P2 = g.P2;
+  const uint32_t P = g.P, P2 = g.P2;
   const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
   uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
-  uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
   uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
   // one zeroed block: coarse cursors, [ncur] = flag, then the fine-bin cursors of k_part2
   uint32_t* cur = (uint32_t*)dmalloc(c, (g.ncur + 1 + (size_t)P) * 4);
   uint32_t* fine_cur = cur ? cur + g.ncur + 1 : nullptr;
-  // ~3.4 k-mers per record on ordinary sequence: room for 2.5, coarse bins 25 % above even
-  uint64_t cap_b = g.windows * 2 / 5 + 65536;
+  // ~3.4 k-mers per record on ordinary sequence: room for 2.5 (of the shard's share of the bins), coarse
+  // bins 25 % above even -- 6 % for big blocks, whose bins are even
+  const bool big = g.windows >= (1ull << 29);  // >= ~4 M reads: worth one synchronisation for exact sizes
+  const double share = (double)(g.bin_hi - g.bin_lo) / (double)P;
+  uint64_t cap_b = (uint64_t)((double)g.windows * 0.4 * share * (share < 1 ? 1.05 : 1.0)) + 65536;
   if (cap_b > g.windows) cap_b = g.windows;
-  const uint64_t cap_a = cap_b / P1 + cap_b / (4ull * P1) + 16384;
-  uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * P1 * 8);
-  uint64_t* inst = (uint64_t*)dmalloc(c, cap_b * 8);
-  auto drop = [&] { dfree(c, cnt); dfree(c, gsum); dfree(c, buf_a); };
-  if (!cnt || !gsum || !bin_start || !cur || !buf_a || !inst) {
+  const uint64_t even = cap_b / g.c_n;
+  const uint64_t cap_a = even + (big ? even / 16 : even / 4) + 16384;
+  if (cap_a >= (1ull << 32)) { dfree(c, cnt); dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
+  uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
+  uint64_t* inst = big ? nullptr : (uint64_t*)dmalloc(c, cap_b * 8);
+  auto drop = [&] { dfree(c, cnt); dfree(c, buf_a); };
+  if (!cnt || !bin_start || !cur || !buf_a || (!big && !inst)) {
     drop(); dfree(c, cur); dfree(c, bin_start); dfree(c, inst);
     return RFX_E_NOMEM;
   }
+  uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;  // the address coarse bin 0 would have (see msp_partition_exact)
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
   rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
-  rfxk::part2(c, buf_a, inst, bin_start, fine_cur, P2, 58, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b, "k_part2",
-              nullptr, 0, cap_b);
+  if (big) {
+    // Big block: wait for the record count and the capacity flag, then give the segment exactly the
+    // memory it needs (at WGS scale the 30 % slack of the estimate is tens of GB) -- and nothing stays pending.
+    uint64_t total = 0;
+    unsigned int flag = 1;
+    hipError_t e = queue_read(c, &total, bin_start + P, 8);
+    if (e == hipSuccess) e = queue_read(c, &flag, cur + g.ncur, 4);
+    if (e == hipSuccess) e = ctx_sync(c);
+    if (e != hipSuccess) { drop(); dfree(c, cur); dfree(c, bin_start); return hip_fail(e, "msp_add"); }
+    if (flag) {  // a coarse bin overflowed (or a 16-bit counter wrapped): exact two-pass partition
+      drop(); dfree(c, cur); dfree(c, bin_start);
+      rfx_segment seg;
+      const int rc = msp_partition_exact(t, r, &seg);
+      if (rc) return rc;
+      t->segs->push_back(seg);
+      t->seg_kind = RFX_COUNT_MSP;
+      return RFX_OK;
+    }
+    inst = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
+    if (!inst) { drop(); dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
+    rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, nullptr, total,
+                "k_part2", nullptr, 0, total, g.rec_mode, t->k);
+    drop();
+    dfree(c, cur);
+    t->segs->push_back(rfx_segment{inst, total, bin_start, g.windows, P});
+    t->seg_kind = RFX_COUNT_MSP;
+    return RFX_OK;
+  }
+  rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b,
+              "k_part2", nullptr, 0, cap_b, g.rec_mode, t->k);
   rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
   drop();
   t->segs->push_back(rfx_segment{inst, cap_b, bin_start, g.windows, P});
@@ -974,52 +1040,6 @@ static int msp_resolve(rfx_table* t) {
   return msp_settle(t, flags);
 }
 
-// Bring every segment to 2^to_bits bins: segments of one bin count are refined together into ONE
-// new segment (slice tag + histogram, scan, third partition pass), at most 6 bits per step.
-static int msp_refine(rfx_table* t, int to_bits) {
-  rfx_ctx* c = t->ctx;
-  for (;;) {
-    uint32_t b = 0;  // the smallest bin count still below the target
-    for (auto& sg : *t->segs)
-      if (sg.bins < (1u << to_bits) && (b == 0 || sg.bins < b)) b = sg.bins;
-    if (!b) return RFX_OK;
-    const int from_bits = ceil_log2(b);
-    const int step = std::min(6, to_bits - from_bits);
-    const uint32_t Pn = b << step;
-    uint64_t total = 0, kmers = 0;
-    for (auto& sg : *t->segs)
-      if (sg.bins == b) {
-        total += sg.n;
-        kmers += sg.kmers;
-      }
-    uint64_t* fine = (uint64_t*)dmalloc(c, ((size_t)Pn + 1) * 8);
-    uint32_t* fine_cur = (uint32_t*)dmalloc(c, (size_t)Pn * 4);
-    uint64_t* out = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
-    if (!fine || !fine_cur || !out) { dfree(c, fine); dfree(c, fine_cur); dfree(c, out); return RFX_E_NOMEM; }
-    HIPCHK(hipMemsetAsync(fine, 0, ((size_t)Pn + 1) * 8, c->stream));
-    HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)Pn * 4, c->stream));
-    for (auto& sg : *t->segs)
-      if (sg.bins == b) rfxk::slice_tag(c, sg.inst, sg.bin_start, t->k, t->canonical, from_bits, from_bits + step, fine);
-    rfxk::scan_tail(c, fine, Pn);
-    for (auto& sg : *t->segs)
-      if (sg.bins == b)
-        rfxk::part2(c, sg.inst, out, fine, fine_cur, 1u << step, 58, nullptr, 0, nullptr, nullptr, total, "k_part3",
-                    sg.bin_start, b);
-    dfree(c, fine_cur);
-    std::vector<rfx_segment> keep;
-    for (auto& sg : *t->segs) {
-      if (sg.bins == b) {
-        dfree(c, sg.inst);  // stream-ordered pool: reused only by later work of this stream
-        dfree(c, sg.bin_start);
-      } else {
-        keep.push_back(sg);
-      }
-    }
-    keep.push_back(rfx_segment{out, total, fine, kmers, Pn});
-    *t->segs = keep;
-  }
-}
-
 static void rfx_reads_release_pending(const rfx_reads* r) {
   rfx_ctx* c = r->ctx;
   std::vector<rfx_table*> hit;
@@ -1050,8 +1070,9 @@ struct rfx_finish {
   bool queued = false;
   uint64_t cap = 0, room = 0, kmers = 0, total_out = 0;
   const uint64_t** d_inst = nullptr;
-  uint64_t *aw = nullptr, *bw = nullptr, *bsq = nullptr;
+  uint64_t *aw = nullptr, *bw = nullptr, *bsq = nullptr, *bs1 = nullptr;
   uint32_t *ac = nullptr, *bc = nullptr;
+  bool segs_dropped = false;  // the leaf phase of a big table is final: its records are already freed
   rfx_records* big = nullptr;
   std::vector<const uint64_t*> h_ptrs;
   std::vector<uint32_t> h_cur;
@@ -1061,10 +1082,101 @@ struct rfx_finish {
 static void msp_emit_drop(rfx_finish* f) {
   rfx_ctx* c = f->t->ctx;
   dfree(c, f->d_inst); dfree(c, f->aw); dfree(c, f->ac); dfree(c, f->bw); dfree(c, f->bc); dfree(c, f->bsq);
+  dfree(c, f->bs1);
   f->d_inst = nullptr;
-  f->aw = f->bw = f->bsq = nullptr;
+  f->aw = f->bw = f->bsq = f->bs1 = nullptr;
   f->ac = f->bc = nullptr;
   f->queued = false;
+}
+
+// Leaf phase over segments whose partition is too coarse for the LDS table (many read blocks in one table,
+// or a WGS-scale sample): the bins are refined chunk by chunk into a scratch buffer -- histogram of the next
+// <= 8 bits of every record's bin hash, scan, scatter (twice when more than 8 bits are missing) -- and the
+// leaf counts each chunk as it appears.  Plain streaming passes; the scratch is a fraction of the records.
+static int msp_leaf_refined(rfx_finish* f, const std::vector<size_t>& group, uint32_t b, int to_bits,
+                            const std::vector<std::vector<uint64_t>>& h_bs, int sel_bits, uint32_t* cur, size_t ncur) {
+  rfx_table* t = f->t;
+  rfx_ctx* c = t->ctx;
+  const int from_bits = ceil_log2(b);
+  const int fbits = to_bits - from_bits;
+  if (fbits > 16) {
+    snprintf(g_err, sizeof g_err, "MSP: partition would need %d more bits", fbits);
+    return RFX_E_FULL;
+  }
+  const int f1bits = std::min(8, fbits), f2bits = fbits - f1bits;
+  const uint32_t F1 = 1u << f1bits, F2 = 1u << f2bits, F = F1 * F2;
+  const int rec_mode = t->canonical ? 1 : 2;
+  // per-parent sizes over the group's segments, chunk boundaries by size
+  std::vector<uint64_t> sz(b, 0);
+  uint64_t R = 0, kmers = 0;
+  for (size_t si : group) {
+    for (uint32_t p = 0; p < b; ++p) sz[p] += h_bs[si][p + 1] - h_bs[si][p];
+    R += h_bs[si][b];
+    kmers += (*t->segs)[si].kmers;
+  }
+  const uint64_t target = std::max<uint64_t>(R / 16, 1ull << 25);
+  const uint32_t max_parents = std::max<uint32_t>(1, (1u << 22) / F);
+  std::vector<uint32_t> cut{0};
+  uint64_t acc = 0, max_chunk = 0;
+  for (uint32_t p = 0; p < b; ++p) {
+    if (p > cut.back() && (acc + sz[p] > target || p - cut.back() >= max_parents)) {
+      max_chunk = std::max(max_chunk, acc);
+      cut.push_back(p);
+      acc = 0;
+    }
+    acc += sz[p];
+  }
+  max_chunk = std::max(max_chunk, acc);
+  cut.push_back(b);
+  uint32_t max_np = 0;
+  for (size_t i = 0; i + 1 < cut.size(); ++i) max_np = std::max(max_np, cut[i + 1] - cut[i]);
+  const size_t n1max = (size_t)max_np * F1, n2max = (size_t)max_np * F;
+  uint64_t* cb1 = (uint64_t*)dmalloc(c, std::max<uint64_t>(max_chunk, 1) * 8);
+  uint64_t* cb2 = f2bits ? (uint64_t*)dmalloc(c, std::max<uint64_t>(max_chunk, 1) * 8) : nullptr;
+  uint64_t* fine1 = (uint64_t*)dmalloc(c, (n1max + 1) * 8 + n1max * 4);
+  uint64_t* fine2 = f2bits ? (uint64_t*)dmalloc(c, (n2max + 1) * 8 + n2max * 4) : nullptr;
+  auto drop = [&] { dfree(c, cb1); dfree(c, cb2); dfree(c, fine1); dfree(c, fine2); };
+  if (!cb1 || !fine1 || (f2bits && (!cb2 || !fine2))) { drop(); return RFX_E_NOMEM; }
+  const int shift1 = 32 - (from_bits + f1bits), shift2 = 32 - to_bits;
+  const int geo_default = kmers / ((uint64_t)b * F) < 8192 ? 1 : 0;
+  int geo = geo_default;
+  if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
+  for (size_t ci = 0; ci + 1 < cut.size(); ++ci) {
+    const uint32_t p0 = cut[ci], np = cut[ci + 1] - cut[ci];
+    uint64_t chunk = 0;
+    for (uint32_t p = p0; p < p0 + np; ++p) chunk += sz[p];
+    if (!chunk) continue;
+    const size_t n1 = (size_t)np * F1, n2 = (size_t)np * F;
+    uint32_t* fcur1 = (uint32_t*)(fine1 + n1 + 1);
+    HIPCHK(hipMemsetAsync(fine1, 0, (n1 + 1) * 8 + n1 * 4, c->stream));
+    for (size_t si : group) {
+      const rfx_segment& sg = (*t->segs)[si];
+      rfxk::bin_hist(c, sg.inst, sg.bin_start + p0, np, chunk, F1, shift1, rec_mode, t->k, fine1);
+    }
+    rfxk::scan_tail(c, fine1, n1);
+    for (size_t si : group) {
+      const rfx_segment& sg = (*t->segs)[si];
+      rfxk::part2(c, sg.inst, cb1, fine1, fcur1, F1, shift1, nullptr, 0, nullptr, nullptr, ~0ull, "k_part3",
+                  sg.bin_start + p0, np, 0, rec_mode, t->k);
+    }
+    const uint64_t* leaf_src = cb1;
+    const uint64_t* leaf_bs = fine1;
+    if (f2bits) {
+      uint32_t* fcur2 = (uint32_t*)(fine2 + n2 + 1);
+      HIPCHK(hipMemsetAsync(fine2, 0, (n2 + 1) * 8 + n2 * 4, c->stream));
+      rfxk::bin_hist(c, cb1, fine1, (uint32_t)n1, chunk, F2, shift2, rec_mode, t->k, fine2);
+      rfxk::scan_tail(c, fine2, n2);
+      rfxk::part2(c, cb1, cb2, fine2, fcur2, F2, shift2, nullptr, 0, nullptr, nullptr, ~0ull, "k_part4", fine1,
+                  (uint32_t)n1, 0, rec_mode, t->k);
+      leaf_src = cb2;
+      leaf_bs = fine2;
+    }
+    rfxk::msp_leaf(c, nullptr, nullptr, 1, leaf_src, leaf_bs, (uint32_t)n2, t->k, t->canonical, t->lut_t, t->ntab,
+                   sel_bits, 2 * t->k - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur, (uint32_t)f->cap,
+                   cur + ncur, cur + ncur + 1, geo);
+  }
+  drop();  // stream-ordered pool
+  return RFX_OK;
 }
 
 static int msp_emit_queue(rfx_finish* f) {
@@ -1074,94 +1186,174 @@ static int msp_emit_queue(rfx_finish* f) {
   const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
   // One bin count for all segments; more bins when the table holds more than ~1.5 x 16 K instances per
   // bin (several read blocks, or blocks far beyond 1 M reads) -- the LDS table of the leaf is fixed.
-  {
-    uint64_t kmers = 0;
-    uint32_t pmax = 0, pmin = ~0u;
-    for (auto& sg : *t->segs) {
-      kmers += sg.kmers;
-      pmax = std::max(pmax, sg.bins);
-      pmin = std::min(pmin, sg.bins);
-    }
-    int to_bits = ceil_log2(pmax);
-    while (to_bits < 24 && (kmers >> to_bits) > 24576) ++to_bits;
-    if (getenv("RFX_MSP_REFINE_BITS")) to_bits = std::max(to_bits, atoi(getenv("RFX_MSP_REFINE_BITS")));
-    if (pmin < (1u << to_bits)) {
-      int rc = msp_resolve(t);  // refinement replaces segments: settle the adds first
-      if (rc == RFX_OK) rc = msp_refine(t, to_bits);
-      if (rc) return rc;
-    }
+  uint64_t kmers = 0;
+  uint32_t pmax = 0, pmin = ~0u;
+  for (auto& sg : *t->segs) {
+    kmers += sg.kmers;
+    pmax = std::max(pmax, sg.bins);
+    pmin = std::min(pmin, sg.bins);
   }
-  const uint32_t P = t->segs->front().bins;
+  int to_bits = ceil_log2(pmax);
+  while (to_bits < 28 && (kmers >> to_bits) > 24576) ++to_bits;
+  if (getenv("RFX_MSP_REFINE_BITS")) to_bits = std::max(to_bits, atoi(getenv("RFX_MSP_REFINE_BITS")));
+  const bool refine = pmin < (1u << to_bits);
+  std::vector<std::vector<uint64_t>> h_bs;
+  if (refine) {
+    // the chunks are cut by size: settle the pending adds and fetch every segment's bin extents (one sync)
+    int rc = msp_resolve(t);
+    if (rc) return rc;
+    h_bs.resize(t->segs->size());
+    for (size_t i = 0; i < t->segs->size(); ++i) {
+      const rfx_segment& sg = (*t->segs)[i];
+      h_bs[i].assign((size_t)sg.bins + 1, 0);
+      HIPCHK(hipMemcpyAsync(h_bs[i].data(), sg.bin_start, ((size_t)sg.bins + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(ctx_sync(c));
+  }
   const int nseg = (int)t->segs->size();
-  f->h_ptrs.assign(2 * (size_t)nseg, nullptr);
-  f->kmers = 0;
-  for (int i = 0; i < nseg; ++i) {
-    f->h_ptrs[i] = (*t->segs)[i].inst;
-    f->h_ptrs[nseg + i] = (*t->segs)[i].bin_start;
-    f->kmers += (*t->segs)[i].kmers;
-  }
+  f->kmers = kmers;
   if (!f->cap) {
     // Survivors per instance: unknown before counting.  Samples of one run look alike, so the ratio the
     // last emit on this ctx saw (+30 %) is the guess; the first emit assumes a quarter (singletons
-    // dropped) or 60 %.  A guess that is too small costs one rerun with the capacity the cursors report.
+    // dropped; an eighth for big inputs, where a rerun is cheaper than the memory) or 60 %.  A guess that
+    // is too small costs one rerun with the capacity the cursors report.
     const double seen = c->msp_surv_frac[f->lower >= 2 ? 1 : 0];
-    double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? 0.25 : 0.6);
+    double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? (kmers > (1ull << 32) ? 0.125 : 0.25) : 0.6);
     if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
     f->cap = (uint64_t)((double)f->kmers * frac) / P1;
     f->cap += f->cap / 8 + 4096;
   }
   if (f->cap >= (1ull << 32)) f->cap = (1ull << 32) - 1;
-  // sparse bins (small inputs, freshly refined partitions): half-size workgroups, two per CU (measured:
-  // -19 % leaf time at 7.7 K instances per bin, +3 % at 15 K)
-  int geo = f->kmers / P < 8192 ? 1 : 0;
-  if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
   const uint64_t cap = f->cap, room = cap * P1;
   f->room = room;
-  uint32_t Pq = 256;
-  while (Pq < 32768 && (uint64_t)Pq * 1536 < room) Pq <<= 1;
-  const uint32_t P2q = Pq / P1;
-  const rfx_ord_cfg cfg = ord_cfg(t, ceil_log2(Pq));
-  f->d_inst = (const uint64_t**)dmalloc(c, 2 * nseg * sizeof(void*));
-  const uint64_t** d_bs = f->d_inst ? f->d_inst + nseg : nullptr;
+  const rfx_ord_cfg cfg0 = ord_cfg(t, 7);
   f->aw = (uint64_t*)dmalloc(c, room * 8);
   f->ac = (uint32_t*)dmalloc(c, room * 4);
-  f->bw = (uint64_t*)dmalloc(c, room * 8);
-  f->bc = (uint32_t*)dmalloc(c, room * 4);
-  // one zeroed block: fine pos-bin sizes, histogram, coarse cursors ([ncur] = capacity flag,
-  // [ncur+1] = error), fine cursors
-  const size_t zero_bytes = ((size_t)Pq + 1 + RFX_HISTO_BINS) * 8 + (ncur + 2 + (size_t)Pq) * 4;
+  // one zeroed block: histogram, coarse cursors ([ncur] = capacity flag, [ncur+1] = error)
+  const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + 2) * 4;
   f->bsq = (uint64_t*)dmalloc(c, zero_bytes);
-  uint64_t* bsq = f->bsq;
-  unsigned long long* d_histo = bsq ? (unsigned long long*)(bsq + Pq + 1) : nullptr;
-  uint32_t* cur = bsq ? (uint32_t*)(d_histo + RFX_HISTO_BINS) : nullptr;
-  uint32_t* fcur = bsq ? cur + ncur + 2 : nullptr;
-  f->big = records_alloc(c, t->k, t->lsize, t->cols, room);
+  unsigned long long* d_histo = (unsigned long long*)f->bsq;
+  uint32_t* cur = f->bsq ? (uint32_t*)(d_histo + RFX_HISTO_BINS) : nullptr;
   auto fail = [&](int rc) {
     msp_emit_drop(f);
     rfx_records_free(f->big);
     f->big = nullptr;
     return rc;
   };
-  if (!f->d_inst || !f->aw || !f->ac || !f->bw || !f->bc || !f->bsq || !f->big) return fail(RFX_E_NOMEM);
-  hipError_t e = upload(c, f->d_inst, f->h_ptrs.data(), 2 * nseg * sizeof(void*));
-  if (e == hipSuccess) e = hipMemsetAsync(bsq, 0, zero_bytes, c->stream);
+  if (!f->aw || !f->ac || !f->bsq) return fail(RFX_E_NOMEM);
+  hipError_t e = hipMemsetAsync(f->bsq, 0, zero_bytes, c->stream);
   if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
-  rfxk::msp_leaf(c, f->d_inst, d_bs, nseg, f->h_ptrs[0], f->h_ptrs[nseg], P, t->k, t->canonical, t->lut_t, t->ntab,
-                 cfg.sel_bits, cfg.c_bits - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur, (uint32_t)cap,
-                 cur + ncur, cur + ncur + 1, geo);
-  if (f->histo) rfxk::histo_bins(c, f->ac, cur, (uint32_t)cap, d_histo);  // count-of-counts of exactly the survivors
-  rfxk::surv_hist(c, f->aw, cur, (uint32_t)cap, P2q, cfg.bin_shift, bsq);
-  rfxk::scan_tail(c, bsq, Pq);
-  rfxk::part2(c, f->aw, f->bw, bsq, fcur, P2q, cfg.bin_shift, cur, (uint32_t)cap, f->ac, f->bc, ~0ull, "k_surv_part2",
-              nullptr, 0, room);
-  // every survivor is kept and fine bins are exact, so the sort writes the records in place
-  rfxk::surv_sort(c, f->bw, f->bc, bsq, Pq, cfg.bin_shift, t->lut_tinv, t->ntab, cfg.sel_bits, f->big->keys,
-                  f->big->counts, f->big->pos);
-  f->total_out = 0;
-  f->h_cur.assign(ncur + 2, 0);
   f->pflags.assign(t->pend->size(), 1u);
-  e = queue_read(c, &f->total_out, bsq + Pq, 8);
-  if (e == hipSuccess) e = queue_read(c, f->h_cur.data(), cur, (ncur + 2) * 4);
+  f->h_cur.assign(ncur + 2, 0);
+
+  // ---- leaf phase: every minimizer bin counted in LDS, survivors appended to 128 coarse pos bins ----
+  if (!refine) {
+    const uint32_t P = t->segs->front().bins;
+    f->h_ptrs.assign(2 * (size_t)nseg, nullptr);
+    for (int i = 0; i < nseg; ++i) {
+      f->h_ptrs[i] = (*t->segs)[i].inst;
+      f->h_ptrs[nseg + i] = (*t->segs)[i].bin_start;
+    }
+    f->d_inst = (const uint64_t**)dmalloc(c, 2 * nseg * sizeof(void*));
+    if (!f->d_inst) return fail(RFX_E_NOMEM);
+    e = upload(c, f->d_inst, f->h_ptrs.data(), 2 * nseg * sizeof(void*));
+    if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
+    // sparse bins (small inputs): half-size workgroups, two per CU (measured: -19 % leaf time at 7.7 K
+    // instances per bin, +3 % at 15 K)
+    int geo = f->kmers / P < 8192 ? 1 : 0;
+    if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
+    rfxk::msp_leaf(c, f->d_inst, f->d_inst + nseg, nseg, f->h_ptrs[0], f->h_ptrs[nseg], P, t->k, t->canonical, t->lut_t,
+                   t->ntab, cfg0.sel_bits, cfg0.c_bits - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur,
+                   (uint32_t)cap, cur + ncur, cur + ncur + 1, geo);
+  } else {
+    std::map<uint32_t, std::vector<size_t>> groups;
+    for (size_t i = 0; i < t->segs->size(); ++i) groups[(*t->segs)[i].bins].push_back(i);
+    for (auto& kv : groups) {
+      if (kv.first == (1u << to_bits)) {  // already fine enough: all its segments in one launch
+        std::vector<const uint64_t*> ptrs(2 * kv.second.size());
+        uint64_t gk = 0;
+        for (size_t j = 0; j < kv.second.size(); ++j) {
+          ptrs[j] = (*t->segs)[kv.second[j]].inst;
+          ptrs[kv.second.size() + j] = (*t->segs)[kv.second[j]].bin_start;
+          gk += (*t->segs)[kv.second[j]].kmers;
+        }
+        const uint64_t** d = (const uint64_t**)dmalloc(c, ptrs.size() * sizeof(void*));
+        if (!d) return fail(RFX_E_NOMEM);
+        e = upload(c, d, ptrs.data(), ptrs.size() * sizeof(void*));
+        if (e != hipSuccess) { dfree(c, d); hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
+        rfxk::msp_leaf(c, d, d + kv.second.size(), (int)kv.second.size(), ptrs[0], ptrs[kv.second.size()], kv.first, t->k,
+                       t->canonical, t->lut_t, t->ntab, cfg0.sel_bits, cfg0.c_bits - 7, t->pos_lo, t->pos_hi, f->lower,
+                       f->upper, f->aw, f->ac, cur, (uint32_t)cap, cur + ncur, cur + ncur + 1,
+                       gk / kv.first < 8192 ? 1 : 0);
+        dfree(c, d);
+      } else {
+        const int rc = msp_leaf_refined(f, kv.second, kv.first, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
+        if (rc) { (void)ctx_sync(c); return fail(rc); }
+      }
+    }
+    // A big table: look at the flags now, while the records are still there for a rerun, and let the records
+    // go before the survivors are sorted (at WGS scale both do not fit side by side).
+    e = queue_read(c, f->h_cur.data(), cur, (ncur + 2) * 4);
+    if (e == hipSuccess) e = ctx_sync(c);
+    if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
+    if (f->h_cur[ncur + 1]) {
+      snprintf(g_err, sizeof g_err, "MSP: a bin could not be split far enough to fit LDS");
+      return fail(RFX_E_FULL);
+    }
+    if (f->h_cur[ncur]) {  // a coarse pos bin overflowed: once more with what the fullest one needs
+      uint64_t need = 1;
+      for (uint32_t cb = 0; cb < P1; ++cb) need = std::max<uint64_t>(need, f->h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
+      if (need <= f->cap) need = f->cap + f->cap / 4;
+      msp_emit_drop(f);
+      f->cap = need + need / 64 + 1024;
+      return msp_emit_queue(f);
+    }
+    uint64_t rec_bytes = 0;
+    for (auto& sg : *t->segs) rec_bytes += sg.n * 8;
+    if (rec_bytes > (4ull << 30)) {  // a big table is consumed by its finish (rufus_hip.h: rfx_count_finish)
+      p2l_drop_segments(t);
+      f->segs_dropped = true;
+    }
+  }
+  if (f->histo) rfxk::histo_bins(c, f->ac, cur, (uint32_t)cap, d_histo);  // count-of-counts of exactly the survivors
+
+  // ---- survivors -> fine pos bins (<= 1536 expected per bin) -> sorted records ----
+  uint32_t Pq = 256;
+  while (Pq < (1u << 23) && (uint64_t)Pq * 1536 < room) Pq <<= 1;
+  const uint32_t Pq1 = std::min<uint32_t>(Pq, 32768), P2a = Pq1 / P1, F2 = Pq / Pq1;
+  const rfx_ord_cfg cfg1 = ord_cfg(t, ceil_log2(Pq1)), cfg = ord_cfg(t, ceil_log2(Pq));
+  f->bw = (uint64_t*)dmalloc(c, room * 8);
+  f->bc = (uint32_t*)dmalloc(c, room * 4);
+  const size_t z1 = ((size_t)Pq1 + 1) * 8 + (size_t)Pq1 * 4, z2 = F2 > 1 ? ((size_t)Pq + 1) * 8 + (size_t)Pq * 4 : 0;
+  f->bs1 = (uint64_t*)dmalloc(c, z1 + z2);
+  f->big = records_alloc(c, t->k, t->lsize, t->cols, room);
+  if (!f->bw || !f->bc || !f->bs1 || !f->big) return fail(RFX_E_NOMEM);
+  uint64_t* bs1 = f->bs1;
+  uint32_t* fcur1 = (uint32_t*)(bs1 + Pq1 + 1);
+  uint64_t* bs2 = F2 > 1 ? (uint64_t*)((char*)bs1 + z1) : nullptr;
+  uint32_t* fcur2 = bs2 ? (uint32_t*)(bs2 + Pq + 1) : nullptr;
+  e = hipMemsetAsync(bs1, 0, z1 + z2, c->stream);
+  if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
+  rfxk::surv_hist(c, f->aw, cur, (uint32_t)cap, P2a, cfg1.bin_shift, bs1);
+  rfxk::scan_tail(c, bs1, Pq1);
+  rfxk::part2(c, f->aw, f->bw, bs1, fcur1, P2a, cfg1.bin_shift, cur, (uint32_t)cap, f->ac, f->bc, ~0ull, "k_surv_part2",
+              nullptr, 0, room);
+  const uint64_t *sw = f->bw, *sbs = bs1;
+  const uint32_t* sc = f->bc;
+  if (F2 > 1) {  // more than 32768 bins: a second level, back into the (now free) coarse arrays
+    rfxk::bin_hist(c, f->bw, bs1, Pq1, room, F2, cfg.bin_shift, 0, 0, bs2);
+    rfxk::scan_tail(c, bs2, Pq);
+    rfxk::part2(c, f->bw, f->aw, bs2, fcur2, F2, cfg.bin_shift, nullptr, 0, f->bc, f->ac, ~0ull, "k_surv_part3", bs1, Pq1);
+    sw = f->aw;
+    sc = f->ac;
+    sbs = bs2;
+  }
+  // every survivor is kept and fine bins are exact, so the sort writes the records in place
+  rfxk::surv_sort(c, sw, sc, sbs, Pq, cfg.bin_shift, t->lut_tinv, t->ntab, cfg.sel_bits, f->big->keys, f->big->counts,
+                  f->big->pos);
+  f->total_out = 0;
+  e = queue_read(c, &f->total_out, sbs + Pq, 8);
+  if (e == hipSuccess && !refine) e = queue_read(c, f->h_cur.data(), cur, (ncur + 2) * 4);
   for (size_t i = 0; i < f->pflags.size() && e == hipSuccess; ++i)
     e = queue_read(c, &f->pflags[i], (*t->pend)[i].cur + (*t->pend)[i].ncur, 4);
   if (e == hipSuccess && f->histo) e = queue_read(c, f->histo, d_histo, RFX_HISTO_BINS * 8);

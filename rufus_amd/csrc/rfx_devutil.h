@@ -24,6 +24,51 @@ __device__ __forceinline__ uint64_t gf2_mul(const uint64_t* __restrict__ lut, ui
   return r;
 }
 
+constexpr int MSP_WL = 15;    // m-mers per k-mer (window of the sliding minimum); m = k - (MSP_WL - 1)
+constexpr int MSP_NMAX = 4;   // k-mers per record: k + 3 <= 28 bases = 56 bits
+constexpr uint64_t MSP_EMPTY = 1ull << 55;  // no record looks like this: a 1-k-mer record uses 2k <= 50 bits
+
+// One multiply each: 32-bit integer multiplies are quarter rate, and k_msp_part1 hashes every base.
+// The xor keeps the all-A m-mer (c = 0) from hashing to 0 = always the minimum.
+__device__ __forceinline__ uint32_t mmer_hash(uint32_t c) {
+  c = (c ^ 0x5BD1E995u) * 0x9E3779B1u;
+  return c ^ (c >> 15);
+}
+
+// The low 5 bits of a hash are replaced by the position (mod 32) of the m-mer's last base: the sliding
+// minimum then carries the position of the minimizer along for free, and ties between equal m-mers of
+// one window are broken consistently.  Only the upper 27 bits decide the bin.
+constexpr uint32_t MSP_HMASK = ~31u;
+// The minimum of 15 hashes crowds towards 0: spread it again before taking the top bits.
+__device__ __forceinline__ uint32_t msp_binhash(uint32_t minh) { return (minh & MSP_HMASK) * 0xC2B2AE3Du; }
+__device__ __forceinline__ uint32_t msp_bin(uint32_t minh, int bin_bits) {
+  return msp_binhash(minh) >> (32 - bin_bits);  // msp_record_binhash() (rfx_devutil.h) repeats this from the record
+}
+
+__device__ __forceinline__ uint64_t revcomp_bases(uint64_t s, int nbases) {
+  uint64_t y = __brevll(~s);  // complement, then reverse: bit pairs end up swapped inside
+  y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+  return y >> (64 - 2 * nbases);
+}
+
+
+// The bin hash of a super-k-mer record, re-derived from the record itself: bits [63:59] hold the offset of
+// its minimizer m-mer (common to all its k-mers), so one m-mer hash gives every further partition bit.
+// Record: [63:59] minimizer offset, [57:56] k-mers - 1, [55:0] k + n - 1 bases, first base most significant.
+template <bool CANON>
+__device__ __forceinline__ uint32_t msp_record_binhash(uint64_t x, int k) {
+  const int n = (int)((x >> 56) & 3u) + 1, m = k - (MSP_WL - 1);
+  const int L = k + n - 1, mpos = (int)(x >> 59);
+  const uint32_t f = (uint32_t)((x & ((1ull << 56) - 1)) >> (2 * (L - m - mpos))) & ((1u << (2 * m)) - 1);
+  uint32_t c = f;
+  if (CANON) {
+    uint32_t y = __brev(~f);
+    y = ((y & 0xAAAAAAAAu) >> 1) | ((y & 0x55555555u) << 1);
+    c = min(f, y >> (32 - 2 * m));
+  }
+  return msp_binhash(mmer_hash(c));
+}
+
 constexpr int P1_BINS = 128;
 constexpr int P1_S = 8;                       // bases per phase
 constexpr int P1_STAGE = P2_BLOCK * P1_S;     // words staged per phase

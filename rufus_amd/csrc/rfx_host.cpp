@@ -13,6 +13,7 @@
 #include <sys/utsname.h>
 
 #include "../../include/rufus_hip.h"
+#include "rfx_synth.h"
 
 namespace {
 
@@ -382,6 +383,68 @@ long rfx_jhash_header(int k, int lsize, const uint64_t* cols, int canonical, int
   memcpy(buf + 9, js.data(), js.size());
   memset(buf + 9 + js.size(), 0, hlen - js.size());
   return (long)(9 + hlen);
+}
+
+// ---- synthetic workload, host twin of rfx_synth.hip ---------------------------------
+int rfx_synth_check(const rfx_synth* p) {
+  if (!p || p->genome_len < 4000 || p->genome_len >= (1ull << 32) || p->read_len == 0 || p->read_len > 256) return RFX_E_INVAL;
+  if (p->insert_lo < p->read_len || p->insert_span == 0 || p->insert_lo + p->insert_span + 1 >= p->genome_len) return RFX_E_INVAL;
+  if (p->n_snv && (p->genome_len - 2000) / p->n_snv < 2ull * p->read_len + 64) return RFX_E_INVAL;
+  return RFX_OK;
+}
+
+int rfx_synth_snv(const rfx_synth* p, uint32_t i, uint64_t* pos, char* ref, char* alt) {
+  if (rfx_synth_check(p) || i >= p->n_snv) return RFX_E_INVAL;
+  const uint64_t q = rfxs::snv_pos(*p, i);
+  const uint32_t r = rfxs::genome_base(*p, q);
+  if (pos) *pos = q;
+  if (ref) *ref = "ACGT"[r];
+  if (alt) *alt = "ACGT"[rfxs::snv_alt(*p, i, r)];
+  return RFX_OK;
+}
+
+int rfx_synth_genome(const rfx_synth* p, uint64_t first, uint64_t n, char* out) {
+  if (rfx_synth_check(p) || !out || first + n > p->genome_len) return RFX_E_INVAL;
+  for (uint64_t i = 0; i < n; ++i) out[i] = "ACGT"[rfxs::genome_base(*p, first + i)];
+  return RFX_OK;
+}
+
+int rfx_synth_text(const rfx_synth* p, uint64_t first_pair, uint32_t n_pairs, char* seq, char* qual) {
+  if (rfx_synth_check(p) || !seq || !qual) return RFX_E_INVAL;
+  const uint32_t L = p->read_len;
+  const uint64_t st = rfxs::snv_stride(*p);
+  auto one_pair = [&](uint32_t q) {
+    const rfxs::pair_geom g = rfxs::pair_of(*p, first_pair + q);
+    for (int mate = 0; mate < 2; ++mate) {
+      const uint64_t mk = rfxs::mate_key(g, mate);
+      char* s = seq + ((size_t)2 * q + mate) * L;
+      char* ql = qual + ((size_t)2 * q + mate) * L;
+      for (uint32_t j = 0; j < L; ++j) {
+        const uint64_t x = rfxs::base_coord(*p, g, mate, j);
+        uint32_t b = rfxs::genome_base(*p, x);
+        if (p->carrier && g.hap && p->n_snv && x >= 1000) {
+          const uint64_t i = std::min<uint64_t>((x - 1000) / st, p->n_snv - 1);
+          if (rfxs::snv_pos(*p, i) == x) b = rfxs::snv_alt(*p, i, b);
+        }
+        const rfxs::base_out o = rfxs::finish_base(*p, b, mate, rfxs::base_bits(mk, j));
+        s[j] = o.is_n ? 'N' : "ACGT"[o.code];
+        ql[j] = o.lowq ? '#' : 'J';
+      }
+    }
+  };
+  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64);
+  if (const char* ev = getenv("RFX_HOST_THREADS")) nt = std::max(1, atoi(ev));
+  if (n_pairs < 4096 || nt <= 1) {
+    for (uint32_t q = 0; q < n_pairs; ++q) one_pair(q);
+    return RFX_OK;
+  }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      for (uint32_t q = (uint64_t)n_pairs * t / nt, e = (uint64_t)n_pairs * (t + 1) / nt; q < e; ++q) one_pair(q);
+    });
+  for (auto& x : th) x.join();
+  return RFX_OK;
 }
 
 }  // extern "C"

@@ -259,7 +259,13 @@ void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fin
            uint32_t P2, int shift2, const uint32_t* coarse_cur, uint32_t cap_a, const uint32_t* pay_a,
            uint32_t* pay_b, uint64_t cap_b /* entries buf_b can hold */, const char* span,
            const uint64_t* coarse_start = nullptr /* n_coarse+1 explicit coarse extents */, uint32_t n_coarse = 0,
-           uint64_t n_hint = 0 /* expected entries: sizes the grid of a small run */);
+           uint64_t n_hint = 0 /* expected entries: sizes the grid of a small run */,
+           int rec_mode = 0 /* 0: sub-bin = bits of the word; 1 / 2: MSP record (canonical / not), sub-bin = bits
+                               of its minimizer bin hash (shift2 then counts from bit 0 of that 32-bit hash) */,
+           int k = 0, uint64_t fine_base = 0 /* buf_b holds the entries from fine_start value fine_base on */);
+// sizes of the P2 sub-bins of every parent bin: fine_tot[parent * P2 + sub] += ...
+void bin_hist(rfx_ctx*, const uint64_t* src, const uint64_t* parent_start, uint32_t n_parents, uint64_t n_hint,
+              uint32_t P2, int shift2, int rec_mode, int k, uint64_t* fine_tot);
 // MSP path (rfx_msp.hip)
 int msp_k_ok(int k);
 int msp_part1_block();  // threads = reads per chunk of k_msp_part1
@@ -271,10 +277,6 @@ void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* 
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err,
               int geo /* 0: 1024 threads + 8192 slots, 1: 512 + 4096 (two per CU) */);
-// refinement of a record partition from 2^from_bits to 2^to_bits bins: writes each record's slice (the
-// next to_bits-from_bits bits of its minimizer hash) into the record's sub-bin field and counts the new bins
-void slice_tag(rfx_ctx*, uint64_t* inst, const uint64_t* bin_start, int k, int canonical, int from_bits, int to_bits,
-               uint64_t* fine_tot);
 void surv_hist(rfx_ctx*, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,
                uint64_t* fine_tot);
 void flag_if_gt(rfx_ctx*, const uint64_t* d_value, uint64_t limit, unsigned int* d_flag);
@@ -292,6 +294,15 @@ void leaf_compact(rfx_ctx*, const uint64_t* tmp_w, const uint32_t* tmp_counts, c
                   const uint64_t* out_off, uint32_t P, const uint64_t* lut_inv, int ntab, int sel_bits,
                   uint64_t* out_keys, uint32_t* out_counts, uint64_t* out_pos);
 }  // namespace rfxk
+
+// Memory / error plumbing of rfx_api.hip for the other translation units.
+namespace rfxi {
+void* dmalloc(rfx_ctx*, size_t bytes);
+void dfree(rfx_ctx*, void*);
+void set_error(const char* msg);
+hipError_t sync(rfx_ctx*);                                               // stream sync + queued read-backs
+hipError_t queue_read(rfx_ctx*, void* dst, const void* d_src, size_t n);  // lands at the next sync
+}  // namespace rfxi
 
 // Launch bracket: records a HIP-event span on the ctx stream when profiling is on.
 struct rfx_span {

@@ -6,10 +6,12 @@
 //
 //   k_msp_part1  reads -> for every k-mer the minimum of hash(canonical m-mer) over its 15 m-mers
 //                (m = k-14); the minimizer picks one of P bins.  Runs of <= 4 consecutive k-mers with
-//                the same bin become ONE 8-byte record (k+3 bases, run length, fine sub-bin).
+//                the same bin become ONE 8-byte record (k+3 bases, run length, position of the minimizer).
 //                ~3.4 k-mers per record -> 2.4 B per instance.  128 coarse bins; every phase (8 bases of
 //                512 reads) reserves one run per bin and the lanes store their records into it.
-//   k_part2      coarse -> fine bins (same kernel as P2L; the sub-bin is in the record)
+//   k_part2      coarse -> fine bins (same kernel as P2L; the bin is re-derived from the record: ONE m-mer
+//                hash, because the record says where its minimizer sits -- so a partition can be refined
+//                to any depth by plain streaming passes, whatever the size of the sample)
 //   k_msp_leaf   one workgroup per fine bin: expand the records, count canonical k-mers in an LDS
 //                hash table (identical records are merged in a small cache first); every instance of
 //                a k-mer has the same minimizer, so counts are final.
@@ -24,22 +26,6 @@
 #include "rfx_internal.h"
 
 namespace {
-
-constexpr int MSP_WL = 15;    // m-mers per k-mer (window of the sliding minimum); m = k - (MSP_WL - 1)
-constexpr int MSP_NMAX = 4;   // k-mers per record: k + 3 <= 28 bases = 56 bits
-constexpr uint64_t MSP_EMPTY = 1ull << 55;  // no record looks like this: a 1-k-mer record uses 2k <= 50 bits
-
-// One multiply each: 32-bit integer multiplies are quarter rate, and k_msp_part1 hashes every base.
-// The xor keeps the all-A m-mer (c = 0) from hashing to 0 = always the minimum.
-__device__ __forceinline__ uint32_t mmer_hash(uint32_t c) {
-  c = (c ^ 0x5BD1E995u) * 0x9E3779B1u;
-  return c ^ (c >> 15);
-}
-
-// The minimum of 15 hashes crowds towards 0: spread it again before taking the top bits.
-__device__ __forceinline__ uint32_t msp_bin(uint32_t minh, int bin_bits) {
-  return (minh * 0xC2B2AE3Du) >> (32 - bin_bits);  // record_bin_hash() repeats this product
-}
 
 // HMODE 0: scatter into fixed-capacity coarse bins + 16-bit fine histogram (one pass, optimistic)
 //       1: 32-bit fine histogram only            } the exact redo after HMODE 0 raised its flag;
@@ -112,7 +98,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
           cur_m >>= 1;
           fm = ((fm << 2) | code) & mmask;
           rm = (rm >> 2) | ((3u - code) << rmshift);
-          const uint32_t h = mmer_hash(CANON ? min(fm, rm) : fm);
+          const uint32_t h = (mmer_hash(CANON ? min(fm, rm) : fm) & MSP_HMASK) | ((p0 & 24u) | (uint32_t)b);
           a[MSP_WL - 1 + b] = h;
           pm = min(pm, h);
           filled = valid ? filled + 1 : 0;
@@ -128,8 +114,12 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
             if (HMODE != 1 && mine) {
               const int L = k + run_n - 1;
               const uint32_t coarse = run_bin >> sub_bits;
-              wv[b] = (hist & ((1ull << (2 * L)) - 1)) | ((uint64_t)(run_n - 1) << 56) |
-                      ((uint64_t)(run_bin & ((1u << sub_bits) - 1)) << 58);
+              // the record ends at base e = p0 + b - 1; its minimizer m-mer ends at the last base q <= e with
+              // q = run_h (mod 32) -- inside the record, so e - q < 32.  mpos = first base of the m-mer
+              // counted from the record's first base: 0 .. L - m <= 17.
+              const uint32_t back = (p0 + (uint32_t)b - 1u - run_h) & 31u;
+              const uint32_t mpos = (uint32_t)(L - m) - back;
+              wv[b] = (hist & ((1ull << (2 * L)) - 1)) | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)mpos << 59);
               br[b] = (coarse << 16) | atomicAdd(&s_cnt[coarse], 1u);
             }
             if (HMODE == 0 && mine) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
@@ -196,62 +186,8 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) cnt_rows[(uint64_t)blockIdx.x * P + b] = s_fine[b];
 }
 
-__device__ __forceinline__ uint64_t revcomp_bases(uint64_t s, int nbases) {
-  uint64_t y = __brevll(~s);  // complement, then reverse: bit pairs end up swapped inside
-  y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
-  return y >> (64 - 2 * nbases);
-}
-
 __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
   return (uint32_t)((key * 0xD6E8FEB86659FD93ull) >> 32);
-}
-
-// msp_bin's pre-shift value for a record: the minimizer hash of its first k-mer (= of all its k-mers),
-// recomputed exactly as k_msp_part1 does.
-template <bool CANON>
-__device__ __forceinline__ uint32_t record_bin_hash(uint64_t x, int k) {
-  const int n = (int)((x >> 56) & 3u) + 1;
-  const uint64_t S = x & ((1ull << 56) - 1);
-  const uint64_t kmask = (1ull << (2 * k)) - 1;
-  const uint64_t fwd = (S >> (2 * (n - 1))) & kmask;
-  const uint64_t rck = CANON ? revcomp_bases(fwd, k) : 0;
-  const int m = k - (MSP_WL - 1);
-  const uint32_t mmask = (1u << (2 * m)) - 1;
-  uint32_t minh = ~0u;
-#pragma unroll
-  for (int i = 0; i < MSP_WL; ++i) {
-    const uint32_t f = (uint32_t)(fwd >> (2 * (MSP_WL - 1 - i))) & mmask;
-    const uint32_t c = CANON ? min(f, (uint32_t)(rck >> (2 * i)) & mmask) : f;
-    minh = min(minh, mmer_hash(c));
-  }
-  return minh * 0xC2B2AE3Du;
-}
-
-// Too many k-mers per bin for the LDS table (many read blocks in one table, or blocks far beyond 1 M
-// reads): refine the partition.  All k-mers of a record share the minimizer, so the next bits of the
-// same hash split every bin into slices without separating instances of a k-mer.  The slice goes into
-// the record's sub-bin field (free after k_part2), k_part2 then moves the records a third time.
-template <bool CANON>
-__global__ __launch_bounds__(256) void k_slice_tag(uint64_t* __restrict__ inst, const uint64_t* __restrict__ bin_start,
-                                                    uint32_t P, int k, int from_bits, int to_bits,
-                                                    unsigned long long* __restrict__ fine_tot) {
-  __shared__ uint32_t s_cnt[64];
-  const int sbits = to_bits - from_bits;
-  for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
-    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    const uint64_t a = bin_start[bin], e = bin_start[bin + 1];
-    for (uint64_t i = a + threadIdx.x; i < e; i += blockDim.x) {
-      const uint64_t x = inst[i];
-      const uint32_t sl = (record_bin_hash<CANON>(x, k) >> (32 - to_bits)) & ((1u << sbits) - 1);
-      inst[i] = (x & ((1ull << 58) - 1)) | ((uint64_t)sl << 58);
-      atomicAdd(&s_cnt[sl], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < (1u << sbits) && s_cnt[threadIdx.x])
-      atomicAdd(&fine_tot[((uint64_t)bin << sbits) + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
-    __syncthreads();
-  }
 }
 
 constexpr int MSP_ILP = 8;
@@ -663,19 +599,6 @@ void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const
     else RFX_MSP_LEAF(false, 0);
   }
 #undef RFX_MSP_LEAF
-}
-
-void slice_tag(rfx_ctx* c, uint64_t* inst, const uint64_t* bin_start, int k, int canonical, int from_bits, int to_bits,
-               uint64_t* fine_tot) {
-  rfx_span sp(c, "k_slice_tag");
-  const uint32_t P = 1u << from_bits;
-  const uint32_t grid = P < (uint32_t)c->n_cu * 16 ? P : (uint32_t)c->n_cu * 16;
-  if (canonical)
-    hipLaunchKernelGGL(k_slice_tag<true>, dim3(grid), dim3(256), 0, c->stream, inst, bin_start, P, k, from_bits, to_bits,
-                       (unsigned long long*)fine_tot);
-  else
-    hipLaunchKernelGGL(k_slice_tag<false>, dim3(grid), dim3(256), 0, c->stream, inst, bin_start, P, k, from_bits,
-                       to_bits, (unsigned long long*)fine_tot);
 }
 
 void surv_hist(rfx_ctx* c, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,

@@ -325,16 +325,45 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part1(rfx_reads_view rv, const uin
   }
 }
 
+// The sub-bin of an entry: MODE 0 -- bits of the word itself; MODE 1 / 2 -- an MSP super-k-mer record
+// (canonical / not): bits of its minimizer bin hash, re-derived from the record.
+template <int MODE>
+__device__ __forceinline__ uint32_t sub_bin_of(uint64_t w, int shift2, uint32_t P2, int k) {
+  if (MODE == 0) return (uint32_t)(w >> shift2) & (P2 - 1);
+  return ((MODE == 1 ? msp_record_binhash<true>(w, k) : msp_record_binhash<false>(w, k)) >> shift2) & (P2 - 1);
+}
+
+// Sizes of the P2 sub-bins of every parent bin (extents ps[b] .. ps[b+1]); W workgroups share a parent.
+template <int MODE>
+__global__ __launch_bounds__(512) void k_bin_hist(const uint64_t* __restrict__ src, const uint64_t* __restrict__ ps,
+                                                   uint32_t n_parents, uint32_t W, uint32_t P2, int shift2, int k,
+                                                   unsigned long long* __restrict__ fine_tot) {
+  __shared__ uint32_t s_cnt[256];
+  for (uint32_t blk = blockIdx.x; blk < n_parents * W; blk += gridDim.x) {
+    const uint32_t b = blk / W, j = blk - b * W;
+    const uint64_t a = ps[b], e = ps[b + 1];
+    if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = a + (uint64_t)j * blockDim.x + threadIdx.x; i < e; i += (uint64_t)W * blockDim.x)
+      atomicAdd(&s_cnt[sub_bin_of<MODE>(src[i], shift2, P2, k)], 1u);
+    __syncthreads();
+    if (threadIdx.x < P2 && s_cnt[threadIdx.x])
+      atomicAdd(&fine_tot[(uint64_t)b * P2 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    __syncthreads();
+  }
+}
+
 // Coarse bin cb of A -> its P2 fine bins in B.  W workgroups share a coarse bin (tiles strided).
 // PAYLOAD: every word carries a 32-bit count that moves with it (survivors of the MSP leaf).
-template <bool PAYLOAD>
+template <bool PAYLOAD, int MODE>
 __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__ buf_a, uint64_t* __restrict__ buf_b,
                                                      const uint64_t* __restrict__ fine_start,
                                                      uint32_t* __restrict__ fine_cur, uint32_t P2, int shift2,
                                                      uint32_t W, const uint32_t* __restrict__ coarse_cur,
                                                      uint32_t cap_a, const uint32_t* __restrict__ pay_a,
                                                      uint32_t* __restrict__ pay_b, uint64_t cap_b,
-                                                     const uint64_t* __restrict__ coarse_start) {
+                                                     const uint64_t* __restrict__ coarse_start, int k,
+                                                     uint64_t fine_base) {
   __shared__ uint64_t s_stage[L2_TILE];
   __shared__ uint32_t s_pay[PAYLOAD ? L2_TILE : 1];
   __shared__ uint8_t s_sbin[L2_TILE];
@@ -363,7 +392,7 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
     for (int u = 0; u < L2_PER; ++u) {
       br[u] = ~0u;
       if (base + threadIdx.x + (uint64_t)u * L2_BLOCK < e) {
-        const uint32_t sub = (uint32_t)(wv[u] >> shift2) & (P2 - 1);
+        const uint32_t sub = sub_bin_of<MODE>(wv[u], shift2, P2, k);
         br[u] = (sub << 16) | atomicAdd(&s_cnt[sub], 1u);
       }
     }
@@ -375,8 +404,8 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
       const uint64_t f = (uint64_t)cb * P2 + threadIdx.x;
       const uint32_t at = c ? atomicAdd(&fine_cur[f], c) : 0u;
       // never write past the fine bin (only possible after the fused part1 raised its flag)
-      s_gbase[threadIdx.x] = fine_start[f] + at + c <= fine_start[f + 1] && fine_start[f + 1] <= cap_b
-                                 ? fine_start[f] + at
+      s_gbase[threadIdx.x] = fine_start[f] + at + c <= fine_start[f + 1] && fine_start[f + 1] - fine_base <= cap_b
+                                 ? fine_start[f] - fine_base + at
                                  : ~0ull;
       s_cnt[threadIdx.x] = 0;
     }
@@ -743,7 +772,7 @@ void part1_fused(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int 
 void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fine_start, uint32_t* fine_cur,
            uint32_t P2, int shift2, const uint32_t* coarse_cur, uint32_t cap_a, const uint32_t* pay_a,
            uint32_t* pay_b, uint64_t cap_b, const char* span, const uint64_t* coarse_start, uint32_t n_coarse,
-           uint64_t n_hint) {
+           uint64_t n_hint, int rec_mode, int k, uint64_t fine_base) {
   rfx_span sp(c, span);
   // 128 coarse bins: up to 16 workgroups share one (two 8192-entry tiles each when the input is small);
   // thousands (refinement): one each
@@ -756,12 +785,32 @@ void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* f
     const uint64_t tiles = (n_hint / nc + L2_TILE - 1) / L2_TILE;
     W = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(W, (tiles + 1) / 2));
   }
-  if (pay_a)
-    hipLaunchKernelGGL(k_part2<true>, dim3(nc * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start, fine_cur,
-                       P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b, coarse_start);
-  else
-    hipLaunchKernelGGL(k_part2<false>, dim3(nc * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start, fine_cur,
-                       P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b, coarse_start);
+#define RFX_PART2(PAY, MODE)                                                                                          \
+  hipLaunchKernelGGL((k_part2<PAY, MODE>), dim3(nc * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start,       \
+                     fine_cur, P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b, coarse_start, k, fine_base)
+  if (pay_a) RFX_PART2(true, 0);  // payload: survivors (plain words)
+  else if (rec_mode == 0) RFX_PART2(false, 0);
+  else if (rec_mode == 1) RFX_PART2(false, 1);
+  else RFX_PART2(false, 2);
+#undef RFX_PART2
+}
+
+void bin_hist(rfx_ctx* c, const uint64_t* src, const uint64_t* parent_start, uint32_t n_parents, uint64_t n_hint,
+              uint32_t P2, int shift2, int rec_mode, int k, uint64_t* fine_tot) {
+  rfx_span sp(c, "k_bin_hist");
+  if (!n_parents) return;
+  const uint32_t resident = (uint32_t)c->n_cu * 4;
+  uint32_t W = n_parents >= resident ? 1 : resident / n_parents;
+  const uint64_t per = n_hint / n_parents / 2048 + 1;  // a workgroup should see a few thousand entries
+  if (W > per) W = (uint32_t)per;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)n_parents * W, (uint64_t)resident * 8);
+#define RFX_BH(MODE)                                                                                               \
+  hipLaunchKernelGGL(k_bin_hist<MODE>, dim3(grid), dim3(512), 0, c->stream, src, parent_start, n_parents, W, P2, shift2, \
+                     k, (unsigned long long*)fine_tot)
+  if (rec_mode == 0) RFX_BH(0);
+  else if (rec_mode == 1) RFX_BH(1);
+  else RFX_BH(2);
+#undef RFX_BH
 }
 
 void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out) {

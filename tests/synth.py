@@ -99,3 +99,77 @@ def flat_reads(sample: Sample, mates=(1, 2)):
     L = sample.s[0].shape[1]
     off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(L))
     return seq, qual, off
+
+
+# ---------------------------------------------------------------------------------------------------
+# Counter-based workload (include/rufus_hip.h `rfx_synth`, rufus_amd/csrc/rfx_synth.h): an independent
+# numpy restatement of the generator, used to pin the C++ host twin and the device kernel.
+# ---------------------------------------------------------------------------------------------------
+_U = np.uint64
+_PHI, _STEP = _U(0x9E3779B97F4A7C15), _U(0xD6E8FEB86659FD93)
+
+
+def _mix64(z):
+    with np.errstate(over="ignore"):
+        z = np.asarray(z, dtype=np.uint64) + _PHI
+        z = (z ^ (z >> _U(30))) * _U(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> _U(27))) * _U(0x94D049BB133111EB)
+        return z ^ (z >> _U(31))
+
+
+def _scale32(r, rng):
+    return ((r >> _U(32)) * _U(rng)) >> _U(32)
+
+
+def synth_text_np(sy, first_pair: int, n_pairs: int):
+    """(seq, qual) uint8 matrices (2*n_pairs, read_len) of a `capi.Synth` sample, numpy only."""
+    L, G = int(sy.read_len), int(sy.genome_len)
+    with np.errstate(over="ignore"):
+        pair = np.arange(first_pair, first_pair + n_pairs, dtype=np.uint64)
+        key = _mix64(_U(sy.read_seed) ^ (pair * _PHI + _U(1)))
+        k1 = _mix64(key + _U(1))
+        start = _scale32(key, G - (sy.insert_lo + sy.insert_span))
+        end = start + _U(sy.insert_lo) + _scale32(k1, sy.insert_span)
+        hap = (k1 & _U(1)).astype(bool)
+        seq = np.zeros((2 * n_pairs, L), dtype=np.uint8)
+        qual = np.zeros_like(seq)
+        j = np.arange(L, dtype=np.uint64)
+        st = (G - 2000) // sy.n_snv if sy.n_snv else 0
+        for mate in (0, 1):
+            mk = _mix64(key + _U(2 + mate))
+            x = (end[:, None] - _U(1) - j[None, :]) if mate else (start[:, None] + j[None, :])
+            gw = _mix64(_U(sy.genome_seed) ^ ((x >> _U(5)) * _PHI))
+            b = ((gw >> (_U(2) * (x & _U(31)))) & _U(3)).astype(np.int64)
+            if sy.carrier and sy.n_snv:
+                i = np.minimum((np.maximum(x, _U(1000)) - _U(1000)) // _U(st), _U(sy.n_snv - 1))
+                h = _mix64(_U(sy.snv_seed) + i)
+                spos = _U(1000) + i * _U(st) + _scale32(h, st - 64)
+                alt = (b + 1 + ((h & _U(0xFFFF)) % _U(3)).astype(np.int64)) & 3
+                b = np.where((spos == x) & hap[:, None], alt, b)
+            if mate:
+                b = 3 - b
+            r = _mix64(mk[:, None] + ((j[None, :] >> _U(1)) + _U(1)) * _STEP)
+            bits = np.where((j[None, :] & _U(1)) == 1, r >> _U(32), r & _U(0xFFFFFFFF)).astype(np.int64)
+            err = (bits & 1023) < sy.err_1024
+            b = np.where(err, (b + 1 + ((bits >> 10) & 15) % 3) & 3, b)
+            lowq = ((bits >> 14) & 255) < sy.lowq_256
+            is_n = (bits >> 22) < sy.n_1024
+            s = ACGT[b]
+            s[is_n] = ord("N")
+            seq[mate::2] = s
+            qual[mate::2] = np.where(lowq, ord("#"), ord("J"))
+    return seq, qual
+
+
+def synth_flat(seq: np.ndarray, qual: np.ndarray):
+    """(seq bytes, qual bytes, off) of read matrices, for capi.PackedReads."""
+    n, L = seq.shape
+    return seq.tobytes(), qual.tobytes(), np.arange(n + 1, dtype=np.uint64) * np.uint64(L)
+
+
+def synth_fastq(seq: np.ndarray, qual: np.ndarray, first_read: int = 0, tag: bytes = b"@r") -> bytes:
+    """4-line FASTQ text of read matrices."""
+    out = []
+    for i in range(seq.shape[0]):
+        out.append(tag + str(first_read + i).encode() + b"\n" + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n")
+    return b"".join(out)

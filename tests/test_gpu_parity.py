@@ -368,11 +368,11 @@ def test_msp_dense_bins_split_and_survivor_capacity_retry(ctx, monkeypatch):
         x.free()
 
 
-@pytest.mark.parametrize("force_bits", [None, "15"])
+@pytest.mark.parametrize("force_bits", [None, "15", "17"])
 def test_msp_refines_the_partition_when_bins_get_dense(ctx, force_bits, monkeypatch):
     """Four read blocks into one table with 256 bins: > 24 K instances per bin, so finish refines the
-    record partition by further minimizer-hash bits (k_slice_tag + a third k_part2 pass, all segments
-    merged into one) before the LDS count; forced to 2^15 bins it takes two refinement steps.  A block
+    record partition by further minimizer-hash bits (k_bin_hist + a third k_part2 pass over all segments,
+    chunk by chunk into a scratch buffer) before the LDS count; forced to 2^17 bins it takes two levels.  A block
     added after a finish joins at the coarse bin count and is refined at the next finish."""
     monkeypatch.setenv("RFX_P2L_BINS", "256")
     if force_bits:
@@ -394,7 +394,8 @@ def test_msp_refines_the_partition_when_bins_get_dense(ctx, force_bits, monkeypa
     rec = t.finish(2)
     names = ctx.prof_dict()
     ctx.prof(False)
-    assert "k_slice_tag" in names and "k_part3" in names, names
+    assert "k_bin_hist" in names and "k_part3" in names, names
+    assert ("k_part4" in names) == (force_bits == "17"), names
     assert rec.payload() == oracle.count(None, k, size, lower=2, reads=seqs[:n4]).payload()
     rec.free()
     blk = ctx.upload(capi.PackedReads.from_reads([seqs[i] for i in parts[4]]))

@@ -1,21 +1,26 @@
 #!/usr/bin/env python3
 """Headline benchmark: reads/s through the k-mer count + set-difference + read-filter hot path at k=25
-(BASELINE.json metric), with the achieved HBM GB/s of the dominant kernel against the roofline.
+(BASELINE.json metric), with the achieved HBM GB/s of the dominant stage against the roofline.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload wgs|s1] [--genome BASES] [--passes S]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Workload (N=1): BASELINE.json configs[1] -- synthetic 1 M x 150 bp trio (0.5 M pairs per sample, 5 Mb
-genome = 30x, 20 planted SNVs, seed 12345), k=25, jellyfish -s 8G / -L 2, MinCov 5, MaxHashDepth 1200,
-MinQ 15, HashCountThreshold 1.  One step = the whole trio through the path, inputs already packed and
-resident in HBM:  for each of the 3 samples count (K2) -> sorted records + histogram (K3);  mutant
-hash list = subject minus controls (K4);  filter of the subject's 1 M reads (K5).
-value = reads that went through the count stage (3 M per step) / wall time.
+Default workload = BASELINE.json configs[2] (the config the metric is quoted on): synthetic 30x WGS trio,
+3.1 Gb random genome, 3.1e8 pairs of 150 bp per sample (6.2e8 reads), 0.5 % substitution errors, 2 % low-
+quality bases, 0.1 % N, 1000 heterozygous SNVs planted in the child; k = 25, jellyfish -s 8G -L 2, MinCov 5,
+MaxHashDepth 1200, MinQ 15, HashCountThreshold 1.  The reads are generated on the device (counter-based
+generator, rufus_amd/csrc/rfx_synth.h) as packed read blocks and stay resident in HBM: 138 GB for the trio.
 
-N>1 (weak scaling): every rank holds its own 1 M-read block of each sample (same genome, different
-reads).  Per sample the ranks count locally, exchange (key,count) partials by pos-range owner with
-an RCCL all-to-all, reduce at the owner, all-reduce the count-of-counts histogram; the owner slices
-of the mutant set are all-gathered and every rank filters its own subject block.
+One step = the whole trio through the path: S minimizer-shard passes (a sample's 187 GB of super-k-mer
+records do not fit beside the reads; S is planned from the free HBM), each counting shard s of the three
+samples (K2) -> sorted records + histogram (K3) -> subject-minus-controls on the shard (K4); then the filter of
+the subject's reads against the mutant k-mers (K5).  value = reads through the count stage (1.86e9 per step)
+/ wall time.  --genome scales the workload down (same coverage); --workload s1 is configs[1] (1 M reads per
+sample, the round-1 bench).
+
+N > 1: the same trio, read blocks dealt to the ranks (strong scaling): every rank partitions its blocks into
+super-k-mer records, the records travel to the owner of their minimizer bin (RCCL all-to-all over xGMI),
+owners count complete bins; histograms all-reduce, mutant k-mers all-gather, every rank filters its blocks.
 """
 import argparse
 import json
@@ -33,6 +38,12 @@ sys.path.insert(0, ROOT)
 K, JF_SIZE, LOWER = 25, 8 << 30, 2
 MIN_COV, MAX_DEPTH, MIN_Q, THRESH = 5, 1200, 15, 1
 READ_LEN = 150
+SEED = 12345
+
+# every launch of the count -> sorted-records stage, whichever path rfx_count_add/finish took
+K2_CHAIN = ("k_msp_part1", "k_msp_count", "k_bin_offsets", "k_part2", "k_bin_hist", "k_part3", "k_part4", "k_msp_leaf",
+            "k_surv_hist", "k_surv_part2", "k_surv_part3", "k_surv_sort", "k_histo",
+            "k_bin_count", "k_bin_scatter", "k_part1", "k_leaf", "k_leaf_compact", "k_count_reads")
 
 
 def algorithmic_bytes_per_read(L=READ_LEN, k=K):
@@ -41,73 +52,123 @@ def algorithmic_bytes_per_read(L=READ_LEN, k=K):
     return (L + 3) // 4 + (L + 7) // 8 + (L - k + 1) * 16
 
 
-def cpu_baseline(n_pairs, genome_len):
-    """Same path on the host CPU, one thread, on a scaled-down trio of the same shape (30x coverage,
-    same read length / error model): oracle C++ port for count + set difference, the REAL reference
-    binary oracle/_ref/RUFUS.Filter (built from /root/reference/src in the build container) for the filter."""
+def cpu_baseline(seconds_budget=25.0):
+    """The same path on the host cores, on a bounded sample of the SAME workload (first pairs of each sample
+    of the synthetic trio, regenerated as text by the generator's host twin): the oracle's C++ port for
+    count (lock-free CAS hash table, mirrors jf/include/jellyfish/large_hash_array.hpp:708-744) and set
+    difference, the REAL reference binary oracle/_ref/RUFUS.Filter (built from /root/reference/src in the
+    build container) for the filter; at T = 1, 8 and nproc-2 threads (runRufus.sh:796,:967 use T-2)."""
     import oracle
-    from tests.synth import make_trio, fastq_bytes
-    trio = make_trio(genome_len=genome_len, n_pairs=n_pairs, n_snv=8, seed=4242)
-    fq = {n: [fastq_bytes(trio[n], m) for m in (1, 2)] for n in ("child", "mother", "father")}
-    t0 = time.perf_counter()
-    recs = {n: oracle.count(fq[n], K, JF_SIZE, lower=LOWER) for n in fq}
-    t_count = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    hl = oracle.hash_list(recs["child"], [recs["mother"], recs["father"]], MIN_COV, MAX_DEPTH)
-    t_merge = time.perf_counter() - t0
-    kind = "port"
-    d = tempfile.mkdtemp(prefix="rfx_cpu_")
+    from rufus_amd import capi
+    from tests.synth import synth_fastq
+    ncpu = os.cpu_count() or 1
+    out = {"unit": "reads/s", "kind": "port", "by_threads": {}}
     exe = os.path.join(ROOT, "oracle", "_ref", "RUFUS.Filter")
-    if os.path.exists(exe):
-        for m in (1, 2):
-            open(f"{d}/m{m}.fq", "wb").write(fq["child"][m - 1])
-        open(f"{d}/hl", "w").write(hl)
+    for T in sorted({1, min(8, ncpu), max(1, ncpu - 2)}):
+        n_pairs = int(min(4_000_000, 60_000 * T ** 0.8))     # ~ equal wall time per leg
+        G = n_pairs * 10
+        sys_ = [capi.Synth.sample(G, w, n_snv=max(4, G // 1_000_000), seed=SEED) for w in range(3)]
+        texts = [sy.text(0, n_pairs) for sy in sys_]
         t0 = time.perf_counter()
-        subprocess.run([exe, f"{d}/hl", f"{d}/m1.fq", f"{d}/m2.fq", f"{d}/o", str(K), str(MIN_Q), str(THRESH), "1"],
-                       stdout=subprocess.DEVNULL, check=True)
-        t_filter = time.perf_counter() - t0
-        filt = "reference binary oracle/_ref/RUFUS.Filter (-O2)"
-    else:
-        fs = oracle.FilterSet(hl.encode())
+        recs = [oracle.count_reads_matrix(seq, K, JF_SIZE, lower=LOWER, threads=T) for seq, _ in texts]
+        t_count = time.perf_counter() - t0
         t0 = time.perf_counter()
-        fs.pairs(fq["child"][0], fq["child"][1], K, MIN_Q, THRESH)
-        t_filter = time.perf_counter() - t0
-        filt = "oracle port of RUFUS.Filter"
-    reads = 3 * 2 * n_pairs
-    total = t_count + t_merge + t_filter
-    return {"value": reads / total, "unit": "reads/s", "cores": 1, "kind": kind,
-            "sample": f"trio of 3 x {2 * n_pairs} reads x {READ_LEN} bp on a {genome_len} bp genome (30x), k={K}: "
-                      f"count {t_count:.2f}s (oracle C++ port, sort-based) + set difference {t_merge:.2f}s (oracle) + "
-                      f"filter of the subject {t_filter:.2f}s ({filt}), 1 thread each"}
+        hl = oracle.hash_list(recs[0], recs[1:], MIN_COV, MAX_DEPTH)
+        t_merge = time.perf_counter() - t0
+        seq, qual = texts[0]
+        m1, m2 = synth_fastq(seq[0::2], qual[0::2]), synth_fastq(seq[1::2], qual[1::2])
+        if os.path.exists(exe):
+            d = tempfile.mkdtemp(prefix="rfx_cpu_")
+            for m, data in ((1, m1), (2, m2)):
+                open(f"{d}/m{m}.fq", "wb").write(data)
+            open(f"{d}/hl", "w").write(hl)
+            t0 = time.perf_counter()
+            subprocess.run([exe, f"{d}/hl", f"{d}/m1.fq", f"{d}/m2.fq", f"{d}/o", str(K), str(MIN_Q), str(THRESH), str(T)],
+                           stdout=subprocess.DEVNULL, check=True)
+            t_filter = time.perf_counter() - t0
+            filt = "reference binary oracle/_ref/RUFUS.Filter (-O2)"
+            out["kind"] = "port (count, set difference) + reference (filter)"
+        else:
+            fs = oracle.FilterSet(hl.encode())
+            t0 = time.perf_counter()
+            fs.pairs(m1, m2, K, MIN_Q, THRESH)
+            t_filter = time.perf_counter() - t0
+            filt = "oracle port of RUFUS.Filter (1 thread)"
+        reads = 3 * 2 * n_pairs
+        total = t_count + t_merge + t_filter
+        out["by_threads"][str(T)] = {"reads_per_s": reads / total, "reads": reads, "count_s": round(t_count, 2),
+                                     "set_difference_s": round(t_merge, 2), "filter_s": round(t_filter, 2)}
+        out["filter_tool"] = filt
+    best = max(out["by_threads"], key=lambda t_: out["by_threads"][t_]["reads_per_s"])
+    out["value"] = out["by_threads"][best]["reads_per_s"]
+    out["cores"] = int(best)
+    out["host_cores"] = ncpu
+    out["sample"] = ("first pairs of each sample of the same synthetic trio at 30x on a proportionally smaller genome "
+                     "(reads per leg in by_threads), k=25: count = CAS hash-table port (oracle), set difference = oracle, "
+                     f"filter = {out['filter_tool']}")
+    return out
 
 
-def revcomp_keys(keys, k):
-    keys = np.asarray(keys, dtype=np.uint64)
-    r = np.zeros_like(keys)
-    x = keys.copy()
-    for _ in range(k):
-        r = (r << np.uint64(2)) | (np.uint64(3) - (x & np.uint64(3)))
-        x >>= np.uint64(2)
-    return r
+def run_s1(args, ctx, rank, world, dist, torch):
+    """BASELINE.json configs[1]: 1 M x 150 bp reads per sample (per GPU), the round-1 workload."""
+    from rufus_amd import capi
+    from rufus_amd.dist import TrioShard
+    from tests.synth import make_trio, flat_reads
+    trio = make_trio(genome_len=5_000_000, n_pairs=500_000, n_snv=20, seed=SEED, read_seed=1000 + rank)
+    blocks = {}
+    for name in ("child", "mother", "father"):
+        seq, qual, off = flat_reads(trio[name])
+        blocks[name] = ctx.upload(capi.PackedReads(seq, off, qual, MIN_Q, capi.PACK_COUNT | capi.PACK_FILTER))
+    n_reads = blocks["child"].n
+    shard = TrioShard(ctx, K, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, capacity=1 << 26,
+                      group=dist.group.WORLD if world > 1 else None)
+    step = lambda: shard.run(blocks["child"], [blocks["mother"], blocks["father"]])  # noqa: E731
+    desc = (f"synthetic trio, {n_reads} x {READ_LEN} bp reads per sample per GPU (genome 5000000 bp, 20 SNVs, seed "
+            f"{SEED}), k={K}, -s 8G -L {LOWER}, MinCov {MIN_COV}, MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}")
+    return step, 3 * n_reads * world, n_reads, n_reads * world, desc, "weak", {"passes": 1}
+
+
+def run_wgs(args, ctx, rank, world, dist, torch):
+    from rufus_amd import capi, wgs
+    G = args.genome
+    n_pairs = G * args.coverage // (2 * READ_LEN)
+    n_snv = max(20, min(1000, G // 3_000_000))
+    sys_ = [capi.Synth.sample(G, w, n_snv=n_snv, seed=SEED) for w in range(3)]
+    if world > 1:
+        raise SystemExit("--workload wgs on N > 1 ranks: use rufus_amd.wgs.WgsTrio(group=...)")  # TODO next commit
+    free0, total = torch.cuda.mem_get_info()
+    bpp = 2 * (40 + 20 + 8)                                   # bytes per pair: codes + acgt mask + offsets
+    resident = n_pairs * (3 * bpp + 2 * 20)                   # + the subject's quality mask
+    passes = args.passes or wgs.plan_passes(2 * n_pairs, READ_LEN, K, resident + (total - free0), total)
+    t0 = time.perf_counter()
+    samples = [wgs.make_sample(ctx, sy, n_pairs, 1 << 24, MIN_Q, want_good=(i == 0)) for i, sy in enumerate(sys_)]
+    ctx.sync()
+    t_gen = time.perf_counter() - t0
+    trio = wgs.WgsTrio(ctx, K, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes)
+    step = lambda: trio.run(samples)  # noqa: E731
+    n_reads = 2 * n_pairs
+    desc = (f"synthetic {args.coverage}x WGS trio (BASELINE configs[2]): genome {G} bp, {n_reads} x {READ_LEN} bp reads "
+            f"per sample in {len(samples[0])} resident blocks ({resident / 1e9:.0f} GB of packed reads in HBM, generated "
+            f"on the device in {t_gen:.1f} s), {n_snv} SNVs, seed {SEED}, k={K}, -s 8G -L {LOWER}, MinCov {MIN_COV}, "
+            f"MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}; {passes} minimizer-shard pass(es) per step")
+    return step, 3 * n_reads, n_reads, n_reads, desc, "strong", {"passes": passes, "hbm_total": total, "hbm_free_at_start": free0}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--cpu-pairs", type=int, default=200_000, help="pairs per sample of the CPU baseline sample")
-    ap.add_argument("--pairs", type=int, default=500_000, help="read pairs per sample per GPU")
-    ap.add_argument("--genome", type=int, default=5_000_000)
-    ap.add_argument("--capacity", type=int, default=1 << 26, help="initial count-table slots")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=("wgs", "s1"), default="wgs")
+    ap.add_argument("--genome", type=int, default=3_100_000_000, help="wgs: genome length (reads scale with it)")
+    ap.add_argument("--coverage", type=int, default=30)
+    ap.add_argument("--passes", type=int, default=0, help="wgs: minimizer-shard passes (0 = plan from free HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from rufus_amd import capi
-    from rufus_amd.dist import TrioShard
-    from tests.synth import make_trio, flat_reads
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,20 +180,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     ctx = capi.Context(local)   # raises without a gfx950 GPU: no CPU fallback
-    # same genome + SNVs on every rank (seed), different reads per rank (read_seed)
-    trio = make_trio(genome_len=args.genome, n_pairs=args.pairs, n_snv=20, seed=12345, read_seed=1000 + rank)
-    blocks = {}
-    for name in ("child", "mother", "father"):
-        seq, qual, off = flat_reads(trio[name])
-        blocks[name] = ctx.upload(capi.PackedReads(seq, off, qual, MIN_Q, capi.PACK_COUNT | capi.PACK_FILTER))
-    n_reads = blocks["child"].n
-    del trio
-
-    shard = TrioShard(ctx, K, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, capacity=args.capacity,
-                      group=dist.group.WORLD if world > 1 else None)
-
-    def step():
-        return shard.run(blocks["child"], [blocks["mother"], blocks["father"]])
+    step, reads_per_step, reads_per_launch, reads_filtered, desc, scaling, extra = (
+        run_wgs if args.workload == "wgs" else run_s1)(args, ctx, rank, world, dist, torch)
 
     def fence():
         ctx.sync()
@@ -141,35 +190,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # every launch of the count -> sorted-records stage, whichever path rfx_count_add/finish took
-    K2_CHAIN = ("k_msp_part1", "k_msp_count", "k_msp_leaf", "k_surv_hist", "k_surv_part2", "k_surv_sort",
-                "k_bin_count", "k_bin_offsets", "k_bin_scatter", "k_part1", "k_part2", "k_leaf", "k_leaf_compact",
-                "k_count_reads")
-    ctx.prof(True)          # warm the profiling path too (event pool)
+    # HIP-event brackets (rfx_prof_*) on the library's stream around every launch of the count chain and the
+    # filter.  A bracket costs ~10-30 us of host time: nothing against the multi-second WGS step, so there they
+    # stay on for the whole timed region; on the 4 ms S1 step only during the last timed step.
+    ctx.prof_filter(K2_CHAIN + ("k_filter",))
+    ctx.prof(True)
     for _ in range(args.warmup):
         res = step()
-    # Timed region.  The HIP-event brackets that give roofline.achieved cost ~30 us of pipeline
-    # bubble each (measured: 8.5 ms/step with all ~100 launches bracketed, 7.6 ms with none), so they
-    # are live on the launches of the dominant stage during the LAST timed step only.
-    ctx.prof_filter(K2_CHAIN + ("k_filter",))
-    ctx.prof(False)
+    live_all = args.workload == "wgs"
+    ctx.prof(live_all)
     ctx.prof_reset()
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == args.steps - 1:
+        if not live_all and i == args.steps - 1:
             ctx.prof(True)
         res = step()
     fence()
     dt = time.perf_counter() - t0
     prof = ctx.prof_dict()
-    # One extra, untimed step with every launch bracketed, for the per-kernel breakdown.
-    ctx.prof(True)
-    ctx.prof_filter(())
-    ctx.prof_reset()
-    step()
-    fence()
-    prof_all = ctx.prof_dict()
+    prof_steps = args.steps if live_all else 1
     ctx.prof(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -177,58 +217,51 @@ def main():
         dt = float(t.item())
 
     if rank == 0:
-        reads_per_step = 3 * n_reads * world
-        # K2+K3 (count -> sorted records) is the dominant stage.  It is a chain of launches per read
-        # block (MSP path: super-k-mer partition in two levels, LDS count of every minimizer bin,
-        # partition + sort of the survivors); the algorithmic bytes of SURVEY 8(d) K2 cover the stage as
-        # a whole, so the time used for roofline.achieved is the SUM of their average durations.
-        k2 = [n for n in K2_CHAIN if n in prof]
-        n_count = max([prof[n][1] for n in k2] or [0])
-        parts = {n: prof[n][0] / max(prof[n][1], 1) for n in k2}
-        avg_ms = sum(parts.values())
-        bytes_per_launch = algorithmic_bytes_per_read() * n_reads
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms else 0.0
+        # K2+K3 (count -> sorted records) is the dominant stage: a chain of launches per sample (super-k-mer
+        # partition of every read block, refinement of the partition, LDS count of every minimizer bin,
+        # partition + sort of the survivors).  The algorithmic bytes of SURVEY 8(d) K2 cover the stage as a
+        # whole, so one "launch" = the chain of one sample, its duration = the SUM of its kernels' durations.
+        k2 = [n for n in K2_CHAIN if n in prof and prof[n][1]]
+        n_chains = 3 * prof_steps
+        parts = {n: prof[n][0] / n_chains for n in k2}
+        chain_ms = sum(parts.values())
+        bytes_per_launch = algorithmic_bytes_per_read() * reads_per_launch
+        achieved = bytes_per_launch / (chain_ms * 1e-3) / 1e9 if chain_ms else 0.0
+        f_ms = prof["k_filter"][0] / prof_steps if "k_filter" in prof and prof["k_filter"][1] else 0.0
         line = {
             "metric": "reads/sec through k-mer count+filter at k=25",
             "value": reads_per_step * args.steps / dt,
             "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"synthetic trio, {n_reads} x {READ_LEN} bp reads per sample per GPU "
-                                   f"(genome {args.genome} bp, 20 SNVs, seed 12345), k={K}, -s 8G -L {LOWER}, "
-                                   f"MinCov {MIN_COV}, MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}",
-                       "reads_counted_per_step": reads_per_step, "reads_filtered_per_step": n_reads * world,
-                       "parallelism": f"read-block shard x{world}" + (
-                           f", all-to-all of super-k-mer records by {shard.shard_by}-bin owner" if world > 1 else ""),
+            "config": {"workload": desc, "reads_counted_per_step": reads_per_step,
+                       "reads_filtered_per_step": reads_filtered, "parallelism": f"read-block shard x{world}",
                        "mutant_kmers": int(res["n_mutant"]), "pulled_pairs": int(res["n_pulled"]),
-                       "records_subject": int(res["n_records"][0])},
-            "roofline": {"bound": "hbm", "kernel": "+".join(k2), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "avg_launch_ms": avg_ms, "avg_launch_ms_by_kernel": {n: round(v, 4) for n, v in parts.items()},
-                         "launches": int(n_count), "reads_per_launch": n_reads,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                       "records_per_sample": [int(x) for x in res["n_records"]], **extra,
+                       "hbm_peak_bytes": ctx.mem_stats()["peak"], "hbm_mapped_bytes": ctx.mem_stats()["mapped"]},
+            "roofline": {"bound": "hbm", "kernel": "count chain of one sample: " + "+".join(k2), "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "avg_launch_ms": chain_ms, "avg_launch_ms_by_kernel": {n: round(v, 3) for n, v in parts.items()},
+                         "launches": n_chains, "reads_per_launch": reads_per_launch,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "launches_by_kernel_per_chain": {n: round(prof[n][1] / n_chains, 1) for n in k2}},
             # K5 (read filter) against the same roofline: SURVEY 8(d) prices it at 61 B/read of streaming
-            "roofline_filter": (lambda ms: {"bound": "hbm", "kernel": "k_filter", "achieved": 61.0 * n_reads / (ms * 1e-3) / 1e9,
-                                            "peak": 8000.0, "unit": "GB/s", "frac": 61.0 * n_reads / (ms * 1e-3) / 1e9 / 8000.0,
-                                            "avg_launch_ms": ms, "algorithmic_bytes_per_launch": 61 * n_reads})(
-                prof["k_filter"][0] / max(prof["k_filter"][1], 1)) if "k_filter" in prof and prof["k_filter"][0] > 0 else None,
-            "kernels_ms_per_step": {k: round(v[0], 4) for k, v in sorted(prof_all.items())},
-            "kernels_ms_per_step_source": "one extra untimed step with every launch bracketed",
+            "roofline_filter": {"bound": "hbm", "kernel": "k_filter", "achieved": 61.0 * reads_filtered / world / (f_ms * 1e-3) / 1e9,
+                                "peak": 8000.0, "unit": "GB/s",
+                                "frac": 61.0 * reads_filtered / world / (f_ms * 1e-3) / 1e9 / 8000.0,
+                                "ms_per_step": f_ms, "algorithmic_bytes_per_step": 61 * reads_filtered // world} if f_ms else None,
         }
-        # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-        # (profiles/summarize_pmc.py; 2*FETCH_SIZE + WRITE_SIZE, KB -> bytes), default workload only.
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc_path) and args.pairs == 500_000 and args.genome == 5_000_000:
+        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json")
+        if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
-            if "_chain" in pmc and "k_msp_part1" in k2 and "k_msp_part1" in pmc:
+            if pmc.get("genome") in (None, getattr(args, "genome", None)) and "_chain" in pmc:
                 line["roofline"]["traffic"] = pmc["_chain"]["hbm_bytes_per_sample"]
-                line["roofline"]["traffic_source"] = ("profiles/r01_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
-                                                      "all launches of the chain, per sample)")
+                line["roofline"]["traffic_source"] = pmc["_chain"].get("source", pmc_path)
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_pairs * 10)
+                line["cpu_baseline"] = cpu_baseline()
             except Exception as e:   # the baseline is a report, never a reason to lose the measurement
                 line["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 1, "kind": "port",
                                         "sample": f"failed: {e!r}"}

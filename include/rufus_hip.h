@@ -94,6 +94,9 @@ rfx_ctx* rfx_open(int device, size_t hbm_budget_bytes); /* NULL on failure (no C
 void rfx_close(rfx_ctx*);
 int rfx_sync(rfx_ctx*);
 void* rfx_stream(rfx_ctx*); /* the hipStream_t every kernel of this ctx is launched on */
+/* Device memory of the ctx: bytes in use now, the high-water mark of that, and bytes of HBM mapped into the ctx's
+ * arena (the library sub-allocates one growable virtual range; mapped memory is kept until rfx_close). */
+int rfx_mem_stats(rfx_ctx*, uint64_t* used, uint64_t* peak, uint64_t* mapped);
 /* Device-to-device copy on the ctx stream, then stream sync (hand-off to / from buffers another
  * runtime owns, e.g. the RCCL exchange buffers of the multi-GPU path). */
 int rfx_memcpy_dev(rfx_ctx*, void* d_dst, const void* d_src, size_t bytes);

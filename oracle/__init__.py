@@ -49,6 +49,9 @@ def lib():
         L.orc_count_total.restype = C.c_uint64
         L.orc_count_get.argtypes = [C.c_void_p, u64p, u64p, u64p]
         L.orc_merge_unique.restype = C.c_size_t
+        L.orc_count_cas.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_int, u64p,
+                                    C.c_uint64, C.c_uint64]
+        L.orc_count_cas.restype = C.c_size_t
         L.orc_hash_to_long.argtypes = [C.c_char_p, C.c_size_t]
         L.orc_hash_to_long.restype = C.c_uint64
         L.orc_revcomp.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p]
@@ -168,6 +171,32 @@ def count(texts, k: int, size: int, lower: int = 0, upper: int = 2**64 - 1, cano
         keys = np.zeros(n, dtype=np.uint64)
         vals = np.zeros(n, dtype=np.uint64)
         pos = np.zeros(n, dtype=np.uint64)
+        L.orc_count_get(h, _u64p(keys), _u64p(vals), _u64p(pos))
+        return Records(k, lsize, cols, keys, vals, pos, canonical, int(L.orc_count_total(h)))
+    finally:
+        L.orc_count_free(h)
+
+
+def count_reads_matrix(seq: np.ndarray, k: int, size: int, lower: int = 0, upper: int = 2**64 - 1,
+                       canonical: bool = True, threads: int = 1, table_bits: int = 0) -> Records:
+    """The CPU-baseline count: all threads insert into ONE lock-free open-addressed table (the way
+    ``jellyfish count -t`` works, ``orc_count_cas``).  ``seq``: uint8 matrix (n_reads, L) of bases.  Same
+    records as :func:`count`."""
+    L = lib()
+    seq = np.ascontiguousarray(seq, dtype=np.uint8)
+    n, rl = seq.shape
+    if not table_bits:     # distinct k-mers <= windows; errors make ~15 % of the windows distinct at 30x
+        table_bits = max(16, ceil_log2(max(1, n * max(rl - k + 1, 1)) // 2))
+    h = L.orc_count_new(k, int(canonical))
+    try:
+        lsize = ceil_log2(size)
+        cols = jf_matrix(lsize, k)
+        while True:
+            m = L.orc_count_cas(h, seq.ctypes.data, n, rl, table_bits, threads, lsize, _u64p(cols), lower, upper)
+            if m != 2**64 - 1:
+                break
+            table_bits += 1
+        keys, vals, pos = np.zeros(m, np.uint64), np.zeros(m, np.uint64), np.zeros(m, np.uint64)
         L.orc_count_get(h, _u64p(keys), _u64p(vals), _u64p(pos))
         return Records(k, lsize, cols, keys, vals, pos, canonical, int(L.orc_count_total(h)))
     finally:

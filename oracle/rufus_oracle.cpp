@@ -93,6 +93,7 @@ struct Counter {
   bool canonical = true;
   std::vector<uint64_t> mers;           // every k-mer instance (sorted + run-length encoded at finish)
   std::vector<uint64_t> keys, vals, pos;  // finished records in (pos,key) order
+  uint64_t cas_total = 0;                // k-mer instances seen by orc_count_cas
   // rolling state persists across add_seq() calls only inside one read
   void add_read(const char* s, size_t n) {
     // jf/include/jellyfish/mer_iterator.hpp:61-88 -- shift in valid codes, reset on anything else;
@@ -231,12 +232,78 @@ size_t orc_count_finish(void* h, int lsize, const uint64_t* cols, uint64_t lower
   for (size_t i = 0; i < idx.size(); ++i) { c->keys[i] = k[idx[i]]; c->vals[i] = v[idx[i]]; c->pos[i] = pos[idx[i]]; }
   return c->keys.size();
 }
-uint64_t orc_count_total(void* h) { return ((Counter*)h)->mers.size(); }
+uint64_t orc_count_total(void* h) { return ((Counter*)h)->mers.size() + ((Counter*)h)->cas_total; }
 void orc_count_get(void* h, uint64_t* keys, uint64_t* vals, uint64_t* pos) {
   Counter* c = (Counter*)h;
   if (keys) memcpy(keys, c->keys.data(), 8 * c->keys.size());
   if (vals) memcpy(vals, c->vals.data(), 8 * c->vals.size());
   if (pos) memcpy(pos, c->pos.data(), 8 * c->pos.size());
+}
+
+// ---- count, the way jellyfish does it: one lock-free hash table shared by all threads ------------
+// CPU-baseline port of the insert loop (jf/sub_commands/count_main.cc:148-180: every thread iterates its
+// share of the reads and calls ary.add(mer, 1)) and of the table (jf/include/jellyfish/
+// large_hash_array.hpp:298-302 add, :513-601 claim_key with quadratic reprobes i(i+1)/2, :708-723 CAS
+// set_key, :733-744 CAS add_val).  Simplification: slots hold the whole key and a 32-bit count (jellyfish
+// packs a key remainder + 7-bit value with overflow entries) -- same one-random-CAS-per-k-mer access
+// pattern, same results.  seq = n_reads rows of L bases.  Fills the Counter's sorted records like
+// orc_count_finish.  Returns the number of records, or (size_t)-1 when the table is too small.
+size_t orc_count_cas(void* h, const char* seq, size_t n_reads, size_t L, int table_bits, int threads, int lsize,
+                     const uint64_t* cols, uint64_t lower, uint64_t upper) {
+  Counter* c = (Counter*)h;
+  const int k = c->k;
+  const uint64_t slots = (uint64_t)1 << table_bits, smask = slots - 1, EMPTY = ~(uint64_t)0;
+  const uint64_t kmask = k == 32 ? ~(uint64_t)0 : (((uint64_t)1 << (2 * k)) - 1);
+  std::vector<uint64_t> tk(slots, EMPTY);
+  std::vector<uint32_t> tv(slots, 0);
+  uint64_t* keys = tk.data();
+  uint32_t* vals = tv.data();
+  int failed = 0;
+  uint64_t total = 0;
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1024) reduction(+ : total) reduction(| : failed)
+  for (long r = 0; r < (long)n_reads; ++r) {
+    const char* s = seq + (size_t)r * L;
+    uint64_t fwd = 0, rc = 0;
+    int filled = 0;
+    for (size_t i = 0; i < L; ++i) {
+      const int code = jf_code((unsigned char)s[i]);
+      if (code < 0) { filled = 0; continue; }  // mer_iterator.hpp:61-88
+      fwd = ((fwd << 2) | (uint64_t)code) & kmask;
+      rc = (rc >> 2) | ((uint64_t)(3 - code) << (2 * (k - 1)));
+      if (++filled < k) continue;
+      const uint64_t key = c->canonical ? std::min(fwd, rc) : fwd;
+      uint64_t slot = jf_times(cols, 2 * k, key) & smask;  // hash = M * key (large_hash_array.hpp:298-302)
+      bool done = false;
+      for (uint64_t i2 = 0; i2 <= 126 && !done; ++i2) {   // max_reprobe 126 (count_main_cmdline.hpp:361-369)
+        const uint64_t at = (slot + (i2 ? i2 * (i2 + 1) / 2 : 0)) & smask;
+        uint64_t cur = __atomic_load_n(&keys[at], __ATOMIC_RELAXED);
+        if (cur == EMPTY) {
+          uint64_t expect = EMPTY;
+          if (__atomic_compare_exchange_n(&keys[at], &expect, key, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) cur = key;
+          else cur = expect;
+        }
+        if (cur == key) {
+          __atomic_fetch_add(&vals[at], 1u, __ATOMIC_RELAXED);
+          done = true;
+        }
+      }
+      if (!done) failed = 1;
+      ++total;
+    }
+  }
+  if (failed) return (size_t)-1;
+  const uint64_t pmask = lsize >= 64 ? ~(uint64_t)0 : (((uint64_t)1 << lsize) - 1);
+  struct Rec { uint64_t pos, key, val; };
+  std::vector<Rec> recs;
+  for (uint64_t i = 0; i < slots; ++i)
+    if (keys[i] != EMPTY && vals[i] >= lower && vals[i] <= upper)
+      recs.push_back({jf_times(cols, 2 * k, keys[i]) & pmask, keys[i], vals[i]});
+  std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.pos != b.pos ? a.pos < b.pos : a.key < b.key; });
+  c->keys.resize(recs.size()); c->vals.resize(recs.size()); c->pos.resize(recs.size());
+  for (size_t i = 0; i < recs.size(); ++i) { c->keys[i] = recs[i].key; c->vals[i] = recs[i].val; c->pos[i] = recs[i].pos; }
+  c->mers.clear();
+  c->cas_total = total;
+  return recs.size();
 }
 
 // ---- set difference -------------------------------------------------------------------------

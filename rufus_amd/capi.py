@@ -40,6 +40,7 @@ SIGNATURES = {
     "rfx_close": (None, [C.c_void_p]),
     "rfx_sync": (C.c_int, [C.c_void_p]),
     "rfx_stream": (C.c_void_p, [C.c_void_p]),
+    "rfx_mem_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "rfx_memcpy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "rfx_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "rfx_prof_filter": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -257,6 +258,11 @@ class Context:
 
     def sync(self):
         _check(lib().rfx_sync(self._h), "rfx_sync")
+
+    def mem_stats(self) -> dict:
+        u, pk, m = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().rfx_mem_stats(self._h, C.byref(u), C.byref(pk), C.byref(m)), "rfx_mem_stats")
+        return {"used": u.value, "peak": pk.value, "mapped": m.value}
 
     def memcpy_dev(self, dst: int, src: int, nbytes: int):
         _check(lib().rfx_memcpy_dev(self._h, dst, src, nbytes), "rfx_memcpy_dev")

@@ -31,9 +31,9 @@ int hip_fail(hipError_t e, const char* what) {
     }                                     \
   } while (0)
 
-// Device allocations go through a small size-keyed cache: the count tables and record arrays of
-// consecutive samples have the same sizes, and hipMalloc/hipFree of GB-sized blocks cost
-// milliseconds each.  `used` counts live + cached bytes; the cache is dropped before giving up.
+// ---- device memory ---------------------------------------------------------------------------------
+// Default: a growable arena on HIP's virtual memory API (see rfx_ctx).  Fallback (no VMM support, or
+// RFX_NO_ARENA=1): hipMalloc per block behind a small size-keyed cache.
 void pool_release(rfx_ctx* c) {
   for (auto& kv : c->pool) {
     c->used -= kv.first;
@@ -42,9 +42,146 @@ void pool_release(rfx_ctx* c) {
   c->pool.clear();
 }
 
+constexpr size_t ARENA_CHUNK = 1ull << 30;  // physical memory is mapped 1 GB at a time
+
+bool arena_init(rfx_ctx* c) {
+  if (c->arena || c->arena_off) return c->arena != nullptr;
+  if (getenv("RFX_NO_ARENA")) { c->arena_off = true; return false; }
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = c->device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || !gran) {
+    c->arena_off = true;
+    (void)hipGetLastError();
+    return false;
+  }
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 288ull << 30;
+  size_t reserve = ((total_b + (8ull << 30)) + ARENA_CHUNK - 1) / ARENA_CHUNK * ARENA_CHUNK;
+  void* base = nullptr;
+  if (hipMemAddressReserve(&base, reserve, gran, nullptr, 0) != hipSuccess || !base) {
+    c->arena_off = true;
+    (void)hipGetLastError();
+    return false;
+  }
+  c->arena = (char*)base;
+  c->arena_reserved = reserve;
+  c->arena_gran = gran;
+  return true;
+}
+
+// Map more physical memory behind the high-water mark so that a free range of `need` bytes ends there.
+bool arena_grow(rfx_ctx* c, size_t need) {
+  size_t tail = 0;  // free bytes already sitting at the end of the mapped part
+  if (!c->arena_free.empty()) {
+    auto last = std::prev(c->arena_free.end());
+    if (last->first + last->second == c->arena_mapped) tail = last->second;
+  }
+  size_t add = need > tail ? need - tail : 0;
+  add = (add + ARENA_CHUNK - 1) / ARENA_CHUNK * ARENA_CHUNK;
+  if (!add) return true;
+  if (c->arena_mapped + add > c->arena_reserved) return false;
+  if (c->budget && c->arena_mapped + add > c->budget + ARENA_CHUNK) return false;
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = c->device;
+  hipMemAccessDesc ad = {};
+  ad.location.type = hipMemLocationTypeDevice;
+  ad.location.id = c->device;
+  ad.flags = hipMemAccessFlagsProtReadWrite;
+  size_t done = 0;
+  while (done < add) {
+    hipMemGenericAllocationHandle_t h;
+    if (hipMemCreate(&h, ARENA_CHUNK, &prop, 0) != hipSuccess) break;
+    char* at = c->arena + c->arena_mapped + done;
+    if (hipMemMap(at, ARENA_CHUNK, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); break; }
+    if (hipMemSetAccess(at, ARENA_CHUNK, &ad, 1) != hipSuccess) {
+      (void)hipMemUnmap(at, ARENA_CHUNK);
+      (void)hipMemRelease(h);
+      break;
+    }
+    c->arena_handles.push_back((void*)h);
+    done += ARENA_CHUNK;
+  }
+  (void)hipGetLastError();
+  if (done) {  // whatever was mapped joins the free list (merged with a free tail)
+    const size_t off = c->arena_mapped;
+    c->arena_mapped += done;
+    auto last = c->arena_free.empty() ? c->arena_free.end() : std::prev(c->arena_free.end());
+    if (last != c->arena_free.end() && last->first + last->second == off) last->second += done;
+    else c->arena_free[off] = done;
+  }
+  return done >= add;
+}
+
+void arena_destroy(rfx_ctx* c) {
+  if (!c->arena) return;
+  for (size_t i = 0; i < c->arena_handles.size(); ++i) {
+    (void)hipMemUnmap(c->arena + i * ARENA_CHUNK, ARENA_CHUNK);
+    (void)hipMemRelease((hipMemGenericAllocationHandle_t)c->arena_handles[i]);
+  }
+  (void)hipMemAddressFree(c->arena, c->arena_reserved);
+  c->arena = nullptr;
+  c->arena_handles.clear();
+  c->arena_free.clear();
+  c->arena_mapped = 0;
+}
+
+void* arena_alloc(rfx_ctx* c, size_t bytes) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    // best fit among the free ranges (ties: lowest address) -- keeps the big holes for the big blocks
+    auto best = c->arena_free.end();
+    for (auto it = c->arena_free.begin(); it != c->arena_free.end(); ++it)
+      if (it->second >= bytes && (best == c->arena_free.end() || it->second < best->second)) best = it;
+    if (best != c->arena_free.end()) {
+      const size_t off = best->first, len = best->second;
+      c->arena_free.erase(best);
+      if (len > bytes) c->arena_free[off + bytes] = len - bytes;
+      c->used += bytes;
+      if (c->used > c->peak_used) c->peak_used = c->used;
+      void* p = c->arena + off;
+      c->allocs[p] = bytes;
+      return p;
+    }
+    if (attempt || !arena_grow(c, bytes)) break;
+  }
+  snprintf(g_err, sizeof g_err, "out of device memory: %zu bytes wanted, %zu in use, %zu mapped", bytes, c->used,
+           c->arena_mapped);
+  return nullptr;
+}
+
+void arena_free_range(rfx_ctx* c, void* p, size_t bytes) {
+  size_t off = (size_t)((char*)p - c->arena), len = bytes;
+  auto next = c->arena_free.lower_bound(off);
+  if (next != c->arena_free.begin()) {
+    auto prev = std::prev(next);
+    if (prev->first + prev->second == off) {
+      off = prev->first;
+      len += prev->second;
+      c->arena_free.erase(prev);
+    }
+  }
+  if (next != c->arena_free.end() && off + len == next->first) {
+    len += next->second;
+    c->arena_free.erase(next);
+  }
+  c->arena_free[off] = len;
+  c->used -= bytes;
+}
+
 void* dmalloc(rfx_ctx* c, size_t bytes) {
   bytes = (bytes + 255) & ~(size_t)255;
   if (bytes == 0) bytes = 256;
+  if (arena_init(c)) {
+    if (c->budget && c->used + bytes > c->budget) {
+      snprintf(g_err, sizeof g_err, "hbm budget exceeded: %zu + %zu > %zu", c->used, bytes, c->budget);
+      return nullptr;
+    }
+    return arena_alloc(c, bytes);
+  }
   auto it = c->pool.lower_bound(bytes);
   if (it != c->pool.end() && it->first <= bytes + bytes / 4) {
     void* p = it->second;
@@ -81,9 +218,10 @@ void dfree(rfx_ctx* c, void* p) {
   }
   const size_t bytes = it->second;
   c->allocs.erase(it);
-  // Everything on this ctx runs on one stream, so a cached block is safe to hand out again: work
+  // Everything on this ctx runs on one stream, so a freed block is safe to hand out again: work
   // that still uses it is ordered before any later kernel or copy on that stream.
-  c->pool.emplace(bytes, p);
+  if (c->arena && (char*)p >= c->arena && (char*)p < c->arena + c->arena_reserved) arena_free_range(c, p, bytes);
+  else c->pool.emplace(bytes, p);
 }
 
 // ---- pinned scratch -------------------------------------------------------------------------------
@@ -465,8 +603,10 @@ void rfx_close(rfx_ctx* c) {
   (void)hipSetDevice(c->device);
   ctx_sync(c);
   resolve_spans(c);
-  for (auto& kv : c->allocs) (void)hipFree(kv.first);
+  for (auto& kv : c->allocs)
+    if (!c->arena || (char*)kv.first < c->arena || (char*)kv.first >= c->arena + c->arena_reserved) (void)hipFree(kv.first);
   pool_release(c);
+  arena_destroy(c);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   if (c->pin) (void)hipHostFree(c->pin);
   (void)hipStreamDestroy(c->stream);
@@ -480,6 +620,14 @@ int rfx_sync(rfx_ctx* c) {
 }
 
 void* rfx_stream(rfx_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int rfx_mem_stats(rfx_ctx* c, uint64_t* used, uint64_t* peak, uint64_t* mapped) {
+  if (!c) return RFX_E_NODEVICE;
+  if (used) *used = c->used;
+  if (peak) *peak = c->peak_used;
+  if (mapped) *mapped = c->arena_mapped;
+  return RFX_OK;
+}
 
 int rfx_memcpy_dev(rfx_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
   if (!c || (bytes && (!d_dst || !d_src))) return RFX_E_INVAL;
@@ -1093,89 +1241,158 @@ static void msp_emit_drop(rfx_finish* f) {
 // or a WGS-scale sample): the bins are refined chunk by chunk into a scratch buffer -- histogram of the next
 // <= 8 bits of every record's bin hash, scan, scatter (twice when more than 8 bits are missing) -- and the
 // leaf counts each chunk as it appears.  Plain streaming passes; the scratch is a fraction of the records.
-static int msp_leaf_refined(rfx_finish* f, const std::vector<size_t>& group, uint32_t b, int to_bits,
-                            const std::vector<std::vector<uint64_t>>& h_bs, int sel_bits, uint32_t* cur, size_t ncur) {
+// Segments come in groups of equal bin count (imports from other ranks may differ from local blocks): every
+// group below the target is refined on its own, the leaf then sees all groups' versions of a chunk's bins.
+static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::vector<uint64_t>>& h_bs, int sel_bits,
+                            uint32_t* cur, size_t ncur) {
   rfx_table* t = f->t;
   rfx_ctx* c = t->ctx;
-  const int from_bits = ceil_log2(b);
-  const int fbits = to_bits - from_bits;
-  if (fbits > 16) {
-    snprintf(g_err, sizeof g_err, "MSP: partition would need %d more bits", fbits);
-    return RFX_E_FULL;
-  }
-  const int f1bits = std::min(8, fbits), f2bits = fbits - f1bits;
-  const uint32_t F1 = 1u << f1bits, F2 = 1u << f2bits, F = F1 * F2;
   const int rec_mode = t->canonical ? 1 : 2;
-  // per-parent sizes over the group's segments, chunk boundaries by size
-  std::vector<uint64_t> sz(b, 0);
-  uint64_t R = 0, kmers = 0;
-  for (size_t si : group) {
-    for (uint32_t p = 0; p < b; ++p) sz[p] += h_bs[si][p + 1] - h_bs[si][p];
-    R += h_bs[si][b];
-    kmers += (*t->segs)[si].kmers;
+  struct group {
+    uint32_t b = 0;
+    int from_bits = 0, f1bits = 0, f2bits = 0;
+    std::vector<size_t> segs;
+    uint64_t *cb1 = nullptr, *cb2 = nullptr, *fine1 = nullptr, *fine2 = nullptr;
+    uint64_t max_chunk = 0;
+  };
+  std::map<uint32_t, group> groups;
+  uint64_t kmers = 0;
+  for (size_t i = 0; i < t->segs->size(); ++i) {
+    group& g = groups[(*t->segs)[i].bins];
+    g.b = (*t->segs)[i].bins;
+    g.segs.push_back(i);
+    kmers += (*t->segs)[i].kmers;
   }
+  const uint32_t bmin = groups.begin()->first;
+  const uint32_t Ftot = (1u << to_bits) / bmin;  // fine bins per coarsest bin
+  for (auto& kv : groups) {
+    group& g = kv.second;
+    g.from_bits = ceil_log2(g.b);
+    const int fbits = to_bits - g.from_bits;
+    if (fbits > 16) {
+      snprintf(g_err, sizeof g_err, "MSP: partition would need %d more bits", fbits);
+      return RFX_E_FULL;
+    }
+    g.f1bits = std::min(8, fbits);
+    g.f2bits = fbits - g.f1bits;
+  }
+  // chunks of coarsest-level bins, cut by size (all groups together)
+  std::vector<uint64_t> sz(bmin, 0);
+  uint64_t R = 0;
+  for (auto& kv : groups)
+    for (size_t si : kv.second.segs) {
+      const uint32_t r = kv.second.b / bmin;
+      for (uint32_t p = 0; p < bmin; ++p) sz[p] += h_bs[si][(size_t)(p + 1) * r] - h_bs[si][(size_t)p * r];
+      R += h_bs[si][kv.second.b];
+    }
   const uint64_t target = std::max<uint64_t>(R / 16, 1ull << 25);
-  const uint32_t max_parents = std::max<uint32_t>(1, (1u << 22) / F);
+  const uint32_t max_parents = std::max<uint32_t>(1, (1u << 22) / Ftot);
   std::vector<uint32_t> cut{0};
-  uint64_t acc = 0, max_chunk = 0;
-  for (uint32_t p = 0; p < b; ++p) {
+  uint64_t acc = 0;
+  for (uint32_t p = 0; p < bmin; ++p) {
     if (p > cut.back() && (acc + sz[p] > target || p - cut.back() >= max_parents)) {
-      max_chunk = std::max(max_chunk, acc);
       cut.push_back(p);
       acc = 0;
     }
     acc += sz[p];
   }
-  max_chunk = std::max(max_chunk, acc);
-  cut.push_back(b);
+  cut.push_back(bmin);
   uint32_t max_np = 0;
   for (size_t i = 0; i + 1 < cut.size(); ++i) max_np = std::max(max_np, cut[i + 1] - cut[i]);
-  const size_t n1max = (size_t)max_np * F1, n2max = (size_t)max_np * F;
-  uint64_t* cb1 = (uint64_t*)dmalloc(c, std::max<uint64_t>(max_chunk, 1) * 8);
-  uint64_t* cb2 = f2bits ? (uint64_t*)dmalloc(c, std::max<uint64_t>(max_chunk, 1) * 8) : nullptr;
-  uint64_t* fine1 = (uint64_t*)dmalloc(c, (n1max + 1) * 8 + n1max * 4);
-  uint64_t* fine2 = f2bits ? (uint64_t*)dmalloc(c, (n2max + 1) * 8 + n2max * 4) : nullptr;
-  auto drop = [&] { dfree(c, cb1); dfree(c, cb2); dfree(c, fine1); dfree(c, fine2); };
-  if (!cb1 || !fine1 || (f2bits && (!cb2 || !fine2))) { drop(); return RFX_E_NOMEM; }
-  const int shift1 = 32 - (from_bits + f1bits), shift2 = 32 - to_bits;
-  const int geo_default = kmers / ((uint64_t)b * F) < 8192 ? 1 : 0;
-  int geo = geo_default;
+  auto drop = [&] {
+    for (auto& kv : groups) {
+      dfree(c, kv.second.cb1); dfree(c, kv.second.cb2); dfree(c, kv.second.fine1); dfree(c, kv.second.fine2);
+    }
+  };
+  size_t nleaf = 0;  // segments the leaf sees: one per refined group + the segments already at the target
+  for (auto& kv : groups) {
+    group& g = kv.second;
+    if (g.f1bits == 0) {
+      nleaf += g.segs.size();
+      continue;
+    }
+    ++nleaf;
+    const uint32_t r = g.b / bmin;
+    for (size_t ci = 0; ci + 1 < cut.size(); ++ci) {
+      uint64_t ch = 0;
+      for (size_t si : g.segs) ch += h_bs[si][(size_t)cut[ci + 1] * r] - h_bs[si][(size_t)cut[ci] * r];
+      g.max_chunk = std::max(g.max_chunk, ch);
+    }
+    const size_t n1max = (size_t)max_np * r << g.f1bits, n2max = (size_t)max_np * Ftot;
+    g.cb1 = (uint64_t*)dmalloc(c, std::max<uint64_t>(g.max_chunk, 1) * 8);
+    g.fine1 = (uint64_t*)dmalloc(c, (n1max + 1) * 8 + n1max * 4);
+    if (g.f2bits) {
+      g.cb2 = (uint64_t*)dmalloc(c, std::max<uint64_t>(g.max_chunk, 1) * 8);
+      g.fine2 = (uint64_t*)dmalloc(c, (n2max + 1) * 8 + n2max * 4);
+    }
+    if (!g.cb1 || !g.fine1 || (g.f2bits && (!g.cb2 || !g.fine2))) { drop(); return RFX_E_NOMEM; }
+  }
+  const uint64_t** d_ptrs = (const uint64_t**)dmalloc(c, 2 * nleaf * sizeof(void*) * (cut.size() - 1));
+  if (!d_ptrs) { drop(); return RFX_E_NOMEM; }
+  int geo = kmers >> to_bits < 8192 ? 1 : 0;
   if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
   for (size_t ci = 0; ci + 1 < cut.size(); ++ci) {
     const uint32_t p0 = cut[ci], np = cut[ci + 1] - cut[ci];
-    uint64_t chunk = 0;
-    for (uint32_t p = p0; p < p0 + np; ++p) chunk += sz[p];
-    if (!chunk) continue;
-    const size_t n1 = (size_t)np * F1, n2 = (size_t)np * F;
-    uint32_t* fcur1 = (uint32_t*)(fine1 + n1 + 1);
-    HIPCHK(hipMemsetAsync(fine1, 0, (n1 + 1) * 8 + n1 * 4, c->stream));
-    for (size_t si : group) {
-      const rfx_segment& sg = (*t->segs)[si];
-      rfxk::bin_hist(c, sg.inst, sg.bin_start + p0, np, chunk, F1, shift1, rec_mode, t->k, fine1);
+    const size_t n2 = (size_t)np * Ftot;
+    std::vector<const uint64_t*> ptrs(2 * nleaf);
+    size_t li = 0;
+    uint64_t chunk_all = 0;
+    for (auto& kv : groups) {
+      group& g = kv.second;
+      const uint32_t r = g.b / bmin, gp0 = p0 * r, gnp = np * r;
+      if (g.f1bits == 0) {  // already at the target: the leaf reads the bins in place
+        for (size_t si : g.segs) {
+          ptrs[li] = (*t->segs)[si].inst;
+          ptrs[nleaf + li] = (*t->segs)[si].bin_start + gp0;
+          ++li;
+          chunk_all += h_bs[si][(size_t)gp0 + gnp] - h_bs[si][gp0];
+        }
+        continue;
+      }
+      uint64_t chunk = 0;
+      for (size_t si : g.segs) chunk += h_bs[si][(size_t)gp0 + gnp] - h_bs[si][gp0];
+      chunk_all += chunk;
+      const uint32_t F1 = 1u << g.f1bits, F2 = 1u << g.f2bits;
+      const int shift1 = 32 - (g.from_bits + g.f1bits), shift2 = 32 - to_bits;
+      const size_t n1 = (size_t)gnp * F1;
+      uint32_t* fcur1 = (uint32_t*)(g.fine1 + n1 + 1);
+      HIPCHK(hipMemsetAsync(g.fine1, 0, (n1 + 1) * 8 + n1 * 4, c->stream));
+      if (chunk) {
+        for (size_t si : g.segs)
+          rfxk::bin_hist(c, (*t->segs)[si].inst, (*t->segs)[si].bin_start + gp0, gnp, chunk, F1, shift1, rec_mode, t->k,
+                         g.fine1);
+        rfxk::scan_tail(c, g.fine1, n1);
+        for (size_t si : g.segs)
+          rfxk::part2(c, (*t->segs)[si].inst, g.cb1, g.fine1, fcur1, F1, shift1, nullptr, 0, nullptr, nullptr, ~0ull,
+                      "k_part3", (*t->segs)[si].bin_start + gp0, gnp, 0, rec_mode, t->k);
+      }
+      const uint64_t *leaf_src = g.cb1, *leaf_bs = g.fine1;
+      if (g.f2bits) {
+        uint32_t* fcur2 = (uint32_t*)(g.fine2 + n2 + 1);
+        HIPCHK(hipMemsetAsync(g.fine2, 0, (n2 + 1) * 8 + n2 * 4, c->stream));
+        if (chunk) {
+          rfxk::bin_hist(c, g.cb1, g.fine1, (uint32_t)n1, chunk, F2, shift2, rec_mode, t->k, g.fine2);
+          rfxk::scan_tail(c, g.fine2, n2);
+          rfxk::part2(c, g.cb1, g.cb2, g.fine2, fcur2, F2, shift2, nullptr, 0, nullptr, nullptr, ~0ull, "k_part4", g.fine1,
+                      (uint32_t)n1, 0, rec_mode, t->k);
+        }
+        leaf_src = g.cb2;
+        leaf_bs = g.fine2;
+      }
+      ptrs[li] = leaf_src;
+      ptrs[nleaf + li] = leaf_bs;
+      ++li;
     }
-    rfxk::scan_tail(c, fine1, n1);
-    for (size_t si : group) {
-      const rfx_segment& sg = (*t->segs)[si];
-      rfxk::part2(c, sg.inst, cb1, fine1, fcur1, F1, shift1, nullptr, 0, nullptr, nullptr, ~0ull, "k_part3",
-                  sg.bin_start + p0, np, 0, rec_mode, t->k);
-    }
-    const uint64_t* leaf_src = cb1;
-    const uint64_t* leaf_bs = fine1;
-    if (f2bits) {
-      uint32_t* fcur2 = (uint32_t*)(fine2 + n2 + 1);
-      HIPCHK(hipMemsetAsync(fine2, 0, (n2 + 1) * 8 + n2 * 4, c->stream));
-      rfxk::bin_hist(c, cb1, fine1, (uint32_t)n1, chunk, F2, shift2, rec_mode, t->k, fine2);
-      rfxk::scan_tail(c, fine2, n2);
-      rfxk::part2(c, cb1, cb2, fine2, fcur2, F2, shift2, nullptr, 0, nullptr, nullptr, ~0ull, "k_part4", fine1,
-                  (uint32_t)n1, 0, rec_mode, t->k);
-      leaf_src = cb2;
-      leaf_bs = fine2;
-    }
-    rfxk::msp_leaf(c, nullptr, nullptr, 1, leaf_src, leaf_bs, (uint32_t)n2, t->k, t->canonical, t->lut_t, t->ntab,
+    if (!chunk_all) continue;
+    const uint64_t** d = d_ptrs + 2 * nleaf * ci;
+    const hipError_t e = upload(c, d, ptrs.data(), 2 * nleaf * sizeof(void*));
+    if (e != hipSuccess) { drop(); dfree(c, d_ptrs); return hip_fail(e, "msp_leaf_refined"); }
+    rfxk::msp_leaf(c, d, d + nleaf, (int)nleaf, ptrs[0], ptrs[nleaf], (uint32_t)n2, t->k, t->canonical, t->lut_t, t->ntab,
                    sel_bits, 2 * t->k - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur, (uint32_t)f->cap,
                    cur + ncur, cur + ncur + 1, geo);
   }
   drop();  // stream-ordered pool
+  dfree(c, d_ptrs);
   return RFX_OK;
 }
 
@@ -1215,10 +1432,10 @@ static int msp_emit_queue(rfx_finish* f) {
   if (!f->cap) {
     // Survivors per instance: unknown before counting.  Samples of one run look alike, so the ratio the
     // last emit on this ctx saw (+30 %) is the guess; the first emit assumes a quarter (singletons
-    // dropped; an eighth for big inputs, where a rerun is cheaper than the memory) or 60 %.  A guess that
+    // dropped; 8 % for big inputs, where a rerun is cheaper than the memory) or 60 %.  A guess that
     // is too small costs one rerun with the capacity the cursors report.
     const double seen = c->msp_surv_frac[f->lower >= 2 ? 1 : 0];
-    double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? (kmers > (1ull << 32) ? 0.125 : 0.25) : 0.6);
+    double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? (kmers > (1ull << 32) ? 0.08 : 0.25) : 0.6);
     if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
     f->cap = (uint64_t)((double)f->kmers * frac) / P1;
     f->cap += f->cap / 8 + 4096;
@@ -1266,30 +1483,9 @@ static int msp_emit_queue(rfx_finish* f) {
                    t->ntab, cfg0.sel_bits, cfg0.c_bits - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur,
                    (uint32_t)cap, cur + ncur, cur + ncur + 1, geo);
   } else {
-    std::map<uint32_t, std::vector<size_t>> groups;
-    for (size_t i = 0; i < t->segs->size(); ++i) groups[(*t->segs)[i].bins].push_back(i);
-    for (auto& kv : groups) {
-      if (kv.first == (1u << to_bits)) {  // already fine enough: all its segments in one launch
-        std::vector<const uint64_t*> ptrs(2 * kv.second.size());
-        uint64_t gk = 0;
-        for (size_t j = 0; j < kv.second.size(); ++j) {
-          ptrs[j] = (*t->segs)[kv.second[j]].inst;
-          ptrs[kv.second.size() + j] = (*t->segs)[kv.second[j]].bin_start;
-          gk += (*t->segs)[kv.second[j]].kmers;
-        }
-        const uint64_t** d = (const uint64_t**)dmalloc(c, ptrs.size() * sizeof(void*));
-        if (!d) return fail(RFX_E_NOMEM);
-        e = upload(c, d, ptrs.data(), ptrs.size() * sizeof(void*));
-        if (e != hipSuccess) { dfree(c, d); hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
-        rfxk::msp_leaf(c, d, d + kv.second.size(), (int)kv.second.size(), ptrs[0], ptrs[kv.second.size()], kv.first, t->k,
-                       t->canonical, t->lut_t, t->ntab, cfg0.sel_bits, cfg0.c_bits - 7, t->pos_lo, t->pos_hi, f->lower,
-                       f->upper, f->aw, f->ac, cur, (uint32_t)cap, cur + ncur, cur + ncur + 1,
-                       gk / kv.first < 8192 ? 1 : 0);
-        dfree(c, d);
-      } else {
-        const int rc = msp_leaf_refined(f, kv.second, kv.first, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
-        if (rc) { (void)ctx_sync(c); return fail(rc); }
-      }
+    {
+      const int rc = msp_leaf_refined(f, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
+      if (rc) { (void)ctx_sync(c); return fail(rc); }
     }
     // A big table: look at the flags now, while the records are still there for a rerun, and let the records
     // go before the survivors are sorted (at WGS scale both do not fit side by side).
@@ -1318,15 +1514,23 @@ static int msp_emit_queue(rfx_finish* f) {
   if (f->histo) rfxk::histo_bins(c, f->ac, cur, (uint32_t)cap, d_histo);  // count-of-counts of exactly the survivors
 
   // ---- survivors -> fine pos bins (<= 1536 expected per bin) -> sorted records ----
+  // (a big table has just been waited for: its survivor count is known, the arrays below are exact)
+  uint64_t out_room = room;
+  if (refine) {
+    out_room = 0;
+    for (uint32_t cb = 0; cb < P1; ++cb) out_room += std::min<uint64_t>(f->h_cur[(size_t)cb * rfxk::p1_cur_stride()], cap);
+    if (!out_room) out_room = 1;
+  }
   uint32_t Pq = 256;
-  while (Pq < (1u << 23) && (uint64_t)Pq * 1536 < room) Pq <<= 1;
+  while (Pq < (1u << 23) && (uint64_t)Pq * 1536 < out_room) Pq <<= 1;
   const uint32_t Pq1 = std::min<uint32_t>(Pq, 32768), P2a = Pq1 / P1, F2 = Pq / Pq1;
   const rfx_ord_cfg cfg1 = ord_cfg(t, ceil_log2(Pq1)), cfg = ord_cfg(t, ceil_log2(Pq));
-  f->bw = (uint64_t*)dmalloc(c, room * 8);
-  f->bc = (uint32_t*)dmalloc(c, room * 4);
+  f->bw = (uint64_t*)dmalloc(c, out_room * 8);
+  f->bc = (uint32_t*)dmalloc(c, out_room * 4);
   const size_t z1 = ((size_t)Pq1 + 1) * 8 + (size_t)Pq1 * 4, z2 = F2 > 1 ? ((size_t)Pq + 1) * 8 + (size_t)Pq * 4 : 0;
   f->bs1 = (uint64_t*)dmalloc(c, z1 + z2);
-  f->big = records_alloc(c, t->k, t->lsize, t->cols, room);
+  f->big = records_alloc(c, t->k, t->lsize, t->cols, out_room);
+  f->room = out_room;
   if (!f->bw || !f->bc || !f->bs1 || !f->big) return fail(RFX_E_NOMEM);
   uint64_t* bs1 = f->bs1;
   uint32_t* fcur1 = (uint32_t*)(bs1 + Pq1 + 1);
@@ -1337,11 +1541,11 @@ static int msp_emit_queue(rfx_finish* f) {
   rfxk::surv_hist(c, f->aw, cur, (uint32_t)cap, P2a, cfg1.bin_shift, bs1);
   rfxk::scan_tail(c, bs1, Pq1);
   rfxk::part2(c, f->aw, f->bw, bs1, fcur1, P2a, cfg1.bin_shift, cur, (uint32_t)cap, f->ac, f->bc, ~0ull, "k_surv_part2",
-              nullptr, 0, room);
+              nullptr, 0, out_room);
   const uint64_t *sw = f->bw, *sbs = bs1;
   const uint32_t* sc = f->bc;
   if (F2 > 1) {  // more than 32768 bins: a second level, back into the (now free) coarse arrays
-    rfxk::bin_hist(c, f->bw, bs1, Pq1, room, F2, cfg.bin_shift, 0, 0, bs2);
+    rfxk::bin_hist(c, f->bw, bs1, Pq1, out_room, F2, cfg.bin_shift, 0, 0, bs2);
     rfxk::scan_tail(c, bs2, Pq);
     rfxk::part2(c, f->bw, f->aw, bs2, fcur2, F2, cfg.bin_shift, nullptr, 0, f->bc, f->ac, ~0ull, "k_surv_part3", bs1, Pq1);
     sw = f->aw;

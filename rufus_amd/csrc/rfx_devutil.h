@@ -24,7 +24,14 @@ __device__ __forceinline__ uint64_t gf2_mul(const uint64_t* __restrict__ lut, ui
   return r;
 }
 
-constexpr int MSP_WL = 15;    // m-mers per k-mer (window of the sliding minimum); m = k - (MSP_WL - 1)
+// m-mers per k-mer (window of the sliding minimum); m = k - (MSP_WL - 1) = 13 .. 15 bases for k = 23 .. 25.
+// The minimizer must be long enough for the SAMPLE, not for the block: all k-mers that share a minimizer
+// m-mer land in one bin however far the partition is refined, and an m-mer that ranks low occurs
+// genome_len / 4^m times x ~WL k-mers x coverage.  With WL = 15 (m = 11, the round-1 choice) that is 6.6e5
+// instances per top m-mer on a 3.1 Gb genome at 30x -- the leaf re-ran such bins in k-mer hash halves and
+// was 12x slower per read at 1 Gb than at 5 Mb; m = 15 gives 2 K.  Shorter windows mean shorter runs
+// (3.0 instead of 3.4 k-mers per record), the price for bins that stay bins at any scale.
+constexpr int MSP_WL = 11;
 constexpr int MSP_NMAX = 4;   // k-mers per record: k + 3 <= 28 bases = 56 bits
 constexpr uint64_t MSP_EMPTY = 1ull << 55;  // no record looks like this: a 1-k-mer record uses 2k <= 50 bits
 

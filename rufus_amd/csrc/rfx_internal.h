@@ -43,7 +43,18 @@ struct rfx_ctx {
   std::vector<hipEvent_t> free_events;  // recycled: creating two events per launch costs more than recording them
   std::map<std::string, rfx_prof_acc> acc;
   std::map<void*, size_t> allocs;
-  std::multimap<size_t, void*> pool;  // freed blocks kept for reuse, keyed by size
+  std::multimap<size_t, void*> pool;  // freed blocks kept for reuse, keyed by size (fallback allocator)
+  // Arena allocator (default): one contiguous virtual range, physical memory mapped behind a high-water mark
+  // in big granules and never given back before rfx_close, a first-fit free list over it.  At WGS scale the
+  // library runs at ~90 % of the HBM with 2-50 GB blocks coming and going; hipMalloc/hipFree per block (and
+  // the frees of a size-keyed cache under pressure) cost seconds per trio and fragment.  Everything on a ctx
+  // runs on one stream, so a freed range can be handed out again at once.
+  char* arena = nullptr;
+  size_t arena_reserved = 0, arena_mapped = 0, arena_gran = 0;
+  std::vector<void*> arena_handles;       // hipMemGenericAllocationHandle_t of the mapped granules
+  std::map<size_t, size_t> arena_free;    // offset -> length of free ranges inside [0, arena_mapped)
+  bool arena_off = false;                 // VMM unavailable (or RFX_NO_ARENA): size-keyed cache of hipMalloc blocks
+  size_t peak_used = 0;
   std::vector<struct rfx_table*> pend_tables;  // tables with unread MSP capacity flags
   double msp_surv_frac[2] = {0, 0};            // survivors / instances seen by the last MSP emit ([lower >= 2])
   // pinned host scratch: small read-backs and uploads go through it (pageable copies cost a

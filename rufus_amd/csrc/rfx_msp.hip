@@ -4,8 +4,8 @@
 // partition) and reads it back once: 32 B of traffic per instance, and one GF(2) LUT multiply per
 // instance.  Consecutive k-mers of a read overlap in k-1 bases, so here they travel together:
 //
-//   k_msp_part1  reads -> for every k-mer the minimum of hash(canonical m-mer) over its 15 m-mers
-//                (m = k-14); the minimizer picks one of P bins.  Runs of <= 4 consecutive k-mers with
+//   k_msp_part1  reads -> for every k-mer the minimum of hash(canonical m-mer) over its 11 m-mers
+//                (m = k-10); the minimizer picks one of P bins.  Runs of <= 4 consecutive k-mers with
 //                the same bin become ONE 8-byte record (k+3 bases, run length, position of the minimizer).
 //                ~3.4 k-mers per record -> 2.4 B per instance.  128 coarse bins; every phase (8 bases of
 //                512 reads) reserves one run per bin and the lanes store their records into it.
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     uint32_t fm = 0, rm = 0, cur_m = 0, run_h = 0;
     uint64_t hist = 0, cur_w = 0;
     int filled = 0, run_n = 0;
-    uint32_t a[MSP_WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-14 .. p0+7
+    uint32_t a[MSP_WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-(WL-1) .. p0+7
 #pragma unroll
     for (int i = 0; i < MSP_WL - 1 + P1_S; ++i) a[i] = ~0u;
     for (uint32_t ph = 0; ph < n_phase; ++ph) {
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(SS_BLOCK) void k_surv_sort(const uint64_t* __restri
 namespace rfxk {
 
 int msp_k_ok(int k) { return k >= 23 && k <= 25; }
-int msp_part1_block() { return MP1_BLOCK; }  // m = k-14 in 9..11; k+3 bases fit 56 bits
+int msp_part1_block() { return MP1_BLOCK; }  // m = k-10 in 13..15 (an m-mer fits 32 bits); k+3 bases fit 56 bits
 
 void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
                int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,

@@ -1,0 +1,175 @@
+"""Scale path on the GPU: the device generator against its host twin, the multi-block / shard-pass trio
+driver (rufus_amd/wgs.py) against the oracle at sizes the oracle finishes in seconds, and a >= 1 Gb-genome
+trio checked through size-independent properties (BASELINE.json configs[2])."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from rufus_amd import capi, tools, wgs
+from tests.synth import synth_fastq, synth_flat
+
+pytestmark = pytest.mark.gpu
+
+K, SIZE, LOWER, MIN_COV, MAX_DEPTH, MIN_Q, THRESH = 25, 8 << 30, 2, 5, 1200, 15, 1
+
+
+@pytest.mark.parametrize("which,first,n_pairs,want_good", [(0, 0, 3001, True), (1, 12345, 2048, False),
+                                                           (0, 7_000_000_000, 513, True)])
+def test_device_generator_matches_host_twin(ctx, which, first, n_pairs, want_good):
+    """rfx_synth_reads == rfx_pack_reads(rfx_synth_text): codes, both masks, offsets, lengths."""
+    sy = capi.Synth.sample(300_000, which, n_snv=50, seed=4242)
+    blk = ctx.synth_reads(sy, first, n_pairs, MIN_Q, want_good)
+    got = blk.get(want_good)
+    seq, qual = sy.text(first, n_pairs)
+    s, q, off = synth_flat(seq, qual)
+    ref = capi.PackedReads(s, off, q, MIN_Q, capi.PACK_COUNT | capi.PACK_FILTER)
+    assert blk.n == 2 * n_pairs and blk.bases == 2 * n_pairs * 150
+    assert np.array_equal(got["codes"], ref.codes[:len(got["codes"])])
+    assert np.array_equal(got["acgt"], ref.acgt[:len(got["acgt"])])
+    if want_good:
+        assert np.array_equal(got["good"], ref.good[:len(got["good"])])
+    assert np.array_equal(got["word_off"], ref.word_off) and np.array_equal(got["len"], ref.len[:blk.n])
+    blk.free()
+
+
+def _oracle_trio(sys_, n_pairs):
+    """Oracle records / hash list / pulled pairs of a synthetic trio regenerated as text on the host."""
+    fq, recs = [], []
+    for sy in sys_:
+        seq, qual = sy.text(0, n_pairs)
+        fq.append((seq, qual))
+        recs.append(oracle.count(None, K, SIZE, lower=LOWER, reads=[r.tobytes() for r in seq]))
+    hl = oracle.hash_list(recs[0], recs[1:], MIN_COV, MAX_DEPTH)
+    seq, qual = fq[0]
+    m1 = synth_fastq(seq[0::2], qual[0::2])
+    m2 = synth_fastq(seq[1::2], qual[1::2])
+    pulled = oracle.FilterSet(hl.encode()).pairs(m1, m2, K, MIN_Q, THRESH) if hl else np.zeros(0, np.int64)
+    return recs, hl, pulled
+
+
+@pytest.mark.parametrize("passes,block_pairs,refine", [(1, 1 << 20, None), (3, 7001, None), (2, 9000, "16"),
+                                                       (5, 25000, "21")])
+def test_trio_in_blocks_and_passes_matches_oracle(ctx, monkeypatch, passes, block_pairs, refine):
+    """Multi-block samples, shard passes and chunked refinement of the partition give the oracle's records
+    (shards interleaved), histogram, hash list and pulled pairs."""
+    if refine:
+        monkeypatch.setenv("RFX_MSP_REFINE_BITS", refine)
+    n_pairs, G = 25_000, 250_000
+    sys_ = [capi.Synth.sample(G, w, n_snv=12, seed=777) for w in range(3)]
+    recs_o, hl_o, pulled_o = _oracle_trio(sys_, n_pairs)
+    samples = [wgs.make_sample(ctx, sy, n_pairs, block_pairs, MIN_Q, want_good=(i == 0)) for i, sy in enumerate(sys_)]
+    trio = wgs.WgsTrio(ctx, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes)
+    res = trio.run(samples, keep_shard_records=True)
+    for si in range(3):
+        parts = [r[si].get() for r in res["shard_records"]]
+        keys = np.concatenate([p[0] for p in parts])
+        counts = np.concatenate([p[1] for p in parts])
+        pos = np.concatenate([p[2] for p in parts])
+        o = np.lexsort((keys, pos))
+        assert np.array_equal(keys[o], recs_o[si].keys) and np.array_equal(counts[o], recs_o[si].counts)
+        assert np.array_equal(res["histos"][si], oracle.histo(recs_o[si].counts, full=True)[0])
+    for shard in res["shard_records"]:
+        for r in shard:
+            r.free()
+    lines = hl_o.splitlines()
+    assert res["n_mutant"] == len(lines) > 0
+    assert tools.keys_to_text(res["mutant_keys"], K) == [ln.split()[0] for ln in lines]
+    got = np.concatenate([np.flatnonzero(_pairs_of(m, b.n)) + off for m, b, off in
+                          zip(res["hit_masks"], samples[0], np.cumsum([0] + [b.n // 2 for b in samples[0]][:-1]))])
+    assert np.array_equal(got, pulled_o.astype(np.int64)) and res["n_pulled"] == len(pulled_o)
+    for s in samples:
+        for b in s:
+            b.free()
+
+
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def _pairs_of(mask, n_reads):
+    bits = np.unpackbits(mask.view(np.uint8), bitorder="little")[:n_reads].astype(bool)
+    return bits[0::2] | bits[1::2]
+
+
+def _valid_windows(acgt: np.ndarray, n_reads: int, L: int, k: int) -> int:
+    """Number of length-k windows made of ACGT only, from the packed masks of fixed-length reads."""
+    wpr = (L + 31) // 32
+    m = acgt.reshape(n_reads, wpr)
+    bits = np.unpackbits(m.view(np.uint8), axis=1, bitorder="little")[:, :L]
+    run = np.zeros(n_reads, dtype=np.int32)
+    tot = 0
+    for j in range(L):
+        run = np.where(bits[:, j] == 1, run + 1, 0)
+        tot += int((run >= k).sum())
+    return tot
+
+
+def test_wgs_slice_properties(ctx):
+    """30x of a 2^30-base genome (2.1e8 reads per sample, 6.4e8 in the trio; RFX_SCALE_GENOME overrides):
+    far beyond what the oracle can count, so check what must hold at any size --
+      * one block counted alone with lower = 1: sum(count) == number of ACGT-only windows (host-computed);
+      * records of every sample strictly (pos,key)-sorted with count >= 2 (checked on the device side by
+        rfx_records_load of the drained payload, and on the host for one shard);
+      * two shard passes give the same record counts, histograms and hash list as one pass;
+      * hash list: >= 97 % of the 25 alt-allele k-mers of every planted SNV, next to nothing else (the odd
+        site where five reads share an error), none of it present in either parent;
+      * a 40 k-read slice of the same sample matches the oracle bit for bit."""
+    G = int(os.environ.get("RFX_SCALE_GENOME", 1 << 30))
+    n_pairs = G // 10            # 2 x 150 bp per pair: 30x
+    n_snv = 200
+    sys_ = [capi.Synth.sample(G, w, n_snv=n_snv, seed=12345) for w in range(3)]
+    # -- one block, lower = 1
+    blk = ctx.synth_reads(sys_[0], 0, 1 << 20, MIN_Q, True)
+    want = _valid_windows(blk.get()["acgt"], blk.n, 150, K)
+    t = capi.CountTable(ctx, K, SIZE)
+    t.add(blk)
+    rec, h = t.finish(1, want_histo=True)
+    assert int(sum(int(x) * i for i, x in enumerate(h))) == want
+    rec.free()
+    t.free()
+    blk.free()
+    # -- the trio, one pass and two passes
+    samples = [wgs.make_sample(ctx, sy, n_pairs, 1 << 24, MIN_Q, want_good=(i == 0)) for i, sy in enumerate(sys_)]
+    res1 = wgs.WgsTrio(ctx, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=1).run(samples, keep_shard_records=True)
+    recs = res1["shard_records"][0]
+    for r in recs:
+        keys, counts, pos = r.get()
+        assert np.all((pos[1:] > pos[:-1]) | ((pos[1:] == pos[:-1]) & (keys[1:] > keys[:-1])))
+        assert int(counts.min()) >= 2
+        del keys, counts, pos
+    # mutant k-mers: exactly the alt-allele k-mers of the planted SNVs (minus the few that sampling loses)
+    expect = set()
+    for p, ref, alt in sys_[0].snvs():
+        ctxt = bytearray(sys_[0].genome(p - K + 1, 2 * K - 1))
+        assert ctxt[K - 1:K] == ref
+        ctxt[K - 1:K] = alt
+        for i in range(K):
+            km = bytes(ctxt[i:i + K])
+            expect.add(min(km, km[::-1].translate(_COMP)))
+    got = [x.encode() for x in tools.keys_to_text(res1["mutant_keys"], K)]
+    # (at 1e9 sites x 30 reads x 0.16 % per wrong base, a handful of sites see the SAME error five times:
+    # real child-only k-mers, ~2e-9 per site and base -- allow for 30 such sites)
+    extra = set(got) - expect
+    assert len(extra) <= 25 * 30, f"{len(extra)} mutant k-mers are not SNV k-mers"
+    assert len(got) == len(set(got)) and len(set(got) & expect) >= 0.97 * 25 * n_snv
+    for parent in recs[1:]:
+        assert not parent.query(res1["mutant_keys"]).any()
+    assert res1["n_pulled"] > 0
+    n_rec1, h1, keys1, pulled1 = res1["n_records"], res1["histos"], res1["mutant_keys"], res1["n_pulled"]
+    for r in recs:
+        r.free()
+    del res1
+    res2 = wgs.WgsTrio(ctx, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=2).run(samples)
+    assert res2["n_records"] == n_rec1 and res2["n_pulled"] == pulled1
+    assert np.array_equal(res2["mutant_keys"], keys1)
+    assert all(np.array_equal(a, b) for a, b in zip(res2["histos"], h1))
+    for s in samples:
+        for b in s:
+            b.free()
+    # -- slice parity against the oracle
+    seq, _ = sys_[0].text(5_000_000, 20_000)
+    sl = [r.tobytes() for r in seq]
+    jf = tools.jellyfish_count(ctx, [b"".join(b">r\n" + r + b"\n" for r in sl)], K, SIZE, lower=2)
+    assert jf.records.payload() == oracle.count(None, K, SIZE, lower=2, reads=sl).payload()
+    jf.records.free()

@@ -41,7 +41,7 @@ READ_LEN = 150
 SEED = 12345
 
 # every launch of the count -> sorted-records stage, whichever path rfx_count_add/finish took
-K2_CHAIN = ("k_msp_part1", "k_msp_count", "k_bin_offsets", "k_part2", "k_bin_hist", "k_part3", "k_part4", "k_msp_leaf",
+K2_CHAIN = ("k_msp_part1", "k_msp_count", "k_bin_offsets", "k_rec_hist", "k_part2", "k_bin_hist", "k_part3", "k_part4", "k_msp_leaf",
             "k_surv_hist", "k_surv_part2", "k_surv_part3", "k_surv_sort", "k_histo",
             "k_bin_count", "k_bin_scatter", "k_part1", "k_leaf", "k_leaf_compact", "k_count_reads")
 
@@ -134,24 +134,32 @@ def run_wgs(args, ctx, rank, world, dist, torch):
     n_pairs = G * args.coverage // (2 * READ_LEN)
     n_snv = max(20, min(1000, G // 3_000_000))
     sys_ = [capi.Synth.sample(G, w, n_snv=n_snv, seed=SEED) for w in range(3)]
-    if world > 1:
-        raise SystemExit("--workload wgs on N > 1 ranks: use rufus_amd.wgs.WgsTrio(group=...)")  # TODO next commit
     free0, total = torch.cuda.mem_get_info()
+    # this rank's share of every sample: pairs [p0, p1) (strong scaling: the trio is the same for every N)
+    p0, p1 = n_pairs * rank // world, n_pairs * (rank + 1) // world
     bpp = 2 * (40 + 20 + 8)                                   # bytes per pair: codes + acgt mask + offsets
-    resident = n_pairs * (3 * bpp + 2 * 20)                   # + the subject's quality mask
-    passes = args.passes or wgs.plan_passes(2 * n_pairs, READ_LEN, K, resident + (total - free0), total)
+    resident = (p1 - p0) * (3 * bpp + 2 * 20)                 # + the subject's quality mask
+    passes = args.passes or wgs.plan_passes(2 * n_pairs, READ_LEN, K, resident + (total - free0), total, world=world)
+    if world > 1:                                             # every rank must run the same number of passes
+        t = torch.tensor([passes], dtype=torch.int64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        passes = int(t.item())
     t0 = time.perf_counter()
-    samples = [wgs.make_sample(ctx, sy, n_pairs, 1 << 24, MIN_Q, want_good=(i == 0)) for i, sy in enumerate(sys_)]
+    samples = [wgs.make_sample(ctx, sy, p1 - p0, 1 << 24, MIN_Q, want_good=(i == 0), first_pair=p0)
+               for i, sy in enumerate(sys_)]
     ctx.sync()
     t_gen = time.perf_counter() - t0
-    trio = wgs.WgsTrio(ctx, K, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes)
+    trio = wgs.WgsTrio(ctx, K, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes,
+                       group=dist.group.WORLD if world > 1 else None)
     step = lambda: trio.run(samples)  # noqa: E731
     n_reads = 2 * n_pairs
     desc = (f"synthetic {args.coverage}x WGS trio (BASELINE configs[2]): genome {G} bp, {n_reads} x {READ_LEN} bp reads "
-            f"per sample in {len(samples[0])} resident blocks ({resident / 1e9:.0f} GB of packed reads in HBM, generated "
-            f"on the device in {t_gen:.1f} s), {n_snv} SNVs, seed {SEED}, k={K}, -s 8G -L {LOWER}, MinCov {MIN_COV}, "
-            f"MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}; {passes} minimizer-shard pass(es) per step")
-    return step, 3 * n_reads, n_reads, n_reads, desc, "strong", {"passes": passes, "hbm_total": total, "hbm_free_at_start": free0}
+            f"per sample, on each of {world} GPU(s) {len(samples[0])} resident blocks per sample ({resident / 1e9:.0f} GB "
+            f"of packed reads in HBM, generated on the device in {t_gen:.1f} s), {n_snv} SNVs, seed {SEED}, k={K}, "
+            f"-s 8G -L {LOWER}, MinCov {MIN_COV}, MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}; "
+            f"{passes} minimizer-shard pass(es) per step")
+    return (step, 3 * n_reads, n_reads // world, n_reads, desc, "strong",
+            {"passes": passes, "hbm_total": total, "hbm_free_at_start": free0})
 
 
 def main():
@@ -251,7 +259,8 @@ def main():
             "roofline_filter": {"bound": "hbm", "kernel": "k_filter", "achieved": 61.0 * reads_filtered / world / (f_ms * 1e-3) / 1e9,
                                 "peak": 8000.0, "unit": "GB/s",
                                 "frac": 61.0 * reads_filtered / world / (f_ms * 1e-3) / 1e9 / 8000.0,
-                                "ms_per_step": f_ms, "algorithmic_bytes_per_step": 61 * reads_filtered // world} if f_ms else None,
+                                "ms_per_step": f_ms, "algorithmic_bytes_per_step": 61 * reads_filtered // world,
+                                "note": "rank 0's share"} if f_ms else None,
         }
         pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json")
         if os.path.exists(pmc_path):

@@ -995,11 +995,15 @@ static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   g.windows = r->windows_of(t->k);
   if (!t->p2l_bins) {
     if (const char* ev = getenv("RFX_P2L_BINS")) t->p2l_bins = (uint32_t)atoi(ev);
+    // up to 8192 bins come with the partition for free (16-bit LDS histogram fused into k_msp_part1); a big
+    // block (>= ~4 M reads) pays a separate histogram pass and gets up to 32768 (256 sub-bins per coarse bin),
+    // which saves a whole refinement level at WGS scale
+    const uint32_t pcap = g.windows >= (1ull << 29) ? 32768 : 8192;
     uint32_t P = 256;
-    while (P < 8192 && (uint64_t)P * 16384 < g.windows) P <<= 1;
+    while (P < pcap && (uint64_t)P * 16384 < g.windows) P <<= 1;
     if (!t->p2l_bins) t->p2l_bins = P;
     if (t->p2l_bins < 256) t->p2l_bins = 256;    // 128 coarse bins x >= 2 sub-bins
-    if (t->p2l_bins > 8192) t->p2l_bins = 8192;  // 6-bit sub-bin field, 16-bit LDS histogram
+    if (t->p2l_bins > 32768) t->p2l_bins = 32768;
   }
   g.P = t->p2l_bins;
   g.P1 = (uint32_t)rfxk::p1_bins();
@@ -1078,13 +1082,15 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   return RFX_OK;
 }
 
+constexpr uint64_t MSP_KMERS_PER_RECORD_MAX = 4;  // a record holds <= 4 k-mers (rfx_msp.hip MSP_NMAX)
+
 static int msp_add(rfx_table* t, const rfx_reads* r) {
   rfx_ctx* c = t->ctx;
   msp_geom g;
   msp_geometry(t, r, g);
   if (g.windows >= (1ull << 32)) return RFX_E_RANGE;
   if (g.windows == 0) return RFX_OK;
-  if (getenv("RFX_P2L_EXACT")) {
+  if (getenv("RFX_P2L_EXACT") && g.P <= 8192) {
     rfx_segment seg;
     const int rc = msp_partition_exact(t, r, &seg);
     if (rc) return rc;
@@ -1094,24 +1100,67 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   }
   const uint32_t P = g.P, P2 = g.P2;
   const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
-  uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
-  uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
-  // one zeroed block: coarse cursors, [ncur] = flag, then the fine-bin cursors of k_part2
-  uint32_t* cur = (uint32_t*)dmalloc(c, (g.ncur + 1 + (size_t)P) * 4);
-  uint32_t* fine_cur = cur ? cur + g.ncur + 1 : nullptr;
-  // ~3.4 k-mers per record on ordinary sequence: room for 2.5 (of the shard's share of the bins), coarse
+  // ~3 k-mers per record on ordinary sequence: room for 2.5 (of the shard's share of the bins), coarse
   // bins 25 % above even -- 6 % for big blocks, whose bins are even
-  const bool big = g.windows >= (1ull << 29);  // >= ~4 M reads: worth one synchronisation for exact sizes
+  const bool big = g.windows >= (1ull << 29) || P > 8192;  // >= ~4 M reads: worth one synchronisation for exact sizes
   const double share = (double)(g.bin_hi - g.bin_lo) / (double)P;
   uint64_t cap_b = (uint64_t)((double)g.windows * 0.4 * share * (share < 1 ? 1.05 : 1.0)) + 65536;
   if (cap_b > g.windows) cap_b = g.windows;
   const uint64_t even = cap_b / g.c_n;
-  const uint64_t cap_a = even + (big ? even / 16 : even / 4) + 16384;
-  if (cap_a >= (1ull << 32)) { dfree(c, cnt); dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
+  uint64_t cap_a = even + (big ? even / 16 : even / 4) + 16384;
+  if (cap_a >= (1ull << 32)) return RFX_E_RANGE;
+  uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
+  // one zeroed block: coarse cursors, [ncur] = flag, then the fine-bin cursors of k_part2
+  uint32_t* cur = (uint32_t*)dmalloc(c, (g.ncur + 1 + (size_t)P) * 4);
+  uint32_t* fine_cur = cur ? cur + g.ncur + 1 : nullptr;
+  if (!bin_start || !cur) { dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
+  if (big) {
+    // Big block: scatter into the coarse bins (no fused histogram: up to 32768 bins), histogram pass over the
+    // records, then wait for the record count and the capacity flag and give the segment exactly the memory
+    // it needs (at WGS scale the 30 % slack of an estimate is tens of GB) -- and nothing stays pending.
+    for (int attempt = 0;; ++attempt) {
+      uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
+      if (!buf_a) { dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
+      uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;  // the address coarse bin 0 would have
+      auto fail = [&](int rc) { dfree(c, buf_a); dfree(c, cur); dfree(c, bin_start); return rc; };
+      hipError_t e = hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(bin_start, 0, ((size_t)P + 1) * 8, c->stream);
+      if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
+      rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr,
+                      cur + g.ncur);
+      rfxk::surv_hist(c, buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
+      rfxk::scan_tail(c, bin_start, P);
+      uint64_t total = 0;
+      std::vector<uint32_t> h_cur(g.ncur + 1, 0);
+      e = queue_read(c, &total, bin_start + P, 8);
+      if (e == hipSuccess) e = queue_read(c, h_cur.data(), cur, (g.ncur + 1) * 4);
+      if (e == hipSuccess) e = ctx_sync(c);
+      if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
+      if (h_cur[g.ncur]) {  // a coarse bin overflowed: the cursors kept counting, they say what it needs
+        uint64_t need = 0;
+        for (uint32_t cb = 0; cb < g.P1; ++cb) need = std::max<uint64_t>(need, h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
+        dfree(c, buf_a);
+        if (attempt >= 3 || need >= (1ull << 32) - 65536) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
+        cap_a = need + need / 64 + 1024;
+        continue;
+      }
+      uint64_t* inst = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
+      if (!inst) return fail(RFX_E_NOMEM);
+      rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, nullptr, total,
+                  "k_part2", nullptr, 0, total, g.rec_mode, t->k);
+      dfree(c, buf_a);
+      dfree(c, cur);
+      // (k-mer instances behind the records: the shard's share of the windows -- sizes the survivor arrays)
+      t->segs->push_back(rfx_segment{inst, total, bin_start, std::min<uint64_t>(g.windows, total * MSP_KMERS_PER_RECORD_MAX), P});
+      t->seg_kind = RFX_COUNT_MSP;
+      return RFX_OK;
+    }
+  }
+  uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
   uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
-  uint64_t* inst = big ? nullptr : (uint64_t*)dmalloc(c, cap_b * 8);
+  uint64_t* inst = (uint64_t*)dmalloc(c, cap_b * 8);
   auto drop = [&] { dfree(c, cnt); dfree(c, buf_a); };
-  if (!cnt || !bin_start || !cur || !buf_a || (!big && !inst)) {
+  if (!cnt || !buf_a || !inst) {
     drop(); dfree(c, cur); dfree(c, bin_start); dfree(c, inst);
     return RFX_E_NOMEM;
   }
@@ -1119,39 +1168,11 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
   rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
   rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
-  if (big) {
-    // Big block: wait for the record count and the capacity flag, then give the segment exactly the
-    // memory it needs (at WGS scale the 30 % slack of the estimate is tens of GB) -- and nothing stays pending.
-    uint64_t total = 0;
-    unsigned int flag = 1;
-    hipError_t e = queue_read(c, &total, bin_start + P, 8);
-    if (e == hipSuccess) e = queue_read(c, &flag, cur + g.ncur, 4);
-    if (e == hipSuccess) e = ctx_sync(c);
-    if (e != hipSuccess) { drop(); dfree(c, cur); dfree(c, bin_start); return hip_fail(e, "msp_add"); }
-    if (flag) {  // a coarse bin overflowed (or a 16-bit counter wrapped): exact two-pass partition
-      drop(); dfree(c, cur); dfree(c, bin_start);
-      rfx_segment seg;
-      const int rc = msp_partition_exact(t, r, &seg);
-      if (rc) return rc;
-      t->segs->push_back(seg);
-      t->seg_kind = RFX_COUNT_MSP;
-      return RFX_OK;
-    }
-    inst = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
-    if (!inst) { drop(); dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
-    rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, nullptr, total,
-                "k_part2", nullptr, 0, total, g.rec_mode, t->k);
-    drop();
-    dfree(c, cur);
-    t->segs->push_back(rfx_segment{inst, total, bin_start, g.windows, P});
-    t->seg_kind = RFX_COUNT_MSP;
-    return RFX_OK;
-  }
   rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b,
               "k_part2", nullptr, 0, cap_b, g.rec_mode, t->k);
   rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
   drop();
-  t->segs->push_back(rfx_segment{inst, cap_b, bin_start, g.windows, P});
+  t->segs->push_back(rfx_segment{inst, cap_b, bin_start, (uint64_t)((double)g.windows * share) + 1, P});
   t->seg_kind = RFX_COUNT_MSP;
   if (t->pend->empty()) c->pend_tables.push_back(t);
   t->pend->push_back(rfx_pending_add{r, cur, t->segs->size() - 1, g.ncur});
@@ -1329,7 +1350,7 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
   }
   const uint64_t** d_ptrs = (const uint64_t**)dmalloc(c, 2 * nleaf * sizeof(void*) * (cut.size() - 1));
   if (!d_ptrs) { drop(); return RFX_E_NOMEM; }
-  int geo = kmers >> to_bits < 8192 ? 1 : 0;
+  int geo = (kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1)) >> to_bits < 8192 ? 1 : 0;
   if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
   for (size_t ci = 0; ci + 1 < cut.size(); ++ci) {
     const uint32_t p0 = cut[ci], np = cut[ci + 1] - cut[ci];
@@ -1411,7 +1432,9 @@ static int msp_emit_queue(rfx_finish* f) {
     pmin = std::min(pmin, sg.bins);
   }
   int to_bits = ceil_log2(pmax);
-  while (to_bits < 28 && (kmers >> to_bits) > 24576) ++to_bits;
+  // (a shard pass fills only its share of the bins: density as if every shard were present)
+  const uint64_t kfull = kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1);
+  while (to_bits < 28 && (kfull >> to_bits) > 24576) ++to_bits;
   if (getenv("RFX_MSP_REFINE_BITS")) to_bits = std::max(to_bits, atoi(getenv("RFX_MSP_REFINE_BITS")));
   const bool refine = pmin < (1u << to_bits);
   std::vector<std::vector<uint64_t>> h_bs;
@@ -1477,7 +1500,7 @@ static int msp_emit_queue(rfx_finish* f) {
     if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
     // sparse bins (small inputs): half-size workgroups, two per CU (measured: -19 % leaf time at 7.7 K
     // instances per bin, +3 % at 15 K)
-    int geo = f->kmers / P < 8192 ? 1 : 0;
+    int geo = kfull / P < 8192 ? 1 : 0;
     if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
     rfxk::msp_leaf(c, f->d_inst, f->d_inst + nseg, nseg, f->h_ptrs[0], f->h_ptrs[nseg], P, t->k, t->canonical, t->lut_t,
                    t->ntab, cfg0.sel_bits, cfg0.c_bits - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur,

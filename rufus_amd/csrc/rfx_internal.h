@@ -289,7 +289,8 @@ void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* 
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err,
               int geo /* 0: 1024 threads + 8192 slots, 1: 512 + 4096 (two per CU) */);
 void surv_hist(rfx_ctx*, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,
-               uint64_t* fine_tot);
+               uint64_t* fine_tot, int rec_mode = 0 /* 1 / 2: super-k-mer records, see part2 */, int k = 0,
+               uint64_t n_hint = 0);
 void flag_if_gt(rfx_ctx*, const uint64_t* d_value, uint64_t limit, unsigned int* d_flag);
 // count-of-counts over the filled part of fixed-capacity coarse bins
 void histo_bins(rfx_ctx*, const uint32_t* counts, const uint32_t* coarse_cur, uint32_t cap, unsigned long long* d_histo);

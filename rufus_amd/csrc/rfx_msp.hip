@@ -445,18 +445,25 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
   }
 }
 
-// Fine pos-bin sizes of the survivors: fine_tot[cb * P2 + sub] += ...  (64-bit counters, scanned later)
+// Fine bin sizes of the entries in fixed-capacity coarse bins: fine_tot[cb * P2 + sub] += ...  (64-bit
+// counters, scanned later).  MODE 0: survivors, sub-bin = bits of the word; MODE 1 / 2: super-k-mer records
+// (canonical / not), sub-bin = bits of the record's minimizer bin hash.
+template <int MODE>
 __global__ __launch_bounds__(L2_BLOCK) void k_surv_hist(const uint64_t* __restrict__ buf_a,
                                                          const uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
-                                                         uint32_t P2, int shift2, uint32_t W,
+                                                         uint32_t P2, int shift2, uint32_t W, int k,
                                                          unsigned long long* __restrict__ fine_tot) {
   __shared__ uint32_t s_cnt[256];
   const uint32_t cb = blockIdx.x / W, jj = blockIdx.x - cb * W;
   const uint64_t a = (uint64_t)cb * cap_a, e = a + min(coarse_cur[cb * P1_CUR_STRIDE], cap_a);
   if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (uint64_t i = a + (uint64_t)jj * L2_BLOCK + threadIdx.x; i < e; i += (uint64_t)W * L2_BLOCK)
-    atomicAdd(&s_cnt[(uint32_t)(buf_a[i] >> shift2) & (P2 - 1)], 1u);
+  for (uint64_t i = a + (uint64_t)jj * L2_BLOCK + threadIdx.x; i < e; i += (uint64_t)W * L2_BLOCK) {
+    const uint64_t w = buf_a[i];
+    const uint32_t sub = MODE == 0 ? (uint32_t)(w >> shift2) & (P2 - 1)
+                                   : ((MODE == 1 ? msp_record_binhash<true>(w, k) : msp_record_binhash<false>(w, k)) >> shift2) & (P2 - 1);
+    atomicAdd(&s_cnt[sub], 1u);
+  }
   __syncthreads();
   if (threadIdx.x < P2 && s_cnt[threadIdx.x])
     atomicAdd(&fine_tot[(uint64_t)cb * P2 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
@@ -602,11 +609,17 @@ void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const
 }
 
 void surv_hist(rfx_ctx* c, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,
-               uint64_t* fine_tot) {
-  rfx_span sp(c, "k_surv_hist");
-  const uint32_t W = 8;
-  hipLaunchKernelGGL(k_surv_hist, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, coarse_cur, cap_a, P2, shift2,
-                     W, (unsigned long long*)fine_tot);
+               uint64_t* fine_tot, int rec_mode, int k, uint64_t n_hint) {
+  rfx_span sp(c, rec_mode ? "k_rec_hist" : "k_surv_hist");
+  uint32_t W = 8;
+  if (n_hint > (1ull << 27)) W = (uint32_t)c->n_cu * 2 / P1_BINS * 4;  // big inputs: every CU busy, several rounds
+#define RFX_SH(MODE)                                                                                                \
+  hipLaunchKernelGGL(k_surv_hist<MODE>, dim3(P1_BINS * W), dim3(L2_BLOCK), 0, c->stream, buf_a, coarse_cur, cap_a, P2, \
+                     shift2, W, k, (unsigned long long*)fine_tot)
+  if (rec_mode == 0) RFX_SH(0);
+  else if (rec_mode == 1) RFX_SH(1);
+  else RFX_SH(2);
+#undef RFX_SH
 }
 
 void flag_if_gt(rfx_ctx* c, const uint64_t* d_value, uint64_t limit, unsigned int* d_flag) {

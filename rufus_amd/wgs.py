@@ -21,6 +21,11 @@ import numpy as np
 from . import capi
 from .dist import revcomp_keys
 
+
+def shard_cut(q: int, n: int) -> int:
+    """First of the 256 virtual top-level minimizer bins of shard q of n (rfx_count_set_shard's cut)."""
+    return -(-q * 256 // n)
+
 _EVEN = np.uint64(0x5555555555555555)
 
 
@@ -31,46 +36,146 @@ def pulled_pairs(mask: np.ndarray, n_reads: int) -> int:
 
 
 def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, hbm_bytes: int, n_samples: int = 3,
-                coverage_hint: float = 30.0) -> int:
-    """Smallest number of shard passes whose transients fit beside the resident reads.
+                coverage_hint: float = 30.0, world: int = 1) -> int:
+    """Smallest number of shard passes whose transients fit beside the resident reads of ONE rank.
 
-    Per pass and sample: super-k-mer records (2.4 B per k-mer instance / S), the refinement scratch
-    (1/8 of that), the survivor arrays (44 B per surviving k-mer: two partition levels + the records), and
-    the records of the samples already counted in this pass (20 B each)."""
+    n_reads_total: reads per sample over all ranks.  Per pass, sample and rank: super-k-mer records (8 B per
+    ~3 k-mer instances; 1 / (S x world) of the sample -- three copies alive at the peak of an exchange: the
+    partition, the receive buffers, the import), the refinement scratch (1/8 of the records), the survivor
+    arrays (44 B per surviving k-mer: two partition levels + the records), and the records of the samples
+    already counted in this pass (20 B each)."""
     windows = n_reads_total * max(read_len - k + 1, 0)           # per sample
     distinct = windows / max(coverage_hint * (read_len - k + 1) / read_len, 1.0)
-    for s in range(1, 257):
-        records = 2.5 * windows / s
-        transient = records * 1.125 + 44.0 * distinct / s * 1.3 + (n_samples - 1) * 20.0 * distinct / s
-        if resident_bytes + transient < 0.92 * hbm_bytes:
+    for s in range(1, 257 // world):
+        share = s * world
+        records = 2.8 * windows / share * (3.0 if world > 1 else 1.0)
+        transient = records * 1.125 + 44.0 * distinct / share * 1.5 + (n_samples - 1) * 20.0 * distinct / share
+        if resident_bytes + transient < 0.90 * hbm_bytes:
             return s
-    return 256
+    return max(1, 256 // world)
 
 
 class WgsTrio:
     """count x (subject + controls) -> histograms -> hash list -> filter, in minimizer-shard passes."""
 
     def __init__(self, ctx: capi.Context, k: int, size: int, lower: int, min_cov: int, max_cov: int, thresh: int,
-                 passes: int = 1):
+                 passes: int = 1, group=None):
+        """group: a torch.distributed process group -- every rank holds ITS blocks of every sample (strong
+        scaling of one trio); records travel to the owner of their minimizer bin, see count_shard()."""
         self.ctx, self.k, self.size = ctx, k, size
         self.lsize = capi.ceil_log2(size)
         self.cols = capi.jf_matrix(self.lsize, k)
         self.lower, self.min_cov, self.max_cov, self.thresh = lower, min_cov, max_cov, thresh
         self.passes = passes
+        self.group = group
+        if group is not None:
+            import torch.distributed as dist
+            self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+        if self.passes * self.world > 256:
+            raise ValueError("passes x ranks must not exceed the 256 virtual minimizer bins")
 
     def count_shard(self, blocks, shard: int):
+        """Records (in (pos,key) order) + histogram of the k-mers of minimizer shard `shard` of `passes` --
+        on N ranks: of this rank's 1/N of that shard.  The cut is flat over passes x ranks virtual shards
+        (q = shard * N + rank of passes * N), so a pass is a contiguous range of bins split among the ranks:
+        every rank partitions ITS blocks restricted to the pass (rfx_count_set_shard(shard, passes)), the
+        records of owner g's bins are one contiguous run per segment -> one all_to_all_single per segment
+        (RCCL over xGMI), the owner imports the runs and counts complete bins.  No partial counts, no reduce."""
         t = capi.CountTable(self.ctx, self.k, self.size, True, mode=capi.COUNT_MSP)
         try:
             if self.passes > 1:
                 t.set_shard(shard, self.passes)
             for b in blocks:
                 t.add(b)
-            return t.finish(self.lower, want_histo=True)
+            if self.world == 1 and not (self.group is not None and os.environ.get("RFX_WGS_FORCE_EXCHANGE")):
+                return t.finish(self.lower, want_histo=True)
+            return self._exchange_and_count(t, shard)
         finally:
             t.free()
 
+    def _exchange_and_count(self, part: capi.CountTable, shard: int):
+        import torch
+        import torch.distributed as dist
+        from .dist import _device_view, _wire
+        W, me, Q = self.world, self.rank, self.passes * self.world
+        dev = torch.device("cuda", torch.cuda.current_device())
+        vb = [shard_cut(shard * W + g, Q) for g in range(W + 1)]       # owners' ranges in virtual bins
+        segs = part.segments()                                          # synchronises: the arrays are complete
+        # every rank may hold a different number of segments (blocks): agree on the rounds
+        n_seg = torch.tensor([len(segs)], dtype=torch.int64, device=dev)
+        n_seg = _wire(n_seg, self.group)
+        dist.all_reduce(n_seg, op=dist.ReduceOp.MAX, group=self.group)
+        rounds = int(n_seg.item())
+        own = capi.CountTable(self.ctx, self.k, self.size, True, mode=capi.COUNT_MSP)
+        try:
+            own.set_shard(shard * W + me, Q)
+            keep = []
+            for i in range(rounds):
+                if i < len(segs):
+                    d_rec, d_bs, bins, n = segs[i]
+                    rec = _device_view(d_rec, n, dev) if n else torch.empty(0, dtype=torch.int64, device=dev)
+                    bs_host = _device_view(d_bs, bins + 1, dev).cpu()
+                else:                                   # nothing to send in this round
+                    bins = 256
+                    rec = torch.empty(0, dtype=torch.int64, device=dev)
+                    bs_host = torch.zeros(bins + 1, dtype=torch.int64)
+                per = bins // 256
+                cuts = bs_host[torch.tensor([v * per for v in vb])]
+                send_l = (cuts[1:] - cuts[:-1]).tolist()
+                # sizes, then the bin offsets of each destination's range (relative to its run), then the records
+                meta_s = _wire(torch.tensor([[send_l[d], bins] for d in range(W)], dtype=torch.int64, device=dev).flatten(),
+                               self.group)
+                meta_r = torch.empty_like(meta_s)
+                dist.all_to_all_single(meta_r, meta_s, group=self.group)
+                meta_r = meta_r.view(W, 2).tolist()
+                recv_l = [m[0] for m in meta_r]
+                off_parts = [bs_host[vb[d] * per:vb[d + 1] * per + 1] - bs_host[vb[d] * per] for d in range(W)]
+                off_sl = [p.numel() for p in off_parts]
+                off_rl = [(vb[me + 1] - vb[me]) * (m[1] // 256) + 1 for m in meta_r]
+                sb = _wire(torch.cat(off_parts).to(dev), self.group)
+                rb = torch.empty(sum(off_rl), dtype=torch.int64, device=sb.device)
+                dist.all_to_all_single(rb, sb, off_rl, off_sl, group=self.group)
+                wr = _wire(rec[int(cuts[0]):int(cuts[-1])], self.group)
+                rr = torch.empty(sum(recv_l), dtype=torch.int64, device=wr.device)
+                dist.all_to_all_single(rr, wr, recv_l, send_l, group=self.group)
+                if rr.is_cuda:
+                    torch.cuda.current_stream(rr.device).synchronize()   # the library runs on its own stream
+                rr, rb = rr.to(dev), rb.cpu()
+                ro = bo = 0
+                for src in range(W):
+                    sbins = meta_r[src][1]
+                    sper = sbins // 256
+                    loc = rb[bo:bo + off_rl[src]]
+                    full = torch.zeros(sbins + 1, dtype=torch.int64)
+                    lo = vb[me] * sper
+                    full[lo:lo + off_rl[src]] = loc
+                    full[lo + off_rl[src]:] = loc[-1]
+                    full = full.to(dev)
+                    run = rr[ro:ro + recv_l[src]]
+                    torch.cuda.synchronize(dev)
+                    if recv_l[src]:
+                        own.add_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), sbins)
+                    keep.append((run, full))
+                    ro += recv_l[src]
+                    bo += off_rl[src]
+                self.ctx.sync()             # the imports are copies: the exchange buffers may go
+                keep.clear()
+                del rr
+            part.free()                     # the send views were this table's memory
+            return own.finish(self.lower, want_histo=True)
+        finally:
+            own.free()
+
     def pos_of(self, keys: np.ndarray) -> np.ndarray:
-        return np.array([capi.jf_pos(self.cols, self.k, self.lsize, int(x)) for x in keys], dtype=np.uint64)
+        """pos = (M * key) & (2^lsize - 1): bit b of the key selects column 2k-1-b."""
+        keys = np.asarray(keys, dtype=np.uint64)
+        pos = np.zeros(len(keys), dtype=np.uint64)
+        c = 2 * self.k
+        for b in range(c):
+            pos ^= np.where((keys >> np.uint64(b)) & np.uint64(1), self.cols[c - 1 - b], np.uint64(0))
+        return pos & np.uint64((1 << self.lsize) - 1) if self.lsize < 64 else pos
 
     def run(self, samples, keep_shard_records: bool = False):
         """samples: [subject blocks, control blocks, ...] (lists of capi.ReadBlock)."""
@@ -105,6 +210,18 @@ class WgsTrio:
                 for r in recs:
                     r.free()
         keys = np.concatenate(keys) if keys else np.zeros(0, np.uint64)
+        if self.world > 1:     # every rank needs the whole hash list; histograms and record counts add up
+            import torch
+            import torch.distributed as dist
+            from .dist import all_gather_keys, _wire
+            dev = torch.device("cuda", torch.cuda.current_device())
+            keys = all_gather_keys(keys, dev, self.group)
+            h = _wire(torch.from_numpy(np.stack(histos).astype(np.int64)).to(dev), self.group)
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            histos = [x.astype(np.uint64) for x in h.cpu().numpy()]
+            nr = _wire(torch.tensor(n_rec, dtype=torch.int64, device=dev), self.group)
+            dist.all_reduce(nr, op=dist.ReduceOp.SUM, group=self.group)
+            n_rec = nr.tolist()
         if len(keys):
             keys = keys[np.lexsort((keys, self.pos_of(keys)))]
         lap("hash list order")
@@ -120,7 +237,12 @@ class WgsTrio:
             finally:
                 mset.free()
         lap("filter")
-        out = {"n_mutant": len(keys), "mutant_keys": keys, "n_pulled": n_pulled, "n_records": n_rec, "histos": histos,
+        n_pulled_local = n_pulled
+        if self.world > 1:
+            t_ = _wire(torch.tensor([n_pulled], dtype=torch.int64, device=dev), self.group)
+            dist.all_reduce(t_, op=dist.ReduceOp.SUM, group=self.group)
+            n_pulled = int(t_.item())
+        out = {"n_mutant": len(keys), "n_pulled_local": n_pulled_local, "mutant_keys": keys, "n_pulled": n_pulled, "n_records": n_rec, "histos": histos,
                "hit_masks": masks}
         if keep_shard_records:
             out["shard_records"] = kept

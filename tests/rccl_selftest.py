@@ -37,5 +37,18 @@ k_, c_, p_ = be.count_partials(blk)
 rk, rc = rdist.exchange_partials(k_, c_, p_, be.lsize, dist.group.WORLD)
 r2, _ = be.reduce_partials(rk, rc, 2, 0, 1 << be.lsize)
 assert r2.payload() == ref.payload()
-print("rccl self-test ok:", len(ref.keys), "records")
+# the WGS driver's exchange (multi-block samples, shard passes, flat owner cut) over the real RCCL backend
+os.environ["RFX_WGS_FORCE_EXCHANGE"] = "1"
+from rufus_amd import wgs
+sy = capi.Synth.sample(150_000, 0, n_snv=6, seed=5)
+blocks = wgs.make_sample(ctx, sy, 12_000, 5000, 15, True)
+tr = wgs.WgsTrio(ctx, 25, 8 << 30, 2, 5, 1200, 1, passes=2, group=dist.group.WORLD)
+seqs, _ = sy.text(0, 12_000)
+ref2 = oracle.count(None, 25, 8 << 30, lower=2, reads=[r.tobytes() for r in seqs])
+shards = [tr.count_shard(blocks, sh)[0] for sh in range(2)]
+got = [s_.get() for s_ in shards]
+k2, c2, p2 = (np.concatenate([g[i] for g in got]) for i in range(3))
+o = np.lexsort((k2, p2))
+assert np.array_equal(k2[o], ref2.keys) and np.array_equal(c2[o].astype(np.uint64), ref2.counts)
+print("rccl self-test ok:", len(ref.keys), "records;", len(ref2.keys), "through the WGS exchange")
 dist.destroy_process_group()

@@ -49,13 +49,17 @@ def _oracle_trio(sys_, n_pairs):
     return recs, hl, pulled
 
 
-@pytest.mark.parametrize("passes,block_pairs,refine", [(1, 1 << 20, None), (3, 7001, None), (2, 9000, "16"),
-                                                       (5, 25000, "21")])
-def test_trio_in_blocks_and_passes_matches_oracle(ctx, monkeypatch, passes, block_pairs, refine):
+@pytest.mark.parametrize("passes,block_pairs,refine,bins", [(1, 1 << 20, None, None), (3, 7001, None, None),
+                                                            (2, 9000, "16", None), (5, 25000, "21", None),
+                                                            (3, 11000, "19", "32768"), (1, 25000, None, "16384")])
+def test_trio_in_blocks_and_passes_matches_oracle(ctx, monkeypatch, passes, block_pairs, refine, bins):
     """Multi-block samples, shard passes and chunked refinement of the partition give the oracle's records
-    (shards interleaved), histogram, hash list and pulled pairs."""
+    (shards interleaved), histogram, hash list and pulled pairs.  bins > 8192 takes the big-block path
+    (scatter, separate histogram pass, exact-size segment) that WGS-size blocks use."""
     if refine:
         monkeypatch.setenv("RFX_MSP_REFINE_BITS", refine)
+    if bins:
+        monkeypatch.setenv("RFX_P2L_BINS", bins)
     n_pairs, G = 25_000, 250_000
     sys_ = [capi.Synth.sample(G, w, n_snv=12, seed=777) for w in range(3)]
     recs_o, hl_o, pulled_o = _oracle_trio(sys_, n_pairs)
@@ -173,3 +177,71 @@ def test_wgs_slice_properties(ctx):
     jf = tools.jellyfish_count(ctx, [b"".join(b">r\n" + r + b"\n" for r in sl)], K, SIZE, lower=2)
     assert jf.records.payload() == oracle.count(None, K, SIZE, lower=2, reads=sl).payload()
     jf.records.free()
+
+
+# ------------------------------------------------------------------------------------------------
+# strong scaling of one trio over ranks: two ranks share the one GPU, exchange over gloo
+# ------------------------------------------------------------------------------------------------
+def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        c = capi.Context(0)
+        sys_ = [capi.Synth.sample(G, w, n_snv=12, seed=777) for w in range(3)]
+        p0, p1 = n_pairs * rank // world, n_pairs * (rank + 1) // world
+        samples = [wgs.make_sample(c, sy, p1 - p0, block_pairs, MIN_Q, want_good=(i == 0), first_pair=p0)
+                   for i, sy in enumerate(sys_)]
+        trio = wgs.WgsTrio(c, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes, group=dist.group.WORLD)
+        res = trio.run(samples, keep_shard_records=True)
+        recs = [[tuple(a.tolist() for a in shard[si].get()) for shard in res["shard_records"]] for si in range(3)]
+        pulled = np.concatenate([np.flatnonzero(_pairs_of(m, b.n)) + off for m, b, off in
+                                 zip(res["hit_masks"], samples[0],
+                                     np.cumsum([0] + [b.n // 2 for b in samples[0]][:-1]))]) + p0
+        q.put((rank, recs, [h.tolist() for h in res["histos"]], res["mutant_keys"].tolist(), res["n_pulled"],
+               pulled.tolist(), res["n_records"]))
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("passes,block_pairs", [(1, 1 << 20), (2, 5000)])
+def test_trio_strong_scaled_over_two_ranks(passes, block_pairs):
+    """WgsTrio(group=...): each rank holds half of every sample's pairs; per pass the ranks exchange their
+    super-k-mer records by minimizer-bin owner (flat cut over passes x ranks) and count complete bins.  The
+    union of all (pass, rank) shards is the oracle's record list; histograms, hash list and pulled pairs too."""
+    import socket
+    import torch.multiprocessing as mp
+    world, n_pairs, G = 2, 20_000, 200_000
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_wgs_worker, args=(r, world, port, q, passes, n_pairs, G, block_pairs))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sys_ = [capi.Synth.sample(G, w, n_snv=12, seed=777) for w in range(3)]
+    recs_o, hl_o, pulled_o = _oracle_trio(sys_, n_pairs)
+    for si in range(3):
+        parts = [sh for g in got for sh in g[1][si]]
+        keys = np.concatenate([np.array(p[0], np.uint64) for p in parts])
+        counts = np.concatenate([np.array(p[1], np.uint64) for p in parts])
+        pos = np.concatenate([np.array(p[2], np.uint64) for p in parts])
+        assert all(len(p[0]) for p in parts)
+        o = np.lexsort((keys, pos))
+        assert np.array_equal(keys[o], recs_o[si].keys) and np.array_equal(counts[o], recs_o[si].counts)
+        assert got[0][2][si] == got[1][2][si] == oracle.histo(recs_o[si].counts, full=True)[0].tolist()
+        assert got[0][6][si] == got[1][6][si] == len(recs_o[si].keys)
+    want = [oracle.jf_encode(ln.split()[0]) for ln in hl_o.splitlines()]
+    assert got[0][3] == got[1][3] == want and want
+    assert got[0][4] == got[1][4] == len(pulled_o)
+    assert sorted(got[0][5] + got[1][5]) == pulled_o.tolist()

@@ -74,6 +74,15 @@ int rfx_pack_reads(const char* seq, const char* qual, const uint64_t* off, uint3
                    uint64_t* codes, uint32_t* acgt, uint32_t* good, uint32_t* word_off /* n_reads+1 */,
                    uint32_t* len /* n_reads */);
 
+/* The same packing for reads that lie scattered in a text buffer (FASTQ parsed in place): read i = seq_len[i]
+ * bytes at base + seq_start[i], qualities (RFX_PACK_FILTER only) as many bytes at base + qual_start[i].
+ * Single-threaded, so that a caller can pack disjoint ranges of one block from several threads: word_off[0] is
+ * an INPUT (first word of this range in the block); word_off[1..n] and len[0..n) are written, codes / acgt / good
+ * are indexed by those offsets. */
+int rfx_pack_spans(const char* base, const uint64_t* seq_start, const uint32_t* seq_len, const uint64_t* qual_start,
+                   uint32_t n_reads, int min_q, int flags, uint64_t* codes, uint32_t* acgt, uint32_t* good,
+                   uint32_t* word_off /* n_reads+1 */, uint32_t* len /* n_reads */);
+
 /* RUFUS.Filter hash-list loader (src/RUFUS.Filter.cpp:121-143; single_end: src/RUFUS.Filter.ss.cpp:
  * 100-118): every line contributes HashToLong(kmer) and HashToLong(RevComp(kmer)) (src/Util.cpp:51-84,
  * :187-210), returned here as forward keys in jellyfish encoding (first base most significant).
@@ -93,6 +102,9 @@ long rfx_jhash_header(int k, int lsize, const uint64_t* cols, int canonical, int
 rfx_ctx* rfx_open(int device, size_t hbm_budget_bytes); /* NULL on failure (no CPU fallback) */
 void rfx_close(rfx_ctx*);
 int rfx_sync(rfx_ctx*);
+/* Page-locked host memory for staging buffers of the ingest pipelines (uploads from it run at PCIe speed). */
+void* rfx_host_alloc(size_t bytes);
+void rfx_host_free(void*);
 void* rfx_stream(rfx_ctx*); /* the hipStream_t every kernel of this ctx is launched on */
 /* Device memory of the ctx: bytes in use now, the high-water mark of that, and bytes of HBM mapped into the ctx's
  * arena (the library sub-allocates one growable virtual range; mapped memory is kept until rfx_close). */
@@ -184,6 +196,14 @@ int rfx_count_set_mode(rfx_table*, int mode);
  * the shard of a k-mer is the same for every sample, so count -> set difference can run shard by shard
  * when a sample's records do not fit the HBM at once, or on every GPU over all reads without any exchange. */
 int rfx_count_set_shard(rfx_table*, int shard, int n_shards);
+/* Bounded-HBM counting of a whole sample (MSP path, call before the first add): rfx_count_add() only
+ * REMEMBERS the read blocks -- they must stay alive until finish -- and rfx_count_finish() runs `passes`
+ * minimizer-shard passes over them (0: planned from the free HBM, 1 if everything fits): per pass the shard's
+ * super-k-mer records of every block are built, counted and freed again, the survivors of all passes are sorted
+ * once.  A 30x human sample is 187 GB of records but 42 GB of packed reads: this is how one GPU counts it, the
+ * analogue of jellyfish's --disk spill-and-merge (jf/include/jellyfish/hash_counter.hpp:182-202,
+ * jf/sub_commands/count_main.cc:326-339).  The table is consumed by its finish. */
+int rfx_count_set_passes(rfx_table*, int passes);
 int rfx_count_add(rfx_table*, const rfx_reads*);
 /* Merge pre-aggregated (key,count) pairs (device pointers): owner-side reduce of the multi-GPU
  * exchange, and the rehash path. */
@@ -232,6 +252,9 @@ int rfx_records_k(const rfx_records*);
 int rfx_records_lsize(const rfx_records*);
 /* Formatted file records (ceil(2k/8) key bytes + counter_len count bytes, saturating) -> host. */
 int rfx_records_payload(const rfx_records*, void* out, size_t cap_bytes, int counter_len);
+/* The same for records [first, first + n): lets a writer stream a 30 GB payload through a small buffer. */
+int rfx_records_payload_range(const rfx_records*, uint64_t first, uint64_t n, void* out, size_t cap_bytes,
+                              int counter_len);
 int rfx_records_get(const rfx_records*, uint64_t* keys, uint32_t* counts, uint64_t* pos); /* any may be NULL */
 /* Load a payload read from a .Jhash file back into HBM (verifies (pos,key) order). */
 rfx_records* rfx_records_load(rfx_ctx*, int k, int lsize, const uint64_t* cols, const void* payload, uint64_t n,

@@ -33,12 +33,15 @@ SIGNATURES = {
     "rfx_pack_words": (C.c_uint64, [u64p, C.c_uint32]),
     "rfx_pack_reads": (C.c_int, [C.c_char_p, C.c_char_p, u64p, C.c_uint32, C.c_int, C.c_int, u64p, u32p, u32p, u32p,
                                  u32p]),
+    "rfx_pack_spans": (C.c_int, [C.c_void_p, u64p, u32p, u64p, C.c_uint32, C.c_int, C.c_int, u64p, u32p, u32p, u32p, u32p]),
     "rfx_hashlist_keys": (C.c_long, [C.c_char_p, C.c_size_t, C.c_int, C.c_int, u64p, C.c_size_t]),
     "rfx_jhash_header": (C.c_long, [C.c_int, C.c_int, u64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_char_p),
                                     C.c_char_p, C.c_size_t]),
     "rfx_open": (C.c_void_p, [C.c_int, C.c_size_t]),
     "rfx_close": (None, [C.c_void_p]),
     "rfx_sync": (C.c_int, [C.c_void_p]),
+    "rfx_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "rfx_host_free": (None, [C.c_void_p]),
     "rfx_stream": (C.c_void_p, [C.c_void_p]),
     "rfx_mem_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
     "rfx_memcpy_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -59,6 +62,7 @@ SIGNATURES = {
     "rfx_synth_genome": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
     "rfx_count_begin": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]),
     "rfx_count_set_mode": (C.c_int, [C.c_void_p, C.c_int]),
+    "rfx_count_set_passes": (C.c_int, [C.c_void_p, C.c_int]),
     "rfx_count_add": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rfx_count_add_pairs_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "rfx_count_stats": (C.c_int, [C.c_void_p, u64p, u64p, u64p]),
@@ -75,6 +79,7 @@ SIGNATURES = {
     "rfx_records_k": (C.c_int, [C.c_void_p]),
     "rfx_records_lsize": (C.c_int, [C.c_void_p]),
     "rfx_records_payload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "rfx_records_payload_range": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]),
     "rfx_records_get": (C.c_int, [C.c_void_p, u64p, u32p, u64p]),
     "rfx_records_load": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, u64p, C.c_void_p, C.c_uint64, C.c_int]),
     "rfx_records_from_dev": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, u64p, C.c_void_p, C.c_void_p, C.c_uint64]),
@@ -368,6 +373,13 @@ class Records:
         _check(lib().rfx_records_payload(self._h, buf.ctypes.data, n, counter_len), "rfx_records_payload")
         return buf[:n].tobytes()
 
+    def payload_range(self, first: int, n: int, counter_len: int = 4) -> bytes:
+        nb = n * ((2 * self.k + 7) // 8 + counter_len)
+        buf = np.zeros(max(nb, 1), dtype=np.uint8)
+        _check(lib().rfx_records_payload_range(self._h, first, n, buf.ctypes.data, nb, counter_len),
+               "rfx_records_payload_range")
+        return buf[:nb].tobytes()
+
     def get(self):
         n = len(self)
         keys, counts, pos = np.zeros(n, np.uint64), np.zeros(n, np.uint32), np.zeros(n, np.uint64)
@@ -426,6 +438,10 @@ class CountTable:
 
     def add_pairs_dev(self, d_keys: int, d_counts: int, n: int):
         _check(lib().rfx_count_add_pairs_dev(self._h, d_keys, d_counts, n), "rfx_count_add_pairs_dev")
+
+    def set_passes(self, passes: int = 0):
+        """Defer the adds: finish() runs `passes` minimizer-shard passes over the (still alive) blocks (0 = plan)."""
+        _check(lib().rfx_count_set_passes(self._h, passes), "rfx_count_set_passes")
 
     def set_shard(self, shard: int, n_shards: int):
         """Count only the k-mers of minimizer shard `shard` of `n_shards` (before the first add)."""

@@ -13,8 +13,9 @@
 
 #include <chrono>
 #include <limits>
+#include <memory>
 
-#include "rfx_cli.hpp"
+#include "rfx_ingest.hpp"
 
 using namespace rfxcli;
 
@@ -56,7 +57,6 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
       default: die("Usage: jellyfish count -m K -s SIZE [-C] [-L n] [-U n] [-t T] [-o OUT] [--disk] file...");
     }
   }
-  (void)threads;
   if (k < 1 || !size_given) die("Missing required switch: -m, --mer-len and -s, --size");
   if (optind >= argc) die("Missing sequence file");
   int lsize = 0;
@@ -68,33 +68,122 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   if (!tab) die(std::string("rufus_amd: ") + rfx_last_error());
   const auto t_init = std::chrono::steady_clock::now();
 
+  // Inputs: regular files are mapped (their size is known), pipes are streamed.  When the input is a pipe
+  // (its size is unknown: RUFUS feeds 30x genomes through FIFOs, scripts/RunJellyForRUFUS.sh:23-31) or a big
+  // file, the packed read blocks stay in HBM and the table counts them in minimizer-shard passes at finish
+  // (rfx_count_set_passes: bounded HBM, the analogue of --disk); small inputs are counted block by block.
+  struct Input { std::string path; int fd; bool regular; size_t size; };
+  std::vector<Input> inputs;
+  size_t known_bytes = 0;
+  bool any_stream = false;
+  for (int i = optind; i < argc; ++i) {
+    Input in{argv[i], -1, false, 0};
+    in.fd = strcmp(argv[i], "stdin") == 0 || strcmp(argv[i], "/dev/stdin") == 0 ? 0 : ::open(argv[i], O_RDONLY);
+    if (in.fd < 0) die(std::string("Failed to open input file '") + argv[i] + "'");
+    struct stat st;
+    if (fstat(in.fd, &st) == 0 && S_ISREG(st.st_mode)) {
+      in.regular = true;
+      in.size = (size_t)st.st_size;
+      known_bytes += in.size;
+    } else {
+      any_stream = true;
+    }
+    inputs.push_back(in);
+  }
+  unsigned nthreads = (unsigned)std::max(1, threads);
+  const unsigned hw = std::thread::hardware_concurrency();
+  if (hw && nthreads > hw) nthreads = hw;
+  if (const char* ev = getenv("RFX_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(ev));
+  const bool msp_ok = k >= 23 && k <= 25;
+  bool defer = msp_ok && (any_stream || known_bytes > (16ull << 30) || getenv("RFX_COUNT_PASSES"));
+  if (const char* ev = getenv("RFX_COUNT_DEFER")) defer = msp_ok && atoi(ev) != 0;
+  if (defer && rfx_count_set_passes(tab, 0) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+  std::vector<rfx_reads*> resident;
+  auto sink = [&](rfx_reads* r) {
+    if (!r) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
+    const int rc = rfx_count_add(tab, r);
+    if (rc) die(std::string("rufus_amd: count failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
+    if (defer) resident.push_back(r);
+    else rfx_reads_free(r);
+  };
+
   ReadBatch batch;
   PackedBatch packed;
   auto flush = [&]() {
     if (batch.n() == 0) return;
     int rc = packed.pack(batch, RFX_PACK_COUNT, 0);
     if (rc) die(std::string("rufus_amd: pack failed: ") + rfx_strerror(rc));
-    rfx_reads* r = packed.upload(ctx, batch.n(), RFX_PACK_COUNT);
-    if (!r) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
-    rc = rfx_count_add(tab, r);
-    rfx_reads_free(r);
-    if (rc) die(std::string("rufus_amd: count failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
+    sink(packed.upload(ctx, batch.n(), RFX_PACK_COUNT));
     batch.clear();
   };
-  for (int i = optind; i < argc; ++i) {
-    LineReader in;
-    if (!in.open(argv[i])) die(std::string("Failed to open input file '") + argv[i] + "'");
+  auto sequential = [&](LineReader& in) {  // the reference's grammar: FASTA, multi-line FASTQ
     const bool ok = parse_sequences(in, [&](const char* s, size_t n) {
       batch.add(s, n);
       if (batch.seq.size() >= (256u << 20) || batch.n() >= (1u << 22)) flush();
     });
     if (!ok) die("Unsupported format");
     flush();  // k-mers never span files
+  };
+  {
+    std::unique_ptr<CountIngest> ingest;
+    for (Input& in : inputs) {
+      bool done = false;
+      if (nthreads > 1) {
+        if (!ingest)
+          ingest.reset(new CountIngest(nthreads, [&](const StageBlock& b) {
+            sink(rfx_reads_upload(ctx, b.codes, b.acgt, nullptr, b.word_off, b.len, b.n_reads));
+          }));
+        if (in.regular) {
+          if (in.size == 0) { if (in.fd > 0) ::close(in.fd); continue; }
+          void* m = mmap(nullptr, in.size, PROT_READ, MAP_PRIVATE, in.fd, 0);
+          if (m != MAP_FAILED) {
+            (void)madvise(m, in.size, MADV_SEQUENTIAL);
+            done = ingest->feed_mapped((const char*)m, in.size);
+            munmap(m, in.size);
+          }
+          if (!done) {
+            LineReader lr;
+            lr.attach(in.fd);
+            in.fd = -1;  // closed by the reader
+            sequential(lr);
+            done = true;
+          }
+        } else {
+          std::vector<char> head(1u << 16);
+          size_t got = 0;
+          for (;;) {
+            const ssize_t n = ::read(in.fd, head.data() + got, head.size() - got);
+            if (n < 0 && errno == EINTR) continue;
+            if (n < 0) die(std::string("read error on input: ") + strerror(errno));
+            if (n == 0) break;
+            got += (size_t)n;
+            if (got == head.size()) break;
+          }
+          head.resize(got);
+          done = got == 0 || ingest->feed_stream(in.fd, head);
+          if (!done) {
+            LineReader lr;
+            lr.preload(head.data(), head.size());
+            lr.attach(in.fd);
+            in.fd = -1;
+            sequential(lr);
+            done = true;
+          }
+        }
+      } else {
+        LineReader lr;
+        lr.attach(in.fd);
+        in.fd = -1;
+        sequential(lr);
+      }
+      if (in.fd > 0) ::close(in.fd);
+    }
   }
   const auto t_count = std::chrono::steady_clock::now();
 
   rfx_records* rec = rfx_count_finish(tab, lower, upper, nullptr);
   if (!rec) die(std::string("rufus_amd: finish failed: ") + rfx_last_error());
+  for (rfx_reads* r : resident) rfx_reads_free(r);
   std::vector<uint64_t> cols(2 * (size_t)k);
   rfx_jf_matrix(lsize, k, cols.data());
   write_jhash(out, rec, cols.data(), canonical, out_counter_len, full_argc, full_argv);

@@ -5,11 +5,15 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <cerrno>
+
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -45,8 +49,11 @@ class LineReader {
       beg_ = 0;
     }
     if (end_ == buf_.size()) buf_.resize(buf_.size() * 2);
-    ssize_t n = ::read(fd_, buf_.data() + end_, buf_.size() - end_);
-    if (n <= 0) {
+    ssize_t n;
+    do n = ::read(fd_, buf_.data() + end_, buf_.size() - end_);
+    while (n < 0 && errno == EINTR);  // a signal is not the end of a pipe
+    if (n < 0) die(std::string("read error on input: ") + strerror(errno));
+    if (n == 0) {
       eof_ = true;
       return false;
     }
@@ -61,6 +68,12 @@ class LineReader {
     return fd_ >= 0;
   }
   void attach(int fd) { fd_ = fd; }
+  // Bytes that were already read from the descriptor (format sniffing) go first.
+  void preload(const char* p, size_t n) {
+    if (end_ + n > buf_.size()) buf_.resize(end_ + n + (1 << 20));
+    memcpy(buf_.data() + end_, p, n);
+    end_ += n;
+  }
   ~LineReader() {
     if (fd_ > 0) ::close(fd_);
   }
@@ -308,15 +321,52 @@ inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols
   const long hl = rfx_jhash_header(k, lsize, cols, canonical, counter_len, argc, argv, hdr.data(), hdr.size());
   if (hl < 0) die("rufus_amd: header too large");
   const uint64_t n = rfx_records_size(rec);
-  const size_t bytes = (size_t)n * ((size_t)(2 * k + 7) / 8 + (size_t)counter_len);
-  std::vector<char> payload(bytes ? bytes : 1);
-  if (rfx_records_payload(rec, payload.data(), bytes, counter_len) != RFX_OK)
-    die(std::string("rufus_amd: drain failed: ") + rfx_last_error());
-  FILE* f = fopen(path, "wb");
-  if (!f) die(std::string("Can't open output file '") + path + "'");
-  fwrite(hdr.data(), 1, (size_t)hl, f);
-  fwrite(payload.data(), 1, bytes, f);
-  fclose(f);
+  const size_t rl = (size_t)(2 * k + 7) / 8 + (size_t)counter_len;
+  const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) die(std::string("Can't open output file '") + path + "'");
+  auto put = [&](const char* p, size_t len, off_t at) {
+    while (len) {
+      const ssize_t w = ::pwrite(fd, p, len, at);
+      if (w < 0 && errno == EINTR) continue;
+      if (w <= 0) die(std::string("write error on '") + path + "': " + strerror(errno));
+      p += w;
+      len -= (size_t)w;
+      at += w;
+    }
+  };
+  put(hdr.data(), (size_t)hl, 0);
+  // The payload of a 30x sample is ~35 GB: formatted on the device and fetched 8 M records at a time into a ring
+  // of page-locked buffers; writer threads put finished buffers into the file at their offsets (one thread copying
+  // into the page cache would be the bottleneck of the whole tool).
+  const uint64_t step = 8ull << 20;
+  const int NBUF = 6;
+  char* buf[NBUF];
+  bool pinned[NBUF];
+  for (int i = 0; i < NBUF; ++i) {
+    buf[i] = (char*)rfx_host_alloc(step * rl);
+    pinned[i] = buf[i] != nullptr;
+    if (!buf[i]) buf[i] = (char*)malloc(step * rl);
+    if (!buf[i]) die("rufus_amd: out of host memory");
+  }
+  std::thread writers[NBUF];
+  for (uint64_t at = 0, i = 0; at < n; at += step, ++i) {
+    const uint64_t m = std::min<uint64_t>(step, n - at);
+    const int bi = (int)(i % NBUF);
+    if (writers[bi].joinable()) writers[bi].join();
+    if (rfx_records_payload_range(rec, at, m, buf[bi], (size_t)m * rl, counter_len) != RFX_OK)
+      die(std::string("rufus_amd: drain failed: ") + rfx_last_error());
+    const char* src = buf[bi];
+    const size_t len = (size_t)m * rl;
+    const off_t off = (off_t)hl + (off_t)(at * rl);
+    writers[bi] = std::thread([=] { put(src, len, off); });
+  }
+  for (auto& w : writers)
+    if (w.joinable()) w.join();
+  for (int i = 0; i < NBUF; ++i) {
+    if (pinned[i]) rfx_host_free(buf[i]);
+    else free(buf[i]);
+  }
+  if (::close(fd) != 0) die(std::string("write error on '") + path + "'");
 }
 
 // yaggo's SI suffixes (jf/sub_commands/count_main_cmdline.hpp:104-109): k M G T P E are powers of 1000.

@@ -1,0 +1,429 @@
+// Parallel FASTQ ingest of the drop-in `jellyfish count`: text in, packed read blocks in HBM out.
+//
+// The reference parses with one producer per file (jf/include/jellyfish/mer_overlap_sequence_parser.hpp:
+// 124-251) and hashes in T threads.  Here the device counts ~100x faster than one core can parse, so the host
+// side is the pipeline to get right:
+//
+//   regular file   mmap; the byte range is cut into ~32 MB pieces at record boundaries, every worker parses
+//                  and packs pieces on its own (no reader thread in the way)
+//   pipe / FIFO    one reader thread (the stream cannot be split) cuts the byte stream every 4k lines and hands
+//                  the pieces to the workers
+//   workers        find the sequence lines of their piece, reserve a range of the current staging block (pinned
+//                  host memory: 2-bit codes, ACGT mask, offsets, lengths) and pack straight into it
+//                  (rfx_pack_spans) -- no intermediate copy of the text
+//   main thread    uploads every full block (rfx_reads_upload) and hands it to the caller (count it, or keep it
+//                  for the shard passes of rfx_count_set_passes)
+//
+// Only strict 4-line FASTQ takes this path (what PassThroughSamCheck and every sequencer write); FASTA and
+// multi-line FASTQ go through the sequential parser of rfx_cli.hpp, which follows the reference's grammar.
+#pragma once
+#include <sys/mman.h>
+#include <sys/stat.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+#include "rfx_cli.hpp"
+
+namespace rfxcli {
+
+struct StageBlock {
+  uint64_t* codes = nullptr;
+  uint32_t *acgt = nullptr, *word_off = nullptr, *len = nullptr;
+  uint32_t cap_reads = 0, n_reads = 0;
+  uint64_t cap_words = 0, n_words = 0;
+  int writers = 0;
+  bool sealed = false;
+};
+
+class CountIngest {
+  std::function<void(const StageBlock&)> sink_;
+  unsigned nthreads_;
+  void (*dealloc_)(void*);
+  std::vector<StageBlock> blocks_;
+  std::mutex mu_;
+  std::condition_variable cv_;  // one for every state change: pieces, blocks, failure
+  struct Piece {
+    const char* b;
+    const char* e;
+    std::vector<char>* owner;  // heap buffer of a pipe piece (returned to the pool), null for mmap
+  };
+  std::deque<Piece> work_;
+  std::deque<int> ready_, free_;
+  std::deque<std::vector<char>*> pool_;
+  int current_ = -1;
+  bool closing_ = false;
+  size_t pieces_open_ = 0;
+  std::atomic<bool> failed_{false};
+  std::string fail_msg_;
+  std::vector<std::thread> workers_;
+  uint64_t reads_total_ = 0;
+
+  size_t PIECE = 32u << 20;  // bytes of text per piece (tests shrink it)
+
+  void fail(const std::string& m) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!failed_.exchange(true)) fail_msg_ = m;
+    cv_.notify_all();
+  }
+
+  // Reserve n reads / w words in the current block (sealing it and taking a fresh one when they do not fit).
+  bool reserve(uint32_t n, uint64_t w, int& blk, uint32_t& r0, uint64_t& w0) {
+    std::unique_lock<std::mutex> g(mu_);
+    for (;;) {
+      if (failed_) return false;
+      if (current_ >= 0) {
+        StageBlock& b = blocks_[(size_t)current_];
+        if (b.n_reads + (uint64_t)n <= b.cap_reads && b.n_words + w <= b.cap_words) {
+          blk = current_;
+          r0 = b.n_reads;
+          w0 = b.n_words;
+          b.n_reads += n;
+          b.n_words += w;
+          ++b.writers;
+          return true;
+        }
+        b.sealed = true;
+        if (b.writers == 0) {
+          ready_.push_back(current_);
+          cv_.notify_all();
+        }
+        current_ = -1;
+      }
+      if (n > blocks_[0].cap_reads || w > blocks_[0].cap_words) {
+        g.unlock();
+        fail("a read is longer than a staging block");
+        return false;
+      }
+      // (another worker may install the next block while this one waits: look again before taking one)
+      cv_.wait(g, [&] { return current_ >= 0 || !free_.empty() || failed_; });
+      if (failed_) return false;
+      if (current_ >= 0) continue;
+      current_ = free_.front();
+      free_.pop_front();
+      StageBlock& b = blocks_[(size_t)current_];
+      b.n_reads = 0;
+      b.n_words = 0;
+      b.writers = 0;
+      b.sealed = false;
+      cv_.notify_all();
+    }
+  }
+
+  void release(int blk) {
+    std::lock_guard<std::mutex> g(mu_);
+    StageBlock& b = blocks_[(size_t)blk];
+    if (--b.writers == 0 && b.sealed) {
+      ready_.push_back(blk);
+      cv_.notify_all();
+    }
+  }
+
+  void parse_piece(const Piece& pc) {
+    std::vector<uint64_t> start;
+    std::vector<uint32_t> slen;
+    start.reserve(1 << 17);
+    slen.reserve(1 << 17);
+    const char *p = pc.b, *e = pc.e;
+    uint64_t words = 0;
+    while (p < e) {
+      if (*p == '\n') { ++p; continue; }  // blank lines between records are skipped (as the reference's parser does)
+      if (*p != '@') return fail("parallel FASTQ reader: a record does not start with '@' (multi-line FASTQ? use RFX_HOST_THREADS=1)");
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+      if (!nl) return fail("truncated FASTQ record");
+      const char* s = nl + 1;
+      nl = (const char*)memchr(s, '\n', (size_t)(e - s));
+      if (!nl) return fail("truncated FASTQ record");
+      const size_t L = (size_t)(nl - s);
+      const char* plus = nl + 1;
+      if (plus >= e || *plus != '+') return fail("parallel FASTQ reader: multi-line FASTQ records (use RFX_HOST_THREADS=1)");
+      nl = (const char*)memchr(plus, '\n', (size_t)(e - plus));
+      if (!nl) return fail("truncated FASTQ record");
+      const char* q = nl + 1;
+      const char* qe = (const char*)memchr(q, '\n', (size_t)(e - q));
+      if (!qe) qe = e;  // last record of a file without a final newline
+      if ((size_t)(qe - q) != L) return fail("parallel FASTQ reader: quality and sequence lengths differ (multi-line FASTQ? use RFX_HOST_THREADS=1)");
+      start.push_back((uint64_t)(s - pc.b));
+      slen.push_back((uint32_t)L);
+      words += (L + 31) / 32;
+      p = qe < e ? qe + 1 : e;
+    }
+    // normally one reservation per piece; a piece with more reads than a staging block holds goes in slices
+    const size_t total = start.size();
+    size_t at = 0;
+    while (at < total) {
+      uint32_t n = 0;
+      uint64_t w = 0;
+      while (at + n < total && n < blocks_[0].cap_reads / 2 + 1) {
+        const uint64_t wr = (slen[at + n] + 31) / 32;
+        if (n && w + wr > blocks_[0].cap_words / 2) break;
+        w += wr;
+        ++n;
+      }
+      int blk;
+      uint32_t r0;
+      uint64_t w0;
+      if (!reserve(n, w, blk, r0, w0)) return;
+      StageBlock& b = blocks_[(size_t)blk];
+      b.word_off[r0] = (uint32_t)w0;
+      // rfx_pack_spans writes word_off[r0 .. r0+n]: the last entry is also the neighbour range's first -- reads and
+      // words are reserved together, so both writers store the same value
+      const int rc = rfx_pack_spans(pc.b, start.data() + at, slen.data() + at, nullptr, n, 0, RFX_PACK_COUNT, b.codes, b.acgt,
+                                    nullptr, b.word_off + r0, b.len + r0);
+      if (rc) fail(std::string("rfx_pack_spans: ") + rfx_strerror(rc));
+      release(blk);
+      at += n;
+    }
+    (void)words;
+  }
+
+  void worker() {
+    for (;;) {
+      Piece pc;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return !work_.empty() || closing_ || failed_; });
+        if (failed_ || (work_.empty() && closing_)) return;
+        pc = work_.front();
+        work_.pop_front();
+      }
+      parse_piece(pc);
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        if (pc.owner) pool_.push_back(pc.owner);
+        --pieces_open_;
+        cv_.notify_all();
+      }
+    }
+  }
+
+  void push_piece(const Piece& pc) {
+    std::lock_guard<std::mutex> g(mu_);
+    work_.push_back(pc);
+    ++pieces_open_;
+    cv_.notify_all();
+  }
+
+  // Upload every block that is ready; with `all`, wait until every queued piece is packed and seal the last block.
+  void drain(bool all) {
+    for (;;) {
+      int blk = -1;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        if (all) {
+          cv_.wait(g, [&] { return !ready_.empty() || pieces_open_ == 0 || failed_; });
+          if (failed_) break;
+          if (ready_.empty() && pieces_open_ == 0) {
+            if (current_ >= 0) {  // the partly filled last block
+              blocks_[(size_t)current_].sealed = true;
+              ready_.push_back(current_);
+              current_ = -1;
+            } else {
+              break;
+            }
+          }
+        }
+        if (ready_.empty()) break;
+        blk = ready_.front();
+        ready_.pop_front();
+      }
+      StageBlock& b = blocks_[(size_t)blk];
+      if (b.n_reads) {
+        b.word_off[b.n_reads] = (uint32_t)b.n_words;
+        reads_total_ += b.n_reads;
+        sink_(b);  // uploads it (rfx_reads_upload): the block is reused as soon as this returns
+      }
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        free_.push_back(blk);
+        cv_.notify_all();
+      }
+    }
+    if (failed_) die("rufus_amd jellyfish: " + fail_msg_);
+  }
+
+  // First position >= p where a 4-line FASTQ record starts ('@' line whose third line starts with '+' and whose
+  // second and fourth lines are equally long); e when there is none.
+  static const char* record_start(const char* p, const char* b, const char* e) {
+    if (p <= b) return b;
+    const char* nl = (const char*)memchr(p - 1, '\n', (size_t)(e - (p - 1)));
+    if (!nl) return e;
+    const char* l0 = nl + 1;
+    for (int tries = 0; tries < 8 && l0 < e; ++tries) {
+      const char* n0 = (const char*)memchr(l0, '\n', (size_t)(e - l0));
+      if (!n0) return e;
+      const char* l1 = n0 + 1;
+      const char* n1 = l1 < e ? (const char*)memchr(l1, '\n', (size_t)(e - l1)) : nullptr;
+      const char* l2 = n1 ? n1 + 1 : e;
+      const char* n2 = l2 < e ? (const char*)memchr(l2, '\n', (size_t)(e - l2)) : nullptr;
+      const char* l3 = n2 ? n2 + 1 : e;
+      const char* n3 = l3 < e ? (const char*)memchr(l3, '\n', (size_t)(e - l3)) : nullptr;
+      const char* l3e = n3 ? n3 : e;
+      if (*l0 == '@' && n1 && n2 && *l2 == '+' && (n1 - l1) == (l3e - l3)) return l0;
+      l0 = l1;
+    }
+    return e;
+  }
+
+ public:
+  // alloc / dealloc: page-locked memory on the GPU box (rfx_host_alloc), plain malloc in host-only tests
+  CountIngest(unsigned threads, std::function<void(const StageBlock&)> sink, void* (*alloc)(size_t) = rfx_host_alloc,
+              void (*dealloc)(void*) = rfx_host_free, uint32_t cap_reads = 4u << 20, uint64_t cap_words = 24ull << 20)
+      : sink_(std::move(sink)), nthreads_(threads ? threads : 1), dealloc_(dealloc) {
+    blocks_.resize(3);
+    for (size_t i = 0; i < blocks_.size(); ++i) {
+      StageBlock& b = blocks_[i];
+      b.cap_reads = cap_reads;
+      b.cap_words = cap_words;
+      b.codes = (uint64_t*)alloc(cap_words * 8);
+      b.acgt = (uint32_t*)alloc(cap_words * 4);
+      b.word_off = (uint32_t*)alloc(((size_t)cap_reads + 1) * 4);
+      b.len = (uint32_t*)alloc((size_t)cap_reads * 4);
+      if (!b.codes || !b.acgt || !b.word_off || !b.len) die("rufus_amd: cannot allocate pinned staging memory");
+      free_.push_back((int)i);
+    }
+    for (unsigned t = 0; t < nthreads_; ++t) workers_.emplace_back([this] { worker(); });
+  }
+
+  ~CountIngest() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      closing_ = true;
+      cv_.notify_all();
+    }
+    for (auto& t : workers_) t.join();
+    for (auto& b : blocks_) {
+      dealloc_(b.codes);
+      dealloc_(b.acgt);
+      dealloc_(b.word_off);
+      dealloc_(b.len);
+    }
+    for (auto* v : pool_) delete v;
+  }
+
+  uint64_t reads() const { return reads_total_; }
+  void set_piece_bytes(size_t n) { PIECE = n; }
+
+  // Does the stream look like strict 4-line FASTQ?  (head: its first bytes)
+  static bool looks_4line(const char* head, size_t n) {
+    if (n == 0 || head[0] != '@') return false;
+    const char* e = head + n;
+    const char* r = record_start(head, head, e);
+    if (r != head) return false;
+    // the second record (when the head is long enough to hold it) must follow immediately
+    const char* p = head;
+    for (int i = 0; i < 4; ++i) {
+      const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+      if (!nl) return true;
+      p = nl + 1;
+    }
+    return p >= e || *p == '@' || *p == '\n';
+  }
+
+  // A whole regular file, mapped.  Returns false if it is not strict 4-line FASTQ (nothing consumed).
+  bool feed_mapped(const char* data, size_t size) {
+    if (!looks_4line(data, std::min<size_t>(size, 1u << 16))) return false;
+    const char *b = data, *e = data + size;
+    const char* at = b;
+    while (at < e) {
+      const char* want = at + PIECE;
+      const char* cut = want >= e ? e : record_start(want, b, e);
+      push_piece(Piece{at, cut, nullptr});
+      at = cut;
+      drain(false);
+    }
+    drain(true);
+    return true;
+  }
+
+  // A pipe: `head` = bytes already read from it (at least the sniffed prefix).  One reader (this thread) cuts the
+  // stream every 4k lines.  Returns false if the head is not strict 4-line FASTQ (the caller then parses
+  // head + rest sequentially).
+  bool feed_stream(int fd, std::vector<char>& head) {
+    if (!looks_4line(head.data(), head.size())) return false;
+    std::vector<char>* buf = nullptr;
+    size_t fill = 0;
+    uint64_t line_in_rec = 0;  // lines of the current record already inside buf[0, scanned)
+    size_t scanned = 0, last_cut = 0;
+    auto fresh = [&]() {
+      // bound the text in flight (2 x workers pieces); this thread is also the uploader, so full blocks are
+      // uploaded while it waits -- the workers may be waiting for exactly that
+      std::vector<char>* v = nullptr;
+      for (;;) {
+        {
+          std::unique_lock<std::mutex> g(mu_);
+          cv_.wait(g, [&] { return !ready_.empty() || !pool_.empty() || pieces_open_ < 2 * (size_t)nthreads_ + 2 || failed_; });
+          if (failed_) break;
+          if (ready_.empty()) {
+            if (!pool_.empty()) {
+              v = pool_.front();
+              pool_.pop_front();
+            }
+            break;
+          }
+        }
+        drain(false);
+      }
+      if (!v) v = new std::vector<char>(PIECE + std::max<size_t>(PIECE / 8, 1u << 16));
+      return v;
+    };
+    buf = fresh();
+    memcpy(buf->data(), head.data(), head.size());
+    fill = head.size();
+    bool eof = false;
+    while (!eof || fill > 0) {
+      if (failed_) break;
+      // read until the buffer holds a piece
+      while (!eof && fill < PIECE) {
+        const ssize_t n = ::read(fd, buf->data() + fill, buf->size() - fill);
+        if (n < 0) {
+          if (errno == EINTR) continue;
+          die(std::string("read error on input: ") + strerror(errno));
+        }
+        if (n == 0) eof = true;
+        else fill += (size_t)n;
+      }
+      // last record boundary inside [0, fill): count lines
+      const char* d = buf->data();
+      size_t pos = scanned;
+      while (pos < fill) {
+        const char* nl = (const char*)memchr(d + pos, '\n', fill - pos);
+        if (!nl) break;
+        pos = (size_t)(nl - d) + 1;
+        if (++line_in_rec == 4) {
+          line_in_rec = 0;
+          last_cut = pos;
+        }
+      }
+      scanned = fill;
+      size_t cut = eof ? fill : last_cut;
+      if (cut == 0) {
+        if (fill == buf->size()) die("a FASTQ record is longer than the read buffer");
+        if (eof) break;
+        continue;
+      }
+      std::vector<char>* next = fresh();
+      const size_t rest = fill - cut;
+      memcpy(next->data(), d + cut, rest);
+      push_piece(Piece{d, d + cut, buf});
+      buf = next;
+      fill = rest;
+      scanned = rest;  // the carried bytes hold line_in_rec complete lines of an unfinished record (already counted)
+      last_cut = 0;
+      drain(false);
+      if (eof && fill == 0) break;
+    }
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      pool_.push_back(buf);
+    }
+    drain(true);
+    return true;
+  }
+};
+
+}  // namespace rfxcli

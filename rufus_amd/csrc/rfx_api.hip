@@ -621,6 +621,18 @@ int rfx_sync(rfx_ctx* c) {
 
 void* rfx_stream(rfx_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+void* rfx_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return p;
+}
+void rfx_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int rfx_mem_stats(rfx_ctx* c, uint64_t* used, uint64_t* peak, uint64_t* mapped) {
   if (!c) return RFX_E_NODEVICE;
   if (used) *used = c->used;
@@ -776,6 +788,8 @@ rfx_table* rfx_count_begin(rfx_ctx* c, int k, int canonical, int lsize, uint64_t
   t->ntab = hc->ntab;
   t->segs = new std::vector<rfx_segment>();
   t->pend = new std::vector<rfx_pending_add>();
+  t->deferred = new std::vector<const rfx_reads*>();
+  t->passes = -1;
   t->d_stats = (rfx_table_stats*)dmalloc(c, sizeof(rfx_table_stats));
   t->d_ctl = (rfx_count_ctl*)dmalloc(c, sizeof(rfx_count_ctl));
   const bool ok = t->d_stats && t->d_ctl &&
@@ -794,6 +808,7 @@ void rfx_count_free(rfx_table* t) {
   if (t->pend) {
     msp_forget_pending(t);
     delete t->pend;
+    delete t->deferred;
   }
   if (t->segs) {
     for (auto& sg : *t->segs) {
@@ -1417,13 +1432,11 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
   return RFX_OK;
 }
 
-static int msp_emit_queue(rfx_finish* f) {
-  rfx_table* t = f->t;
+// Bin count the leaf needs for the table's current segments, and (when they are coarser than that) the host
+// copies of their bin extents, after settling the pending adds: *refine tells which leaf path applies.
+static int msp_prepare_leaf(rfx_table* t, int* to_bits_out, bool* refine_out, std::vector<std::vector<uint64_t>>& h_bs,
+                            uint64_t* kmers_out, bool force_refine) {
   rfx_ctx* c = t->ctx;
-  const uint32_t P1 = (uint32_t)rfxk::p1_bins();
-  const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
-  // One bin count for all segments; more bins when the table holds more than ~1.5 x 16 K instances per
-  // bin (several read blocks, or blocks far beyond 1 M reads) -- the LDS table of the leaf is fixed.
   uint64_t kmers = 0;
   uint32_t pmax = 0, pmin = ~0u;
   for (auto& sg : *t->segs) {
@@ -1431,13 +1444,15 @@ static int msp_emit_queue(rfx_finish* f) {
     pmax = std::max(pmax, sg.bins);
     pmin = std::min(pmin, sg.bins);
   }
+  // One bin count for all segments; more bins when the table holds more than ~1.5 x 16 K instances per
+  // bin (several read blocks, or blocks far beyond 1 M reads) -- the LDS table of the leaf is fixed.
   int to_bits = ceil_log2(pmax);
   // (a shard pass fills only its share of the bins: density as if every shard were present)
   const uint64_t kfull = kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1);
   while (to_bits < 28 && (kfull >> to_bits) > 24576) ++to_bits;
   if (getenv("RFX_MSP_REFINE_BITS")) to_bits = std::max(to_bits, atoi(getenv("RFX_MSP_REFINE_BITS")));
-  const bool refine = pmin < (1u << to_bits);
-  std::vector<std::vector<uint64_t>> h_bs;
+  const bool refine = force_refine || pmin < (1u << to_bits);
+  h_bs.clear();
   if (refine) {
     // the chunks are cut by size: settle the pending adds and fetch every segment's bin extents (one sync)
     int rc = msp_resolve(t);
@@ -1450,44 +1465,219 @@ static int msp_emit_queue(rfx_finish* f) {
     }
     HIPCHK(ctx_sync(c));
   }
-  const int nseg = (int)t->segs->size();
-  f->kmers = kmers;
-  if (!f->cap) {
-    // Survivors per instance: unknown before counting.  Samples of one run look alike, so the ratio the
-    // last emit on this ctx saw (+30 %) is the guess; the first emit assumes a quarter (singletons
-    // dropped; 8 % for big inputs, where a rerun is cheaper than the memory) or 60 %.  A guess that
-    // is too small costs one rerun with the capacity the cursors report.
-    const double seen = c->msp_surv_frac[f->lower >= 2 ? 1 : 0];
-    double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? (kmers > (1ull << 32) ? 0.08 : 0.25) : 0.6);
-    if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
-    f->cap = (uint64_t)((double)f->kmers * frac) / P1;
-    f->cap += f->cap / 8 + 4096;
+  *to_bits_out = to_bits;
+  *refine_out = refine;
+  *kmers_out = kmers;
+  return RFX_OK;
+}
+
+static int msp_add(rfx_table* t, const rfx_reads* r);
+
+// Deferred adds (rfx_count_set_passes): the read blocks stayed with the caller, nothing was partitioned yet.
+// S minimizer-shard passes over them: partition the shard's runs of every block, refine + count (the leaf
+// appends the shard's survivors to the coarse pos bins), free the records, next shard.  Only 1/S of the
+// sample's super-k-mer records ever exist -- the analogue of jellyfish filling its table, dumping a sorted
+// partial file and merging at the end (jf/include/jellyfish/hash_counter.hpp:182-202,
+// jf/sub_commands/count_main.cc:326-339), except that the shards are disjoint in k-mer space, so the "merge"
+// is the one survivor sort that follows anyway.  Leaves f->aw / f->ac / f->cap / f->bsq filled and f->h_cur
+// = the final cursors.
+static int msp_passes_leaf(rfx_finish* f) {
+  rfx_table* t = f->t;
+  rfx_ctx* c = t->ctx;
+  const uint32_t P1 = (uint32_t)rfxk::p1_bins();
+  const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride(), stride = (size_t)rfxk::p1_cur_stride();
+  uint64_t windows = 0;
+  for (const rfx_reads* r : *t->deferred) windows += r->windows_of(t->k);
+  int S = t->passes;
+  if (S <= 0) {  // plan: the records of a pass (8 B per ~3 k-mers) + scratch beside what is already resident
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 64ull << 30;
+    const double avail = 0.88 * ((double)free_b + (double)(c->arena_mapped - std::min(c->arena_mapped, c->used)));
+    const double surv = (double)windows / 20.0 * 44.0;  // survivor arrays at the end (12 + 12 + 20 B each)
+    const double records = (double)windows * 2.9 * 1.15;
+    S = 1;
+    while (S < 256 && records / S + surv > avail) ++S;
+    if (const char* ev = getenv("RFX_COUNT_PASSES")) S = std::max(1, atoi(ev));
   }
-  if (f->cap >= (1ull << 32)) f->cap = (1ull << 32) - 1;
-  const uint64_t cap = f->cap, room = cap * P1;
-  f->room = room;
-  const rfx_ord_cfg cfg0 = ord_cfg(t, 7);
-  f->aw = (uint64_t*)dmalloc(c, room * 8);
-  f->ac = (uint32_t*)dmalloc(c, room * 4);
-  // one zeroed block: histogram, coarse cursors ([ncur] = capacity flag, [ncur+1] = error)
+  if (S > 256) S = 256;
   const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + 2) * 4;
   f->bsq = (uint64_t*)dmalloc(c, zero_bytes);
-  unsigned long long* d_histo = (unsigned long long*)f->bsq;
-  uint32_t* cur = f->bsq ? (uint32_t*)(d_histo + RFX_HISTO_BINS) : nullptr;
+  if (!f->bsq) return RFX_E_NOMEM;
+  uint32_t* cur = (uint32_t*)((unsigned long long*)f->bsq + RFX_HISTO_BINS);
+  HIPCHK(hipMemsetAsync(f->bsq, 0, zero_bytes, c->stream));
+  std::vector<uint32_t> cur_prev(ncur + 2, 0);
+  f->h_cur.assign(ncur + 2, 0);
+  f->kmers = 0;
+  const rfx_ord_cfg cfg0 = ord_cfg(t, 7);
+  for (int s = 0; s < S; ++s) {
+    t->shard = s;
+    t->n_shards = S;
+    for (const rfx_reads* r : *t->deferred) {
+      if (r->n == 0) continue;
+      const int rc = msp_add(t, r);
+      if (rc) return rc;
+    }
+    if (t->segs->empty()) continue;
+    int to_bits = 0;
+    bool refine = false;
+    uint64_t kmers = 0;
+    std::vector<std::vector<uint64_t>> h_bs;
+    int rc = msp_prepare_leaf(t, &to_bits, &refine, h_bs, &kmers, true);
+    if (rc) return rc;
+    f->kmers += kmers;
+    if (!f->aw) {  // first pass with records: the store is sized for ONE pass, then for all (below)
+      const double seen = c->msp_surv_frac[f->lower >= 2 ? 1 : 0];
+      double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? (kmers > (1ull << 32) ? 0.08 : 0.25) : 0.6);
+      if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
+      f->cap = (uint64_t)((double)kmers * frac) / P1;
+      f->cap += f->cap / 8 + 4096;
+      if (f->cap >= (1ull << 32)) f->cap = (1ull << 32) - 1;
+      f->aw = (uint64_t*)dmalloc(c, f->cap * P1 * 8);
+      f->ac = (uint32_t*)dmalloc(c, f->cap * P1 * 4);
+      if (!f->aw || !f->ac) return RFX_E_NOMEM;
+    }
+    for (int attempt = 0;; ++attempt) {
+      rc = msp_leaf_refined(f, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
+      if (rc) { (void)ctx_sync(c); return rc; }
+      hipError_t e = queue_read(c, f->h_cur.data(), cur, (ncur + 2) * 4);
+      if (e == hipSuccess) e = ctx_sync(c);
+      if (e != hipSuccess) return hip_fail(e, "msp_passes");
+      if (f->h_cur[ncur + 1]) {
+        snprintf(g_err, sizeof g_err, "MSP: a bin could not be split far enough to fit LDS");
+        return RFX_E_FULL;
+      }
+      if (!f->h_cur[ncur]) break;
+      // A coarse pos bin overflowed in this pass.  The cursors kept counting: enlarge the store, put back what
+      // the earlier passes left (their content and cursors), and run the pass's leaf again.
+      if (attempt >= 3) {
+        snprintf(g_err, sizeof g_err, "MSP: survivor store did not converge (internal error)");
+        return RFX_E_FULL;
+      }
+      uint64_t need = f->cap;
+      for (uint32_t cb = 0; cb < P1; ++cb) need = std::max<uint64_t>(need, f->h_cur[cb * stride]);
+      const uint64_t ncap = std::min<uint64_t>(need + need / 16 + 4096, (1ull << 32) - 1);
+      uint64_t* naw = (uint64_t*)dmalloc(c, ncap * P1 * 8);
+      uint32_t* nac = (uint32_t*)dmalloc(c, ncap * P1 * 4);
+      if (!naw || !nac) { dfree(c, naw); dfree(c, nac); return RFX_E_NOMEM; }
+      for (uint32_t cb = 0; cb < P1; ++cb) {
+        const uint64_t n = cur_prev[cb * stride];
+        if (!n) continue;
+        HIPCHK(hipMemcpyAsync(naw + cb * ncap, f->aw + cb * f->cap, n * 8, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(nac + cb * ncap, f->ac + cb * f->cap, n * 4, hipMemcpyDeviceToDevice, c->stream));
+      }
+      dfree(c, f->aw);
+      dfree(c, f->ac);
+      f->aw = naw;
+      f->ac = nac;
+      f->cap = ncap;
+      cur_prev[ncur] = cur_prev[ncur + 1] = 0;
+      HIPCHK(upload(c, cur, cur_prev.data(), (ncur + 2) * 4));
+    }
+    p2l_drop_segments(t);
+    cur_prev = f->h_cur;
+    if (s == 0 && S > 1) {  // now sized for all passes: the shards are equal shares of a hash space
+      uint64_t mx = 0;
+      for (uint32_t cb = 0; cb < P1; ++cb) mx = std::max<uint64_t>(mx, f->h_cur[cb * stride]);
+      const uint64_t ncap = std::min<uint64_t>(mx * (uint64_t)S + mx * (uint64_t)S / 12 + 8192, (1ull << 32) - 1);
+      if (ncap > f->cap) {
+        uint64_t* naw = (uint64_t*)dmalloc(c, ncap * P1 * 8);
+        uint32_t* nac = (uint32_t*)dmalloc(c, ncap * P1 * 4);
+        if (!naw || !nac) { dfree(c, naw); dfree(c, nac); return RFX_E_NOMEM; }
+        for (uint32_t cb = 0; cb < P1; ++cb) {
+          const uint64_t n = f->h_cur[cb * stride];
+          if (!n) continue;
+          HIPCHK(hipMemcpyAsync(naw + cb * ncap, f->aw + cb * f->cap, n * 8, hipMemcpyDeviceToDevice, c->stream));
+          HIPCHK(hipMemcpyAsync(nac + cb * ncap, f->ac + cb * f->cap, n * 4, hipMemcpyDeviceToDevice, c->stream));
+        }
+        dfree(c, f->aw);
+        dfree(c, f->ac);
+        f->aw = naw;
+        f->ac = nac;
+        f->cap = ncap;
+      }
+    }
+  }
+  t->shard = 0;
+  t->n_shards = 1;
+  if (!f->aw) {  // no k-mer at all
+    f->cap = 1;
+    f->aw = (uint64_t*)dmalloc(c, P1 * 8);
+    f->ac = (uint32_t*)dmalloc(c, P1 * 4);
+    if (!f->aw || !f->ac) return RFX_E_NOMEM;
+  }
+  t->deferred->clear();
+  f->segs_dropped = true;
+  return RFX_OK;
+}
+
+static int msp_emit_queue(rfx_finish* f) {
+  rfx_table* t = f->t;
+  rfx_ctx* c = t->ctx;
+  const uint32_t P1 = (uint32_t)rfxk::p1_bins();
+  const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
+  const bool deferred = !t->deferred->empty();
+  int to_bits = 0;
+  bool refine = false;
+  uint64_t kmers = 0;
+  std::vector<std::vector<uint64_t>> h_bs;
+  if (deferred) {
+    const int rc = msp_passes_leaf(f);
+    if (rc) {
+      (void)ctx_sync(c);
+      msp_emit_drop(f);
+      p2l_drop_segments(t);
+      return rc;
+    }
+    refine = true;
+    kmers = f->kmers;
+  } else {
+    const int rc = msp_prepare_leaf(t, &to_bits, &refine, h_bs, &kmers, false);
+    if (rc) return rc;
+  }
+  const uint64_t kfull = kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1);
+  const int nseg = (int)t->segs->size();
+  f->kmers = kmers;
+  const rfx_ord_cfg cfg0 = ord_cfg(t, 7);
   auto fail = [&](int rc) {
     msp_emit_drop(f);
     rfx_records_free(f->big);
     f->big = nullptr;
     return rc;
   };
-  if (!f->aw || !f->ac || !f->bsq) return fail(RFX_E_NOMEM);
-  hipError_t e = hipMemsetAsync(f->bsq, 0, zero_bytes, c->stream);
-  if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
+  hipError_t e = hipSuccess;
+  if (!deferred) {
+    if (!f->cap) {
+      // Survivors per instance: unknown before counting.  Samples of one run look alike, so the ratio the
+      // last emit on this ctx saw (+30 %) is the guess; the first emit assumes a quarter (singletons
+      // dropped; 8 % for big inputs, where a rerun is cheaper than the memory) or 60 %.  A guess that
+      // is too small costs one rerun with the capacity the cursors report.
+      const double seen = c->msp_surv_frac[f->lower >= 2 ? 1 : 0];
+      double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? (kmers > (1ull << 32) ? 0.08 : 0.25) : 0.6);
+      if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
+      f->cap = (uint64_t)((double)f->kmers * frac) / P1;
+      f->cap += f->cap / 8 + 4096;
+    }
+    if (f->cap >= (1ull << 32)) f->cap = (1ull << 32) - 1;
+    f->aw = (uint64_t*)dmalloc(c, f->cap * P1 * 8);
+    f->ac = (uint32_t*)dmalloc(c, f->cap * P1 * 4);
+    // one zeroed block: histogram, coarse cursors ([ncur] = capacity flag, [ncur+1] = error)
+    const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + 2) * 4;
+    f->bsq = (uint64_t*)dmalloc(c, zero_bytes);
+    if (!f->aw || !f->ac || !f->bsq) return fail(RFX_E_NOMEM);
+    e = hipMemsetAsync(f->bsq, 0, zero_bytes, c->stream);
+    if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
+    f->h_cur.assign(ncur + 2, 0);
+  }
+  const uint64_t cap = f->cap, room = cap * P1;
+  f->room = room;
+  unsigned long long* d_histo = (unsigned long long*)f->bsq;
+  uint32_t* cur = (uint32_t*)(d_histo + RFX_HISTO_BINS);
   f->pflags.assign(t->pend->size(), 1u);
-  f->h_cur.assign(ncur + 2, 0);
 
   // ---- leaf phase: every minimizer bin counted in LDS, survivors appended to 128 coarse pos bins ----
-  if (!refine) {
+  if (deferred) {
+    // done by msp_passes_leaf, shard by shard
+  } else if (!refine) {
     const uint32_t P = t->segs->front().bins;
     f->h_ptrs.assign(2 * (size_t)nseg, nullptr);
     for (int i = 0; i < nseg; ++i) {
@@ -1692,6 +1882,11 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
   if (r->n == 0) return RFX_OK;
+  if (t->passes >= 0) {  // rfx_count_set_passes: counted at finish, shard pass by shard pass
+    if (r->windows_of(t->k) >= (1ull << 32)) return RFX_E_RANGE;
+    t->deferred->push_back(r);
+    return RFX_OK;
+  }
   if (t->mode != RFX_COUNT_TABLE && !t->table_active && t->lut_t) {  // P2L needs 2k <= 62 and full-rank M
     // segments of one table are of one kind; MSP where the record format allows it
     const bool msp = t->seg_kind ? t->seg_kind == RFX_COUNT_MSP
@@ -1767,6 +1962,21 @@ int rfx_count_set_shard(rfx_table* t, int shard, int n_shards) {
   t->shard = shard;
   t->n_shards = n_shards;
   if (n_shards > 1) t->mode = RFX_COUNT_MSP;
+  return RFX_OK;
+}
+
+int rfx_count_set_passes(rfx_table* t, int passes) {
+  if (!t || passes < 0 || passes > 256) return RFX_E_INVAL;
+  if (!t->segs->empty() || t->table_active || t->n_shards > 1) {
+    snprintf(g_err, sizeof g_err, "rfx_count_set_passes: set the passes before the first rfx_count_add, not on a shard table");
+    return RFX_E_INVAL;
+  }
+  if (!rfxk::msp_k_ok(t->k) || !t->lut_t) {
+    snprintf(g_err, sizeof g_err, "rfx_count_set_passes: shard passes need the MSP path (23 <= k <= 25)");
+    return RFX_E_INVAL;
+  }
+  t->passes = passes;
+  t->mode = RFX_COUNT_MSP;
   return RFX_OK;
 }
 
@@ -1871,7 +2081,7 @@ rfx_finish* rfx_count_finish_begin(rfx_table* t, uint64_t lower, uint64_t upper,
   f->lower = lower;
   f->upper = upper;
   f->histo = histo;
-  if (!t->pend_error && !t->segs->empty() && !t->table_active && t->seg_kind == RFX_COUNT_MSP) {
+  if (!t->pend_error && !t->table_active && ((!t->segs->empty() && t->seg_kind == RFX_COUNT_MSP) || !t->deferred->empty())) {
     if (msp_emit_queue(f) != RFX_OK) f->failed = true;  // nothing waited for: the work is only queued
   } else {
     f->ready = rfx_count_finish(t, lower, upper, histo);  // paths without a queued form finish here
@@ -1901,6 +2111,7 @@ rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint
     snprintf(g_err, sizeof g_err, "a deferred MSP re-partition failed (%s); the table is incomplete", rfx_strerror(t->pend_error));
     return nullptr;
   }
+  if (!t->deferred->empty() && !t->table_active) return msp_emit(t, lower, upper, histo);
   if (!t->segs->empty()) {
     if (!t->table_active) {
       if (t->seg_kind == RFX_COUNT_MSP) return msp_emit(t, lower, upper, histo);
@@ -1991,6 +2202,23 @@ int rfx_records_payload(const rfx_records* r, void* out, size_t cap_bytes, int c
   if (e == hipSuccess) e = ctx_sync(c);
   dfree(c, d);
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_payload");
+}
+
+int rfx_records_payload_range(const rfx_records* r, uint64_t first, uint64_t n, void* out, size_t cap_bytes, int counter_len) {
+  if (!r || counter_len < 1 || counter_len > 8 || first > r->n || n > r->n - first) return RFX_E_INVAL;
+  rfx_ctx* c = r->ctx;
+  (void)hipSetDevice(c->device);
+  const int kb = (2 * r->k + 7) / 8;
+  const size_t bytes = (size_t)n * (kb + counter_len);
+  if (bytes > cap_bytes) return RFX_E_RANGE;
+  if (n == 0) return RFX_OK;
+  uint8_t* d = (uint8_t*)dmalloc(c, bytes);
+  if (!d) return RFX_E_NOMEM;
+  rfxk::format_records(c, r->keys + first, r->counts + first, n, kb, counter_len, d);
+  hipError_t e = hipMemcpyAsync(out, d, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = ctx_sync(c);
+  dfree(c, d);
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_payload_range");
 }
 
 int rfx_records_get(const rfx_records* r, uint64_t* keys, uint32_t* counts, uint64_t* pos) {

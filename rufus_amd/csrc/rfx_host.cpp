@@ -297,6 +297,55 @@ int rfx_pack_reads(const char* seq, const char* qual, const uint64_t* off, uint3
   return err.load();
 }
 
+// Packing of reads that lie scattered in a text buffer (FASTQ records parsed in place): read i is the seq_len[i]
+// bytes at base + seq_start[i], its qualities (RFX_PACK_FILTER) the same number of bytes at base + qual_start[i].
+// Single-threaded: the callers (the drop-in executables' ingest pipelines) run one call per worker thread on
+// disjoint output ranges.  word_off[0] is an INPUT (the first word index of this range in the block), the
+// other n entries and len[0..n) are written; codes / acgt / good are indexed by those word offsets.
+int rfx_pack_spans(const char* base, const uint64_t* seq_start, const uint32_t* seq_len, const uint64_t* qual_start,
+                   uint32_t n_reads, int min_q, int flags, uint64_t* codes, uint32_t* acgt, uint32_t* good,
+                   uint32_t* word_off, uint32_t* len) {
+  if (!base || !seq_start || !seq_len || !codes || !word_off || !len) return RFX_E_INVAL;
+  const bool want_count = flags & RFX_PACK_COUNT, want_filter = flags & RFX_PACK_FILTER;
+  if ((want_count && !acgt) || (want_filter && (!good || !qual_start)) || (!want_count && !want_filter)) return RFX_E_INVAL;
+  const PackLut& T = g_pack_lut;
+  uint64_t w = word_off[0];
+  for (uint32_t r = 0; r < n_reads; ++r) {
+    const uint32_t L = seq_len[r];
+    const unsigned char* s = (const unsigned char*)base + seq_start[r];
+    const signed char* q = want_filter ? (const signed char*)base + qual_start[r] : nullptr;
+    word_off[r] = (uint32_t)w;
+    len[r] = L;
+    if (w + (L + 31) / 32 > 0xFFFFFFFFull) return RFX_E_RANGE;
+    for (uint32_t i = 0; i < L; i += 32, ++w) {
+      uint64_t cw = 0;
+      uint32_t ma = 0, mg = 0;
+      const uint32_t nb = std::min<uint32_t>(32, L - i);
+      if (!want_filter) {
+        for (uint32_t b = 0; b < nb; ++b) {
+          cw |= (uint64_t)T.jcode[s[i + b]] << (2 * b);
+          ma |= (uint32_t)T.jvalid[s[i + b]] << b;
+        }
+      } else {
+        for (uint32_t b = 0; b < nb; ++b) {
+          const unsigned char ch = s[i + b];
+          cw |= (uint64_t)T.fcode[ch] << (2 * b);
+          if (want_count) {
+            if (T.lower_cgt[ch]) return RFX_E_MIXEDCASE;
+            ma |= (uint32_t)T.jvalid[ch] << b;
+          }
+          mg |= (uint32_t)(!((int)q[i + b] - 33 < min_q || ch == 'N')) << b;  // src/RUFUS.Filter.cpp:205
+        }
+      }
+      codes[w] = cw;
+      if (acgt) acgt[w] = ma;
+      if (good) good[w] = mg;
+    }
+  }
+  word_off[n_reads] = (uint32_t)w;
+  return RFX_OK;
+}
+
 long rfx_hashlist_keys(const char* text, size_t n, int k, int single_end, uint64_t* keys_out, size_t cap) {
   if (!text || k < 1 || k > 32) return RFX_E_INVAL;
   const char first = single_end ? '\t' : ' ', second = single_end ? ' ' : '\t';

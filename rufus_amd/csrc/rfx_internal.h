@@ -170,6 +170,8 @@ struct rfx_table {
   int seg_kind;       // what the segments hold: 0 nothing yet, RFX_COUNT_P2L words, RFX_COUNT_MSP records
   std::vector<rfx_pending_add>* pend;
   int shard, n_shards;  // n_shards > 1: keep only the minimizer bins of this shard (rfx_count_set_shard)
+  int passes;           // -1: adds count at once; >= 0: adds are deferred, finish runs that many shard passes (0 = plan)
+  std::vector<const rfx_reads*>* deferred;  // read blocks of the deferred adds (not owned)
   int pend_error;     // a deferred redo failed: the table cannot be finished
   std::vector<rfx_segment>* segs;
   uint64_t* lut_t;     // device LUT of T (key -> sortable word), null when M is rank deficient

@@ -121,3 +121,58 @@ def test_count_reads_a_named_pipe_and_several_files(testrun, tmp_path):
     blob = open(f"{d}/M2.Jhash", "rb").read()
     assert hashlib.sha256(blob[9 + int(blob[:9]):]).hexdigest() == want
     assert sh([f"{BIN}/jellyfish", "count", "-m", "25", "-s", "1M", "nonexistent.fa"], d).returncode != 0
+
+
+def _payload(path):
+    blob = open(path, "rb").read()
+    return blob[9 + int(blob[:9]):]
+
+
+def test_count_cli_parallel_ingest_and_shard_passes(tmp_path):
+    """`jellyfish count` with worker threads: a mapped file, a named pipe (one reader cutting the stream), the
+    deferred mode (packed reads resident, shard passes inside the table: what a 30x sample takes) and the
+    sequential parser all write the same payload -- the oracle's.  A FASTQ without a final newline and blank
+    lines between records are tolerated; a multi-line FASTQ falls back to the sequential parser."""
+    import numpy as np
+    import oracle
+    from rufus_amd import capi
+    d = str(tmp_path)
+    n_pairs = 40_000
+    r = sh([f"{BIN}/rfx_synth_fastq", "400000", "0", "12", "4242", "0", str(n_pairs), "reads.fq"], d)
+    assert r.returncode == 0, r.stderr
+    sy = capi.Synth.sample(400_000, 0, n_snv=12, seed=4242)
+    seq, _ = sy.text(0, n_pairs)
+    ref = oracle.count(None, 25, 8 << 30, lower=2, reads=[x.tobytes() for x in seq]).payload()
+    args = [f"{BIN}/jellyfish", "count", "--disk", "-m", "25", "-L", "2", "-s", "8G", "-C"]
+    env = dict(os.environ)
+
+    def run(out, src, extra_env=None, t="8"):
+        e = dict(env)
+        e.update(extra_env or {})
+        p = subprocess.run(args + ["-t", t, "-o", out, src], cwd=d, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=300)
+        assert p.returncode == 0, p.stderr
+        return _payload(f"{d}/{out}")
+
+    assert run("mapped.jf", "reads.fq") == ref
+    assert run("seq.jf", "reads.fq", t="1") == ref
+    assert run("defer.jf", "reads.fq", {"RFX_COUNT_DEFER": "1", "RFX_COUNT_PASSES": "3"}) == ref
+    os.mkfifo(f"{d}/pipe.fq")
+    feeder = threading.Thread(target=lambda: open(f"{d}/pipe.fq", "wb").write(open(f"{d}/reads.fq", "rb").read()))
+    feeder.start()
+    got = run("pipe.jf", "pipe.fq", {"RFX_COUNT_PASSES": "2"})
+    feeder.join()
+    assert got == ref
+    # no final newline + blank lines between records
+    text = open(f"{d}/reads.fq", "rb").read()
+    recs = text.rstrip(b"\n").split(b"\n@")
+    open(f"{d}/odd.fq", "wb").write(b"\n\n@".join(recs))
+    assert run("odd.jf", "odd.fq") == ref
+    # multi-line FASTQ: sequence and qualities wrapped at 60 columns
+    lines = text.split(b"\n")
+    wrapped = []
+    for i in range(0, len(lines) - 1, 4):
+        h, s, p, q = lines[i:i + 4]
+        wrapped += [h] + [s[j:j + 60] for j in range(0, len(s), 60)] + [p] + [q[j:j + 60] for j in range(0, len(q), 60)]
+    open(f"{d}/wrapped.fq", "wb").write(b"\n".join(wrapped) + b"\n")
+    assert run("wrapped.jf", "wrapped.fq") == ref

@@ -245,3 +245,35 @@ def test_trio_strong_scaled_over_two_ranks(passes, block_pairs):
     assert got[0][3] == got[1][3] == want and want
     assert got[0][4] == got[1][4] == len(pulled_o)
     assert sorted(got[0][5] + got[1][5]) == pulled_o.tolist()
+
+
+@pytest.mark.parametrize("passes,surv_frac,refine", [(0, None, None), (1, None, None), (3, None, "17"), (4, "0.0005", None),
+                                                      (7, "0.02", "20")])
+def test_table_counts_a_sample_in_shard_passes(ctx, monkeypatch, passes, surv_frac, refine):
+    """rfx_count_set_passes: the adds only remember the blocks, finish runs the shard passes inside the table
+    and sorts the survivors of all passes once -- the full (pos,key)-ordered record list, as the drop-in
+    `jellyfish count` writes it.  A starved survivor store (RFX_MSP_SURV_FRAC) exercises the regrow-and-redo
+    of the first and of later passes."""
+    if surv_frac:
+        monkeypatch.setenv("RFX_MSP_SURV_FRAC", surv_frac)
+    if refine:
+        monkeypatch.setenv("RFX_MSP_REFINE_BITS", refine)
+    sy = capi.Synth.sample(300_000, 0, n_snv=10, seed=99)
+    n_pairs = 30_000
+    seq, _ = sy.text(0, n_pairs)
+    ref = oracle.count(None, K, SIZE, lower=LOWER, reads=[r.tobytes() for r in seq])
+    blocks = wgs.make_sample(ctx, sy, n_pairs, 8000, MIN_Q, want_good=False)
+    t = capi.CountTable(ctx, K, SIZE)
+    t.set_passes(passes)
+    for b in blocks:
+        t.add(b)
+    rec, h = t.finish(LOWER, want_histo=True)
+    assert rec.payload() == ref.payload()
+    assert np.array_equal(h, oracle.histo(ref.counts, full=True)[0])
+    n = len(rec)
+    cuts = [0, 1, n // 3, n // 3, n - 5, n]
+    assert b"".join(rec.payload_range(a, b - a) for a, b in zip(cuts, cuts[1:])) == ref.payload()
+    rec.free()
+    t.free()
+    for b in blocks:
+        b.free()

@@ -50,7 +50,10 @@ class CountIngest {
   struct Piece {
     const char* b;
     const char* e;
-    std::vector<char>* owner;  // heap buffer of a pipe piece (returned to the pool), null for mmap
+    std::vector<char>* owner;  // heap buffer of a pipe piece (returned to the pool), null otherwise
+    int fd = -1;               // >= 0: a byte range [lo, hi) of a regular file -- the worker reads it itself and
+    uint64_t lo = 0, hi = 0;   // parses the records that START inside the range
+    uint64_t fsize = 0;
   };
   std::deque<Piece> work_;
   std::deque<int> ready_, free_;
@@ -181,7 +184,31 @@ class CountIngest {
     (void)words;
   }
 
+  // A range of a regular file: read it (plus one byte before and the tail of the record that straddles its
+  // end) into the worker's own buffer -- pread scales with the threads, faulting a 20 GB mapping page by page
+  // does not -- and parse the records that start inside [lo, hi).
+  void parse_range(const Piece& pc, std::vector<char>& buf) {
+    const uint64_t SLACK = 1u << 20;  // longest record the tail may hold
+    const uint64_t from = pc.lo ? pc.lo - 1 : 0, to = std::min<uint64_t>(pc.fsize, pc.hi + SLACK);
+    buf.resize((size_t)(to - from));
+    size_t got = 0;
+    while (got < buf.size()) {
+      const ssize_t n = ::pread(pc.fd, buf.data() + got, buf.size() - got, (off_t)(from + got));
+      if (n < 0 && errno == EINTR) continue;
+      if (n <= 0) return fail(std::string("read error on input: ") + strerror(errno));
+      got += (size_t)n;
+    }
+    const char *b = buf.data(), *e = buf.data() + buf.size();
+    const char* s0 = pc.lo ? record_start(b + 1, b, e) : b;                       // first record starting at >= lo
+    const char* hi_p = b + (pc.hi - from);
+    const char* s1 = pc.hi >= pc.fsize ? e : record_start(hi_p, b, e);             // first record starting at >= hi
+    if (pc.hi < pc.fsize && s1 == e && to < pc.fsize) return fail("a FASTQ record is longer than 1 MB");
+    if (s0 >= s1) return;
+    parse_piece(Piece{s0, s1, nullptr});
+  }
+
   void worker() {
+    std::vector<char> buf;
     for (;;) {
       Piece pc;
       {
@@ -191,7 +218,8 @@ class CountIngest {
         pc = work_.front();
         work_.pop_front();
       }
-      parse_piece(pc);
+      if (pc.fd >= 0) parse_range(pc, buf);
+      else parse_piece(pc);
       {
         std::lock_guard<std::mutex> g(mu_);
         if (pc.owner) pool_.push_back(pc.owner);
@@ -334,6 +362,31 @@ class CountIngest {
       const char* cut = want >= e ? e : record_start(want, b, e);
       push_piece(Piece{at, cut, nullptr});
       at = cut;
+      drain(false);
+    }
+    drain(true);
+    return true;
+  }
+
+  // A whole regular file by descriptor: byte ranges, read by the workers themselves.  Returns false if the file
+  // does not start like strict 4-line FASTQ (nothing consumed).
+  bool feed_file(int fd, uint64_t size) {
+    std::vector<char> head((size_t)std::min<uint64_t>(size, 1u << 16));
+    size_t got = 0;
+    while (got < head.size()) {
+      const ssize_t n = ::pread(fd, head.data() + got, head.size() - got, (off_t)got);
+      if (n < 0 && errno == EINTR) continue;
+      if (n <= 0) break;
+      got += (size_t)n;
+    }
+    if (!looks_4line(head.data(), got)) return false;
+    for (uint64_t lo = 0; lo < size; lo += PIECE) {
+      Piece pc{nullptr, nullptr, nullptr};
+      pc.fd = fd;
+      pc.lo = lo;
+      pc.hi = std::min<uint64_t>(size, lo + PIECE);
+      pc.fsize = size;
+      push_piece(pc);
       drain(false);
     }
     drain(true);

@@ -7,47 +7,15 @@
 // they are read interleaved, 4 lines each (src/RUFUS.Filter.cpp:165-173) -- never one file ahead.
 // Pulled records are written in input order (the reference's order depends on OpenMP scheduling; at
 // one thread it is input order too).  The scan itself runs in k_filter; no CPU fallback.
+#include <condition_variable>
+#include <deque>
 #include <fstream>
+#include <map>
+#include <mutex>
 
 #include "rfx_cli.hpp"
 
 using namespace rfxcli;
-
-// The 4 lines of every record of a batch, back to back in one arena (no per-line allocations: a batch is
-// half a million records).  Line j of record i is text[off[4i+j] .. off[4i+j+1]).
-struct RecBatch {
-  std::string text;
-  std::vector<uint64_t> off{0};
-  void clear() {
-    text.clear();
-    off.assign(1, 0);
-  }
-  size_t n() const { return (off.size() - 1) / 4; }
-  const char* line(size_t i, int j) const { return text.data() + off[4 * i + (size_t)j]; }
-  size_t len(size_t i, int j) const { return (size_t)(off[4 * i + (size_t)j + 1] - off[4 * i + (size_t)j]); }
-  // Appends one record; false at end of input.  Missing trailing lines read as empty (the reference's
-  // getline leaves the previous/empty string there; an incomplete last record is garbage in both).
-  bool read(LineReader& in) {
-    const char *b, *e;
-    if (!in.getline(b, e)) return false;
-    text.append(b, e);
-    off.push_back(text.size());
-    for (int j = 1; j < 4; ++j) {
-      if (in.getline(b, e)) text.append(b, e);
-      off.push_back(text.size());
-    }
-    return true;
-  }
-  void write(std::ostream& os, size_t i, const char* header_suffix = nullptr) const {
-    os.write(line(i, 0), (std::streamsize)len(i, 0));
-    if (header_suffix) os << header_suffix;
-    os.put('\n');
-    for (int j = 1; j < 4; ++j) {
-      os.write(line(i, j), (std::streamsize)len(i, j));
-      os.put('\n');
-    }
-  }
-};
 
 int main(int argc, char** argv) {
 #ifdef RFX_SINGLE_END
@@ -79,8 +47,8 @@ int main(int argc, char** argv) {
     }
     text.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
   }
-  LineReader in1;
-  if (!in1.open(m1)) {
+  const int fd1 = strcmp(m1, "stdin") == 0 || strcmp(m1, "/dev/stdin") == 0 ? 0 : ::open(m1, O_RDONLY);
+  if (fd1 < 0) {
     printf("Error, MutFile could not be opened");
     return 0;
   }
@@ -89,8 +57,8 @@ int main(int argc, char** argv) {
   std::ofstream out1((stub + ".Mutations.fastq").c_str(), std::ios::binary);
 #else
   const int single = 0;
-  LineReader in2;
-  if (!in2.open(m2)) {
+  const int fd2 = ::open(m2, O_RDONLY);
+  if (fd2 < 0) {
     printf("Error, MutFile could not be opened");
     return 0;
   }
@@ -117,69 +85,251 @@ int main(int argc, char** argv) {
   rfx_set* set = rfx_set_build(ctx, keys.data(), (uint64_t)nk, k);
   if (!set) die(std::string("rufus_amd: ") + rfx_last_error());
 
-  const size_t BATCH = 1u << 19;
-  RecBatch r1, r2;
-  ReadBatch b1, b2;
-  PackedBatch p;
-  std::vector<uint64_t> mask1, mask2;
-  std::vector<uint32_t> hits;
-  unsigned long long found = 0, total = 0;
-  bool more = true;
-  while (more) {
-    r1.clear();
-    r2.clear();
-    b1.clear();
-    b2.clear();
-    while (r1.n() < BATCH) {
-      if (!r1.read(in1)) {
-        more = false;
-        break;
-      }
-      const size_t i = r1.n() - 1;
-      if (r1.len(i, 1) == 0) die("rufus_amd RUFUS.Filter: empty sequence line (undefined behaviour in the reference) -- rejected");
-      b1.add(r1.line(i, 1), r1.len(i, 1), r1.line(i, 3), r1.len(i, 3), true);
+  // Pipeline (the device scans ~1000x faster than one core parses, so the host side is what counts):
+  //   one reader per mate stream cuts it into pieces of PIECE_RECS records (4 lines each, counted blindly like the
+  //   reference's getline x 4); the two pipes are always being drained, so a writer in lock step
+  //   (PassThroughSamCheck.stranded, runRufus.sh:966) never blocks on the one while we wait on the other;
+  //   workers take piece i of both streams, find the lines, pack bases + quality mask of both mates
+  //   (rfx_pack_spans), run the scan (k_filter; device calls are serialised, they take microseconds) and format
+  //   the pulled records;
+  //   the main thread writes the formatted pieces in input order.
+  const size_t PIECE_RECS = 1u << 16;
+  struct Piece { std::vector<char> text; size_t recs = 0; };
+  struct Stream {
+    int fd = -1;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Piece*> q;
+    bool done = false;
+  };
+  const int n_streams = single ? 1 : 2;
+  Stream st[2];
+  st[0].fd = fd1;
 #ifndef RFX_SINGLE_END
-      if (!r2.read(in2)) {  // lock step: exactly one record of mate 2 per record of mate 1
-        r2.off.insert(r2.off.end(), 4, r2.text.size());
-      }
-      b2.add(r2.line(i, 1), r2.len(i, 1), r2.line(i, 3), r2.len(i, 3), true);
+  st[1].fd = fd2;
 #endif
+  const size_t MAX_AHEAD = 48;  // pieces a reader may be ahead of the workers (~1 GB of text per stream)
+  auto reader = [&](Stream& S) {
+    std::vector<char> carry;
+    std::vector<char> buf(8u << 20);
+    Piece* cur = new Piece();
+    size_t lines = 0;
+    bool eof = false;
+    while (!eof) {
+      ssize_t n = ::read(S.fd, buf.data(), buf.size());
+      if (n < 0 && errno == EINTR) continue;
+      if (n < 0) die(std::string("read error on input: ") + strerror(errno));
+      if (n == 0) eof = true;
+      const char *p = buf.data(), *e = buf.data() + (n > 0 ? n : 0);
+      while (p < e) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+        const char* upto = nl ? nl + 1 : e;
+        cur->text.insert(cur->text.end(), p, upto);
+        p = upto;
+        if (nl && ++lines == 4 * PIECE_RECS) {
+          cur->recs = PIECE_RECS;
+          {
+            std::unique_lock<std::mutex> g(S.mu);
+            S.cv.wait(g, [&] { return S.q.size() < MAX_AHEAD; });
+            S.q.push_back(cur);
+            S.cv.notify_all();
+          }
+          cur = new Piece();
+          cur->text.reserve(PIECE_RECS * 340);
+          lines = 0;
+        }
+      }
     }
-    const uint32_t n = (uint32_t)r1.n();
-    if (n == 0) break;
-    total += n;
-    auto scan = [&](ReadBatch& b, std::vector<uint64_t>& mask, std::vector<uint32_t>* h) {
-      if (p.pack(b, RFX_PACK_FILTER, min_q) != RFX_OK) die("rufus_amd: pack failed");
-      rfx_reads* rd = p.upload(ctx, n, RFX_PACK_FILTER);
-      if (!rd) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
-      mask.assign(((size_t)n + 63) / 64, 0);
-      if (h) h->assign(n, 0);
-      uint64_t nh = 0;
-      // paired tool: `i < length()-1`, the last base is never examined (src/RUFUS.Filter.cpp:203)
-      const int rc = rfx_filter(set, rd, thresh, single ? 0 : 1, h ? h->data() : nullptr, mask.data(), &nh);
-      rfx_reads_free(rd);
-      if (rc) die(std::string("rufus_amd: filter failed: ") + rfx_last_error());
-    };
-#ifdef RFX_SINGLE_END
-    scan(b1, mask1, &hits);
-    for (uint32_t i = 0; i < n; ++i)
-      if ((mask1[i >> 6] >> (i & 63)) & 1) {
-        const std::string suffix = ":MH" + std::to_string(hits[i]);
-        r1.write(out1, i, suffix.c_str());
-        ++found;
+    if (!cur->text.empty()) {
+      if (cur->text.back() != '\n') {  // std::getline semantics: a final unterminated line still counts
+        cur->text.push_back('\n');
+        ++lines;
       }
-#else
-    scan(b1, mask1, nullptr);
-    scan(b2, mask2, nullptr);  // equivalent to the reference's "mate 2 only if mate 1 failed" (:237-277)
-    for (uint32_t i = 0; i < n; ++i)
-      if (((mask1[i >> 6] | mask2[i >> 6]) >> (i & 63)) & 1) {
-        r1.write(out1, i);
-        r2.write(out2, i);
-        ++found;
+      cur->recs = (lines + 3) / 4;  // an incomplete last record: its missing lines read as empty
+      while (lines < 4 * cur->recs) {
+        cur->text.push_back('\n');
+        ++lines;
       }
+    }
+    std::lock_guard<std::mutex> g(S.mu);
+    if (cur->recs) S.q.push_back(cur);
+    else delete cur;
+    S.done = true;
+    S.cv.notify_all();
+  };
+  std::thread readers[2];
+  for (int i = 0; i < n_streams; ++i) readers[i] = std::thread(reader, std::ref(st[i]));
+
+  struct Result { std::string out1, out2; unsigned long long recs = 0, found = 0; bool ready = false; };
+  std::mutex res_mu, dev_mu, take_mu;
+  std::condition_variable res_cv;
+  std::map<uint64_t, Result> results;
+  uint64_t next_seq = 0;
+  bool input_done = false;
+  auto take = [&](Piece*& a, Piece*& b, uint64_t& seq) -> bool {  // piece `seq` of both streams, in order
+    std::lock_guard<std::mutex> tg(take_mu);
+    a = b = nullptr;
+    {
+      std::unique_lock<std::mutex> g(st[0].mu);
+      st[0].cv.wait(g, [&] { return !st[0].q.empty() || st[0].done; });
+      if (st[0].q.empty()) {
+        std::lock_guard<std::mutex> rg(res_mu);
+        input_done = true;
+        res_cv.notify_all();
+        return false;
+      }
+      a = st[0].q.front();
+      st[0].q.pop_front();
+      st[0].cv.notify_all();
+    }
+    if (n_streams == 2) {
+      std::unique_lock<std::mutex> g(st[1].mu);
+      st[1].cv.wait(g, [&] { return !st[1].q.empty() || st[1].done; });
+      if (!st[1].q.empty()) {
+        b = st[1].q.front();
+        st[1].q.pop_front();
+        st[1].cv.notify_all();
+      } else {
+        b = new Piece();  // mate 2 ran out: its records read as empty (lock step: one per record of mate 1)
+      }
+    }
+    seq = next_seq++;
+    return true;
+  };
+  auto worker = [&]() {
+    std::vector<uint64_t> ls[2], ss[2], qs[2], codes, mask;  // line starts, sequence / quality starts
+    std::vector<uint32_t> sl[2], good, woff, lens, hits;
+    for (;;) {
+      Piece *pc[2];
+      uint64_t seq;
+      if (!take(pc[0], pc[1], seq)) return;
+      const size_t n = pc[0]->recs;
+      for (int m = 0; m < n_streams; ++m) {
+        const std::vector<char>& t = pc[m]->text;
+        ls[m].assign(4 * n + 1, t.size());
+        size_t li = 0;
+        const char *p = t.data(), *e = t.data() + t.size();
+        while (p < e && li < 4 * n) {
+          ls[m][li++] = (uint64_t)(p - t.data());
+          const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+          p = nl ? nl + 1 : e;
+        }
+        ss[m].resize(n);
+        qs[m].resize(n);
+        sl[m].resize(n);
+        for (size_t i = 0; i < n; ++i) {
+          auto len_of = [&](size_t line) {
+            const uint64_t a0 = ls[m][line], a1 = ls[m][line + 1];
+            return a1 > a0 ? (uint32_t)(a1 - a0 - 1) : 0u;  // without the '\n'
+          };
+          ss[m][i] = ls[m][4 * i + 1];
+          sl[m][i] = len_of(4 * i + 1);
+          qs[m][i] = ls[m][4 * i + 3];
+          if (m == 0 && sl[m][i] == 0)
+            die("rufus_amd RUFUS.Filter: empty sequence line (undefined behaviour in the reference) -- rejected");
+        }
+      }
+      // pack: reads of mate 1, then of mate 2, into one block
+      const size_t nr = n * (size_t)n_streams;
+      uint64_t words = 0;
+      for (int m = 0; m < n_streams; ++m)
+        for (size_t i = 0; i < n; ++i) words += (sl[m][i] + 31) / 32;
+      codes.assign(words + 1, 0);
+      good.assign(words + 1, 0);
+      woff.assign(nr + 1, 0);
+      lens.assign(nr + 1, 0);
+      uint32_t w0 = 0;
+      for (int m = 0; m < n_streams; ++m) {
+        // a quality line shorter than its read would make the packer read the next line's bytes: such reads get
+        // a private copy of their quality string, padded with '\0' (= bad, what the reference's missing chars are)
+        std::vector<char>& t = pc[m]->text;
+        for (size_t i = 0; i < n; ++i) {
+          const uint64_t q0 = ls[m][4 * i + 3], q1 = ls[m][4 * i + 4];
+          const uint32_t ql = q1 > q0 ? (uint32_t)(q1 - q0 - 1) : 0u;
+          if (ql < sl[m][i]) {
+            const size_t at = t.size();
+            t.insert(t.end(), t.begin() + (ptrdiff_t)q0, t.begin() + (ptrdiff_t)(q0 + ql));
+            t.insert(t.end(), sl[m][i] - ql, '\0');
+            qs[m][i] = at;
+          }
+        }
+        woff[m * n] = w0;
+        if (n && rfx_pack_spans(t.data(), ss[m].data(), sl[m].data(), qs[m].data(), (uint32_t)n, min_q, RFX_PACK_FILTER,
+                                codes.data(), nullptr, good.data(), woff.data() + m * n, lens.data() + m * n) != RFX_OK)
+          die("rufus_amd: pack failed");
+        w0 = woff[(m + 1) * n];
+      }
+      mask.assign((nr + 63) / 64, 0);
+      if (single) hits.assign(nr, 0);
+      {
+        std::lock_guard<std::mutex> g(dev_mu);
+        rfx_reads* rd = rfx_reads_upload(ctx, codes.data(), nullptr, good.data(), woff.data(), lens.data(), (uint32_t)nr);
+        if (!rd) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
+        uint64_t nh = 0;
+        // paired tool: `i < length()-1`, the last base is never examined (src/RUFUS.Filter.cpp:203)
+        const int rc = rfx_filter(set, rd, thresh, single ? 0 : 1, single ? hits.data() : nullptr, mask.data(), &nh);
+        rfx_reads_free(rd);
+        if (rc) die(std::string("rufus_amd: filter failed: ") + rfx_last_error());
+      }
+      Result res;
+      res.recs = n;
+      auto bit = [&](size_t r) { return (mask[r >> 6] >> (r & 63)) & 1; };
+      auto put = [&](std::string& o, int m, size_t i, const char* suffix) {
+        const std::vector<char>& t = pc[m]->text;
+        for (int j = 0; j < 4; ++j) {
+          const uint64_t a0 = ls[m][4 * i + j], a1 = ls[m][4 * i + j + 1];
+          const size_t len = a1 > a0 ? (size_t)(a1 - a0 - 1) : 0;
+          o.append(t.data() + a0, len);
+          if (j == 0 && suffix) o.append(suffix);
+          o.push_back('\n');
+        }
+      };
+      for (size_t i = 0; i < n; ++i) {
+        if (single) {
+          if (bit(i)) {
+            const std::string suffix = ":MH" + std::to_string(hits[i]);
+            put(res.out1, 0, i, suffix.c_str());
+            ++res.found;
+          }
+        } else if (bit(i) | bit(n + i)) {  // == the reference's "mate 2 only if mate 1 failed" (:237-277)
+          put(res.out1, 0, i, nullptr);
+          put(res.out2, 1, i, nullptr);
+          ++res.found;
+        }
+      }
+      for (int m = 0; m < n_streams; ++m) delete pc[m];
+      res.ready = true;
+      std::lock_guard<std::mutex> g(res_mu);
+      results[seq] = std::move(res);
+      res_cv.notify_all();
+    }
+  };
+  unsigned nthreads = (unsigned)std::max(1, atoi(argv[a]));
+  const unsigned hw = std::thread::hardware_concurrency();
+  if (hw && nthreads > hw) nthreads = hw;
+  if (const char* ev = getenv("RFX_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(ev));
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t < nthreads; ++t) workers.emplace_back(worker);
+  unsigned long long found = 0, total = 0;
+  for (uint64_t want = 0;; ++want) {
+    Result res;
+    {
+      std::unique_lock<std::mutex> g(res_mu);
+      res_cv.wait(g, [&] { return results.count(want) || (input_done && want >= next_seq); });
+      if (!results.count(want)) break;
+      res = std::move(results[want]);
+      results.erase(want);
+    }
+    out1.write(res.out1.data(), (std::streamsize)res.out1.size());
+#ifndef RFX_SINGLE_END
+    out2.write(res.out2.data(), (std::streamsize)res.out2.size());
 #endif
+    total += res.recs;
+    found += res.found;
     printf("Read in %llu lines: Found %llu \r", total * 4, found);
   }
+  for (auto& w : workers) w.join();
+  for (int i = 0; i < n_streams; ++i) readers[i].join();
   rfx_set_free(set);
   rfx_close(ctx);
   printf("\nDone running RUFUS.Filter.cpp\n");

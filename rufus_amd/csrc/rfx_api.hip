@@ -2411,6 +2411,14 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
   // the fast filter's own pre-filters (small sets only: two 2^16-bit bitmaps that live in LDS)
   const size_t bm2_words = (k >= 16 && n <= 4096) ? 4096 : 0;
   if (bm2_words) s->bitmap2 = (uint32_t*)dmalloc(c, bm2_words * 4);
+  const size_t bm3_words = (k >= 20 && n > 4096 && n <= (1u << 17)) ? (size_t)rfxk::filter_big_words() : 0;
+  if (bm3_words) {
+    s->bitmap3 = (uint32_t*)dmalloc(c, bm3_words * 4);
+    if (!s->bitmap3 || hipMemsetAsync(s->bitmap3, 0, bm3_words * 4, c->stream) != hipSuccess) {
+      rfx_set_free(s);
+      return nullptr;
+    }
+  }
   uint64_t* dk = (uint64_t*)dmalloc(c, n * 8);
   bool ok = s->slots && dk && s->bitmap && (!bm2_words || s->bitmap2);
   if (ok && bm2_words) ok = hipMemsetAsync(s->bitmap2, 0, bm2_words * 4, c->stream) == hipSuccess;
@@ -2421,6 +2429,7 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
     rfxk::set_insert(c, dk, n, s->slots, s->bits);
     rfxk::set_bitmap(c, dk, n, s->bitmap, s->bm_bits, s->bm_shift);
     if (s->bitmap2) rfxk::set_bitmap_packed(c, dk, n, s->bitmap2);
+    if (s->bitmap3) rfxk::set_bitmap_big(c, dk, n, s->bitmap3);
     // no synchronisation: upload() staged the keys, everything else is ordered on the ctx stream, and a
     // device error surfaces at the first rfx_filter / rfx_annotate (which wait for their results)
   }
@@ -2437,6 +2446,7 @@ void rfx_set_free(rfx_set* s) {
   dfree(s->ctx, s->slots);
   dfree(s->ctx, s->bitmap);
   dfree(s->ctx, s->bitmap2);
+  dfree(s->ctx, s->bitmap3);
   delete s;
 }
 
@@ -2459,6 +2469,9 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
     if (s->bitmap2 && !getenv("RFX_FILTER_GENERIC"))
       rfxk::filter_fast(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap2, s->k, thresh, last_base_skipped,
                         d_hits, d_mask, d_n);
+    else if (s->bitmap3 && !getenv("RFX_FILTER_GENERIC"))
+      rfxk::filter_big(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap3, s->k, thresh, last_base_skipped, d_hits,
+                       d_mask, d_n);
     else
       rfxk::filter(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap, s->bm_bits, s->bm_shift, s->k, thresh,
                    last_base_skipped, d_hits, d_mask, d_n);

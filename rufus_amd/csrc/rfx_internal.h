@@ -198,6 +198,7 @@ struct rfx_set {
   uint32_t* bitmap;  // 2^bm_bits bits indexed by (fwd >> bm_shift): pre-filter of the probe
   int bm_bits, bm_shift;
   uint32_t* bitmap2;  // k >= 16, <= 4096 keys: the two packed-order bitmaps of k_filter_fast (else null)
+  uint32_t* bitmap3;  // k >= 20, 4096 < keys <= 2^17: the 2^20-bit packed-order bitmap of k_filter_big (else null)
 };
 
 // ---- kernel launchers (rfx_kernels.hip) -------------------------------------------------------
@@ -240,6 +241,11 @@ void set_bitmap(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm, int bm
 void set_bitmap_packed(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm /* 4096 words */);
 void filter_fast(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
                  int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit);
+// k >= 20, 4096 < keys <= 2^17: one 2^20-bit bitmap over a window's last 10 bases, LDS resident
+int filter_big_words();
+void set_bitmap_big(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm /* filter_big_words() */);
+void filter_big(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
+                int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit);
 void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
             int bm_bits, int bm_shift, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
             unsigned long long* d_nhit);

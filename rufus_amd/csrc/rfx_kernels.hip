@@ -852,6 +852,97 @@ inline int grid_for(rfx_ctx* c, uint64_t work_items, int block, int per_cu) {
   return (int)(blocks < cap ? blocks : cap);
 }
 
+
+// k_filter_fast's idea for sets beyond 4096 keys (a 30x WGS trio with 1000 de-novo SNVs has 5e4): the two 2^16-bit
+// bitmaps would be nearly full, so ONE bitmap over the last 10 bases of a window -- 2^20 bits = 128 KB of LDS, one
+// 1024-thread workgroup per CU -- takes their place: 5 % of the positions pass at 5e4 keys and are probed exactly.
+constexpr int FB_NB = 10;
+constexpr int FB_WORDS = 1 << (2 * FB_NB - 5);
+constexpr int FB_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void k_set_bitmap_big(const uint64_t* __restrict__ keys, uint64_t n,
+                                                         uint32_t* __restrict__ bm) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i];  // first base most significant: the last base is bits [1:0]
+    uint32_t ia = 0;
+#pragma unroll
+    for (int b = 0; b < FB_NB; ++b) ia |= (uint32_t)((key >> (2 * b)) & 3u) << (2 * (FB_NB - 1 - b));  // packed order
+    atomicOr(&bm[ia >> 5], 1u << (ia & 31));
+  }
+}
+
+__global__ __launch_bounds__(FB_BLOCK) void k_filter_big(rfx_reads_view rv, const uint64_t* __restrict__ g_slots, int bits,
+                                                          int has_all_ones, const uint32_t* __restrict__ g_bm, int k,
+                                                          int thresh, int last_base_skipped,
+                                                          uint32_t* __restrict__ hits_out, uint64_t* __restrict__ hitmask,
+                                                          unsigned long long* __restrict__ d_nhit) {
+  extern __shared__ uint32_t s_bmb[];  // FB_WORDS
+  for (uint32_t i = threadIdx.x; i < (uint32_t)FB_WORDS; i += blockDim.x) s_bmb[i] = g_bm[i];
+  __syncthreads();
+  const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+  const uint32_t n_chunks = (rv.n + FB_BLOCK - 1) / FB_BLOCK;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t r = chunk * FB_BLOCK + threadIdx.x;
+    uint32_t found = 0;
+    if (r < rv.n) {
+      const uint32_t wr = rv.word_off[r];
+      const uint32_t len = rv.len[r];
+      const uint64_t* __restrict__ cw = rv.codes + wr;
+      const uint32_t* __restrict__ cm = rv.good + wr;
+      const uint32_t stop = last_base_skipped ? (len ? len - 1 : 0) : len;  // src/RUFUS.Filter.cpp:203
+      const uint32_t nw = (stop + 31) >> 5;
+      uint64_t prev_c = 0;
+      uint32_t prev_g = 0;
+      for (uint32_t wi = 0; wi < nw; ++wi) {
+        const uint64_t cur_c = cw[wi];
+        uint32_t cur_g = cm[wi];
+        const uint32_t nb = stop - (wi << 5);
+        if (nb < 32) cur_g &= (1u << nb) - 1;
+        const uint64_t X = ((uint64_t)cur_g << 32) | prev_g;
+        uint64_t acc = ~0ull, run = X;
+        int off = 0;
+        for (int bit = 0; (k >> bit) != 0; ++bit) {  // V: the k good bits ending here are all set (see k_filter_fast)
+          if ((k >> bit) & 1) {
+            acc &= run << off;
+            off += 1 << bit;
+          }
+          run &= run << (1 << bit);
+        }
+        const uint32_t V = (uint32_t)(acc >> 32);
+        if (V) {
+          uint32_t cand = 0;
+#pragma unroll
+          for (int j = 0; j < 32; ++j) {
+            const int sa = 2 * (j - FB_NB + 1);
+            const uint32_t ia = (uint32_t)(sa >= 0 ? cur_c >> sa : (cur_c << (-sa)) | (prev_c >> (64 + sa))) & ((1u << (2 * FB_NB)) - 1);
+            cand |= ((s_bmb[ia >> 5] >> (ia & 31)) & 1u) << j;
+          }
+          cand &= V;
+          while (cand) {
+            const int j = __ffs(cand) - 1;
+            cand &= cand - 1;
+            const int sh = 2 * (j - k + 1) + 64;  // 2 .. 126
+            const uint64_t packed = sh >= 64 ? cur_c >> (sh - 64) : (prev_c >> sh) | (cur_c << (64 - sh));
+            uint64_t y = __brevll(packed);
+            y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+            const uint64_t fwd = (k == 32 ? y : y >> (64 - 2 * k)) & kmask;
+            found += fwd == RFX_EMPTY ? (has_all_ones != 0) : set_has(g_slots, bits, fwd);
+          }
+        }
+        prev_c = cur_c;
+        prev_g = cur_g;
+      }
+      if (hits_out) hits_out[r] = found;
+    }
+    const bool pass = r < rv.n && (int)found >= thresh;
+    const unsigned long long mm = __ballot(pass);
+    if ((threadIdx.x & (WAVE - 1)) == 0 && r < rv.n) {
+      if (hitmask) hitmask[r >> 6] = mm;
+      if (mm) atomicAdd(d_nhit, (unsigned long long)__popcll(mm));
+    }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1014,6 +1105,27 @@ void filter_fast(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, in
   rfx_span sp(c, "k_filter");
   const int grid = grid_for(c, (rv.n + K5_BLOCK - 1) / K5_BLOCK, 1, 8);
   hipLaunchKernelGGL(k_filter_fast, dim3(grid), dim3(K5_BLOCK), 0, c->stream, rv, slots, bits, has_all_ones, bm, k,
+                     thresh, last_base_skipped, hits, hitmask, d_nhit);
+}
+
+int filter_big_words() { return FB_WORDS; }
+
+void set_bitmap_big(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* bm) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_set_bitmap");
+  hipLaunchKernelGGL(k_set_bitmap_big, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, bm);
+}
+
+void filter_big(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones,
+                const uint32_t* bm, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
+                unsigned long long* d_nhit) {
+  if (rv.n == 0) return;
+  // 128 KB of dynamic LDS: opt in (per device: the attribute is cheap to set, so simply on every launch)
+  (void)hipFuncSetAttribute((const void*)k_filter_big, hipFuncAttributeMaxDynamicSharedMemorySize, FB_WORDS * 4);
+  rfx_span sp(c, "k_filter");
+  const uint32_t chunks = (rv.n + FB_BLOCK - 1) / FB_BLOCK;
+  const int grid = (int)std::min<uint32_t>(chunks, (uint32_t)c->n_cu);  // one resident workgroup per CU
+  hipLaunchKernelGGL(k_filter_big, dim3(grid), dim3(FB_BLOCK), FB_WORDS * 4, c->stream, rv, slots, bits, has_all_ones, bm, k,
                      thresh, last_base_skipped, hits, hitmask, d_nhit);
 }
 

@@ -48,9 +48,11 @@ def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, 
     distinct = windows / max(coverage_hint * (read_len - k + 1) / read_len, 1.0)
     for s in range(1, 257 // world):
         share = s * world
-        records = 2.8 * windows / share * (3.0 if world > 1 else 1.0)
-        transient = records * 1.125 + 44.0 * distinct / share * 1.5 + (n_samples - 1) * 20.0 * distinct / share
-        if resident_bytes + transient < 0.90 * hbm_bytes:
+        records = 2.7 * windows / share * (3.0 if world > 1 else 1.0)
+        # leaf phase of the last sample of a pass: records + scratch, survivor store, the other samples' records
+        transient = records * 1.125 + 12.0 * distinct / share * 1.3 + (n_samples - 1) * 20.0 * distinct / share
+        # (measured on the 30x WGS trio, 1 GPU: 219 GB at 5 passes, ~243 GB at 4 of 288 GiB)
+        if resident_bytes + transient < 0.85 * hbm_bytes:
             return s
     return max(1, 256 // world)
 

@@ -47,8 +47,12 @@ int main(int argc, char** argv) {
     const int fd = ::open(argv[5], O_RDONLY);
     struct stat st;
     if (fd < 0 || fstat(fd, &st)) return 1;
-    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    ok = ing.feed_mapped((const char*)m, (size_t)st.st_size);
+    if (getenv("INGEST_MMAP")) {
+      void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      ok = ing.feed_mapped((const char*)m, (size_t)st.st_size);
+    } else {
+      ok = ing.feed_file(fd, (uint64_t)st.st_size);
+    }
   }
   printf("%s %llu %llu %llu %llu\n", ok ? "ok" : "not4line", (unsigned long long)reads, (unsigned long long)bases,
          (unsigned long long)sum, (unsigned long long)blocks);

@@ -53,10 +53,11 @@ def test_ingest_pipeline_delivers_every_read_once(harness, tmp_path, threads, ca
     path.write_bytes(fq)
     want = f"ok {len(seqs)} {sum(map(len, seqs))} {_expected(seqs)}"
     for rep in range(3):
-        out = subprocess.run([harness, str(threads), str(cap_reads), str(cap_reads * 6), str(piece), str(path)],
-                             stdout=subprocess.PIPE, timeout=120, check=True).stdout.decode()
-        assert out.rsplit(" ", 1)[0] == want, out
-        assert int(out.split()[-1]) >= len(seqs) // cap_reads
+        for env in ({}, {"INGEST_MMAP": "1"}):      # ranges read by the workers / the mapped file
+            out = subprocess.run([harness, str(threads), str(cap_reads), str(cap_reads * 6), str(piece), str(path)],
+                                 stdout=subprocess.PIPE, timeout=120, check=True, env={**os.environ, **env}).stdout.decode()
+            assert out.rsplit(" ", 1)[0] == want, out
+            assert int(out.split()[-1]) >= len(seqs) // cap_reads
         out = subprocess.run([harness, str(threads), str(cap_reads), str(cap_reads * 6), str(piece), "-"], input=fq,
                              stdout=subprocess.PIPE, timeout=120, check=True).stdout.decode()
         assert out.rsplit(" ", 1)[0] == want, out

@@ -1079,21 +1079,27 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   // address coarse bin 0 would have
   buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
   inst = (uint64_t*)dmalloc(c, cap_b * 8);
-  if (!buf_a || !inst) return fail(RFX_E_NOMEM);
+  const bool wide = rfxk::msp_wide(t->k);
+  uint32_t* ext_a = wide ? (uint32_t*)dmalloc(c, cap_a * g.c_n * 4) : nullptr;
+  uint32_t* ext = wide ? (uint32_t*)dmalloc(c, cap_b * 4) : nullptr;
+  if (!buf_a || !inst || (wide && (!ext_a || !ext))) { dfree(c, ext_a); dfree(c, ext); return fail(RFX_E_NOMEM); }
   uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;
+  uint32_t* ext_a0 = wide ? ext_a - (size_t)g.c_lo * cap_a : nullptr;
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1) * 4, c->stream));
   HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr, cur + g.ncur);
-  rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b,
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr, cur + g.ncur, ext_a0);
+  rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, ext_a0, ext, cap_b,
               "k_part2", nullptr, 0, cap_b, g.rec_mode, t->k);
   unsigned int flag = 1;
-  if (queue_read(c, &flag, cur + g.ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) return fail(RFX_E_HIP);
+  if (queue_read(c, &flag, cur + g.ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) { dfree(c, ext_a); dfree(c, ext); return fail(RFX_E_HIP); }
   if (flag) {
     snprintf(g_err, sizeof g_err, "MSP: exact partition overflowed (internal error)");
+    dfree(c, ext_a); dfree(c, ext);
     return fail(RFX_E_HIP);
   }
   drop();
-  *seg = rfx_segment{inst, total, bin_start, g.windows, P};
+  dfree(c, ext_a);
+  *seg = rfx_segment{inst, total, bin_start, g.windows, P, ext};
   return RFX_OK;
 }
 
@@ -1118,6 +1124,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   // ~3 k-mers per record on ordinary sequence: room for 2.5 (of the shard's share of the bins), coarse
   // bins 25 % above even -- 6 % for big blocks, whose bins are even
   const bool big = g.windows >= (1ull << 29) || P > 8192;  // >= ~4 M reads: worth one synchronisation for exact sizes
+  const bool wide = rfxk::msp_wide(t->k);                  // k = 26 .. 31: the records' 32-bit plane travels along
   const double share = (double)(g.bin_hi - g.bin_lo) / (double)P;
   uint64_t cap_b = (uint64_t)((double)g.windows * 0.4 * share * (share < 1 ? 1.05 : 1.0)) + 65536;
   if (cap_b > g.windows) cap_b = g.windows;
@@ -1135,14 +1142,16 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
     // it needs (at WGS scale the 30 % slack of an estimate is tens of GB) -- and nothing stays pending.
     for (int attempt = 0;; ++attempt) {
       uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
-      if (!buf_a) { dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
+      uint32_t* ext_a = wide ? (uint32_t*)dmalloc(c, cap_a * g.c_n * 4) : nullptr;
+      if (!buf_a || (wide && !ext_a)) { dfree(c, buf_a); dfree(c, ext_a); dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
       uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;  // the address coarse bin 0 would have
-      auto fail = [&](int rc) { dfree(c, buf_a); dfree(c, cur); dfree(c, bin_start); return rc; };
+      uint32_t* ext_a0 = wide ? ext_a - (size_t)g.c_lo * cap_a : nullptr;
+      auto fail = [&](int rc) { dfree(c, buf_a); dfree(c, ext_a); dfree(c, cur); dfree(c, bin_start); return rc; };
       hipError_t e = hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream);
       if (e == hipSuccess) e = hipMemsetAsync(bin_start, 0, ((size_t)P + 1) * 8, c->stream);
       if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
       rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr,
-                      cur + g.ncur);
+                      cur + g.ncur, ext_a0);
       rfxk::surv_hist(c, buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
       rfxk::scan_tail(c, bin_start, P);
       uint64_t total = 0;
@@ -1155,18 +1164,21 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
         uint64_t need = 0;
         for (uint32_t cb = 0; cb < g.P1; ++cb) need = std::max<uint64_t>(need, h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
         dfree(c, buf_a);
+        dfree(c, ext_a);
         if (attempt >= 3 || need >= (1ull << 32) - 65536) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
         cap_a = need + need / 64 + 1024;
         continue;
       }
       uint64_t* inst = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
-      if (!inst) return fail(RFX_E_NOMEM);
-      rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, nullptr, total,
+      uint32_t* ext = wide ? (uint32_t*)dmalloc(c, (total ? total : 1) * 4) : nullptr;
+      if (!inst || (wide && !ext)) { dfree(c, inst); dfree(c, ext); return fail(RFX_E_NOMEM); }
+      rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, ext_a0, ext, total,
                   "k_part2", nullptr, 0, total, g.rec_mode, t->k);
       dfree(c, buf_a);
+      dfree(c, ext_a);
       dfree(c, cur);
       // (k-mer instances behind the records: the shard's share of the windows -- sizes the survivor arrays)
-      t->segs->push_back(rfx_segment{inst, total, bin_start, std::min<uint64_t>(g.windows, total * MSP_KMERS_PER_RECORD_MAX), P});
+      t->segs->push_back(rfx_segment{inst, total, bin_start, std::min<uint64_t>(g.windows, total * MSP_KMERS_PER_RECORD_MAX), P, ext});
       t->seg_kind = RFX_COUNT_MSP;
       return RFX_OK;
     }
@@ -1174,20 +1186,23 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
   uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
   uint64_t* inst = (uint64_t*)dmalloc(c, cap_b * 8);
-  auto drop = [&] { dfree(c, cnt); dfree(c, buf_a); };
-  if (!cnt || !buf_a || !inst) {
-    drop(); dfree(c, cur); dfree(c, bin_start); dfree(c, inst);
+  uint32_t* ext_a = wide ? (uint32_t*)dmalloc(c, cap_a * g.c_n * 4) : nullptr;
+  uint32_t* ext = wide ? (uint32_t*)dmalloc(c, cap_b * 4) : nullptr;
+  auto drop = [&] { dfree(c, cnt); dfree(c, buf_a); dfree(c, ext_a); };
+  if (!cnt || !buf_a || !inst || (wide && (!ext_a || !ext))) {
+    drop(); dfree(c, cur); dfree(c, bin_start); dfree(c, inst); dfree(c, ext);
     return RFX_E_NOMEM;
   }
   uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;  // the address coarse bin 0 would have (see msp_partition_exact)
+  uint32_t* ext_a0 = wide ? ext_a - (size_t)g.c_lo * cap_a : nullptr;
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur);
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur, ext_a0);
   rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
-  rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, nullptr, cap_b,
+  rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, ext_a0, ext, cap_b,
               "k_part2", nullptr, 0, cap_b, g.rec_mode, t->k);
   rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
   drop();
-  t->segs->push_back(rfx_segment{inst, cap_b, bin_start, (uint64_t)((double)g.windows * share) + 1, P});
+  t->segs->push_back(rfx_segment{inst, cap_b, bin_start, (uint64_t)((double)g.windows * share) + 1, P, ext});
   t->seg_kind = RFX_COUNT_MSP;
   if (t->pend->empty()) c->pend_tables.push_back(t);
   t->pend->push_back(rfx_pending_add{r, cur, t->segs->size() - 1, g.ncur});
@@ -1204,7 +1219,9 @@ static int msp_settle(rfx_table* t, const std::vector<unsigned int>& flags) {
     rfx_segment& sg = (*t->segs)[p.seg];
     dfree(c, sg.inst);
     dfree(c, sg.bin_start);
+    dfree(c, sg.ext);
     sg.inst = sg.bin_start = nullptr;
+    sg.ext = nullptr;
     rfx_segment fresh{};
     rc = msp_partition_exact(t, p.r, &fresh);
     if (rc == RFX_OK) sg = fresh;
@@ -1289,8 +1306,10 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
     int from_bits = 0, f1bits = 0, f2bits = 0;
     std::vector<size_t> segs;
     uint64_t *cb1 = nullptr, *cb2 = nullptr, *fine1 = nullptr, *fine2 = nullptr;
+    uint32_t *ce1 = nullptr, *ce2 = nullptr;  // wide records: scratch for the 32-bit plane
     uint64_t max_chunk = 0;
   };
+  const bool wide = rfxk::msp_wide(t->k);
   std::map<uint32_t, group> groups;
   uint64_t kmers = 0;
   for (size_t i = 0; i < t->segs->size(); ++i) {
@@ -1338,6 +1357,7 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
   auto drop = [&] {
     for (auto& kv : groups) {
       dfree(c, kv.second.cb1); dfree(c, kv.second.cb2); dfree(c, kv.second.fine1); dfree(c, kv.second.fine2);
+      dfree(c, kv.second.ce1); dfree(c, kv.second.ce2);
     }
   };
   size_t nleaf = 0;  // segments the leaf sees: one per refined group + the segments already at the target
@@ -1357,20 +1377,25 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
     const size_t n1max = (size_t)max_np * r << g.f1bits, n2max = (size_t)max_np * Ftot;
     g.cb1 = (uint64_t*)dmalloc(c, std::max<uint64_t>(g.max_chunk, 1) * 8);
     g.fine1 = (uint64_t*)dmalloc(c, (n1max + 1) * 8 + n1max * 4);
+    if (wide) g.ce1 = (uint32_t*)dmalloc(c, std::max<uint64_t>(g.max_chunk, 1) * 4);
     if (g.f2bits) {
       g.cb2 = (uint64_t*)dmalloc(c, std::max<uint64_t>(g.max_chunk, 1) * 8);
       g.fine2 = (uint64_t*)dmalloc(c, (n2max + 1) * 8 + n2max * 4);
+      if (wide) g.ce2 = (uint32_t*)dmalloc(c, std::max<uint64_t>(g.max_chunk, 1) * 4);
     }
-    if (!g.cb1 || !g.fine1 || (g.f2bits && (!g.cb2 || !g.fine2))) { drop(); return RFX_E_NOMEM; }
+    if (!g.cb1 || !g.fine1 || (g.f2bits && (!g.cb2 || !g.fine2)) || (wide && (!g.ce1 || (g.f2bits && !g.ce2)))) {
+      drop();
+      return RFX_E_NOMEM;
+    }
   }
-  const uint64_t** d_ptrs = (const uint64_t**)dmalloc(c, 2 * nleaf * sizeof(void*) * (cut.size() - 1));
+  const uint64_t** d_ptrs = (const uint64_t**)dmalloc(c, 3 * nleaf * sizeof(void*) * (cut.size() - 1));
   if (!d_ptrs) { drop(); return RFX_E_NOMEM; }
   int geo = (kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1)) >> to_bits < 8192 ? 1 : 0;
   if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
   for (size_t ci = 0; ci + 1 < cut.size(); ++ci) {
     const uint32_t p0 = cut[ci], np = cut[ci + 1] - cut[ci];
     const size_t n2 = (size_t)np * Ftot;
-    std::vector<const uint64_t*> ptrs(2 * nleaf);
+    std::vector<const uint64_t*> ptrs(3 * nleaf, nullptr);  // records, bin extents, planes (wide records)
     size_t li = 0;
     uint64_t chunk_all = 0;
     for (auto& kv : groups) {
@@ -1380,6 +1405,7 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
         for (size_t si : g.segs) {
           ptrs[li] = (*t->segs)[si].inst;
           ptrs[nleaf + li] = (*t->segs)[si].bin_start + gp0;
+          ptrs[2 * nleaf + li] = (const uint64_t*)(*t->segs)[si].ext;
           ++li;
           chunk_all += h_bs[si][(size_t)gp0 + gnp] - h_bs[si][gp0];
         }
@@ -1399,33 +1425,36 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
                          g.fine1);
         rfxk::scan_tail(c, g.fine1, n1);
         for (size_t si : g.segs)
-          rfxk::part2(c, (*t->segs)[si].inst, g.cb1, g.fine1, fcur1, F1, shift1, nullptr, 0, nullptr, nullptr, ~0ull,
+          rfxk::part2(c, (*t->segs)[si].inst, g.cb1, g.fine1, fcur1, F1, shift1, nullptr, 0, (*t->segs)[si].ext, g.ce1, ~0ull,
                       "k_part3", (*t->segs)[si].bin_start + gp0, gnp, 0, rec_mode, t->k);
       }
       const uint64_t *leaf_src = g.cb1, *leaf_bs = g.fine1;
+      const uint32_t* leaf_ext = g.ce1;
       if (g.f2bits) {
         uint32_t* fcur2 = (uint32_t*)(g.fine2 + n2 + 1);
         HIPCHK(hipMemsetAsync(g.fine2, 0, (n2 + 1) * 8 + n2 * 4, c->stream));
         if (chunk) {
           rfxk::bin_hist(c, g.cb1, g.fine1, (uint32_t)n1, chunk, F2, shift2, rec_mode, t->k, g.fine2);
           rfxk::scan_tail(c, g.fine2, n2);
-          rfxk::part2(c, g.cb1, g.cb2, g.fine2, fcur2, F2, shift2, nullptr, 0, nullptr, nullptr, ~0ull, "k_part4", g.fine1,
+          rfxk::part2(c, g.cb1, g.cb2, g.fine2, fcur2, F2, shift2, nullptr, 0, g.ce1, g.ce2, ~0ull, "k_part4", g.fine1,
                       (uint32_t)n1, 0, rec_mode, t->k);
         }
         leaf_src = g.cb2;
         leaf_bs = g.fine2;
+        leaf_ext = g.ce2;
       }
       ptrs[li] = leaf_src;
       ptrs[nleaf + li] = leaf_bs;
+      ptrs[2 * nleaf + li] = (const uint64_t*)leaf_ext;
       ++li;
     }
     if (!chunk_all) continue;
-    const uint64_t** d = d_ptrs + 2 * nleaf * ci;
-    const hipError_t e = upload(c, d, ptrs.data(), 2 * nleaf * sizeof(void*));
+    const uint64_t** d = d_ptrs + 3 * nleaf * ci;
+    const hipError_t e = upload(c, d, ptrs.data(), 3 * nleaf * sizeof(void*));
     if (e != hipSuccess) { drop(); dfree(c, d_ptrs); return hip_fail(e, "msp_leaf_refined"); }
     rfxk::msp_leaf(c, d, d + nleaf, (int)nleaf, ptrs[0], ptrs[nleaf], (uint32_t)n2, t->k, t->canonical, t->lut_t, t->ntab,
                    sel_bits, 2 * t->k - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur, (uint32_t)f->cap,
-                   cur + ncur, cur + ncur + 1, geo);
+                   cur + ncur, cur + ncur + 1, geo, (const uint32_t* const*)(d + 2 * nleaf), (const uint32_t*)ptrs[2 * nleaf]);
   }
   drop();  // stream-ordered pool
   dfree(c, d_ptrs);
@@ -1449,7 +1478,9 @@ static int msp_prepare_leaf(rfx_table* t, int* to_bits_out, bool* refine_out, st
   int to_bits = ceil_log2(pmax);
   // (a shard pass fills only its share of the bins: density as if every shard were present)
   const uint64_t kfull = kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1);
-  while (to_bits < 28 && (kfull >> to_bits) > 24576) ++to_bits;
+  // (wide records, k = 26 .. 31, are counted with the half-size leaf: half the instances per bin)
+  const uint64_t per_bin = rfxk::msp_wide(t->k) ? 12288 : 24576;
+  while (to_bits < 28 && (kfull >> to_bits) > per_bin) ++to_bits;
   if (getenv("RFX_MSP_REFINE_BITS")) to_bits = std::max(to_bits, atoi(getenv("RFX_MSP_REFINE_BITS")));
   const bool refine = force_refine || pmin < (1u << to_bits);
   h_bs.clear();
@@ -1679,14 +1710,15 @@ static int msp_emit_queue(rfx_finish* f) {
     // done by msp_passes_leaf, shard by shard
   } else if (!refine) {
     const uint32_t P = t->segs->front().bins;
-    f->h_ptrs.assign(2 * (size_t)nseg, nullptr);
+    f->h_ptrs.assign(3 * (size_t)nseg, nullptr);
     for (int i = 0; i < nseg; ++i) {
       f->h_ptrs[i] = (*t->segs)[i].inst;
       f->h_ptrs[nseg + i] = (*t->segs)[i].bin_start;
+      f->h_ptrs[2 * nseg + i] = (const uint64_t*)(*t->segs)[i].ext;  // the plane of wide records (else null)
     }
-    f->d_inst = (const uint64_t**)dmalloc(c, 2 * nseg * sizeof(void*));
+    f->d_inst = (const uint64_t**)dmalloc(c, 3 * nseg * sizeof(void*));
     if (!f->d_inst) return fail(RFX_E_NOMEM);
-    e = upload(c, f->d_inst, f->h_ptrs.data(), 2 * nseg * sizeof(void*));
+    e = upload(c, f->d_inst, f->h_ptrs.data(), 3 * nseg * sizeof(void*));
     if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
     // sparse bins (small inputs): half-size workgroups, two per CU (measured: -19 % leaf time at 7.7 K
     // instances per bin, +3 % at 15 K)
@@ -1694,7 +1726,8 @@ static int msp_emit_queue(rfx_finish* f) {
     if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
     rfxk::msp_leaf(c, f->d_inst, f->d_inst + nseg, nseg, f->h_ptrs[0], f->h_ptrs[nseg], P, t->k, t->canonical, t->lut_t,
                    t->ntab, cfg0.sel_bits, cfg0.c_bits - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur,
-                   (uint32_t)cap, cur + ncur, cur + ncur + 1, geo);
+                   (uint32_t)cap, cur + ncur, cur + ncur + 1, geo, (const uint32_t* const*)(f->d_inst + 2 * nseg),
+                   (const uint32_t*)f->h_ptrs[2 * nseg]);
   } else {
     {
       const int rc = msp_leaf_refined(f, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
@@ -1861,6 +1894,7 @@ static void p2l_drop_segments(rfx_table* t) {
   for (auto& sg : *t->segs) {
     dfree(t->ctx, sg.inst);
     dfree(t->ctx, sg.bin_start);
+    dfree(t->ctx, sg.ext);
   }
   t->segs->clear();
   t->seg_kind = 0;
@@ -1892,7 +1926,7 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
     const bool msp = t->seg_kind ? t->seg_kind == RFX_COUNT_MSP
                                  : (t->mode != RFX_COUNT_P2L && rfxk::msp_k_ok(t->k) && !getenv("RFX_NO_MSP"));
     if (t->mode == RFX_COUNT_MSP && !msp) {
-      snprintf(g_err, sizeof g_err, "RFX_COUNT_MSP needs 23 <= k <= 25");
+      snprintf(g_err, sizeof g_err, "RFX_COUNT_MSP needs 23 <= k <= 31");
       return RFX_E_INVAL;
     }
     const int rc = msp ? msp_add(t, r) : p2l_add(t, r);
@@ -1956,7 +1990,7 @@ int rfx_count_set_shard(rfx_table* t, int shard, int n_shards) {
     return RFX_E_INVAL;
   }
   if (n_shards > 1 && (!rfxk::msp_k_ok(t->k) || !t->lut_t)) {
-    snprintf(g_err, sizeof g_err, "rfx_count_set_shard: minimizer shards need the MSP path (23 <= k <= 25)");
+    snprintf(g_err, sizeof g_err, "rfx_count_set_shard: minimizer shards need the MSP path (23 <= k <= 31)");
     return RFX_E_INVAL;
   }
   t->shard = shard;
@@ -1972,7 +2006,7 @@ int rfx_count_set_passes(rfx_table* t, int passes) {
     return RFX_E_INVAL;
   }
   if (!rfxk::msp_k_ok(t->k) || !t->lut_t) {
-    snprintf(g_err, sizeof g_err, "rfx_count_set_passes: shard passes need the MSP path (23 <= k <= 25)");
+    snprintf(g_err, sizeof g_err, "rfx_count_set_passes: shard passes need the MSP path (23 <= k <= 31)");
     return RFX_E_INVAL;
   }
   t->passes = passes;
@@ -2012,6 +2046,10 @@ int rfx_count_segments(rfx_table* t) {
 int rfx_count_segment_get(rfx_table* t, int i, const uint64_t** d_records, const uint64_t** d_bin_start, uint32_t* bins,
                           uint64_t* n_records) {
   if (!t || t->seg_kind != RFX_COUNT_MSP || i < 0 || i >= (int)t->segs->size()) return RFX_E_INVAL;
+  if (rfxk::msp_wide(t->k)) {
+    snprintf(g_err, sizeof g_err, "rfx_count_segment_get: record export is implemented for k <= 25 (one 64-bit word per record)");
+    return RFX_E_INVAL;
+  }
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
   // One synchronisation for both: the capacity flags of the pending adds and the exact record count of
@@ -2044,8 +2082,9 @@ int rfx_count_add_records_dev(rfx_table* t, const uint64_t* d_records, uint64_t 
   if (!t || !d_bin_start || (n_records && !d_records) || bins < 256 || (bins & (bins - 1))) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
-  if (!rfxk::msp_k_ok(t->k) || !t->lut_t || t->table_active || (t->seg_kind && t->seg_kind != RFX_COUNT_MSP)) {
-    snprintf(g_err, sizeof g_err, "rfx_count_add_records_dev: the table is not on the MSP path");
+  if (!rfxk::msp_k_ok(t->k) || rfxk::msp_wide(t->k) || !t->lut_t || t->table_active ||
+      (t->seg_kind && t->seg_kind != RFX_COUNT_MSP)) {
+    snprintf(g_err, sizeof g_err, "rfx_count_add_records_dev: the table is not on the MSP path (k = 23 .. 25 for record import)");
     return RFX_E_INVAL;
   }
   uint64_t* inst = (uint64_t*)dmalloc(c, (n_records ? n_records : 1) * 8);

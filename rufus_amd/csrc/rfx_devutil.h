@@ -32,7 +32,11 @@ __device__ __forceinline__ uint64_t gf2_mul(const uint64_t* __restrict__ lut, ui
 // was 12x slower per read at 1 Gb than at 5 Mb; m = 15 gives 2 K.  Shorter windows mean shorter runs
 // (3.0 instead of 3.4 k-mers per record), the price for bins that stay bins at any scale.
 constexpr int MSP_WL = 11;
-constexpr int MSP_NMAX = 4;   // k-mers per record: k + 3 <= 28 bases = 56 bits
+// k = 26 .. 31 ("wide" records, see below): window 16, m = k - 15 = 11 .. 16 (an m-mer still fits 32 bits)
+constexpr int MSP_WL_WIDE = 16;
+__host__ __device__ __forceinline__ int msp_wl(int k) { return k <= 25 ? MSP_WL : MSP_WL_WIDE; }
+__host__ __device__ __forceinline__ int msp_m(int k) { return k - (msp_wl(k) - 1); }
+constexpr int MSP_NMAX = 4;   // k-mers per record: k + 3 <= 28 bases = 56 bits (k <= 25; beyond that see msp_record_binhash)
 constexpr uint64_t MSP_EMPTY = 1ull << 55;  // no record looks like this: a 1-k-mer record uses 2k <= 50 bits
 
 // One multiply each: 32-bit integer multiplies are quarter rate, and k_msp_part1 hashes every base.
@@ -61,12 +65,18 @@ __device__ __forceinline__ uint64_t revcomp_bases(uint64_t s, int nbases) {
 
 // The bin hash of a super-k-mer record, re-derived from the record itself: bits [63:59] hold the offset of
 // its minimizer m-mer (common to all its k-mers), so one m-mer hash gives every further partition bit.
-// Record: [63:59] minimizer offset, [57:56] k-mers - 1, [55:0] k + n - 1 bases, first base most significant.
+// Record: [63:59] minimizer offset, [58] side, [57:56] k-mers - 1, [55:0] bases, first base most significant.
+// k <= 25: the k + n - 1 <= 28 bases of the run fit, side = 0, done.  k = 26 .. 31 ("wide"): a run has up to
+// 34 bases; the word holds 28 of them -- the LAST 28 (side 0) or the FIRST 28 (side 1), whichever contains the
+// minimizer m-mer (m <= 16: one of the two always does) -- and the other <= 6 bases travel in a parallel
+// 32-bit plane.  The minimizer offset counts from the first base IN THE WORD, so every partition kernel gets
+// its bits from the 64-bit word alone; only the leaf puts the run back together.
 template <bool CANON>
 __device__ __forceinline__ uint32_t msp_record_binhash(uint64_t x, int k) {
-  const int n = (int)((x >> 56) & 3u) + 1, m = k - (MSP_WL - 1);
-  const int L = k + n - 1, mpos = (int)(x >> 59);
-  const uint32_t f = (uint32_t)((x & ((1ull << 56) - 1)) >> (2 * (L - m - mpos))) & ((1u << (2 * m)) - 1);
+  const int n = (int)((x >> 56) & 3u) + 1, m = msp_m(k);
+  const int L = min(k + n - 1, 28), mpos = (int)(x >> 59);
+  const uint32_t mmask = m >= 16 ? ~0u : (1u << (2 * m)) - 1;
+  const uint32_t f = (uint32_t)((x & ((1ull << 56) - 1)) >> (2 * (L - m - mpos))) & mmask;
   uint32_t c = f;
   if (CANON) {
     uint32_t y = __brev(~f);

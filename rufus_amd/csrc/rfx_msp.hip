@@ -33,9 +33,11 @@ namespace {
 // 768 threads = reads per chunk: two blocks per CU fill the 24 waves that 80 VGPRs allow, and the runs of a
 // phase are 1.5x longer than with 512 (measured 256 / 512 / 768 / 1024 threads: 0.75 / 0.409 / 0.395 / 0.418 ms)
 constexpr int MP1_BLOCK = 768;
-template <bool CANON, int HMODE>
+// WL: m-mers per k-mer; WIDE: k = 26 .. 31, runs of up to 34 bases = 64-bit word + 32-bit plane (rfx_devutil.h).
+template <bool CANON, int HMODE, int WL, bool WIDE>
 __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int k, int bin_bits, uint32_t bin_lo,
                                                          uint32_t bin_hi, uint64_t* __restrict__ buf_a,
+                                                         uint32_t* __restrict__ ext_a,
                                                          uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
                                                          uint32_t* __restrict__ cnt_rows,
                                                          unsigned int* __restrict__ flag) {
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   __shared__ uint32_t s_maxlen;
   const uint32_t P = 1u << bin_bits;
   const int sub_bits = bin_bits - 7;  // P1_BINS = 2^7 coarse bins
-  const int m = k - (MSP_WL - 1);
-  const uint32_t mmask = (1u << (2 * m)) - 1;
+  const int m = k - (WL - 1);
+  const uint32_t mmask = m >= 16 ? ~0u : (1u << (2 * m)) - 1;
   const int rmshift = 2 * (m - 1);
   uint32_t n_emit = 0;  // records this thread stored (or dropped over capacity)
   if (HMODE == 0)
@@ -67,14 +69,15 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     atomicMax(&s_maxlen, lenp);
     __syncthreads();
     const uint32_t n_phase = (s_maxlen + P1_S - 1) / P1_S;
-    uint32_t fm = 0, rm = 0, cur_m = 0, run_h = 0;
+    uint32_t fm = 0, rm = 0, cur_m = 0, run_h = 0, hist_hi = 0;
     uint64_t hist = 0, cur_w = 0;
     int filled = 0, run_n = 0;
-    uint32_t a[MSP_WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-(WL-1) .. p0+7
+    uint32_t a[WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-(WL-1) .. p0+7
 #pragma unroll
-    for (int i = 0; i < MSP_WL - 1 + P1_S; ++i) a[i] = ~0u;
+    for (int i = 0; i < WL - 1 + P1_S; ++i) a[i] = ~0u;
     for (uint32_t ph = 0; ph < n_phase; ++ph) {
       uint64_t wv[P1_S];
+      uint32_t xv[WIDE ? P1_S : 1];
       uint32_t br[P1_S];  // (coarse bin << 16) | rank, or ~0: no record closed at this base
       const uint32_t p0 = ph * P1_S;
       if ((ph & 3) == 0 && p0 < len) {
@@ -82,10 +85,10 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
         cur_m = cm[p0 >> 5];
       }
       // window minimum = min(suffix minimum of the 14 old hashes, prefix minimum of the new ones)
-      uint32_t sfx[MSP_WL - 1];
-      sfx[MSP_WL - 2] = a[MSP_WL - 2];
+      uint32_t sfx[WL - 1];
+      sfx[WL - 2] = a[WL - 2];
 #pragma unroll
-      for (int i = MSP_WL - 3; i >= 0; --i) sfx[i] = min(a[i], sfx[i + 1]);
+      for (int i = WL - 3; i >= 0; --i) sfx[i] = min(a[i], sfx[i + 1]);
       uint32_t pm = ~0u;
 #pragma unroll
       for (int b = 0; b < P1_S; ++b) {
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
           fm = ((fm << 2) | code) & mmask;
           rm = (rm >> 2) | ((3u - code) << rmshift);
           const uint32_t h = (mmer_hash(CANON ? min(fm, rm) : fm) & MSP_HMASK) | ((p0 & 24u) | (uint32_t)b);
-          a[MSP_WL - 1 + b] = h;
+          a[WL - 1 + b] = h;
           pm = min(pm, h);
           filled = valid ? filled + 1 : 0;
           const bool kvalid = filled >= k;
@@ -119,7 +122,27 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
               // counted from the record's first base: 0 .. L - m <= 17.
               const uint32_t back = (p0 + (uint32_t)b - 1u - run_h) & 31u;
               const uint32_t mpos = (uint32_t)(L - m) - back;
-              wv[b] = (hist & ((1ull << (2 * L)) - 1)) | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)mpos << 59);
+              if (!WIDE || L <= 28) {
+                wv[b] = (hist & ((1ull << (2 * L)) - 1)) | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)mpos << 59);
+                if (WIDE) xv[b] = 0;
+              } else {  // 29 .. 34 bases: the word takes the 28 that contain the minimizer, the plane the other x
+                const int x = L - 28;
+                const uint64_t m56 = (1ull << 56) - 1;
+                uint64_t bases;
+                uint32_t side, mp;
+                if (mpos >= (uint32_t)x) {  // the LAST 28 bases hold it: the plane gets the first x (S >> 56)
+                  bases = hist & m56;
+                  xv[b] = (uint32_t)((hist >> 56) | ((uint64_t)hist_hi << 8)) & ((1u << (2 * x)) - 1);
+                  side = 0;
+                  mp = mpos - (uint32_t)x;
+                } else {  // the FIRST 28 (S >> 2x); the plane gets the last x
+                  bases = ((hist >> (2 * x)) | ((uint64_t)hist_hi << (64 - 2 * x))) & m56;
+                  xv[b] = (uint32_t)hist & ((1u << (2 * x)) - 1);
+                  side = 1;
+                  mp = mpos;
+                }
+                wv[b] = bases | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)side << 58) | ((uint64_t)mp << 59);
+              }
               br[b] = (coarse << 16) | atomicAdd(&s_cnt[coarse], 1u);
             }
             if (HMODE == 0 && mine) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
@@ -130,11 +153,12 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
             if (!run_n) run_h = mh;
             ++run_n;
           }
+          if (WIDE) hist_hi = (hist_hi << 2) | (uint32_t)(hist >> 62);
           hist = (hist << 2) | code;
         }
       }
 #pragma unroll
-      for (int i = 0; i < MSP_WL - 1; ++i) a[i] = a[i + P1_S];
+      for (int i = 0; i < WL - 1; ++i) a[i] = a[i + P1_S];
       if (HMODE == 1) continue;
       // Every lane stores its own records straight into the reserved runs (rank inside the run = the
       // value its LDS atomic returned).  The stores of one run come from many lanes, but they fall into
@@ -156,7 +180,10 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
       for (int b = 0; b < P1_S; ++b)
         if (br[b] != ~0u) {
           const uint64_t base = s_gbase[br[b] >> 16];
-          if (base != ~0ull) buf_a[base + (br[b] & 0xFFFFu)] = wv[b];
+          if (base != ~0ull) {
+            buf_a[base + (br[b] & 0xFFFFu)] = wv[b];
+            if (WIDE) ext_a[base + (br[b] & 0xFFFFu)] = xv[b];
+          }
           ++n_emit;
         }
       // no barrier here: s_gbase is rewritten only after the next phase's first barrier
@@ -197,10 +224,14 @@ constexpr int MSP_RC_PROBES = 8;  // a record that finds no cache slot within th
 // table is split in two by a hash bit and each half retried -- results already appended stay valid.
 // GEO 0: one 1024-thread workgroup per CU (8192-slot table, 4096-slot record cache);
 // GEO 1: half of everything, two workgroups per CU -- for bins of ~8 K instances.
-template <bool CANON, int GEO>
+// WIDE (k = 26 .. 31, GEO 1 only): a record is a 64-bit word + the <= 6 bases in the 32-bit plane; the cache
+// matches both (the plane value is published after the word: a reader that comes too early counts its record
+// directly -- the cache is best effort anyway).
+template <bool CANON, int GEO, bool WIDE>
 __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     const uint64_t* const* __restrict__ seg_inst, const uint64_t* const* __restrict__ seg_bs, int nseg,
-    const uint64_t* __restrict__ inst0, const uint64_t* __restrict__ bs0, uint32_t P, int k,
+    const uint64_t* __restrict__ inst0, const uint64_t* __restrict__ bs0, const uint32_t* const* __restrict__ seg_ext,
+    const uint32_t* __restrict__ ext0, uint32_t P, int k,
     const uint64_t* __restrict__ g_lut, int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi,
     uint64_t lower, uint64_t upper, uint64_t* __restrict__ out_w, uint32_t* __restrict__ out_c,
     uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err) {
@@ -213,11 +244,13 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
   __shared__ uint64_t s_lk[LIST];
   __shared__ uint32_t s_lc[LIST];
   __shared__ uint32_t s_nd, s_ovf, s_nl;
+  __shared__ uint32_t s_rx[WIDE ? RC : 1];  // WIDE: plane value of the cached record | 0x80000000 once published
   unsigned long long* s_rk = (unsigned long long*)s_lk;  // the record cache lives in the (then idle) survivor list
   uint32_t* s_rc = s_lc;
   const uint64_t kmask = (1ull << (2 * k)) - 1;
 
   uint64_t pre[MSP_ILP];
+  uint32_t prex[WIDE ? MSP_ILP : 1];
   uint64_t pre_a = 0, pre_e = 0;
   auto prefetch = [&](uint32_t b) {
     if (b >= P) return;
@@ -227,6 +260,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     for (int u = 0; u < MSP_ILP; ++u) {
       const uint64_t i = pre_a + threadIdx.x + (uint64_t)u * BLK;
       pre[u] = i < pre_e ? inst0[i] : MSP_EMPTY;
+      if (WIDE) prex[u] = i < pre_e ? ext0[i] : 0u;
     }
   };
   prefetch(blockIdx.x);
@@ -246,6 +280,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
       for (int i = threadIdx.x; i < RC; i += BLK) {
         s_rk[i] = MSP_EMPTY;
         s_rc[i] = 0;
+        if (WIDE) s_rx[i] = 0;
       }
       if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
       if (threadIdx.x == 0) {
@@ -255,15 +290,37 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
       }
       __syncthreads();
       // k-mer q of record x into the table, counted `mult` times.
-      auto insert_kmer = [&](uint64_t x, int q, uint32_t mult) {
+      auto insert_kmer = [&](uint64_t x, uint32_t xe, int q, uint32_t mult) {
         const int n = (int)((x >> 56) & 3u) + 1;
         if (q >= n) return;
         const uint64_t S = x & ((1ull << 56) - 1);
-        const uint64_t fwd = (S >> (2 * (n - 1 - q))) & kmask;
-        uint64_t key = fwd;
-        if (CANON) {
-          const uint64_t rc = (revcomp_bases(S, k + n - 1) >> (2 * q)) & kmask;
-          key = rc < fwd ? rc : fwd;
+        uint64_t fwd, key;
+        if (!WIDE) {
+          fwd = (S >> (2 * (n - 1 - q))) & kmask;
+          key = fwd;
+          if (CANON) {
+            const uint64_t rc = (revcomp_bases(S, k + n - 1) >> (2 * q)) & kmask;
+            key = rc < fwd ? rc : fwd;
+          }
+        } else {  // put the run back together (up to 68 bits), then cut the k-mer out
+          const int L = k + n - 1, xx = L - 28;
+          uint64_t lo = S, hi = 0;
+          if (xx > 0) {
+            if ((x >> 58) & 1u) {  // side 1: the word holds the FIRST 28 bases, the plane the last xx
+              lo = (S << (2 * xx)) | xe;
+              hi = S >> (64 - 2 * xx);
+            } else {               // side 0: the word holds the LAST 28, the plane the first xx
+              lo = S | ((uint64_t)xe << 56);
+              hi = xe >> 8;
+            }
+          }
+          const int sh = 2 * (n - 1 - q);
+          fwd = (sh ? (lo >> sh) | (hi << (64 - sh)) : lo) & kmask;
+          key = fwd;
+          if (CANON) {
+            const uint64_t rc = revcomp_bases(fwd, k);
+            key = rc < fwd ? rc : fwd;
+          }
         }
         if (r > 0 && (split_hash(key) >> (32 - r)) != j) return;
         // The probe is ONE returning CAS: it yields "was empty, now mine", "already mine" or "someone
@@ -289,8 +346,8 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
           slot = (slot + 1) & (TBL - 1);
         }
       };
-      auto insert_record = [&](uint64_t x, uint32_t mult) {
-        for (int q = 0; q < MSP_NMAX; ++q) insert_kmer(x, q, mult);
+      auto insert_record = [&](uint64_t x, uint32_t xe, uint32_t mult) {
+        for (int q = 0; q < MSP_NMAX; ++q) insert_kmer(x, xe, q, mult);
       };
       // Phase A: identical records first.  Reads that cover the same stretch of genome cut it into the
       // same records (run boundaries follow the minimizers, not the read), so at sequencing depth most
@@ -300,35 +357,57 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
       for (int sg = 0; sg < nseg; ++sg) {
         const uint64_t a = sg == 0 ? a0 : seg_bs[sg][bin], e = sg == 0 ? e0 : seg_bs[sg][bin + 1];
         const uint64_t* __restrict__ src = sg == 0 ? inst0 : seg_inst[sg];
+        const uint32_t* __restrict__ srcx = WIDE ? (sg == 0 ? ext0 : seg_ext[sg]) : nullptr;
         for (uint64_t base = a; base < e; base += (uint64_t)MSP_ILP * BLK) {
           uint64_t rec[MSP_ILP];
+          uint32_t recx[WIDE ? MSP_ILP : 1];
           if (sg == 0 && base == a && !prefetched_next) {
 #pragma unroll
-            for (int u = 0; u < MSP_ILP; ++u) rec[u] = pre[u];
+            for (int u = 0; u < MSP_ILP; ++u) {
+              rec[u] = pre[u];
+              if (WIDE) recx[u] = prex[u];
+            }
           } else {
 #pragma unroll
             for (int u = 0; u < MSP_ILP; ++u) {
               const uint64_t i = base + threadIdx.x + (uint64_t)u * BLK;
               rec[u] = i < e ? src[i] : MSP_EMPTY;
+              if (WIDE) recx[u] = i < e ? srcx[i] : 0u;
             }
           }
 #pragma unroll
           for (int u = 0; u < MSP_ILP; ++u) {
             const uint64_t x = rec[u];
+            const uint32_t xe = WIDE ? recx[u] : 0u;
             if (x == MSP_EMPTY) continue;
-            uint32_t h = (uint32_t)x ^ (uint32_t)(x >> 23) ^ (uint32_t)(x >> 41);
+            uint32_t h = (uint32_t)x ^ (uint32_t)(x >> 23) ^ (uint32_t)(x >> 41) ^ (WIDE ? xe * 0x85EBCA6Bu : 0u);
             h = (h * 0x9E3779B1u) >> (32 - RC_LOG2);
             bool cached = false;
             for (int p = 0; p < MSP_RC_PROBES; ++p) {
               const unsigned long long old = atomicCAS(&s_rk[h], (unsigned long long)MSP_EMPTY, (unsigned long long)x);
-              if (old == MSP_EMPTY || old == x) {
+              if (!WIDE) {
+                if (old == MSP_EMPTY || old == x) {
+                  atomicAdd(&s_rc[h], 1u);
+                  cached = true;
+                  break;
+                }
+              } else if (old == MSP_EMPTY) {  // mine: publish the plane value
+                __hip_atomic_store(&s_rx[h], xe | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 atomicAdd(&s_rc[h], 1u);
                 cached = true;
                 break;
+              } else if (old == x) {
+                const uint32_t px = __hip_atomic_load(&s_rx[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (px == (xe | 0x80000000u)) {
+                  atomicAdd(&s_rc[h], 1u);
+                  cached = true;
+                  break;
+                }
+                if (px == 0) break;  // not published yet: count this one directly
               }
               h = (h + 1) & (RC - 1);
             }
-            if (!cached) insert_record(x, 1u);
+            if (!cached) insert_record(x, xe, 1u);
           }
         }
       }
@@ -340,10 +419,12 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
       {  // Phase B: pack the cache (in place, through registers), then one dense pass over the distinct records
         uint64_t ex[RC / BLK];
         uint32_t ec[RC / BLK];
+        uint32_t exx[WIDE ? RC / BLK : 1];
 #pragma unroll
         for (int h = 0; h < RC / BLK; ++h) {
           ex[h] = s_rk[h * BLK + threadIdx.x];
           ec[h] = s_rc[h * BLK + threadIdx.x];
+          if (WIDE) exx[h] = s_rx[h * BLK + threadIdx.x];
         }
         __syncthreads();
 #pragma unroll
@@ -352,13 +433,14 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
             const uint32_t o = atomicAdd(&s_nl, 1u);
             s_rk[o] = ex[h];
             s_rc[o] = ec[h];
+            if (WIDE) s_rx[o] = exx[h] & 0x7FFFFFFFu;
           }
         __syncthreads();
         const uint32_t nrec = s_nl;
         // one k-mer per thread: four times the parallelism of one record per thread, and the table
         // round trips of a record's k-mers overlap instead of queueing in one lane
         for (uint32_t i = threadIdx.x; i < MSP_NMAX * nrec; i += BLK)
-          insert_kmer(s_rk[i >> 2], (int)(i & 3u), s_rc[i >> 2]);
+          insert_kmer(s_rk[i >> 2], WIDE ? s_rx[i >> 2] : 0u, (int)(i & 3u), s_rc[i >> 2]);
         __syncthreads();
         if (threadIdx.x == 0) s_nl = 0;
       }
@@ -564,25 +646,32 @@ __global__ __launch_bounds__(SS_BLOCK) void k_surv_sort(const uint64_t* __restri
 
 namespace rfxk {
 
-int msp_k_ok(int k) { return k >= 23 && k <= 25; }
+int msp_k_ok(int k) { return k >= 23 && k <= 31; }
 int msp_part1_block() { return MP1_BLOCK; }  // m = k-10 in 13..15 (an m-mer fits 32 bits); k+3 bases fit 56 bits
+
+int msp_wide(int k) { return k > 25; }
 
 void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
                int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
-               unsigned int* flag) {
+               unsigned int* flag, uint32_t* ext_a) {
   rfx_span sp(c, hmode == 1 ? "k_msp_count" : "k_msp_part1");
-#define RFX_MSP_P1(CANON, HM)                                                                                      \
-  hipLaunchKernelGGL((k_msp_part1<CANON, HM>), dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, k, bin_bits, bin_lo, \
-                     bin_hi, buf_a, coarse_cur, cap_a, cnt_rows, flag)
-  if (canonical) {
-    if (hmode == 0) RFX_MSP_P1(true, 0);
-    else if (hmode == 1) RFX_MSP_P1(true, 1);
-    else RFX_MSP_P1(true, 2);
+#define RFX_MSP_P1(CANON, HM, WL, WIDE)                                                                             \
+  hipLaunchKernelGGL((k_msp_part1<CANON, HM, WL, WIDE>), dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, k, bin_bits, \
+                     bin_lo, bin_hi, buf_a, ext_a, coarse_cur, cap_a, cnt_rows, flag)
+#define RFX_MSP_P1_HM(CANON, WL, WIDE)          \
+  do {                                          \
+    if (hmode == 0) RFX_MSP_P1(CANON, 0, WL, WIDE);      \
+    else if (hmode == 1) RFX_MSP_P1(CANON, 1, WL, WIDE); \
+    else RFX_MSP_P1(CANON, 2, WL, WIDE);                 \
+  } while (0)
+  if (!msp_wide(k)) {
+    if (canonical) RFX_MSP_P1_HM(true, MSP_WL, false);
+    else RFX_MSP_P1_HM(false, MSP_WL, false);
   } else {
-    if (hmode == 0) RFX_MSP_P1(false, 0);
-    else if (hmode == 1) RFX_MSP_P1(false, 1);
-    else RFX_MSP_P1(false, 2);
+    if (canonical) RFX_MSP_P1_HM(true, MSP_WL_WIDE, true);
+    else RFX_MSP_P1_HM(false, MSP_WL_WIDE, true);
   }
+#undef RFX_MSP_P1_HM
 #undef RFX_MSP_P1
 }
 
@@ -590,20 +679,25 @@ void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err,
-              int geo) {
+              int geo, const uint32_t* const* seg_ext, const uint32_t* ext0) {
   rfx_span sp(c, "k_msp_leaf");
+  const bool wide = msp_wide(k);
+  if (wide) geo = 1;  // the plane of the record cache does not fit beside the full-size tables
   const uint32_t per_cu = geo ? 8 : 4;  // (1..8 per CU measured: no difference)
   const uint32_t grid = P < (uint32_t)c->n_cu * per_cu ? P : (uint32_t)c->n_cu * per_cu;
-#define RFX_MSP_LEAF(CANON, GEO)                                                                                     \
-  hipLaunchKernelGGL((k_msp_leaf<CANON, GEO>), dim3(grid), dim3(GEO ? 512 : 1024), 0, c->stream, seg_inst, seg_bs, nseg, \
-                     inst0, bs0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w, out_c, cur,  \
-                     cap, flag, err)
-  if (canonical) {
-    if (geo) RFX_MSP_LEAF(true, 1);
-    else RFX_MSP_LEAF(true, 0);
+#define RFX_MSP_LEAF(CANON, GEO, WIDE)                                                                                 \
+  hipLaunchKernelGGL((k_msp_leaf<CANON, GEO, WIDE>), dim3(grid), dim3(GEO ? 512 : 1024), 0, c->stream, seg_inst, seg_bs,  \
+                     nseg, inst0, bs0, seg_ext, ext0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, \
+                     out_w, out_c, cur, cap, flag, err)
+  if (wide) {
+    if (canonical) RFX_MSP_LEAF(true, 1, true);
+    else RFX_MSP_LEAF(false, 1, true);
+  } else if (canonical) {
+    if (geo) RFX_MSP_LEAF(true, 1, false);
+    else RFX_MSP_LEAF(true, 0, false);
   } else {
-    if (geo) RFX_MSP_LEAF(false, 1);
-    else RFX_MSP_LEAF(false, 0);
+    if (geo) RFX_MSP_LEAF(false, 1, false);
+    else RFX_MSP_LEAF(false, 0, false);
   }
 #undef RFX_MSP_LEAF
 }

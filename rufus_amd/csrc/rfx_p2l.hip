@@ -788,7 +788,9 @@ void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* f
 #define RFX_PART2(PAY, MODE)                                                                                          \
   hipLaunchKernelGGL((k_part2<PAY, MODE>), dim3(nc * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start,       \
                      fine_cur, P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b, coarse_start, k, fine_base)
-  if (pay_a) RFX_PART2(true, 0);  // payload: survivors (plain words)
+  if (pay_a && rec_mode == 0) RFX_PART2(true, 0);  // payload: counts of survivors / the plane of wide records
+  else if (pay_a && rec_mode == 1) RFX_PART2(true, 1);
+  else if (pay_a) RFX_PART2(true, 2);
   else if (rec_mode == 0) RFX_PART2(false, 0);
   else if (rec_mode == 1) RFX_PART2(false, 1);
   else RFX_PART2(false, 2);

@@ -136,7 +136,7 @@ class HipBackend:
 
     # -- minimizer-shard path ----------------------------------------------------------------------
     def msp_capable(self) -> bool:
-        return 23 <= self.k <= 25
+        return 23 <= self.k <= 25     # record export / import between ranks: one 64-bit word per record
 
     def partition(self, block):
         """(records int64[n], bin_start int64[bins+1], keep): the block's super-k-mer records grouped by

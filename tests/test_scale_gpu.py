@@ -277,3 +277,42 @@ def test_table_counts_a_sample_in_shard_passes(ctx, monkeypatch, passes, surv_fr
     t.free()
     for b in blocks:
         b.free()
+
+
+@pytest.mark.parametrize("k,passes,refine,bins", [(31, 1, None, None), (31, 3, "18", None), (27, 2, None, "32768"),
+                                                  (31, 2, "21", "16384")])
+def test_tumor_normal_k31_in_passes_matches_oracle(ctx, monkeypatch, k, passes, refine, bins):
+    """BASELINE.json configs[4] in miniature: tumor at 60x, ONE control at 30x, k = 31 (wide super-k-mer
+    records: 64-bit word + 32-bit plane) -- count in blocks and shard passes, set difference against the single
+    control, filter: records, histograms, hash list and pulled pairs are the oracle's."""
+    if refine:
+        monkeypatch.setenv("RFX_MSP_REFINE_BITS", refine)
+    if bins:
+        monkeypatch.setenv("RFX_P2L_BINS", bins)
+    G = 150_000
+    sys_ = [capi.Synth.sample(G, 0, n_snv=10, seed=31), capi.Synth.sample(G, 1, n_snv=10, seed=31)]
+    n_pairs = [30_000, 15_000]          # 60x and 30x
+    recs_o = []
+    for sy, n in zip(sys_, n_pairs):
+        seq, _ = sy.text(0, n)
+        recs_o.append(oracle.count(None, k, SIZE, lower=LOWER, reads=[r.tobytes() for r in seq]))
+    hl_o = oracle.hash_list(recs_o[0], recs_o[1:], MIN_COV, MAX_DEPTH)
+    seq, qual = sys_[0].text(0, n_pairs[0])
+    pulled_o = oracle.FilterSet(hl_o.encode()).pairs(synth_fastq(seq[0::2], qual[0::2]), synth_fastq(seq[1::2], qual[1::2]),
+                                                     k, MIN_Q, THRESH)
+    samples = [wgs.make_sample(ctx, sy, n, 9000, MIN_Q, want_good=(i == 0)) for i, (sy, n) in enumerate(zip(sys_, n_pairs))]
+    res = wgs.WgsTrio(ctx, k, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes).run(samples, keep_shard_records=True)
+    for si in range(2):
+        parts = [r[si].get() for r in res["shard_records"]]
+        keys, counts, pos = (np.concatenate([p[j] for p in parts]) for j in range(3))
+        o = np.lexsort((keys, pos))
+        assert np.array_equal(keys[o], recs_o[si].keys) and np.array_equal(counts[o], recs_o[si].counts)
+        assert np.array_equal(res["histos"][si], oracle.histo(recs_o[si].counts, full=True)[0])
+    for shard in res["shard_records"]:
+        for r in shard:
+            r.free()
+    assert tools.keys_to_text(res["mutant_keys"], k) == [ln.split()[0] for ln in hl_o.splitlines()] and res["n_mutant"] > 0
+    assert res["n_pulled"] == len(pulled_o) > 0
+    for s_ in samples:
+        for b in s_:
+            b.free()

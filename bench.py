@@ -131,34 +131,41 @@ def run_s1(args, ctx, rank, world, dist, torch):
 def run_wgs(args, ctx, rank, world, dist, torch):
     from rufus_amd import capi, wgs
     G = args.genome
-    n_pairs = G * args.coverage // (2 * READ_LEN)
+    tn = args.workload == "tn"      # BASELINE configs[4]: tumor 60x / normal 30x, one control, k = 31
+    k = args.k or (31 if tn else K)
+    covs = [2 * args.coverage, args.coverage] if tn else [args.coverage] * 3
+    pairs = [G * c_ // (2 * READ_LEN) for c_ in covs]
+    n_pairs = pairs[0]
     n_snv = max(20, min(1000, G // 3_000_000))
-    sys_ = [capi.Synth.sample(G, w, n_snv=n_snv, seed=SEED) for w in range(3)]
+    sys_ = [capi.Synth.sample(G, w, n_snv=n_snv, seed=SEED) for w in range(len(covs))]
     free0, total = torch.cuda.mem_get_info()
     # this rank's share of every sample: pairs [p0, p1) (strong scaling: the trio is the same for every N)
-    p0, p1 = n_pairs * rank // world, n_pairs * (rank + 1) // world
     bpp = 2 * (40 + 20 + 8)                                   # bytes per pair: codes + acgt mask + offsets
-    resident = (p1 - p0) * (3 * bpp + 2 * 20)                 # + the subject's quality mask
-    passes = args.passes or wgs.plan_passes(2 * n_pairs, READ_LEN, K, resident + (total - free0), total, world=world)
+    resident = sum(n * (rank + 1) // world - n * rank // world for n in pairs) * bpp + (n_pairs // world) * 2 * 20
+    passes = args.passes or wgs.plan_passes(2 * n_pairs, READ_LEN, k, resident + (total - free0), total, world=world,
+                                            n_samples=len(covs), coverage_hint=covs[0], wide=k > 25)
     if world > 1:                                             # every rank must run the same number of passes
         t = torch.tensor([passes], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         passes = int(t.item())
     t0 = time.perf_counter()
-    samples = [wgs.make_sample(ctx, sy, p1 - p0, 1 << 24, MIN_Q, want_good=(i == 0), first_pair=p0)
-               for i, sy in enumerate(sys_)]
+    samples = [wgs.make_sample(ctx, sy, n * (rank + 1) // world - n * rank // world, 1 << 24, MIN_Q, want_good=(i == 0),
+                               first_pair=n * rank // world) for i, (sy, n) in enumerate(zip(sys_, pairs))]
     ctx.sync()
     t_gen = time.perf_counter() - t0
-    trio = wgs.WgsTrio(ctx, K, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes,
+    trio = wgs.WgsTrio(ctx, k, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes,
                        group=dist.group.WORLD if world > 1 else None)
     step = lambda: trio.run(samples)  # noqa: E731
-    n_reads = 2 * n_pairs
-    desc = (f"synthetic {args.coverage}x WGS trio (BASELINE configs[2]): genome {G} bp, {n_reads} x {READ_LEN} bp reads "
-            f"per sample, on each of {world} GPU(s) {len(samples[0])} resident blocks per sample ({resident / 1e9:.0f} GB "
-            f"of packed reads in HBM, generated on the device in {t_gen:.1f} s), {n_snv} SNVs, seed {SEED}, k={K}, "
-            f"-s 8G -L {LOWER}, MinCov {MIN_COV}, MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}; "
-            f"{passes} minimizer-shard pass(es) per step")
-    return (step, 3 * n_reads, n_reads // world, n_reads, desc, "strong",
+    reads = [2 * n for n in pairs]
+    what = (f"tumor {covs[0]}x / normal {covs[1]}x pair (BASELINE configs[4])" if tn
+            else f"{args.coverage}x WGS trio (BASELINE configs[2])")
+    desc = (f"synthetic {what}: genome {G} bp, {'/'.join(map(str, reads))} x {READ_LEN} bp reads per sample, on each of "
+            f"{world} GPU(s) {len(samples[0])} resident blocks of the subject ({resident / 1e9:.0f} GB of packed reads in "
+            f"HBM, generated on the device in {t_gen:.1f} s), {n_snv} SNVs, seed {SEED}, k={k}, -s 8G -L {LOWER}, MinCov "
+            f"{MIN_COV}, MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}; {passes} minimizer-shard pass(es) per step")
+    args.k = k
+    args.n_samples = len(covs)
+    return (step, sum(reads), sum(reads) // len(reads) // world, reads[0], desc, "strong",
             {"passes": passes, "hbm_total": total, "hbm_free_at_start": free0})
 
 
@@ -167,7 +174,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=("wgs", "s1"), default="wgs")
+    ap.add_argument("--workload", choices=("wgs", "tn", "s1"), default="wgs",
+                    help="wgs: 30x trio, k=25 (configs[2]); tn: tumor 60x / normal 30x, k=31 (configs[4]); s1: configs[1]")
+    ap.add_argument("--k", type=int, default=0, help="k-mer length (default 25; 31 for tn)")
     ap.add_argument("--genome", type=int, default=3_100_000_000, help="wgs: genome length (reads scale with it)")
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--passes", type=int, default=0, help="wgs: minimizer-shard passes (0 = plan from free HBM)")
@@ -189,7 +198,9 @@ def main():
 
     ctx = capi.Context(local)   # raises without a gfx950 GPU: no CPU fallback
     step, reads_per_step, reads_per_launch, reads_filtered, desc, scaling, extra = (
-        run_wgs if args.workload == "wgs" else run_s1)(args, ctx, rank, world, dist, torch)
+        run_wgs if args.workload != "s1" else run_s1)(args, ctx, rank, world, dist, torch)
+    k_used = getattr(args, "k", 0) or K
+    n_samples = getattr(args, "n_samples", 3)
 
     def fence():
         ctx.sync()
@@ -205,7 +216,7 @@ def main():
     ctx.prof(True)
     for _ in range(args.warmup):
         res = step()
-    live_all = args.workload == "wgs"
+    live_all = args.workload != "s1"
     ctx.prof(live_all)
     ctx.prof_reset()
     fence()
@@ -230,14 +241,14 @@ def main():
         # partition + sort of the survivors).  The algorithmic bytes of SURVEY 8(d) K2 cover the stage as a
         # whole, so one "launch" = the chain of one sample, its duration = the SUM of its kernels' durations.
         k2 = [n for n in K2_CHAIN if n in prof and prof[n][1]]
-        n_chains = 3 * prof_steps
+        n_chains = n_samples * prof_steps
         parts = {n: prof[n][0] / n_chains for n in k2}
         chain_ms = sum(parts.values())
-        bytes_per_launch = algorithmic_bytes_per_read() * reads_per_launch
+        bytes_per_launch = algorithmic_bytes_per_read(k=k_used) * reads_per_launch
         achieved = bytes_per_launch / (chain_ms * 1e-3) / 1e9 if chain_ms else 0.0
         f_ms = prof["k_filter"][0] / prof_steps if "k_filter" in prof and prof["k_filter"][1] else 0.0
         line = {
-            "metric": "reads/sec through k-mer count+filter at k=25",
+            "metric": f"reads/sec through k-mer count+filter at k={k_used}",
             "value": reads_per_step * args.steps / dt,
             "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -174,7 +174,7 @@ int rfx_synth_genome(const rfx_synth*, uint64_t first, uint64_t n, char* out);
 rfx_table* rfx_count_begin(rfx_ctx*, int k, int canonical, int lsize, uint64_t capacity_slots, uint64_t pos_lo,
                            uint64_t pos_hi);
 /* Three exact implementations sit behind rfx_count_add(); results are identical.
- *  RFX_COUNT_MSP   (23 <= k <= 25) cuts reads into super-k-mers (runs of consecutive k-mers sharing a
+ *  RFX_COUNT_MSP   (23 <= k <= 31) cuts reads into super-k-mers (runs of consecutive k-mers sharing a
  *                  minimizer bin, 8 bytes per <= 4 k-mers), partitions those, counts every bin in LDS and
  *                  sorts only the surviving (key,count) pairs into (pos,key) order.  Fastest, least HBM.
  *  RFX_COUNT_P2L   (2k <= 62) partitions one 8-byte sortable word per k-mer instance by (pos,key) prefix
@@ -220,13 +220,18 @@ int rfx_count_stats(rfx_table*, uint64_t* distinct, uint64_t* capacity, uint64_t
  *                            Valid until the next add/finish/free on the table.
  *   rfx_count_add_records_dev  append a copy of records grouped the same way (bin b = bin_start[b]..
  *                            bin_start[b+1]); `bins` is a power of two >= 256 and the table must be MSP
- *                            capable (23 <= k <= 25).  All segments of a table must come from the same
+ *                            capable (23 <= k <= 25; k = 26 .. 31 through rfx_count_add_records_ext_dev).  All segments of a table must come from the same
  *                            k / canonical setting; bins may differ (finish refines to a common count). */
 int rfx_count_segments(rfx_table*);
 int rfx_count_segment_get(rfx_table*, int i, const uint64_t** d_records, const uint64_t** d_bin_start, uint32_t* bins,
                           uint64_t* n_records);
 int rfx_count_add_records_dev(rfx_table*, const uint64_t* d_records, uint64_t n_records, const uint64_t* d_bin_start,
                               uint32_t bins);
+/* k = 26 .. 31: a record is a 64-bit word plus a 32-bit plane entry (the bases of a run beyond the 28 the word
+ * holds); the plane is grouped like the records and travels with them. */
+int rfx_count_segment_ext(rfx_table*, int i, const uint32_t** d_ext); /* NULL plane for k <= 25 */
+int rfx_count_add_records_ext_dev(rfx_table*, const uint64_t* d_records, const uint32_t* d_ext, uint64_t n_records,
+                                  const uint64_t* d_bin_start, uint32_t bins);
 void rfx_count_free(rfx_table*);
 
 /* K3: table -> records with lower <= count <= upper in (pos,key) order (jf/include/jellyfish/

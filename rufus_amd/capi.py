@@ -73,6 +73,8 @@ SIGNATURES = {
     "rfx_count_segment_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_uint32), u64p]),
     "rfx_count_add_records_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
+    "rfx_count_segment_ext": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "rfx_count_add_records_ext_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
     "rfx_count_free": (None, [C.c_void_p]),
     "rfx_count_finish": (C.c_void_p, [C.c_void_p, C.c_uint64, C.c_uint64, u64p]),
     "rfx_records_size": (C.c_uint64, [C.c_void_p]),
@@ -460,9 +462,16 @@ class CountTable:
             out.append((dr.value or 0, db.value or 0, bins.value, nr.value))
         return out
 
-    def add_records_dev(self, d_records: int, n_records: int, d_bin_start: int, bins: int):
-        _check(lib().rfx_count_add_records_dev(self._h, d_records, n_records, d_bin_start, bins),
+    def add_records_dev(self, d_records: int, n_records: int, d_bin_start: int, bins: int, d_ext: int = 0):
+        """d_ext: the 32-bit plane of the records (k = 26 .. 31), grouped like them."""
+        _check(lib().rfx_count_add_records_ext_dev(self._h, d_records, d_ext or None, n_records, d_bin_start, bins),
                "rfx_count_add_records_dev")
+
+    def segment_ext(self, i: int) -> int:
+        """Device pointer of the 32-bit plane of segment i (0 for k <= 25)."""
+        p = C.c_void_p(0)
+        _check(lib().rfx_count_segment_ext(self._h, i, C.byref(p)), "rfx_count_segment_ext")
+        return p.value or 0
 
     def stats(self):
         d, c, m = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)

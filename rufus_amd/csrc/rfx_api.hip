@@ -2043,13 +2043,15 @@ int rfx_count_segments(rfx_table* t) {
   return t->seg_kind == RFX_COUNT_MSP ? (int)t->segs->size() : 0;
 }
 
+int rfx_count_segment_ext(rfx_table* t, int i, const uint32_t** d_ext) {
+  if (!t || t->seg_kind != RFX_COUNT_MSP || i < 0 || i >= (int)t->segs->size() || !d_ext) return RFX_E_INVAL;
+  *d_ext = (*t->segs)[(size_t)i].ext;
+  return RFX_OK;
+}
+
 int rfx_count_segment_get(rfx_table* t, int i, const uint64_t** d_records, const uint64_t** d_bin_start, uint32_t* bins,
                           uint64_t* n_records) {
   if (!t || t->seg_kind != RFX_COUNT_MSP || i < 0 || i >= (int)t->segs->size()) return RFX_E_INVAL;
-  if (rfxk::msp_wide(t->k)) {
-    snprintf(g_err, sizeof g_err, "rfx_count_segment_get: record export is implemented for k <= 25 (one 64-bit word per record)");
-    return RFX_E_INVAL;
-  }
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
   // One synchronisation for both: the capacity flags of the pending adds and the exact record count of
@@ -2077,27 +2079,40 @@ int rfx_count_segment_get(rfx_table* t, int i, const uint64_t** d_records, const
   return RFX_E_HIP;
 }
 
-int rfx_count_add_records_dev(rfx_table* t, const uint64_t* d_records, uint64_t n_records, const uint64_t* d_bin_start,
-                              uint32_t bins) {
+int rfx_count_add_records_ext_dev(rfx_table* t, const uint64_t* d_records, const uint32_t* d_ext, uint64_t n_records,
+                                  const uint64_t* d_bin_start, uint32_t bins) {
   if (!t || !d_bin_start || (n_records && !d_records) || bins < 256 || (bins & (bins - 1))) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
-  if (!rfxk::msp_k_ok(t->k) || rfxk::msp_wide(t->k) || !t->lut_t || t->table_active ||
-      (t->seg_kind && t->seg_kind != RFX_COUNT_MSP)) {
-    snprintf(g_err, sizeof g_err, "rfx_count_add_records_dev: the table is not on the MSP path (k = 23 .. 25 for record import)");
+  if (!rfxk::msp_k_ok(t->k) || !t->lut_t || t->table_active || (t->seg_kind && t->seg_kind != RFX_COUNT_MSP)) {
+    snprintf(g_err, sizeof g_err, "rfx_count_add_records_dev: the table is not on the MSP path");
+    return RFX_E_INVAL;
+  }
+  const bool wide = rfxk::msp_wide(t->k);
+  if (wide && n_records && !d_ext) {
+    snprintf(g_err, sizeof g_err, "rfx_count_add_records_dev: k = 26 .. 31 records come with their 32-bit plane "
+                                  "(rfx_count_add_records_ext_dev)");
     return RFX_E_INVAL;
   }
   uint64_t* inst = (uint64_t*)dmalloc(c, (n_records ? n_records : 1) * 8);
+  uint32_t* ext = wide ? (uint32_t*)dmalloc(c, (n_records ? n_records : 1) * 4) : nullptr;
   uint64_t* bs = (uint64_t*)dmalloc(c, ((size_t)bins + 1) * 8);
-  if (!inst || !bs) { dfree(c, inst); dfree(c, bs); return RFX_E_NOMEM; }
+  if (!inst || !bs || (wide && !ext)) { dfree(c, inst); dfree(c, bs); dfree(c, ext); return RFX_E_NOMEM; }
   hipError_t e = hipMemcpyAsync(bs, d_bin_start, ((size_t)bins + 1) * 8, hipMemcpyDeviceToDevice, c->stream);
   if (e == hipSuccess && n_records)
     e = hipMemcpyAsync(inst, d_records, n_records * 8, hipMemcpyDeviceToDevice, c->stream);
-  if (e != hipSuccess) { dfree(c, inst); dfree(c, bs); return hip_fail(e, "rfx_count_add_records_dev"); }
+  if (e == hipSuccess && n_records && wide)
+    e = hipMemcpyAsync(ext, d_ext, n_records * 4, hipMemcpyDeviceToDevice, c->stream);
+  if (e != hipSuccess) { dfree(c, inst); dfree(c, bs); dfree(c, ext); return hip_fail(e, "rfx_count_add_records_dev"); }
   if (!t->p2l_bins) t->p2l_bins = bins > 8192 ? 8192 : bins;  // geometry of later rfx_count_add calls
-  t->segs->push_back(rfx_segment{inst, n_records, bs, n_records * 4, bins});  // <= 4 k-mers per record
+  t->segs->push_back(rfx_segment{inst, n_records, bs, n_records * 4, bins, ext});  // <= 4 k-mers per record
   t->seg_kind = RFX_COUNT_MSP;
   return RFX_OK;
+}
+
+int rfx_count_add_records_dev(rfx_table* t, const uint64_t* d_records, uint64_t n_records, const uint64_t* d_bin_start,
+                              uint32_t bins) {
+  return rfx_count_add_records_ext_dev(t, d_records, nullptr, n_records, d_bin_start, bins);
 }
 
 int rfx_count_stats(rfx_table* t, uint64_t* distinct, uint64_t* capacity, uint64_t* max_displacement) {

@@ -22,6 +22,19 @@ from . import capi
 from .dist import revcomp_keys
 
 
+class _DevMem32:
+    """n int32 at a raw device address, for torch.as_tensor (no copy)."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 3,
+                                         "strides": None}
+
+
+def _device_view32(ptr: int, n: int, device):
+    import torch
+    return torch.as_tensor(_DevMem32(ptr, n), device=device)
+
+
 def shard_cut(q: int, n: int) -> int:
     """First of the 256 virtual top-level minimizer bins of shard q of n (rfx_count_set_shard's cut)."""
     return -(-q * 256 // n)
@@ -36,7 +49,7 @@ def pulled_pairs(mask: np.ndarray, n_reads: int) -> int:
 
 
 def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, hbm_bytes: int, n_samples: int = 3,
-                coverage_hint: float = 30.0, world: int = 1) -> int:
+                coverage_hint: float = 30.0, world: int = 1, wide: bool = False) -> int:
     """Smallest number of shard passes whose transients fit beside the resident reads of ONE rank.
 
     n_reads_total: reads per sample over all ranks.  Per pass, sample and rank: super-k-mer records (8 B per
@@ -48,7 +61,7 @@ def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, 
     distinct = windows / max(coverage_hint * (read_len - k + 1) / read_len, 1.0)
     for s in range(1, 257 // world):
         share = s * world
-        records = 2.7 * windows / share * (3.0 if world > 1 else 1.0)
+        records = (4.1 if wide else 2.7) * windows / share * (3.0 if world > 1 else 1.0)   # wide: 12 B per record
         # leaf phase of the last sample of a pass: records + scratch, survivor store, the other samples' records
         transient = records * 1.125 + 12.0 * distinct / share * 1.3 + (n_samples - 1) * 20.0 * distinct / share
         # (measured on the 30x WGS trio, 1 GPU: 219 GB at 5 passes, ~243 GB at 4 of 288 GiB)
@@ -114,15 +127,23 @@ class WgsTrio:
         try:
             own.set_shard(shard * W + me, Q)
             keep = []
+            wide = self.k > 25      # records = 64-bit word + 32-bit plane: the plane travels in a second all-to-all
             for i in range(rounds):
+                ext = None
                 if i < len(segs):
                     d_rec, d_bs, bins, n = segs[i]
                     rec = _device_view(d_rec, n, dev) if n else torch.empty(0, dtype=torch.int64, device=dev)
                     bs_host = _device_view(d_bs, bins + 1, dev).cpu()
+                    if wide:
+                        d_ext = part.segment_ext(i)
+                        ext = (_device_view32(d_ext, n, dev) if n and d_ext else
+                               torch.empty(0, dtype=torch.int32, device=dev))
                 else:                                   # nothing to send in this round
                     bins = 256
                     rec = torch.empty(0, dtype=torch.int64, device=dev)
                     bs_host = torch.zeros(bins + 1, dtype=torch.int64)
+                    if wide:
+                        ext = torch.empty(0, dtype=torch.int32, device=dev)
                 per = bins // 256
                 cuts = bs_host[torch.tensor([v * per for v in vb])]
                 send_l = (cuts[1:] - cuts[:-1]).tolist()
@@ -142,6 +163,12 @@ class WgsTrio:
                 wr = _wire(rec[int(cuts[0]):int(cuts[-1])], self.group)
                 rr = torch.empty(sum(recv_l), dtype=torch.int64, device=wr.device)
                 dist.all_to_all_single(rr, wr, recv_l, send_l, group=self.group)
+                re_ = None
+                if wide:
+                    we = _wire(ext[int(cuts[0]):int(cuts[-1])], self.group)
+                    re_ = torch.empty(sum(recv_l), dtype=torch.int32, device=we.device)
+                    dist.all_to_all_single(re_, we, recv_l, send_l, group=self.group)
+                    re_ = re_.to(dev)
                 if rr.is_cuda:
                     torch.cuda.current_stream(rr.device).synchronize()   # the library runs on its own stream
                 rr, rb = rr.to(dev), rb.cpu()
@@ -156,10 +183,12 @@ class WgsTrio:
                     full[lo + off_rl[src]:] = loc[-1]
                     full = full.to(dev)
                     run = rr[ro:ro + recv_l[src]]
+                    run_e = re_[ro:ro + recv_l[src]] if wide else None
                     torch.cuda.synchronize(dev)
                     if recv_l[src]:
-                        own.add_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), sbins)
-                    keep.append((run, full))
+                        own.add_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), sbins,
+                                            run_e.data_ptr() if wide else 0)
+                    keep.append((run, full, run_e))
                     ro += recv_l[src]
                     bo += off_rl[src]
                 self.ctx.sync()             # the imports are copies: the exchange buffers may go

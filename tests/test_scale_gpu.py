@@ -34,18 +34,18 @@ def test_device_generator_matches_host_twin(ctx, which, first, n_pairs, want_goo
     blk.free()
 
 
-def _oracle_trio(sys_, n_pairs):
+def _oracle_trio(sys_, n_pairs, k=K):
     """Oracle records / hash list / pulled pairs of a synthetic trio regenerated as text on the host."""
     fq, recs = [], []
     for sy in sys_:
         seq, qual = sy.text(0, n_pairs)
         fq.append((seq, qual))
-        recs.append(oracle.count(None, K, SIZE, lower=LOWER, reads=[r.tobytes() for r in seq]))
+        recs.append(oracle.count(None, k, SIZE, lower=LOWER, reads=[r.tobytes() for r in seq]))
     hl = oracle.hash_list(recs[0], recs[1:], MIN_COV, MAX_DEPTH)
     seq, qual = fq[0]
     m1 = synth_fastq(seq[0::2], qual[0::2])
     m2 = synth_fastq(seq[1::2], qual[1::2])
-    pulled = oracle.FilterSet(hl.encode()).pairs(m1, m2, K, MIN_Q, THRESH) if hl else np.zeros(0, np.int64)
+    pulled = oracle.FilterSet(hl.encode()).pairs(m1, m2, k, MIN_Q, THRESH) if hl else np.zeros(0, np.int64)
     return recs, hl, pulled
 
 
@@ -182,7 +182,7 @@ def test_wgs_slice_properties(ctx):
 # ------------------------------------------------------------------------------------------------
 # strong scaling of one trio over ranks: two ranks share the one GPU, exchange over gloo
 # ------------------------------------------------------------------------------------------------
-def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs):
+def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs, k=K):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -194,7 +194,7 @@ def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs):
         p0, p1 = n_pairs * rank // world, n_pairs * (rank + 1) // world
         samples = [wgs.make_sample(c, sy, p1 - p0, block_pairs, MIN_Q, want_good=(i == 0), first_pair=p0)
                    for i, sy in enumerate(sys_)]
-        trio = wgs.WgsTrio(c, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes, group=dist.group.WORLD)
+        trio = wgs.WgsTrio(c, k, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes, group=dist.group.WORLD)
         res = trio.run(samples, keep_shard_records=True)
         recs = [[tuple(a.tolist() for a in shard[si].get()) for shard in res["shard_records"]] for si in range(3)]
         pulled = np.concatenate([np.flatnonzero(_pairs_of(m, b.n)) + off for m, b, off in
@@ -207,8 +207,8 @@ def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("passes,block_pairs", [(1, 1 << 20), (2, 5000)])
-def test_trio_strong_scaled_over_two_ranks(passes, block_pairs):
+@pytest.mark.parametrize("passes,block_pairs,k", [(1, 1 << 20, K), (2, 5000, K), (2, 6000, 31)])
+def test_trio_strong_scaled_over_two_ranks(passes, block_pairs, k):
     """WgsTrio(group=...): each rank holds half of every sample's pairs; per pass the ranks exchange their
     super-k-mer records by minimizer-bin owner (flat cut over passes x ranks) and count complete bins.  The
     union of all (pass, rank) shards is the oracle's record list; histograms, hash list and pulled pairs too."""
@@ -221,7 +221,7 @@ def test_trio_strong_scaled_over_two_ranks(passes, block_pairs):
     s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_wgs_worker, args=(r, world, port, q, passes, n_pairs, G, block_pairs))
+    procs = [mpc.Process(target=_wgs_worker, args=(r, world, port, q, passes, n_pairs, G, block_pairs, k))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -230,7 +230,7 @@ def test_trio_strong_scaled_over_two_ranks(passes, block_pairs):
         p.join(60)
         assert p.exitcode == 0
     sys_ = [capi.Synth.sample(G, w, n_snv=12, seed=777) for w in range(3)]
-    recs_o, hl_o, pulled_o = _oracle_trio(sys_, n_pairs)
+    recs_o, hl_o, pulled_o = _oracle_trio(sys_, n_pairs, k)
     for si in range(3):
         parts = [sh for g in got for sh in g[1][si]]
         keys = np.concatenate([np.array(p[0], np.uint64) for p in parts])

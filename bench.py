@@ -52,20 +52,24 @@ def algorithmic_bytes_per_read(L=READ_LEN, k=K):
     return (L + 3) // 4 + (L + 7) // 8 + (L - k + 1) * 16
 
 
-def cpu_baseline(seconds_budget=25.0):
+def cpu_baseline():
     """The same path on the host cores, on a bounded sample of the SAME workload (first pairs of each sample
     of the synthetic trio, regenerated as text by the generator's host twin): the oracle's C++ port for
     count (lock-free CAS hash table, mirrors jf/include/jellyfish/large_hash_array.hpp:708-744) and set
     difference, the REAL reference binary oracle/_ref/RUFUS.Filter (built from /root/reference/src in the
-    build container) for the filter; at T = 1, 8 and nproc-2 threads (runRufus.sh:796,:967 use T-2)."""
+    build container) for the filter; at T = 1, 8 and nproc-2 threads (runRufus.sh:796,:967 use T-2).
+    The filter leg runs on the first 60 k pairs of the subject and is scaled to the leg's read count: the
+    reference forks its OpenMP team once per 60 pairs (src/RUFUS.Filter.cpp:196), which at 254 threads takes
+    minutes per million pairs -- measured on the 256-core box, it is why the first version of this leg timed out."""
     import oracle
     from rufus_amd import capi
     from tests.synth import synth_fastq
     ncpu = os.cpu_count() or 1
     out = {"unit": "reads/s", "kind": "port", "by_threads": {}}
     exe = os.path.join(ROOT, "oracle", "_ref", "RUFUS.Filter")
+    n_filter = 60_000
     for T in sorted({1, min(8, ncpu), max(1, ncpu - 2)}):
-        n_pairs = int(min(4_000_000, 60_000 * T ** 0.8))     # ~ equal wall time per leg
+        n_pairs = int(min(1_000_000, 40_000 * T ** 0.8))     # ~ equal wall time per leg
         G = n_pairs * 10
         sys_ = [capi.Synth.sample(G, w, n_snv=max(4, G // 1_000_000), seed=SEED) for w in range(3)]
         texts = [sy.text(0, n_pairs) for sy in sys_]
@@ -76,28 +80,34 @@ def cpu_baseline(seconds_budget=25.0):
         hl = oracle.hash_list(recs[0], recs[1:], MIN_COV, MAX_DEPTH)
         t_merge = time.perf_counter() - t0
         seq, qual = texts[0]
-        m1, m2 = synth_fastq(seq[0::2], qual[0::2]), synth_fastq(seq[1::2], qual[1::2])
+        nf = min(n_filter, n_pairs)
+        m1, m2 = synth_fastq(seq[0:2 * nf:2], qual[0:2 * nf:2]), synth_fastq(seq[1:2 * nf:2], qual[1:2 * nf:2])
+        note = ""
         if os.path.exists(exe):
             d = tempfile.mkdtemp(prefix="rfx_cpu_")
             for m, data in ((1, m1), (2, m2)):
                 open(f"{d}/m{m}.fq", "wb").write(data)
             open(f"{d}/hl", "w").write(hl)
             t0 = time.perf_counter()
-            subprocess.run([exe, f"{d}/hl", f"{d}/m1.fq", f"{d}/m2.fq", f"{d}/o", str(K), str(MIN_Q), str(THRESH), str(T)],
-                           stdout=subprocess.DEVNULL, check=True)
-            t_filter = time.perf_counter() - t0
+            try:
+                subprocess.run([exe, f"{d}/hl", f"{d}/m1.fq", f"{d}/m2.fq", f"{d}/o", str(K), str(MIN_Q), str(THRESH), str(T)],
+                               stdout=subprocess.DEVNULL, check=True, timeout=90)
+            except subprocess.TimeoutExpired:
+                note = " (stopped after 90 s: a lower bound of its time)"
+            t_filter = (time.perf_counter() - t0) * n_pairs / nf
             filt = "reference binary oracle/_ref/RUFUS.Filter (-O2)"
             out["kind"] = "port (count, set difference) + reference (filter)"
         else:
             fs = oracle.FilterSet(hl.encode())
             t0 = time.perf_counter()
             fs.pairs(m1, m2, K, MIN_Q, THRESH)
-            t_filter = time.perf_counter() - t0
+            t_filter = (time.perf_counter() - t0) * n_pairs / nf
             filt = "oracle port of RUFUS.Filter (1 thread)"
         reads = 3 * 2 * n_pairs
         total = t_count + t_merge + t_filter
         out["by_threads"][str(T)] = {"reads_per_s": reads / total, "reads": reads, "count_s": round(t_count, 2),
-                                     "set_difference_s": round(t_merge, 2), "filter_s": round(t_filter, 2)}
+                                     "set_difference_s": round(t_merge, 2),
+                                     "filter_s_scaled_from_%d_pairs" % nf: round(t_filter, 2), "note": note.strip()}
         out["filter_tool"] = filt
     best = max(out["by_threads"], key=lambda t_: out["by_threads"][t_]["reads_per_s"])
     out["value"] = out["by_threads"][best]["reads_per_s"]
@@ -105,7 +115,7 @@ def cpu_baseline(seconds_budget=25.0):
     out["host_cores"] = ncpu
     out["sample"] = ("first pairs of each sample of the same synthetic trio at 30x on a proportionally smaller genome "
                      "(reads per leg in by_threads), k=25: count = CAS hash-table port (oracle), set difference = oracle, "
-                     f"filter = {out['filter_tool']}")
+                     f"filter = {out['filter_tool']} on the subject's first {n_filter} pairs, scaled")
     return out
 
 
@@ -181,7 +191,11 @@ def main():
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--passes", type=int, default=0, help="wgs: minimizer-shard passes (0 = plan from free HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline()))
+        return
 
     import torch
     import torch.distributed as dist
@@ -280,11 +294,16 @@ def main():
                 line["roofline"]["traffic"] = pmc["_chain"]["hbm_bytes_per_sample"]
                 line["roofline"]["traffic_source"] = pmc["_chain"].get("source", pmc_path)
         if world == 1 and not args.no_cpu_baseline:
+            # in a child process: the baseline is a report, never a reason to lose the measurement (a crash of the
+            # CPU code, an OpenMP runtime clash with torch's, a timeout -- the line below is printed regardless)
             try:
-                line["cpu_baseline"] = cpu_baseline()
-            except Exception as e:   # the baseline is a report, never a reason to lose the measurement
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only"], stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, timeout=420)
+                line["cpu_baseline"] = json.loads(p.stdout.decode().strip().splitlines()[-1])
+            except Exception as e:
+                err = locals().get("p")
                 line["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 1, "kind": "port",
-                                        "sample": f"failed: {e!r}"}
+                                        "sample": f"failed: {e!r} " + (err.stderr.decode()[-300:] if err is not None else "")}
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -44,19 +44,26 @@ def main():
     # The count -> sorted-records chain of one sample (what bench.py prices against the roofline): every
     # launch between two k_msp_part1 launches that belongs to rfx_count_add / rfx_count_finish.
     chain = ["k_msp_part1", "k_msp_count", "k_col_sums", "k_bin_group_sums", "k_bin_offsets", "k_scan_tail", "k_part2",
-             "k_flag_if_gt", "k_slice_tag",
-             "k_msp_leaf", "k_surv_hist", "k_surv_sort", "k_bin_count", "k_part1", "k_leaf", "k_leaf_compact",
+             "k_flag_if_gt", "k_slice_tag", "k_bin_hist",
+             "k_msp_leaf", "k_surv_hist", "k_surv_sort", "k_histo_bins", "k_bin_count", "k_part1", "k_leaf", "k_leaf_compact",
              "k_bin_scatter", "k_tmp_start"]
-    samples = max(out.get("k_msp_part1", {}).get("launches", 0), out.get("k_part1", {}).get("launches", 0),
-                  out.get("k_bin_scatter", {}).get("launches", 0))
+    # round 2: a sample is many read blocks (one k_msp_part1 launch each, per shard pass): the number of sample
+    # chains in the profiled run is given on the command line (3 per trio step)
+    samples = int(sys.argv[4]) if len(sys.argv) > 4 else max(
+        out.get("k_msp_part1", {}).get("launches", 0), out.get("k_part1", {}).get("launches", 0),
+        out.get("k_bin_scatter", {}).get("launches", 0))
     if samples:
         tot = sum(out[k]["hbm_bytes_per_launch"] * out[k]["launches"] for k in chain if k in out)
         out["_chain"] = {"kernels": [k for k in chain if k in out], "samples": samples,
-                         "hbm_bytes_per_sample": int(tot / samples)}
+                         "hbm_bytes_per_sample": int(tot / samples),
+                         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), (2*FETCH+WRITE)*1024, all "
+                                   "launches of the count chain of the profiled bench command / sample chains"}
+        if len(sys.argv) > 5:
+            out["genome"] = int(sys.argv[5])
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     if "_chain" in out:
         print(f"count chain: {out['_chain']['hbm_bytes_per_sample'] / 1e6:.1f} MB per sample over {samples} samples")
-    for k, v in sorted(((k, v) for k, v in out.items() if k != "_chain"), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+    for k, v in sorted(((k, v) for k, v in out.items() if isinstance(v, dict) and "launches" in v), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
         print(f"{k:26s} {v['launches']:4d} {v['FETCH_SIZE_KB_avg']:14.1f} {v['WRITE_SIZE_KB_avg']:14.1f} "
               f"{v['hbm_bytes_per_launch'] / 1e6:10.1f} MB")
 

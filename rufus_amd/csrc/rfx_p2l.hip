@@ -676,6 +676,55 @@ __global__ __launch_bounds__(1024) void k_scan_tail(uint64_t* __restrict__ v, ui
   }
 }
 
+// Large scans (the bin tables of a refinement chunk hold millions of entries): block sums, a one-block scan of
+// those, then every block scans its 8192 entries from its offset.  v[n] = total as in k_scan_tail.
+constexpr int SCAN_CHUNK = 8192;
+__global__ __launch_bounds__(1024) void k_scan_sums(const uint64_t* __restrict__ v, uint64_t n, uint64_t* __restrict__ sums) {
+  __shared__ uint64_t s_w[16];
+  const uint64_t a = (uint64_t)blockIdx.x * SCAN_CHUNK;
+  uint64_t x = 0;
+  for (int u = 0; u < SCAN_CHUNK / 1024; ++u) {
+    const uint64_t i = a + (uint64_t)u * 1024 + threadIdx.x;
+    if (i < n) x += v[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint64_t t = 0;
+    for (int i = 0; i < 16; ++i) t += s_w[i];
+    sums[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(1024) void k_scan_apply(uint64_t* __restrict__ v, uint64_t n, const uint64_t* __restrict__ sums,
+                                                      uint32_t n_blocks) {
+  __shared__ uint64_t s_w[16];
+  const uint64_t a = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * (SCAN_CHUNK / 1024);
+  uint64_t loc[SCAN_CHUNK / 1024], sum = 0;
+#pragma unroll
+  for (int u = 0; u < SCAN_CHUNK / 1024; ++u) {
+    loc[u] = a + u < n ? v[a + u] : 0;
+    sum += loc[u];
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint64_t inc = sum;
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) s_w[wv] = inc;
+  __syncthreads();
+  uint64_t base = sums[blockIdx.x];  // exclusive prefix of the block sums (scanned in place by k_scan_tail)
+  for (int i = 0; i < wv; ++i) base += s_w[i];
+  uint64_t run = base + inc - sum;
+#pragma unroll
+  for (int u = 0; u < SCAN_CHUNK / 1024; ++u) {
+    if (a + u < n) v[a + u] = run;
+    run += loc[u];
+  }
+  if (blockIdx.x == n_blocks - 1 && threadIdx.x == 1023) v[n] = sums[n_blocks];
+}
+
 }  // namespace
 
 namespace rfxk {
@@ -830,7 +879,21 @@ void leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* se
 }
 
 void scan_tail(rfx_ctx* c, uint64_t* v, uint64_t n) {
-  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, c->stream, v, n);
+  if (n <= 65536) {
+    hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, c->stream, v, n);
+    return;
+  }
+  // one block would take milliseconds on the multi-million-entry bin tables of WGS-scale refinement chunks
+  const uint32_t nb = (uint32_t)((n + SCAN_CHUNK - 1) / SCAN_CHUNK);
+  uint64_t* sums = (uint64_t*)rfxi::dmalloc(c, ((size_t)nb + 1) * 8);
+  if (!sums) {  // no scratch: the slow way is still correct
+    hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, c->stream, v, n);
+    return;
+  }
+  hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(1024), 0, c->stream, v, n, sums);
+  hipLaunchKernelGGL(k_scan_tail, dim3(1), dim3(1024), 0, c->stream, sums, (uint64_t)nb);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(1024), 0, c->stream, v, n, sums, nb);
+  rfxi::dfree(c, sums);  // stream-ordered
 }
 
 void leaf_compact(rfx_ctx* c, const uint64_t* tmp_w, const uint32_t* tmp_counts, const uint64_t* tmp_start_,

@@ -319,6 +319,21 @@ int rfx_filter(rfx_set*, const rfx_reads*, int thresh, int last_base_skipped, ui
 #define RFX_OVL_REGION 2
 int rfx_overlap_score(rfx_ctx*, const char* a, int alen, const char* const* b, const int* blen, int nb, float min_pct,
                       int min_ovl, int variant, int* out /* nb x 5 */);
+/* The same scoring against a DEVICE-RESIDENT pool of sequences: the assemblers' outer loops are sequential (read i
+ * merges into its best partner, which is seen later: src/OverlapSam.cpp:866-1024, src/Overlap.cpp:935-1126,
+ * src/OverlapRegion.cpp:702-841), so one scoring call per read is unavoidable -- but not uploading the candidates
+ * again for every call (OverlapRegion scores read i against ALL later reads).  The pool is uploaded once,
+ * rfx_ovl_pool_set() patches the one entry a merge changes, a score call moves only the candidate indices and the
+ * results, with no allocation.  query: a pool entry, or an explicit string (a_explicit != NULL).  strands: 0 = the
+ * query as it is, 1 = its reverse complement (built on the device: the query must consist of ACGTN only, as
+ * Util::RevComp drops other characters), 2 = both in one launch: out holds nb x 5 for the forward strand, then
+ * nb x 5 for the reverse complement. */
+typedef struct rfx_ovl_pool rfx_ovl_pool;
+rfx_ovl_pool* rfx_ovl_pool_create(rfx_ctx*, const char* const* seqs, const int* lens, int n);
+int rfx_ovl_pool_set(rfx_ovl_pool*, int idx, const char* seq, int len);
+int rfx_ovl_pool_score(rfx_ovl_pool*, int query, const char* a_explicit, int a_len, const int* cand, int nb,
+                       float min_pct, int min_ovl, int variant, int strands, int* out);
+void rfx_ovl_pool_free(rfx_ovl_pool*);
 /* AnnotateOverlap (src/AnnotateOverlap.cpp:88-134): for each packed contig of the block (good mask =
  * base != 'N' && qual-33 >= 3, i.e. RFX_PACK_FILTER with min_q 3) the number of mutant windows that
  * cover every base; cov_out holds rfx_reads_bases() counters, contig after contig. */

@@ -102,6 +102,11 @@ SIGNATURES = {
     "rfx_overlap_score": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
                                     C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rfx_annotate": (C.c_int, [C.c_void_p, C.c_void_p, u32p]),
+    "rfx_ovl_pool_create": (C.c_void_p, [C.c_void_p, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_int]),
+    "rfx_ovl_pool_set": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+    "rfx_ovl_pool_score": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float,
+                                     C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "rfx_ovl_pool_free": (None, [C.c_void_p]),
 }
 
 

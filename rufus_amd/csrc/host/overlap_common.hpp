@@ -79,23 +79,11 @@ struct AlignResult {
   int score = 0, overlap = -1, index = -1;
 };
 
-inline AlignResult align3(rfx_ctx* ctx, const std::vector<std::string>& seqs, const std::string& a,
-                          const std::vector<int>& idx, float min_pct, int min_ovl, int variant, bool& perfect,
-                          int k_init, int index_init) {
+// The reference's cross-candidate rules over the device's per-candidate results (5 ints each, rufus_hip.h).
+inline AlignResult pick_best(const int* out, const std::vector<int>& idx, bool& perfect, int k_init, int index_init) {
   AlignResult res;
   res.overlap = k_init;
   res.index = index_init;
-  if (idx.empty()) return res;
-  std::vector<const char*> b(idx.size());
-  std::vector<int> bl(idx.size());
-  for (size_t j = 0; j < idx.size(); ++j) {
-    b[j] = seqs[(size_t)idx[j]].data();
-    bl[j] = (int)seqs[(size_t)idx[j]].size();
-  }
-  std::vector<int> out(idx.size() * 5);
-  const int rc = rfx_overlap_score(ctx, a.data(), (int)a.size(), b.data(), bl.data(), (int)idx.size(), min_pct, min_ovl,
-                                   variant, out.data());
-  if (rc) rfxcli::die(std::string("rufus_amd: overlap scoring failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
   for (size_t j = 0; j < idx.size(); ++j) {
     const int* o = &out[5 * j];
     // candidates visited after a perfect match only run phase 1 (the `if (PerfectMatch == false)` guard)
@@ -110,6 +98,80 @@ inline AlignResult align3(rfx_ctx* ctx, const std::vector<std::string>& seqs, co
   }
   return res;
 }
+
+inline bool acgtn_only(const std::string& s) {
+  for (char c : s)
+    if (c != 'A' && c != 'C' && c != 'G' && c != 'T' && c != 'N') return false;
+  return true;
+}
+
+// The read pool on the device (uploaded once; a merge patches one entry) and the two Align3 calls of a greedy
+// step: the query (pool entry i, == `a`) forward against `fwd_idx`, and -- unless the forward pass found a perfect
+// match -- reverse-complemented against `rev_idx`.  When both lists are the same (OverlapSam, OverlapRegion) the
+// two strands are scored in ONE launch; the reverse complement is built on the device when the query has only
+// ACGTN (Util::RevComp drops other characters: then the host string goes up instead).
+struct PoolScorer {
+  rfx_ovl_pool* pool = nullptr;
+  std::vector<int> out;
+  void create(rfx_ctx* ctx, const std::vector<std::string>& seqs) {
+    std::vector<const char*> ptr(seqs.size());
+    std::vector<int> len(seqs.size());
+    for (size_t i = 0; i < seqs.size(); ++i) {
+      ptr[i] = seqs[i].data();
+      len[i] = (int)seqs[i].size();
+    }
+    pool = rfx_ovl_pool_create(ctx, ptr.data(), len.data(), (int)seqs.size());
+    if (!pool) rfxcli::die(std::string("rufus_amd: cannot build the device read pool: ") + rfx_last_error());
+  }
+  void set(int idx, const std::string& s) {
+    const int rc = rfx_ovl_pool_set(pool, idx, s.data(), (int)s.size());
+    if (rc) rfxcli::die(std::string("rufus_amd: pool update failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
+  }
+  void score(int query, const std::string* explicit_a, const std::vector<int>& idx, float min_pct, int min_ovl, int variant,
+             int strands) {
+    out.assign(idx.size() * 5 * (strands == 2 ? 2 : 1) + 1, 0);
+    if (idx.empty()) return;
+    const int rc = rfx_ovl_pool_score(pool, query, explicit_a ? explicit_a->data() : nullptr,
+                                      explicit_a ? (int)explicit_a->size() : 0, idx.data(), (int)idx.size(), min_pct, min_ovl,
+                                      variant, strands, out.data());
+    if (rc) rfxcli::die(std::string("rufus_amd: overlap scoring failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
+  }
+  // best forward partner; then, if nothing was perfect, the best partner of the reverse complement (in `rev`;
+  // rev_done says whether it was looked for).  fwd_init / rev_init: the variant's initial (overlap, index).
+  AlignResult both(int query, const std::string& a, const std::vector<int>& fwd_idx, const std::vector<int>& rev_idx,
+                   bool same_lists, float min_pct, int min_ovl, int variant, int fwd_k_init, AlignResult& rev, bool& rev_done) {
+    bool perfect = false;
+    const bool clean = acgtn_only(a);
+    rev_done = false;
+    if (same_lists && clean) {
+      score(query, nullptr, fwd_idx, min_pct, min_ovl, variant, 2);
+      AlignResult best = pick_best(out.data(), fwd_idx, perfect, fwd_k_init, -1);
+      if (!perfect) {
+        rev = pick_best(out.data() + 5 * fwd_idx.size(), fwd_idx, perfect, -1, -1);
+        rev_done = true;
+      }
+      return best;
+    }
+    score(query, nullptr, fwd_idx, min_pct, min_ovl, variant, 0);
+    AlignResult best = pick_best(out.data(), fwd_idx, perfect, fwd_k_init, -1);
+    if (!perfect) {
+      if (clean) {
+        score(query, nullptr, rev_idx, min_pct, min_ovl, variant, 1);
+      } else {
+        const std::string ra = revcomp(a);
+        score(query, &ra, rev_idx, min_pct, min_ovl, variant, 0);
+      }
+      rev = pick_best(out.data(), rev_idx, perfect, -1, -1);
+      rev_done = true;
+    }
+    return best;
+  }
+  void release() {
+    rfx_ovl_pool_free(pool);
+    pool = nullptr;
+  }
+  ~PoolScorer() { release(); }
+};
 
 // ColapsContigs, three flavours (src/OverlapSam.cpp:243-357, src/Overlap.cpp:362-466,
 // src/OverlapRegion.cpp:233-358).  Returns the merged sequence; bq/bd/bs are updated in place.

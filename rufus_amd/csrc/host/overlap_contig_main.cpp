@@ -163,6 +163,8 @@ int main(int argc, char** argv) {
 #endif
   const int n = (int)p.seq.size();
   rfx_ctx* ctx = n ? rfxcli::open_ctx() : nullptr;
+  PoolScorer scorer;  // the reads live on the device; a merge patches the one entry it changes
+  if (n) scorer.create(ctx, p.seq);
 
 #ifdef REGION
   // ---- OverlapRegion: every later read is a candidate (src/OverlapRegion.cpp:37-41) ----------------
@@ -170,18 +172,19 @@ int main(int argc, char** argv) {
     std::string a = p.seq[(size_t)i], aq = p.qual[(size_t)i], ad = p.depth[(size_t)i], as = p.strand[(size_t)i];
     std::vector<int> idx;
     for (int j = i + 1; j < n; ++j) idx.push_back(j);
-    bool perfect = false;
-    AlignResult best = align3(ctx, p.seq, a, idx, min_pct, min_ovl, RFX_OVL_REGION, perfect, -1, -1);
-    if (!perfect) {
-      const std::string ra = revcomp(a), raq = revqual(aq), rad = revqual(ad), ras = flip_strands(as);
-      const AlignResult rev = align3(ctx, p.seq, ra, idx, min_pct, min_ovl, RFX_OVL_REGION, perfect, -1, -1);
-      if (rev.score > best.score) { a = ra; aq = raq; ad = rad; as = ras; best = rev; }
+    AlignResult rev;
+    bool rev_done = false;
+    AlignResult best = scorer.both(i, a, idx, idx, true, min_pct, min_ovl, RFX_OVL_REGION, -1, rev, rev_done);
+    if (rev_done && rev.score > best.score) {
+      a = revcomp(a); aq = revqual(aq); ad = revqual(ad); as = flip_strands(as);
+      best = rev;
     }
     if (best.score < min_ovl) continue;
     const size_t bi = (size_t)best.index;
     std::string bq = p.qual[bi], bd = p.depth[bi], bs = p.strand[bi];
     p.seq[bi] = collapse(a, p.seq[bi], best.overlap, aq, bq, ad, bd, as, bs, MERGE_REGION);
     p.qual[bi] = bq; p.depth[bi] = bd; p.strand[bi] = bs;
+    scorer.set((int)bi, p.seq[bi]);
     p.seq[(size_t)i] = "moved";
   }
 #else
@@ -244,23 +247,26 @@ int main(int argc, char** argv) {
     for (int i = b; i < hi; ++i) rev[(size_t)(i - b)] = rank(revcomp(p.seq[(size_t)i]), i);
     for (int i = b; i < hi; ++i) {
       std::string a = p.seq[(size_t)i], aq = p.qual[(size_t)i], ad = p.depth[(size_t)i], as = p.strand[(size_t)i];
-      bool perfect = false;
-      AlignResult best = align3(ctx, p.seq, a, fwd[(size_t)(i - b)], min_pct, min_ovl, RFX_OVL_CONTIG, perfect, 0, -1);
-      if (!perfect) {
-        const std::string ra = revcomp(a), raq = revqual(aq), rad = revqual(ad), ras = flip_strands(as);
-        const AlignResult r2 = align3(ctx, p.seq, ra, rev[(size_t)(i - b)], min_pct, min_ovl, RFX_OVL_CONTIG, perfect, -1, -1);
-        if (r2.score > best.score) { a = ra; aq = raq; ad = rad; as = ras; best = r2; }
+      AlignResult r2;
+      bool rev_done = false;
+      AlignResult best = scorer.both(i, a, fwd[(size_t)(i - b)], rev[(size_t)(i - b)], false, min_pct, min_ovl,
+                                     RFX_OVL_CONTIG, 0, r2, rev_done);
+      if (rev_done && r2.score > best.score) {
+        a = revcomp(a); aq = revqual(aq); ad = revqual(ad); as = flip_strands(as);
+        best = r2;
       }
       if (best.score < min_ovl) continue;
       const size_t bi = (size_t)best.index;
       std::string bq = p.qual[bi], bd = p.depth[bi], bs = p.strand[bi];
       p.seq[bi] = collapse(a, p.seq[bi], best.overlap, aq, bq, ad, bd, as, bs, MERGE_CONTIG);
       p.qual[bi] = bq; p.depth[bi] = bd; p.strand[bi] = bs;
+      scorer.set((int)bi, p.seq[bi]);
       p.seq[(size_t)i] = "moved";
     }
   }
 #endif
   write_nodes(p, stub, node, min_cov);
+  scorer.release();  // before the context goes
   if (ctx) rfx_close(ctx);
   return 0;
 }

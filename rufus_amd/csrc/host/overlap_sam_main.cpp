@@ -161,24 +161,24 @@ int main(int argc, char** argv) {
   std::vector<std::string>&seqs = main_pool.seq, &quals = main_pool.qual, &depths = main_pool.depth,
                           &strands = main_pool.strand;
   const int n = (int)seqs.size();
+  PoolScorer scorer;  // the reads live on the device; a merge patches the one entry it changes
+  if (n) scorer.create(ctx, seqs);
   for (int i = 0; i < n; ++i) {
     std::string a = seqs[(size_t)i], aq = quals[(size_t)i], ad = depths[(size_t)i], as = strands[(size_t)i];
     std::vector<int> idx;
     for (int j = i + 1; j < std::min(n, i + 11); ++j) idx.push_back(j);
-    bool perfect = false;
-    AlignResult best = align3(ctx, seqs, a, idx, min_pct, min_ovl, RFX_OVL_SAM, perfect, -1, -1);
-    if (!perfect) {
-      const std::string ra = revcomp(a), raq = revqual(aq), rad = revqual(ad), ras = flip_strands(as);
-      const AlignResult rev = align3(ctx, seqs, ra, idx, min_pct, min_ovl, RFX_OVL_SAM, perfect, -1, -1);
-      if (rev.score > best.score) {
-        a = ra; aq = raq; ad = rad; as = ras;
-        best = rev;
-      }
+    AlignResult rev;
+    bool rev_done = false;
+    AlignResult best = scorer.both(i, a, idx, idx, true, min_pct, min_ovl, RFX_OVL_SAM, -1, rev, rev_done);
+    if (rev_done && rev.score > best.score) {
+      a = revcomp(a); aq = revqual(aq); ad = revqual(ad); as = flip_strands(as);
+      best = rev;
     }
     if (best.score < min_ovl) continue;
     const size_t bi = (size_t)best.index;
     std::string bq = quals[bi], bd = depths[bi], bs = strands[bi];
     const std::string merged = collapse(a, seqs[bi], best.overlap, aq, bq, ad, bd, as, bs, MERGE_SAM);
+    scorer.set((int)bi, merged);
     seqs[bi] = merged;
     quals[bi] = bq;
     depths[bi] = bd;
@@ -216,6 +216,7 @@ int main(int argc, char** argv) {
     std::cout << "min coverage = " << min_cov << " skipping Unaligned sequences" << std::endl;
   }
   std::cout << "\nWrote " << count << " sequences" << std::endl;
+  scorer.release();  // before the context goes
   rfx_set_free(set);
   rfx_close(ctx);
   return 0;

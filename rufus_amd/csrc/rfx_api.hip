@@ -2576,6 +2576,159 @@ int rfx_overlap_score(rfx_ctx* c, const char* a, int alen, const char* const* b,
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_overlap_score");
 }
 
+// ---- device-resident sequence pool of the greedy assemblers ----------------------------------------------------
+struct rfx_ovl_pool {
+  rfx_ctx* ctx;
+  char* arena = nullptr;
+  size_t cap = 0, used = 0;
+  uint64_t* d_off = nullptr;
+  int* d_len = nullptr;
+  std::vector<uint64_t> off;
+  std::vector<int> len, room;  // room: bytes reserved for the entry at its current place
+  int* d_cand = nullptr;
+  int* d_out = nullptr;
+  size_t cand_cap = 0;
+  char* d_a = nullptr;
+  size_t a_cap = 0;
+  int* h_out = nullptr;  // pinned
+  int* h_cand = nullptr;
+};
+
+static int ovl_arena_grow(rfx_ovl_pool* p, size_t need) {
+  rfx_ctx* c = p->ctx;
+  size_t ncap = std::max<size_t>(p->cap * 2, p->used + need + (1u << 20));
+  char* na = (char*)dmalloc(c, ncap);
+  if (!na) return RFX_E_NOMEM;
+  if (p->used) HIPCHK(hipMemcpyAsync(na, p->arena, p->used, hipMemcpyDeviceToDevice, c->stream));
+  dfree(c, p->arena);  // stream-ordered
+  p->arena = na;
+  p->cap = ncap;
+  return RFX_OK;
+}
+
+rfx_ovl_pool* rfx_ovl_pool_create(rfx_ctx* c, const char* const* seqs, const int* lens, int n) {
+  if (!c || n < 0 || (n && (!seqs || !lens))) return nullptr;
+  (void)hipSetDevice(c->device);
+  rfx_ovl_pool* p = new rfx_ovl_pool();
+  p->ctx = c;
+  p->off.resize((size_t)n);
+  p->len.assign(lens, lens + n);
+  p->room.resize((size_t)n);
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (lens[i] < 0) { delete p; return nullptr; }
+    p->off[(size_t)i] = total;
+    p->room[(size_t)i] = lens[i] + lens[i] / 2 + 64;  // merges lengthen entries: leave room in place
+    total += (size_t)p->room[(size_t)i];
+  }
+  p->cap = total + total / 4 + (1u << 20);
+  p->used = total;
+  p->arena = (char*)dmalloc(c, p->cap);
+  p->d_off = (uint64_t*)dmalloc(c, std::max<size_t>((size_t)n, 1) * 8);
+  p->d_len = (int*)dmalloc(c, std::max<size_t>((size_t)n, 1) * 4);
+  p->h_out = (int*)rfx_host_alloc((size_t)1 << 22);
+  p->h_cand = (int*)rfx_host_alloc((size_t)1 << 20);
+  bool ok = p->arena && p->d_off && p->d_len && p->h_out && p->h_cand;
+  if (ok && n) {
+    std::string cat(total, 'Z');
+    for (int i = 0; i < n; ++i) memcpy(&cat[p->off[(size_t)i]], seqs[i], (size_t)lens[i]);
+    ok = hipMemcpyAsync(p->arena, cat.data(), total, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+         hipMemcpyAsync(p->d_off, p->off.data(), (size_t)n * 8, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+         hipMemcpyAsync(p->d_len, p->len.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+         ctx_sync(c) == hipSuccess;
+  }
+  if (!ok) {
+    rfx_ovl_pool_free(p);
+    return nullptr;
+  }
+  return p;
+}
+
+void rfx_ovl_pool_free(rfx_ovl_pool* p) {
+  if (!p) return;
+  rfx_ctx* c = p->ctx;
+  dfree(c, p->arena); dfree(c, p->d_off); dfree(c, p->d_len); dfree(c, p->d_cand); dfree(c, p->d_out); dfree(c, p->d_a);
+  rfx_host_free(p->h_out);
+  rfx_host_free(p->h_cand);
+  delete p;
+}
+
+int rfx_ovl_pool_set(rfx_ovl_pool* p, int idx, const char* seq, int len) {
+  if (!p || idx < 0 || idx >= (int)p->len.size() || len < 0 || (len && !seq)) return RFX_E_INVAL;
+  rfx_ctx* c = p->ctx;
+  (void)hipSetDevice(c->device);
+  if (len > p->room[(size_t)idx]) {  // does not fit in place: move the entry to the end of the arena
+    const size_t room = (size_t)len + (size_t)len / 2 + 64;
+    if (p->used + room > p->cap) {
+      const int rc = ovl_arena_grow(p, room);
+      if (rc) return rc;
+    }
+    p->off[(size_t)idx] = p->used;
+    p->room[(size_t)idx] = (int)room;
+    p->used += room;
+  }
+  p->len[(size_t)idx] = len;
+  if (len) HIPCHK(upload(c, p->arena + p->off[(size_t)idx], seq, (size_t)len));
+  HIPCHK(upload(c, p->d_off + idx, &p->off[(size_t)idx], 8));
+  HIPCHK(upload(c, p->d_len + idx, &p->len[(size_t)idx], 4));
+  return RFX_OK;
+}
+
+int rfx_ovl_pool_score(rfx_ovl_pool* p, int query, const char* a_explicit, int a_len, const int* cand, int nb,
+                       float min_pct, int min_ovl, int variant, int strands, int* out) {
+  if (!p || nb < 0 || (nb && (!cand || !out)) || strands < 0 || strands > 2) return RFX_E_INVAL;
+  if (!a_explicit && (query < 0 || query >= (int)p->len.size())) return RFX_E_INVAL;
+  rfx_ctx* c = p->ctx;
+  (void)hipSetDevice(c->device);
+  if (nb == 0) return RFX_OK;
+  const int alen = a_explicit ? a_len : p->len[(size_t)query];
+  int max_blen = 0;
+  for (int j = 0; j < nb; ++j) {
+    if (cand[j] < 0 || cand[j] >= (int)p->len.size()) return RFX_E_INVAL;
+    max_blen = std::max(max_blen, p->len[(size_t)cand[j]]);
+  }
+  const size_t lds = (size_t)alen + (size_t)max_blen + 16;
+  if (lds > 150 * 1024) return RFX_E_RANGE;  // both strings live in LDS
+  const int nstr = strands == 2 ? 2 : 1;
+  const size_t n_out = (size_t)nb * nstr * 5;
+  if ((size_t)nb > p->cand_cap) {  // persistent device buffers, grown on demand: no allocation per call
+    dfree(c, p->d_cand);
+    dfree(c, p->d_out);
+    p->cand_cap = std::max<size_t>((size_t)nb * 2, 4096);
+    p->d_cand = (int*)dmalloc(c, p->cand_cap * 4);
+    p->d_out = (int*)dmalloc(c, p->cand_cap * 2 * 5 * 4);
+    if (!p->d_cand || !p->d_out) { p->cand_cap = 0; return RFX_E_NOMEM; }
+  }
+  const bool pinned_ok = (size_t)nb * 4 <= ((size_t)1 << 20) && n_out * 4 <= ((size_t)1 << 22);
+  hipError_t e;
+  if (pinned_ok) {
+    memcpy(p->h_cand, cand, (size_t)nb * 4);
+    e = hipMemcpyAsync(p->d_cand, p->h_cand, (size_t)nb * 4, hipMemcpyHostToDevice, c->stream);
+  } else {
+    e = hipMemcpyAsync(p->d_cand, cand, (size_t)nb * 4, hipMemcpyHostToDevice, c->stream);
+  }
+  const char* d_a = nullptr;
+  if (e == hipSuccess && a_explicit) {
+    if ((size_t)alen + 1 > p->a_cap) {
+      dfree(c, p->d_a);
+      p->a_cap = (size_t)alen * 2 + 1024;
+      p->d_a = (char*)dmalloc(c, p->a_cap);
+      if (!p->d_a) { p->a_cap = 0; return RFX_E_NOMEM; }
+    }
+    e = upload(c, p->d_a, a_explicit, (size_t)alen);
+    d_a = p->d_a;
+  }
+  if (e != hipSuccess) return hip_fail(e, "rfx_ovl_pool_score");
+  rfxk::overlap_pool(c, p->arena, p->d_off, p->d_len, d_a, alen, query, p->d_cand, nb, strands == 1 ? 1 : 0,
+                     strands == 0 ? 0 : 1, lds, min_pct, min_ovl, variant == RFX_OVL_CONTIG,
+                     variant == RFX_OVL_CONTIG ? -1 : 0, p->d_out);
+  e = hipMemcpyAsync(pinned_ok ? p->h_out : out, p->d_out, n_out * 4, hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = ctx_sync(c);
+  if (e != hipSuccess) return hip_fail(e, "rfx_ovl_pool_score");
+  if (pinned_ok) memcpy(out, p->h_out, n_out * 4);
+  return RFX_OK;
+}
+
 int rfx_annotate(rfx_set* s, const rfx_reads* r, uint32_t* cov_out) {
   if (!s || !r || s->ctx != r->ctx || !r->good || !cov_out) return RFX_E_INVAL;
   rfx_ctx* c = s->ctx;

@@ -252,6 +252,9 @@ void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, in
             unsigned long long* d_nhit);
 void overlap_score(rfx_ctx*, const char* d_a, int alen, const char* d_bcat, const uint32_t* d_boff, int nb, int max_blen,
                    float min_pct, int min_ovl, int strict3, int local_init, int* d_out /* nb x 5 */);
+void overlap_pool(rfx_ctx*, const char* arena, const uint64_t* off, const int* len, const char* a_explicit,
+                  int a_explicit_len, int query, const int* cand, int nb, int strand_lo, int strand_hi, size_t lds,
+                  float min_pct, int min_ovl, int strict3, int local_init, int* d_out);
 void annotate(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, int k,
               const uint64_t* base_off, uint32_t* cov);
 int p2l_grid(rfx_ctx*, uint32_t n_reads);

@@ -93,10 +93,10 @@ def test_overlap_score_kernel_matches_restatement(ctx):
             assert tuple(int(x) for x in got[j]) == want, (variant, j, got[j], want)
 
 
-def fabricate_sam(seed=31):
+def fabricate_sam(seed=31, genome_len=30_000, n_pairs=4000, n_snv=3):
     """Position-sorted SAM (flags 99/147 + a few unmapped, duplicate-flagged, short and low-quality records)
     of the child read pairs that carry a mutant k-mer, as bwa + samtools sort would hand them over."""
-    trio = make_trio(genome_len=30_000, n_pairs=4000, n_snv=3, seed=seed)
+    trio = make_trio(genome_len=genome_len, n_pairs=n_pairs, n_snv=n_snv, seed=seed)
     k = 25
     reads = {n: [r.tobytes() for m in (0, 1) for r in trio[n].s[m]] for n in ("child", "mother", "father")}
     recs = {n: oracle.count(None, k, 1 << 27, lower=2, reads=reads[n]) for n in reads}
@@ -191,3 +191,88 @@ def test_full_assembly_chain_matches_reference(tmp_path):
     # the chain really assembles: node counts shrink stage by stage and something comes out
     nodes = [sizes[f] // 6 for f in ("sam.fastqd", "1.fastqd", "2.fastqd", "3.fastqd", "4.fastqd")]
     assert nodes[0] > nodes[-1] >= 1, nodes
+
+
+def _chain(d, tag, where, sam, hl, final_cov="2", timings=None):
+    """scripts/Overlap.shorter.sh:127-194 for one side (ours / reference), Threads = 1."""
+    import time
+
+    def run(exe, args, stdout=None):
+        t0 = time.perf_counter()
+        r = subprocess.run([f"{where}/{exe}"] + args, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1800)
+        assert r.returncode == 0, (exe, r.stderr[-500:])
+        if stdout:
+            open(f"{d}/{stdout}", "wb").write(r.stdout)
+        if timings is not None:
+            timings[exe + ":" + (args[-3] if exe == "Overlap" else "")] = round(time.perf_counter() - t0, 2)
+
+    t = tag
+    run("OverlapSam", [sam, ".95", "20", "1", f"{t}.sam", "NS", "1", hl, "1"])
+    run("Overlap", [f"{t}.sam.fastqd", ".98", "100", "1", "FP", "20", "1", f"{t}.1", "0", "1"])
+    run("Overlap", [f"{t}.1.fastqd", ".98", "75", "2", "FP", "20", "1", f"{t}.2", "1", "1"])
+    run("Overlap", [f"{t}.2.fastqd", ".98", "50", "2", "NS", "20", "1", f"{t}.3", "1", "1"])
+    run("OverlapRegion", [f"{t}.3.fastqd", ".98", "50", final_cov, f"{t}.4", "NS", "1", "1"])
+    run("ReplaceQwithDinFASTQD", [f"{t}.4.fastqd"], f"{t}.overlap.fastqd")
+    run("ConvertFASTqD.to.FASTQ", [f"{t}.overlap.fastqd"], f"{t}.overlap.fastq")
+    run("AnnotateOverlap", [hl, f"{t}.overlap.fastq", f"{t}.asm.hash.fastq"], f"{t}.hashcount.fastq")
+
+
+_STAGES = ["sam.fastqd", "1.fastqd", "2.fastqd", "3.fastqd", "4.fastqd", "4.fastq", "overlap.fastqd", "overlap.fastq",
+           "hashcount.fastq", "asm.hash.fastq"]
+
+
+@needs_ref
+def test_testrun_pulled_pairs_assemble_like_the_reference(testrun, tmp_path):
+    """SURVEY 8(c) golden 3: the 26 read pairs RUFUS.Filter pulls from the reference's own test trio, as a
+    fabricated position-sorted SAM (flags 99/147; no bwa here), through the whole assembly chain with the
+    reference's arguments (FinalCoverage 5): byte-identical to the reference binaries at every stage, 7 -> 7 -> 3 ->
+    3 -> 2 nodes (the survey's probe counted 8 after OverlapSam: its read order is not recorded) and the 2-record
+    hashcount.fastq the VCF step would start from."""
+    import gzip
+    d = str(tmp_path)
+    names = testrun["expected"]["filter_paired_names"]
+
+    def recs(blob):
+        t = blob.split(b"\n")
+        return {t[i][1:].split()[0].decode(): (t[i + 1], t[i + 3]) for i in range(0, len(t) - 1, 4)}
+
+    m1, m2 = recs(testrun["Child"][0]), recs(testrun["Child"][1])
+    rows = []
+    for i, n in enumerate(names):
+        key = n.lstrip("@")
+        for flag, (s, q), off in ((b"99", m1[key], 0), (b"147", m2[key], 5)):
+            rows.append(b"\t".join([key.encode(), flag, b"5", str(1000 + 10 * i + off).encode(), b"60", b"151M", b"=", b"1",
+                                    b"0", s, q, b"NM:i:0"]))
+    open(f"{d}/in.sam", "wb").write(b"\n".join(rows) + b"\n")
+    open(f"{d}/hl", "w").write(testrun["hashlist"])
+    for tag, where in (("ours", BIN), ("ref", REF)):
+        _chain(d, tag, where, "in.sam", "hl", final_cov="5")
+    nodes = []
+    for f in _STAGES:
+        a, b = open(f"{d}/ours.{f}", "rb").read(), open(f"{d}/ref.{f}", "rb").read()
+        assert a == b, f
+        if f.endswith(".fastqd") and f[0] in "s1234":
+            nodes.append(a.count(b"\n") // 6)
+    assert nodes == [7, 7, 3, 3, 2], nodes
+    assert open(f"{d}/ours.hashcount.fastq", "rb").read().count(b"\n") == 8
+
+
+@needs_ref
+def test_assembly_chain_on_ten_thousand_reads(tmp_path):
+    """The chain on > 10^4 pulled reads (500 SNVs): the device-resident read pool (uploaded once, one patched entry
+    per merge, both strands per launch) gives the reference's files byte for byte at Threads = 1; wall times of
+    both sides are printed (pytest -s) -- the reference's own O(N L^2) scans against one launch per greedy step."""
+    sam, hl, n = fabricate_sam(seed=5, genome_len=600_000, n_pairs=60_000, n_snv=500)
+    assert n > 10_000
+    d = str(tmp_path)
+    open(f"{d}/in.sam", "wb").write(sam)
+    open(f"{d}/hl", "w").write(hl)
+    times = {}
+    for tag, where in (("ours", BIN), ("ref", REF)):
+        times[tag] = {}
+        _chain(d, tag, where, "in.sam", "hl", timings=times[tag])
+    print("assembly chain wall times (s):", n, "SAM records;", times)
+    for f in _STAGES:
+        a, b = open(f"{d}/ours.{f}", "rb").read(), open(f"{d}/ref.{f}", "rb").read()
+        assert a == b, f
+    assert open(f"{d}/ours.4.fastqd", "rb").read().count(b"\n") // 6 >= 50

@@ -119,6 +119,111 @@ def cpu_baseline():
     return out
 
 
+def end_to_end(n_pairs=12_000_000):
+    """the path through the DROP-IN EXECUTABLES, text in -> files out, process start and HIP init
+    included: rfx_synth_fastq writes a bounded 30x sample of the same synthetic trio as FASTQ (tmpfs when there is
+    one); then, as runRufus.sh does, `jellyfish count` x 3 -> modified `jellyfish merge` -> `jellyfish query` + the
+    [MinCov, MaxDepth] filter (CheckJellyHashList.sh:12) -> `RUFUS.Filter` -> (no bwa in the image: the pulled pairs
+    get their true coordinates from the generator) OverlapSam -> Overlap x 3 -> OverlapRegion -> tail tools."""
+    from rufus_amd import capi
+    B = os.path.join(ROOT, "rufus_amd", "bin")
+    ncpu = os.cpu_count() or 1
+    T = str(max(1, min(64, ncpu - 2)))
+    G = n_pairs * 10
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="rfx_e2e_", dir=base)
+    out = {"reads_per_sample": 2 * n_pairs, "threads": int(T), "stages_s": {}}
+
+    def run(name, args, stdout=None, stdin=None):
+        t0 = time.perf_counter()
+        p = subprocess.run(args, cwd=d, stdout=open(os.path.join(d, stdout), "wb") if stdout else subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, stdin=stdin, timeout=900)
+        if p.returncode != 0:
+            raise RuntimeError(f"{name}: rc {p.returncode}: {p.stderr.decode()[-300:]}")
+        out["stages_s"][name] = round(out["stages_s"].get(name, 0.0) + time.perf_counter() - t0, 3)
+
+    try:
+        n_snv = max(8, G // 1_000_000)
+        t_gen = time.perf_counter()
+        for w, name in enumerate(("child", "mother", "father")):
+            if w == 0:
+                run("generate", [f"{B}/rfx_synth_fastq", str(G), "0", str(n_snv), str(SEED), "0", str(n_pairs), "c.m1.fq", "c.m2.fq"])
+                run("generate", ["sh", "-c", "cat c.m1.fq c.m2.fq > child.fq"])
+            else:
+                run("generate", [f"{B}/rfx_synth_fastq", str(G), str(w), str(n_snv), str(SEED), "0", str(n_pairs), f"{name}.fq"])
+        out["generate_s (not counted)"] = round(time.perf_counter() - t_gen, 2)
+        out["stages_s"].pop("generate", None)
+        t0 = time.perf_counter()
+        for name in ("child", "mother", "father"):
+            run("jellyfish count", [f"{B}/jellyfish", "count", "--disk", "-m", str(K), "-L", str(LOWER), "-s", "8G", "-t", T,
+                                    "-o", f"{name}.Jhash", "-C", f"{name}.fq"])
+            run("jellyfish histo", [f"{B}/jellyfish", "histo", "-f", "-o", f"{name}.Jhash.histo", f"{name}.Jhash"])
+        run("jellyfish merge", [f"{B}/jellyfish", "merge", "child.Jhash", "mother.Jhash", "father.Jhash"], stdout="merge.txt")
+        t1 = time.perf_counter()
+        with open(os.path.join(d, "merge.txt")) as f, open(os.path.join(d, "q.fa"), "w") as q:
+            for ln in f:
+                km = ln.split()[0]
+                q.write(f">{km}\n{km}\n")
+        out["stages_s"]["awk (python)"] = round(time.perf_counter() - t1, 3)
+        run("jellyfish query", [f"{B}/jellyfish", "query", "-s", "q.fa", "child.Jhash"], stdout="query.txt")
+        t1 = time.perf_counter()
+        with open(os.path.join(d, "query.txt")) as f, open(os.path.join(d, "child.HashList"), "w") as h:
+            n_hl = 0
+            for ln in f:
+                c_ = int(ln.split()[1])
+                if MIN_COV <= c_ <= MAX_DEPTH:
+                    h.write(ln)
+                    n_hl += 1
+        out["stages_s"]["awk (python)"] += round(time.perf_counter() - t1, 3)
+        run("RUFUS.Filter", [f"{B}/RUFUS.Filter", "child.HashList", "c.m1.fq", "c.m2.fq", "child", str(K), str(MIN_Q),
+                             str(THRESH), T])
+        t_path = time.perf_counter() - t0
+        out["mutant_kmers"] = n_hl
+        out["count_to_filter_s"] = round(t_path, 2)
+        out["value"] = 3 * 2 * n_pairs / t_path
+        out["unit"] = "reads/s (3 samples counted, subject filtered; FASTQ text in tmpfs -> .Jhash, .histo, HashList, Mutations.Mate*.fastq)"
+        # ---- overlap chain on the pulled pairs: a position-sorted SAM from the generator's own coordinates ----
+        from tests.synth import _PHI, _U, _mix64, _scale32
+        sy = capi.Synth.sample(G, 0, n_snv=n_snv, seed=SEED)
+        comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+        m1 = open(os.path.join(d, "child.Mutations.Mate1.fastq"), "rb").read().split(b"\n")
+        m2 = open(os.path.join(d, "child.Mutations.Mate2.fastq"), "rb").read().split(b"\n")
+        rows = []
+        for i in range(0, len(m1) - 1, 4):
+            pair = int(m1[i][2:].split(b"/")[0])
+            with np.errstate(over="ignore"):
+                key = _mix64(_U(sy.read_seed) ^ (_U(pair) * _PHI + _U(1)))
+                k1 = _mix64(key + _U(1))
+                start = int(_scale32(key, G - (sy.insert_lo + sy.insert_span)))
+                end = start + sy.insert_lo + int(_scale32(k1, sy.insert_span))
+            name = m1[i][1:].split(b"/")[0]
+            rows.append((start, name, b"99", m1[i + 1], m1[i + 3]))
+            rows.append((end - READ_LEN, name, b"147", m2[i + 1].translate(comp)[::-1], m2[i + 3][::-1]))
+        rows.sort(key=lambda r: r[0])
+        with open(os.path.join(d, "pulled.sam"), "wb") as f:
+            for pos, name, flag, s_, q_ in rows:
+                f.write(b"\t".join([name, flag, b"chr1", str(pos + 1).encode(), b"60", b"150M", b"=", b"1", b"0", s_, q_,
+                                    b"NM:i:0"]) + b"\n")
+        t0 = time.perf_counter()
+        ov = {}
+        out["stages_s"], keep = ov, out["stages_s"]
+        run("OverlapSam", [f"{B}/OverlapSam", "pulled.sam", ".95", "20", "1", "ov.sam", "N", "1", "child.HashList", T])
+        run("Overlap", [f"{B}/Overlap", "ov.sam.fastqd", ".98", "100", "1", "FP", "20", "1", "ov.1", "0", "1"])
+        run("Overlap", [f"{B}/Overlap", "ov.1.fastqd", ".98", "75", "2", "FP", "20", "1", "ov.2", "1", "1"])
+        run("Overlap", [f"{B}/Overlap", "ov.2.fastqd", ".98", "50", "2", "N", "20", "1", "ov.3", "1", "1"])
+        run("OverlapRegion", [f"{B}/OverlapRegion", "ov.3.fastqd", ".98", "50", "5", "ov.4", "N", "1", "1"])
+        run("tail", [f"{B}/ReplaceQwithDinFASTQD", "ov.4.fastqd"], stdout="ov.overlap.fastqd")
+        run("tail", [f"{B}/ConvertFASTqD.to.FASTQ", "ov.overlap.fastqd"], stdout="ov.overlap.fastq")
+        run("tail", [f"{B}/AnnotateOverlap", "child.HashList", "ov.overlap.fastq", "ov.hash.fastq"], stdout="ov.hashcount.fastq")
+        out["stages_s"] = keep
+        out["overlap_wall_s"] = round(time.perf_counter() - t0, 2)
+        out["overlap"] = {"sam_records": len(rows), "stages_s": ov,
+                          "contigs": open(os.path.join(d, "ov.hashcount.fastq"), "rb").read().count(b"\n") // 4}
+    finally:
+        subprocess.run(["rm", "-rf", d])
+    return out
+
+
 def run_s1(args, ctx, rank, world, dist, torch):
     """BASELINE.json configs[1]: 1 M x 150 bp reads per sample (per GPU), the round-1 workload."""
     from rufus_amd import capi
@@ -192,9 +297,14 @@ def main():
     ap.add_argument("--passes", type=int, default=0, help="wgs: minimizer-shard passes (0 = plan from free HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
+    ap.add_argument("--end-to-end-only", action="store_true", help="(internal) print the end_to_end object and exit")
+    ap.add_argument("--no-end-to-end", action="store_true")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()))
+        return
+    if args.end_to_end_only:
+        print(json.dumps(end_to_end()))
         return
 
     import torch
@@ -304,11 +414,21 @@ def main():
                 err = locals().get("p")
                 line["cpu_baseline"] = {"value": None, "unit": "reads/s", "cores": 1, "kind": "port",
                                         "sample": f"failed: {e!r} " + (err.stderr.decode()[-300:] if err is not None else "")}
-        print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    ctx.close()      # gives the HBM back: the end-to-end leg starts its own processes on this GPU
+    if rank == 0:
+        if world == 1 and not args.no_end_to_end and not args.no_cpu_baseline:
+            try:
+                p = subprocess.run([sys.executable, os.path.abspath(__file__), "--end-to-end-only"], stdout=subprocess.PIPE,
+                                   stderr=subprocess.PIPE, timeout=600)
+                line["end_to_end"] = json.loads(p.stdout.decode().strip().splitlines()[-1])
+                line["overlap_wall_s"] = line["end_to_end"].get("overlap_wall_s")
+            except Exception as e:
+                err = locals().get("p")
+                line["end_to_end"] = {"value": None, "error": f"{e!r} " + (err.stderr.decode()[-300:] if err is not None else "")}
+        print(json.dumps(line))
 
 
 if __name__ == "__main__":

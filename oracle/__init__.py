@@ -282,6 +282,15 @@ def histo(counts: np.ndarray, low: int = 1, high: int = 10000, inc: int = 1, ful
 # ------------------------------------------------------------------------------------------------
 # set difference
 # ------------------------------------------------------------------------------------------------
+def stats_text(counts: np.ndarray, low: int = 0, high: int = 2**64 - 1) -> str:
+    """``jellyfish stats`` (jf/sub_commands/stats_main.cc:33-46,:73-77): Unique / Distinct / Total / Max_count of the
+    records with low <= count <= high."""
+    c = np.asarray(counts, dtype=np.uint64)
+    c = c[(c >= np.uint64(low)) & (c <= np.uint64(high))]
+    return (f"Unique:    {int((c == 1).sum())}\nDistinct:  {len(c)}\nTotal:     {int(c.sum())}\n"
+            f"Max_count: {int(c.max()) if len(c) else 0}\n")
+
+
 def merge_unique(files, min_count: int = 5, with_file: bool = False):
     """RUFUS's modified ``jellyfish merge`` (jf/jellyfish/merge_files.cc:69-155): k-way merge in
     (pos, key) order; a key present in exactly one input with count >= 5 is printed ``KMER\\tCOUNT``.

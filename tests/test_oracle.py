@@ -40,8 +40,11 @@ def test_jellyfish_md5_kats():
     rec = oracle.count(None, 15, 2 << 20, reads=[seq10m])
     txt = oracle.histo(rec.counts)[1]
     assert hashlib.md5(txt.encode()).hexdigest() == "864c0b0826854bdc72a85d170549b64b"
+    # `jellyfish stats` of the same database (tests/parallel_hashing.sh: ${pref}_m15.stats)
+    assert hashlib.md5(oracle.stats_text(rec.counts).encode()).hexdigest() == "41fd8408dde0ea14bec7425b1a877140"
     rec = oracle.count(None, 15, 2 << 20, lower=2, upper=3, reads=[seq10m])
     txt = oracle.histo(rec.counts)[1]
+    # (the same md5 pins both the plain -L2 -U3 run and the --disk automerge run of parallel_hashing.sh)
     assert hashlib.md5(txt.encode()).hexdigest() == "94625cd2d59e278f08421a673eb0926a"
     seq1m = mt_sequence(1040104553, [1_000_000] * 5)
     rec = oracle.count(None, 15, 2 << 20, reads=seq1m[:3] + [seq10m] + seq1m[3:])

@@ -248,6 +248,23 @@ hipError_t queue_read(rfx_ctx* c, void* dst, const void* d_src, size_t n) {
   return hipMemcpyAsync(dst, d_src, n, hipMemcpyDeviceToHost, c->stream);
 }
 
+// queue_read() destinations are often locals of the calling function.  Every success path ends with a ctx_sync()
+// that delivers and clears them; an error return in between would leave entries pointing into a dead stack frame,
+// to be written by whichever ctx_sync() comes next.  A guard at the top of such a function drops, on the way out,
+// whatever the function queued and did not deliver.  (Not for rfx_count_finish_begin: its read-backs go to heap
+// and caller memory that outlives the call by design.)
+struct pin_guard {
+  rfx_ctx* c;
+  size_t mark;
+  explicit pin_guard(rfx_ctx* ctx) : c(ctx), mark(ctx->pin_reads.size()) {}
+  ~pin_guard() {
+    if (c->pin_reads.size() > mark) {
+      (void)hipStreamSynchronize(c->stream);  // the copies into the pinned scratch may still be in flight
+      c->pin_reads.resize(mark);
+    }
+  }
+};
+
 // Host -> device copy of a buffer the caller may free right away (staged in the pinned scratch when it fits).
 hipError_t upload(rfx_ctx* c, void* d_dst, const void* src, size_t n) {
   if (n == 0) return hipSuccess;
@@ -322,6 +339,7 @@ int read_stats(rfx_table* t, rfx_table_stats* out) {
 // Rehash into a table of new_cap slots.
 int table_grow(rfx_table* t, uint64_t new_cap) {
   rfx_ctx* c = t->ctx;
+  pin_guard guard(c);
   rfx_table_stats st;
   int rc = read_stats(t, &st);
   if (rc) return rc;
@@ -332,9 +350,15 @@ int table_grow(rfx_table* t, uint64_t new_cap) {
     dfree(c, pk); dfree(c, pc); dfree(c, d_n);
     return RFX_E_FULL;
   }
-  HIPCHK(hipMemsetAsync(d_n, 0, 8, c->stream));
-  rfxk::table_pairs(c, view_of(t), pk, pc, d_n);
-  HIPCHK(ctx_sync(c));
+  hipError_t e = hipMemsetAsync(d_n, 0, 8, c->stream);
+  if (e == hipSuccess) {
+    rfxk::table_pairs(c, view_of(t), pk, pc, d_n);
+    e = ctx_sync(c);
+  }
+  if (e != hipSuccess) {
+    dfree(c, pk); dfree(c, pc); dfree(c, d_n);
+    return hip_fail(e, "table_grow");
+  }
   dfree(c, t->keys);
   dfree(c, t->counts);
   t->keys = nullptr;
@@ -346,13 +370,15 @@ int table_grow(rfx_table* t, uint64_t new_cap) {
   }
   t->cap = new_cap;
   t->tbits = ceil_log2(new_cap);
-  HIPCHK(hipMemsetAsync(t->d_stats, 0, sizeof(rfx_table_stats), c->stream));
-  // the pairs already passed the pos range; widen it for the re-insert
-  rfx_table_view v = view_of(t);
-  rfxk::count_pairs(c, pk, pc, st.distinct, v, t->lut, t->d_stats);
-  HIPCHK(ctx_sync(c));
+  e = hipMemsetAsync(t->d_stats, 0, sizeof(rfx_table_stats), c->stream);
+  if (e == hipSuccess) {
+    // the pairs already passed the pos range; widen it for the re-insert
+    rfx_table_view v = view_of(t);
+    rfxk::count_pairs(c, pk, pc, st.distinct, v, t->lut, t->d_stats);
+    e = ctx_sync(c);
+  }
   dfree(c, pk); dfree(c, pc); dfree(c, d_n);
-  return RFX_OK;
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "table_grow");
 }
 
 // Sortable-word transform of the P2L path.  M (r x c, r = lsize, c = 2k) has kernel dimension c - r;
@@ -501,6 +527,7 @@ struct HostRun {
 // flags = count in [lo,hi] and key absent from every other file; compacted (order kept) to the host.
 int unique_run(rfx_ctx* c, const rfx_records* f, const rfx_records* const* all, int n_all, uint32_t lo, uint32_t hi,
                HostRun& out) {
+  pin_guard guard(c);
   out.keys.clear(); out.pos.clear(); out.counts.clear();
   if (f->n == 0) return RFX_OK;
   const uint64_t nblk = (f->n + 2047) / 2048;
@@ -1052,6 +1079,7 @@ static void msp_forget_pending(rfx_table* t) {
 // Exact two-pass sizing (32-bit histogram, then scatter into coarse bins as large as the fullest one).
 static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* seg) {
   rfx_ctx* c = t->ctx;
+  pin_guard guard(c);
   msp_geom g;
   msp_geometry(t, r, g);
   const uint32_t P = g.P, P1 = g.P1, P2 = g.P2;
@@ -1914,6 +1942,7 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   if (!t || !r || t->ctx != r->ctx) return RFX_E_INVAL;
   if (!r->acgt) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
+  pin_guard guard(c);
   (void)hipSetDevice(c->device);
   if (r->n == 0) return RFX_OK;
   if (t->passes >= 0) {  // rfx_count_set_passes: counted at finish, shard pass by shard pass
@@ -2053,6 +2082,7 @@ int rfx_count_segment_get(rfx_table* t, int i, const uint64_t** d_records, const
                           uint64_t* n_records) {
   if (!t || t->seg_kind != RFX_COUNT_MSP || i < 0 || i >= (int)t->segs->size()) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
+  pin_guard guard(c);
   (void)hipSetDevice(c->device);
   // One synchronisation for both: the capacity flags of the pending adds and the exact record count of
   // the segment (segments are sized optimistically; the count lives on the device).
@@ -2448,6 +2478,7 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
   s->n = n;
   s->bits = std::max(6, ceil_log2(n * 2 + 1));
   if (s->bits > 31) {
+    snprintf(g_err, sizeof g_err, "rfx_set_build: %llu keys are more than a mutant set holds (2^30)", (unsigned long long)n);
     delete s;
     return nullptr;
   }
@@ -2508,6 +2539,7 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
                uint64_t* hitmask_out, uint64_t* n_hit_reads) {
   if (!s || !r || s->ctx != r->ctx || !r->good) return RFX_E_INVAL;
   rfx_ctx* c = s->ctx;
+  pin_guard guard(c);
   (void)hipSetDevice(c->device);
   if (n_hit_reads) *n_hit_reads = 0;
   if (r->n == 0) return RFX_OK;

@@ -365,7 +365,17 @@ long rfx_hashlist_keys(const char* text, size_t n, int k, int single_end, uint64
       if (!t.empty()) { kmer = t[0]; have = true; }
     }
     if (!have) continue;
-    const uint64_t fw = rufus_key(kmer, k), rv = rufus_key(rufus_revcomp(kmer), k);
+    // A list entry LONGER than k: Util::HashToLong (src/Util.cpp:51-84) packs up to 32 bases, so its value has bits
+    // above 2k and equals no k-base window -- unless every extra base encodes 00 ('A' or an invalid character).
+    // Such entries still count (the reference's map holds them) but get a key no window can have.
+    auto key_of = [&](const std::string& s_) -> uint64_t {
+      uint64_t key = rufus_key(s_, k);
+      if (k < 32)
+        for (size_t i = (size_t)k; i < s_.size() && i < 32; ++i)
+          if (s_[i] == 'C' || s_[i] == 'G' || s_[i] == 'T') return key | (1ull << 63);
+      return key;
+    };
+    const uint64_t fw = key_of(kmer), rv = key_of(rufus_revcomp(kmer));
     if (keys_out) {
       if ((size_t)count + 2 > cap) return RFX_E_RANGE;
       keys_out[count] = fw;

@@ -176,3 +176,23 @@ def test_count_cli_parallel_ingest_and_shard_passes(tmp_path):
         wrapped += [h] + [s[j:j + 60] for j in range(0, len(s), 60)] + [p] + [q[j:j + 60] for j in range(0, len(q), 60)]
     open(f"{d}/wrapped.fq", "wb").write(b"\n".join(wrapped) + b"\n")
     assert run("wrapped.jf", "wrapped.fq") == ref
+
+
+def test_count_cli_reproduces_jellyfish_own_md5_kats(tmp_path):
+    """jellyfish's own functional known-answer tests (tests/parallel_hashing.sh in jellyfish-2.2.5.tar.gz) against the
+    DROP-IN executable: `count -m 15 -C -s 2M` (+ `-L2 -U3 --disk`) on the seeded 10 Mb sequence, md5 of `histo`."""
+    from tests.test_oracle import mt_sequence
+    d = str(tmp_path)
+    seq10m, = mt_sequence(3141592653, [10_000_000])
+    with open(f"{d}/seq10m.fa", "wb") as f:
+        f.write(b">read0\n")
+        for i in range(0, len(seq10m), 70):
+            f.write(seq10m[i:i + 70] + b"\n")
+    for extra, md5 in (([], "864c0b0826854bdc72a85d170549b64b"),
+                       (["-L2", "-U3", "--disk"], "94625cd2d59e278f08421a673eb0926a")):
+        r = sh([f"{BIN}/jellyfish", "count", "-t", "4", "-o", "m15.jf", "-s", "2M", "-C", "-m", "15"] + extra + ["seq10m.fa"], d,
+               timeout=600)
+        assert r.returncode == 0, r.stderr
+        r = sh([f"{BIN}/jellyfish", "histo", "m15.jf"], d)
+        assert r.returncode == 0, r.stderr
+        assert hashlib.md5(r.stdout).hexdigest() == md5

@@ -983,3 +983,22 @@ def test_two_ranks_exchange_on_the_hip_backend(shard_by):
         assert got[r][4] == want.tolist()
         tot += int(want.sum())
     assert got[0][5] == got[1][5] == tot and tot > 0
+
+
+def test_filter_hash_list_entries_longer_than_k(ctx):
+    """Util::HashToLong packs up to 32 bases: a list entry longer than K has bits above 2K and matches no window --
+    unless its extra bases encode 00 ('A').  The loader keeps that quirk."""
+    k = 25
+    core = b"ACGTTGCAAGGCTTAACCGGATATC"
+    reads = [b"GG" + core + b"TTGA", b"GG" + core + b"ATGA", b"CCCC" + core[::-1] + b"AAAA"]
+    quals = [b"I" * len(r) for r in reads]
+    for extra in (b"C", b"A", b"AA", b"AC", b""):
+        text = (core + extra).decode() + " 7\n"
+        fs = oracle.FilterSet(text.encode())
+        mset = capi.MutantSet(ctx, capi.hashlist_keys(text.encode(), k), k)
+        blk = ctx.upload(capi.PackedReads.from_reads(reads, quals, 15, capi.PACK_FILTER))
+        hits, _, _ = mset.filter(blk, 1, True)
+        want = [fs.scan(a, b, k, 15) for a, b in zip(reads, quals)]
+        assert hits.tolist() == want, (extra, hits.tolist(), want)
+        blk.free()
+        mset.free()

@@ -64,8 +64,9 @@ def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, 
         records = (4.1 if wide else 2.7) * windows / share * (3.0 if world > 1 else 1.0)   # wide: 12 B per record
         # leaf phase of the last sample of a pass: records + scratch, survivor store, the other samples' records
         transient = records * 1.125 + 12.0 * distinct / share * 1.3 + (n_samples - 1) * 20.0 * distinct / share
-        # (measured on the 30x WGS trio, 1 GPU: 219 GB at 5 passes, ~243 GB at 4 of 288 GiB)
-        if resident_bytes + transient < 0.85 * hbm_bytes:
+        # (measured on the 30x WGS trio, 1 GPU, of 288 GiB: 219 GB at 5 passes, 238 at 4, 271 at 3 -- which this
+        # picks; WgsTrio.run() takes one more pass and starts over should a pass not fit after all)
+        if resident_bytes + transient < 0.90 * hbm_bytes:
             return s
     return max(1, 256 // world)
 
@@ -210,9 +211,6 @@ class WgsTrio:
 
     def run(self, samples, keep_shard_records: bool = False):
         """samples: [subject blocks, control blocks, ...] (lists of capi.ReadBlock)."""
-        histos = [np.zeros(capi.HISTO_BINS, dtype=np.uint64) for _ in samples]
-        n_rec = [0] * len(samples)
-        keys, kept = [], []
         trace = os.environ.get("RFX_WGS_TRACE")
         t_last = time.perf_counter()
 
@@ -224,22 +222,39 @@ class WgsTrio:
                 print(f"[wgs] {what}: {(now - t_last) * 1e3:.1f} ms", flush=True)
                 t_last = now
 
-        for sh in range(self.passes):
-            recs = []
-            for si, blocks in enumerate(samples):
-                rec, h = self.count_shard(blocks, sh)
-                recs.append(rec)
-                histos[si] += h
-                n_rec[si] += len(rec)
-                lap(f"pass {sh} sample {si} count ({len(rec)} records)")
-            k_, _ = capi.unique_to_subject(self.ctx, recs[0], recs[1:], self.min_cov, self.max_cov)
-            lap(f"pass {sh} set difference ({len(k_)} k-mers)")
-            keys.append(k_)
-            if keep_shard_records:
-                kept.append(recs)
-            else:
-                for r in recs:
+        while True:
+            histos = [np.zeros(capi.HISTO_BINS, dtype=np.uint64) for _ in samples]
+            n_rec = [0] * len(samples)
+            keys, kept, recs = [], [], []
+            try:
+                for sh in range(self.passes):
+                    recs = []
+                    for si, blocks in enumerate(samples):
+                        rec, h = self.count_shard(blocks, sh)
+                        recs.append(rec)
+                        histos[si] += h
+                        n_rec[si] += len(rec)
+                        lap(f"pass {sh} sample {si} count ({len(rec)} records)")
+                    k_, _ = capi.unique_to_subject(self.ctx, recs[0], recs[1:], self.min_cov, self.max_cov)
+                    lap(f"pass {sh} set difference ({len(k_)} k-mers)")
+                    keys.append(k_)
+                    if keep_shard_records:
+                        kept.append(recs)
+                    else:
+                        for r in recs:
+                            r.free()
+                    recs = []
+                break
+            except capi.RufusError as e:
+                # the pass plan is an estimate: if a pass does not fit after all, take one more pass and start over
+                # (single rank only: the ranks of a group must agree on the passes)
+                if self.world > 1 or self.passes >= 64 or "memory" not in str(e).lower():
+                    raise
+                for r in recs + [r_ for shard in kept for r_ in shard]:
                     r.free()
+                self.passes += 1
+                if trace:
+                    print(f"[wgs] out of device memory: retrying with {self.passes} passes", flush=True)
         keys = np.concatenate(keys) if keys else np.zeros(0, np.uint64)
         if self.world > 1:     # every rank needs the whole hash list; histograms and record counts add up
             import torch

@@ -316,3 +316,18 @@ def test_tumor_normal_k31_in_passes_matches_oracle(ctx, monkeypatch, k, passes, 
     for s_ in samples:
         for b in s_:
             b.free()
+
+
+def test_trio_takes_more_passes_when_a_pass_does_not_fit(monkeypatch):
+    """The pass plan is an estimate: a context with a tiny HBM budget makes the first plan fail with
+    out-of-memory inside a pass; the driver frees what it holds, adds a pass and starts over -- same hash list."""
+    n_pairs, G = 25_000, 250_000
+    sys_ = [capi.Synth.sample(G, w, n_snv=12, seed=777) for w in range(3)]
+    _, hl_o, pulled_o = _oracle_trio(sys_, n_pairs)
+    with capi.Context(0, hbm_budget=48 << 20) as small:
+        samples = [wgs.make_sample(small, sy, n_pairs, 9000, MIN_Q, want_good=(i == 0)) for i, sy in enumerate(sys_)]
+        trio = wgs.WgsTrio(small, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=1)
+        res = trio.run(samples)
+        assert trio.passes > 1, small.mem_stats()
+        assert tools.keys_to_text(res["mutant_keys"], K) == [ln.split()[0] for ln in hl_o.splitlines()]
+        assert res["n_pulled"] == len(pulled_o)

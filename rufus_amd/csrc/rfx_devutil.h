@@ -37,7 +37,7 @@ constexpr int MSP_WL_WIDE = 16;
 __host__ __device__ __forceinline__ int msp_wl(int k) { return k <= 25 ? MSP_WL : MSP_WL_WIDE; }
 __host__ __device__ __forceinline__ int msp_m(int k) { return k - (msp_wl(k) - 1); }
 constexpr int MSP_NMAX = 4;   // k-mers per record: k + 3 <= 28 bases = 56 bits (k <= 25; beyond that see msp_record_binhash)
-constexpr uint64_t MSP_EMPTY = 1ull << 55;  // no record looks like this: a 1-k-mer record uses 2k <= 50 bits
+constexpr uint64_t MSP_EMPTY = ~0ull;  // no record looks like this: the minimizer offset (bits 63:59) stays below 18
 
 // One multiply each: 32-bit integer multiplies are quarter rate, and k_msp_part1 hashes every base.
 // The xor keeps the all-A m-mer (c = 0) from hashing to 0 = always the minimum.

@@ -296,6 +296,28 @@ def test_msp_rejects_k_outside_its_record_format(ctx):
     t.free()
 
 
+@pytest.mark.parametrize("k,canonical", [(25, True), (28, True), (28, False), (29, False), (31, True)])
+def test_msp_low_complexity_records(ctx, k, canonical):
+    """Homopolymer stretches after one other base ("G" + "A" * 27 ...) give record words with a single high bit
+    set -- the bit patterns an in-band "empty" marker could collide with; random flanks move the minimizer around."""
+    rng = np.random.default_rng(k * 2 + canonical)
+    reads = []
+    for lead in b"CGT":
+        for run in range(k - 4, 36):
+            for _ in range(12):
+                fl = lambda n: bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), n))
+                reads.append(fl(int(rng.integers(0, 12))) + bytes([lead]) + b"A" * run + fl(int(rng.integers(0, 12))))
+    reads = [r for r in reads if len(r) >= k]
+    ref = oracle.count(None, k, 1 << 24, lower=1, reads=reads, canonical=canonical)
+    blk = ctx.upload(capi.PackedReads.from_reads(reads))
+    t = capi.CountTable(ctx, k, 1 << 24, canonical=canonical, mode=capi.COUNT_MSP)
+    t.add(blk)
+    rec = t.finish(1)
+    assert rec.payload() == ref.payload()
+    for x in (rec, t, blk):
+        x.free()
+
+
 @pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("bins", ["256", "2048", "8192"])
 def test_msp_bins_ragged_reads_and_pos_range(ctx, bins, exact, monkeypatch):

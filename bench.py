@@ -57,7 +57,8 @@ def cpu_baseline():
     of the synthetic trio, regenerated as text by the generator's host twin): the oracle's C++ port for
     count (lock-free CAS hash table, mirrors jf/include/jellyfish/large_hash_array.hpp:708-744) and set
     difference, the REAL reference binary oracle/_ref/RUFUS.Filter (built from /root/reference/src in the
-    build container) for the filter; at T = 1, 8 and nproc-2 threads (runRufus.sh:796,:967 use T-2).
+    build container) for the filter; at T = 1, 8, the CPUs the cgroup lets the process use (rfx_host_cpus: the GPU
+    box gives its container 16 CPUs' worth of time on 256 hardware threads) and nproc-2 (runRufus.sh:796,:967).
     The filter leg runs on the first 60 k pairs of the subject and is scaled to the leg's read count: the
     reference forks its OpenMP team once per 60 pairs (src/RUFUS.Filter.cpp:196), which at 254 threads takes
     minutes per million pairs -- measured on the 256-core box, it is why the first version of this leg timed out."""
@@ -65,10 +66,11 @@ def cpu_baseline():
     from rufus_amd import capi
     from tests.synth import synth_fastq
     ncpu = os.cpu_count() or 1
-    out = {"unit": "reads/s", "kind": "port", "by_threads": {}}
+    usable = int(capi.lib().rfx_host_cpus())         # affinity and cgroup CPU quota: 16 on the 256-thread GPU box
+    out = {"unit": "reads/s", "kind": "port", "by_threads": {}, "usable_cpus": usable}
     exe = os.path.join(ROOT, "oracle", "_ref", "RUFUS.Filter")
     n_filter = 60_000
-    for T in sorted({1, min(8, ncpu), max(1, ncpu - 2)}):
+    for T in sorted({1, min(8, ncpu), usable, max(1, ncpu - 2)}):
         n_pairs = int(min(1_000_000, 40_000 * T ** 0.8))     # ~ equal wall time per leg
         G = n_pairs * 10
         sys_ = [capi.Synth.sample(G, w, n_snv=max(4, G // 1_000_000), seed=SEED) for w in range(3)]
@@ -128,7 +130,7 @@ def end_to_end(n_pairs=12_000_000):
     from rufus_amd import capi
     B = os.path.join(ROOT, "rufus_amd", "bin")
     ncpu = os.cpu_count() or 1
-    T = str(max(1, min(64, ncpu - 2)))
+    T = str(max(1, min(64, ncpu - 2)))                # (the tools cap it to rfx_host_cpus())
     G = n_pairs * 10
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     d = tempfile.mkdtemp(prefix="rfx_e2e_", dir=base)

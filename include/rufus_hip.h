@@ -105,6 +105,10 @@ int rfx_sync(rfx_ctx*);
 /* Page-locked host memory for staging buffers of the ingest pipelines (uploads from it run at PCIe speed). */
 void* rfx_host_alloc(size_t bytes);
 void rfx_host_free(void*);
+/* Host threads this process can keep busy: hardware threads, cut to its CPU affinity and to the CPU-bandwidth quota
+ * of its cgroup (a container given 16 CPUs' worth of time on a 256-thread host runs 64 parser threads three times
+ * SLOWER than 16: measured).  The -t / Threads arguments of the drop-in tools are capped by this. */
+unsigned rfx_host_cpus(void);
 void* rfx_stream(rfx_ctx*); /* the hipStream_t every kernel of this ctx is launched on */
 /* Device memory of the ctx: bytes in use now, the high-water mark of that, and bytes of HBM mapped into the ctx's
  * arena (the library sub-allocates one growable virtual range; mapped memory is kept until rfx_close). */

@@ -3,9 +3,11 @@
 // hashes or compares k-mers.
 #pragma once
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <unistd.h>
 
 #include <cerrno>
+#include <csignal>
 
 #include <cstdint>
 #include <cstdio>
@@ -14,7 +16,10 @@
 #include <stdexcept>
 #include <thread>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../../include/rufus_hip.h"
@@ -314,15 +319,59 @@ inline rfx_records* load_records(rfx_ctx* c, const char* path, JhashHeader& h) {
   return r;
 }
 
+// RFX_CLI_TRACE=1: wall-clock marks of a tool's phases on stderr (scratch/cli_scale.sh reads them)
+inline void trace(const char* what) {
+  static const bool on = getenv("RFX_CLI_TRACE") != nullptr;
+  static const auto t0 = std::chrono::steady_clock::now();
+  if (on) fprintf(stderr, "[rfx %8.3f s] %s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what);
+}
+
+// The pages of a big output file cost as much as the copy into them (tmpfs: 5 GB/s on one thread, and neither
+// parallel pwrite()s nor parallel faults on a mapping get past that -- inode and page-cache locks).  A tool that knows
+// roughly how much it will write starts a background thread that fallocate()s the file beyond its (zero) size while
+// the tool is still busy with its input; write_jhash() then sizes the file exactly (which frees any excess) and
+// only copies.  Everything here is best effort: an unsupported or failed fallocate just leaves pages for later.
+class OutputPrealloc {
+  int fd_ = -1;
+  std::thread th_;
+  std::atomic<bool> stop_{false};
+
+ public:
+  void start(const char* path, uint64_t bytes) {
+    fd_ = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd_ < 0 || bytes == 0) return;
+    th_ = std::thread([this, bytes] {
+      const uint64_t step = 256ull << 20;
+      for (uint64_t at = 0; at < bytes && !stop_.load(std::memory_order_relaxed); at += step)
+        if (::fallocate(fd_, FALLOC_FL_KEEP_SIZE, (off_t)at, (off_t)std::min(step, bytes - at)) != 0) break;
+    });
+  }
+  // stops the thread; the descriptor (or -1: the writer opens the file itself and reports the error) goes to the caller
+  int take() {
+    stop_ = true;
+    if (th_.joinable()) th_.join();
+    const int fd = fd_;
+    fd_ = -1;
+    return fd;
+  }
+  ~OutputPrealloc() {
+    const int fd = take();
+    if (fd >= 0) ::close(fd);
+  }
+};
+
+// `lend`: page-locked buffers the caller no longer needs (the ingest's staging blocks), used as the drain ring
+// instead of pinning more memory.
 inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols, bool canonical, int counter_len,
-                        int argc, char** argv) {
+                        int argc, char** argv, const std::vector<std::pair<char*, size_t>>& lend = {}, int open_fd = -1) {
   const int k = rfx_records_k(rec), lsize = rfx_records_lsize(rec);
   std::vector<char> hdr(1 << 16);
   const long hl = rfx_jhash_header(k, lsize, cols, canonical, counter_len, argc, argv, hdr.data(), hdr.size());
   if (hl < 0) die("rufus_amd: header too large");
   const uint64_t n = rfx_records_size(rec);
   const size_t rl = (size_t)(2 * k + 7) / 8 + (size_t)counter_len;
-  const int fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  int fd = open_fd >= 0 ? open_fd : ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);  // open_fd: OutputPrealloc's
+  if (fd < 0) fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);  // a write-only special file
   if (fd < 0) die(std::string("Can't open output file '") + path + "'");
   auto put = [&](const char* p, size_t len, off_t at) {
     while (len) {
@@ -334,37 +383,83 @@ inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols
       at += w;
     }
   };
-  put(hdr.data(), (size_t)hl, 0);
-  // The payload of a 30x sample is ~35 GB: formatted on the device and fetched 8 M records at a time into a ring
-  // of page-locked buffers; writer threads put finished buffers into the file at their offsets (one thread copying
-  // into the page cache would be the bottleneck of the whole tool).
-  const uint64_t step = 8ull << 20;
-  const int NBUF = 6;
+  // The payload of a 30x sample is ~35 GB: formatted on the device and fetched a few M records at a time into a
+  // ring of page-locked buffers; writer threads copy finished buffers into the file.  Through a shared mapping of
+  // the (pre-sized) file when it can be had: buffered write()s to ONE file serialise on its inode lock -- six
+  // pwrite threads gave 3.8 GB/s into tmpfs, one thread's worth -- page faults of a mapping do not.
+  const uint64_t total = (uint64_t)hl + n * rl;
+  char* map = nullptr;
+  if (n && ::ftruncate(fd, (off_t)total) == 0) {
+    void* m = mmap(nullptr, (size_t)total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (m != MAP_FAILED) map = (char*)m;
+  }
+  struct sigaction old_bus;
+  if (map) {  // a full file system shows up as SIGBUS on the mapping, not as a failed write(): report it the same way
+    static char bus_msg[512];
+    snprintf(bus_msg, sizeof bus_msg, "write error on '%s': no space left on device (or the file was truncated)\n", path);
+    struct sigaction sa;
+    memset(&sa, 0, sizeof sa);
+    sa.sa_handler = [](int) {
+      (void)!::write(2, bus_msg, strlen(bus_msg));
+      _exit(1);
+    };
+    sigaction(SIGBUS, &sa, &old_bus);
+    memcpy(map, hdr.data(), (size_t)hl);
+  } else {
+    put(hdr.data(), (size_t)hl, 0);
+  }
+  trace("write: header out");
+  const uint64_t step = 4ull << 20;
+  const int NBUF = 8;
   char* buf[NBUF];
-  bool pinned[NBUF];
+  int kind[NBUF];  // 0 malloc, 1 pinned here, 2 lent
+  size_t lent = 0;
   for (int i = 0; i < NBUF; ++i) {
-    buf[i] = (char*)rfx_host_alloc(step * rl);
-    pinned[i] = buf[i] != nullptr;
-    if (!buf[i]) buf[i] = (char*)malloc(step * rl);
+    buf[i] = nullptr;
+    while (lent < lend.size() && !buf[i]) {
+      if (lend[lent].second >= step * rl) buf[i] = lend[lent].first, kind[i] = 2;
+      ++lent;
+    }
+    if (!buf[i] && n > (uint64_t)i * step) buf[i] = (char*)rfx_host_alloc(step * rl), kind[i] = 1;  // (only what a small payload needs)
+    if (!buf[i]) buf[i] = (char*)malloc(step * rl), kind[i] = 0;
     if (!buf[i]) die("rufus_amd: out of host memory");
   }
+  trace("write: buffers ready");
   std::thread writers[NBUF];
+  double t_wait = 0, t_fetch = 0;  // main thread: waiting for a free buffer / formatting + device-to-host copy
   for (uint64_t at = 0, i = 0; at < n; at += step, ++i) {
     const uint64_t m = std::min<uint64_t>(step, n - at);
     const int bi = (int)(i % NBUF);
+    const auto ta = std::chrono::steady_clock::now();
     if (writers[bi].joinable()) writers[bi].join();
+    const auto tb = std::chrono::steady_clock::now();
     if (rfx_records_payload_range(rec, at, m, buf[bi], (size_t)m * rl, counter_len) != RFX_OK)
       die(std::string("rufus_amd: drain failed: ") + rfx_last_error());
+    t_wait += std::chrono::duration<double>(tb - ta).count();
+    t_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count();
     const char* src = buf[bi];
     const size_t len = (size_t)m * rl;
     const off_t off = (off_t)hl + (off_t)(at * rl);
-    writers[bi] = std::thread([=] { put(src, len, off); });
+    if (map) writers[bi] = std::thread([=] { memcpy(map + off, src, len); });
+    else writers[bi] = std::thread([=] { put(src, len, off); });
   }
   for (auto& w : writers)
     if (w.joinable()) w.join();
+  {
+    char msg[128];
+    snprintf(msg, sizeof msg, "write: payload out (%s; waited %.3f s for buffers, %.3f s fetching)", map ? "mapped" : "pwrite",
+             t_wait, t_fetch);
+    trace(msg);
+  }
   for (int i = 0; i < NBUF; ++i) {
-    if (pinned[i]) rfx_host_free(buf[i]);
-    else free(buf[i]);
+    if (kind[i] == 1) rfx_host_free(buf[i]);
+    else if (kind[i] == 0) free(buf[i]);
+  }
+  if (map) {
+    if (munmap(map, (size_t)total) != 0) die(std::string("write error on '") + path + "'");
+    sigaction(SIGBUS, &old_bus, nullptr);
+  } else if (open_fd >= 0) {
+    (void)!::ftruncate(fd, (off_t)total);  // drop what was preallocated past the end
   }
   if (::close(fd) != 0) die(std::string("write error on '") + path + "'");
 }

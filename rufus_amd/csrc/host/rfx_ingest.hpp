@@ -20,6 +20,9 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -64,6 +67,7 @@ class CountIngest {
   std::atomic<bool> failed_{false};
   std::string fail_msg_;
   std::vector<std::thread> workers_;
+  std::thread pinner_;
   uint64_t reads_total_ = 0;
 
   size_t PIECE = 32u << 20;  // bytes of text per piece (tests shrink it)
@@ -126,6 +130,19 @@ class CountIngest {
     }
   }
 
+  // memchr(p, '\n', e - p) for the short lines of a FASTQ record: 16 bytes per step, no call
+  static inline const char* find_nl(const char* p, const char* e) {
+#if defined(__SSE2__)
+    const __m128i nl = _mm_set1_epi8('\n');
+    while (e - p >= 16) {
+      const int m = _mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)p), nl));
+      if (m) return p + __builtin_ctz((unsigned)m);
+      p += 16;
+    }
+#endif
+    return p < e ? (const char*)memchr(p, '\n', (size_t)(e - p)) : nullptr;
+  }
+
   void parse_piece(const Piece& pc) {
     std::vector<uint64_t> start;
     std::vector<uint32_t> slen;
@@ -136,18 +153,19 @@ class CountIngest {
     while (p < e) {
       if (*p == '\n') { ++p; continue; }  // blank lines between records are skipped (as the reference's parser does)
       if (*p != '@') return fail("parallel FASTQ reader: a record does not start with '@' (multi-line FASTQ? use RFX_HOST_THREADS=1)");
-      const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+      const char* nl = find_nl(p, e);
       if (!nl) return fail("truncated FASTQ record");
       const char* s = nl + 1;
-      nl = (const char*)memchr(s, '\n', (size_t)(e - s));
+      nl = find_nl(s, e);
       if (!nl) return fail("truncated FASTQ record");
       const size_t L = (size_t)(nl - s);
       const char* plus = nl + 1;
       if (plus >= e || *plus != '+') return fail("parallel FASTQ reader: multi-line FASTQ records (use RFX_HOST_THREADS=1)");
-      nl = (const char*)memchr(plus, '\n', (size_t)(e - plus));
+      nl = plus + 1 < e && plus[1] == '\n' ? plus + 1 : find_nl(plus, e);  // almost always a bare "+"
       if (!nl) return fail("truncated FASTQ record");
       const char* q = nl + 1;
-      const char* qe = (const char*)memchr(q, '\n', (size_t)(e - q));
+      // the quality line has to be as long as the sequence: look there first, search only if that is not its end
+      const char* qe = (size_t)(e - q) > L && q[L] == '\n' && !memchr(q, '\n', L) ? q + L : find_nl(q, e);
       if (!qe) qe = e;  // last record of a file without a final newline
       if ((size_t)(qe - q) != L) return fail("parallel FASTQ reader: quality and sequence lengths differ (multi-line FASTQ? use RFX_HOST_THREADS=1)");
       start.push_back((uint64_t)(s - pc.b));
@@ -303,21 +321,43 @@ class CountIngest {
               void (*dealloc)(void*) = rfx_host_free, uint32_t cap_reads = 4u << 20, uint64_t cap_words = 24ull << 20)
       : sink_(std::move(sink)), nthreads_(threads ? threads : 1), dealloc_(dealloc) {
     blocks_.resize(3);
-    for (size_t i = 0; i < blocks_.size(); ++i) {
-      StageBlock& b = blocks_[i];
+    for (StageBlock& b : blocks_) {
       b.cap_reads = cap_reads;
       b.cap_words = cap_words;
-      b.codes = (uint64_t*)alloc(cap_words * 8);
-      b.acgt = (uint32_t*)alloc(cap_words * 4);
-      b.word_off = (uint32_t*)alloc(((size_t)cap_reads + 1) * 4);
-      b.len = (uint32_t*)alloc((size_t)cap_reads * 4);
-      if (!b.codes || !b.acgt || !b.word_off || !b.len) die("rufus_amd: cannot allocate pinned staging memory");
-      free_.push_back((int)i);
     }
+    // Page-locking ~1 GB takes 0.2 s: the workers start on the first block while the others are still being pinned.
+    auto pin = [this, alloc](size_t i) {
+      StageBlock& b = blocks_[i];
+      b.codes = (uint64_t*)alloc(b.cap_words * 8);
+      b.acgt = (uint32_t*)alloc(b.cap_words * 4);
+      b.word_off = (uint32_t*)alloc(((size_t)b.cap_reads + 1) * 4);
+      b.len = (uint32_t*)alloc((size_t)b.cap_reads * 4);
+      if (!b.codes || !b.acgt || !b.word_off || !b.len) die("rufus_amd: cannot allocate pinned staging memory");
+      std::lock_guard<std::mutex> g(mu_);
+      free_.push_back((int)i);
+      cv_.notify_all();
+    };
+    pin(0);
+    pinner_ = std::thread([this, pin] {
+      for (size_t i = 1; i < blocks_.size(); ++i) pin(i);
+    });
     for (unsigned t = 0; t < nthreads_; ++t) workers_.emplace_back([this] { worker(); });
   }
 
+  // The staging memory cut into page-locked pieces of `piece` bytes, for a caller that is done feeding (the count
+  // tool drains its result through them).  Valid until this object is destroyed.
+  std::vector<std::pair<char*, size_t>> lend_buffers(size_t piece) {
+    if (pinner_.joinable()) pinner_.join();
+    std::vector<std::pair<char*, size_t>> out;
+    for (StageBlock& b : blocks_) {
+      for (size_t at = 0; at + piece <= b.cap_words * 8; at += piece) out.emplace_back((char*)b.codes + at, piece);
+      for (size_t at = 0; at + piece <= b.cap_words * 4; at += piece) out.emplace_back((char*)b.acgt + at, piece);
+    }
+    return out;
+  }
+
   ~CountIngest() {
+    if (pinner_.joinable()) pinner_.join();
     {
       std::lock_guard<std::mutex> g(mu_);
       closing_ = true;

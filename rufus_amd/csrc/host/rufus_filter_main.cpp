@@ -81,8 +81,10 @@ int main(int argc, char** argv) {
   rfx_hashlist_keys(text.data(), text.size(), k, single, keys.data(), keys.size());
   printf("\nDone Hash Files\n\t Mutations Hash size is %ld\n", nk);
 
+  trace("filter: hash list parsed");
   rfx_ctx* ctx = open_ctx();
   rfx_set* set = rfx_set_build(ctx, keys.data(), (uint64_t)nk, k);
+  trace("filter: device open, set built");
   if (!set) die(std::string("rufus_amd: ") + rfx_last_error());
 
   // Pipeline (the device scans ~1000x faster than one core parses, so the host side is what counts):
@@ -305,8 +307,7 @@ int main(int argc, char** argv) {
     }
   };
   unsigned nthreads = (unsigned)std::max(1, atoi(argv[a]));
-  const unsigned hw = std::thread::hardware_concurrency();
-  if (hw && nthreads > hw) nthreads = hw;
+  nthreads = std::min(nthreads, rfx_host_cpus());
   if (const char* ev = getenv("RFX_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(ev));
   std::vector<std::thread> workers;
   for (unsigned t = 0; t < nthreads; ++t) workers.emplace_back(worker);
@@ -328,10 +329,12 @@ int main(int argc, char** argv) {
     found += res.found;
     printf("Read in %llu lines: Found %llu \r", total * 4, found);
   }
+  trace("filter: all pieces written");
   for (auto& w : workers) w.join();
   for (int i = 0; i < n_streams; ++i) readers[i].join();
   rfx_set_free(set);
   rfx_close(ctx);
+  trace("filter: closed");
   printf("\nDone running RUFUS.Filter.cpp\n");
   return 0;
 }

@@ -49,7 +49,7 @@ int main(int argc, char** argv) {
     const uint32_t m = (uint32_t)std::min<uint64_t>(step, n_pairs - at);
     if (rfx_synth_text(&p, first + at, m, seq.data(), qual.data()) != RFX_OK) { fprintf(stderr, "bad parameters\n"); return 1; }
     // text of the records, formatted in parallel into per-thread strings
-    const unsigned nt = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const unsigned nt = std::max(1u, std::min(64u, rfx_host_cpus()));
     std::vector<std::string> part1(nt), part2(nt);
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; ++t)

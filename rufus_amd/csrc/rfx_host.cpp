@@ -1,14 +1,18 @@
 // Host-only half of the C-ABI: jellyfish hash matrix, read packing, hash-list loader, .Jhash header.
 // No device code here; everything is callable on a machine without a GPU.
+#include <immintrin.h>
+
 #include <algorithm>
 #include <atomic>
 #include <thread>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
 #include <string>
 #include <vector>
 
+#include <sched.h>
 #include <unistd.h>
 #include <sys/utsname.h>
 
@@ -217,45 +221,149 @@ struct PackLut {
 };
 const PackLut g_pack_lut;
 
+// One read: L bases at s (qualities at q, may be null = all '\0') into ceil(L / 32) words at codes / acgt / good.
+// The packing rules (one place, two implementations that must agree bit for bit):
+//   count only      code = A C G T a c g t -> 0 1 2 3 0 1 2 3, anything else 0; acgt bit = one of those eight
+//   filter          code = A C G T -> 0 1 2 3, anything else (lower case too) 0     (src/Util.cpp:51-84)
+//                   good bit = !(q - 33 < min_q || base == 'N')                     (src/RUFUS.Filter.cpp:205)
+//   filter + count  as filter, plus the acgt bit; lower-case c g t -> RFX_E_MIXEDCASE (the two tools disagree there)
+typedef int (*pack_one_fn)(const unsigned char* s, const signed char* q, uint32_t L, int min_q, bool want_count,
+                           bool want_filter, uint64_t* codes, uint32_t* acgt, uint32_t* good);
+
+int pack_one_scalar(const unsigned char* s, const signed char* q, uint32_t L, int min_q, bool want_count,
+                    bool want_filter, uint64_t* codes, uint32_t* acgt, uint32_t* good) {
+  const PackLut& T = g_pack_lut;
+  for (uint32_t i = 0, w = 0; i < L; i += 32, ++w) {
+    uint64_t cw = 0;
+    uint32_t ma = 0, mg = 0;
+    const uint32_t nb = std::min<uint32_t>(32, L - i);
+    if (!want_filter) {
+      for (uint32_t b = 0; b < nb; ++b) {
+        cw |= (uint64_t)T.jcode[s[i + b]] << (2 * b);
+        ma |= (uint32_t)T.jvalid[s[i + b]] << b;
+      }
+    } else {
+      for (uint32_t b = 0; b < nb; ++b) {
+        const unsigned char ch = s[i + b];
+        cw |= (uint64_t)T.fcode[ch] << (2 * b);
+        if (want_count) {
+          if (T.lower_cgt[ch]) return RFX_E_MIXEDCASE;
+          ma |= (uint32_t)T.jvalid[ch] << b;
+        }
+        const int qv = q ? (int)q[i + b] : 0;
+        mg |= (uint32_t)(!(qv - 33 < min_q || ch == 'N')) << b;
+      }
+    }
+    codes[w] = cw;
+    if (acgt) acgt[w] = ma;
+    if (good) good[w] = mg;
+  }
+  return RFX_OK;
+}
+
+// 32 bases per step: compares give the masks, and with u = base & 0xDF the code is bit0 = u.1 ^ u.2, bit1 = u.2 ^ u.3
+// (A 0x41 -> 00, C 0x43 -> 01, G 0x47 -> 10, T 0x54 -> 11): two byte-mask extractions, interleaved by pdep.
+// The host parsers of the drop-in tools spend most of their time here: 3.2 cycles per base scalar.
+__attribute__((target("avx2,bmi2"))) int pack_one_avx2(const unsigned char* s, const signed char* q, uint32_t L, int min_q,
+                                                       bool want_count, bool want_filter, uint64_t* codes,
+                                                       uint32_t* acgt, uint32_t* good) {
+  const __m256i cA = _mm256_set1_epi8('A'), cC = _mm256_set1_epi8('C'), cG = _mm256_set1_epi8('G'),
+                cT = _mm256_set1_epi8('T'), cN = _mm256_set1_epi8('N'), fold = _mm256_set1_epi8((char)0xDF);
+  const int qmin = min_q + 33;  // good needs q >= qmin (signed chars, like the reference's plain `char`)
+  const __m256i qlim = _mm256_set1_epi8((char)std::max(-128, std::min(127, qmin)));
+  for (uint32_t i = 0, w = 0; i < L; i += 32, ++w) {
+    const uint32_t nb = std::min<uint32_t>(32, L - i);
+    __m256i v, qv = _mm256_setzero_si256();
+    if (nb == 32) {
+      v = _mm256_loadu_si256((const __m256i*)(s + i));
+      if (want_filter && q) qv = _mm256_loadu_si256((const __m256i*)(q + i));
+    } else {  // the last word of a read: through a zero-padded copy (a zero byte packs as 0 / not valid / not good)
+      alignas(32) unsigned char tmp[32] = {0};
+      memcpy(tmp, s + i, nb);
+      v = _mm256_load_si256((const __m256i*)tmp);
+      if (want_filter && q) {
+        alignas(32) signed char tq[32] = {0};
+        memcpy(tq, q + i, nb);
+        qv = _mm256_load_si256((const __m256i*)tq);
+      }
+    }
+    const __m256i u = _mm256_and_si256(v, fold);
+    const __m256i any_case = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(u, cA), _mm256_cmpeq_epi8(u, cC)),
+                                             _mm256_or_si256(_mm256_cmpeq_epi8(u, cG), _mm256_cmpeq_epi8(u, cT)));
+    const uint32_t m_any = (uint32_t)_mm256_movemask_epi8(any_case);
+    const __m256i t = _mm256_xor_si256(u, _mm256_srli_epi16(u, 1));  // bit 1 = u.1 ^ u.2, bit 2 = u.2 ^ u.3
+    uint32_t b0 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(t, 6));
+    uint32_t b1 = (uint32_t)_mm256_movemask_epi8(_mm256_slli_epi16(t, 5));
+    uint32_t m_code = m_any, mg = 0;
+    if (want_filter) {
+      const __m256i upper = _mm256_or_si256(_mm256_or_si256(_mm256_cmpeq_epi8(v, cA), _mm256_cmpeq_epi8(v, cC)),
+                                            _mm256_or_si256(_mm256_cmpeq_epi8(v, cG), _mm256_cmpeq_epi8(v, cT)));
+      m_code = (uint32_t)_mm256_movemask_epi8(upper);
+      if (want_count) {  // lower-case c g t: in any_case, not upper case, and not 'a'
+        const uint32_t m_a = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, _mm256_set1_epi8('a')));
+        if (m_any & ~m_code & ~m_a) return RFX_E_MIXEDCASE;
+      }
+      uint32_t bad = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, cN));
+      if (qmin > 127) bad = ~0u;
+      else if (qmin > -128) bad |= (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi8(qlim, qv));
+      mg = ~bad;
+      if (nb < 32) mg &= (1u << nb) - 1;
+    }
+    b0 &= m_code;
+    b1 &= m_code;
+    codes[w] = _pdep_u64(b0, 0x5555555555555555ull) | _pdep_u64(b1, 0xAAAAAAAAAAAAAAAAull);
+    if (acgt) acgt[w] = m_any;
+    if (good) good[w] = mg;
+  }
+  return RFX_OK;
+}
+
+pack_one_fn pick_pack_one() {
+  if (getenv("RFX_PACK_SCALAR")) return pack_one_scalar;  // tests compare the two
+  __builtin_cpu_init();
+  return __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi2") ? pack_one_avx2 : pack_one_scalar;
+}
+const pack_one_fn g_pack_one = pick_pack_one();
+
 // Reads [r0, r1): their word offsets are already in word_off.  Returns RFX_OK or RFX_E_MIXEDCASE.
 int pack_range(const char* seq, const char* qual, const uint64_t* off, uint32_t r0, uint32_t r1, int min_q, bool want_count,
                bool want_filter, uint64_t* codes, uint32_t* acgt, uint32_t* good, const uint32_t* word_off) {
-  const PackLut& T = g_pack_lut;
   for (uint32_t r = r0; r < r1; ++r) {
     const uint64_t b0 = off[r], L = off[r + 1] - off[r];
-    uint64_t w = word_off[r];
-    for (uint64_t i = 0; i < L; i += 32, ++w) {
-      uint64_t cw = 0;
-      uint32_t ma = 0, mg = 0;
-      const uint64_t nb = std::min<uint64_t>(32, L - i);
-      const unsigned char* s = (const unsigned char*)seq + b0 + i;
-      if (!want_filter) {
-        for (uint64_t b = 0; b < nb; ++b) {
-          cw |= (uint64_t)T.jcode[s[b]] << (2 * b);
-          ma |= (uint32_t)T.jvalid[s[b]] << b;
-        }
-      } else {
-        const signed char* q = qual ? (const signed char*)qual + b0 + i : nullptr;
-        for (uint64_t b = 0; b < nb; ++b) {
-          const unsigned char ch = s[b];
-          cw |= (uint64_t)T.fcode[ch] << (2 * b);
-          if (want_count) {
-            if (T.lower_cgt[ch]) return RFX_E_MIXEDCASE;
-            ma |= (uint32_t)T.jvalid[ch] << b;
-          }
-          const int qv = q ? (int)q[b] : 0;
-          mg |= (uint32_t)(!(qv - 33 < min_q || ch == 'N')) << b;  // src/RUFUS.Filter.cpp:205
-        }
-      }
-      codes[w] = cw;
-      if (acgt) acgt[w] = ma;
-      if (good) good[w] = mg;
-    }
+    const uint64_t w = word_off[r];
+    const int rc = g_pack_one((const unsigned char*)seq + b0, qual ? (const signed char*)qual + b0 : nullptr, (uint32_t)L,
+                              min_q, want_count, want_filter, codes + w, acgt ? acgt + w : nullptr,
+                              good ? good + w : nullptr);
+    if (rc) return rc;
   }
   return RFX_OK;
 }
 
 }  // namespace
+
+unsigned rfx_host_cpus(void) {
+  static const unsigned cached = [] {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+    auto cut = [&](double quota, double period) {
+      if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max(1.0, std::ceil(quota / period)));
+    };
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+      char q[32];
+      double per;
+      if (fscanf(f, "%31s %lf", q, &per) == 2 && strcmp(q, "max") != 0) cut(atof(q), per);
+      fclose(f);
+    } else {  // cgroup v1
+      double q = -1, per = 0;
+      if (FILE* a = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(a, "%lf", &q) != 1) q = -1; fclose(a); }
+      if (FILE* b = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(b, "%lf", &per) != 1) per = 0; fclose(b); }
+      cut(q, per);
+    }
+    return n;
+  }();
+  return cached;
+}
 
 int rfx_pack_reads(const char* seq, const char* qual, const uint64_t* off, uint32_t n_reads, int min_q, int flags,
                    uint64_t* codes, uint32_t* acgt, uint32_t* good, uint32_t* word_off, uint32_t* len) {
@@ -276,8 +384,7 @@ int rfx_pack_reads(const char* seq, const char* qual, const uint64_t* off, uint3
   // batch is big enough to pay for them (RFX_HOST_THREADS overrides the count; 1 = inline).
   const uint64_t bases = n_reads ? off[n_reads] - off[0] : 0;
   unsigned nt = (unsigned)std::min<uint64_t>(bases / (2u << 20), 32);
-  const unsigned hw = std::thread::hardware_concurrency();
-  if (hw && nt > hw) nt = hw;
+  nt = std::min(nt, rfx_host_cpus());
   if (const char* ev = getenv("RFX_HOST_THREADS")) nt = (unsigned)atoi(ev);
   if (nt <= 1 || n_reads < 2 * nt)
     return pack_range(seq, qual, off, 0, n_reads, min_q, want_count, want_filter, codes, acgt, good, word_off);
@@ -308,39 +415,17 @@ int rfx_pack_spans(const char* base, const uint64_t* seq_start, const uint32_t* 
   if (!base || !seq_start || !seq_len || !codes || !word_off || !len) return RFX_E_INVAL;
   const bool want_count = flags & RFX_PACK_COUNT, want_filter = flags & RFX_PACK_FILTER;
   if ((want_count && !acgt) || (want_filter && (!good || !qual_start)) || (!want_count && !want_filter)) return RFX_E_INVAL;
-  const PackLut& T = g_pack_lut;
   uint64_t w = word_off[0];
   for (uint32_t r = 0; r < n_reads; ++r) {
     const uint32_t L = seq_len[r];
-    const unsigned char* s = (const unsigned char*)base + seq_start[r];
-    const signed char* q = want_filter ? (const signed char*)base + qual_start[r] : nullptr;
     word_off[r] = (uint32_t)w;
     len[r] = L;
     if (w + (L + 31) / 32 > 0xFFFFFFFFull) return RFX_E_RANGE;
-    for (uint32_t i = 0; i < L; i += 32, ++w) {
-      uint64_t cw = 0;
-      uint32_t ma = 0, mg = 0;
-      const uint32_t nb = std::min<uint32_t>(32, L - i);
-      if (!want_filter) {
-        for (uint32_t b = 0; b < nb; ++b) {
-          cw |= (uint64_t)T.jcode[s[i + b]] << (2 * b);
-          ma |= (uint32_t)T.jvalid[s[i + b]] << b;
-        }
-      } else {
-        for (uint32_t b = 0; b < nb; ++b) {
-          const unsigned char ch = s[i + b];
-          cw |= (uint64_t)T.fcode[ch] << (2 * b);
-          if (want_count) {
-            if (T.lower_cgt[ch]) return RFX_E_MIXEDCASE;
-            ma |= (uint32_t)T.jvalid[ch] << b;
-          }
-          mg |= (uint32_t)(!((int)q[i + b] - 33 < min_q || ch == 'N')) << b;  // src/RUFUS.Filter.cpp:205
-        }
-      }
-      codes[w] = cw;
-      if (acgt) acgt[w] = ma;
-      if (good) good[w] = mg;
-    }
+    const int rc = g_pack_one((const unsigned char*)base + seq_start[r],
+                              want_filter ? (const signed char*)base + qual_start[r] : nullptr, L, min_q, want_count,
+                              want_filter, codes + w, acgt ? acgt + w : nullptr, good ? good + w : nullptr);
+    if (rc) return rc;
+    w += (L + 31) / 32;
   }
   word_off[n_reads] = (uint32_t)w;
   return RFX_OK;
@@ -491,7 +576,7 @@ int rfx_synth_text(const rfx_synth* p, uint64_t first_pair, uint32_t n_pairs, ch
       }
     }
   };
-  unsigned nt = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 64);
+  unsigned nt = std::min<unsigned>(rfx_host_cpus(), 64);
   if (const char* ev = getenv("RFX_HOST_THREADS")) nt = std::max(1, atoi(ev));
   if (n_pairs < 4096 || nt <= 1) {
     for (uint32_t q = 0; q < n_pairs; ++q) one_pair(q);

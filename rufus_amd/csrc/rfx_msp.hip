@@ -243,7 +243,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
   __shared__ uint64_t s_pbase[P1_BINS];
   __shared__ uint64_t s_lk[LIST];
   __shared__ uint32_t s_lc[LIST];
-  __shared__ uint32_t s_nd, s_ovf, s_nl, s_more;
+  __shared__ uint32_t s_nd, s_ovf, s_nl;
   __shared__ uint32_t s_rx[WIDE ? RC : 1];  // WIDE: plane value of the cached record | 0x80000000 once published
   unsigned long long* s_rk = (unsigned long long*)s_lk;  // the record cache lives in the (then idle) survivor list
   uint32_t* s_rc = s_lc;
@@ -264,7 +264,6 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     }
   };
   prefetch(blockIdx.x);
-  bool clean = false;  // the survivor scan empties the table as it reads it
 
   for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
     const uint64_t a0 = pre_a, e0 = pre_e;
@@ -274,12 +273,10 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     uint32_t j = 0;
     bool failed = false;
     for (;;) {
-      if (!clean)
-        for (int i = threadIdx.x; i < TBL; i += BLK) {
-          s_keys[i] = RFX_EMPTY;
-          s_cnt[i] = 0;
-        }
-      clean = false;
+      for (int i = threadIdx.x; i < TBL; i += BLK) {
+        s_keys[i] = RFX_EMPTY;
+        s_cnt[i] = 0;
+      }
       for (int i = threadIdx.x; i < RC; i += BLK) {
         s_rk[i] = MSP_EMPTY;
         s_rc[i] = 0;
@@ -290,13 +287,12 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         s_nd = 0;
         s_ovf = 0;
         s_nl = 0;
-        s_more = 0;
       }
       __syncthreads();
-      // k-mer q of record x (RFX_EMPTY: the record has no such k-mer, or it belongs to another sub-range)
-      auto kmer_of = [&](uint64_t x, uint32_t xe, int q) -> uint64_t {
+      // k-mer q of record x into the table, counted `mult` times.
+      auto insert_kmer = [&](uint64_t x, uint32_t xe, int q, uint32_t mult) {
         const int n = (int)((x >> 56) & 3u) + 1;
-        if (q >= n) return RFX_EMPTY;
+        if (q >= n) return;
         const uint64_t S = x & ((1ull << 56) - 1);
         uint64_t fwd, key;
         if (!WIDE) {
@@ -326,47 +322,32 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
             key = rc < fwd ? rc : fwd;
           }
         }
-        if (r > 0 && (split_hash(key) >> (32 - r)) != j) return RFX_EMPTY;
-        return key;
-      };
-      // The probe is ONE returning CAS: it yields "was empty, now mine", "already mine" or "someone
-      // else's" without a separate read-and-branch for the new-key case.  New keys are only counted
-      // (no returned ticket: one wave-aggregated LDS add).  Inserts stop once FILL keys are in; the few a
-      // thread may have in flight past that point fit the spare slots unless the bin is far over, and a
-      // probe that went all the way round gives up -- either way the pass is void and the range is split.
-      auto table_full = [&]() -> bool {
-        if (__hip_atomic_load(&s_nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)FILL) return false;
-        s_ovf = 1;
-        return true;
-      };
-      // `old` = what the CAS at `slot` returned
-      auto table_settle = [&](uint64_t key, uint32_t mult, uint32_t slot, unsigned long long old) {
-        for (int probes = 0;; ++probes) {
+        if (r > 0 && (split_hash(key) >> (32 - r)) != j) return;
+        // The probe is ONE returning CAS: it yields "was empty, now mine", "already mine" or "someone
+        // else's" without a separate read-and-branch for the new-key case.  New keys are only counted
+        // (no returned ticket: one wave-aggregated LDS add); the count is looked at before every
+        // insert, so at most one key per thread can follow FILL, which the TBL - FILL
+        // spare slots absorb -- probing always terminates.  A skipped insert voids the pass.
+        if (__hip_atomic_load(&s_nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)FILL) {
+          s_ovf = 1;
+          return;
+        }
+        uint32_t slot = leaf_hash(key) >> (LEAF_TBL_LOG2 - TBL_LOG2);
+        for (;;) {
+          unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
           if (old == RFX_EMPTY) {
             atomicAdd(&s_nd, 1u);
             old = key;
           }
           if (old == key) {
             atomicAdd(&s_cnt[slot], mult);
-            return;
-          }
-          if (probes >= TBL) {
-            s_ovf = 1;
-            return;
+            break;
           }
           slot = (slot + 1) & (TBL - 1);
-          old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
         }
       };
-      auto slot_of = [&](uint64_t key) -> uint32_t { return leaf_hash(key) >> (LEAF_TBL_LOG2 - TBL_LOG2); };
       auto insert_record = [&](uint64_t x, uint32_t xe, uint32_t mult) {
-        for (int q = 0; q < MSP_NMAX; ++q) {
-          const uint64_t key = kmer_of(x, xe, q);
-          if (key == RFX_EMPTY || table_full()) continue;
-          const uint32_t slot = slot_of(key);
-          table_settle(key, mult, slot,
-                       atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key));
-        }
+        for (int q = 0; q < MSP_NMAX; ++q) insert_kmer(x, xe, q, mult);
       };
       // Phase A: identical records first.  Reads that cover the same stretch of genome cut it into the
       // same records (run boundaries follow the minimizers, not the read), so at sequencing depth most
@@ -394,38 +375,15 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
               if (WIDE) recx[u] = i < e ? srcx[i] : 0u;
             }
           }
-          // the first probe of all eight records is in flight at once (a CAS of the empty marker against
-          // itself, for the padding past the end of the bin, changes nothing)
-          uint32_t hv[MSP_ILP];
-          unsigned long long first[WIDE ? 1 : MSP_ILP];
-#pragma unroll
-          for (int u = 0; u < MSP_ILP; ++u) {
-            const uint64_t x = rec[u];
-            const uint32_t h = (uint32_t)x ^ (uint32_t)(x >> 23) ^ (uint32_t)(x >> 41) ^ (WIDE ? recx[u] * 0x85EBCA6Bu : 0u);
-            hv[u] = (h * 0x9E3779B1u) >> (32 - RC_LOG2);
-          }
-          if (!WIDE) {
-#pragma unroll
-            for (int u = 0; u < MSP_ILP; ++u)
-              first[u] = atomicCAS(&s_rk[hv[u]], (unsigned long long)MSP_EMPTY, (unsigned long long)rec[u]);
-          }
 #pragma unroll
           for (int u = 0; u < MSP_ILP; ++u) {
             const uint64_t x = rec[u];
             const uint32_t xe = WIDE ? recx[u] : 0u;
             if (x == MSP_EMPTY) continue;
-            uint32_t h = hv[u];
+            uint32_t h = (uint32_t)x ^ (uint32_t)(x >> 23) ^ (uint32_t)(x >> 41) ^ (WIDE ? xe * 0x85EBCA6Bu : 0u);
+            h = (h * 0x9E3779B1u) >> (32 - RC_LOG2);
             bool cached = false;
-            int p = 0;
-            if (!WIDE) {
-              if (first[u] == MSP_EMPTY || first[u] == x) {
-                atomicAdd(&s_rc[h], 1u);
-                continue;
-              }
-              h = (h + 1) & (RC - 1);
-              p = 1;
-            }
-            for (; p < MSP_RC_PROBES; ++p) {
+            for (int p = 0; p < MSP_RC_PROBES; ++p) {
               const unsigned long long old = atomicCAS(&s_rk[h], (unsigned long long)MSP_EMPTY, (unsigned long long)x);
               if (!WIDE) {
                 if (old == MSP_EMPTY || old == x) {
@@ -481,33 +439,8 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         const uint32_t nrec = s_nl;
         // one k-mer per thread: four times the parallelism of one record per thread, and the table
         // round trips of a record's k-mers overlap instead of queueing in one lane
-        // -- and four such k-mers per thread in flight
-        constexpr int BI = 4;
-        for (uint32_t i0 = threadIdx.x; i0 < MSP_NMAX * nrec; i0 += BI * BLK) {
-          uint64_t key[BI];
-          uint32_t mult[BI], slot[BI];
-          unsigned long long got[BI];
-          bool any = false;
-#pragma unroll
-          for (int u = 0; u < BI; ++u) {
-            const uint32_t i = i0 + (uint32_t)u * BLK;
-            key[u] = RFX_EMPTY;
-            mult[u] = 0;
-            if (i < MSP_NMAX * nrec) {
-              key[u] = kmer_of(s_rk[i >> 2], WIDE ? s_rx[i >> 2] : 0u, (int)(i & 3u));
-              mult[u] = s_rc[i >> 2];
-            }
-            slot[u] = slot_of(key[u]);
-            any |= key[u] != RFX_EMPTY;
-          }
-          if (!any || table_full()) continue;
-#pragma unroll
-          for (int u = 0; u < BI; ++u)  // (empty against empty: no effect)
-            got[u] = atomicCAS(&s_keys[slot[u]], (unsigned long long)RFX_EMPTY, (unsigned long long)key[u]);
-#pragma unroll
-          for (int u = 0; u < BI; ++u)
-            if (key[u] != RFX_EMPTY) table_settle(key[u], mult[u], slot[u], got[u]);
-        }
+        for (uint32_t i = threadIdx.x; i < MSP_NMAX * nrec; i += BLK)
+          insert_kmer(s_rk[i >> 2], WIDE ? s_rx[i >> 2] : 0u, (int)(i & 3u), s_rc[i >> 2]);
         __syncthreads();
         if (threadIdx.x == 0) s_nl = 0;
       }
@@ -519,7 +452,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         // odd lane of every wave that scans the table.
         auto flush = [&]() {
           __syncthreads();
-          const uint32_t nl = min(s_nl, (uint32_t)LIST);
+          const uint32_t nl = s_nl;
           for (uint32_t i = threadIdx.x; i < nl; i += BLK) {
             uint64_t w = gf2_mul(g_lut, s_lk[i], ntab);  // 14 KB table, L1-resident; only survivors get here
             const uint64_t pos = w >> sel_bits;
@@ -555,41 +488,22 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
           if (threadIdx.x == 0) s_nl = 0;
           __syncthreads();
         };
-        // One sweep: every thread takes its slots into registers and leaves them empty for the next pass; what
-        // does not fit the list (rare: more than LIST survivors in one bin) waits in the registers for another
-        // round.
-        uint64_t pk[TBL / BLK];
-        uint32_t pc[TBL / BLK];
+        for (int base = 0; base < TBL; base += 2 * BLK) {
 #pragma unroll
-        for (int h = 0; h < TBL / BLK; ++h) {
-          const int i = h * BLK + threadIdx.x;
-          pk[h] = s_keys[i];
-          pc[h] = s_cnt[i];
-          s_keys[i] = RFX_EMPTY;
-          s_cnt[i] = 0;
-          if (!(pc[h] >= lower && pc[h] <= upper)) pk[h] = RFX_EMPTY;
-        }
-        clean = true;
-        for (;;) {
-#pragma unroll
-          for (int h = 0; h < TBL / BLK; ++h)
-            if (pk[h] != RFX_EMPTY) {
+          for (int h = 0; h < 2; ++h) {
+            const int i = base + h * BLK + threadIdx.x;
+            const uint64_t key = s_keys[i];
+            const uint32_t c = s_cnt[i];
+            if (key != RFX_EMPTY && c >= lower && c <= upper) {
               const uint32_t o = atomicAdd(&s_nl, 1u);
-              if (o < (uint32_t)LIST) {
-                s_lk[o] = pk[h];
-                s_lc[o] = pc[h];
-                pk[h] = RFX_EMPTY;
-              } else {
-                s_more = 1;
-              }
+              s_lk[o] = key;
+              s_lc[o] = c;
             }
-          flush();
-          const bool more = s_more != 0;
+          }
           __syncthreads();
-          if (!more) break;
-          if (threadIdx.x == 0) s_more = 0;
-          __syncthreads();
+          if (s_nl > LIST - 2 * BLK) flush();  // the next two rounds might not fit
         }
+        flush();
       }
       __syncthreads();
       if (ovf) {  // split this sub-range

@@ -20,7 +20,7 @@ with open("$D/hl", "w") as f:
             f.write(km.decode() + " 12\n")
 PY
 s=$(date +%s.%N)
-$BIN/RUFUS.Filter $D/hl $D/m1.fq $D/m2.fq $D/out 25 15 1 $T > $D/log.txt || exit 1
+RFX_CLI_TRACE=1 $BIN/RUFUS.Filter $D/hl $D/m1.fq $D/m2.fq $D/out 25 15 1 $T > $D/log.txt || exit 1
 e=$(date +%s.%N)
 python3 -c "print('cli_filter threads=$T reads=%d wall=%.2fs rate=%.1f M reads/s' % (2*$PAIRS, $e-$s, 2*$PAIRS/($e-$s)/1e6))"
 tail -c 200 $D/log.txt | tr '\r' '\n' | tail -2

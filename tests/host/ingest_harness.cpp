@@ -24,8 +24,13 @@ int main(int argc, char** argv) {
   const uint32_t cap_reads = (uint32_t)atoi(argv[2]);
   const uint64_t cap_words = strtoull(argv[3], 0, 10);
   uint64_t reads = 0, bases = 0, sum = 0, blocks = 0;
+  const bool nosum = getenv("INGEST_NOSUM") != nullptr;
   CountIngest ing(threads, [&](const StageBlock& b) {
     ++blocks;
+    if (nosum) {  // throughput runs: INGEST_NOSUM=1
+      reads += b.n_reads;
+      return;
+    }
     for (uint32_t r = 0; r < b.n_reads; ++r) {
       uint64_t h = fnv(0xCBF29CE484222325ull, b.len[r]);
       const uint32_t w0 = b.word_off[r], w1 = b.word_off[r + 1];

@@ -66,6 +66,64 @@ def test_pack_layout_and_masks():
     assert int(f.good[3]) == (1 << 10) - 1 and int(f.good[4]) == 0          # '5' = Q20 ok; missing quals bad
 
 
+def _pack_rules(seq: bytes, qual, min_q: int, want_count: bool, want_filter: bool):
+    """The packing rules restated base by base (rufus_amd/csrc/rfx_host.cpp states them once for its scalar and
+    its 32-bases-per-step implementation)."""
+    nw = (len(seq) + 31) // 32
+    codes, acgt, good = [0] * nw, [0] * nw, [0] * nw
+    for i, ch in enumerate(seq):
+        c = bytes([ch])
+        if want_filter:
+            code = b"ACGT".find(c) if c in b"ACGT" else 0
+            q = qual[i] if qual is not None else 0
+            q = q - 256 if q > 127 else q                                   # plain (signed) char
+            good[i // 32] |= int(not (q - 33 < min_q or c == b"N")) << (i % 32)
+        else:
+            code = b"ACGT".find(c.upper()) if c.upper() in b"ACGT" and c.isalpha() else 0
+        codes[i // 32] |= code << (2 * (i % 32))
+        if c in b"ACGTacgt":
+            acgt[i // 32] |= 1 << (i % 32)
+    return codes, acgt, good
+
+
+@pytest.mark.parametrize("scalar", [False, True])
+def test_pack_every_byte_value_and_length(scalar):
+    """Both implementations of the packer (RFX_PACK_SCALAR=1 picks the scalar one at load time, hence the child
+    process) against the rules above: all 256 byte values as bases and as qualities, lengths around the word size."""
+    if scalar:
+        import subprocess, sys
+        env = dict(os.environ, RFX_PACK_SCALAR="1")
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", __file__, "-k",
+                            "test_pack_every_byte_value_and_length and False"], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        return
+    rng = np.random.default_rng(77)
+    alphabet = np.frombuffer(b"ACGT" * 12 + b"acgtNn" + bytes(range(256)), np.uint8)
+    upper_only = np.frombuffer(b"ACGT" * 12 + b"aNn" + bytes(x for x in range(256) if x not in b"cgt"), np.uint8)
+    lens = list(range(0, 70)) + [95, 96, 97, 127, 128, 129, 150, 151, 250, 1000]
+    for min_q in (15, 0, -40, 95, 200):
+        seqs = [bytes(rng.choice(alphabet, n)) for n in lens]
+        quals = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in lens]
+        p = capi.PackedReads.from_reads(seqs, flags=capi.PACK_COUNT)
+        f = capi.PackedReads.from_reads(seqs, quals, min_q, capi.PACK_FILTER)
+        seqs_u = [bytes(rng.choice(upper_only, n)) for n in lens]
+        b = capi.PackedReads.from_reads(seqs_u, quals, min_q, capi.PACK_COUNT | capi.PACK_FILTER)
+        for r, n in enumerate(lens):
+            w0, w1 = int(p.word_off[r]), int(p.word_off[r + 1])
+            assert w1 - w0 == (n + 31) // 32
+            c, a, _ = _pack_rules(seqs[r], None, 0, True, False)
+            assert p.codes[w0:w1].tolist() == c and p.acgt[w0:w1].tolist() == a, (r, n)
+            c, _, g = _pack_rules(seqs[r], quals[r], min_q, False, True)
+            assert f.codes[w0:w1].tolist() == c and f.good[w0:w1].tolist() == g, (r, n, min_q)
+            c, a, g = _pack_rules(seqs_u[r], quals[r], min_q, True, True)
+            assert b.codes[w0:w1].tolist() == c and b.acgt[w0:w1].tolist() == a and b.good[w0:w1].tolist() == g
+    for bad in (b"c", b"g", b"t"):                                           # wherever it sits in a word
+        for at in (0, 5, 31, 32, 40, 63, 64, 70):
+            seq = b"A" * at + bad + b"A" * 3
+            with pytest.raises(capi.RufusError):
+                capi.PackedReads.from_reads([seq], [b"J" * len(seq)], 15, capi.PACK_COUNT | capi.PACK_FILTER)
+
+
 def test_hashlist_keys_match_oracle_set(testrun):
     k = 25
     texts = [testrun["hashlist"], testrun["merge"], "ACGTACGTACGTACGTACGTACGTA\n",

@@ -2,6 +2,9 @@
 // All arithmetic of the hot path happens behind the C-ABI (include/rufus_hip.h); nothing here counts,
 // hashes or compares k-mers.
 #pragma once
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <unistd.h>
@@ -317,6 +320,113 @@ inline rfx_records* load_records(rfx_ctx* c, const char* path, JhashHeader& h) {
   rfx_records* r = rfx_records_load(c, h.k, h.lsize, h.cols.data(), payload.data(), payload.size() / rl, h.counter_len);
   if (!r) die(std::string("rufus_amd: cannot load '") + path + "': " + rfx_last_error());
   return r;
+}
+
+// ---- newline scanning -----------------------------------------------------------------------------------------
+// The text side of every tool is a search for '\n'; a memchr call per (short) FASTQ line costs ~20 ns, which at four
+// lines per record is what one reader thread can do and no more.  These walk the buffer 16 / 32 bytes per step.
+#if defined(__x86_64__)
+#define RFX_X86 1
+#endif
+
+// memchr(p, '\n', e - p) for short lines, no call
+static inline const char* find_nl(const char* p, const char* e) {
+#if RFX_X86
+  const __m128i nl = _mm_set1_epi8('\n');
+  while (e - p >= 16) {
+    const int m = _mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)p), nl));
+    if (m) return p + __builtin_ctz((unsigned)m);
+    p += 16;
+  }
+#endif
+  return p < e ? (const char*)memchr(p, '\n', (size_t)(e - p)) : nullptr;
+}
+
+// Walks [p, e) until `want` newlines have been seen: returns the position just after the last one seen that
+// counts (e when the buffer ran out first), `got` = how many were seen.
+typedef const char* (*skip_lines_fn)(const char* p, const char* e, size_t want, size_t& got);
+static inline const char* skip_lines_plain(const char* p, const char* e, size_t want, size_t& got) {
+  got = 0;
+  while (got < want && p < e) {
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+    if (!nl) return e;
+    ++got;
+    p = nl + 1;
+  }
+  return got == want ? p : e;
+}
+#if RFX_X86
+__attribute__((target("avx2,popcnt"))) static inline const char* skip_lines_avx2(const char* p, const char* e, size_t want,
+                                                                               size_t& got) {
+  got = 0;
+  if (want == 0) return p;
+  const __m256i nl = _mm256_set1_epi8('\n');
+  while (e - p >= 32) {
+    uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)p), nl));
+    const size_t c = (size_t)__builtin_popcount(m);
+    if (got + c >= want) {
+      for (size_t drop = want - got - 1; drop; --drop) m &= m - 1;
+      got = want;
+      return p + __builtin_ctz(m) + 1;
+    }
+    got += c;
+    p += 32;
+  }
+  size_t tail;
+  const char* r = skip_lines_plain(p, e, want - got, tail);
+  got += tail;
+  return r;
+}
+#endif
+static inline skip_lines_fn pick_skip_lines() {
+#if RFX_X86
+  __builtin_cpu_init();
+  if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt")) return skip_lines_avx2;
+#endif
+  return skip_lines_plain;
+}
+
+// starts[i] = offset of line i of [b, e) for i < max (line 0 starts at 0); returns the number of lines found
+// (a last line without '\n' counts).
+typedef size_t (*index_lines_fn)(const char* b, const char* e, uint64_t* starts, size_t max);
+static inline size_t index_lines_plain(const char* b, const char* e, uint64_t* starts, size_t max) {
+  size_t li = 0;
+  const char* p = b;
+  while (p < e && li < max) {
+    starts[li++] = (uint64_t)(p - b);
+    const char* nl = find_nl(p, e);
+    p = nl ? nl + 1 : e;
+  }
+  return li;
+}
+#if RFX_X86
+__attribute__((target("avx2"))) static inline size_t index_lines_avx2(const char* b, const char* e, uint64_t* starts,
+                                                                      size_t max) {
+  if (b >= e || max == 0) return 0;
+  size_t li = 0;
+  starts[li++] = 0;
+  const __m256i nl = _mm256_set1_epi8('\n');
+  const char* p = b;
+  while (e - p >= 32 && li < max) {
+    uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)p), nl));
+    while (m && li < max) {
+      starts[li++] = (uint64_t)(p - b) + (uint64_t)__builtin_ctz(m) + 1;
+      m &= m - 1;
+    }
+    p += 32;
+  }
+  for (; p < e && li < max; ++p)
+    if (*p == '\n') starts[li++] = (uint64_t)(p - b) + 1;
+  if (li && starts[li - 1] >= (uint64_t)(e - b)) --li;  // the buffer ended with '\n': no line starts there
+  return li;
+}
+#endif
+static inline index_lines_fn pick_index_lines() {
+#if RFX_X86
+  __builtin_cpu_init();
+  if (__builtin_cpu_supports("avx2")) return index_lines_avx2;
+#endif
+  return index_lines_plain;
 }
 
 // RFX_CLI_TRACE=1: wall-clock marks of a tool's phases on stderr (scratch/cli_scale.sh reads them)

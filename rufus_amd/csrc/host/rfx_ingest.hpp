@@ -20,9 +20,6 @@
 #include <sys/mman.h>
 #include <sys/stat.h>
 
-#if defined(__SSE2__)
-#include <emmintrin.h>
-#endif
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -128,19 +125,6 @@ class CountIngest {
       ready_.push_back(blk);
       cv_.notify_all();
     }
-  }
-
-  // memchr(p, '\n', e - p) for the short lines of a FASTQ record: 16 bytes per step, no call
-  static inline const char* find_nl(const char* p, const char* e) {
-#if defined(__SSE2__)
-    const __m128i nl = _mm_set1_epi8('\n');
-    while (e - p >= 16) {
-      const int m = _mm_movemask_epi8(_mm_cmpeq_epi8(_mm_loadu_si128((const __m128i*)p), nl));
-      if (m) return p + __builtin_ctz((unsigned)m);
-      p += 16;
-    }
-#endif
-    return p < e ? (const char*)memchr(p, '\n', (size_t)(e - p)) : nullptr;
   }
 
   void parse_piece(const Piece& pc) {

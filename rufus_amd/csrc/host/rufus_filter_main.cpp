@@ -11,7 +11,11 @@
 #include <deque>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <mutex>
+
+#include <sys/mman.h>
+#include <sys/stat.h>
 
 #include "rfx_cli.hpp"
 
@@ -96,13 +100,22 @@ int main(int argc, char** argv) {
   //   the pulled records;
   //   the main thread writes the formatted pieces in input order.
   const size_t PIECE_RECS = 1u << 16;
-  struct Piece { std::vector<char> text; size_t recs = 0; };
+  // A piece: PIECE_RECS records (the last one of a stream: fewer) = 4 * recs lines of text, each ending in '\n'.
+  // Its bytes are the piece's own buffer (filled by read()) or lie in the mapping of a regular input file.
+  struct Piece {
+    const char* data = nullptr;
+    size_t size = 0, recs = 0;
+    std::unique_ptr<char[]> own;
+    size_t cap = 0;
+  };
   struct Stream {
     int fd = -1;
     std::mutex mu;
     std::condition_variable cv;
     std::deque<Piece*> q;
     bool done = false;
+    const char* map = nullptr;  // regular file: mapped
+    size_t map_size = 0;
   };
   const int n_streams = single ? 1 : 2;
   Stream st[2];
@@ -110,54 +123,116 @@ int main(int argc, char** argv) {
 #ifndef RFX_SINGLE_END
   st[1].fd = fd2;
 #endif
+  for (int i = 0; i < n_streams; ++i) {
+    struct stat sb;
+    if (fstat(st[i].fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !getenv("RFX_FILTER_NO_MMAP")) {
+      void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, st[i].fd, 0);
+      if (m != MAP_FAILED) {
+        (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+        st[i].map = (const char*)m;
+        st[i].map_size = (size_t)sb.st_size;
+      }
+    } else {
+#ifdef F_SETPIPE_SZ
+      (void)fcntl(st[i].fd, F_SETPIPE_SZ, 1 << 20);  // a pipe: fewer, larger reads (ignored on anything else)
+#endif
+    }
+  }
+  const skip_lines_fn skip_lines = pick_skip_lines();
+  const index_lines_fn index_lines = pick_index_lines();
   const size_t MAX_AHEAD = 48;  // pieces a reader may be ahead of the workers (~1 GB of text per stream)
+  auto new_piece = [](size_t cap) {
+    Piece* p = new Piece();
+    p->own.reset(new char[cap]);  // (not value-initialised: nothing is written that read() will not overwrite)
+    p->cap = cap;
+    p->data = p->own.get();
+    return p;
+  };
+  auto grow = [](Piece* p, size_t cap) {
+    std::unique_ptr<char[]> nb(new char[cap]);
+    memcpy(nb.get(), p->data, p->size);
+    p->own = std::move(nb);
+    p->cap = cap;
+    p->data = p->own.get();
+  };
   auto reader = [&](Stream& S) {
-    std::vector<char> carry;
-    std::vector<char> buf(8u << 20);
-    Piece* cur = new Piece();
-    size_t lines = 0;
-    bool eof = false;
-    while (!eof) {
-      ssize_t n = ::read(S.fd, buf.data(), buf.size());
-      if (n < 0 && errno == EINTR) continue;
-      if (n < 0) die(std::string("read error on input: ") + strerror(errno));
-      if (n == 0) eof = true;
-      const char *p = buf.data(), *e = buf.data() + (n > 0 ? n : 0);
-      while (p < e) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
-        const char* upto = nl ? nl + 1 : e;
-        cur->text.insert(cur->text.end(), p, upto);
-        p = upto;
-        if (nl && ++lines == 4 * PIECE_RECS) {
-          cur->recs = PIECE_RECS;
-          {
-            std::unique_lock<std::mutex> g(S.mu);
-            S.cv.wait(g, [&] { return S.q.size() < MAX_AHEAD; });
-            S.q.push_back(cur);
-            S.cv.notify_all();
-          }
-          cur = new Piece();
-          cur->text.reserve(PIECE_RECS * 340);
-          lines = 0;
+    auto push = [&](Piece* pc) {
+      std::unique_lock<std::mutex> g(S.mu);
+      S.cv.wait(g, [&] { return S.q.size() < MAX_AHEAD; });
+      S.q.push_back(pc);
+      S.cv.notify_all();
+    };
+    // the end of a stream, std::getline semantics: a final unterminated line still counts, and the missing lines
+    // of an incomplete last record read as empty
+    auto finish_tail = [&](Piece* cur, size_t lines) {
+      if (cur->size) {
+        if (cur->cap < cur->size + 8) grow(cur, cur->size + 8);
+        char* d = cur->own.get();
+        if (d[cur->size - 1] != '\n') {
+          d[cur->size++] = '\n';
+          ++lines;
+        }
+        cur->recs = (lines + 3) / 4;
+        while (lines < 4 * cur->recs) {
+          d[cur->size++] = '\n';
+          ++lines;
         }
       }
-    }
-    if (!cur->text.empty()) {
-      if (cur->text.back() != '\n') {  // std::getline semantics: a final unterminated line still counts
-        cur->text.push_back('\n');
-        ++lines;
+      std::lock_guard<std::mutex> g(S.mu);
+      if (cur->recs) S.q.push_back(cur);
+      else delete cur;
+      S.done = true;
+      S.cv.notify_all();
+    };
+    if (S.map) {  // cut the mapping in place: only the last piece is copied (it may need lines added)
+      const char *p = S.map, *e = S.map + S.map_size;
+      for (;;) {
+        size_t got;
+        const char* cut = skip_lines(p, e, 4 * PIECE_RECS, got);
+        if (got == 4 * PIECE_RECS) {
+          Piece* pc = new Piece();
+          pc->data = p;
+          pc->size = (size_t)(cut - p);
+          pc->recs = PIECE_RECS;
+          push(pc);
+          p = cut;
+          continue;
+        }
+        Piece* last = new_piece((size_t)(e - p) + 8);
+        memcpy(last->own.get(), p, (size_t)(e - p));
+        last->size = (size_t)(e - p);
+        finish_tail(last, got);
+        return;
       }
-      cur->recs = (lines + 3) / 4;  // an incomplete last record: its missing lines read as empty
-      while (lines < 4 * cur->recs) {
-        cur->text.push_back('\n');
-        ++lines;
+    }
+    const size_t CAP0 = PIECE_RECS * 360, RD = 1u << 20;
+    Piece* cur = new_piece(CAP0);
+    size_t lines = 0, scanned = 0;
+    for (;;) {
+      if (cur->cap - cur->size < RD) grow(cur, cur->cap + cur->cap / 2 + RD);
+      const ssize_t n = ::read(S.fd, cur->own.get() + cur->size, RD);
+      if (n < 0 && errno == EINTR) continue;
+      if (n < 0) die(std::string("read error on input: ") + strerror(errno));
+      if (n == 0) break;
+      cur->size += (size_t)n;
+      while (scanned < cur->size) {
+        size_t got;
+        const char* stop = skip_lines(cur->data + scanned, cur->data + cur->size, 4 * PIECE_RECS - lines, got);
+        lines += got;
+        scanned = (size_t)(stop - cur->data);
+        if (lines < 4 * PIECE_RECS) break;  // (stop == end of what has been read)
+        Piece* nx = new_piece(CAP0);
+        nx->size = cur->size - scanned;
+        memcpy(nx->own.get(), cur->data + scanned, nx->size);
+        cur->size = scanned;
+        cur->recs = PIECE_RECS;
+        push(cur);
+        cur = nx;
+        lines = 0;
+        scanned = 0;
       }
     }
-    std::lock_guard<std::mutex> g(S.mu);
-    if (cur->recs) S.q.push_back(cur);
-    else delete cur;
-    S.done = true;
-    S.cv.notify_all();
+    finish_tail(cur, lines);
   };
   std::thread readers[2];
   for (int i = 0; i < n_streams; ++i) readers[i] = std::thread(reader, std::ref(st[i]));
@@ -199,23 +274,36 @@ int main(int argc, char** argv) {
     return true;
   };
   auto worker = [&]() {
-    std::vector<uint64_t> ls[2], ss[2], qs[2], codes, mask;  // line starts, sequence / quality starts
-    std::vector<uint32_t> sl[2], good, woff, lens, hits;
+    std::vector<uint64_t> ls[2], ss[2], qs[2], mask;  // line starts, sequence / quality starts
+    std::vector<uint32_t> sl[2], hits;
+    std::vector<char> fix;  // private copies of quality strings that are shorter than their read
+    // packed reads go up from page-locked memory (a pageable source costs a staging copy inside the runtime, under
+    // the device lock)
+    struct Pinned {
+      void* p = nullptr;
+      size_t cap = 0;
+      void* need(size_t bytes) {
+        if (bytes > cap) {
+          if (p) rfx_host_free(p);
+          cap = bytes + bytes / 4;
+          p = rfx_host_alloc(cap);
+          if (!p) die("rufus_amd: cannot allocate pinned staging memory");
+        }
+        return p;
+      }
+      ~Pinned() { if (p) rfx_host_free(p); }
+    } pin_codes, pin_good, pin_woff, pin_lens;
     for (;;) {
       Piece *pc[2];
       uint64_t seq;
       if (!take(pc[0], pc[1], seq)) return;
       const size_t n = pc[0]->recs;
       for (int m = 0; m < n_streams; ++m) {
-        const std::vector<char>& t = pc[m]->text;
-        ls[m].assign(4 * n + 1, t.size());
-        size_t li = 0;
-        const char *p = t.data(), *e = t.data() + t.size();
-        while (p < e && li < 4 * n) {
-          ls[m][li++] = (uint64_t)(p - t.data());
-          const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
-          p = nl ? nl + 1 : e;
-        }
+        const char* t = pc[m]->data;
+        const size_t tsize = pc[m]->size;
+        ls[m].resize(4 * n + 1);
+        const size_t found_lines = index_lines(t, t + tsize, ls[m].data(), 4 * n);
+        for (size_t li = found_lines; li <= 4 * n; ++li) ls[m][li] = tsize;  // (mate 2 ran out: empty lines)
         ss[m].resize(n);
         qs[m].resize(n);
         sl[m].resize(n);
@@ -236,36 +324,49 @@ int main(int argc, char** argv) {
       uint64_t words = 0;
       for (int m = 0; m < n_streams; ++m)
         for (size_t i = 0; i < n; ++i) words += (sl[m][i] + 31) / 32;
-      codes.assign(words + 1, 0);
-      good.assign(words + 1, 0);
-      woff.assign(nr + 1, 0);
-      lens.assign(nr + 1, 0);
+      uint64_t* codes = (uint64_t*)pin_codes.need((words + 1) * 8);
+      uint32_t* good = (uint32_t*)pin_good.need((words + 1) * 4);
+      uint32_t* woff = (uint32_t*)pin_woff.need((nr + 1) * 4);
+      uint32_t* lens = (uint32_t*)pin_lens.need((nr + 1) * 4);
       uint32_t w0 = 0;
       for (int m = 0; m < n_streams; ++m) {
-        // a quality line shorter than its read would make the packer read the next line's bytes: such reads get
-        // a private copy of their quality string, padded with '\0' (= bad, what the reference's missing chars are)
-        std::vector<char>& t = pc[m]->text;
-        for (size_t i = 0; i < n; ++i) {
-          const uint64_t q0 = ls[m][4 * i + 3], q1 = ls[m][4 * i + 4];
-          const uint32_t ql = q1 > q0 ? (uint32_t)(q1 - q0 - 1) : 0u;
-          if (ql < sl[m][i]) {
-            const size_t at = t.size();
-            t.insert(t.end(), t.begin() + (ptrdiff_t)q0, t.begin() + (ptrdiff_t)(q0 + ql));
-            t.insert(t.end(), sl[m][i] - ql, '\0');
-            qs[m][i] = at;
-          }
-        }
+        const char* t = pc[m]->data;
         woff[m * n] = w0;
-        if (n && rfx_pack_spans(t.data(), ss[m].data(), sl[m].data(), qs[m].data(), (uint32_t)n, min_q, RFX_PACK_FILTER,
-                                codes.data(), nullptr, good.data(), woff.data() + m * n, lens.data() + m * n) != RFX_OK)
-          die("rufus_amd: pack failed");
+        // Runs of ordinary reads are packed in place.  A quality line shorter than its read would make the packer
+        // read the next line's bytes: such a read is packed on its own from a private copy of its sequence and
+        // quality string, the latter padded with '\0' (= bad, what the reference's missing chars are).
+        size_t at = 0;
+        while (at < n) {
+          size_t run = at;
+          auto qlen = [&](size_t i) {
+            const uint64_t q0 = ls[m][4 * i + 3], q1 = ls[m][4 * i + 4];
+            return q1 > q0 ? (uint32_t)(q1 - q0 - 1) : 0u;
+          };
+          while (run < n && qlen(run) >= sl[m][run]) ++run;
+          if (run > at &&
+              rfx_pack_spans(t, ss[m].data() + at, sl[m].data() + at, qs[m].data() + at, (uint32_t)(run - at), min_q,
+                             RFX_PACK_FILTER, codes, nullptr, good, woff + m * n + at, lens + m * n + at) != RFX_OK)
+            die("rufus_amd: pack failed");
+          if (run < n) {
+            const uint32_t L = sl[m][run], ql = qlen(run);
+            fix.assign((size_t)2 * L, '\0');
+            memcpy(fix.data(), t + ss[m][run], L);
+            memcpy(fix.data() + L, t + qs[m][run], ql);
+            const uint64_t s0 = 0, q0 = L;
+            if (rfx_pack_spans(fix.data(), &s0, &L, &q0, 1, min_q, RFX_PACK_FILTER, codes, nullptr, good,
+                               woff + m * n + run, lens + m * n + run) != RFX_OK)
+              die("rufus_amd: pack failed");
+            ++run;
+          }
+          at = run;
+        }
         w0 = woff[(m + 1) * n];
       }
       mask.assign((nr + 63) / 64, 0);
       if (single) hits.assign(nr, 0);
       {
         std::lock_guard<std::mutex> g(dev_mu);
-        rfx_reads* rd = rfx_reads_upload(ctx, codes.data(), nullptr, good.data(), woff.data(), lens.data(), (uint32_t)nr);
+        rfx_reads* rd = rfx_reads_upload(ctx, codes, nullptr, good, woff, lens, (uint32_t)nr);
         if (!rd) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
         uint64_t nh = 0;
         // paired tool: `i < length()-1`, the last base is never examined (src/RUFUS.Filter.cpp:203)
@@ -277,11 +378,11 @@ int main(int argc, char** argv) {
       res.recs = n;
       auto bit = [&](size_t r) { return (mask[r >> 6] >> (r & 63)) & 1; };
       auto put = [&](std::string& o, int m, size_t i, const char* suffix) {
-        const std::vector<char>& t = pc[m]->text;
+        const char* t = pc[m]->data;
         for (int j = 0; j < 4; ++j) {
           const uint64_t a0 = ls[m][4 * i + j], a1 = ls[m][4 * i + j + 1];
           const size_t len = a1 > a0 ? (size_t)(a1 - a0 - 1) : 0;
-          o.append(t.data() + a0, len);
+          o.append(t + a0, len);
           if (j == 0 && suffix) o.append(suffix);
           o.push_back('\n');
         }

@@ -6,6 +6,7 @@ import os
 import subprocess
 import threading
 
+import numpy as np
 import pytest
 
 from tests.conftest import ROOT
@@ -95,6 +96,63 @@ def test_filter_reads_lock_step_named_pipes(testrun, tmp_path):
     for m in (1, 2):
         data = open(f"{d}/piped.Mutations.Mate{m}.fastq", "rb").read()
         assert hashlib.sha256(data).hexdigest() == exp["filter_paired_sha256"][str(m)]
+
+
+@pytest.mark.parametrize("route", ["mapped", "read", "pipe"])
+def test_filter_pieces_and_ragged_records_match_the_reference_binary(tmp_path, route):
+    """More records than one pipeline piece (65536), reads of every length from 26 up, N and lower-case bases, low
+    qualities, no newline after the last record -- through the mapped-file, the read() and the pipe route of the
+    reader; byte-identical to the reference's own binary (one thread: its output order is then input order)."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "RUFUS.Filter")
+    if not os.path.exists(ref):
+        pytest.skip("oracle/_ref not built")
+    from rufus_amd import capi
+    d = str(tmp_path)
+    n_pairs, G = 70_000, 700_000
+    sy = capi.Synth.sample(G, 0, n_snv=40, seed=7)
+    seq, qual = sy.text(0, n_pairs)
+    rng = np.random.default_rng(5)
+    cut = rng.integers(26, 151, 2 * n_pairs)
+    cut[rng.random(2 * n_pairs) < 0.5] = 150
+    low = rng.random(2 * n_pairs) < 0.01
+    mates = [[], []]
+    for r in range(2 * n_pairs):
+        s_, q_ = bytearray(seq[r, :cut[r]].tobytes()), bytearray(qual[r, :cut[r]].tobytes())
+        if low[r]:
+            s_[5:9] = bytes(s_[5:9]).lower()
+            q_[10:14] = b"####"
+        mates[r & 1].append(b"@r%d/%d\n%s\n+\n%s\n" % (r >> 1, (r & 1) + 1, bytes(s_), bytes(q_)))
+    m1, m2 = b"".join(mates[0]), b"".join(mates[1])[:-1]        # mate 2: no final newline
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    with open(f"{d}/hl", "w") as f:
+        for p_, _, alt in sy.snvs():
+            c = bytearray(sy.genome(p_ - 24, 49))
+            c[24:25] = alt
+            for i in range(25):
+                km = bytes(c[i:i + 25])
+                f.write(min(km, km[::-1].translate(comp)).decode() + " 12\n")
+    open(f"{d}/m1.fq", "wb").write(m1)
+    open(f"{d}/m2.fq", "wb").write(m2)
+    r = sh([ref, "hl", "m1.fq", "m2.fq", "ref", "25", "15", "1", "1"], d, timeout=600)
+    assert r.returncode == 0
+    env = dict(os.environ)
+    args = [f"{BIN}/RUFUS.Filter", "hl", "m1.fq", "m2.fq", "out", "25", "15", "1", "5"]
+    if route == "read":
+        env["RFX_FILTER_NO_MMAP"] = "1"
+    if route == "pipe":
+        os.mkfifo(f"{d}/p1")
+        os.mkfifo(f"{d}/p2")
+        args[2:4] = ["p1", "p2"]
+        feeders = [threading.Thread(target=lambda a=a, b=b: open(f"{d}/{a}", "wb").write(b), daemon=True)
+                   for a, b in (("p1", m1), ("p2", m2))]
+        for t in feeders:
+            t.start()
+    r = subprocess.run(args, cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for m in (1, 2):
+        got = open(f"{d}/out.Mutations.Mate{m}.fastq", "rb").read()
+        want = open(f"{d}/ref.Mutations.Mate{m}.fastq", "rb").read()
+        assert len(want) > 10_000 and got == want
 
 
 def test_count_reads_a_named_pipe_and_several_files(testrun, tmp_path):

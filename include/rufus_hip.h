@@ -268,6 +268,11 @@ int rfx_records_get(const rfx_records*, uint64_t* keys, uint32_t* counts, uint64
 /* Load a payload read from a .Jhash file back into HBM (verifies (pos,key) order). */
 rfx_records* rfx_records_load(rfx_ctx*, int k, int lsize, const uint64_t* cols, const void* payload, uint64_t n,
                               int counter_len);
+/* The same straight from an open .Jhash file: n records at byte `offset` of fd, streamed through a ring of
+ * page-locked buffers (several threads pread, the copies and the parsing overlap) -- neither a host copy of the
+ * payload nor a device copy of it is ever whole (a 30x sample's file is 35 GB).  The file is only read. */
+rfx_records* rfx_records_load_fd(rfx_ctx*, int k, int lsize, const uint64_t* cols, int fd, uint64_t offset, uint64_t n,
+                                 int counter_len);
 rfx_records* rfx_records_from_dev(rfx_ctx*, int k, int lsize, const uint64_t* cols, const uint64_t* d_keys,
                                   const uint32_t* d_counts, uint64_t n); /* copies; computes pos */
 const uint64_t* rfx_records_dev_keys(const rfx_records*);

@@ -85,6 +85,7 @@ SIGNATURES = {
     "rfx_records_payload_range": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_int]),
     "rfx_records_get": (C.c_int, [C.c_void_p, u64p, u32p, u64p]),
     "rfx_records_load": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, u64p, C.c_void_p, C.c_uint64, C.c_int]),
+    "rfx_records_load_fd": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, u64p, C.c_int, C.c_uint64, C.c_uint64, C.c_int]),
     "rfx_records_from_dev": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, u64p, C.c_void_p, C.c_void_p, C.c_uint64]),
     "rfx_records_dev_keys": (C.c_void_p, [C.c_void_p]),
     "rfx_records_dev_counts": (C.c_void_p, [C.c_void_p]),
@@ -416,6 +417,16 @@ class Records:
         n = len(payload) // rl
         buf = np.frombuffer(payload, dtype=np.uint8)
         h = lib().rfx_records_load(ctx._h, k, lsize, _p(cols, u64p), buf.ctypes.data if n else None, n, counter_len)
+        return cls(ctx, h)
+
+    @classmethod
+    def load_fd(cls, ctx: Context, k: int, lsize: int, cols: np.ndarray, fd: int, offset: int, n: int,
+                counter_len: int = 4):
+        """n records at byte `offset` of an open .Jhash file, streamed (no whole copy of the payload anywhere)."""
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        h = lib().rfx_records_load_fd(ctx._h, k, lsize, _p(cols, u64p), fd, offset, n, counter_len)
+        if not h:
+            raise RufusError("rfx_records_load_fd: " + lib().rfx_last_error().decode())
         return cls(ctx, h)
 
     @classmethod

@@ -201,13 +201,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   write_jhash(out, rec, cols.data(), canonical, out_counter_len, full_argc, full_argv,
               ingest ? ingest->lend_buffers(48u << 20) : std::vector<std::pair<char*, size_t>>(), prealloc.take());
   trace("count: output closed");
-  if (!timing && !getenv("RFX_CLEAN_EXIT")) {
-    // Nothing is left to do but hand memory back: unpinning ~1 GB of staging blocks and unmapping the device arena
-    // call by call takes 0.2 s (measured; 15 % of the whole run on a 64 M-read input) -- the kernel does the same
-    // at process exit anyway.
-    fflush(nullptr);
-    _exit(0);
-  }
+  if (!timing) leave(0);
   ingest.reset();
   rfx_records_free(rec);
   rfx_count_free(tab);
@@ -247,15 +241,19 @@ static int histo_main(int argc, char** argv) {
   if (low != 1 || high != 10000 || inc != 1)
     die("rufus_amd jellyfish histo: only the default --low 1 --high 10000 --increment 1 is supported");
   rfx_ctx* ctx = open_ctx();
+  trace("histo: device open");
   JhashHeader h;
   rfx_records* rec = load_records(ctx, argv[optind], h);
+  trace("histo: records loaded");
   std::vector<uint64_t> hist(RFX_HISTO_BINS);
   if (rfx_records_histo(rec, hist.data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+  trace("histo: counted");
   FILE* f = out ? fopen(out, "w") : stdout;
   if (!f) die(std::string("Error opening output file '") + out + "'");
   for (int i = 0; i < RFX_HISTO_BINS; ++i)  // jf/sub_commands/histo_main.cc:82-84
     if (hist[(size_t)i] > 0 || full) fprintf(f, "%d %llu\n", i, (unsigned long long)hist[(size_t)i]);
   if (out) fclose(f);
+  leave(0);
   rfx_records_free(rec);
   rfx_close(ctx);
   return 0;
@@ -317,6 +315,7 @@ static int query_main(int argc, char** argv) {
   if (!f) die(std::string("Error opening output file '") + out + "'");
   for (size_t i = 0; i < keys.size(); ++i) fprintf(f, "%s %u\n", key_to_text(keys[i], k).c_str(), counts[i]);
   if (out) fclose(f);
+  leave(0);
   rfx_records_free(rec);
   rfx_close(ctx);
   return 0;
@@ -357,6 +356,7 @@ static int dump_main(int argc, char** argv) {
     else fprintf(f, ">%u\n%s\n", counts[i], key_to_text(keys[i], h.k).c_str());
   }
   if (out) fclose(f);
+  leave(0);
   rfx_records_free(rec);
   rfx_close(ctx);
   return 0;
@@ -399,6 +399,7 @@ static int merge_main(int argc, char** argv, int full_argc, char** full_argv) {
       fwrite(hdr.data(), 1, (size_t)hl, f);
       fclose(f);
     }
+  leave(0);
   for (auto* r : files) rfx_records_free(r);
   rfx_close(ctx);
   return 0;

@@ -5,7 +5,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <cerrno>
 #include <queue>
+#include <thread>
+#include <vector>
+
+#include <unistd.h>
 
 #include "rfx_internal.h"
 
@@ -2340,6 +2346,89 @@ rfx_records* rfx_records_load(rfx_ctx* c, int k, int lsize, const uint64_t* cols
   }
   dfree(c, d);
   dfree(c, d_bad);
+  if (ok && bad) {
+    snprintf(g_err, sizeof g_err, "records are not in (pos,key) order for this matrix");
+    ok = false;
+  }
+  if (!ok) {
+    rfx_records_free(r);
+    return nullptr;
+  }
+  return r;
+}
+
+rfx_records* rfx_records_load_fd(rfx_ctx* c, int k, int lsize, const uint64_t* cols, int fd, uint64_t offset, uint64_t n,
+                                 int counter_len) {
+  if (!c || !cols || k < 1 || k > 32 || counter_len < 1 || counter_len > 8 || fd < 0) return nullptr;
+  (void)hipSetDevice(c->device);
+  rfx_records* r = records_alloc(c, k, lsize, cols, n);
+  if (!r || n == 0) return r;
+  const int kb = (2 * k + 7) / 8;
+  const size_t rl = (size_t)kb + (size_t)counter_len;
+  constexpr int NB = 3;
+  const uint64_t step = std::min<uint64_t>(n, 8ull << 20);
+  uint8_t* pin[NB] = {nullptr, nullptr, nullptr};
+  uint8_t* dev[NB] = {nullptr, nullptr, nullptr};
+  hipEvent_t done[NB];
+  bool ok = true, have_ev[NB] = {false, false, false};
+  const int nb = (int)std::min<uint64_t>(NB, (n + step - 1) / step);
+  for (int i = 0; i < nb && ok; ++i) {
+    ok = hipHostMalloc((void**)&pin[i], step * rl, hipHostMallocDefault) == hipSuccess && (dev[i] = (uint8_t*)dmalloc(c, step * rl)) &&
+         hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
+    have_ev[i] = ok;
+  }
+  unsigned int* d_bad = (unsigned int*)dmalloc(c, 4);
+  unsigned int bad = 0;
+  ok = ok && d_bad && hipMemsetAsync(d_bad, 0, 4, c->stream) == hipSuccess;
+  const unsigned nt = std::max(1u, std::min(8u, rfx_host_cpus()));
+  std::atomic<bool> io_ok{true};
+  uint64_t at = 0;
+  for (uint64_t i = 0; at < n && ok; ++i, at += step) {
+    const int bi = (int)(i % NB);
+    const uint64_t m = std::min(step, n - at);
+    if (i >= (uint64_t)NB) ok = hipEventSynchronize(done[bi]) == hipSuccess;  // its last upload has left the buffer
+    if (!ok) break;
+    {  // several readers: one pread stream from the page cache (or a disk) does not keep up with the link
+      const size_t bytes = (size_t)m * rl;
+      const unsigned parts = bytes >= (8u << 20) ? nt : 1;
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < parts; ++t) {
+        const size_t lo = bytes * t / parts, hi = bytes * (t + 1) / parts;
+        auto job = [&, lo, hi] {
+          size_t got = lo;
+          while (got < hi) {
+            const ssize_t w = ::pread(fd, pin[bi] + got, hi - got, (off_t)(offset + at * rl + got));
+            if (w < 0 && errno == EINTR) continue;
+            if (w <= 0) { io_ok = false; return; }
+            got += (size_t)w;
+          }
+        };
+        if (t + 1 < parts) th.emplace_back(job);
+        else job();
+      }
+      for (auto& x : th) x.join();
+    }
+    if (!io_ok) {
+      snprintf(g_err, sizeof g_err, "short read: the file holds fewer records than its size says");
+      ok = false;
+      break;
+    }
+    ok = hipMemcpyAsync(dev[bi], pin[bi], (size_t)m * rl, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+         hipEventRecord(done[bi], c->stream) == hipSuccess;
+    if (ok) rfxk::parse_records(c, dev[bi], m, kb, counter_len, r->keys + at, r->counts + at);
+  }
+  if (ok) {
+    rfxk::compute_pos(c, r->keys, n, r->lut, r->ntab, r->pos);
+    rfxk::check_sorted(c, r->keys, r->pos, n, d_bad);
+    ok = queue_read(c, &bad, d_bad, 4) == hipSuccess;
+  }
+  ok = (ctx_sync(c) == hipSuccess) && ok;
+  for (int i = 0; i < NB; ++i) {
+    if (have_ev[i]) (void)hipEventDestroy(done[i]);
+    if (pin[i]) (void)hipHostFree(pin[i]);
+    if (dev[i]) dfree(c, dev[i]);
+  }
+  if (d_bad) dfree(c, d_bad);
   if (ok && bad) {
     snprintf(g_err, sizeof g_err, "records are not in (pos,key) order for this matrix");
     ok = false;

@@ -331,3 +331,42 @@ def test_trio_takes_more_passes_when_a_pass_does_not_fit(monkeypatch):
         assert trio.passes > 1, small.mem_stats()
         assert tools.keys_to_text(res["mutant_keys"], K) == [ln.split()[0] for ln in hl_o.splitlines()]
         assert res["n_pulled"] == len(pulled_o)
+
+
+def test_records_load_fd_streams_a_file_in_chunks(ctx, tmp_path):
+    """A .Jhash payload of three 8 M-record chunks: rfx_records_load_fd (pread ring -> parse at an offset) gives the
+    same records as rfx_records_load of the whole payload; a truncated file and records out of order are refused."""
+    G = 4_000_000
+    sy = capi.Synth.sample(G, 0, n_snv=10, seed=4242)
+    blocks = wgs.make_sample(ctx, sy, 600_000, want_good=False)
+    t = capi.CountTable(ctx, K, SIZE, mode=capi.COUNT_MSP)
+    for b in blocks:
+        t.add(b)
+    rec = t.finish(1)
+    n = len(rec)
+    assert n > (16 << 20), n
+    lsize, cols = capi.ceil_log2(SIZE), capi.jf_matrix(capi.ceil_log2(SIZE), K)
+    for clen in (4, 2):
+        payload = rec.payload(clen)
+        rl = 7 + clen
+        path = str(tmp_path / f"p{clen}.bin")
+        with open(path, "wb") as f:
+            f.write(b"x" * 1234 + payload)
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            got = capi.Records.load_fd(ctx, K, lsize, cols, fd, 1234, n, clen)
+            want = capi.Records.load(ctx, K, lsize, cols, payload, clen)
+            for a, b in zip(got.get(), want.get()):
+                assert np.array_equal(a, b)
+            if clen == 4:
+                assert np.array_equal(got.get()[0], rec.get()[0]) and np.array_equal(got.get()[1], rec.get()[1])
+            got.free()
+            want.free()
+            with pytest.raises(capi.RufusError, match="short read"):
+                capi.Records.load_fd(ctx, K, lsize, cols, fd, 1234, n + 5, clen)
+            with pytest.raises(capi.RufusError, match="order"):
+                capi.Records.load_fd(ctx, K, lsize, cols, fd, 1234 + rl * 3 + 1, n - 10, clen)
+        finally:
+            os.close(fd)
+    for x in blocks + [t, rec]:
+        x.free()

@@ -121,7 +121,7 @@ def cpu_baseline():
     return out
 
 
-def end_to_end(n_pairs=12_000_000):
+def end_to_end(n_pairs=32_000_000):
     """the path through the DROP-IN EXECUTABLES, text in -> files out, process start and HIP init
     included: rfx_synth_fastq writes a bounded 30x sample of the same synthetic trio as FASTQ (tmpfs when there is
     one); then, as runRufus.sh does, `jellyfish count` x 3 -> modified `jellyfish merge` -> `jellyfish query` + the
@@ -150,15 +150,15 @@ def end_to_end(n_pairs=12_000_000):
         for w, name in enumerate(("child", "mother", "father")):
             if w == 0:
                 run("generate", [f"{B}/rfx_synth_fastq", str(G), "0", str(n_snv), str(SEED), "0", str(n_pairs), "c.m1.fq", "c.m2.fq"])
-                run("generate", ["sh", "-c", "cat c.m1.fq c.m2.fq > child.fq"])
             else:
                 run("generate", [f"{B}/rfx_synth_fastq", str(G), str(w), str(n_snv), str(SEED), "0", str(n_pairs), f"{name}.fq"])
         out["generate_s (not counted)"] = round(time.perf_counter() - t_gen, 2)
         out["stages_s"].pop("generate", None)
         t0 = time.perf_counter()
         for name in ("child", "mother", "father"):
+            files = ["c.m1.fq", "c.m2.fq"] if name == "child" else [f"{name}.fq"]   # (the filter wants the mates apart)
             run("jellyfish count", [f"{B}/jellyfish", "count", "--disk", "-m", str(K), "-L", str(LOWER), "-s", "8G", "-t", T,
-                                    "-o", f"{name}.Jhash", "-C", f"{name}.fq"])
+                                    "-o", f"{name}.Jhash", "-C"] + files)
             run("jellyfish histo", [f"{B}/jellyfish", "histo", "-f", "-o", f"{name}.Jhash.histo", f"{name}.Jhash"])
         run("jellyfish merge", [f"{B}/jellyfish", "merge", "child.Jhash", "mother.Jhash", "father.Jhash"], stdout="merge.txt")
         t1 = time.perf_counter()

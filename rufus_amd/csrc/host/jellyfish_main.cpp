@@ -382,13 +382,42 @@ static int merge_main(int argc, char** argv, int full_argc, char** full_argv) {
     if (hs[i].lsize != hs[0].lsize) die("Can't merge hash with different size");
     if (hs[i].cols != hs[0].cols) die("Can't merge hash with different hash function");
   }
-  uint64_t cap = 0, n = 0;
-  for (auto* r : files) cap += rfx_records_size(r);
+  // The result is a small part of the inputs (k-mers private to one sample): room for 64 M of them first, the
+  // exact number -- which a short call reports -- if that was not enough.  (Sizing by the inputs would be 115 GB
+  // of host memory for a 30x trio.)
+  uint64_t total = 0, n = 0;
+  for (auto* r : files) total += rfx_records_size(r);
+  uint64_t cap = std::min<uint64_t>(total, 64ull << 20);
   std::vector<uint64_t> keys(cap + 1);
   std::vector<uint32_t> counts(cap + 1);
-  const int rc = rfx_merge_unique(ctx, files.data(), (int)files.size(), 5, keys.data(), counts.data(), cap, &n);
+  int rc = rfx_merge_unique(ctx, files.data(), (int)files.size(), 5, keys.data(), counts.data(), cap, &n);
+  if (rc == RFX_E_RANGE && n > cap) {
+    cap = n;
+    keys.resize(cap + 1);
+    counts.resize(cap + 1);
+    rc = rfx_merge_unique(ctx, files.data(), (int)files.size(), 5, keys.data(), counts.data(), cap, &n);
+  }
   if (rc) die(std::string("rufus_amd: merge failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
-  for (uint64_t i = 0; i < n; ++i) printf("%s\t%u\n", key_to_text(keys[i], hs[0].k).c_str(), counts[i]);
+  {  // formatted by hand: printf + std::string per line is 10x slower, and the list can have 1e8 lines
+    std::vector<char> line((size_t)1 << 20);
+    size_t fill = 0;
+    const int kk = hs[0].k;
+    for (uint64_t i = 0; i < n; ++i) {
+      if (fill + (size_t)kk + 16 > line.size()) {
+        fwrite(line.data(), 1, fill, stdout);
+        fill = 0;
+      }
+      for (int b = 0; b < kk; ++b) line[fill++] = "ACGT"[(keys[i] >> (2 * (kk - 1 - b))) & 3u];
+      line[fill++] = '\t';
+      char dig[12];
+      int nd = 0;
+      uint32_t v = counts[i];
+      do { dig[nd++] = (char)('0' + v % 10); v /= 10; } while (v);
+      while (nd) line[fill++] = dig[--nd];
+      line[fill++] = '\n';
+    }
+    fwrite(line.data(), 1, fill, stdout);
+  }
   fflush(stdout);
   // the reference leaves a header-only database behind (merge_files.cc:207-224; testRun/clean.sh:1 removes it)
   std::vector<char> hdr(1 << 16);

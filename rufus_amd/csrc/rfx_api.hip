@@ -2494,25 +2494,25 @@ int rfx_merge_unique(rfx_ctx* c, const rfx_records* const* files, int n_files, u
     int rc = unique_run(c, files[i], files, n_files, min_count, 0xFFFFFFFFu, runs[i]);
     if (rc) return rc;
   }
-  // k-way merge of the per-file runs by (pos, key): each run is already sorted.
-  struct Head { uint64_t pos, key; int f; size_t i; };
-  auto gt = [](const Head& a, const Head& b) { return a.pos != b.pos ? a.pos > b.pos : a.key > b.key; };
-  std::priority_queue<Head, std::vector<Head>, decltype(gt)> pq(gt);
+  // k-way merge of the per-file runs by (pos, key): each run is already sorted, and k is a handful (a trio: 3) --
+  // the smallest head is found by looking at all of them, which beats a heap until k is in the dozens.
   uint64_t total = 0;
-  for (int f = 0; f < n_files; ++f) {
-    total += runs[f].keys.size();
-    if (!runs[f].keys.empty()) pq.push(Head{runs[f].pos[0], runs[f].keys[0], f, 0});
-  }
+  for (int f = 0; f < n_files; ++f) total += runs[f].keys.size();
   *n_out = total;
   if (total > cap) return RFX_E_RANGE;
-  uint64_t o = 0;
-  while (!pq.empty()) {
-    Head h = pq.top();
-    pq.pop();
-    if (keys_out) keys_out[o] = h.key;
-    if (counts_out) counts_out[o] = runs[h.f].counts[h.i];
-    ++o;
-    if (h.i + 1 < runs[h.f].keys.size()) pq.push(Head{runs[h.f].pos[h.i + 1], runs[h.f].keys[h.i + 1], h.f, h.i + 1});
+  std::vector<size_t> at((size_t)n_files, 0);
+  for (uint64_t o = 0; o < total; ++o) {
+    int best = -1;
+    uint64_t bp = 0, bk = 0;
+    for (int f = 0; f < n_files; ++f) {
+      const size_t i = at[(size_t)f];
+      if (i >= runs[f].keys.size()) continue;
+      const uint64_t p = runs[f].pos[i], k_ = runs[f].keys[i];
+      if (best < 0 || p < bp || (p == bp && k_ < bk)) best = f, bp = p, bk = k_;
+    }
+    if (keys_out) keys_out[o] = bk;
+    if (counts_out) counts_out[o] = runs[best].counts[at[(size_t)best]];
+    ++at[(size_t)best];
   }
   return RFX_OK;
 }

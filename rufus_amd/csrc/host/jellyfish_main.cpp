@@ -93,8 +93,14 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   }
   // ~11 bytes of output per distinct solid k-mer: 0.18 of the FASTQ bytes at 30x, less on shallow or filtered input
   OutputPrealloc prealloc;
-  if (!any_stream && known_bytes > (256u << 20) && !getenv("RFX_NO_PREALLOC"))
-    prealloc.start(out, (uint64_t)(known_bytes * 0.19));
+  {
+    size_t min_bytes = 256u << 20;  // RFX_PREALLOC_MIN / RFX_PREALLOC_FRAC: the tests reach both sides of the guess
+    double frac = 0.19;
+    if (const char* ev = getenv("RFX_PREALLOC_MIN")) min_bytes = (size_t)strtoull(ev, nullptr, 10);
+    if (const char* ev = getenv("RFX_PREALLOC_FRAC")) frac = atof(ev);
+    if (!any_stream && known_bytes > min_bytes && !getenv("RFX_NO_PREALLOC"))
+      prealloc.start(out, (uint64_t)((double)known_bytes * frac));
+  }
   unsigned nthreads = (unsigned)std::max(1, threads);
   nthreads = std::min(nthreads, rfx_host_cpus());  // -t 40 on a 16-CPU cgroup: 16 parsers
   if (const char* ev = getenv("RFX_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(ev));
@@ -198,8 +204,10 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   for (rfx_reads* r : resident) rfx_reads_free(r);
   std::vector<uint64_t> cols(2 * (size_t)k);
   rfx_jf_matrix(lsize, k, cols.data());
+  const int out_fd = prealloc.take();
   write_jhash(out, rec, cols.data(), canonical, out_counter_len, full_argc, full_argv,
-              ingest ? ingest->lend_buffers(48u << 20) : std::vector<std::pair<char*, size_t>>(), prealloc.take());
+              ingest ? ingest->lend_buffers(48u << 20) : std::vector<std::pair<char*, size_t>>(), out_fd,
+              prealloc.reached());
   trace("count: output closed");
   if (!timing) leave(0);
   ingest.reset();

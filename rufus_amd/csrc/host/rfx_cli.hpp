@@ -475,6 +475,7 @@ class OutputPrealloc {
   int fd_ = -1;
   std::thread th_;
   std::atomic<bool> stop_{false};
+  std::atomic<uint64_t> reached_{0};
 
  public:
   void start(const char* path, uint64_t bytes) {
@@ -482,10 +483,13 @@ class OutputPrealloc {
     if (fd_ < 0 || bytes == 0) return;
     th_ = std::thread([this, bytes] {
       const uint64_t step = 256ull << 20;
-      for (uint64_t at = 0; at < bytes && !stop_.load(std::memory_order_relaxed); at += step)
+      for (uint64_t at = 0; at < bytes && !stop_.load(std::memory_order_relaxed); at += step) {
         if (::fallocate(fd_, FALLOC_FL_KEEP_SIZE, (off_t)at, (off_t)std::min(step, bytes - at)) != 0) break;
+        reached_ = at + std::min(step, bytes - at);
+      }
     });
   }
+  uint64_t reached() const { return reached_; }  // bytes allocated so far (valid after take())
   // stops the thread; the descriptor (or -1: the writer opens the file itself and reports the error) goes to the caller
   int take() {
     stop_ = true;
@@ -503,7 +507,8 @@ class OutputPrealloc {
 // `lend`: page-locked buffers the caller no longer needs (the ingest's staging blocks), used as the drain ring
 // instead of pinning more memory.
 inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols, bool canonical, int counter_len,
-                        int argc, char** argv, const std::vector<std::pair<char*, size_t>>& lend = {}, int open_fd = -1) {
+                        int argc, char** argv, const std::vector<std::pair<char*, size_t>>& lend = {}, int open_fd = -1,
+                        uint64_t preallocated = 0) {
   const int k = rfx_records_k(rec), lsize = rfx_records_lsize(rec);
   std::vector<char> hdr(1 << 16);
   const long hl = rfx_jhash_header(k, lsize, cols, canonical, counter_len, argc, argv, hdr.data(), hdr.size());
@@ -529,6 +534,8 @@ inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols
   // pwrite threads gave 3.8 GB/s into tmpfs, one thread's worth -- page faults of a mapping do not.
   const uint64_t total = (uint64_t)hl + n * rl;
   char* map = nullptr;
+  // blocks preallocated past the end: ext4 keeps them when the size only grows -- grow over them, then cut back
+  if (preallocated > total) (void)!::ftruncate(fd, (off_t)preallocated);
   if (n && ::ftruncate(fd, (off_t)total) == 0) {
     void* m = mmap(nullptr, (size_t)total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     if (m != MAP_FAILED) map = (char*)m;

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <queue>
 #include <thread>
 #include <vector>
@@ -642,6 +643,8 @@ void rfx_close(rfx_ctx* c) {
   arena_destroy(c);
   for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
   if (c->pin) (void)hipHostFree(c->pin);
+  for (uint8_t* p : c->load_pin)
+    if (p) (void)hipHostFree(p);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -2361,8 +2364,13 @@ rfx_records* rfx_records_load_fd(rfx_ctx* c, int k, int lsize, const uint64_t* c
                                  int counter_len) {
   if (!c || !cols || k < 1 || k > 32 || counter_len < 1 || counter_len > 8 || fd < 0) return nullptr;
   (void)hipSetDevice(c->device);
+  const bool tr = getenv("RFX_TRACE_LOAD") != nullptr;  // phase times on stderr
+  const auto t0 = std::chrono::steady_clock::now();
+  auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+  double t_read = 0;
   rfx_records* r = records_alloc(c, k, lsize, cols, n);
   if (!r || n == 0) return r;
+  if (tr) fprintf(stderr, "[load_fd %.3f] records allocated (%llu)\n", since(), (unsigned long long)n);
   const int kb = (2 * k + 7) / 8;
   const size_t rl = (size_t)kb + (size_t)counter_len;
   constexpr int NB = 3;
@@ -2372,14 +2380,24 @@ rfx_records* rfx_records_load_fd(rfx_ctx* c, int k, int lsize, const uint64_t* c
   hipEvent_t done[NB];
   bool ok = true, have_ev[NB] = {false, false, false};
   const int nb = (int)std::min<uint64_t>(NB, (n + step - 1) / step);
+  if (c->load_pin_bytes < step * rl) {  // (a ring kept from an earlier load that is too small: start over)
+    for (int i = 0; i < NB; ++i) {
+      if (c->load_pin[i]) (void)hipHostFree(c->load_pin[i]);
+      c->load_pin[i] = nullptr;
+    }
+    c->load_pin_bytes = step * rl;
+  }
   for (int i = 0; i < nb && ok; ++i) {
-    ok = hipHostMalloc((void**)&pin[i], step * rl, hipHostMallocDefault) == hipSuccess && (dev[i] = (uint8_t*)dmalloc(c, step * rl)) &&
+    if (!c->load_pin[i]) ok = hipHostMalloc((void**)&c->load_pin[i], c->load_pin_bytes, hipHostMallocDefault) == hipSuccess;
+    pin[i] = c->load_pin[i];
+    ok = ok && (dev[i] = (uint8_t*)dmalloc(c, step * rl)) &&
          hipEventCreateWithFlags(&done[i], hipEventDisableTiming) == hipSuccess;
     have_ev[i] = ok;
   }
   unsigned int* d_bad = (unsigned int*)dmalloc(c, 4);
   unsigned int bad = 0;
   ok = ok && d_bad && hipMemsetAsync(d_bad, 0, 4, c->stream) == hipSuccess;
+  if (tr) fprintf(stderr, "[load_fd %.3f] ring pinned\n", since());
   const unsigned nt = std::max(1u, std::min(8u, rfx_host_cpus()));
   std::atomic<bool> io_ok{true};
   uint64_t at = 0;
@@ -2389,6 +2407,8 @@ rfx_records* rfx_records_load_fd(rfx_ctx* c, int k, int lsize, const uint64_t* c
     if (i >= (uint64_t)NB) ok = hipEventSynchronize(done[bi]) == hipSuccess;  // its last upload has left the buffer
     if (!ok) break;
     {  // several readers: one pread stream from the page cache (or a disk) does not keep up with the link
+      const double ta = since();
+      struct Acc { double& t; double a; decltype(since)& f; ~Acc() { t += f() - a; } } acc{t_read, ta, since};
       const size_t bytes = (size_t)m * rl;
       const unsigned parts = bytes >= (8u << 20) ? nt : 1;
       std::vector<std::thread> th;
@@ -2422,10 +2442,11 @@ rfx_records* rfx_records_load_fd(rfx_ctx* c, int k, int lsize, const uint64_t* c
     rfxk::check_sorted(c, r->keys, r->pos, n, d_bad);
     ok = queue_read(c, &bad, d_bad, 4) == hipSuccess;
   }
+  if (tr) fprintf(stderr, "[load_fd %.3f] all chunks queued (%.3f s in pread)\n", since(), t_read);
   ok = (ctx_sync(c) == hipSuccess) && ok;
+  if (tr) fprintf(stderr, "[load_fd %.3f] device done\n", since());
   for (int i = 0; i < NB; ++i) {
     if (have_ev[i]) (void)hipEventDestroy(done[i]);
-    if (pin[i]) (void)hipHostFree(pin[i]);
     if (dev[i]) dfree(c, dev[i]);
   }
   if (d_bad) dfree(c, d_bad);

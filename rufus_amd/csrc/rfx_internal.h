@@ -61,6 +61,10 @@ struct rfx_ctx {
   // staging round trip each); a bump allocator that is reset at every stream synchronisation
   char* pin = nullptr;
   size_t pin_cap = 0, pin_used = 0;
+  // page-locked ring of rfx_records_load_fd, kept for the next load (pinning 280 MB and letting it go again costs
+  // 0.2 s, as much as reading a 3.7 GB database through it)
+  uint8_t* load_pin[3] = {nullptr, nullptr, nullptr};
+  size_t load_pin_bytes = 0;
   struct pin_read { void* dst; size_t off, n; };
   std::vector<pin_read> pin_reads;
   std::map<std::pair<int, uint64_t>, rfx_hash_consts> consts;  // (k*64+lsize, matrix digest) -> device tables

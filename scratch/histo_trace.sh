@@ -1,10 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 D=/dev/shm/rfx_h; mkdir -p $D; BIN=rufus_amd/bin
-$BIN/rfx_synth_fastq 120000000 0 100 12345 0 12000000 $D/reads.fq || exit 1
-RFX_CLI_TRACE=1 $BIN/jellyfish count --disk -m 25 -L 2 -s 8G -t 16 -o $D/out.Jhash -C $D/reads.fq
+$BIN/rfx_synth_fastq 320000000 0 100 12345 0 32000000 $D/reads.fq || exit 1
+RFX_CLI_TRACE=1 $BIN/jellyfish count --disk -m 25 -L 2 -s 8G -t 16 -o $D/out.Jhash -C $D/reads.fq 2>&1 | grep "finished\|parsed"
 ls -la $D/out.Jhash
-for i in 1 2; do s=$(date +%s.%N); RFX_CLI_TRACE=1 $BIN/jellyfish histo -f -o $D/h.txt $D/out.Jhash; e=$(date +%s.%N); python3 -c "print('histo wall %.2f' % ($e-$s))"; done
-s=$(date +%s.%N); $BIN/jellyfish --version; e=$(date +%s.%N); python3 -c "print('version wall %.3f' % ($e-$s))"
+for i in 1 2 3; do s=$(date +%s.%N); RFX_TRACE_LOAD=1 RFX_CLI_TRACE=1 $BIN/jellyfish histo -f -o $D/h.txt $D/out.Jhash; e=$(date +%s.%N); python3 -c "print('histo wall %.2f' % ($e-$s))"; done
 rm -rf $D
-timeout 600 python -m pytest tests/test_scale_gpu.py -x -q -k "load_fd" 2>&1 | grep -v "^$" | tail -30

@@ -3,8 +3,8 @@
 cd /tmp && export TMPDIR=/tmp
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/pmc_sq; rm -rf $O; mkdir -p $O
-timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/a -o s -- python bench.py --genome 1000000000 --steps 1 --warmup 0 --no-cpu-baseline > $O/a.log 2>&1
-timeout 900 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_VMEM --kernel-trace --output-format csv -d $O/b -o s -- python bench.py --genome 1000000000 --steps 1 --warmup 0 --no-cpu-baseline > $O/b.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/a -o s -- python bench.py --inner --genome 1000000000 --steps 1 --warmup 0 --no-cpu-baseline > $O/a.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVES SQ_INSTS_SMEM SQ_INSTS_VMEM --kernel-trace --output-format csv -d $O/b -o s -- python bench.py --inner --genome 1000000000 --steps 1 --warmup 0 --no-cpu-baseline > $O/b.log 2>&1
 python - <<'PY'
 import csv, collections, re, glob
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); calls = collections.Counter()

@@ -214,6 +214,15 @@ def test_count_cli_parallel_ingest_and_shard_passes(tmp_path):
 
     assert run("mapped.jf", "reads.fq") == ref
     assert run("seq.jf", "reads.fq", t="1") == ref
+    # the output's pages allocated ahead of time (inputs > 256 MB only, unless told otherwise): a guess far too
+    # large is cut back to the exact size, one far too small is topped up -- same file either way
+    whole = open(f"{d}/mapped.jf", "rb").read()
+    for frac in ("3.0", "0.001"):
+        assert run("pre.jf", "reads.fq", {"RFX_PREALLOC_MIN": "0", "RFX_PREALLOC_FRAC": frac}) == ref
+        blob = open(f"{d}/pre.jf", "rb").read()
+        assert len(blob) == 9 + int(blob[:9]) + len(ref)
+        assert os.stat(f"{d}/pre.jf").st_blocks * 512 < len(whole) + (1 << 20)     # nothing left allocated past the end
+    assert run("nopre.jf", "reads.fq", {"RFX_NO_PREALLOC": "1", "RFX_CLEAN_EXIT": "1"}) == ref
     assert run("defer.jf", "reads.fq", {"RFX_COUNT_DEFER": "1", "RFX_COUNT_PASSES": "3"}) == ref
     os.mkfifo(f"{d}/pipe.fq")
     feeder = threading.Thread(target=lambda: open(f"{d}/pipe.fq", "wb").write(open(f"{d}/reads.fq", "rb").read()))

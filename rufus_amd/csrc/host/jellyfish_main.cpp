@@ -285,8 +285,14 @@ static int query_main(int argc, char** argv) {
   }
   if (optind >= argc) die("Missing database");
   rfx_ctx* ctx = open_ctx();
-  JhashHeader h;
-  rfx_records* rec = load_records(ctx, argv[optind], h);
+  JhashFile db;
+  rfx_records* rec = nullptr;
+  const bool sliced = db.open(argv[optind]);
+  const JhashHeader& h = db.h;
+  if (!sliced) {
+    JhashHeader h2;
+    rec = load_records(ctx, argv[optind], h2);
+  }
   const int k = h.k;
   const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
   std::vector<uint64_t> keys;
@@ -318,13 +324,43 @@ static int query_main(int argc, char** argv) {
     keys.push_back(h.canonical ? std::min(key, revcomp_key(key, k)) : key);
   }
   std::vector<uint32_t> counts(keys.size() + 1);
-  if (rfx_query(rec, keys.data(), keys.size(), counts.data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+  if (!sliced) {
+    if (rfx_query(rec, keys.data(), keys.size(), counts.data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+  } else if (!keys.empty() && db.n) {
+    // The database stays on disk: it is cut into position ranges of ~64 M records (RFX_QUERY_SLICE_RECORDS), the
+    // queries are dealt to the ranges by their own position, and only ranges that got queries are read -- a few
+    // hundred MB of HBM whatever the database size, and several queries can run side by side
+    // (scripts/Overlap.shorter.sh:265-299 starts them with &).
+    uint64_t per = 64ull << 20;
+    if (const char* ev = getenv("RFX_QUERY_SLICE_RECORDS")) per = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
+    const uint64_t S = std::max<uint64_t>(1, (db.n + per - 1) / per);
+    std::vector<std::vector<uint32_t>> in_slice(S);
+    if (keys.size() > 0xFFFFFFFFull) die("rufus_amd jellyfish query: too many k-mers in one call");
+    for (size_t i = 0; i < keys.size(); ++i)
+      in_slice[slice_of(rfx_jf_pos(h.cols.data(), h.k, h.lsize, keys[i]), S, h.lsize)].push_back((uint32_t)i);
+    std::vector<uint64_t> sub;
+    std::vector<uint32_t> got;
+    for (uint64_t sidx = 0; sidx < S; ++sidx) {
+      if (in_slice[sidx].empty()) continue;
+      const uint64_t i0 = sidx == 0 ? 0 : db.lower_bound_pos(slice_start(sidx, S, h.lsize));
+      const uint64_t i1 = sidx + 1 == S ? db.n : db.lower_bound_pos(slice_start(sidx + 1, S, h.lsize));
+      if (i1 == i0) continue;  // an empty range: its queries count 0
+      rfx_records* part = db.load(ctx, i0, i1);
+      sub.clear();
+      for (uint32_t qi : in_slice[sidx]) sub.push_back(keys[qi]);
+      got.assign(sub.size() + 1, 0);
+      if (rfx_query(part, sub.data(), sub.size(), got.data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+      for (size_t j = 0; j < sub.size(); ++j) counts[in_slice[sidx][j]] = got[j];
+      rfx_records_free(part);
+    }
+  }
   FILE* f = out ? fopen(out, "w") : stdout;
   if (!f) die(std::string("Error opening output file '") + out + "'");
   for (size_t i = 0; i < keys.size(); ++i) fprintf(f, "%s %u\n", key_to_text(keys[i], k).c_str(), counts[i]);
   if (out) fclose(f);
   leave(0);
-  rfx_records_free(rec);
+  db.close();
+  if (rec) rfx_records_free(rec);
   rfx_close(ctx);
   return 0;
 }
@@ -382,32 +418,27 @@ static int merge_main(int argc, char** argv, int full_argc, char** full_argv) {
   }
   if (optind >= argc) die("Missing database");
   rfx_ctx* ctx = open_ctx();
-  std::vector<rfx_records*> files;
-  std::vector<JhashHeader> hs(argc - optind);
-  for (int i = optind; i < argc; ++i) files.push_back(load_records(ctx, argv[i], hs[i - optind]));
+  const int nf = argc - optind;
+  std::vector<JhashFile> jf((size_t)nf);
+  std::vector<JhashHeader> hs((size_t)nf);
+  std::vector<rfx_records*> whole((size_t)nf, nullptr);  // inputs that are not regular files: loaded as before
+  bool all_sliced = true;
+  for (int i = 0; i < nf; ++i) {
+    if (!jf[(size_t)i].open(argv[optind + i])) {
+      all_sliced = false;
+      whole[(size_t)i] = load_records(ctx, argv[optind + i], hs[(size_t)i]);
+    } else {
+      hs[(size_t)i] = jf[(size_t)i].h;
+    }
+  }
   for (size_t i = 1; i < hs.size(); ++i) {  // jf/jellyfish/merge_files.cc:193-203
     if (hs[i].k != hs[0].k) die("Can't merge hashes of different key lengths");
     if (hs[i].lsize != hs[0].lsize) die("Can't merge hash with different size");
     if (hs[i].cols != hs[0].cols) die("Can't merge hash with different hash function");
   }
-  // The result is a small part of the inputs (k-mers private to one sample): room for 64 M of them first, the
-  // exact number -- which a short call reports -- if that was not enough.  (Sizing by the inputs would be 115 GB
-  // of host memory for a 30x trio.)
-  uint64_t total = 0, n = 0;
-  for (auto* r : files) total += rfx_records_size(r);
-  uint64_t cap = std::min<uint64_t>(total, 64ull << 20);
-  std::vector<uint64_t> keys(cap + 1);
-  std::vector<uint32_t> counts(cap + 1);
-  int rc = rfx_merge_unique(ctx, files.data(), (int)files.size(), 5, keys.data(), counts.data(), cap, &n);
-  if (rc == RFX_E_RANGE && n > cap) {
-    cap = n;
-    keys.resize(cap + 1);
-    counts.resize(cap + 1);
-    rc = rfx_merge_unique(ctx, files.data(), (int)files.size(), 5, keys.data(), counts.data(), cap, &n);
-  }
-  if (rc) die(std::string("rufus_amd: merge failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
-  {  // formatted by hand: printf + std::string per line is 10x slower, and the list can have 1e8 lines
-    std::vector<char> line((size_t)1 << 20);
+  // formatted by hand: printf + std::string per line is 10x slower, and the list can have 1e8 lines
+  std::vector<char> line((size_t)1 << 20);
+  auto emit = [&](const uint64_t* keys, const uint32_t* counts, uint64_t n) {
     size_t fill = 0;
     const int kk = hs[0].k;
     for (uint64_t i = 0; i < n; ++i) {
@@ -425,6 +456,52 @@ static int merge_main(int argc, char** argv, int full_argc, char** full_argv) {
       line[fill++] = '\n';
     }
     fwrite(line.data(), 1, fill, stdout);
+  };
+  // The result is a small part of the inputs (k-mers private to one sample): room for 64 M of them first, the
+  // exact number -- which a short call reports -- if that was not enough.  (Sizing by the inputs would be 115 GB
+  // of host memory for a 30x trio.)
+  std::vector<uint64_t> keys;
+  std::vector<uint32_t> counts;
+  auto merge_and_emit = [&](const std::vector<rfx_records*>& files) {
+    uint64_t total = 0, n = 0;
+    for (auto* r : files) total += rfx_records_size(r);
+    uint64_t cap = std::min<uint64_t>(total, 64ull << 20);
+    if (keys.size() < cap + 1) keys.resize(cap + 1), counts.resize(cap + 1);
+    int rc = rfx_merge_unique(ctx, files.data(), (int)files.size(), 5, keys.data(), counts.data(), cap, &n);
+    if (rc == RFX_E_RANGE && n > cap) {
+      cap = n;
+      keys.resize(cap + 1);
+      counts.resize(cap + 1);
+      rc = rfx_merge_unique(ctx, files.data(), (int)files.size(), 5, keys.data(), counts.data(), cap, &n);
+    }
+    if (rc) die(std::string("rufus_amd: merge failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
+    emit(keys.data(), counts.data(), n);
+  };
+  if (!all_sliced) {
+    for (int i = 0; i < nf; ++i)
+      if (!whole[(size_t)i]) whole[(size_t)i] = jf[(size_t)i].load(ctx, 0, jf[(size_t)i].n);
+    merge_and_emit(whole);
+  } else {
+    // A merge-path join over position ranges (the files are sorted by position first): range by range, the part
+    // of every input that falls into it is read, joined on the device and printed -- ranges come in increasing
+    // order, so the output is the same sorted list.  ~1.2e9 records (24 GB of HBM) per range: one range for
+    // anything small, 8 for a 30x trio (RFX_MERGE_SLICES overrides).
+    uint64_t total = 0;
+    for (auto& f : jf) total += f.n;
+    uint64_t S = std::max<uint64_t>(1, (total + 1199999999ull) / 1200000000ull);
+    if (const char* ev = getenv("RFX_MERGE_SLICES")) S = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
+    std::vector<uint64_t> lo((size_t)nf, 0);
+    for (uint64_t sidx = 0; sidx < S; ++sidx) {
+      std::vector<rfx_records*> part((size_t)nf, nullptr);
+      for (int i = 0; i < nf; ++i) {
+        const JhashFile& f = jf[(size_t)i];
+        const uint64_t hi = sidx + 1 == S ? f.n : f.lower_bound_pos(slice_start(sidx + 1, S, hs[0].lsize));
+        part[(size_t)i] = f.load(ctx, lo[(size_t)i], hi);
+        lo[(size_t)i] = hi;
+      }
+      merge_and_emit(part);
+      for (auto* r : part) rfx_records_free(r);
+    }
   }
   fflush(stdout);
   // the reference leaves a header-only database behind (merge_files.cc:207-224; testRun/clean.sh:1 removes it)
@@ -437,7 +514,9 @@ static int merge_main(int argc, char** argv, int full_argc, char** full_argv) {
       fclose(f);
     }
   leave(0);
-  for (auto* r : files) rfx_records_free(r);
+  for (auto* r : whole)
+    if (r) rfx_records_free(r);
+  for (auto& f : jf) f.close();
   rfx_close(ctx);
   return 0;
 }

@@ -342,6 +342,73 @@ inline rfx_records* load_records(rfx_ctx* c, const char* path, JhashHeader& h) {
   return r;
 }
 
+// A sorted database on disk, cut by ranges of the position (the high-order sort key) without loading it: merge and
+// query walk it slice by slice, so their HBM footprint is a slice, not the 64 GB a 30x sample's records take
+// (jf/jellyfish/merge_files.cc:69-155 and jf/include/jellyfish/binary_dumper.hpp:156-203 stream / search the file
+// the same way on the host).
+struct JhashFile {
+  std::string path;
+  JhashHeader h;
+  int fd = -1;
+  uint64_t n = 0;
+  size_t rl = 0, kb = 0;
+
+  bool open(const char* p) {  // false: not a regular file (the caller loads it whole instead)
+    path = p;
+    if (!read_jhash(p, h, nullptr)) die(std::string("Failed to parse header of file '") + p + "'");
+    if (h.format != "binary/sorted") die("Unknown format '" + h.format + "'");
+    kb = (size_t)(2 * h.k + 7) / 8;
+    rl = kb + (size_t)h.counter_len;
+    if (h.file_size < h.payload_offset) return false;
+    const uint64_t bytes = h.file_size - h.payload_offset;
+    if (bytes % rl != 0)
+      die("Size of database (" + std::to_string(bytes) + ") must be a multiple of the length of a record (" +
+          std::to_string(rl) + ")");
+    n = bytes / rl;
+    fd = ::open(p, O_RDONLY);
+    if (fd < 0) die(std::string("Failed to open file '") + p + "'");
+    return true;
+  }
+  uint64_t pos_at(uint64_t i) const {
+    unsigned char b[16] = {0};
+    size_t got = 0;
+    while (got < kb) {
+      const ssize_t w = ::pread(fd, b + got, kb - got, (off_t)(h.payload_offset + i * rl + got));
+      if (w < 0 && errno == EINTR) continue;
+      if (w <= 0) die("read error on '" + path + "'");
+      got += (size_t)w;
+    }
+    uint64_t key = 0;
+    for (size_t j = 0; j < kb; ++j) key |= (uint64_t)b[j] << (8 * j);
+    return rfx_jf_pos(h.cols.data(), h.k, h.lsize, key);
+  }
+  // index of the first record whose position is >= pos (n when there is none): ~32 single-record reads
+  uint64_t lower_bound_pos(uint64_t pos) const {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      if (pos_at(mid) < pos) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  }
+  rfx_records* load(rfx_ctx* c, uint64_t i0, uint64_t i1) const {
+    rfx_records* r = rfx_records_load_fd(c, h.k, h.lsize, h.cols.data(), fd, h.payload_offset + i0 * rl, i1 - i0, h.counter_len);
+    if (!r) die("rufus_amd: cannot load '" + path + "': " + rfx_last_error());
+    return r;
+  }
+  void close() {
+    if (fd >= 0) ::close(fd);
+    fd = -1;
+  }
+};
+// first position of slice s of S equal position ranges of a 2^lsize table (ceil, so that slice_of() below agrees)
+inline uint64_t slice_start(uint64_t s, uint64_t S, int lsize) {
+  const unsigned __int128 num = ((unsigned __int128)s << lsize) + (S - 1);
+  return (uint64_t)(num / S);
+}
+inline uint64_t slice_of(uint64_t pos, uint64_t S, int lsize) { return (uint64_t)(((unsigned __int128)pos * S) >> lsize); }
+
 // ---- newline scanning -----------------------------------------------------------------------------------------
 // The text side of every tool is a search for '\n'; a memchr call per (short) FASTQ line costs ~20 ns, which at four
 // lines per record is what one reader thread can do and no more.  These walk the buffer 16 / 32 bytes per step.

@@ -39,12 +39,24 @@ def test_jellyfish_and_filter_executables_reproduce_the_goldens(testrun, tmp_pat
     r = sh([f"{BIN}/jellyfish", "merge", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d)
     assert r.returncode == 0 and r.stdout.decode() == testrun["merge"]
     assert os.path.getsize(f"{d}/mer_counts_merged.jf") > 1000
+    # the join walks the inputs by position ranges (one range for small inputs; a 30x trio takes 8): any number of
+    # ranges, empty ones included, prints the same list
+    for slices in ("2", "7", "300"):
+        r = subprocess.run([f"{BIN}/jellyfish", "merge", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], cwd=d,
+                           env=dict(os.environ, RFX_MERGE_SLICES=slices), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.decode() == testrun["merge"], slices
     # scripts/CheckJellyHashList.sh:12
     open(f"{d}/q.fa", "w").write("".join(f">{ln.split()[0]}\n{ln.split()[0]}\n" for ln in testrun["merge"].splitlines()))
     r = sh([f"{BIN}/jellyfish", "query", "-s", "q.fa", "Child.Jhash"], d)
     assert r.returncode == 0, r.stderr
     hl = "".join(ln + "\n" for ln in r.stdout.decode().splitlines() if 5 <= int(ln.split()[1]) <= 140)
     assert hl == testrun["hashlist"]
+    whole_answer = r.stdout
+    for per in ("1000", "37"):        # the database read in ranges of ~per records, only those that got a query
+        r = subprocess.run([f"{BIN}/jellyfish", "query", "-s", "q.fa", "Child.Jhash"], cwd=d,
+                           env=dict(os.environ, RFX_QUERY_SLICE_RECORDS=per), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == whole_answer, r.stderr
     open(f"{d}/Child.HashList", "w").write(hl)
     # dump -c and a command-line query
     r = sh([f"{BIN}/jellyfish", "dump", "-c", "Child.Jhash"], d)

@@ -250,11 +250,24 @@ static int histo_main(int argc, char** argv) {
     die("rufus_amd jellyfish histo: only the default --low 1 --high 10000 --increment 1 is supported");
   rfx_ctx* ctx = open_ctx();
   trace("histo: device open");
-  JhashHeader h;
-  rfx_records* rec = load_records(ctx, argv[optind], h);
-  trace("histo: records loaded");
-  std::vector<uint64_t> hist(RFX_HISTO_BINS);
-  if (rfx_records_histo(rec, hist.data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+  std::vector<uint64_t> hist(RFX_HISTO_BINS, 0);
+  rfx_records* rec = nullptr;
+  JhashFile db;
+  if (!db.open(argv[optind])) {  // not a regular file: loaded whole
+    JhashHeader h;
+    rec = load_records(ctx, argv[optind], h);
+    if (rfx_records_histo(rec, hist.data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+  } else {  // 256 M records (5 GB of HBM) at a time, whatever the size of the database
+    uint64_t per = 256ull << 20;
+    if (const char* ev = getenv("RFX_HISTO_SLICE_RECORDS")) per = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
+    std::vector<uint64_t> part_hist(RFX_HISTO_BINS);
+    for (uint64_t at = 0; at < db.n; at += per) {
+      rfx_records* part = db.load(ctx, at, std::min(db.n, at + per));
+      if (rfx_records_histo(part, part_hist.data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+      for (int i = 0; i < RFX_HISTO_BINS; ++i) hist[(size_t)i] += part_hist[(size_t)i];
+      rfx_records_free(part);
+    }
+  }
   trace("histo: counted");
   FILE* f = out ? fopen(out, "w") : stdout;
   if (!f) die(std::string("Error opening output file '") + out + "'");
@@ -262,7 +275,8 @@ static int histo_main(int argc, char** argv) {
     if (hist[(size_t)i] > 0 || full) fprintf(f, "%d %llu\n", i, (unsigned long long)hist[(size_t)i]);
   if (out) fclose(f);
   leave(0);
-  rfx_records_free(rec);
+  db.close();
+  if (rec) rfx_records_free(rec);
   rfx_close(ctx);
   return 0;
 }

@@ -35,6 +35,9 @@ def test_jellyfish_and_filter_executables_reproduce_the_goldens(testrun, tmp_pat
         assert r.returncode == 0, r.stderr
         h = open(f"{d}/{s}.Jhash.histo", "rb").read()
         assert hashlib.md5(h).hexdigest() == exp["samples"][s]["s100M"]["histo_full_md5"]
+        r = subprocess.run([f"{BIN}/jellyfish", "histo", "-f", f"{s}.Jhash"], cwd=d, stdout=subprocess.PIPE,
+                           env=dict(os.environ, RFX_HISTO_SLICE_RECORDS="999"))      # the database in 19 pieces
+        assert r.stdout == h
     # modified merge: stdout is the data channel, plus the header-only side file
     r = sh([f"{BIN}/jellyfish", "merge", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d)
     assert r.returncode == 0 and r.stdout.decode() == testrun["merge"]

@@ -133,6 +133,15 @@ def end_to_end(n_pairs=32_000_000):
     T = str(max(1, min(64, ncpu - 2)))                # (the tools cap it to rfx_host_cpus())
     G = n_pairs * 10
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    # tmpfs pages count against the container's memory limit (300 GiB on the GPU box: a full-size trio, 700 GB of text,
+    # gets the whole box killed -- it did), so the leg refuses sizes that would not leave room
+    need = n_pairs * 2 * 3 * 330 + n_pairs * 2 * 3 * 60
+    try:
+        limit = int(open("/sys/fs/cgroup/memory.max").read())
+    except (OSError, ValueError):
+        limit = None
+    if base and limit and need > 0.6 * limit:
+        raise RuntimeError(f"end_to_end: {need >> 30} GiB of tmpfs would not fit the container's memory limit ({limit >> 30} GiB)")
     d = tempfile.mkdtemp(prefix="rfx_e2e_", dir=base)
     out = {"reads_per_sample": 2 * n_pairs, "threads": int(T), "stages_s": {}}
 
@@ -303,13 +312,15 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--end-to-end-only", action="store_true", help="(internal) print the end_to_end object and exit")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--e2e-pairs", type=int, default=32_000_000,
+                    help="read pairs per sample of the end-to-end leg (refused when the text would not fit the container's memory)")
     ap.add_argument("--inner", action="store_true", help="(internal) the GPU part only, run by the launcher below")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()))
         return
     if args.end_to_end_only:
-        print(json.dumps(end_to_end()))
+        print(json.dumps(end_to_end(args.e2e_pairs)))
         return
 
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.inner:

@@ -1561,7 +1561,10 @@ static int msp_passes_leaf(rfx_finish* f) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 64ull << 30;
     const double avail = 0.88 * ((double)free_b + (double)(c->arena_mapped - std::min(c->arena_mapped, c->used)));
-    const double surv = (double)windows / 20.0 * 44.0;  // survivor arrays at the end (12 + 12 + 20 B each)
+    // Beside the records of a pass live the survivors gathered so far (12 B each, ~windows / 20 of them at 30x);
+    // their sort at the end (12 + 12 + 20 B each) runs when no pass records are left, so it does not add up
+    // with them.  (Planning with the sum took 5 passes for a 30x sample where 2 fit: measured, 6.3 s of finish.)
+    const double surv = (double)windows / 20.0 * 14.0;
     const double records = (double)windows * 2.9 * 1.15;
     S = 1;
     while (S < 256 && records / S + surv > avail) ++S;

@@ -19,8 +19,8 @@ sz = os.path.getsize("$D/child.Jhash"); blob = open("$D/child.Jhash","rb").read(
 n = (sz - 9 - hl) / 11
 print("records in the file: %.0f  (bench.py's library path counts 3244291368 for this sample at the full size)" % n)
 PY
-s=$(date +%s.%N); RFX_CLI_TRACE=1 timeout 600 $BIN/jellyfish histo -f -o $D/child.histo $D/child.Jhash 2> $O/histo.trace; e=$(date +%s.%N)
-python3 -c "print('jellyfish histo: %.1f s' % ($e-$s))"; head -8 $D/child.histo | tr '\n' ' '; echo
+s=$(date +%s.%N); RFX_TRACE_LOAD=1 RFX_CLI_TRACE=1 timeout 600 $BIN/jellyfish histo -f -o $D/child.histo $D/child.Jhash 2> $O/histo.trace; e=$(date +%s.%N)
+grep "load_fd" $O/histo.trace | head -12; python3 -c "print('jellyfish histo: %.1f s' % ($e-$s))"; head -8 $D/child.histo | tr '\n' ' '; echo
 python3 - <<PY
 tot = 0; distinct = 0
 for ln in open("$D/child.histo"):

@@ -498,11 +498,12 @@ static int merge_main(int argc, char** argv, int full_argc, char** full_argv) {
   } else {
     // A merge-path join over position ranges (the files are sorted by position first): range by range, the part
     // of every input that falls into it is read, joined on the device and printed -- ranges come in increasing
-    // order, so the output is the same sorted list.  ~1.2e9 records (24 GB of HBM) per range: one range for
-    // anything small, 8 for a 30x trio (RFX_MERGE_SLICES overrides).
+    // order, so the output is the same sorted list.  ~2.4e9 records (48 GB of HBM) per range: one range for
+    // anything small, 5 for a 30x trio (RFX_MERGE_SLICES overrides; a range costs ~0.6 s of fixed work: three 30x
+    // samples of a 1 Gb genome, 3.1e9 records, merge in 1.8 s as one range and in 3.6 s as three).
     uint64_t total = 0;
     for (auto& f : jf) total += f.n;
-    uint64_t S = std::max<uint64_t>(1, (total + 1199999999ull) / 1200000000ull);
+    uint64_t S = std::max<uint64_t>(1, (total + 2399999999ull) / 2400000000ull);
     if (const char* ev = getenv("RFX_MERGE_SLICES")) S = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
     std::vector<uint64_t> lo((size_t)nf, 0);
     for (uint64_t sidx = 0; sidx < S; ++sidx) {

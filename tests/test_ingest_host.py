@@ -72,3 +72,15 @@ def test_ingest_rejects_what_is_not_4_line_fastq(harness, tmp_path):
     out = subprocess.run([harness, "2", "100", "600", "1000", str(tmp_path / "w.fq")], stdout=subprocess.PIPE,
                          timeout=60, check=True).stdout.decode()
     assert out.startswith("not4line")
+
+
+def test_line_scanners_agree_with_memchr(tmp_path):
+    """skip_lines / index_lines / find_nl (32 or 16 bytes per step) against their memchr versions: random text,
+    empty lines, every buffer alignment, with and without a final newline (tests/host/lines_harness.cpp)."""
+    out = str(tmp_path / "lines_harness")
+    lib = os.path.join(ROOT, "rufus_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-o", out,
+                           os.path.join(ROOT, "tests", "host", "lines_harness.cpp"), f"-L{lib}", "-lrufus_hip",
+                           f"-Wl,-rpath,{lib}"])
+    r = subprocess.run([out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith(b"ok "), r.stdout + r.stderr

@@ -31,11 +31,15 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   bool canonical = false, size_given = false;
   const char* out = "mer_counts.jf";
   const char* timing = nullptr;
-  enum { OPT_DISK = 1000, OPT_OCL, OPT_TIMING, OPT_TEXT };
+  // --sam CHR_FILE (not in jellyfish): the input is SAM text and this process does what
+  // `PassThroughSamCheck CHR_FILE | jellyfish count` does (scripts/RunJellyForRUFUS.sh:28-29) -- the sequence of
+  // every record counted, the chromosome log written -- without the FASTQ text in between: SURVEY 8 row N1.
+  const char* sam_chr = nullptr;
+  enum { OPT_DISK = 1000, OPT_OCL, OPT_TIMING, OPT_TEXT, OPT_SAM };
   static option lo[] = {{"mer-len", 1, 0, 'm'},      {"size", 1, 0, 's'},        {"threads", 1, 0, 't'},
                         {"output", 1, 0, 'o'},       {"counter-len", 1, 0, 'c'}, {"out-counter-len", 1, 0, OPT_OCL},
                         {"canonical", 0, 0, 'C'},    {"disk", 0, 0, OPT_DISK},   {"lower-count", 1, 0, 'L'},
-                        {"upper-count", 1, 0, 'U'},  {"timing", 1, 0, OPT_TIMING}, {"text", 0, 0, OPT_TEXT},
+                        {"upper-count", 1, 0, 'U'},  {"timing", 1, 0, OPT_TIMING}, {"text", 0, 0, OPT_TEXT}, {"sam", 1, 0, OPT_SAM},
                         {"reprobes", 1, 0, 'p'},     {0, 0, 0, 0}};
   optind = 1;
   int ch;
@@ -53,6 +57,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
       case OPT_DISK: break;  // table growth / merging is internal
       case OPT_OCL: out_counter_len = atoi(optarg); break;
       case OPT_TIMING: timing = optarg; break;
+      case OPT_SAM: sam_chr = optarg; break;
       case OPT_TEXT: die("rufus_amd jellyfish: --text output is not on the RUFUS path");
       default: die("Usage: jellyfish count -m K -s SIZE [-C] [-L n] [-U n] [-t T] [-o OUT] [--disk] file...");
     }
@@ -138,16 +143,20 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   {
     for (Input& in : inputs) {
       bool done = false;
-      if (nthreads > 1) {
-        if (!ingest)
+      if (nthreads > 1 || sam_chr) {
+        if (!ingest) {
           ingest.reset(new CountIngest(nthreads, [&](const StageBlock& b) {
             sink(rfx_reads_upload(ctx, b.codes, b.acgt, nullptr, b.word_off, b.len, b.n_reads));
-          })), trace("count: staging blocks pinned, workers up");
+          }));
+          ingest->set_sam(sam_chr != nullptr);
+          if (const char* ev = getenv("RFX_INGEST_PIECE")) ingest->set_piece_bytes((size_t)std::max(1024ll, atoll(ev)));
+          trace("count: staging blocks pinned, workers up");
+        }
         if (in.regular) {
           if (in.size == 0) { if (in.fd > 0) ::close(in.fd); continue; }
           // mapped, not pread: measured on the 256-core box (20 GB FASTQ in tmpfs, 64 workers) 1.1 s against 3.2 s
           // with every worker pread-ing its range into a private buffer (RFX_INGEST_PREAD=1 keeps that path testable)
-          if (getenv("RFX_INGEST_PREAD")) {
+          if (getenv("RFX_INGEST_PREAD") && !sam_chr) {
             done = ingest->feed_file(in.fd, in.size);
           } else {
             void* m = mmap(nullptr, in.size, PROT_READ, MAP_PRIVATE, in.fd, 0);
@@ -193,6 +202,17 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
         sequential(lr);
       }
       if (in.fd > 0) ::close(in.fd);
+    }
+  }
+  if (sam_chr) {
+    FILE* cf = fopen(sam_chr, "w");
+    if (!cf) {  // src/PassThroughSamCheck.cpp:37-44
+      printf("ERROR, Output file could not be opened -%s\n", sam_chr);
+    } else {
+      if (ingest)
+        for (const std::string& name : ingest->chr_log()) fprintf(cf, "%s\n", name.c_str());
+      else fprintf(cf, "notachr\n");
+      fclose(cf);
     }
   }
   const auto t_count = std::chrono::steady_clock::now();

@@ -24,6 +24,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
 
@@ -54,6 +55,7 @@ class CountIngest {
     int fd = -1;               // >= 0: a byte range [lo, hi) of a regular file -- the worker reads it itself and
     uint64_t lo = 0, hi = 0;   // parses the records that START inside the range
     uint64_t fsize = 0;
+    uint64_t seq = 0;          // SAM mode: position of the piece in the stream (the chromosome log is stitched in order)
   };
   std::deque<Piece> work_;
   std::deque<int> ready_, free_;
@@ -68,6 +70,13 @@ class CountIngest {
   uint64_t reads_total_ = 0;
 
   size_t PIECE = 32u << 20;  // bytes of text per piece (tests shrink it)
+  // SAM mode (`jellyfish count --sam`): one record per line, the sequence is field 10; the runs of equal RNAME
+  // (field 3) of every piece are kept, in stream order they are PassThroughSamCheck's chromosome log
+  // (src/PassThroughSamCheck.cpp:140-155)
+  bool sam_ = false;
+  uint64_t next_seq_ = 0;
+  std::map<uint64_t, std::vector<std::string>> chr_runs_;
+  const skip_lines_fn skip_lines_ = pick_skip_lines();
 
   void fail(const std::string& m) {
     std::lock_guard<std::mutex> g(mu_);
@@ -157,6 +166,55 @@ class CountIngest {
       words += (L + 31) / 32;
       p = qe < e ? qe + 1 : e;
     }
+    pack_spans_of(pc, start, slen);
+    (void)words;
+  }
+
+  // SAM text (no header lines: `samtools view` without -h, as scripts/RunJellyForRUFUS.sh feeds it): what
+  // PassThroughSamCheck would print as the sequence line of each record, packed in place.
+  void parse_piece_sam(const Piece& pc) {
+    std::vector<uint64_t> start;
+    std::vector<uint32_t> slen;
+    start.reserve(1 << 17);
+    slen.reserve(1 << 17);
+    std::vector<std::string> runs;
+    const char *p = pc.b, *e = pc.e;
+    const char* cur_chr = nullptr;
+    size_t cur_len = 0;
+    while (p < e) {
+      const char* nl = find_nl(p, e);
+      const char* le = nl ? nl : e;
+      // tabs 2 and 3 bound RNAME, tabs 9 and 10 (or the end of the line) bound SEQ
+      const char* tab[10];
+      int nt = 0;
+      for (const char* q = p; nt < 10 && q < le;) {
+        const char* t = (const char*)memchr(q, '\t', (size_t)(le - q));
+        if (!t) break;
+        tab[nt++] = t;
+        q = t + 1;
+      }
+      if (nt < 9) return fail("--sam: a line has fewer than 10 tab-separated fields (a header? feed `samtools view` without -h)");
+      const char* chr = tab[1] + 1;
+      const size_t chr_len = (size_t)(tab[2] - chr);
+      if (!cur_chr || chr_len != cur_len || memcmp(chr, cur_chr, chr_len) != 0) {
+        runs.emplace_back(chr, chr_len);
+        cur_chr = chr;
+        cur_len = chr_len;
+      }
+      const char* sq = tab[8] + 1;
+      const char* sq_e = nt >= 10 ? tab[9] : le;
+      start.push_back((uint64_t)(sq - pc.b));
+      slen.push_back((uint32_t)(sq_e - sq));
+      p = nl ? nl + 1 : e;
+    }
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      chr_runs_[pc.seq] = std::move(runs);
+    }
+    pack_spans_of(pc, start, slen);
+  }
+
+  void pack_spans_of(const Piece& pc, const std::vector<uint64_t>& start, const std::vector<uint32_t>& slen) {
     // normally one reservation per piece; a piece with more reads than a staging block holds goes in slices
     const size_t total = start.size();
     size_t at = 0;
@@ -183,7 +241,6 @@ class CountIngest {
       release(blk);
       at += n;
     }
-    (void)words;
   }
 
   // A range of a regular file: read it (plus one byte before and the tail of the record that straddles its
@@ -221,6 +278,7 @@ class CountIngest {
         work_.pop_front();
       }
       if (pc.fd >= 0) parse_range(pc, buf);
+      else if (sam_) parse_piece_sam(pc);
       else parse_piece(pc);
       {
         std::lock_guard<std::mutex> g(mu_);
@@ -377,14 +435,31 @@ class CountIngest {
   }
 
   // A whole regular file, mapped.  Returns false if it is not strict 4-line FASTQ (nothing consumed).
+  void set_sam(bool on) { sam_ = on; }
+  // PassThroughSamCheck's side file: "notachr", then the name of every run of equal RNAME, in stream order
+  std::vector<std::string> chr_log() {
+    std::vector<std::string> out{"notachr"};
+    for (auto& kv : chr_runs_)
+      for (auto& name : kv.second)
+        if (out.size() == 1 || out.back() != name) out.push_back(name);
+    return out;
+  }
+
   bool feed_mapped(const char* data, size_t size) {
-    if (!looks_4line(data, std::min<size_t>(size, 1u << 16))) return false;
+    if (!sam_ && !looks_4line(data, std::min<size_t>(size, 1u << 16))) return false;
     const char *b = data, *e = data + size;
     const char* at = b;
     while (at < e) {
       const char* want = at + PIECE;
-      const char* cut = want >= e ? e : record_start(want, b, e);
-      push_piece(Piece{at, cut, nullptr});
+      const char* cut;
+      if (want >= e) cut = e;
+      else if (sam_) {
+        const char* nl = (const char*)memchr(want, '\n', (size_t)(e - want));
+        cut = nl ? nl + 1 : e;
+      } else cut = record_start(want, b, e);
+      Piece pc{at, cut, nullptr};
+      pc.seq = next_seq_++;
+      push_piece(pc);
       at = cut;
       drain(false);
     }
@@ -421,7 +496,11 @@ class CountIngest {
   // stream every 4k lines.  Returns false if the head is not strict 4-line FASTQ (the caller then parses
   // head + rest sequentially).
   bool feed_stream(int fd, std::vector<char>& head) {
-    if (!looks_4line(head.data(), head.size())) return false;
+    if (!sam_ && !looks_4line(head.data(), head.size())) return false;
+    const uint64_t lines_per_rec = sam_ ? 1 : 4;
+#ifdef F_SETPIPE_SZ
+    (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);  // a pipe: fewer, larger reads (ignored on anything else)
+#endif
     std::vector<char>* buf = nullptr;
     size_t fill = 0;
     uint64_t line_in_rec = 0;  // lines of the current record already inside buf[0, scanned)
@@ -464,18 +543,18 @@ class CountIngest {
         if (n == 0) eof = true;
         else fill += (size_t)n;
       }
-      // last record boundary inside [0, fill): count lines
+      // last record boundary inside [0, fill): count the new lines (32 bytes per step), then walk to the newline
+      // that completes the last whole record
       const char* d = buf->data();
-      size_t pos = scanned;
-      while (pos < fill) {
-        const char* nl = (const char*)memchr(d + pos, '\n', fill - pos);
-        if (!nl) break;
-        pos = (size_t)(nl - d) + 1;
-        if (++line_in_rec == 4) {
-          line_in_rec = 0;
-          last_cut = pos;
-        }
+      size_t got = 0;
+      (void)skip_lines_(d + scanned, d + fill, ~(size_t)0, got);
+      const uint64_t total_lines = line_in_rec + got, recs = total_lines / lines_per_rec;
+      if (recs) {
+        size_t g2 = 0;
+        const char* cut_at = skip_lines_(d + scanned, d + fill, (size_t)(recs * lines_per_rec - line_in_rec), g2);
+        last_cut = (size_t)(cut_at - d);
       }
+      line_in_rec = total_lines - recs * lines_per_rec;
       scanned = fill;
       size_t cut = eof ? fill : last_cut;
       if (cut == 0) {
@@ -486,7 +565,11 @@ class CountIngest {
       std::vector<char>* next = fresh();
       const size_t rest = fill - cut;
       memcpy(next->data(), d + cut, rest);
-      push_piece(Piece{d, d + cut, buf});
+      {
+        Piece pc{d, d + cut, buf};
+        pc.seq = next_seq_++;
+        push_piece(pc);
+      }
       buf = next;
       fill = rest;
       scanned = rest;  // the carried bytes hold line_in_rec complete lines of an unfinished record (already counted)

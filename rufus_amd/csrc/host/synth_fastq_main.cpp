@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
   FILE* f2 = argc > 8 ? fopen(argv[8], "wb") : nullptr;
   if (!f1 || (argc > 8 && !f2)) { perror("open"); return 1; }
   const uint32_t L = p.read_len;
+  const bool as_sam = getenv("RFX_SYNTH_SAM") != nullptr;  // SAM lines instead of FASTQ records (for `count --sam`)
   const uint64_t step = 1u << 20;
   std::vector<char> seq(2 * step * L), qual(2 * step * L), out1, out2;
   for (uint64_t at = 0; at < n_pairs; at += step) {
@@ -54,10 +55,21 @@ int main(int argc, char** argv) {
     std::vector<std::thread> th;
     for (unsigned t = 0; t < nt; ++t)
       th.emplace_back([&, t] {
-        char hdr[48];
+        char hdr[96];
         for (uint32_t q = (uint64_t)m * t / nt, e = (uint64_t)m * (t + 1) / nt; q < e; ++q)
           for (int mate = 0; mate < 2; ++mate) {
             std::string& o = (f2 && mate) ? part2[t] : part1[t];
+            if (as_sam) {  // what `samtools view` would print for it (mapped somewhere on chr1 .. chr22, by pair number)
+              const unsigned long long pr = (unsigned long long)(first + at + q);
+              const int hl = snprintf(hdr, sizeof hdr, "r%llu\t%d\tchr%llu\t%llu\t60\t150M\t=\t1\t0\t", pr,
+                                      mate ? 147 : 99, 1 + pr * 22 / (first + n_pairs), 1 + pr % 1000000);
+              o.append(hdr, (size_t)hl);
+              o.append(seq.data() + ((size_t)2 * q + mate) * L, L);
+              o.push_back('\t');
+              o.append(qual.data() + ((size_t)2 * q + mate) * L, L);
+              o.append("\tNM:i:0\n", 8);
+              continue;
+            }
             const int hl = snprintf(hdr, sizeof hdr, "@r%llu/%d\n", (unsigned long long)(first + at + q), mate + 1);
             o.append(hdr, (size_t)hl);
             o.append(seq.data() + ((size_t)2 * q + mate) * L, L);

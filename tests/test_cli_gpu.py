@@ -170,6 +170,47 @@ def test_filter_pieces_and_ragged_records_match_the_reference_binary(tmp_path, r
         assert len(want) > 10_000 and got == want
 
 
+@pytest.mark.parametrize("route", ["pipe", "file"])
+def test_count_sam_input_equals_passthrough_plus_count(testrun, tmp_path, route):
+    """`jellyfish count --sam X.chr` on SAM text = `PassThroughSamCheck X.chr | jellyfish count`
+    (scripts/RunJellyForRUFUS.sh:28-29) without the FASTQ text in between: same .Jhash payload, same chromosome log
+    (also the reference binary's), with the stream cut into many pieces handled by different threads."""
+    d = str(tmp_path)
+    rng = np.random.default_rng(11)
+    lines = []
+    chrs = [b"chr1", b"chr1", b"chr2", b"chr10", b"chr1", b"chrX", b"*"]
+    for m, text in enumerate(testrun["Child"]):
+        recs = text.split(b"\n")
+        for i in range(0, len(recs) - 1, 4):
+            c = chrs[min(len(chrs) - 1, (i // 4) * len(chrs) // (len(recs) // 4))] if m == 0 else chrs[int(rng.integers(0, 3))]
+            lines.append(b"\t".join([recs[i][1:], b"99", c, b"%d" % (i + 1), b"60", b"100M", b"=", b"1", b"0", recs[i + 1],
+                                     recs[i + 3], b"NM:i:0"]))
+    sam = b"\n".join(lines) + b"\n"
+    open(f"{d}/in.sam", "wb").write(sam)
+    r = subprocess.run(f"{BIN}/PassThroughSamCheck a.chr < in.sam | {BIN}/jellyfish count --disk -m 25 -L 2 -s 100M -t 4 "
+                       f"-o a.Jhash -C /dev/stdin", shell=True, cwd=d, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, RFX_INGEST_PIECE="65536")
+    cmd = [f"{BIN}/jellyfish", "count", "--sam", "b.chr", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "6", "-o",
+           "b.Jhash", "-C"]
+    if route == "pipe":
+        r = subprocess.run(cmd + ["/dev/stdin"], cwd=d, env=env, input=sam, stderr=subprocess.PIPE)
+    else:
+        r = subprocess.run(cmd + ["in.sam"], cwd=d, env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    assert _payload(f"{d}/a.Jhash") == _payload(f"{d}/b.Jhash") and len(_payload(f"{d}/b.Jhash")) > 100_000
+    assert open(f"{d}/a.chr").read() == open(f"{d}/b.chr").read()
+    assert open(f"{d}/b.chr").read().split() == ["notachr", "chr1", "chr2", "chr10", "chr1", "chrX", "*"] + \
+        open(f"{d}/b.chr").read().split()[7:]
+    ref = os.path.join(ROOT, "oracle", "_ref", "PassThroughSamCheck")
+    if os.path.exists(ref):
+        subprocess.run(f"{ref} ref.chr < in.sam > /dev/null", shell=True, cwd=d, check=True)
+        assert open(f"{d}/ref.chr").read() == open(f"{d}/b.chr").read()
+    # a header line is not a record (the reference tool would read past the end of the line)
+    r = subprocess.run(cmd + ["/dev/stdin"], cwd=d, env=env, input=b"@HD\tVN:1.6\n" + sam, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"--sam" in r.stderr
+
+
 def test_count_reads_a_named_pipe_and_several_files(testrun, tmp_path):
     d = str(tmp_path)
     os.mkfifo(f"{d}/gen.fq")

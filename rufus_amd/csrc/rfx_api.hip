@@ -1060,7 +1060,7 @@ static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   g.P1 = (uint32_t)rfxk::p1_bins();
   g.P2 = g.P / g.P1;
   g.bin_bits = ceil_log2(g.P);
-  // k_msp_part1 fits two 768-thread blocks per CU: a grid of exactly the resident blocks, each looping over
+  // k_msp_part1 fits two 512-thread blocks per CU: a grid of exactly the resident blocks, each looping over
   // its share of the chunks, beats a larger one whose last wave of blocks runs on a half-empty chip
   {
     const uint32_t blk = (uint32_t)rfxk::msp_part1_block();

@@ -30,9 +30,12 @@ namespace {
 // HMODE 0: scatter into fixed-capacity coarse bins + 16-bit fine histogram (one pass, optimistic)
 //       1: 32-bit fine histogram only            } the exact redo after HMODE 0 raised its flag;
 //       2: scatter only                          } cap_a then comes from the cursors of the failed run
-// 768 threads = reads per chunk: two blocks per CU fill the 24 waves that 80 VGPRs allow, and the runs of a
-// phase are 1.5x longer than with 512 (measured 256 / 512 / 768 / 1024 threads: 0.75 / 0.409 / 0.395 / 0.418 ms)
-constexpr int MP1_BLOCK = 768;
+// 512 threads = reads per chunk.  The kernel needs 82 VGPRs = 5 waves per SIMD: two 512-thread workgroups per CU
+// (4 waves per SIMD) fit, two of 768 (6) do not -- and with ONE 768-thread workgroup per CU (3 waves per SIMD) the
+// VALUs starve.  Measured on the 30x trio of a 1 Gb genome, ms per sample: 384 / 448 / 512 / 576 / 640 / 768 threads
+// = 105 / 93 / 90 / 132 / 123 / 110 (768 was the choice of round 1, made on a cache-resident 1 M-read sample when
+// the kernel still fit 80 VGPRs; forcing 6 waves per SIMD, `__launch_bounds__(768, 6)`, gives 89).
+constexpr int MP1_BLOCK = 512;
 // WL: m-mers per k-mer; WIDE: k = 26 .. 31, runs of up to 34 bases = 64-bit word + 32-bit plane (rfx_devutil.h).
 template <bool CANON, int HMODE, int WL, bool WIDE>
 __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int k, int bin_bits, uint32_t bin_lo,

@@ -78,6 +78,34 @@ def test_pass_through_stranded_pairs(tmp_path):
 
 
 @needs_ref
+def test_pass_through_stranded_many_waiting_reads(tmp_path):
+    """Records in random order (tens of thousands of reads wait for their mate: the table grows, fills with
+    deletions, is rebuilt), names seen three and four times, lower-case and IUPAC bases in reverse-strand reads
+    (the reference drops them), flags with other bits set."""
+    rng = np.random.default_rng(9)
+    n = 30_000
+    alphabet = np.frombuffer(b"ACGT" * 8 + b"Nacgtn" + b"RY", np.uint8)
+    recs = []
+    for i in range(n):
+        times = 2 if i % 97 else (3 if i % 2 else 4)
+        for t in range(times):
+            L = int(rng.integers(30, 151))
+            seq = bytes(rng.choice(alphabet, L))
+            qual = bytes(rng.integers(35, 75, L, dtype=np.uint8))
+            flag = int(rng.choice([99, 147, 83, 163, 16, 0, 1040, 65]))
+            recs.append(b"\t".join([b"q%d" % i, b"%d" % flag, b"chr%d" % (1 + i % 5), b"%d" % (i + t), b"60", b"*", b"=",
+                                    b"1", b"0", seq, qual, b"XS:i:%d" % t]) + b"\n")
+    order = rng.permutation(len(recs))
+    sam = b"".join(recs[j] for j in order)
+    run(f"{BIN}/PassThroughSamCheck.stranded", ["ours.chr", "ours"], sam, tmp_path)
+    run(f"{REF}/PassThroughSamCheck.stranded", ["ref.chr", "ref"], sam, tmp_path)
+    for m in (1, 2):
+        a, b = (tmp_path / f"ours.mate{m}.fastq").read_bytes(), (tmp_path / f"ref.mate{m}.fastq").read_bytes()
+        assert a == b and a.count(b"\n") > 4 * n
+    assert (tmp_path / "ours.chr").read_bytes() == (tmp_path / "ref.chr").read_bytes()
+
+
+@needs_ref
 def test_pass_through_stranded_single_end(tmp_path):
     sam = make_sam()
     a = run(f"{BIN}/PassThroughSamCheck.stranded.se", ["ours.chr"], sam, tmp_path)

@@ -106,6 +106,44 @@ def test_pass_through_stranded_many_waiting_reads(tmp_path):
 
 
 @needs_ref
+def test_stranded_feeder_keeps_the_reference_lock_step_reader_moving(tmp_path):
+    """runRufus.sh:964-967 with the reference's own RUFUS.Filter as the reader (four lines from one pipe, four from
+    the other): the feeder writes both pipes in chunks that hold the same pairs, never one pipe ahead by more than a
+    chunk -- the run ends, with the pairs the file route pulls."""
+    import threading
+    from rufus_amd import capi
+    d = str(tmp_path)
+    subprocess.run([f"{BIN}/rfx_synth_fastq", "2000000", "0", "20", "7", "0", "40000", "in.sam"], cwd=d, check=True,
+                   env=dict(os.environ, RFX_SYNTH_SAM="1"))
+    sy = capi.Synth.sample(2_000_000, 0, n_snv=20, seed=7)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    with open(f"{d}/hl", "w") as f:
+        for p_, _, alt in sy.snvs():
+            c = bytearray(sy.genome(p_ - 24, 49))
+            c[24:25] = alt
+            for i in range(25):
+                km = bytes(c[i:i + 25])
+                f.write(min(km, km[::-1].translate(comp)).decode() + " 12\n")
+    os.mkfifo(f"{d}/s.mate1.fastq")
+    os.mkfifo(f"{d}/s.mate2.fastq")
+    feeder = subprocess.Popen([f"{BIN}/PassThroughSamCheck.stranded", "f.chr", "s"], cwd=d, stdin=open(f"{d}/in.sam", "rb"))
+    r = subprocess.run([f"{REF}/RUFUS.Filter", "hl", "s.mate1.fastq", "s.mate2.fastq", "piped", "25", "15", "1", "2"], cwd=d,
+                       stdout=subprocess.DEVNULL, timeout=120)
+    assert r.returncode == 0 and feeder.wait(30) == 0
+    subprocess.run([f"{BIN}/PassThroughSamCheck.stranded", "g.chr", "t"], cwd=d, stdin=open(f"{d}/in.sam", "rb"), check=True)
+    subprocess.run([f"{REF}/RUFUS.Filter", "hl", "t.mate1.fastq", "t.mate2.fastq", "files", "25", "15", "1", "1"], cwd=d,
+                   stdout=subprocess.DEVNULL, check=True, timeout=120)
+
+    def records(path):
+        lines = open(path, "rb").read().split(b"\n")
+        return sorted(b"\n".join(lines[i:i + 4]) for i in range(0, len(lines) - 1, 4))
+
+    for m in (1, 2):
+        a, b = records(f"{d}/piped.Mutations.Mate{m}.fastq"), records(f"{d}/files.Mutations.Mate{m}.fastq")
+        assert a == b and len(a) > 20
+
+
+@needs_ref
 def test_pass_through_stranded_single_end(tmp_path):
     sam = make_sam()
     a = run(f"{BIN}/PassThroughSamCheck.stranded.se", ["ours.chr"], sam, tmp_path)

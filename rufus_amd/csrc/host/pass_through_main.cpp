@@ -13,6 +13,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <mutex>
+#include <map>
+#include <deque>
+#include <condition_variable>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -181,6 +186,67 @@ struct CompLut {
   fputc('\n', f);
 }
 
+[[maybe_unused]] int sam_flag(const Field& fl) {  // atoi of the field: optional sign, digits, anything after them ignored
+  int flag = 0;
+  size_t i = 0;
+  bool neg = false;
+  while (i < fl.n && (fl.p[i] == ' ' || (fl.p[i] >= 9 && fl.p[i] <= 13))) ++i;
+  if (i < fl.n && (fl.p[i] == '+' || fl.p[i] == '-')) neg = fl.p[i++] == '-';
+  for (; i < fl.n && fl.p[i] >= '0' && fl.p[i] <= '9'; ++i) flag = flag * 10 + (fl.p[i] - '0');
+  return neg ? -flag : flag;
+}
+
+#if PTS_MODE == 1
+// The stranded tool with helpers: the stream is cut into pieces at line ends; worker threads find the fields of
+// every line, hash the name and put reverse-strand reads back the way they were sequenced; ONE thread then walks
+// the pieces in stream order and does what cannot be split -- the chromosome log and the pairing (a record meets
+// its mate, or waits) -- on records that are ready to print.
+struct Parsed {
+  const char *name, *chr, *seq, *qual;
+  uint32_t name_len, chr_len, seq_len, qual_len;
+  uint64_t hash;
+};
+struct Piece {
+  std::vector<char> text;
+  size_t size = 0;
+  std::string arena;  // reverse-complemented sequences / reversed qualities of this piece (never reallocated)
+  std::vector<Parsed> recs;
+  uint64_t seq = 0;
+};
+
+void parse_piece(Piece& pc) {
+  pc.arena.clear();
+  pc.arena.reserve(pc.size + 16);
+  pc.recs.clear();
+  const char *p = pc.text.data(), *e = p + pc.size;
+  Field f[11];
+  std::string rs, rq;
+  while (p < e) {
+    const char* nl = rfxcli::find_nl(p, e);
+    const char* le = nl ? nl : e;
+    if (split_sam(p, le, f)) {  // fewer than 11 fields: skipped (the reference reads past the line there)
+      Parsed r;
+      r.name = f[0].p; r.name_len = (uint32_t)f[0].n;
+      r.chr = f[2].p; r.chr_len = (uint32_t)f[2].n;
+      r.seq = f[9].p; r.seq_len = (uint32_t)f[9].n;
+      r.qual = f[10].p; r.qual_len = (uint32_t)f[10].n;
+      if (sam_flag(f[1]) & 16) {
+        revcomp_into(rs, f[9]);
+        reverse_into(rq, f[10]);
+        const size_t at = pc.arena.size();
+        pc.arena.append(rs);  // (within the reserved capacity: the pointers below stay valid)
+        pc.arena.append(rq);
+        r.seq = pc.arena.data() + at; r.seq_len = (uint32_t)rs.size();
+        r.qual = pc.arena.data() + at + rs.size(); r.qual_len = (uint32_t)rq.size();
+      }
+      r.hash = name_hash(r.name, r.name_len);
+      pc.recs.push_back(r);
+    }
+    p = nl ? nl + 1 : e;
+  }
+}
+#endif
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -207,12 +273,63 @@ int main(int argc, char** argv) {
   setvbuf(m1, nullptr, _IONBF, 0);
   setvbuf(m2, nullptr, _IONBF, 0);
   std::string out1, out2;
-  const size_t CHUNK = 24u << 10;
+  size_t CHUNK = 24u << 10;
+#ifdef F_SETPIPE_SZ
+  // bigger pipes, bigger chunks (a quarter of the pipe: the argument above holds for any chunk below its capacity)
+  {
+    const int c1 = fcntl(fileno(m1), F_SETPIPE_SZ, 1 << 20), c2 = fcntl(fileno(m2), F_SETPIPE_SZ, 1 << 20);
+    if (c1 >= (1 << 20) && c2 >= (1 << 20) && !getenv("RFX_PTS_SMALL_CHUNKS")) CHUNK = 256u << 10;
+  }
+#endif
+  // The two writes of a chunk happen on a writer thread (when there are helpers at all): a full pipe then stops the
+  // writer, not the pairing.
+  std::mutex wmu;
+  std::condition_variable wcv;
+  std::deque<std::pair<std::string, std::string>> wq;
+  bool w_end = false, w_on = false;
+  std::thread writer;
+  auto write_chunk = [&](const std::string& a, const std::string& b) {
+    if (!a.empty()) fwrite(a.data(), 1, a.size(), m1);
+    if (!b.empty()) fwrite(b.data(), 1, b.size(), m2);
+  };
   auto flush_pairs = [&]() {
-    if (!out1.empty()) fwrite(out1.data(), 1, out1.size(), m1);
-    if (!out2.empty()) fwrite(out2.data(), 1, out2.size(), m2);
+    if (!w_on) {
+      write_chunk(out1, out2);
+    } else {
+      std::unique_lock<std::mutex> g(wmu);
+      wcv.wait(g, [&] { return wq.size() < 4; });
+      wq.emplace_back(std::move(out1), std::move(out2));
+      wcv.notify_all();
+    }
     out1.clear();
     out2.clear();
+  };
+  auto start_writer = [&]() {
+    w_on = true;
+    writer = std::thread([&] {
+      for (;;) {
+        std::pair<std::string, std::string> c;
+        {
+          std::unique_lock<std::mutex> g(wmu);
+          wcv.wait(g, [&] { return !wq.empty() || w_end; });
+          if (wq.empty()) return;
+          c = std::move(wq.front());
+          wq.pop_front();
+          wcv.notify_all();
+        }
+        write_chunk(c.first, c.second);
+      }
+    });
+  };
+  auto stop_writer = [&]() {
+    if (!w_on) return;
+    {
+      std::lock_guard<std::mutex> g(wmu);
+      w_end = true;
+      wcv.notify_all();
+    }
+    writer.join();
+    w_on = false;
   };
   auto put_text = [](std::string& o, const char* name, size_t nn, const char* seq, size_t ls, const char* qual, size_t lq) {
     o.push_back('@');
@@ -224,6 +341,130 @@ int main(int argc, char** argv) {
     o.push_back('\n');
   };
   Waiting waiting;
+  // (measured on the 16-CPU GPU box, 32 M reads into drained pipes: 0 / 4 / 8 helpers = 6.7 / 12.4 / 8.9 M reads/s --
+  // the pairing thread is the limit from four on, and the filter behind the pipes wants CPUs too)
+  unsigned helpers = std::min(4u, rfxcli::usable_cpus() > 2 ? rfxcli::usable_cpus() - 2 : 0u);
+  if (const char* ev = getenv("RFX_PTS_THREADS")) helpers = (unsigned)std::max(0, atoi(ev));
+  if (helpers > 0) {
+    start_writer();
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Piece*> todo, spare;
+    std::map<uint64_t, Piece*> done;
+    bool input_end = false;
+    uint64_t n_pieces = 0;
+    const size_t PIECE = 4u << 20;
+    const size_t MAX_IN_FLIGHT = 2 * (size_t)helpers + 4;
+    size_t in_flight = 0;
+    std::thread reader([&] {
+      const rfxcli::skip_lines_fn skip = rfxcli::pick_skip_lines();
+      (void)skip;
+      std::vector<char> carry;
+      bool eof = false;
+      while (!eof) {
+        Piece* pc = nullptr;
+        {
+          std::unique_lock<std::mutex> g(mu);
+          cv.wait(g, [&] { return in_flight < MAX_IN_FLIGHT; });
+          if (!spare.empty()) { pc = spare.front(); spare.pop_front(); }
+          ++in_flight;
+        }
+        if (!pc) pc = new Piece();
+        if (pc->text.size() < PIECE + (1u << 20)) pc->text.resize(PIECE + (1u << 20));
+        size_t fill = carry.size();
+        if (fill > pc->text.size()) pc->text.resize(fill + PIECE);
+        memcpy(pc->text.data(), carry.data(), fill);
+        carry.clear();
+        while (fill < PIECE) {
+          const ssize_t n = ::read(0, pc->text.data() + fill, pc->text.size() - fill);
+          if (n < 0 && errno == EINTR) continue;
+          if (n <= 0) { eof = true; break; }
+          fill += (size_t)n;
+        }
+        size_t cut = fill;
+        if (!eof) {  // back to the last line end; a line longer than the buffer grows it
+          while (cut > 0 && pc->text[cut - 1] != '\n') --cut;
+          if (cut == 0) {
+            carry.assign(pc->text.data(), pc->text.data() + fill);
+            std::lock_guard<std::mutex> g(mu);
+            spare.push_back(pc);
+            --in_flight;
+            // read more into a bigger carry next round
+            carry.reserve(fill * 2 + PIECE);
+            continue;
+          }
+          carry.assign(pc->text.data() + cut, pc->text.data() + fill);
+        }
+        pc->size = cut;
+        std::lock_guard<std::mutex> g(mu);
+        pc->seq = n_pieces++;
+        todo.push_back(pc);
+        cv.notify_all();
+      }
+      std::lock_guard<std::mutex> g(mu);
+      input_end = true;
+      cv.notify_all();
+    });
+    std::vector<std::thread> workers;
+    for (unsigned t = 0; t < helpers; ++t)
+      workers.emplace_back([&] {
+        for (;;) {
+          Piece* pc;
+          {
+            std::unique_lock<std::mutex> g(mu);
+            cv.wait(g, [&] { return !todo.empty() || input_end; });
+            if (todo.empty()) return;
+            pc = todo.front();
+            todo.pop_front();
+          }
+          parse_piece(*pc);
+          std::lock_guard<std::mutex> g(mu);
+          done[pc->seq] = pc;
+          cv.notify_all();
+        }
+      });
+    std::string current = "notachr";
+    for (uint64_t want = 0;; ++want) {
+      Piece* pc;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return done.count(want) || (input_end && want >= n_pieces); });
+        if (!done.count(want)) break;
+        pc = done[want];
+        done.erase(want);
+      }
+      for (const Parsed& r : pc->recs) {
+        if (r.chr_len != current.size() || memcmp(r.chr, current.data(), r.chr_len) != 0) {
+          fprintf(chr, "%s\n", current.c_str());
+          current.assign(r.chr, r.chr_len);
+        }
+        const long at = waiting.find(r.hash, r.name, r.name_len);
+        if (at < 0) {
+          waiting.insert(r.hash, r.name, r.name_len, r.seq, r.seq_len, r.qual, r.qual_len);
+        } else {
+          const Waiting::Entry& en = waiting.pool[waiting.slot[(size_t)at] - 2];
+          put_text(out1, r.name, r.name_len, r.seq, r.seq_len, r.qual, r.qual_len);
+          put_text(out2, r.name, r.name_len, en.bytes.data() + en.name_len, en.seq_len,
+                   en.bytes.data() + en.name_len + en.seq_len, en.bytes.size() - en.name_len - en.seq_len);
+          waiting.erase(at);
+          if (out1.size() >= CHUNK || out2.size() >= CHUNK) flush_pairs();
+        }
+      }
+      std::lock_guard<std::mutex> g(mu);
+      spare.push_back(pc);
+      --in_flight;
+      cv.notify_all();
+    }
+    reader.join();
+    for (auto& w : workers) w.join();
+    fprintf(chr, "%s\n", current.c_str());
+    fclose(chr);
+    flush_pairs();
+    stop_writer();
+    fclose(m1);
+    fclose(m2);
+    return 0;
+  }
 #endif
   rfxcli::LineReader in;
   in.attach(0);
@@ -239,16 +480,7 @@ int main(int argc, char** argv) {
 #if PTS_MODE == 0
     put_record(stdout, f[0], f[9].p, f[9].n, f[10].p, f[10].n);
 #else
-    int flag = 0;  // atoi of the field: optional sign, digits, anything after them ignored
-    {
-      size_t i = 0;
-      bool neg = false;
-      while (i < f[1].n && (f[1].p[i] == ' ' || (f[1].p[i] >= 9 && f[1].p[i] <= 13))) ++i;
-      if (i < f[1].n && (f[1].p[i] == '+' || f[1].p[i] == '-')) neg = f[1].p[i++] == '-';
-      for (; i < f[1].n && f[1].p[i] >= '0' && f[1].p[i] <= '9'; ++i) flag = flag * 10 + (f[1].p[i] - '0');
-      if (neg) flag = -flag;
-    }
-    const bool reverse = (flag & 16) != 0;
+    const bool reverse = (sam_flag(f[1]) & 16) != 0;
     const char *sp = f[9].p, *qp = f[10].p;
     size_t sn = f[9].n, qn = f[10].n;
     if (reverse) {

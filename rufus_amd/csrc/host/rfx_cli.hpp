@@ -6,6 +6,7 @@
 #include <immintrin.h>
 #endif
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -514,6 +515,22 @@ static inline index_lines_fn pick_index_lines() {
   if (__builtin_cpu_supports("avx2")) return index_lines_avx2;
 #endif
   return index_lines_plain;
+}
+
+// rfx_host_cpus() for the tools that do not link the device library (the SAM feeders): hardware threads, cut to the
+// affinity mask and the cgroup CPU quota.
+inline unsigned usable_cpus() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32];
+    double per = 0;
+    if (fscanf(f, "%31s %lf", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0)
+      n = std::min<unsigned>(n, (unsigned)std::max(1.0, atof(q) / per + 0.999));
+    fclose(f);
+  }
+  return n;
 }
 
 // The end of a tool whose outputs are flushed and closed.  Nothing is left to do but hand memory back: unpinning

@@ -97,12 +97,14 @@ def test_pass_through_stranded_many_waiting_reads(tmp_path):
                                     b"1", b"0", seq, qual, b"XS:i:%d" % t]) + b"\n")
     order = rng.permutation(len(recs))
     sam = b"".join(recs[j] for j in order)
-    run(f"{BIN}/PassThroughSamCheck.stranded", ["ours.chr", "ours"], sam, tmp_path)
     run(f"{REF}/PassThroughSamCheck.stranded", ["ref.chr", "ref"], sam, tmp_path)
-    for m in (1, 2):
-        a, b = (tmp_path / f"ours.mate{m}.fastq").read_bytes(), (tmp_path / f"ref.mate{m}.fastq").read_bytes()
-        assert a == b and a.count(b"\n") > 4 * n
-    assert (tmp_path / "ours.chr").read_bytes() == (tmp_path / "ref.chr").read_bytes()
+    for helpers in ("0", "1", "5"):                 # the single-threaded loop, and pieces parsed by helper threads
+        subprocess.run([f"{BIN}/PassThroughSamCheck.stranded", "ours.chr", "ours"], input=sam, cwd=tmp_path, check=True,
+                       timeout=120, env=dict(os.environ, RFX_PTS_THREADS=helpers))
+        for m in (1, 2):
+            a, b = (tmp_path / f"ours.mate{m}.fastq").read_bytes(), (tmp_path / f"ref.mate{m}.fastq").read_bytes()
+            assert a == b and a.count(b"\n") > 4 * n, helpers
+        assert (tmp_path / "ours.chr").read_bytes() == (tmp_path / "ref.chr").read_bytes()
 
 
 @needs_ref

@@ -196,11 +196,10 @@ struct CompLut {
   return neg ? -flag : flag;
 }
 
-#if PTS_MODE == 1
-// The stranded tool with helpers: the stream is cut into pieces at line ends; worker threads find the fields of
-// every line, hash the name and put reverse-strand reads back the way they were sequenced; ONE thread then walks
-// the pieces in stream order and does what cannot be split -- the chromosome log and the pairing (a record meets
-// its mate, or waits) -- on records that are ready to print.
+// The tools with helpers: the stream is cut into pieces at line ends; worker threads find the fields of every line
+// and prepare what the record will print (reverse-strand reads put back the way they were sequenced; for the
+// one-output tools the FASTQ text itself); ONE thread then walks the pieces in stream order and does what cannot
+// be split -- the chromosome log, and for the stranded tool the pairing (a record meets its mate, or waits).
 struct Parsed {
   const char *name, *chr, *seq, *qual;
   uint32_t name_len, chr_len, seq_len, qual_len;
@@ -209,10 +208,152 @@ struct Parsed {
 struct Piece {
   std::vector<char> text;
   size_t size = 0;
-  std::string arena;  // reverse-complemented sequences / reversed qualities of this piece (never reallocated)
+  std::string arena;  // stranded: reverse-complemented sequences / reversed qualities (never reallocated);
+                      // one-output tools: the FASTQ text of the piece
   std::vector<Parsed> recs;
+  std::vector<std::string> chr_runs;  // one-output tools: the runs of equal RNAME in this piece
   uint64_t seq = 0;
 };
+
+// reader thread -> `helpers` x parse -> consume in stream order (on the calling thread)
+template <class Parse, class Consume>
+void process_stream(unsigned helpers, Parse parse, Consume consume) {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<Piece*> todo, spare;
+  std::map<uint64_t, Piece*> done;
+  bool input_end = false;
+  uint64_t n_pieces = 0;
+  const size_t PIECE = 4u << 20;
+  const size_t MAX_IN_FLIGHT = 2 * (size_t)helpers + 4;
+  size_t in_flight = 0;
+  std::thread reader([&] {
+    std::vector<char> carry;
+    bool eof = false;
+    while (!eof) {
+      Piece* pc = nullptr;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return in_flight < MAX_IN_FLIGHT; });
+        if (!spare.empty()) { pc = spare.front(); spare.pop_front(); }
+        ++in_flight;
+      }
+      if (!pc) pc = new Piece();
+      size_t fill = carry.size();
+      if (pc->text.size() < fill + PIECE + (1u << 20)) pc->text.resize(fill + PIECE + (1u << 20));
+      memcpy(pc->text.data(), carry.data(), fill);
+      carry.clear();
+      while (fill < PIECE || (fill == pc->text.size())) {
+        if (fill == pc->text.size()) pc->text.resize(fill * 2);  // one line longer than the buffer
+        const ssize_t n = ::read(0, pc->text.data() + fill, pc->text.size() - fill);
+        if (n < 0 && errno == EINTR) continue;
+        if (n <= 0) { eof = true; break; }
+        fill += (size_t)n;
+        if (fill >= PIECE && memchr(pc->text.data() + fill - (size_t)n, '\n', (size_t)n)) break;
+      }
+      size_t cut = fill;
+      if (!eof) {  // back to the last line end
+        while (cut > 0 && pc->text[cut - 1] != '\n') --cut;
+        if (cut == 0) {  // (not a single line end yet: keep reading into the same piece)
+          carry.assign(pc->text.data(), pc->text.data() + fill);
+          std::lock_guard<std::mutex> g(mu);
+          spare.push_back(pc);
+          --in_flight;
+          continue;
+        }
+        carry.assign(pc->text.data() + cut, pc->text.data() + fill);
+      }
+      pc->size = cut;
+      std::lock_guard<std::mutex> g(mu);
+      pc->seq = n_pieces++;
+      todo.push_back(pc);
+      cv.notify_all();
+    }
+    std::lock_guard<std::mutex> g(mu);
+    input_end = true;
+    cv.notify_all();
+  });
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t < helpers; ++t)
+    workers.emplace_back([&] {
+      for (;;) {
+        Piece* pc;
+        {
+          std::unique_lock<std::mutex> g(mu);
+          cv.wait(g, [&] { return !todo.empty() || input_end; });
+          if (todo.empty()) return;
+          pc = todo.front();
+          todo.pop_front();
+        }
+        parse(*pc);
+        std::lock_guard<std::mutex> g(mu);
+        done[pc->seq] = pc;
+        cv.notify_all();
+      }
+    });
+  for (uint64_t want = 0;; ++want) {
+    Piece* pc;
+    {
+      std::unique_lock<std::mutex> g(mu);
+      cv.wait(g, [&] { return done.count(want) || (input_end && want >= n_pieces); });
+      if (!done.count(want)) break;
+      pc = done[want];
+      done.erase(want);
+    }
+    consume(*pc);
+    std::lock_guard<std::mutex> g(mu);
+    spare.push_back(pc);
+    --in_flight;
+    cv.notify_all();
+  }
+  reader.join();
+  for (auto& w : workers) w.join();
+}
+
+#if PTS_MODE != 1
+// one-output tools: the FASTQ text of a piece and its runs of equal RNAME
+void format_piece(Piece& pc) {
+  pc.arena.clear();
+  pc.arena.reserve(pc.size + pc.size / 8);
+  pc.chr_runs.clear();
+  const char *p = pc.text.data(), *e = p + pc.size;
+  Field f[11];
+  std::string rs, rq;
+  const char* cur = nullptr;
+  size_t cur_len = 0;
+  while (p < e) {
+    const char* nl = rfxcli::find_nl(p, e);
+    const char* le = nl ? nl : e;
+    if (split_sam(p, le, f)) {
+      if (!cur || f[2].n != cur_len || memcmp(f[2].p, cur, cur_len) != 0) {
+        pc.chr_runs.emplace_back(f[2].p, f[2].n);
+        cur = f[2].p;
+        cur_len = f[2].n;
+      }
+      const char *sp = f[9].p, *qp = f[10].p;
+      size_t sn = f[9].n, qn = f[10].n;
+#if PTS_MODE == 2
+      if (sam_flag(f[1]) & 16) {
+        revcomp_into(rs, f[9]);
+        reverse_into(rq, f[10]);
+        sp = rs.data(); sn = rs.size();
+        qp = rq.data(); qn = rq.size();
+      }
+#endif
+      pc.arena.push_back('@');
+      pc.arena.append(f[0].p, f[0].n);
+      pc.arena.push_back('\n');
+      pc.arena.append(sp, sn);
+      pc.arena.append("\n+\n", 3);
+      pc.arena.append(qp, qn);
+      pc.arena.push_back('\n');
+    }
+    p = nl ? nl + 1 : e;
+  }
+}
+#endif
+
+#if PTS_MODE == 1
 
 void parse_piece(Piece& pc) {
   pc.arena.clear();
@@ -347,93 +488,9 @@ int main(int argc, char** argv) {
   if (const char* ev = getenv("RFX_PTS_THREADS")) helpers = (unsigned)std::max(0, atoi(ev));
   if (helpers > 0) {
     start_writer();
-    std::mutex mu;
-    std::condition_variable cv;
-    std::deque<Piece*> todo, spare;
-    std::map<uint64_t, Piece*> done;
-    bool input_end = false;
-    uint64_t n_pieces = 0;
-    const size_t PIECE = 4u << 20;
-    const size_t MAX_IN_FLIGHT = 2 * (size_t)helpers + 4;
-    size_t in_flight = 0;
-    std::thread reader([&] {
-      const rfxcli::skip_lines_fn skip = rfxcli::pick_skip_lines();
-      (void)skip;
-      std::vector<char> carry;
-      bool eof = false;
-      while (!eof) {
-        Piece* pc = nullptr;
-        {
-          std::unique_lock<std::mutex> g(mu);
-          cv.wait(g, [&] { return in_flight < MAX_IN_FLIGHT; });
-          if (!spare.empty()) { pc = spare.front(); spare.pop_front(); }
-          ++in_flight;
-        }
-        if (!pc) pc = new Piece();
-        if (pc->text.size() < PIECE + (1u << 20)) pc->text.resize(PIECE + (1u << 20));
-        size_t fill = carry.size();
-        if (fill > pc->text.size()) pc->text.resize(fill + PIECE);
-        memcpy(pc->text.data(), carry.data(), fill);
-        carry.clear();
-        while (fill < PIECE) {
-          const ssize_t n = ::read(0, pc->text.data() + fill, pc->text.size() - fill);
-          if (n < 0 && errno == EINTR) continue;
-          if (n <= 0) { eof = true; break; }
-          fill += (size_t)n;
-        }
-        size_t cut = fill;
-        if (!eof) {  // back to the last line end; a line longer than the buffer grows it
-          while (cut > 0 && pc->text[cut - 1] != '\n') --cut;
-          if (cut == 0) {
-            carry.assign(pc->text.data(), pc->text.data() + fill);
-            std::lock_guard<std::mutex> g(mu);
-            spare.push_back(pc);
-            --in_flight;
-            // read more into a bigger carry next round
-            carry.reserve(fill * 2 + PIECE);
-            continue;
-          }
-          carry.assign(pc->text.data() + cut, pc->text.data() + fill);
-        }
-        pc->size = cut;
-        std::lock_guard<std::mutex> g(mu);
-        pc->seq = n_pieces++;
-        todo.push_back(pc);
-        cv.notify_all();
-      }
-      std::lock_guard<std::mutex> g(mu);
-      input_end = true;
-      cv.notify_all();
-    });
-    std::vector<std::thread> workers;
-    for (unsigned t = 0; t < helpers; ++t)
-      workers.emplace_back([&] {
-        for (;;) {
-          Piece* pc;
-          {
-            std::unique_lock<std::mutex> g(mu);
-            cv.wait(g, [&] { return !todo.empty() || input_end; });
-            if (todo.empty()) return;
-            pc = todo.front();
-            todo.pop_front();
-          }
-          parse_piece(*pc);
-          std::lock_guard<std::mutex> g(mu);
-          done[pc->seq] = pc;
-          cv.notify_all();
-        }
-      });
     std::string current = "notachr";
-    for (uint64_t want = 0;; ++want) {
-      Piece* pc;
-      {
-        std::unique_lock<std::mutex> g(mu);
-        cv.wait(g, [&] { return done.count(want) || (input_end && want >= n_pieces); });
-        if (!done.count(want)) break;
-        pc = done[want];
-        done.erase(want);
-      }
-      for (const Parsed& r : pc->recs) {
+    process_stream(helpers, parse_piece, [&](Piece& pc) {
+      for (const Parsed& r : pc.recs) {
         if (r.chr_len != current.size() || memcmp(r.chr, current.data(), r.chr_len) != 0) {
           fprintf(chr, "%s\n", current.c_str());
           current.assign(r.chr, r.chr_len);
@@ -450,13 +507,7 @@ int main(int argc, char** argv) {
           if (out1.size() >= CHUNK || out2.size() >= CHUNK) flush_pairs();
         }
       }
-      std::lock_guard<std::mutex> g(mu);
-      spare.push_back(pc);
-      --in_flight;
-      cv.notify_all();
-    }
-    reader.join();
-    for (auto& w : workers) w.join();
+    });
     fprintf(chr, "%s\n", current.c_str());
     fclose(chr);
     flush_pairs();
@@ -464,6 +515,27 @@ int main(int argc, char** argv) {
     fclose(m1);
     fclose(m2);
     return 0;
+  }
+#endif
+#if PTS_MODE != 1
+  {
+    unsigned helpers = std::min(4u, rfxcli::usable_cpus() > 2 ? rfxcli::usable_cpus() - 2 : 0u);
+    if (const char* ev = getenv("RFX_PTS_THREADS")) helpers = (unsigned)std::max(0, atoi(ev));
+    if (helpers > 0) {
+      std::string current = "notachr";
+      process_stream(helpers, format_piece, [&](Piece& pc) {
+        for (const std::string& name : pc.chr_runs)
+          if (name != current) {
+            fprintf(chr, "%s\n", current.c_str());
+            current = name;
+          }
+        fwrite(pc.arena.data(), 1, pc.arena.size(), stdout);
+      });
+      fprintf(chr, "%s\n", current.c_str());
+      fclose(chr);
+      fflush(stdout);
+      return 0;
+    }
   }
 #endif
   rfxcli::LineReader in;

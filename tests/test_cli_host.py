@@ -58,12 +58,14 @@ def run(exe, args, stdin, cwd):
 
 @needs_ref
 def test_pass_through_sam_check(tmp_path):
-    sam = make_sam()
-    a = run(f"{BIN}/PassThroughSamCheck", ["ours.chr"], sam, tmp_path)
+    sam = make_sam() + make_sam(20_000, seed=5)          # 13 MB: several pieces for the helper threads
     b = run(f"{REF}/PassThroughSamCheck", ["ref.chr"], sam, tmp_path)
-    assert a == b and a.count(b"\n") % 4 == 0 and len(a) > 100000
-    assert (tmp_path / "ours.chr").read_bytes() == (tmp_path / "ref.chr").read_bytes()
-    assert (tmp_path / "ours.chr").read_text().startswith("notachr\n")
+    for helpers in ("0", "3"):
+        a = subprocess.run([f"{BIN}/PassThroughSamCheck", "ours.chr"], input=sam, stdout=subprocess.PIPE, cwd=tmp_path,
+                           check=True, timeout=120, env=dict(os.environ, RFX_PTS_THREADS=helpers)).stdout
+        assert a == b and a.count(b"\n") % 4 == 0 and len(a) > 100000
+        assert (tmp_path / "ours.chr").read_bytes() == (tmp_path / "ref.chr").read_bytes()
+        assert (tmp_path / "ours.chr").read_text().startswith("notachr\n")
 
 
 @needs_ref
@@ -147,11 +149,13 @@ def test_stranded_feeder_keeps_the_reference_lock_step_reader_moving(tmp_path):
 
 @needs_ref
 def test_pass_through_stranded_single_end(tmp_path):
-    sam = make_sam()
-    a = run(f"{BIN}/PassThroughSamCheck.stranded.se", ["ours.chr"], sam, tmp_path)
+    sam = make_sam() + make_sam(20_000, seed=6)
     b = run(f"{REF}/PassThroughSamCheck.stranded.se", ["ref.chr"], sam, tmp_path)
-    assert a == b
-    assert (tmp_path / "ours.chr").read_bytes() == (tmp_path / "ref.chr").read_bytes()
+    for helpers in ("0", "3"):
+        a = subprocess.run([f"{BIN}/PassThroughSamCheck.stranded.se", "ours.chr"], input=sam, stdout=subprocess.PIPE,
+                           cwd=tmp_path, check=True, timeout=120, env=dict(os.environ, RFX_PTS_THREADS=helpers)).stdout
+        assert a == b
+        assert (tmp_path / "ours.chr").read_bytes() == (tmp_path / "ref.chr").read_bytes()
 
 
 @needs_ref

@@ -1515,8 +1515,9 @@ static int msp_prepare_leaf(rfx_table* t, int* to_bits_out, bool* refine_out, st
   int to_bits = ceil_log2(pmax);
   // (a shard pass fills only its share of the bins: density as if every shard were present)
   const uint64_t kfull = kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1);
-  // (wide records, k = 26 .. 31, are counted with the half-size leaf: half the instances per bin)
-  const uint64_t per_bin = rfxk::msp_wide(t->k) ? 12288 : 24576;
+  // (wide records, k = 26 .. 31, were counted with the half-size leaf until their plane cache became 16 bits wide:
+  // RFX_MSP_WIDE_HALF=1 brings that back for comparison)
+  const uint64_t per_bin = rfxk::msp_wide(t->k) && getenv("RFX_MSP_WIDE_HALF") ? 12288 : 24576;
   while (to_bits < 28 && (kfull >> to_bits) > per_bin) ++to_bits;
   if (getenv("RFX_MSP_REFINE_BITS")) to_bits = std::max(to_bits, atoi(getenv("RFX_MSP_REFINE_BITS")));
   const bool refine = force_refine || pmin < (1u << to_bits);

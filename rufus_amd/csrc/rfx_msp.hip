@@ -227,7 +227,7 @@ constexpr int MSP_RC_PROBES = 8;  // a record that finds no cache slot within th
 // table is split in two by a hash bit and each half retried -- results already appended stay valid.
 // GEO 0: one 1024-thread workgroup per CU (8192-slot table, 4096-slot record cache);
 // GEO 1: half of everything, two workgroups per CU -- for bins of ~8 K instances.
-// WIDE (k = 26 .. 31, GEO 1 only): a record is a 64-bit word + the <= 6 bases in the 32-bit plane; the cache
+// WIDE (k = 26 .. 31): a record is a 64-bit word + the <= 6 bases in the 32-bit plane; the cache
 // matches both (the plane value is published after the word: a reader that comes too early counts its record
 // directly -- the cache is best effort anyway).
 template <bool CANON, int GEO, bool WIDE>
@@ -247,7 +247,9 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
   __shared__ uint64_t s_lk[LIST];
   __shared__ uint32_t s_lc[LIST];
   __shared__ uint32_t s_nd, s_ovf, s_nl;
-  __shared__ uint32_t s_rx[WIDE ? RC : 1];  // WIDE: plane value of the cached record | 0x80000000 once published
+  // WIDE: plane value of the cached record (<= 6 bases = 12 bits) | 0x8000 once published; 16 bits so that it fits
+  // beside the full-size tables (157 of the 160 KB)
+  __shared__ uint16_t s_rx[WIDE ? RC : 1];
   unsigned long long* s_rk = (unsigned long long*)s_lk;  // the record cache lives in the (then idle) survivor list
   uint32_t* s_rc = s_lc;
   const uint64_t kmask = (1ull << (2 * k)) - 1;
@@ -395,13 +397,13 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
                   break;
                 }
               } else if (old == MSP_EMPTY) {  // mine: publish the plane value
-                __hip_atomic_store(&s_rx[h], xe | 0x80000000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&s_rx[h], (uint16_t)(xe | 0x8000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 atomicAdd(&s_rc[h], 1u);
                 cached = true;
                 break;
               } else if (old == x) {
                 const uint32_t px = __hip_atomic_load(&s_rx[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (px == (xe | 0x80000000u)) {
+                if (px == (xe | 0x8000u)) {
                   atomicAdd(&s_rc[h], 1u);
                   cached = true;
                   break;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
             const uint32_t o = atomicAdd(&s_nl, 1u);
             s_rk[o] = ex[h];
             s_rc[o] = ec[h];
-            if (WIDE) s_rx[o] = exx[h] & 0x7FFFFFFFu;
+            if (WIDE) s_rx[o] = (uint16_t)(exx[h] & 0x7FFFu);
           }
         __syncthreads();
         const uint32_t nrec = s_nl;
@@ -685,7 +687,7 @@ void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const
               int geo, const uint32_t* const* seg_ext, const uint32_t* ext0) {
   rfx_span sp(c, "k_msp_leaf");
   const bool wide = msp_wide(k);
-  if (wide) geo = 1;  // the plane of the record cache does not fit beside the full-size tables
+
   const uint32_t per_cu = geo ? 8 : 4;  // (1..8 per CU measured: no difference)
   const uint32_t grid = P < (uint32_t)c->n_cu * per_cu ? P : (uint32_t)c->n_cu * per_cu;
 #define RFX_MSP_LEAF(CANON, GEO, WIDE)                                                                                 \
@@ -693,8 +695,13 @@ void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const
                      nseg, inst0, bs0, seg_ext, ext0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, \
                      out_w, out_c, cur, cap, flag, err)
   if (wide) {
-    if (canonical) RFX_MSP_LEAF(true, 1, true);
-    else RFX_MSP_LEAF(false, 1, true);
+    if (canonical) {
+      if (geo) RFX_MSP_LEAF(true, 1, true);
+      else RFX_MSP_LEAF(true, 0, true);
+    } else {
+      if (geo) RFX_MSP_LEAF(false, 1, true);
+      else RFX_MSP_LEAF(false, 0, true);
+    }
   } else if (canonical) {
     if (geo) RFX_MSP_LEAF(true, 1, false);
     else RFX_MSP_LEAF(true, 0, false);

@@ -61,7 +61,10 @@ def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, 
     distinct = windows / max(coverage_hint * (read_len - k + 1) / read_len, 1.0)
     for s in range(1, 257 // world):
         share = s * world
-        records = (4.1 if wide else 2.7) * windows / share * (3.0 if world > 1 else 1.0)   # wide: 12 B per record
+        # bytes of records per k-mer instance: 8 B per ~3 k-mers; wide (k >= 26) records are 12 B but hold more k-mers
+        # (measured on the full-size tumor/normal pair, 1 GPU: peak 255 / 272 / 297 GB at 7 / 6 / 5 passes = 5.0 B per
+        # instance all in, the same as k = 25 -- 4.1 here made the plan take 7 where 6 fit)
+        records = (3.2 if wide else 2.7) * windows / share * (3.0 if world > 1 else 1.0)
         # leaf phase of the last sample of a pass: records + scratch, survivor store, the other samples' records
         transient = records * 1.125 + 12.0 * distinct / share * 1.3 + (n_samples - 1) * 20.0 * distinct / share
         # (measured on the 30x WGS trio, 1 GPU, of 288 GiB: 219 GB at 5 passes, 238 at 4, 271 at 3 -- which this

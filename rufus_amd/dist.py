@@ -38,6 +38,8 @@ HIP kernels).  The tests drive the same exchange logic on CPU with gloo and a ch
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -234,6 +236,46 @@ def _wire(t: torch.Tensor, group) -> torch.Tensor:
     return t.cpu() if dist.get_backend(group) == "gloo" and t.is_cuda else t
 
 
+def exchange_rows(out: torch.Tensor, inp: torch.Tensor, recv_l, send_l, group, max_bytes: int = 0):
+    """all_to_all_single(out, inp, recv_l, send_l) for payloads that can be GBs per peer: this rank's own share is a
+    device copy, every other (source, destination) share travels in pieces of at most max_bytes (default 512 MiB,
+    RFX_WGS_A2A_MAX_BYTES), one grouped isend/irecv round per piece.  RCCL 2.26's send/recv delivers only the first
+    half of a message beyond ~1 GiB (measured on the one-rank group: scratch/a2a_big.py -- 1.0 GiB arrives whole,
+    1.5 GiB and 10 GiB arrive as their first half), silently; pieces this size are far below that."""
+    world, me = dist.get_world_size(group), dist.get_rank(group)
+    so = [0] * (world + 1)
+    ro = [0] * (world + 1)
+    for d in range(world):
+        so[d + 1] = so[d] + int(send_l[d])
+        ro[d + 1] = ro[d] + int(recv_l[d])
+    if int(send_l[me]) != int(recv_l[me]):
+        raise ValueError("exchange_rows: a rank's share for itself differs between send and receive lists")
+    if send_l[me]:
+        out[ro[me]:ro[me + 1]].copy_(inp[so[me]:so[me + 1]])
+    if world == 1:
+        return
+    if not max_bytes:
+        max_bytes = int(os.environ.get("RFX_WGS_A2A_MAX_BYTES", 512 << 20))
+    m = max(1, max_bytes // inp.element_size())
+    most = max([int(send_l[d]) for d in range(world) if d != me] + [int(recv_l[d]) for d in range(world) if d != me] + [0])
+    rounds = -(-most // m)
+    for r in range(rounds):
+        ops = []
+        for d in range(world):
+            if d == me:
+                continue
+            peer = dist.get_global_rank(group, d) if group is not None else d
+            s0, s1 = min(r * m, int(send_l[d])), min((r + 1) * m, int(send_l[d]))
+            if s1 > s0:
+                ops.append(dist.P2POp(dist.isend, inp[so[d] + s0:so[d] + s1], peer, group))
+            r0, r1 = min(r * m, int(recv_l[d])), min((r + 1) * m, int(recv_l[d]))
+            if r1 > r0:
+                ops.append(dist.P2POp(dist.irecv, out[ro[d] + r0:ro[d] + r1], peer, group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+
 def exchange_partials(keys: torch.Tensor, counts: torch.Tensor, pos: torch.Tensor, lsize: int, group):
     """Send each (pos-sorted) partial to the owner of its pos; returns what this rank received."""
     world = dist.get_world_size(group)
@@ -247,8 +289,8 @@ def exchange_partials(keys: torch.Tensor, counts: torch.Tensor, pos: torch.Tenso
     wk, wc = _wire(keys, group), _wire(counts, group)
     rk = torch.empty(sum(recv_l), dtype=keys.dtype, device=wk.device)
     rc = torch.empty(sum(recv_l), dtype=counts.dtype, device=wc.device)
-    dist.all_to_all_single(rk, wk, recv_l, send_l, group=group)
-    dist.all_to_all_single(rc, wc, recv_l, send_l, group=group)
+    exchange_rows(rk, wk, recv_l, send_l, group)
+    exchange_rows(rc, wc, recv_l, send_l, group)
     return rk.to(dev), rc.to(dev)
 
 
@@ -279,8 +321,8 @@ def exchange_records_begin(records: torch.Tensor, bin_start: torch.Tensor, group
     dist.all_to_all_single(rb, sb, len_rl, len_sl, group=group)
     wr = _wire(records[:int(cuts[-1])], group)
     rr = torch.empty(sum(recv_l), dtype=records.dtype, device=wr.device)
-    work = dist.all_to_all_single(rr, wr, recv_l, send_l, group=group, async_op=True)
-    return {"work": work, "rr": rr, "wr": wr, "rb": rb, "recv_l": recv_l, "len_rl": len_rl, "world": world, "me": me,
+    exchange_rows(rr, wr, recv_l, send_l, group)       # (in pieces, see exchange_rows: no longer asynchronous)
+    return {"work": None, "rr": rr, "wr": wr, "rb": rb, "recv_l": recv_l, "len_rl": len_rl, "world": world, "me": me,
             "dev": dev}
 
 
@@ -288,7 +330,8 @@ def exchange_records_end(st):
     """Wait for the record all-to-all.  Returns [(records_from_rank, bin_start_full)] for this rank's bins,
     one entry per source rank; bin_start_full has the sender's bin count + 1 entries (empty outside the
     owned range) so that the run can be imported as it is."""
-    st["work"].wait()
+    if st["work"] is not None:
+        st["work"].wait()
     if st["rr"].is_cuda:       # wait() orders torch's stream only; the library runs on its own stream
         torch.cuda.current_stream(st["rr"].device).synchronize()
     world, me, dev, rr, rb = st["world"], st["me"], st["dev"], st["rr"], st["rb"]

@@ -117,7 +117,7 @@ class WgsTrio:
     def _exchange_and_count(self, part: capi.CountTable, shard: int):
         import torch
         import torch.distributed as dist
-        from .dist import _device_view, _wire
+        from .dist import _device_view, _wire, exchange_rows
         W, me, Q = self.world, self.rank, self.passes * self.world
         dev = torch.device("cuda", torch.cuda.current_device())
         vb = [shard_cut(shard * W + g, Q) for g in range(W + 1)]       # owners' ranges in virtual bins
@@ -166,12 +166,12 @@ class WgsTrio:
                 dist.all_to_all_single(rb, sb, off_rl, off_sl, group=self.group)
                 wr = _wire(rec[int(cuts[0]):int(cuts[-1])], self.group)
                 rr = torch.empty(sum(recv_l), dtype=torch.int64, device=wr.device)
-                dist.all_to_all_single(rr, wr, recv_l, send_l, group=self.group)
+                exchange_rows(rr, wr, recv_l, send_l, self.group)
                 re_ = None
                 if wide:
                     we = _wire(ext[int(cuts[0]):int(cuts[-1])], self.group)
                     re_ = torch.empty(sum(recv_l), dtype=torch.int32, device=we.device)
-                    dist.all_to_all_single(re_, we, recv_l, send_l, group=self.group)
+                    exchange_rows(re_, we, recv_l, send_l, self.group)
                     re_ = re_.to(dev)
                 if rr.is_cuda:
                     torch.cuda.current_stream(rr.device).synchronize()   # the library runs on its own stream

@@ -139,7 +139,8 @@ class OracleBackend:
 
 
 def _worker(rank, world, port, q, shard_by):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    # pieces of 4 KB: every (source, destination) share of the record exchange takes many isend / irecv rounds
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RFX_WGS_A2A_MAX_BYTES="4096")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         trio = make_trio(genome_len=30_000, n_pairs=1500, n_snv=4, seed=5, read_seed=100 + rank)

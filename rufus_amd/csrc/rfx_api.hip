@@ -680,7 +680,7 @@ int rfx_mem_stats(rfx_ctx* c, uint64_t* used, uint64_t* peak, uint64_t* mapped) 
 int rfx_memcpy_dev(rfx_ctx* c, void* d_dst, const void* d_src, size_t bytes) {
   if (!c || (bytes && (!d_dst || !d_src))) return RFX_E_INVAL;
   (void)hipSetDevice(c->device);
-  if (bytes) HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  if (bytes) HIPCHK(rfxk::copy_bytes(c, d_dst, d_src, bytes));
   HIPCHK(ctx_sync(c));
   return RFX_OK;
 }
@@ -1634,8 +1634,8 @@ static int msp_passes_leaf(rfx_finish* f) {
       for (uint32_t cb = 0; cb < P1; ++cb) {
         const uint64_t n = cur_prev[cb * stride];
         if (!n) continue;
-        HIPCHK(hipMemcpyAsync(naw + cb * ncap, f->aw + cb * f->cap, n * 8, hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(hipMemcpyAsync(nac + cb * ncap, f->ac + cb * f->cap, n * 4, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(rfxk::copy_bytes(c, naw + cb * ncap, f->aw + cb * f->cap, n * 8));
+        HIPCHK(rfxk::copy_bytes(c, nac + cb * ncap, f->ac + cb * f->cap, n * 4));
       }
       dfree(c, f->aw);
       dfree(c, f->ac);
@@ -1658,8 +1658,8 @@ static int msp_passes_leaf(rfx_finish* f) {
         for (uint32_t cb = 0; cb < P1; ++cb) {
           const uint64_t n = f->h_cur[cb * stride];
           if (!n) continue;
-          HIPCHK(hipMemcpyAsync(naw + cb * ncap, f->aw + cb * f->cap, n * 8, hipMemcpyDeviceToDevice, c->stream));
-          HIPCHK(hipMemcpyAsync(nac + cb * ncap, f->ac + cb * f->cap, n * 4, hipMemcpyDeviceToDevice, c->stream));
+          HIPCHK(rfxk::copy_bytes(c, naw + cb * ncap, f->aw + cb * f->cap, n * 8));
+          HIPCHK(rfxk::copy_bytes(c, nac + cb * ncap, f->ac + cb * f->cap, n * 4));
         }
         dfree(c, f->aw);
         dfree(c, f->ac);
@@ -1894,9 +1894,9 @@ static int msp_emit_collect(rfx_finish* f, rfx_records** out) {
   if ((f->room - total_out) * 20 > (2ull << 30)) {
     rfx_records* fit = records_alloc(c, t->k, t->lsize, t->cols, total_out);
     if (fit) {
-      hipError_t e2 = hipMemcpyAsync(fit->keys, big->keys, total_out * 8, hipMemcpyDeviceToDevice, c->stream);
-      if (e2 == hipSuccess) e2 = hipMemcpyAsync(fit->counts, big->counts, total_out * 4, hipMemcpyDeviceToDevice, c->stream);
-      if (e2 == hipSuccess) e2 = hipMemcpyAsync(fit->pos, big->pos, total_out * 8, hipMemcpyDeviceToDevice, c->stream);
+      hipError_t e2 = rfxk::copy_bytes(c, fit->keys, big->keys, total_out * 8);
+      if (e2 == hipSuccess) e2 = rfxk::copy_bytes(c, fit->counts, big->counts, total_out * 4);
+      if (e2 == hipSuccess) e2 = rfxk::copy_bytes(c, fit->pos, big->pos, total_out * 8);
       if (e2 == hipSuccess) {
         rfx_records_free(big);  // stream-ordered pool: reused only by later work of this stream
         big = fit;
@@ -2141,11 +2141,11 @@ int rfx_count_add_records_ext_dev(rfx_table* t, const uint64_t* d_records, const
   uint32_t* ext = wide ? (uint32_t*)dmalloc(c, (n_records ? n_records : 1) * 4) : nullptr;
   uint64_t* bs = (uint64_t*)dmalloc(c, ((size_t)bins + 1) * 8);
   if (!inst || !bs || (wide && !ext)) { dfree(c, inst); dfree(c, bs); dfree(c, ext); return RFX_E_NOMEM; }
-  hipError_t e = hipMemcpyAsync(bs, d_bin_start, ((size_t)bins + 1) * 8, hipMemcpyDeviceToDevice, c->stream);
+  hipError_t e = rfxk::copy_bytes(c, bs, d_bin_start, ((size_t)bins + 1) * 8);
   if (e == hipSuccess && n_records)
-    e = hipMemcpyAsync(inst, d_records, n_records * 8, hipMemcpyDeviceToDevice, c->stream);
+    e = rfxk::copy_bytes(c, inst, d_records, n_records * 8);
   if (e == hipSuccess && n_records && wide)
-    e = hipMemcpyAsync(ext, d_ext, n_records * 4, hipMemcpyDeviceToDevice, c->stream);
+    e = rfxk::copy_bytes(c, ext, d_ext, n_records * 4);
   if (e != hipSuccess) { dfree(c, inst); dfree(c, bs); dfree(c, ext); return hip_fail(e, "rfx_count_add_records_dev"); }
   if (!t->p2l_bins) t->p2l_bins = bins > 8192 ? 8192 : bins;  // geometry of later rfx_count_add calls
   t->segs->push_back(rfx_segment{inst, n_records, bs, n_records * 4, bins, ext});  // <= 4 k-mers per record
@@ -2471,8 +2471,8 @@ rfx_records* rfx_records_from_dev(rfx_ctx* c, int k, int lsize, const uint64_t* 
   (void)hipSetDevice(c->device);
   rfx_records* r = records_alloc(c, k, lsize, cols, n);
   if (!r || n == 0) return r;
-  bool ok = hipMemcpyAsync(r->keys, d_keys, n * 8, hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
-            hipMemcpyAsync(r->counts, d_counts, n * 4, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+  bool ok = rfxk::copy_bytes(c, r->keys, d_keys, n * 8) == hipSuccess &&
+            rfxk::copy_bytes(c, r->counts, d_counts, n * 4) == hipSuccess;
   if (ok) {
     rfxk::compute_pos(c, r->keys, n, r->lut, r->ntab, r->pos);
     ok = ctx_sync(c) == hipSuccess;
@@ -2745,7 +2745,7 @@ static int ovl_arena_grow(rfx_ovl_pool* p, size_t need) {
   size_t ncap = std::max<size_t>(p->cap * 2, p->used + need + (1u << 20));
   char* na = (char*)dmalloc(c, ncap);
   if (!na) return RFX_E_NOMEM;
-  if (p->used) HIPCHK(hipMemcpyAsync(na, p->arena, p->used, hipMemcpyDeviceToDevice, c->stream));
+  if (p->used) HIPCHK(rfxk::copy_bytes(c, na, p->arena, p->used));
   dfree(c, p->arena);  // stream-ordered
   p->arena = na;
   p->cap = ncap;

@@ -228,6 +228,7 @@ void tile_emit(rfx_ctx*, const rfx_table_view&, const uint64_t* lut, uint32_t ha
 void histo(rfx_ctx*, const uint32_t* counts, uint64_t n, unsigned long long* d_histo);
 void format_records(rfx_ctx*, const uint64_t* keys, const uint32_t* counts, uint64_t n, int key_bytes, int counter_len,
                     uint8_t* out);
+hipError_t copy_bytes(rfx_ctx* c, void* dst, const void* src, size_t bytes);  // big device-to-device copies
 void parse_records(rfx_ctx*, const uint8_t* in, uint64_t n, int key_bytes, int counter_len, uint64_t* keys,
                    uint32_t* counts);
 void compute_pos(rfx_ctx*, const uint64_t* keys, uint64_t n, const uint64_t* lut, int ntab, uint64_t* pos);

@@ -943,12 +943,34 @@ __global__ __launch_bounds__(FB_BLOCK) void k_filter_big(rfx_reads_view rv, cons
   }
 }
 
+// Device-to-device copy of big blocks.  hipMemcpyAsync between a hipMalloc'ed buffer (another runtime's: torch's
+// exchange buffers) and the ctx's VMM-mapped arena took 140 ms per 11 GB segment (~80 GB/s: not a blit kernel);
+// this streams 16 bytes per lane.
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
 namespace rfxk {
+
+hipError_t copy_bytes(rfx_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return hipSuccess;
+  if (bytes < (1u << 20) || (((uintptr_t)dst | (uintptr_t)src) & 15u))
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream);
+  const uint64_t n16 = bytes / 16;
+  {
+    rfx_span sp(c, "k_copy16");
+    hipLaunchKernelGGL(k_copy16, dim3(grid_for(c, n16, 256, 16)), dim3(256), 0, c->stream, (const uint4*)src, (uint4*)dst, n16);
+  }
+  const size_t done = (size_t)n16 * 16;
+  if (done < bytes) return hipMemcpyAsync((char*)dst + done, (const char*)src + done, bytes - done, hipMemcpyDeviceToDevice, c->stream);
+  return hipSuccess;  // (a failed launch surfaces at the next synchronisation, like every other kernel here)
+}
 
 int count_reads_block() { return K2_BLOCK; }
 int count_reads_grid(rfx_ctx* c, uint32_t n_reads) { return grid_for(c, (n_reads + K2_BLOCK - 1) / K2_BLOCK, 1, 3); }

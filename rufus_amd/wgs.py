@@ -128,6 +128,14 @@ class WgsTrio:
         dist.all_reduce(n_seg, op=dist.ReduceOp.MAX, group=self.group)
         rounds = int(n_seg.item())
         own = capi.CountTable(self.ctx, self.k, self.size, True, mode=capi.COUNT_MSP)
+        trace = os.environ.get("RFX_WGS_TRACE")
+        tt = {"meta": 0.0, "alloc": 0.0, "move": 0.0, "import": 0.0}
+
+        def lap(what, t0):
+            if trace:
+                torch.cuda.synchronize(dev)
+                tt[what] += time.perf_counter() - t0
+            return time.perf_counter()
         try:
             own.set_shard(shard * W + me, Q)
             keep = []
@@ -148,6 +156,7 @@ class WgsTrio:
                     bs_host = torch.zeros(bins + 1, dtype=torch.int64)
                     if wide:
                         ext = torch.empty(0, dtype=torch.int32, device=dev)
+                t_ = time.perf_counter()
                 per = bins // 256
                 cuts = bs_host[torch.tensor([v * per for v in vb])]
                 send_l = (cuts[1:] - cuts[:-1]).tolist()
@@ -164,8 +173,10 @@ class WgsTrio:
                 sb = _wire(torch.cat(off_parts).to(dev), self.group)
                 rb = torch.empty(sum(off_rl), dtype=torch.int64, device=sb.device)
                 dist.all_to_all_single(rb, sb, off_rl, off_sl, group=self.group)
+                t_ = lap("meta", t_)
                 wr = _wire(rec[int(cuts[0]):int(cuts[-1])], self.group)
                 rr = torch.empty(sum(recv_l), dtype=torch.int64, device=wr.device)
+                t_ = lap("alloc", t_)
                 exchange_rows(rr, wr, recv_l, send_l, self.group)
                 re_ = None
                 if wide:
@@ -176,6 +187,7 @@ class WgsTrio:
                 if rr.is_cuda:
                     torch.cuda.current_stream(rr.device).synchronize()   # the library runs on its own stream
                 rr, rb = rr.to(dev), rb.cpu()
+                t_ = lap("move", t_)
                 ro = bo = 0
                 for src in range(W):
                     sbins = meta_r[src][1]
@@ -198,6 +210,9 @@ class WgsTrio:
                 self.ctx.sync()             # the imports are copies: the exchange buffers may go
                 keep.clear()
                 del rr
+                t_ = lap("import", t_)
+            if trace:
+                print("[wgs] exchange of shard %d: " % shard + ", ".join(f"{k_} {v * 1e3:.0f} ms" for k_, v in tt.items()), flush=True)
             part.free()                     # the send views were this table's memory
             return own.finish(self.lower, want_histo=True)
         finally:

@@ -11,13 +11,14 @@ ctx = capi.Context(0)
 G = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
 passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n_pairs = G // 10
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 sys_ = [capi.Synth.sample(G, w, n_snv=max(8, G // 3_100_000), seed=12345) for w in range(3)]
 samples = [wgs.make_sample(ctx, sy, n_pairs, 1 << 24, 15, want_good=(i == 0)) for i, sy in enumerate(sys_)]
 res = {}
 for forced in (True, False):
     if not forced:
         os.environ.pop("RFX_WGS_FORCE_EXCHANGE")
-    trio = wgs.WgsTrio(ctx, 25, 8 << 30, 2, 5, 1200, 1, passes=passes, group=dist.group.WORLD)
+    trio = wgs.WgsTrio(ctx, K, 8 << 30, 2, 5, 1200, 1, passes=passes, group=dist.group.WORLD)
     t0 = time.perf_counter()
     r = trio.run(samples)
     ctx.sync()

@@ -109,7 +109,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   unsigned nthreads = (unsigned)std::max(1, threads);
   nthreads = std::min(nthreads, rfx_host_cpus());  // -t 40 on a 16-CPU cgroup: 16 parsers
   if (const char* ev = getenv("RFX_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(ev));
-  const bool msp_ok = k >= 23 && k <= 25;
+  const bool msp_ok = k >= 23 && k <= 31;  // the super-k-mer path (rfx_count_set_passes needs it)
   bool defer = msp_ok && (any_stream || known_bytes > (16ull << 30) || getenv("RFX_COUNT_PASSES"));
   if (const char* ev = getenv("RFX_COUNT_DEFER")) defer = msp_ok && atoi(ev) != 0;
   if (defer && rfx_count_set_passes(tab, 0) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());

@@ -1566,7 +1566,8 @@ static int msp_passes_leaf(rfx_finish* f) {
     // their sort at the end (12 + 12 + 20 B each) runs when no pass records are left, so it does not add up
     // with them.  (Planning with the sum took 5 passes for a 30x sample where 2 fit: measured, 6.3 s of finish.)
     const double surv = (double)windows / 20.0 * 14.0;
-    const double records = (double)windows * 2.9 * 1.15;
+    // (8 B per ~3 k-mers; the wide records of k = 26 .. 31 are 12 B)
+    const double records = (double)windows * (rfxk::msp_wide(t->k) ? 3.6 : 2.9) * 1.15;
     S = 1;
     while (S < 256 && records / S + surv > avail) ++S;
     if (const char* ev = getenv("RFX_COUNT_PASSES")) S = std::max(1, atoi(ev));

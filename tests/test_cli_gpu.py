@@ -279,6 +279,14 @@ def test_count_cli_parallel_ingest_and_shard_passes(tmp_path):
         assert len(blob) == 9 + int(blob[:9]) + len(ref)
         assert os.stat(f"{d}/pre.jf").st_blocks * 512 < len(whole) + (1 << 20)     # nothing left allocated past the end
     assert run("nopre.jf", "reads.fq", {"RFX_NO_PREALLOC": "1", "RFX_CLEAN_EXIT": "1"}) == ref
+    # k = 31 (the tumor/normal config): eager and deferred (shard passes inside the table) agree with the oracle
+    ref31 = oracle.count(None, 31, 8 << 30, lower=2, reads=[x.tobytes() for x in seq]).payload()
+    for extra in ({}, {"RFX_COUNT_DEFER": "1", "RFX_COUNT_PASSES": "3"}):
+        p = subprocess.run([f"{BIN}/jellyfish", "count", "--disk", "-m", "31", "-L", "2", "-s", "8G", "-C", "-t", "8", "-o",
+                            "k31.jf", "reads.fq"], cwd=d, env=dict(env, **extra), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, timeout=300)
+        assert p.returncode == 0, p.stderr
+        assert _payload(f"{d}/k31.jf") == ref31
     assert run("defer.jf", "reads.fq", {"RFX_COUNT_DEFER": "1", "RFX_COUNT_PASSES": "3"}) == ref
     os.mkfifo(f"{d}/pipe.fq")
     feeder = threading.Thread(target=lambda: open(f"{d}/pipe.fq", "wb").write(open(f"{d}/reads.fq", "rb").read()))

@@ -247,9 +247,10 @@ def test_trio_strong_scaled_over_two_ranks(passes, block_pairs, k):
     assert sorted(got[0][5] + got[1][5]) == pulled_o.tolist()
 
 
+@pytest.mark.parametrize("k", [K, 31, 27])
 @pytest.mark.parametrize("passes,surv_frac,refine", [(0, None, None), (1, None, None), (3, None, "17"), (4, "0.0005", None),
                                                       (7, "0.02", "20")])
-def test_table_counts_a_sample_in_shard_passes(ctx, monkeypatch, passes, surv_frac, refine):
+def test_table_counts_a_sample_in_shard_passes(ctx, monkeypatch, passes, surv_frac, refine, k):
     """rfx_count_set_passes: the adds only remember the blocks, finish runs the shard passes inside the table
     and sorts the survivors of all passes once -- the full (pos,key)-ordered record list, as the drop-in
     `jellyfish count` writes it.  A starved survivor store (RFX_MSP_SURV_FRAC) exercises the regrow-and-redo
@@ -261,9 +262,9 @@ def test_table_counts_a_sample_in_shard_passes(ctx, monkeypatch, passes, surv_fr
     sy = capi.Synth.sample(300_000, 0, n_snv=10, seed=99)
     n_pairs = 30_000
     seq, _ = sy.text(0, n_pairs)
-    ref = oracle.count(None, K, SIZE, lower=LOWER, reads=[r.tobytes() for r in seq])
+    ref = oracle.count(None, k, SIZE, lower=LOWER, reads=[r.tobytes() for r in seq])
     blocks = wgs.make_sample(ctx, sy, n_pairs, 8000, MIN_Q, want_good=False)
-    t = capi.CountTable(ctx, K, SIZE)
+    t = capi.CountTable(ctx, k, SIZE)
     t.set_passes(passes)
     for b in blocks:
         t.add(b)

@@ -2,13 +2,13 @@
 # Config W through the drop-in executable: one 30x sample of the 3.1 Gb synthetic genome (6.2e8 reads, 200 GB of FASTQ
 # in tmpfs) -> jellyfish count (--disk) -> .Jhash -> histo / query.  usage: cli_w_sample.sh [pairs=310000000] [genome=3100000000]
 cd "$GRAFT_REPO_ROOT" || exit 1
-PAIRS=${1:-310000000}; G=${2:-3100000000}
+PAIRS=${1:-310000000}; G=${2:-3100000000}; KK=${K:-25}; SAMPLE=${SAMPLE:-0}
 D=/dev/shm/rfx_w; mkdir -p $D; O=gpurun_out/cli_w; mkdir -p $O; BIN=rufus_amd/bin
 df -h /dev/shm | tail -1
-s=$(date +%s.%N); $BIN/rfx_synth_fastq $G 0 1000 12345 0 $PAIRS $D/child.fq || exit 1; e=$(date +%s.%N)
+s=$(date +%s.%N); $BIN/rfx_synth_fastq $G $SAMPLE 1000 12345 0 $PAIRS $D/child.fq || exit 1; e=$(date +%s.%N)
 python3 -c "print('generate: %.1f s' % ($e-$s))"; ls -la $D/child.fq
 s=$(date +%s.%N)
-RFX_CLI_TRACE=1 timeout 900 $BIN/jellyfish count --disk -m 25 -L 2 -s 8G -t 64 -o $D/child.Jhash -C $D/child.fq 2> $O/count.trace; rc=$?
+RFX_CLI_TRACE=1 timeout 900 $BIN/jellyfish count --disk -m $KK -L 2 -s 8G -t 64 -o $D/child.Jhash -C $D/child.fq 2> $O/count.trace; rc=$?
 e=$(date +%s.%N)
 python3 -c "print('jellyfish count rc=$rc: wall %.1f s = %.1f M reads/s' % ($e-$s, 2*$PAIRS/($e-$s)/1e6))"
 cat $O/count.trace
@@ -16,7 +16,7 @@ ls -la $D/child.Jhash
 python3 - <<PY
 import os
 sz = os.path.getsize("$D/child.Jhash"); blob = open("$D/child.Jhash","rb").read(9); hl = int(blob)
-n = (sz - 9 - hl) / 11
+n = (sz - 9 - hl) / ((2 * $KK + 7) // 8 + 4)
 print("records in the file: %.0f  (bench.py's library path counts 3244291368 for this sample at the full size)" % n)
 PY
 s=$(date +%s.%N); RFX_TRACE_LOAD=1 RFX_CLI_TRACE=1 timeout 600 $BIN/jellyfish histo -f -o $D/child.histo $D/child.Jhash 2> $O/histo.trace; e=$(date +%s.%N)
@@ -28,8 +28,8 @@ for ln in open("$D/child.histo"):
 print("histo: distinct(>=2) %d, instances in them %d" % (distinct, tot))
 PY
 # a handful of lookups: read 1's first k-mers (present, count ~30) and a poly-A (absent or rare)
-sed -n 2p $D/child.fq | cut -c1-25 > $D/q.txt; sed -n 2p $D/child.fq | cut -c40-64 >> $D/q.txt
-s=$(date +%s.%N); timeout 600 $BIN/jellyfish query $D/child.Jhash $(cat $D/q.txt) AAAAAAAAAAAAAAAAAAAAAAAAA; e=$(date +%s.%N)
+sed -n 2p $D/child.fq | cut -c1-$KK > $D/q.txt; sed -n 2p $D/child.fq | cut -c40-$((39+KK)) >> $D/q.txt
+s=$(date +%s.%N); timeout 600 $BIN/jellyfish query $D/child.Jhash $(cat $D/q.txt) $(printf "A%.0s" $(seq 1 $KK)); e=$(date +%s.%N)
 python3 -c "print('jellyfish query (3 k-mers): %.2f s' % ($e-$s))"
 nvidia-smi >/dev/null 2>&1; rocm-smi --showmemuse 2>/dev/null | grep -i "vram" | head -2
 rm -rf $D

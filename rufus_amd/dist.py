@@ -238,7 +238,7 @@ def _wire(t: torch.Tensor, group) -> torch.Tensor:
 
 def exchange_rows(out: torch.Tensor, inp: torch.Tensor, recv_l, send_l, group, max_bytes: int = 0):
     """all_to_all_single(out, inp, recv_l, send_l) for payloads that can be GBs per peer: this rank's own share is a
-    device copy, every other (source, destination) share travels in pieces of at most max_bytes (default 512 MiB,
+    device copy, every other (source, destination) share travels in pieces of at most max_bytes (default 256 MiB,
     RFX_WGS_A2A_MAX_BYTES), one grouped isend/irecv round per piece.  RCCL 2.26's send/recv delivers only the first
     half of a message beyond ~1 GiB (measured on the one-rank group: scratch/a2a_big.py -- 1.0 GiB arrives whole,
     1.5 GiB and 10 GiB arrive as their first half), silently; pieces this size are far below that."""
@@ -255,7 +255,7 @@ def exchange_rows(out: torch.Tensor, inp: torch.Tensor, recv_l, send_l, group, m
     if world == 1:
         return
     if not max_bytes:
-        max_bytes = int(os.environ.get("RFX_WGS_A2A_MAX_BYTES", 512 << 20))
+        max_bytes = int(os.environ.get("RFX_WGS_A2A_MAX_BYTES", 256 << 20))
     m = max(1, max_bytes // inp.element_size())
     most = max([int(send_l[d]) for d in range(world) if d != me] + [int(recv_l[d]) for d in range(world) if d != me] + [0])
     rounds = -(-most // m)

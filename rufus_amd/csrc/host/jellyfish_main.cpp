@@ -218,12 +218,24 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   const auto t_count = std::chrono::steady_clock::now();
   trace("count: input parsed and queued");
 
-  rfx_records* rec = rfx_count_finish(tab, lower, upper, nullptr);
+  // RFX_COUNT_HISTO=1 (opt-in, not jellyfish behaviour): also write OUT.histo, byte for byte what
+  // `jellyfish histo -f -o OUT.histo OUT` would -- the count has the histogram anyway, and
+  // scripts/RunJellyForRUFUS.sh:36-38 runs histo only when that file is missing (a 35 GB re-read saved per sample).
+  const bool side_histo = getenv("RFX_COUNT_HISTO") != nullptr;
+  std::vector<uint64_t> hist(side_histo ? RFX_HISTO_BINS : 0);
+  rfx_records* rec = rfx_count_finish(tab, lower, upper, side_histo ? hist.data() : nullptr);
   if (!rec) die(std::string("rufus_amd: finish failed: ") + rfx_last_error());
   trace("count: finished on the device");
   for (rfx_reads* r : resident) rfx_reads_free(r);
   std::vector<uint64_t> cols(2 * (size_t)k);
   rfx_jf_matrix(lsize, k, cols.data());
+  if (side_histo && rec) {
+    const std::string hp = std::string(out) + ".histo";
+    if (FILE* hf = fopen(hp.c_str(), "w")) {
+      for (int i = 0; i < RFX_HISTO_BINS; ++i) fprintf(hf, "%d %llu\n", i, (unsigned long long)hist[(size_t)i]);
+      fclose(hf);
+    }
+  }
   const int out_fd = prealloc.take();
   write_jhash(out, rec, cols.data(), canonical, out_counter_len, full_argc, full_argv,
               ingest ? ingest->lend_buffers(48u << 20) : std::vector<std::pair<char*, size_t>>(), out_fd,

@@ -31,6 +31,12 @@ def test_jellyfish_and_filter_executables_reproduce_the_goldens(testrun, tmp_pat
         blob = open(f"{d}/{s}.Jhash", "rb").read()
         hlen = int(blob[:9])
         assert hashlib.sha256(blob[9 + hlen:]).hexdigest() == exp["samples"][s]["s100M"]["payload_sha256"]
+        if s == "Child":      # the opt-in side output of count == what histo -f writes
+            r = subprocess.run([f"{BIN}/jellyfish", "count", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "4", "-o",
+                                "side.Jhash", "-C", f"{s}.fq"], cwd=d, env=dict(os.environ, RFX_COUNT_HISTO="1"))
+            assert r.returncode == 0
+            side = open(f"{d}/side.Jhash.histo", "rb").read()
+            assert hashlib.md5(side).hexdigest() == exp["samples"][s]["s100M"]["histo_full_md5"]
         r = sh([f"{BIN}/jellyfish", "histo", "-f", "-o", f"{s}.Jhash.histo", f"{s}.Jhash"], d)
         assert r.returncode == 0, r.stderr
         h = open(f"{d}/{s}.Jhash.histo", "rb").read()

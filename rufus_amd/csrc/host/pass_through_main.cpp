@@ -243,24 +243,19 @@ void process_stream(unsigned helpers, Parse parse, Consume consume) {
       if (pc->text.size() < fill + PIECE + (1u << 20)) pc->text.resize(fill + PIECE + (1u << 20));
       memcpy(pc->text.data(), carry.data(), fill);
       carry.clear();
-      while (fill < PIECE || (fill == pc->text.size())) {
-        if (fill == pc->text.size()) pc->text.resize(fill * 2);  // one line longer than the buffer
+      // a piece = at least PIECE bytes AND at least one line end (a line may be longer than any buffer so far)
+      bool have_nl = fill && memchr(pc->text.data(), '\n', fill);
+      while (fill < PIECE || !have_nl) {
+        if (fill == pc->text.size()) pc->text.resize(fill * 2);
         const ssize_t n = ::read(0, pc->text.data() + fill, pc->text.size() - fill);
         if (n < 0 && errno == EINTR) continue;
         if (n <= 0) { eof = true; break; }
+        if (!have_nl && memchr(pc->text.data() + fill, '\n', (size_t)n)) have_nl = true;
         fill += (size_t)n;
-        if (fill >= PIECE && memchr(pc->text.data() + fill - (size_t)n, '\n', (size_t)n)) break;
       }
       size_t cut = fill;
-      if (!eof) {  // back to the last line end
+      if (!eof) {  // back to the last line end (there is one)
         while (cut > 0 && pc->text[cut - 1] != '\n') --cut;
-        if (cut == 0) {  // (not a single line end yet: keep reading into the same piece)
-          carry.assign(pc->text.data(), pc->text.data() + fill);
-          std::lock_guard<std::mutex> g(mu);
-          spare.push_back(pc);
-          --in_flight;
-          continue;
-        }
         carry.assign(pc->text.data() + cut, pc->text.data() + fill);
       }
       pc->size = cut;
@@ -481,6 +476,18 @@ int main(int argc, char** argv) {
     o.append(qual, lq);
     o.push_back('\n');
   };
+  // A chunk never grows past CHUNK: it is flushed BEFORE a pair that would not fit (a record may be tens of KB: a
+  // chunk of CHUNK - 1 bytes plus one such record would not fit a 64 KB pipe, and the alternating reader would wait
+  // on the other pipe for ever); a pair that is larger than CHUNK by itself travels alone -- mate 1 then mate 2,
+  // the order the reader consumes them in, which is what the reference does for every pair.
+  auto add_pair = [&](const char* name, size_t nn, const char* s1, size_t ls1, const char* q1, size_t lq1, const char* s2,
+                      size_t ls2, const char* q2, size_t lq2) {
+    const size_t a = nn + ls1 + lq1 + 6, b = nn + ls2 + lq2 + 6;
+    if ((!out1.empty() || !out2.empty()) && (out1.size() + a > CHUNK || out2.size() + b > CHUNK)) flush_pairs();
+    put_text(out1, name, nn, s1, ls1, q1, lq1);
+    put_text(out2, name, nn, s2, ls2, q2, lq2);
+    if (out1.size() >= CHUNK || out2.size() >= CHUNK) flush_pairs();
+  };
   Waiting waiting;
   // (measured on the 16-CPU GPU box, 32 M reads into drained pipes: 0 / 4 / 8 helpers = 6.7 / 12.4 / 8.9 M reads/s --
   // the pairing thread is the limit from four on, and the filter behind the pipes wants CPUs too)
@@ -500,11 +507,9 @@ int main(int argc, char** argv) {
           waiting.insert(r.hash, r.name, r.name_len, r.seq, r.seq_len, r.qual, r.qual_len);
         } else {
           const Waiting::Entry& en = waiting.pool[waiting.slot[(size_t)at] - 2];
-          put_text(out1, r.name, r.name_len, r.seq, r.seq_len, r.qual, r.qual_len);
-          put_text(out2, r.name, r.name_len, en.bytes.data() + en.name_len, en.seq_len,
+          add_pair(r.name, r.name_len, r.seq, r.seq_len, r.qual, r.qual_len, en.bytes.data() + en.name_len, en.seq_len,
                    en.bytes.data() + en.name_len + en.seq_len, en.bytes.size() - en.name_len - en.seq_len);
           waiting.erase(at);
-          if (out1.size() >= CHUNK || out2.size() >= CHUNK) flush_pairs();
         }
       }
     });
@@ -570,11 +575,9 @@ int main(int argc, char** argv) {
       waiting.insert(nh, f[0].p, f[0].n, sp, sn, qp, qn);
     } else {
       const Waiting::Entry& en = waiting.pool[waiting.slot[(size_t)at] - 2];
-      put_text(out1, f[0].p, f[0].n, sp, sn, qp, qn);
-      put_text(out2, f[0].p, f[0].n, en.bytes.data() + en.name_len, en.seq_len,
+      add_pair(f[0].p, f[0].n, sp, sn, qp, qn, en.bytes.data() + en.name_len, en.seq_len,
                en.bytes.data() + en.name_len + en.seq_len, en.bytes.size() - en.name_len - en.seq_len);
       waiting.erase(at);
-      if (out1.size() >= CHUNK || out2.size() >= CHUNK) flush_pairs();
     }
 #endif
 #endif

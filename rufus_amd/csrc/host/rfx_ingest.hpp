@@ -32,6 +32,63 @@
 
 namespace rfxcli {
 
+// The stream cutter's line count.  Fast pass: newlines of [p, e) and how many of them are blank lines (a '\n' at a
+// line start); at_start (in / out): the byte at p begins a line.
+static inline void count_newlines_plain(const char* p, const char* e, bool& at_start, size_t& nl, size_t& blanks) {
+  for (; p < e; ++p) {
+    if (*p == '\n') {
+      ++nl;
+      blanks += at_start;
+      at_start = true;
+    } else {
+      at_start = false;
+    }
+  }
+}
+#if RFX_X86
+__attribute__((target("avx2,popcnt"))) static inline void count_newlines_avx2(const char* p, const char* e, bool& at_start,
+                                                                             size_t& nl, size_t& blanks) {
+  const __m256i v = _mm256_set1_epi8('\n');
+  while (e - p >= 32) {
+    const uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)p), v));
+    nl += (size_t)__builtin_popcount(m);
+    blanks += (size_t)__builtin_popcount(m & ((m << 1) | (at_start ? 1u : 0u)));
+    at_start = (m >> 31) & 1u;
+    p += 32;
+  }
+  count_newlines_plain(p, e, at_start, nl, blanks);
+}
+#endif
+static inline void count_newlines(const char* p, const char* e, bool& at_start, size_t& nl, size_t& blanks) {
+  nl = blanks = 0;
+#if RFX_X86
+  static const bool fast = (__builtin_cpu_init(), __builtin_cpu_supports("avx2") && __builtin_cpu_supports("popcnt"));
+  if (fast) return count_newlines_avx2(p, e, at_start, nl, blanks);
+#endif
+  count_newlines_plain(p, e, at_start, nl, blanks);
+}
+// Slow pass (only for stretches that hold blank lines): the grammar parse_piece applies -- blank lines BETWEEN records
+// are skipped, an empty sequence or quality line inside a record is a line.  line_in_rec: lines of the current
+// record seen so far; rec_end: set to just after the last line that completed a record (untouched if none did).
+static inline void walk_fastq_lines(const char* p, const char* e, bool& at_start, uint64_t& line_in_rec, const char*& rec_end) {
+  bool partial = !at_start;  // p continues a line that began earlier: it is not blank
+  while (p < e) {
+    const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+    if (!nl) {
+      at_start = false;
+      return;
+    }
+    const bool blank = nl == p && !partial;
+    partial = false;
+    if (!(line_in_rec == 0 && blank) && ++line_in_rec == 4) {
+      line_in_rec = 0;
+      rec_end = nl + 1;
+    }
+    p = nl + 1;
+    at_start = true;
+  }
+}
+
 struct StageBlock {
   uint64_t* codes = nullptr;
   uint32_t *acgt = nullptr, *word_off = nullptr, *len = nullptr;
@@ -505,7 +562,10 @@ class CountIngest {
     size_t fill = 0;
     uint64_t line_in_rec = 0;  // lines of the current record already inside buf[0, scanned)
     size_t scanned = 0, last_cut = 0;
-    auto fresh = [&]() {
+    // FASTQ: blank lines do not count (parse_piece skips them between records, as the mapped and pread routes do);
+    // line_start = the byte at `scanned` begins a line
+    bool line_start = true;
+    auto fresh = [&](size_t at_least) {
       // bound the text in flight (2 x workers pieces); this thread is also the uploader, so full blocks are
       // uploaded while it waits -- the workers may be waiting for exactly that
       std::vector<char>* v = nullptr;
@@ -525,16 +585,21 @@ class CountIngest {
         drain(false);
       }
       if (!v) v = new std::vector<char>(PIECE + std::max<size_t>(PIECE / 8, 1u << 16));
+      if (v->size() < at_least + PIECE) v->resize(at_least + PIECE + std::max<size_t>(PIECE / 8, 1u << 16));
       return v;
     };
-    buf = fresh();
+    buf = fresh(head.size());
     memcpy(buf->data(), head.data(), head.size());
     fill = head.size();
-    bool eof = false;
+    bool eof = false, need_more = false;
     while (!eof || fill > 0) {
       if (failed_) break;
-      // read until the buffer holds a piece
-      while (!eof && fill < PIECE) {
+      // read until the buffer holds a piece (and, after a pass that found no record end, something new)
+      while (!eof && (fill < PIECE || need_more)) {
+        if (fill == buf->size()) {  // one record longer than the buffer: grow it (a real limit ends the run)
+          if (buf->size() >= ((size_t)1 << 31)) die("a FASTQ record is longer than 2 GiB");
+          buf->resize(buf->size() * 2);
+        }
         const ssize_t n = ::read(fd, buf->data() + fill, buf->size() - fill);
         if (n < 0) {
           if (errno == EINTR) continue;
@@ -542,28 +607,38 @@ class CountIngest {
         }
         if (n == 0) eof = true;
         else fill += (size_t)n;
+        need_more = false;
       }
       // last record boundary inside [0, fill): count the new lines (32 bytes per step), then walk to the newline
       // that completes the last whole record
       const char* d = buf->data();
-      size_t got = 0;
-      (void)skip_lines_(d + scanned, d + fill, ~(size_t)0, got);
-      const uint64_t total_lines = line_in_rec + got, recs = total_lines / lines_per_rec;
-      if (recs) {
-        size_t g2 = 0;
-        const char* cut_at = skip_lines_(d + scanned, d + fill, (size_t)(recs * lines_per_rec - line_in_rec), g2);
-        last_cut = (size_t)(cut_at - d);
+      size_t got = 0, blanks = 0;
+      bool st = line_start;
+      count_newlines(d + scanned, d + fill, st, got, blanks);
+      if (sam_ || blanks == 0) {
+        const uint64_t total_lines = line_in_rec + got, recs = total_lines / lines_per_rec;
+        if (recs) {
+          size_t g2 = 0;
+          const char* cut_at = skip_lines_(d + scanned, d + fill, (size_t)(recs * lines_per_rec - line_in_rec), g2);
+          last_cut = (size_t)(cut_at - d);
+        }
+        line_in_rec = total_lines - recs * lines_per_rec;
+      } else {  // blank lines: between records they do not count (parse_piece skips them there)
+        st = line_start;
+        const char* rec_end = nullptr;
+        walk_fastq_lines(d + scanned, d + fill, st, line_in_rec, rec_end);
+        if (rec_end) last_cut = (size_t)(rec_end - d);
       }
-      line_in_rec = total_lines - recs * lines_per_rec;
       scanned = fill;
+      line_start = st;
       size_t cut = eof ? fill : last_cut;
       if (cut == 0) {
-        if (fill == buf->size()) die("a FASTQ record is longer than the read buffer");
         if (eof) break;
+        need_more = true;  // not one whole record yet: keep reading into the same buffer
         continue;
       }
-      std::vector<char>* next = fresh();
       const size_t rest = fill - cut;
+      std::vector<char>* next = fresh(rest);
       memcpy(next->data(), d + cut, rest);
       {
         Piece pc{d, d + cut, buf};

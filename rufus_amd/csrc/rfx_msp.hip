@@ -25,6 +25,22 @@
 #include "rfx_devutil.h"
 #include "rfx_internal.h"
 
+#ifdef RFX_TIMING
+__device__ unsigned long long g_tm[32];
+#define TM_DECL unsigned long long tm_prev = __builtin_amdgcn_s_memtime()
+#define TM(i) do { if (threadIdx.x == 0) { const unsigned long long tm_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_tm[i], tm_now - tm_prev); tm_prev = tm_now; } } while (0)
+extern "C" int rfx_debug_timing(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tm), sizeof(g_tm)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tm), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#define TMC(i, c) do { if (threadIdx.x == 0 && (c)) atomicAdd(&g_tm[i], 1ull); } while (0)
+#else
+#define TM_DECL
+#define TM(i)
+#define TMC(i, c)
+#endif
+
 namespace {
 
 // HMODE 0: scatter into fixed-capacity coarse bins + 16-bit fine histogram (one pass, optimistic)
@@ -78,7 +94,9 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     uint32_t a[WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-(WL-1) .. p0+7
 #pragma unroll
     for (int i = 0; i < WL - 1 + P1_S; ++i) a[i] = ~0u;
+    TM_DECL;
     for (uint32_t ph = 0; ph < n_phase; ++ph) {
+      TM(3);
       uint64_t wv[P1_S];
       uint32_t xv[WIDE ? P1_S : 1];
       uint32_t br[P1_S];  // (coarse bin << 16) | rank, or ~0: no record closed at this base
@@ -116,7 +134,11 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
           if (run_n && (!kvalid || mh != run_h || run_n == MSP_NMAX)) {
             // close the run that ended at the previous base: `hist` still ends there
             const uint32_t run_bin = msp_bin(run_h, bin_bits);
+#ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
+            const bool mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
+#else
             const bool mine = run_bin >= bin_lo && run_bin < bin_hi;  // shard passes: other bins are not ours
+#endif
             if (HMODE != 1 && mine) {
               const int L = k + run_n - 1;
               const uint32_t coarse = run_bin >> sub_bits;
@@ -162,6 +184,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
       }
 #pragma unroll
       for (int i = 0; i < WL - 1; ++i) a[i] = a[i + P1_S];
+      TM(0);
       if (HMODE == 1) continue;
       // Every lane stores its own records straight into the reserved runs (rank inside the run = the
       // value its LDS atomic returned).  The stores of one run come from many lanes, but they fall into
@@ -179,6 +202,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
         }
       }
       __syncthreads();
+      TM(1);
 #pragma unroll
       for (int b = 0; b < P1_S; ++b)
         if (br[b] != ~0u) {
@@ -189,6 +213,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
           }
           ++n_emit;
         }
+      TM(2);
       // no barrier here: s_gbase is rewritten only after the next phase's first barrier
     }
   }
@@ -277,7 +302,9 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     int r = 0;
     uint32_t j = 0;
     bool failed = false;
+    TM_DECL;
     for (;;) {
+      TM(15);
       for (int i = threadIdx.x; i < TBL; i += BLK) {
         s_keys[i] = RFX_EMPTY;
         s_cnt[i] = 0;
@@ -294,6 +321,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         s_nl = 0;
       }
       __syncthreads();
+      TM(8);
       // k-mer q of record x into the table, counted `mult` times.
       auto insert_kmer = [&](uint64_t x, uint32_t xe, int q, uint32_t mult) {
         const int n = (int)((x >> 56) & 3u) + 1;
@@ -421,6 +449,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         prefetched_next = true;
       }
       __syncthreads();
+      TM(9);
       {  // Phase B: pack the cache (in place, through registers), then one dense pass over the distinct records
         uint64_t ex[RC / BLK];
         uint32_t ec[RC / BLK];
@@ -442,6 +471,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
           }
         __syncthreads();
         const uint32_t nrec = s_nl;
+        TM(10);
         // one k-mer per thread: four times the parallelism of one record per thread, and the table
         // round trips of a record's k-mers overlap instead of queueing in one lane
         for (uint32_t i = threadIdx.x; i < MSP_NMAX * nrec; i += BLK)
@@ -450,6 +480,9 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         if (threadIdx.x == 0) s_nl = 0;
       }
       __syncthreads();
+      TM(11);
+      TMC(20, s_ovf != 0);
+      TMC(21, 1);
       const bool ovf = s_ovf != 0;
       if (!ovf) {
         // Survivors are few (a twelfth of the slots on 30x data): gather them into a dense list first so
@@ -508,7 +541,9 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
           __syncthreads();
           if (s_nl > LIST - 2 * BLK) flush();  // the next two rounds might not fit
         }
+        TM(12);
         flush();
+        TM(13);
       }
       __syncthreads();
       if (ovf) {  // split this sub-range

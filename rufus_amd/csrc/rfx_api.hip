@@ -234,7 +234,8 @@ void dfree(rfx_ctx* c, void* p) {
 // ---- pinned scratch -------------------------------------------------------------------------------
 // Stream sync + delivery of the queued read-backs; every synchronisation of the API goes through here.
 hipError_t ctx_sync(rfx_ctx* c) {
-  const hipError_t e = hipStreamSynchronize(c->stream);
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && c->launch_error != hipSuccess) e = c->launch_error;  // a launch that could not be set up
   if (e == hipSuccess)
     for (auto& r : c->pin_reads) memcpy(r.dst, c->pin + r.off, r.n);
   c->pin_reads.clear();
@@ -598,6 +599,17 @@ void dfree(rfx_ctx* c, void* p) { ::dfree(c, p); }
 void set_error(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
 hipError_t sync(rfx_ctx* c) { return ctx_sync(c); }
 hipError_t queue_read(rfx_ctx* c, void* dst, const void* d_src, size_t n) { return ::queue_read(c, dst, d_src, n); }
+bool lds_opt_in(rfx_ctx* c, const void* fn, size_t bytes, int bit, const char* name) {
+  if (c->lds_opt_in & (1u << bit)) return true;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof g_err, "%s: %zu bytes of dynamic LDS refused: %s", name, bytes, hipGetErrorString(e));
+    c->launch_error = e;
+    return false;
+  }
+  c->lds_opt_in |= 1u << bit;
+  return true;
+}
 }  // namespace rfxi
 
 extern "C" {
@@ -1187,24 +1199,44 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
       hipError_t e = hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream);
       if (e == hipSuccess) e = hipMemsetAsync(bin_start, 0, ((size_t)P + 1) * 8, c->stream);
       if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
-      rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr,
-                      cur + g.ncur, ext_a0);
-      rfxk::surv_hist(c, buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
-      rfxk::scan_tail(c, bin_start, P);
+      // the exact fine histogram comes with the scatter (16-bit LDS counters, 64 KB per workgroup); only if one of
+      // them wrapped are the records read once more for it
+      uint32_t* cnt = getenv("RFX_MSP_REC_HIST") ? nullptr : (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
+      if (cnt) {
+        rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 3, g.G, buf_a0, cur, (uint32_t)cap_a, cnt,
+                        cur + g.ncur, ext_a0);
+        rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
+      } else {
+        rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr,
+                        cur + g.ncur, ext_a0);
+        rfxk::surv_hist(c, buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
+        rfxk::scan_tail(c, bin_start, P);
+      }
       uint64_t total = 0;
       std::vector<uint32_t> h_cur(g.ncur + 1, 0);
       e = queue_read(c, &total, bin_start + P, 8);
       if (e == hipSuccess) e = queue_read(c, h_cur.data(), cur, (g.ncur + 1) * 4);
       if (e == hipSuccess) e = ctx_sync(c);
+      dfree(c, cnt);
       if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
       if (h_cur[g.ncur]) {  // a coarse bin overflowed: the cursors kept counting, they say what it needs
         uint64_t need = 0;
         for (uint32_t cb = 0; cb < g.P1; ++cb) need = std::max<uint64_t>(need, h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
-        dfree(c, buf_a);
-        dfree(c, ext_a);
-        if (attempt >= 3 || need >= (1ull << 32) - 65536) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
-        cap_a = need + need / 64 + 1024;
-        continue;
+        if (need <= cap_a && cnt) {  // ... or only a 16-bit counter of the fused histogram wrapped: count the records
+          e = hipMemsetAsync(bin_start, 0, ((size_t)P + 1) * 8, c->stream);
+          if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
+          rfxk::surv_hist(c, buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
+          rfxk::scan_tail(c, bin_start, P);
+          e = queue_read(c, &total, bin_start + P, 8);
+          if (e == hipSuccess) e = ctx_sync(c);
+          if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
+        } else {
+          dfree(c, buf_a);
+          dfree(c, ext_a);
+          if (attempt >= 3 || need >= (1ull << 32) - 65536) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
+          cap_a = need + need / 64 + 1024;
+          continue;
+        }
       }
       uint64_t* inst = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
       uint32_t* ext = wide ? (uint32_t*)dmalloc(c, (total ? total : 1) * 4) : nullptr;
@@ -1427,7 +1459,7 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
   }
   const uint64_t** d_ptrs = (const uint64_t**)dmalloc(c, 3 * nleaf * sizeof(void*) * (cut.size() - 1));
   if (!d_ptrs) { drop(); return RFX_E_NOMEM; }
-  int geo = (kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1)) >> to_bits < 8192 ? 1 : 0;
+  int geo = (kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1)) >> to_bits <= 12288 ? 1 : 0;
   if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
   for (size_t ci = 0; ci + 1 < cut.size(); ++ci) {
     const uint32_t p0 = cut[ci], np = cut[ci + 1] - cut[ci];
@@ -1519,6 +1551,16 @@ static int msp_prepare_leaf(rfx_table* t, int* to_bits_out, bool* refine_out, st
   // RFX_MSP_WIDE_HALF=1 brings that back for comparison)
   const uint64_t per_bin = rfxk::msp_wide(t->k) && getenv("RFX_MSP_WIDE_HALF") ? 12288 : 24576;
   while (to_bits < 28 && (kfull >> to_bits) > per_bin) ++to_bits;
+  // When the partition has to be refined anyway, one more bit costs nothing (as long as it does not take another
+  // level of <= 8 bits): bins of half the size go through the half-size leaf, two workgroups per CU, which hides
+  // the barriers of one behind the other -- 117 -> 108 ms per sample on the 1 Gb slice.  (Wide records stay with
+  // the full-size leaf: their plane cache needs the room.)
+  if (!rfxk::msp_wide(t->k) && !getenv("RFX_MSP_NO_HALF") && pmin < (1u << to_bits) && to_bits < 28) {
+    const int lo = ceil_log2(pmin), hi = ceil_log2(pmax);
+    auto levels = [](int d) { return d <= 0 ? 0 : (d + 7) / 8; };
+    if (levels(to_bits + 1 - lo) == levels(to_bits - lo) && levels(to_bits + 1 - hi) == std::max(levels(to_bits - hi), 1))
+      ++to_bits;
+  }
   if (getenv("RFX_MSP_REFINE_BITS")) to_bits = std::max(to_bits, atoi(getenv("RFX_MSP_REFINE_BITS")));
   const bool refine = force_refine || pmin < (1u << to_bits);
   h_bs.clear();

@@ -55,6 +55,10 @@ struct rfx_ctx {
   std::map<size_t, size_t> arena_free;    // offset -> length of free ranges inside [0, arena_mapped)
   bool arena_off = false;                 // VMM unavailable (or RFX_NO_ARENA): size-keyed cache of hipMalloc blocks
   size_t peak_used = 0;
+  // kernels that need more than 64 KB of dynamic LDS opt in once per ctx (= per device: the attribute belongs to the
+  // device's copy of the function); a refused opt-in is remembered and fails the next synchronisation
+  uint32_t lds_opt_in = 0;
+  hipError_t launch_error = hipSuccess;
   std::vector<struct rfx_table*> pend_tables;  // tables with unread MSP capacity flags
   double msp_surv_frac[2] = {0, 0};            // survivors / instances seen by the last MSP emit ([lower >= 2])
   // pinned host scratch: small read-backs and uploads go through it (pageable copies cost a
@@ -333,6 +337,8 @@ void dfree(rfx_ctx*, void*);
 void set_error(const char* msg);
 hipError_t sync(rfx_ctx*);                                               // stream sync + queued read-backs
 hipError_t queue_read(rfx_ctx*, void* dst, const void* d_src, size_t n);  // lands at the next sync
+// once per ctx and kernel (`bit` names the kernel): allow `bytes` of dynamic LDS; false (and the ctx poisoned) if refused
+bool lds_opt_in(rfx_ctx*, const void* fn, size_t bytes, int bit, const char* name);
 }  // namespace rfxi
 
 // Launch bracket: records a HIP-event span on the ctx stream when profiling is on.

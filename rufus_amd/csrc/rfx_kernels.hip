@@ -1020,11 +1020,7 @@ void tile_emit(rfx_ctx* c, const rfx_table_view& tv, const uint64_t* lut, uint32
                uint64_t upper, const uint64_t* tile_off, uint64_t n_tiles, uint32_t sort_cap, uint64_t* out_keys,
                uint32_t* out_counts, uint64_t* out_pos) {
   const size_t lds = (size_t)8 * 256 * 8 + (size_t)sort_cap * 20;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)k_tile_emit, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    attr_set = true;
-  }
+  if (!rfxi::lds_opt_in(c, (const void*)k_tile_emit, 160 * 1024 - 64, 0, "k_tile_emit")) return;
   rfx_span sp(c, "k_tile_emit");
   hipLaunchKernelGGL(k_tile_emit, dim3(grid_for(c, n_tiles, 1, 8)), dim3(256), lds, c->stream, tv, lut, halo, lower,
                      upper, tile_off, n_tiles, sort_cap, out_keys, out_counts, out_pos);
@@ -1142,8 +1138,7 @@ void filter_big(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int
                 const uint32_t* bm, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
                 unsigned long long* d_nhit) {
   if (rv.n == 0) return;
-  // 128 KB of dynamic LDS: opt in (per device: the attribute is cheap to set, so simply on every launch)
-  (void)hipFuncSetAttribute((const void*)k_filter_big, hipFuncAttributeMaxDynamicSharedMemorySize, FB_WORDS * 4);
+  if (!rfxi::lds_opt_in(c, (const void*)k_filter_big, FB_WORDS * 4, 1, "k_filter_big")) return;  // 128 KB of dynamic LDS
   rfx_span sp(c, "k_filter");
   const uint32_t chunks = (rv.n + FB_BLOCK - 1) / FB_BLOCK;
   const int grid = (int)std::min<uint32_t>(chunks, (uint32_t)c->n_cu);  // one resident workgroup per CU

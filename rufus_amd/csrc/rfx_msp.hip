@@ -43,7 +43,8 @@ extern "C" int rfx_debug_timing(unsigned long long* out, int reset) {
 
 namespace {
 
-// HMODE 0: scatter into fixed-capacity coarse bins + 16-bit fine histogram (one pass, optimistic)
+// HMODE 0: scatter into fixed-capacity coarse bins + 16-bit fine histogram (one pass, optimistic; <= 8192 bins)
+//       3: the same with 64 KB of LDS for the histogram: up to 32768 bins (big read blocks)
 //       1: 32-bit fine histogram only            } the exact redo after HMODE 0 raised its flag;
 //       2: scatter only                          } cap_a then comes from the cursors of the failed run
 // 512 threads = reads per chunk.  The kernel needs 82 VGPRs = 5 waves per SIMD: two 512-thread workgroups per CU
@@ -60,9 +61,13 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
                                                          uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
                                                          uint32_t* __restrict__ cnt_rows,
                                                          unsigned int* __restrict__ flag) {
-  __shared__ uint32_t s_cnt[P1_BINS];
-  __shared__ uint64_t s_gbase[P1_BINS];  // 64-bit: the exact redo may size a coarse bin by a skewed maximum
-  __shared__ uint32_t s_fine[HMODE == 0 ? 4096 : HMODE == 1 ? 8192 : 1];
+  // Two of each, by phase parity (the second barrier of a phase then only has to cover the addresses).  Tried in
+  // round 3 and dropped: reserving phase p's runs while phase p + 1 is hashed and storing p's records one phase late
+  // (one barrier per phase, nobody waits for the atomic) -- 126 VGPRs, 94 instead of 90 ms per 1 Gb sample: the other
+  // workgroup of the CU already covers the round trip, the kernel is bound by what it issues.
+  __shared__ uint32_t s_cnt[2][P1_BINS];
+  __shared__ uint64_t s_gbase[2][P1_BINS];  // 64-bit: the exact redo may size a coarse bin by a skewed maximum
+  __shared__ uint32_t s_fine[HMODE == 0 ? 4096 : HMODE == 1 ? 8192 : HMODE == 3 ? 16384 : 1];
   __shared__ uint32_t s_maxlen;
   const uint32_t P = 1u << bin_bits;
   const int sub_bits = bin_bits - 7;  // P1_BINS = 2^7 coarse bins
@@ -74,7 +79,9 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) s_fine[i] = 0;
   if (HMODE == 1)
     for (uint32_t i = threadIdx.x; i < 8192; i += blockDim.x) s_fine[i] = 0;
-  if (threadIdx.x < P1_BINS) s_cnt[threadIdx.x] = 0;
+  if (HMODE == 3)
+    for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) s_fine[i] = 0;
+  if (threadIdx.x < 2 * P1_BINS) (&s_cnt[0][0])[threadIdx.x] = 0;
   const uint32_t n_chunks = (rv.n + MP1_BLOCK - 1) / MP1_BLOCK;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t r = chunk * MP1_BLOCK + threadIdx.x;
@@ -97,128 +104,146 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     TM_DECL;
     for (uint32_t ph = 0; ph < n_phase; ++ph) {
       TM(3);
+      const uint32_t X = ph & 1u;
       uint64_t wv[P1_S];
       uint32_t xv[WIDE ? P1_S : 1];
       uint32_t br[P1_S];  // (coarse bin << 16) | rank, or ~0: no record closed at this base
-      const uint32_t p0 = ph * P1_S;
-      if ((ph & 3) == 0 && p0 < len) {
-        cur_w = cw[p0 >> 5];
-        cur_m = cm[p0 >> 5];
-      }
-      // window minimum = min(suffix minimum of the 14 old hashes, prefix minimum of the new ones)
-      uint32_t sfx[WL - 1];
-      sfx[WL - 2] = a[WL - 2];
 #pragma unroll
-      for (int i = WL - 3; i >= 0; --i) sfx[i] = min(a[i], sfx[i + 1]);
-      uint32_t pm = ~0u;
-#pragma unroll
-      for (int b = 0; b < P1_S; ++b) {
-        br[b] = ~0u;
-        if (p0 + b < lenp) {
-          const bool real = p0 + b < len;
-          const uint32_t code = real ? (uint32_t)cur_w & 3u : 0u;
-          const bool valid = real && (cur_m & 1u);
-          cur_w >>= 2;
-          cur_m >>= 1;
-          fm = ((fm << 2) | code) & mmask;
-          rm = (rm >> 2) | ((3u - code) << rmshift);
-          const uint32_t h = (mmer_hash(CANON ? min(fm, rm) : fm) & MSP_HMASK) | ((p0 & 24u) | (uint32_t)b);
-          a[WL - 1 + b] = h;
-          pm = min(pm, h);
-          filled = valid ? filled + 1 : 0;
-          const bool kvalid = filled >= k;
-          // A run = consecutive k-mers with the same minimizer HASH (not merely the same bin): every
-          // further bit of that hash is then common to the record's k-mers, which is what lets
-          // k_slice_tag refine the partition later without separating instances of a k-mer.
-          const uint32_t mh = min(sfx[b], pm);
-          if (run_n && (!kvalid || mh != run_h || run_n == MSP_NMAX)) {
-            // close the run that ended at the previous base: `hist` still ends there
-            const uint32_t run_bin = msp_bin(run_h, bin_bits);
-#ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
-            const bool mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
-#else
-            const bool mine = run_bin >= bin_lo && run_bin < bin_hi;  // shard passes: other bins are not ours
-#endif
-            if (HMODE != 1 && mine) {
-              const int L = k + run_n - 1;
-              const uint32_t coarse = run_bin >> sub_bits;
-              // the record ends at base e = p0 + b - 1; its minimizer m-mer ends at the last base q <= e with
-              // q = run_h (mod 32) -- inside the record, so e - q < 32.  mpos = first base of the m-mer
-              // counted from the record's first base: 0 .. L - m <= 17.
-              const uint32_t back = (p0 + (uint32_t)b - 1u - run_h) & 31u;
-              const uint32_t mpos = (uint32_t)(L - m) - back;
-              if (!WIDE || L <= 28) {
-                wv[b] = (hist & ((1ull << (2 * L)) - 1)) | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)mpos << 59);
-                if (WIDE) xv[b] = 0;
-              } else {  // 29 .. 34 bases: the word takes the 28 that contain the minimizer, the plane the other x
-                const int x = L - 28;
-                const uint64_t m56 = (1ull << 56) - 1;
-                uint64_t bases;
-                uint32_t side, mp;
-                if (mpos >= (uint32_t)x) {  // the LAST 28 bases hold it: the plane gets the first x (S >> 56)
-                  bases = hist & m56;
-                  xv[b] = (uint32_t)((hist >> 56) | ((uint64_t)hist_hi << 8)) & ((1u << (2 * x)) - 1);
-                  side = 0;
-                  mp = mpos - (uint32_t)x;
-                } else {  // the FIRST 28 (S >> 2x); the plane gets the last x
-                  bases = ((hist >> (2 * x)) | ((uint64_t)hist_hi << (64 - 2 * x))) & m56;
-                  xv[b] = (uint32_t)hist & ((1u << (2 * x)) - 1);
-                  side = 1;
-                  mp = mpos;
-                }
-                wv[b] = bases | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)side << 58) | ((uint64_t)mp << 59);
-              }
-              br[b] = (coarse << 16) | atomicAdd(&s_cnt[coarse], 1u);
-            }
-            if (HMODE == 0 && mine) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
-            if (HMODE == 1 && mine) atomicAdd(&s_fine[run_bin], 1u);
-            run_n = 0;
-          }
-          if (kvalid) {
-            if (!run_n) run_h = mh;
-            ++run_n;
-          }
-          if (WIDE) hist_hi = (hist_hi << 2) | (uint32_t)(hist >> 62);
-          hist = (hist << 2) | code;
+      for (int b = 0; b < P1_S; ++b) br[b] = ~0u;
+      {
+        const uint32_t p0 = ph * P1_S;
+        if ((ph & 3) == 0 && p0 < len) {
+          cur_w = cw[p0 >> 5];
+          cur_m = cm[p0 >> 5];
         }
+        // window minimum = min(suffix minimum of the 14 old hashes, prefix minimum of the new ones)
+        uint32_t sfx[WL - 1];
+        sfx[WL - 2] = a[WL - 2];
+  #pragma unroll
+        for (int i = WL - 3; i >= 0; --i) sfx[i] = min(a[i], sfx[i + 1]);
+        uint32_t pm = ~0u;
+  #pragma unroll
+        for (int b = 0; b < P1_S; ++b) {
+          if (p0 + b < lenp) {
+            const bool real = p0 + b < len;
+            const uint32_t code = real ? (uint32_t)cur_w & 3u : 0u;
+            const bool valid = real && (cur_m & 1u);
+            cur_w >>= 2;
+            cur_m >>= 1;
+            fm = ((fm << 2) | code) & mmask;
+            rm = (rm >> 2) | ((3u - code) << rmshift);
+            const uint32_t h = (mmer_hash(CANON ? min(fm, rm) : fm) & MSP_HMASK) | ((p0 & 24u) | (uint32_t)b);
+            a[WL - 1 + b] = h;
+            pm = min(pm, h);
+            filled = valid ? filled + 1 : 0;
+            const bool kvalid = filled >= k;
+            // A run = consecutive k-mers with the same minimizer HASH (not merely the same bin): every
+            // further bit of that hash is then common to the record's k-mers, which is what lets
+            // k_slice_tag refine the partition later without separating instances of a k-mer.
+            const uint32_t mh = min(sfx[b], pm);
+            if (run_n && (!kvalid || mh != run_h || run_n == MSP_NMAX)) {
+              // close the run that ended at the previous base: `hist` still ends there
+              const uint32_t run_bin = msp_bin(run_h, bin_bits);
+  #ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
+              const bool mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
+  #else
+              const bool mine = run_bin >= bin_lo && run_bin < bin_hi;  // shard passes: other bins are not ours
+  #endif
+              if (HMODE != 1 && mine) {
+                const int L = k + run_n - 1;
+                const uint32_t coarse = run_bin >> sub_bits;
+                // the record ends at base e = p0 + b - 1; its minimizer m-mer ends at the last base q <= e with
+                // q = run_h (mod 32) -- inside the record, so e - q < 32.  mpos = first base of the m-mer
+                // counted from the record's first base: 0 .. L - m <= 17.
+                const uint32_t back = (p0 + (uint32_t)b - 1u - run_h) & 31u;
+                const uint32_t mpos = (uint32_t)(L - m) - back;
+                if (!WIDE || L <= 28) {
+                  wv[b] = (hist & ((1ull << (2 * L)) - 1)) | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)mpos << 59);
+                  if (WIDE) xv[b] = 0;
+                } else {  // 29 .. 34 bases: the word takes the 28 that contain the minimizer, the plane the other x
+                  const int x = L - 28;
+                  const uint64_t m56 = (1ull << 56) - 1;
+                  uint64_t bases;
+                  uint32_t side, mp;
+                  if (mpos >= (uint32_t)x) {  // the LAST 28 bases hold it: the plane gets the first x (S >> 56)
+                    bases = hist & m56;
+                    xv[b] = (uint32_t)((hist >> 56) | ((uint64_t)hist_hi << 8)) & ((1u << (2 * x)) - 1);
+                    side = 0;
+                    mp = mpos - (uint32_t)x;
+                  } else {  // the FIRST 28 (S >> 2x); the plane gets the last x
+                    bases = ((hist >> (2 * x)) | ((uint64_t)hist_hi << (64 - 2 * x))) & m56;
+                    xv[b] = (uint32_t)hist & ((1u << (2 * x)) - 1);
+                    side = 1;
+                    mp = mpos;
+                  }
+                  wv[b] = bases | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)side << 58) | ((uint64_t)mp << 59);
+                }
+                br[b] = (coarse << 16) | atomicAdd(&s_cnt[X][coarse], 1u);
+              }
+              if ((HMODE == 0 || HMODE == 3) && mine) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
+              if (HMODE == 1 && mine) atomicAdd(&s_fine[run_bin], 1u);
+              run_n = 0;
+            }
+            if (kvalid) {
+              if (!run_n) run_h = mh;
+              ++run_n;
+            }
+            if (WIDE) hist_hi = (hist_hi << 2) | (uint32_t)(hist >> 62);
+            hist = (hist << 2) | code;
+          }
+        }
+  #pragma unroll
+        for (int i = 0; i < WL - 1; ++i) a[i] = a[i + P1_S];
       }
-#pragma unroll
-      for (int i = 0; i < WL - 1; ++i) a[i] = a[i + P1_S];
       TM(0);
       if (HMODE == 1) continue;
-      // Every lane stores its own records straight into the reserved runs (rank inside the run = the
-      // value its LDS atomic returned).  The stores of one run come from many lanes, but they fall into
-      // the same one or two 128-byte lines within a few hundred cycles and merge in the L2.
-      __syncthreads();
-      if (threadIdx.x < P1_BINS) {  // reserve this phase's runs: one global atomic per coarse bin
-        const uint32_t cn = s_cnt[threadIdx.x];
-        const uint32_t at = cn ? atomicAdd(&coarse_cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
-        s_cnt[threadIdx.x] = 0;
-        if ((uint64_t)at + cn > cap_a) {  // over capacity: the run is dropped, the host redoes the block
-          atomicExch(flag, 1u);
-          s_gbase[threadIdx.x] = ~0ull;
-        } else {
-          s_gbase[threadIdx.x] = (uint64_t)threadIdx.x * cap_a + at;
+      uint32_t at_prev = 0, cn_prev = 0;
+      auto settle = [&](uint32_t Y) {  // the reserved runs' addresses, for everybody (waits for the atomic)
+        if (threadIdx.x < P1_BINS) {
+          if ((uint64_t)at_prev + cn_prev > cap_a) {  // over capacity: the run is dropped, the host redoes the block
+            atomicExch(flag, 1u);
+            s_gbase[Y][threadIdx.x] = ~0ull;
+          } else {
+            s_gbase[Y][threadIdx.x] = (uint64_t)threadIdx.x * cap_a + at_prev;
+          }
         }
-      }
+      };
+      auto reserve = [&](uint32_t Y) {  // one global atomic per coarse bin reserves the phase's run in it
+        if (threadIdx.x < P1_BINS) {
+          cn_prev = s_cnt[Y][threadIdx.x];
+          at_prev = cn_prev ? atomicAdd(&coarse_cur[threadIdx.x * P1_CUR_STRIDE], cn_prev) : 0u;
+          s_cnt[Y][threadIdx.x] = 0;  // (next used two phases on: a barrier lies between)
+        }
+      };
+      // Every lane stores its own records straight into the reserved runs (rank inside the run = the value its
+      // LDS atomic returned).  The stores of one run come from many lanes, but they fall into the same one or two
+      // 128-byte lines within a few hundred cycles and merge in the L2.
+      auto store = [&](const uint32_t* brx, const uint64_t* wvx, const uint32_t* xvx, uint32_t Y) {
+        uint64_t base[P1_S];
+#pragma unroll
+        for (int b = 0; b < P1_S; ++b) base[b] = s_gbase[Y][(brx[b] >> 16) & (P1_BINS - 1)];
+#pragma unroll
+        for (int b = 0; b < P1_S; ++b)
+          if (brx[b] != ~0u) {
+            if (base[b] != ~0ull) {
+              buf_a[base[b] + (brx[b] & 0xFFFFu)] = wvx[b];
+              if (WIDE) ext_a[base[b] + (brx[b] & 0xFFFFu)] = xvx[b];
+            }
+            ++n_emit;
+          }
+      };
+      __syncthreads();
+      reserve(X);
+      settle(X);
       __syncthreads();
       TM(1);
-#pragma unroll
-      for (int b = 0; b < P1_S; ++b)
-        if (br[b] != ~0u) {
-          const uint64_t base = s_gbase[br[b] >> 16];
-          if (base != ~0ull) {
-            buf_a[base + (br[b] & 0xFFFFu)] = wv[b];
-            if (WIDE) ext_a[base + (br[b] & 0xFFFFu)] = xv[b];
-          }
-          ++n_emit;
-        }
+      store(br, wv, xv, X);
       TM(2);
-      // no barrier here: s_gbase is rewritten only after the next phase's first barrier
+      // (s_gbase[X ^ 1] is rewritten two phases on: a barrier lies between)
     }
   }
   __syncthreads();
-  if (HMODE == 0) {
+  if (HMODE == 0 || HMODE == 3) {
     __shared__ uint32_t s_emit;
     if (threadIdx.x == 0) {
       s_maxlen = 0;
@@ -702,6 +727,7 @@ void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int b
   do {                                          \
     if (hmode == 0) RFX_MSP_P1(CANON, 0, WL, WIDE);      \
     else if (hmode == 1) RFX_MSP_P1(CANON, 1, WL, WIDE); \
+    else if (hmode == 3) RFX_MSP_P1(CANON, 3, WL, WIDE); \
     else RFX_MSP_P1(CANON, 2, WL, WIDE);                 \
   } while (0)
   if (!msp_wide(k)) {

@@ -212,7 +212,7 @@ void overlap_score(rfx_ctx* c, const char* d_a, int alen, const char* d_bcat, co
   rfx_span sp(c, "k_overlap_score");
   const size_t lds = (size_t)alen + (size_t)max_blen + 16;
   // (per device and cheap: set on every launch rather than behind a process-wide flag)
-  (void)hipFuncSetAttribute((const void*)k_overlap_score, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (!rfxi::lds_opt_in(c, (const void*)k_overlap_score, 150 * 1024, 4, "k_overlap_score")) return;
   hipLaunchKernelGGL(k_overlap_score, dim3(nb < 4096 ? nb : 4096), dim3(256), lds, c->stream, d_a, alen, d_bcat, d_boff,
                      nb, min_pct, min_ovl, strict3, local_init, d_out);
 }
@@ -223,7 +223,7 @@ void overlap_pool(rfx_ctx* c, const char* arena, const uint64_t* off, const int*
   const int work = nb * (strand_hi - strand_lo + 1);
   if (work == 0) return;
   rfx_span sp(c, "k_overlap_score");
-  (void)hipFuncSetAttribute((const void*)k_overlap_pool, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+  if (!rfxi::lds_opt_in(c, (const void*)k_overlap_pool, 150 * 1024, 5, "k_overlap_pool")) return;
   hipLaunchKernelGGL(k_overlap_pool, dim3(work < 8192 ? work : 8192), dim3(256), lds, c->stream, arena,
                      (const unsigned long long*)off, len, a_explicit, a_explicit_len, query, cand, nb, strand_lo, strand_hi,
                      min_pct, min_ovl, strict3, local_init, d_out);

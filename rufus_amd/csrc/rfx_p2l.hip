@@ -740,12 +740,10 @@ int p2l_grid(rfx_ctx* c, uint32_t n_reads) {
 void bin_count(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* lut, int ntab, int k, int canonical,
                const rfx_ord_cfg& cfg, uint32_t P, uint64_t pos_lo, uint64_t pos_hi, int grid, uint32_t* cnt) {
   const size_t lds = 8 * 256 * 8 + (size_t)P * 4;
-  static bool attr_set = false;
-  if (!attr_set) {  // 16 K bins: 80 KB of dynamic LDS
-    (void)hipFuncSetAttribute((const void*)k_bin_count<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute((const void*)k_bin_count<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
+  // 16 K bins: 80 KB of dynamic LDS
+  if (!rfxi::lds_opt_in(c, (const void*)k_bin_count<true>, 96 * 1024, 2, "k_bin_count") ||
+      !rfxi::lds_opt_in(c, (const void*)k_bin_count<false>, 96 * 1024, 3, "k_bin_count"))
+    return;
   rfx_span sp(c, "k_bin_count");
   if (canonical)
     hipLaunchKernelGGL(k_bin_count<true>, dim3(grid), dim3(P2_BLOCK), lds, c->stream, rv, lut, ntab, k, cfg, P, pos_lo,

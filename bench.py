@@ -268,8 +268,11 @@ def run_wgs(args, ctx, rank, world, dist, torch):
     sys_ = [capi.Synth.sample(G, w, n_snv=n_snv, seed=SEED) for w in range(len(covs))]
     free0, total = torch.cuda.mem_get_info()
     # this rank's share of every sample: pairs [p0, p1) (strong scaling: the trio is the same for every N)
-    bpp = 2 * (40 + 20 + 8)                                   # bytes per pair: codes + acgt mask + offsets
-    resident = sum(n * (rank + 1) // world - n * rank // world for n in pairs) * bpp + (n_pairs // world) * 2 * 20
+    # bytes per pair, resident: codes + ACGT mask + offsets -- or the compact block form (rufus_hip.h RFX_SYNTH_COMPACT:
+    # reads of one length need no offsets, and only the ~14 % of reads with an N keep a mask): 43 instead of 68 B/read
+    compact = not args.dense_reads
+    bpp = 2 * (40 + 0.2 + 0.15 * 20) if compact else 2 * (40 + 20 + 8)
+    resident = int(sum(n * (rank + 1) // world - n * rank // world for n in pairs) * bpp) + (n_pairs // world) * 2 * 20
     passes = args.passes or wgs.plan_passes(2 * n_pairs, READ_LEN, k, resident + (total - free0), total, world=world,
                                             n_samples=len(covs), coverage_hint=covs[0], wide=k > 25)
     if world > 1:                                             # every rank must run the same number of passes
@@ -278,8 +281,9 @@ def run_wgs(args, ctx, rank, world, dist, torch):
         passes = int(t.item())
     t0 = time.perf_counter()
     samples = [wgs.make_sample(ctx, sy, n * (rank + 1) // world - n * rank // world, 1 << 24, MIN_Q, want_good=(i == 0),
-                               first_pair=n * rank // world) for i, (sy, n) in enumerate(zip(sys_, pairs))]
+                               first_pair=n * rank // world, compact=compact) for i, (sy, n) in enumerate(zip(sys_, pairs))]
     ctx.sync()
+    resident = sum(b.device_bytes for s_ in samples for b in s_)
     t_gen = time.perf_counter() - t0
     trio = wgs.WgsTrio(ctx, k, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes,
                        group=dist.group.WORLD if world > 1 else None)
@@ -294,7 +298,8 @@ def run_wgs(args, ctx, rank, world, dist, torch):
     args.k = k
     args.n_samples = len(covs)
     return (step, sum(reads), sum(reads) // len(reads) // world, reads[0], desc, "strong",
-            {"passes": passes, "hbm_total": total, "hbm_free_at_start": free0})
+            {"passes": passes, "hbm_total": total, "hbm_free_at_start": free0, "resident_read_bytes": resident,
+             "read_blocks": "compact" if compact else "dense"})
 
 
 def main():
@@ -308,6 +313,8 @@ def main():
     ap.add_argument("--genome", type=int, default=3_100_000_000, help="wgs: genome length (reads scale with it)")
     ap.add_argument("--coverage", type=int, default=30)
     ap.add_argument("--passes", type=int, default=0, help="wgs: minimizer-shard passes (0 = plan from free HBM)")
+    ap.add_argument("--dense-reads", action="store_true",
+                    help="wgs: keep the read blocks in the dense form (68 B per 150 bp read instead of 43)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--end-to-end-only", action="store_true", help="(internal) print the end_to_end object and exit")

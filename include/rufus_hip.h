@@ -159,8 +159,16 @@ typedef struct rfx_synth {
 } rfx_synth;
 /* Reads 2*first_pair .. 2*(first_pair+n_pairs)-1 of the sample (read 2p = mate 1 of pair p, 2p+1 = mate 2),
  * packed as rfx_pack_reads(RFX_PACK_COUNT [| RFX_PACK_FILTER with min_q]) would pack their text. */
+/* want_good: bit 0 = also the filter's `good` mask; bit 1 (RFX_SYNTH_COMPACT) = the compact block form -- reads of
+ * one length need no offset / length arrays, and the ACGT mask is kept only for the reads that hold an N (a bit per
+ * read says which): 43 instead of 68 bytes per 150 bp read resident in HBM.  The kernels read both forms; the
+ * global-table count path (k = 32) takes only the dense one.  rfx_reads_get hands out the dense arrays either way. */
+#define RFX_SYNTH_GOOD 1
+#define RFX_SYNTH_COMPACT 2
 rfx_reads* rfx_synth_reads(rfx_ctx*, const rfx_synth*, uint64_t first_pair, uint32_t n_pairs, int min_q,
                            int want_good);
+/* Bytes of device memory a read block holds. */
+uint64_t rfx_reads_device_bytes(const rfx_reads*);
 /* Host twin: the same reads as text, read after read: seq and qual hold 2*n_pairs*read_len bytes each. */
 int rfx_synth_text(const rfx_synth*, uint64_t first_pair, uint32_t n_pairs, char* seq, char* qual);
 /* SNV i: 0-based genome position, reference and alternative base ('A','C','G','T'). */
@@ -296,6 +304,13 @@ int rfx_query(const rfx_records* db, const uint64_t* keys, uint64_t n, uint32_t*
 int rfx_unique_to_subject(rfx_ctx*, const rfx_records* subject, const rfx_records* const* others, int n_others,
                           uint32_t min_count, uint32_t min_cov, uint32_t max_cov, uint64_t* keys_out,
                           uint32_t* counts_out, uint64_t cap, uint64_t* n_out);
+/* The same difference one input at a time, device to device: the records of `a` with min_count <= count <=
+ * max_count that occur in none of `others`, as a new (pos,key)-ordered record set (NULL on error).  A caller that
+ * counts the controls one after the other keeps only the shrinking candidate set of the subject instead of every
+ * sample's records: subtract(subject, {}, MinCov, MaxDepth), then subtract(candidates, {control_i}, 0, ~0) per control
+ * gives the keys of rfx_unique_to_subject (jf/jellyfish/merge_files.cc:69-155 + scripts/CheckJellyHashList.sh:12). */
+rfx_records* rfx_records_subtract(rfx_ctx*, const rfx_records* a, const rfx_records* const* others, int n_others,
+                                  uint32_t min_count, uint32_t max_count);
 
 /* ---------------------------------------------------------------------------------------------
  * K5: read filter (src/RUFUS.Filter.cpp:196-277, src/RUFUS.Filter.ss.cpp:164-203)

@@ -51,6 +51,8 @@ SIGNATURES = {
     "rfx_prof_reset": (C.c_int, [C.c_void_p]),
     "rfx_prof_query": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), u64p]),
     "rfx_prof_names": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "rfx_reads_device_bytes": (C.c_uint64, [C.c_void_p]),
+    "rfx_records_subtract": (C.c_void_p, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_uint32, C.c_uint32]),
     "rfx_reads_upload": (C.c_void_p, [C.c_void_p, u64p, u32p, u32p, u32p, u32p, C.c_uint32]),
     "rfx_reads_free": (None, [C.c_void_p]),
     "rfx_reads_count": (C.c_uint32, [C.c_void_p]),
@@ -305,9 +307,11 @@ class Context:
     def upload(self, p: PackedReads) -> "ReadBlock":
         return ReadBlock(self, p)
 
-    def synth_reads(self, sy: Synth, first_pair: int, n_pairs: int, min_q: int = 15, want_good: bool = True):
-        """Pairs [first_pair, first_pair + n_pairs) of a synthetic sample, generated on the device."""
-        h = lib().rfx_synth_reads(self._h, C.byref(sy), first_pair, n_pairs, min_q, int(want_good))
+    def synth_reads(self, sy: Synth, first_pair: int, n_pairs: int, min_q: int = 15, want_good: bool = True,
+                    compact: bool = False):
+        """Pairs [first_pair, first_pair + n_pairs) of a synthetic sample, generated on the device.  compact: no
+        offset / length arrays, ACGT mask only for the reads with an N (43 instead of 68 B per 150 bp read)."""
+        h = lib().rfx_synth_reads(self._h, C.byref(sy), first_pair, n_pairs, min_q, int(want_good) | (2 if compact else 0))
         if not h:
             raise RufusError("rfx_synth_reads failed: " + lib().rfx_last_error().decode())
         return ReadBlock.from_handle(self, h)
@@ -338,6 +342,10 @@ class ReadBlock:
     @property
     def bases(self) -> int:
         return int(lib().rfx_reads_bases(self._h))
+
+    @property
+    def device_bytes(self) -> int:
+        return int(lib().rfx_reads_device_bytes(self._h))
 
     def get(self, want_good: bool = True):
         """Download the packed arrays: dict codes / acgt / good / word_off / len."""
@@ -548,6 +556,12 @@ def unique_to_subject(ctx: Context, subject: Records, others, min_cov: int, max_
             continue
         _check(rc, "rfx_unique_to_subject")
         return keys[:n.value].copy(), counts[:n.value].copy()
+
+
+def records_subtract(ctx: Context, a: Records, others, min_count: int = 0, max_count: int = 0xFFFFFFFF) -> Records:
+    """Records of `a` with min_count <= count <= max_count that occur in none of `others` (device resident)."""
+    arr = (C.c_void_p * max(1, len(others)))(*[f._h for f in others])
+    return Records(ctx, lib().rfx_records_subtract(ctx._h, a._h, arr, len(others), min_count, max_count))
 
 
 OVL_SAM, OVL_CONTIG, OVL_REGION = 0, 1, 2

@@ -783,17 +783,48 @@ void rfx_reads_free(rfx_reads* r) {
   rfx_reads_release_pending(r);  // a count table may still need these reads to redo its partition
   dfree(r->ctx, r->codes); dfree(r->ctx, r->acgt); dfree(r->ctx, r->good);
   dfree(r->ctx, r->word_off); dfree(r->ctx, r->len);
+  dfree(r->ctx, r->nbits); dfree(r->ctx, r->nrank);
   delete r;
 }
 uint32_t rfx_reads_count(const rfx_reads* r) { return r ? r->n : 0; }
 uint64_t rfx_reads_bases(const rfx_reads* r) { return r ? r->n_bases : 0; }
 uint64_t rfx_reads_words(const rfx_reads* r) { return r ? r->n_words : 0; }
+uint64_t rfx_reads_device_bytes(const rfx_reads* r) {
+  if (!r) return 0;
+  uint64_t b = r->n_words * 8 + (r->good ? r->n_words * 4 : 0);
+  if (r->ulen) return b + (((uint64_t)r->n + 63) / 64) * 12 + r->n_exc * r->uwpr * 4;
+  return b + (r->acgt ? r->n_words * 4 : 0) + ((uint64_t)r->n + 1) * 4 + (uint64_t)r->n * 4;
+}
 
 int rfx_reads_get(const rfx_reads* r, uint64_t* codes, uint32_t* acgt, uint32_t* good, uint32_t* word_off, uint32_t* len) {
   if (!r) return RFX_E_INVAL;
   rfx_ctx* c = r->ctx;
   (void)hipSetDevice(c->device);
-  if ((acgt && !r->acgt) || (good && !r->good)) return RFX_E_INVAL;
+  if ((acgt && !r->acgt && !r->ulen) || (good && !r->good)) return RFX_E_INVAL;
+  if (r->ulen) {  // compact block: hand out the classic arrays
+    if (codes && r->n_words) HIPCHK(hipMemcpyAsync(codes, r->codes, r->n_words * 8, hipMemcpyDeviceToHost, c->stream));
+    if (good && r->n_words) HIPCHK(hipMemcpyAsync(good, r->good, r->n_words * 4, hipMemcpyDeviceToHost, c->stream));
+    const size_t ng = ((size_t)r->n + 63) / 64;
+    std::vector<uint64_t> bits(ng);
+    std::vector<uint32_t> exc((size_t)r->n_exc * r->uwpr);
+    if (acgt && ng) HIPCHK(hipMemcpyAsync(bits.data(), r->nbits, ng * 8, hipMemcpyDeviceToHost, c->stream));
+    if (acgt && !exc.empty()) HIPCHK(hipMemcpyAsync(exc.data(), r->acgt, exc.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(ctx_sync(c));
+    size_t x = 0;
+    for (uint32_t i = 0; i < r->n; ++i) {
+      if (word_off) word_off[i] = i * r->uwpr;
+      if (len) len[i] = r->ulen;
+      if (!acgt) continue;
+      const bool flagged = (bits[i >> 6] >> (i & 63)) & 1;
+      for (uint32_t w = 0; w < r->uwpr; ++w) {
+        const uint32_t nb = std::min<uint32_t>(32, r->ulen - 32 * w);
+        acgt[(size_t)i * r->uwpr + w] = flagged ? exc[x * r->uwpr + w] : (nb == 32 ? ~0u : (1u << nb) - 1);
+      }
+      x += flagged;
+    }
+    if (word_off) word_off[r->n] = r->n * r->uwpr;
+    return RFX_OK;
+  }
   if (codes && r->n_words) HIPCHK(hipMemcpyAsync(codes, r->codes, r->n_words * 8, hipMemcpyDeviceToHost, c->stream));
   if (acgt && r->n_words) HIPCHK(hipMemcpyAsync(acgt, r->acgt, r->n_words * 4, hipMemcpyDeviceToHost, c->stream));
   if (good && r->n_words) HIPCHK(hipMemcpyAsync(good, r->good, r->n_words * 4, hipMemcpyDeviceToHost, c->stream));
@@ -909,7 +940,7 @@ static int p2l_add(rfx_table* t, const rfx_reads* r) {
   uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
   uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
   if (!cnt || !bin_start || !gsum) { dfree(c, cnt); dfree(c, bin_start); dfree(c, gsum); return RFX_E_NOMEM; }
-  const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+  const rfx_reads_view rv = r->view();
   const uint32_t P1 = (uint32_t)rfxk::p1_bins();
   const bool two_level = P >= 2048 && !getenv("RFX_P2L_ONE_LEVEL");
   const uint32_t P2 = P / P1;
@@ -1104,7 +1135,7 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   msp_geom g;
   msp_geometry(t, r, g);
   const uint32_t P = g.P, P1 = g.P1, P2 = g.P2;
-  const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+  const rfx_reads_view rv = r->view();
   uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
   uint32_t* gsum = (uint32_t*)dmalloc(c, (size_t)8 * P * 4);
   uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
@@ -1169,7 +1200,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
     return RFX_OK;
   }
   const uint32_t P = g.P, P2 = g.P2;
-  const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+  const rfx_reads_view rv = r->view();
   // ~3 k-mers per record on ordinary sequence: room for 2.5 (of the shard's share of the bins), coarse
   // bins 25 % above even -- 6 % for big blocks, whose bins are even
   const bool big = g.windows >= (1ull << 29) || P > 8192;  // >= ~4 M reads: worth one synchronisation for exact sizes
@@ -1996,7 +2027,12 @@ static int grow_for(rfx_table* t, uint64_t distinct_after) {
 
 int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   if (!t || !r || t->ctx != r->ctx) return RFX_E_INVAL;
-  if (!r->acgt) return RFX_E_INVAL;
+  if (!r->acgt && !r->ulen) return RFX_E_INVAL;
+  if (r->ulen && (t->lut_t == nullptr || t->mode == RFX_COUNT_TABLE || t->table_active)) {
+    // (the global-table kernel stages the dense mask of a chunk in LDS: it has no sparse form)
+    snprintf(g_err, sizeof g_err, "compact read blocks are counted by the partition paths only (2k <= 62, full-rank matrix)");
+    return RFX_E_INVAL;
+  }
   rfx_ctx* c = t->ctx;
   pin_guard guard(c);
   (void)hipSetDevice(c->device);
@@ -2017,6 +2053,7 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
     const int rc = msp ? msp_add(t, r) : p2l_add(t, r);
     if (rc == RFX_OK || t->mode == RFX_COUNT_P2L || t->mode == RFX_COUNT_MSP) return rc;
     if (rc != RFX_E_NOMEM && rc != RFX_E_RANGE) return rc;  // auto: no room for the instance lists
+    if (r->ulen) return rc;  // (compact blocks cannot fall back to the global table)
   }
   {
     const int rc = ensure_table(t);
@@ -2034,7 +2071,7 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   }
   HIPCHK(hipMemsetAsync(t->d_ctl, 0, sizeof(rfx_count_ctl), c->stream));
   const uint32_t n_chunks = (r->n + rfxk::count_reads_block() - 1) / rfxk::count_reads_block();
-  const rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+  const rfx_reads_view rv = r->view();
   for (;;) {
     const uint64_t limit = (uint64_t)((double)t->cap * kLoadLimit);
     rfxk::count_reads(c, rv, view_of(t), t->lut, t->k, t->canonical, t->d_stats, t->d_ctl, t->ovf_keys, t->ovf_cap,
@@ -2624,6 +2661,35 @@ int rfx_unique_to_subject(rfx_ctx* c, const rfx_records* subject, const rfx_reco
   return RFX_OK;
 }
 
+rfx_records* rfx_records_subtract(rfx_ctx* c, const rfx_records* a, const rfx_records* const* others, int n_others,
+                                  uint32_t min_count, uint32_t max_count) {
+  if (!c || !a || n_others < 0 || (n_others && !others)) { snprintf(g_err, sizeof g_err, "rfx_records_subtract: bad argument"); return nullptr; }
+  (void)hipSetDevice(c->device);
+  for (int i = 0; i < n_others; ++i)
+    if (!others[i] || !same_function(a, others[i])) { snprintf(g_err, sizeof g_err, "rfx_records_subtract: databases of different hash functions"); return nullptr; }
+  pin_guard guard(c);
+  if (a->n == 0) return records_alloc(c, a->k, a->lsize, a->cols, 0);
+  const uint64_t nblk = (a->n + 2047) / 2048;
+  uint8_t* flags = (uint8_t*)dmalloc(c, a->n);
+  uint64_t* boff = (uint64_t*)dmalloc(c, nblk * 8);
+  unsigned long long* d_tot = (unsigned long long*)dmalloc(c, 8);
+  auto cleanup = [&] { dfree(c, flags); dfree(c, boff); dfree(c, d_tot); };
+  if (!flags || !boff || !d_tot) { cleanup(); snprintf(g_err, sizeof g_err, "rfx_records_subtract: out of device memory"); return nullptr; }
+  rfxk::flag_range(c, a->counts, a->n, min_count, max_count, flags);
+  for (int j = 0; j < n_others; ++j)
+    rfxk::flag_absent(c, a->keys, a->pos, a->n, others[j]->keys, others[j]->pos, others[j]->n, a->lsize, flags);
+  rfxk::compact_count(c, flags, a->n, boff, d_tot);
+  unsigned long long tot = 0;
+  hipError_t e = queue_read(c, &tot, d_tot, 8);
+  if (e == hipSuccess) e = ctx_sync(c);
+  if (e != hipSuccess) { cleanup(); hip_fail(e, "rfx_records_subtract"); return nullptr; }
+  rfx_records* out = records_alloc(c, a->k, a->lsize, a->cols, tot);
+  if (!out) { cleanup(); return nullptr; }
+  if (tot) rfxk::compact_scatter(c, flags, a->keys, a->counts, a->pos, a->n, boff, out->keys, out->counts, out->pos);
+  cleanup();  // (stream-ordered: the scatter is queued before any reuse)
+  return out;
+}
+
 // ---------------------------------------------------------------------------------------------
 rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) {
   if (!c || k < 1 || k > 32 || (n && !fwd_keys)) return nullptr;
@@ -2708,7 +2774,7 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
   if ((hits_out && !d_hits) || !d_mask || !d_n) { cleanup(); return RFX_E_NOMEM; }
   hipError_t e = hipMemsetAsync(d_n, 0, 8, c->stream);
   if (e == hipSuccess) {
-    rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+    const rfx_reads_view rv = r->view();
     if (s->bitmap2 && !getenv("RFX_FILTER_GENERIC"))
       rfxk::filter_fast(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap2, s->k, thresh, last_base_skipped,
                         d_hits, d_mask, d_n);
@@ -2923,9 +2989,12 @@ int rfx_annotate(rfx_set* s, const rfx_reads* r, uint32_t* cov_out) {
   rfx_ctx* c = s->ctx;
   (void)hipSetDevice(c->device);
   if (r->n == 0 || r->n_bases == 0) return RFX_OK;
-  std::vector<uint32_t> len(r->n);
-  hipError_t e = hipMemcpyAsync(len.data(), r->len, (size_t)r->n * 4, hipMemcpyDeviceToHost, c->stream);
-  if (e == hipSuccess) e = ctx_sync(c);
+  std::vector<uint32_t> len(r->n, r->ulen);
+  hipError_t e = hipSuccess;
+  if (!r->ulen) {
+    e = hipMemcpyAsync(len.data(), r->len, (size_t)r->n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = ctx_sync(c);
+  }
   std::vector<uint64_t> off((size_t)r->n + 1, 0);
   for (uint32_t i = 0; i < r->n; ++i) off[(size_t)i + 1] = off[i] + len[i];
   uint64_t* d_off = (uint64_t*)dmalloc(c, off.size() * 8);
@@ -2934,7 +3003,7 @@ int rfx_annotate(rfx_set* s, const rfx_reads* r, uint32_t* cov_out) {
   if (e == hipSuccess) e = hipMemcpyAsync(d_off, off.data(), off.size() * 8, hipMemcpyHostToDevice, c->stream);
   if (e == hipSuccess) e = hipMemsetAsync(d_cov, 0, r->n_bases * 4, c->stream);
   if (e == hipSuccess) {
-    rfx_reads_view rv{r->codes, r->acgt, r->good, r->word_off, r->len, r->n};
+    const rfx_reads_view rv = r->view();
     rfxk::annotate(c, rv, s->slots, s->bits, s->has_all_ones, s->k, d_off, d_cov);
     e = hipMemcpyAsync(cov_out, d_cov, r->n_bases * 4, hipMemcpyDeviceToHost, c->stream);
   }

@@ -136,7 +136,25 @@ struct rfx_reads_view {
   const uint32_t* word_off;
   const uint32_t* len;
   uint32_t n;
+  // Compact blocks (every read `ulen` bases long, rfx_reads::ulen): no word_off / len arrays -- read r starts at word
+  // r * uwpr -- and the ACGT mask is kept only for the reads that have a non-ACGT base: bit r % 64 of nbits[r / 64]
+  // says so, their uwpr mask words follow each other in `acgt` in read order, nrank[r / 64] = index of the first
+  // flagged read of the group of 64 among the flagged.  (A 150 bp read: 40 B instead of 68; `good` stays dense.)
+  uint32_t ulen, uwpr;
+  const uint64_t* nbits;
+  const uint32_t* nrank;
 };
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t rv_len(const rfx_reads_view& rv, uint32_t r) { return rv.ulen ? rv.ulen : rv.len[r]; }
+__device__ __forceinline__ uint32_t rv_off(const rfx_reads_view& rv, uint32_t r) { return rv.ulen ? r * rv.uwpr : rv.word_off[r]; }
+// the ACGT mask words of read r (starting at word `off`), or nullptr: every base of the read is A, C, G or T
+__device__ __forceinline__ const uint32_t* rv_acgt(const rfx_reads_view& rv, uint32_t r, uint32_t off) {
+  if (!rv.nbits) return rv.acgt + off;
+  const uint64_t bits = rv.nbits[r >> 6];
+  if (!((bits >> (r & 63u)) & 1ull)) return nullptr;
+  return rv.acgt + (size_t)(rv.nrank[r >> 6] + (uint32_t)__popcll(bits & ((1ull << (r & 63u)) - 1ull))) * rv.uwpr;
+}
+#endif
 
 struct rfx_reads {
   rfx_ctx* ctx;
@@ -145,6 +163,12 @@ struct rfx_reads {
   uint32_t max_len;
   uint64_t* codes;
   uint32_t *acgt, *good, *word_off, *len;
+  // compact form (see rfx_reads_view): ulen > 0, word_off == len == nullptr, acgt = the masks of the n_exc flagged reads
+  uint32_t ulen, uwpr;
+  uint64_t* nbits;
+  uint32_t* nrank;
+  uint64_t n_exc;
+  rfx_reads_view view() const { return rfx_reads_view{codes, acgt, good, word_off, len, n, ulen, uwpr, nbits, nrank}; }
   uint32_t short_cnt[32];  // reads of length 0..31: they have no window for k > length, see windows_of()
   // exact number of length-k windows of the block: sum over reads of max(0, len - k + 1)
   uint64_t windows_of(int k) const {
@@ -243,6 +267,9 @@ void flag_absent(rfx_ctx*, const uint64_t* keys, const uint64_t* pos, uint64_t n
 void compact(rfx_ctx*, const uint8_t* flags, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos,
              uint64_t n, uint64_t* out_keys, uint32_t* out_counts, uint64_t* out_pos, uint64_t* block_off,
              unsigned long long* d_total);
+void compact_count(rfx_ctx*, const uint8_t* flags, uint64_t n, uint64_t* block_off, unsigned long long* d_total);
+void compact_scatter(rfx_ctx*, const uint8_t* flags, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos,
+                     uint64_t n, const uint64_t* block_off, uint64_t* out_keys, uint32_t* out_counts, uint64_t* out_pos);
 void query(rfx_ctx*, const uint64_t* qkeys, uint64_t nq, const uint64_t* lut, int ntab, const uint64_t* keys,
            const uint64_t* pos, const uint32_t* counts, uint64_t n, uint32_t* out);
 void set_insert(rfx_ctx*, const uint64_t* keys, uint64_t n, uint64_t* slots, int bits);

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(K2_BLOCK) void k_count_reads(rfx_reads_view rv, rfx
     uint32_t n_new = 0, max_disp = 0;
     const uint32_t r = r0 + threadIdx.x;
     if (r < r1) {
-      const uint32_t wr = rv.word_off[r];
-      const uint32_t len = rv.len[r];
+      const uint32_t wr = rv_off(rv, r);
+      const uint32_t len = rv_len(rv, r);
       const uint64_t* cw = staged ? s_codes + (wr - w0) : rv.codes + wr;
       const uint32_t* cm = staged ? s_mask + (wr - w0) : rv.acgt + wr;
       uint64_t fwd = 0, rc = 0;
@@ -698,8 +698,8 @@ __global__ __launch_bounds__(K5_BLOCK) void k_filter(rfx_reads_view rv, const ui
     const uint32_t r = chunk * K5_BLOCK + threadIdx.x;
     uint32_t found = 0;
     if (r < rv.n) {
-      const uint32_t wr = rv.word_off[r];
-      const uint32_t len = rv.len[r];
+      const uint32_t wr = rv_off(rv, r);
+      const uint32_t len = rv_len(rv, r);
       const uint64_t* __restrict__ cw = rv.codes + wr;
       const uint32_t* __restrict__ cm = rv.good + wr;
       // src/RUFUS.Filter.cpp:203: `i < length()-1` -- the last base is never examined.
@@ -778,8 +778,8 @@ __global__ __launch_bounds__(K5_BLOCK) void k_filter_fast(rfx_reads_view rv, con
     const uint32_t r = chunk * K5_BLOCK + threadIdx.x;
     uint32_t found = 0;
     if (r < rv.n) {
-      const uint32_t wr = rv.word_off[r];
-      const uint32_t len = rv.len[r];
+      const uint32_t wr = rv_off(rv, r);
+      const uint32_t len = rv_len(rv, r);
       const uint64_t* __restrict__ cw = rv.codes + wr;
       const uint32_t* __restrict__ cm = rv.good + wr;
       // src/RUFUS.Filter.cpp:203: `i < length()-1` -- the last base is never examined.
@@ -885,8 +885,8 @@ __global__ __launch_bounds__(FB_BLOCK) void k_filter_big(rfx_reads_view rv, cons
     const uint32_t r = chunk * FB_BLOCK + threadIdx.x;
     uint32_t found = 0;
     if (r < rv.n) {
-      const uint32_t wr = rv.word_off[r];
-      const uint32_t len = rv.len[r];
+      const uint32_t wr = rv_off(rv, r);
+      const uint32_t len = rv_len(rv, r);
       const uint64_t* __restrict__ cw = rv.codes + wr;
       const uint32_t* __restrict__ cm = rv.good + wr;
       const uint32_t stop = last_base_skipped ? (len ? len - 1 : 0) : len;  // src/RUFUS.Filter.cpp:203
@@ -1085,6 +1085,26 @@ void compact(rfx_ctx* c, const uint8_t* flags, const uint64_t* keys, const uint3
   rfx_span sp(c, "k_compact");
   hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, n, block_off);
   hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, c->stream, block_off, nblk, d_total);
+  hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)nblk), dim3(64), 0, c->stream, flags, keys, counts, pos, n,
+                     block_off, out_keys, out_counts, out_pos);
+}
+
+// the two halves of compact(), for a caller that sizes the output by the total (one synchronisation in between)
+void compact_count(rfx_ctx* c, const uint8_t* flags, uint64_t n, uint64_t* block_off, unsigned long long* d_total) {
+  const uint64_t nblk = (n + CP_ITEMS - 1) / CP_ITEMS;
+  if (nblk == 0) {
+    hipMemsetAsync(d_total, 0, sizeof(unsigned long long), c->stream);
+    return;
+  }
+  rfx_span sp(c, "k_compact");
+  hipLaunchKernelGGL(k_compact_count, dim3((unsigned)nblk), dim3(256), 0, c->stream, flags, n, block_off);
+  hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, c->stream, block_off, nblk, d_total);
+}
+void compact_scatter(rfx_ctx* c, const uint8_t* flags, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos,
+                     uint64_t n, const uint64_t* block_off, uint64_t* out_keys, uint32_t* out_counts, uint64_t* out_pos) {
+  const uint64_t nblk = (n + CP_ITEMS - 1) / CP_ITEMS;
+  if (nblk == 0) return;
+  rfx_span sp(c, "k_compact");
   hipLaunchKernelGGL(k_compact_scatter, dim3((unsigned)nblk), dim3(64), 0, c->stream, flags, keys, counts, pos, n,
                      block_off, out_keys, out_counts, out_pos);
 }

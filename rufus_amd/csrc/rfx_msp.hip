@@ -86,10 +86,11 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t r = chunk * MP1_BLOCK + threadIdx.x;
     const bool live = r < rv.n;
-    const uint32_t len = live ? rv.len[r] : 0;
+    const uint32_t len = live ? rv_len(rv, r) : 0;
     const uint32_t lenp = live ? len + 1 : 0;  // one virtual invalid base closes the last run
-    const uint64_t* cw = rv.codes + (live ? rv.word_off[r] : 0);
-    const uint32_t* cm = rv.acgt + (live ? rv.word_off[r] : 0);
+    const uint32_t roff = live ? rv_off(rv, r) : 0;
+    const uint64_t* cw = rv.codes + roff;
+    const uint32_t* cm = live ? rv_acgt(rv, r, roff) : nullptr;  // nullptr: all of the read is A/C/G/T (compact blocks)
     if (threadIdx.x == 0) s_maxlen = 0;
     __syncthreads();
     atomicMax(&s_maxlen, lenp);
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
         const uint32_t p0 = ph * P1_S;
         if ((ph & 3) == 0 && p0 < len) {
           cur_w = cw[p0 >> 5];
-          cur_m = cm[p0 >> 5];
+          cur_m = cm ? cm[p0 >> 5] : ~0u;
         }
         // window minimum = min(suffix minimum of the 14 old hashes, prefix minimum of the new ones)
         uint32_t sfx[WL - 1];

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void k_annotate(rfx_reads_view rv, const uint64
                                                   uint32_t* __restrict__ cov /* per base, zeroed */) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rv.n) return;
-  const uint32_t wr = rv.word_off[r], len = rv.len[r];
+  const uint32_t wr = rv_off(rv, r), len = rv_len(rv, r);
   const uint64_t* cw = rv.codes + wr;
   const uint32_t* cm = rv.good + wr;
   const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);

@@ -30,16 +30,16 @@ __device__ __forceinline__ void for_each_kmer(const rfx_reads_view& rv, uint32_t
                                               int ntab, int sel_bits, uint64_t pos_lo, uint64_t pos_hi, F&& f) {
   const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
   const int rcshift = 2 * (k - 1);
-  const uint32_t wr = rv.word_off[r];
-  const uint32_t len = rv.len[r];
+  const uint32_t wr = rv_off(rv, r);
+  const uint32_t len = rv_len(rv, r);
   const uint64_t* cw = rv.codes + wr;
-  const uint32_t* cm = rv.acgt + wr;
+  const uint32_t* cm = rv_acgt(rv, r, wr);  // nullptr: no mask kept, every base counts (compact blocks)
   uint64_t fwd = 0, rc = 0;
   int filled = 0;
   const uint32_t nw = (len + 31) >> 5;
   for (uint32_t wi = 0; wi < nw; ++wi) {
     uint64_t w = cw[wi];
-    uint32_t m = cm[wi];
+    uint32_t m = cm ? cm[wi] : ~0u;
     const int nb = min(32u, len - (wi << 5));
     for (int b = 0; b < nb; ++b) {
       const uint32_t code = (uint32_t)w & 3u;
@@ -219,9 +219,10 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part1(rfx_reads_view rv, const uin
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t r = chunk * P2_BLOCK + threadIdx.x;
     const bool live = r < rv.n;
-    const uint32_t len = live ? rv.len[r] : 0;
-    const uint64_t* cw = rv.codes + (live ? rv.word_off[r] : 0);
-    const uint32_t* cm = rv.acgt + (live ? rv.word_off[r] : 0);
+    const uint32_t len = live ? rv_len(rv, r) : 0;
+    const uint32_t roff = live ? rv_off(rv, r) : 0;
+    const uint64_t* cw = rv.codes + roff;
+    const uint32_t* cm = live ? rv_acgt(rv, r, roff) : nullptr;
     if (threadIdx.x == 0) s_maxlen = 0;
     __syncthreads();
     if (len) atomicMax(&s_maxlen, len);
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(P2_BLOCK) void k_part1(rfx_reads_view rv, const uin
       const uint32_t p0 = ph * P1_S;
       if ((ph & 3) == 0 && p0 < len) {  // 32 bases per code word = 4 phases
         cur_w = cw[p0 >> 5];
-        cur_m = cm[p0 >> 5];
+        cur_m = cm ? cm[p0 >> 5] : ~0u;
       }
 #pragma unroll
       for (int b = 0; b < P1_S; ++b) {

@@ -55,8 +55,8 @@ def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, 
     n_reads_total: reads per sample over all ranks.  Per pass, sample and rank: super-k-mer records (8 B per
     ~3 k-mer instances; 1 / (S x world) of the sample -- three copies alive at the peak of an exchange: the
     partition, the receive buffers, the import), the refinement scratch (1/8 of the records), the survivor
-    arrays (44 B per surviving k-mer: two partition levels + the records), and the records of the samples
-    already counted in this pass (20 B each)."""
+    arrays (44 B per surviving k-mer: two partition levels + the records), and the subject's candidate records
+    of this pass (20 B each; WgsTrio.run counts the subject first and keeps only them)."""
     windows = n_reads_total * max(read_len - k + 1, 0)           # per sample
     distinct = windows / max(coverage_hint * (read_len - k + 1) / read_len, 1.0)
     for s in range(1, 257 // world):
@@ -66,7 +66,8 @@ def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, 
         # instance all in, the same as k = 25 -- 4.1 here made the plan take 7 where 6 fit)
         records = (3.2 if wide else 2.7) * windows / share * (3.0 if world > 1 else 1.0)
         # leaf phase of the last sample of a pass: records + scratch, survivor store, the other samples' records
-        transient = records * 1.125 + 12.0 * distinct / share * 1.3 + (n_samples - 1) * 20.0 * distinct / share
+        # (the controls are struck off the subject's candidates one at a time: one set of 20-byte records stays)
+        transient = records * 1.125 + 12.0 * distinct / share * 1.3 + (20.0 if n_samples > 1 else 0.0) * distinct / share
         # (measured on the 30x WGS trio, 1 GPU, of 288 GiB: 219 GB at 5 passes, 238 at 4, 271 at 3 -- which this
         # picks; WgsTrio.run() takes one more pass and starts over should a pass not fit after all)
         if resident_bytes + transient < 0.90 * hbm_bytes:
@@ -244,23 +245,39 @@ class WgsTrio:
             histos = [np.zeros(capi.HISTO_BINS, dtype=np.uint64) for _ in samples]
             n_rec = [0] * len(samples)
             keys, kept, recs = [], [], []
+            cand = None
             try:
                 for sh in range(self.passes):
                     recs = []
+                    # The subject (sample 0) is counted first and only its CANDIDATES stay: the records with MinCov <=
+                    # count <= MaxDepth; every control then strikes out what it holds and is freed at once
+                    # (rfx_records_subtract) -- one sample's records alive at a time instead of all of them.
                     for si, blocks in enumerate(samples):
                         rec, h = self.count_shard(blocks, sh)
                         recs.append(rec)
                         histos[si] += h
                         n_rec[si] += len(rec)
                         lap(f"pass {sh} sample {si} count ({len(rec)} records)")
-                    k_, _ = capi.unique_to_subject(self.ctx, recs[0], recs[1:], self.min_cov, self.max_cov)
-                    lap(f"pass {sh} set difference ({len(k_)} k-mers)")
-                    keys.append(k_)
+                        if keep_shard_records:
+                            continue
+                        if si == 0:
+                            cand = capi.records_subtract(self.ctx, rec, [], max(5, self.min_cov), self.max_cov)
+                        else:
+                            nxt = capi.records_subtract(self.ctx, cand, [rec])
+                            cand.free()
+                            cand = nxt
+                        rec.free()
+                        recs.pop()
+                        lap(f"pass {sh} sample {si} candidates ({len(cand)})")
                     if keep_shard_records:
+                        k_, _ = capi.unique_to_subject(self.ctx, recs[0], recs[1:], self.min_cov, self.max_cov)
                         kept.append(recs)
                     else:
-                        for r in recs:
-                            r.free()
+                        k_ = cand.get()[0]
+                        cand.free()
+                        cand = None
+                    lap(f"pass {sh} set difference ({len(k_)} k-mers)")
+                    keys.append(k_)
                     recs = []
                 break
             except capi.RufusError as e:
@@ -268,7 +285,7 @@ class WgsTrio:
                 # (single rank only: the ranks of a group must agree on the passes)
                 if self.world > 1 or self.passes >= 64 or "memory" not in str(e).lower():
                     raise
-                for r in recs + [r_ for shard in kept for r_ in shard]:
+                for r in recs + [r_ for shard in kept for r_ in shard] + ([cand] if cand is not None else []):
                     r.free()
                 self.passes += 1
                 if trace:
@@ -314,11 +331,11 @@ class WgsTrio:
 
 
 def make_sample(ctx: capi.Context, sy: capi.Synth, n_pairs: int, block_pairs: int = 1 << 24, min_q: int = 15,
-                want_good: bool = True, first_pair: int = 0):
+                want_good: bool = True, first_pair: int = 0, compact: bool = False):
     """Blocks of a synthetic sample, generated on the device (pairs first_pair .. first_pair + n_pairs)."""
     blocks, p = [], first_pair
     while p < first_pair + n_pairs:
         n = min(block_pairs, first_pair + n_pairs - p)
-        blocks.append(ctx.synth_reads(sy, p, n, min_q, want_good))
+        blocks.append(ctx.synth_reads(sy, p, n, min_q, want_good, compact))
         p += n
     return blocks

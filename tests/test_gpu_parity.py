@@ -725,6 +725,17 @@ def test_merge_hashlist_query_on_random_configurations(ctx, seed):
     assert tools.rufus_merge(ctx, files) == oracle.merge_unique_text(orcs)
     for lo, hi in ((1, 10**6), (int(rng.integers(1, 6)), int(rng.integers(6, 40)))):
         assert tools.hash_list(ctx, files[0], files[1:], lo, hi) == oracle.hash_list(orcs[0], orcs[1:], lo, hi)
+        # the same one control at a time, device to device (rfx_records_subtract): candidates, then strike out
+        cand = capi.records_subtract(ctx, files[0].records, [], max(5, lo), hi)
+        for f in files[1:]:
+            nxt = capi.records_subtract(ctx, cand, [f.records])
+            cand.free()
+            cand = nxt
+        ck, cc, cp = cand.get()
+        assert "".join(f"{t} {int(c)}\n" for t, c in zip(tools.keys_to_text(ck, k), cc)) == \
+            oracle.hash_list(orcs[0], orcs[1:], lo, hi)
+        assert np.all((cp[1:] > cp[:-1]) | ((cp[1:] == cp[:-1]) & (ck[1:] > ck[:-1])))
+        cand.free()
     kmers = [bytes(base[s0:s0 + k]).decode() for s0 in rng.integers(0, len(base) - k, 200)]
     kmers += ["".join(rng.choice(list("ACGT"), k)) for _ in range(50)]
     want = "".join(f"{oracle.jf_decode(key, k)} {c}\n" for key, c in oracle.query(orcs[-1], kmers))

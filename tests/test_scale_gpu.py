@@ -15,12 +15,16 @@ pytestmark = pytest.mark.gpu
 K, SIZE, LOWER, MIN_COV, MAX_DEPTH, MIN_Q, THRESH = 25, 8 << 30, 2, 5, 1200, 15, 1
 
 
+@pytest.mark.parametrize("compact", [False, True])
 @pytest.mark.parametrize("which,first,n_pairs,want_good", [(0, 0, 3001, True), (1, 12345, 2048, False),
                                                            (0, 7_000_000_000, 513, True)])
-def test_device_generator_matches_host_twin(ctx, which, first, n_pairs, want_good):
-    """rfx_synth_reads == rfx_pack_reads(rfx_synth_text): codes, both masks, offsets, lengths."""
+def test_device_generator_matches_host_twin(ctx, which, first, n_pairs, want_good, compact):
+    """rfx_synth_reads == rfx_pack_reads(rfx_synth_text): codes, both masks, offsets, lengths -- also when the block
+    is kept in the compact form (no offsets / lengths, masks only of the reads with an N)."""
     sy = capi.Synth.sample(300_000, which, n_snv=50, seed=4242)
-    blk = ctx.synth_reads(sy, first, n_pairs, MIN_Q, want_good)
+    blk = ctx.synth_reads(sy, first, n_pairs, MIN_Q, want_good, compact)
+    dense_bytes = 2 * n_pairs * (40 + 20 + 8 + (20 if want_good else 0)) + 4
+    assert (blk.device_bytes < dense_bytes - 2 * n_pairs * 20) if compact else (blk.device_bytes == dense_bytes)
     got = blk.get(want_good)
     seq, qual = sy.text(first, n_pairs)
     s, q, off = synth_flat(seq, qual)
@@ -49,10 +53,11 @@ def _oracle_trio(sys_, n_pairs, k=K):
     return recs, hl, pulled
 
 
-@pytest.mark.parametrize("passes,block_pairs,refine,bins", [(1, 1 << 20, None, None), (3, 7001, None, None),
-                                                            (2, 9000, "16", None), (5, 25000, "21", None),
-                                                            (3, 11000, "19", "32768"), (1, 25000, None, "16384")])
-def test_trio_in_blocks_and_passes_matches_oracle(ctx, monkeypatch, passes, block_pairs, refine, bins):
+@pytest.mark.parametrize("passes,block_pairs,refine,bins,compact",
+                         [(1, 1 << 20, None, None, False), (3, 7001, None, None, True), (2, 9000, "16", None, False),
+                          (5, 25000, "21", None, False), (3, 11000, "19", "32768", True),
+                          (1, 25000, None, "16384", True)])
+def test_trio_in_blocks_and_passes_matches_oracle(ctx, monkeypatch, passes, block_pairs, refine, bins, compact):
     """Multi-block samples, shard passes and chunked refinement of the partition give the oracle's records
     (shards interleaved), histogram, hash list and pulled pairs.  bins > 8192 takes the big-block path
     (scatter, separate histogram pass, exact-size segment) that WGS-size blocks use."""
@@ -63,8 +68,15 @@ def test_trio_in_blocks_and_passes_matches_oracle(ctx, monkeypatch, passes, bloc
     n_pairs, G = 25_000, 250_000
     sys_ = [capi.Synth.sample(G, w, n_snv=12, seed=777) for w in range(3)]
     recs_o, hl_o, pulled_o = _oracle_trio(sys_, n_pairs)
-    samples = [wgs.make_sample(ctx, sy, n_pairs, block_pairs, MIN_Q, want_good=(i == 0)) for i, sy in enumerate(sys_)]
+    samples = [wgs.make_sample(ctx, sy, n_pairs, block_pairs, MIN_Q, want_good=(i == 0), compact=compact)
+               for i, sy in enumerate(sys_)]
     trio = wgs.WgsTrio(ctx, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes)
+    # the bench's route: subject first, the controls struck off its candidates one at a time, nothing kept
+    inc = trio.run(samples)
+    assert inc["n_records"] == [len(r.keys) for r in recs_o]
+    assert tools.keys_to_text(inc["mutant_keys"], K) == [ln.split()[0] for ln in hl_o.splitlines()]
+    assert inc["n_pulled"] == len(pulled_o)
+    assert all(np.array_equal(inc["histos"][si], oracle.histo(recs_o[si].counts, full=True)[0]) for si in range(3))
     res = trio.run(samples, keep_shard_records=True)
     for si in range(3):
         parts = [r[si].get() for r in res["shard_records"]]

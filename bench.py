@@ -299,7 +299,8 @@ def run_wgs(args, ctx, rank, world, dist, torch):
     args.n_samples = len(covs)
     return (step, sum(reads), sum(reads) // len(reads) // world, reads[0], desc, "strong",
             {"passes": passes, "hbm_total": total, "hbm_free_at_start": free0, "resident_read_bytes": resident,
-             "read_blocks": "compact" if compact else "dense"})
+             "read_blocks": "compact" if compact else "dense", "_trio": trio, "_samples": samples, "_sys": sys_,
+             "_pairs": pairs})
 
 
 def main():
@@ -319,6 +320,8 @@ def main():
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) print the cpu_baseline object and exit")
     ap.add_argument("--end-to-end-only", action="store_true", help="(internal) print the end_to_end object and exit")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the self-check after the timed region (rufus_amd.wgs.self_check: three more steps)")
     ap.add_argument("--e2e-pairs", type=int, default=32_000_000,
                     help="read pairs per sample of the end-to-end leg (refused when the text would not fit the container's memory)")
     ap.add_argument("--inner", action="store_true", help="(internal) the GPU part only, run by the launcher below")
@@ -394,6 +397,14 @@ def main():
     prof = ctx.prof_dict()
     prof_steps = args.steps if live_all else 1
     ctx.prof(False)
+    # After the timed region: the run proves itself (size-independent properties -- at 3.1 Gb nothing else can).
+    checks = None
+    if args.workload != "s1" and not args.no_check:
+        from rufus_amd import wgs
+        t_chk = time.perf_counter()
+        checks = wgs.self_check(ctx, extra["_trio"], extra["_samples"], extra["_sys"], res, extra["_pairs"][0], MIN_Q)
+        checks["seconds"] = round(time.perf_counter() - t_chk, 1)
+    extra = {k_: v for k_, v in extra.items() if not k_.startswith("_")}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -423,6 +434,7 @@ def main():
                        "reads_filtered_per_step": reads_filtered, "parallelism": f"read-block shard x{world}",
                        "mutant_kmers": int(res["n_mutant"]), "pulled_pairs": int(res["n_pulled"]),
                        "records_per_sample": [int(x) for x in res["n_records"]], **extra,
+                       "checked": checks is not None, "checks": checks,
                        "hbm_peak_bytes": ctx.mem_stats()["peak"], "hbm_mapped_bytes": ctx.mem_stats()["mapped"]},
             "roofline": {"bound": "hbm", "kernel": "count chain of one sample: " + "+".join(k2), "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,

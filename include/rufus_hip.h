@@ -287,6 +287,11 @@ const uint64_t* rfx_records_dev_keys(const rfx_records*);
 const uint32_t* rfx_records_dev_counts(const rfx_records*);
 const uint64_t* rfx_records_dev_pos(const rfx_records*);
 int rfx_records_histo(const rfx_records*, uint64_t* histo /* RFX_HISTO_BINS */);
+/* Self-check of a record set where it lies (full-size runs are beyond any CPU oracle): out[0] = records out of the
+ * strict (pos,key) order of jf/include/jellyfish/sorted_dumper.hpp:80-112, out[1] = records whose pos is not M * key
+ * (jf/include/jellyfish/rectangular_binary_matrix.hpp:206-243), out[2] = counts outside [min_count, max_count],
+ * out[3] = sum of the counts.  A correct set gives 0, 0, 0. */
+int rfx_records_verify(const rfx_records*, uint32_t min_count, uint32_t max_count, uint64_t out[4]);
 void rfx_records_free(rfx_records*);
 
 /* ---------------------------------------------------------------------------------------------

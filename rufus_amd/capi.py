@@ -93,6 +93,7 @@ SIGNATURES = {
     "rfx_records_dev_counts": (C.c_void_p, [C.c_void_p]),
     "rfx_records_dev_pos": (C.c_void_p, [C.c_void_p]),
     "rfx_records_histo": (C.c_int, [C.c_void_p, u64p]),
+    "rfx_records_verify": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u64p]),
     "rfx_records_free": (None, [C.c_void_p]),
     "rfx_merge_unique": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_uint32, u64p, u32p, C.c_uint64,
                                    u64p]),
@@ -407,6 +408,12 @@ class Records:
         h = np.zeros(HISTO_BINS, dtype=np.uint64)
         _check(lib().rfx_records_histo(self._h, _p(h, u64p)), "rfx_records_histo")
         return h
+
+    def verify(self, min_count: int = 0, max_count: int = 0xFFFFFFFF) -> dict:
+        """Device-side invariants: strict (pos,key) order, pos == M * key, counts in range (all 0 when correct)."""
+        o = np.zeros(4, dtype=np.uint64)
+        _check(lib().rfx_records_verify(self._h, min_count, max_count, _p(o, u64p)), "rfx_records_verify")
+        return {"bad_order": int(o[0]), "bad_pos": int(o[1]), "bad_count": int(o[2]), "sum_counts": int(o[3])}
 
     def query(self, keys: np.ndarray) -> np.ndarray:
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

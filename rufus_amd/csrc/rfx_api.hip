@@ -1209,7 +1209,12 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   uint64_t cap_b = (uint64_t)((double)g.windows * 0.4 * share * (share < 1 ? 1.05 : 1.0)) + 65536;
   if (cap_b > g.windows) cap_b = g.windows;
   const uint64_t even = cap_b / g.c_n;
-  uint64_t cap_a = even + (big ? even / 16 : even / 4) + 16384;
+  // k_msp_part1 hands out the coarse bins in slabs per workgroup (rfx_msp.hip): 1/32 of what a workgroup puts into a
+  // bin, 16 .. 128 records; up to three of them per workgroup and bin stay (partly) unused
+  int slab_log2 = 4;
+  while (slab_log2 < 7 && (even / (uint64_t)g.G >> (slab_log2 + 6)) != 0) ++slab_log2;
+  if (const char* ev = getenv("RFX_MSP_SLAB")) slab_log2 = std::min(7, std::max(2, atoi(ev)));
+  uint64_t cap_a = even + (big ? even / 16 : even / 4) + 16384 + rfxk::msp_part1_slack(g.G, slab_log2);
   if (cap_a >= (1ull << 32)) return RFX_E_RANGE;
   uint64_t* bin_start = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
   // one zeroed block: coarse cursors, [ncur] = flag, then the fine-bin cursors of k_part2
@@ -1235,7 +1240,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
       uint32_t* cnt = getenv("RFX_MSP_REC_HIST") ? nullptr : (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
       if (cnt) {
         rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 3, g.G, buf_a0, cur, (uint32_t)cap_a, cnt,
-                        cur + g.ncur, ext_a0);
+                        cur + g.ncur, ext_a0, slab_log2);
         rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
       } else {
         rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr,
@@ -1296,7 +1301,8 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;  // the address coarse bin 0 would have (see msp_partition_exact)
   uint32_t* ext_a0 = wide ? ext_a - (size_t)g.c_lo * cap_a : nullptr;
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur, ext_a0);
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur, ext_a0,
+                  slab_log2);
   rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
   rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, ext_a0, ext, cap_b,
               "k_part2", nullptr, 0, cap_b, g.rec_mode, t->k);
@@ -2580,6 +2586,25 @@ int rfx_records_histo(const rfx_records* r, uint64_t* histo) {
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_histo");
 }
 
+int rfx_records_verify(const rfx_records* r, uint32_t min_count, uint32_t max_count, uint64_t out[4]) {
+  if (!r || !out) return RFX_E_INVAL;
+  rfx_ctx* c = r->ctx;
+  (void)hipSetDevice(c->device);
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (r->n == 0) return RFX_OK;
+  unsigned long long* d = (unsigned long long*)dmalloc(c, 4 * 8);
+  if (!d) return RFX_E_NOMEM;
+  hipError_t e = hipMemsetAsync(d, 0, 4 * 8, c->stream);
+  if (e == hipSuccess) {
+    const uint64_t pos_mask = r->lsize >= 64 ? ~0ull : ((1ull << r->lsize) - 1);
+    rfxk::records_verify(c, r->keys, r->counts, r->pos, r->n, r->lut, r->ntab, pos_mask, min_count, max_count, d);
+    e = queue_read(c, out, d, 4 * 8);
+  }
+  if (e == hipSuccess) e = ctx_sync(c);
+  dfree(c, d);
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_verify");
+}
+
 // ---------------------------------------------------------------------------------------------
 static int same_function(const rfx_records* a, const rfx_records* b) {
   return a->k == b->k && a->lsize == b->lsize && memcmp(a->cols, b->cols, sizeof(uint64_t) * 2 * a->k) == 0;
@@ -2727,6 +2752,15 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
       return nullptr;
     }
   }
+  s->bm4_bits = rfxk::filter_q_bits(n, k);
+  if (s->bm4_bits) {
+    const size_t bm4_bytes = (size_t)4 << (s->bm4_bits - 5);
+    s->bitmap4 = (uint32_t*)dmalloc(c, bm4_bytes);
+    if (!s->bitmap4 || hipMemsetAsync(s->bitmap4, 0, bm4_bytes, c->stream) != hipSuccess) {
+      rfx_set_free(s);
+      return nullptr;
+    }
+  }
   uint64_t* dk = (uint64_t*)dmalloc(c, n * 8);
   bool ok = s->slots && dk && s->bitmap && (!bm2_words || s->bitmap2);
   if (ok && bm2_words) ok = hipMemsetAsync(s->bitmap2, 0, bm2_words * 4, c->stream) == hipSuccess;
@@ -2738,6 +2772,7 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
     rfxk::set_bitmap(c, dk, n, s->bitmap, s->bm_bits, s->bm_shift);
     if (s->bitmap2) rfxk::set_bitmap_packed(c, dk, n, s->bitmap2);
     if (s->bitmap3) rfxk::set_bitmap_big(c, dk, n, s->bitmap3);
+    if (s->bitmap4) rfxk::set_bitmap_q(c, dk, n, s->bitmap4, s->bm4_bits);
     // no synchronisation: upload() staged the keys, everything else is ordered on the ctx stream, and a
     // device error surfaces at the first rfx_filter / rfx_annotate (which wait for their results)
   }
@@ -2755,6 +2790,7 @@ void rfx_set_free(rfx_set* s) {
   dfree(s->ctx, s->bitmap);
   dfree(s->ctx, s->bitmap2);
   dfree(s->ctx, s->bitmap3);
+  dfree(s->ctx, s->bitmap4);
   delete s;
 }
 
@@ -2767,15 +2803,23 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
   if (n_hit_reads) *n_hit_reads = 0;
   if (r->n == 0) return RFX_OK;
   const uint64_t nmask = ((uint64_t)r->n + 63) / 64;
-  uint32_t* d_hits = hits_out ? (uint32_t*)dmalloc(c, (size_t)r->n * 4) : nullptr;
+  // (the queue filter counts into the array whether the caller wants the counts or not; reads beyond 2^22 bases do not
+  // fit its queue entries)
+  const bool use_q = s->bitmap4 && r->max_len < (1u << 22) && !getenv("RFX_FILTER_GENERIC") && !getenv("RFX_FILTER_OLD");
+  uint32_t* d_hits = hits_out || use_q ? (uint32_t*)dmalloc(c, (size_t)r->n * 4) : nullptr;
   uint64_t* d_mask = (uint64_t*)dmalloc(c, nmask * 8);
   unsigned long long* d_n = (unsigned long long*)dmalloc(c, 8);
   auto cleanup = [&] { dfree(c, d_hits); dfree(c, d_mask); dfree(c, d_n); };
-  if ((hits_out && !d_hits) || !d_mask || !d_n) { cleanup(); return RFX_E_NOMEM; }
+  if (((hits_out || use_q) && !d_hits) || !d_mask || !d_n) { cleanup(); return RFX_E_NOMEM; }
   hipError_t e = hipMemsetAsync(d_n, 0, 8, c->stream);
+  if (e == hipSuccess && use_q) e = hipMemsetAsync(d_hits, 0, (size_t)r->n * 4, c->stream);
   if (e == hipSuccess) {
     const rfx_reads_view rv = r->view();
-    if (s->bitmap2 && !getenv("RFX_FILTER_GENERIC"))
+    // RFX_FILTER_OLD: round 2's k_filter_fast / k_filter_big (kept for A/B runs and as a second opinion in the tests)
+    if (use_q)
+      rfxk::filter_q(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap4, s->bm4_bits, s->k, thresh, last_base_skipped,
+                     d_hits, d_mask, d_n);
+    else if (s->bitmap2 && !getenv("RFX_FILTER_GENERIC"))
       rfxk::filter_fast(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap2, s->k, thresh, last_base_skipped,
                         d_hits, d_mask, d_n);
     else if (s->bitmap3 && !getenv("RFX_FILTER_GENERIC"))

@@ -232,6 +232,8 @@ struct rfx_set {
   int bm_bits, bm_shift;
   uint32_t* bitmap2;  // k >= 16, <= 4096 keys: the two packed-order bitmaps of k_filter_fast (else null)
   uint32_t* bitmap3;  // k >= 20, 4096 < keys <= 2^17: the 2^20-bit packed-order bitmap of k_filter_big (else null)
+  uint32_t* bitmap4;  // k >= 10, keys <= 2^18: the queue filter's bitmap of 2^bm4_bits bits (else null)
+  int bm4_bits;
 };
 
 // ---- kernel launchers (rfx_kernels.hip) -------------------------------------------------------
@@ -261,6 +263,9 @@ void parse_records(rfx_ctx*, const uint8_t* in, uint64_t n, int key_bytes, int c
                    uint32_t* counts);
 void compute_pos(rfx_ctx*, const uint64_t* keys, uint64_t n, const uint64_t* lut, int ntab, uint64_t* pos);
 void check_sorted(rfx_ctx*, const uint64_t* keys, const uint64_t* pos, uint64_t n, unsigned int* d_bad);
+void records_verify(rfx_ctx*, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos, uint64_t n,
+                    const uint64_t* lut, int ntab, uint64_t pos_mask, uint32_t min_count, uint32_t max_count,
+                    unsigned long long* d_out /* 4 counters, see k_records_verify */);
 void flag_range(rfx_ctx*, const uint32_t* counts, uint64_t n, uint32_t lo, uint32_t hi, uint8_t* flags);
 void flag_absent(rfx_ctx*, const uint64_t* keys, const uint64_t* pos, uint64_t n, const uint64_t* bkeys,
                  const uint64_t* bpos, uint64_t nb, int lsize, uint8_t* flags);
@@ -283,6 +288,13 @@ int filter_big_words();
 void set_bitmap_big(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm /* filter_big_words() */);
 void filter_big(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
                 int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit);
+// k >= 10, <= 2^18 keys: bitmap of 2^16 .. 2^20 bits over a window's last 10 bases (LDS resident), candidates queued per
+// wave and probed by full waves (filter_q_bits: the bitmap's size for a set, 0 = not applicable)
+int filter_q_bits(uint64_t n_keys, int k);
+void set_bitmap_q(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm /* 2^(bm_bits-5) words */, int bm_bits);
+void filter_q(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
+              int bm_bits, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
+              unsigned long long* d_nhit);
 void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
             int bm_bits, int bm_shift, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
             unsigned long long* d_nhit);
@@ -331,7 +343,10 @@ int msp_part1_block();  // threads = reads per chunk of k_msp_part1
 int msp_wide(int k);  // k = 26 .. 31: records are a 64-bit word + a 32-bit plane (rfx_devutil.h)
 void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
                int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
-               unsigned int* flag, uint32_t* ext_a = nullptr);
+               unsigned int* flag, uint32_t* ext_a = nullptr,
+               int slab_log2 = 4 /* hmode 0 / 3: a workgroup fills slabs of 2^slab_log2 records per coarse bin; cap_a
+                                    must leave room for msp_part1_slack(grid, slab_log2) unused slots per bin */);
+inline uint64_t msp_part1_slack(int grid, int slab_log2) { return (uint64_t)grid * 3u << slab_log2; }
 void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,

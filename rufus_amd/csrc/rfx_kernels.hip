@@ -455,6 +455,42 @@ __global__ __launch_bounds__(256) void k_check_sorted(const uint64_t* __restrict
   }
 }
 
+// Invariants of a finished record set, checked where it lies (full-size runs are far beyond the oracle):
+// out[0] += records out of strict (pos,key) order, out[1] += records whose stored pos is not M * key (& mask),
+// out[2] += records with count < min_count or > max_count, out[3] += sum of the counts.
+__global__ __launch_bounds__(256) void k_records_verify(const uint64_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ counts,
+                                                         const uint64_t* __restrict__ pos, uint64_t n,
+                                                         const uint64_t* __restrict__ g_lut, int ntab, uint64_t pos_mask,
+                                                         uint32_t min_count, uint32_t max_count,
+                                                         unsigned long long* __restrict__ out) {
+  __shared__ uint64_t s_lut[8 * 256];
+  load_lut(s_lut, g_lut, ntab);
+  __syncthreads();
+  unsigned long long bad_order = 0, bad_pos = 0, bad_cnt = 0, sum = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = pos[i], ky = keys[i];
+    if (i + 1 < n) bad_order += !(p < pos[i + 1] || (p == pos[i + 1] && ky < keys[i + 1]));
+    bad_pos += (gf2_pos(s_lut, ky, ntab) & pos_mask) != p;
+    const uint32_t cc = counts[i];
+    bad_cnt += cc < min_count || cc > max_count;
+    sum += cc;
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    bad_order += __shfl_xor(bad_order, o);
+    bad_pos += __shfl_xor(bad_pos, o);
+    bad_cnt += __shfl_xor(bad_cnt, o);
+    sum += __shfl_xor(sum, o);
+  }
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    if (bad_order) atomicAdd(&out[0], bad_order);
+    if (bad_pos) atomicAdd(&out[1], bad_pos);
+    if (bad_cnt) atomicAdd(&out[2], bad_cnt);
+    atomicAdd(&out[3], sum);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K4: set difference on sorted records
 // ---------------------------------------------------------------------------------------------
@@ -943,6 +979,246 @@ __global__ __launch_bounds__(FB_BLOCK) void k_filter_big(rfx_reads_view rv, cons
   }
 }
 
+// ---- queue filter (k >= 10, sets of <= 2^18 keys): the K5 of round 3 -----------------------------------------------
+// What k_filter_big did not do (97 ms for the 6.2e8 reads of config W, 0.049 of the HBM roofline):
+//   * a lane loaded its read one 8-byte word per loop trip, 40 bytes apart from its neighbour's: the 2.5 KB span of a
+//     wave was fetched five times through an L1 that the other 15 waves had flushed in between.  A uniform 150 bp read is
+//     now loaded whole (5 + 5 words in one burst of loads) before anything is computed;
+//   * every window that passed the bitmap was probed on the spot: a dependent L2 round trip per candidate, taken by
+//     the whole wave whenever ONE lane had a candidate (3-4 trips per word, 20 per read).  Candidates now go into a
+//     per-wave LDS queue (ballot + mbcnt compaction, 4 bytes each: lane of the read | position) and are probed 64 at a
+//     time by full waves, which cut the window out of the packed read themselves;
+//   * the bitmap is sized by the set (2^16 .. 2^20 bits, <= 5 % full): word = LOW bits of the packed 10-mer, bit = the 5
+//     bits above them, so address and bit index are one alignbit + and / shift each: 5 VALU + 1 LDS read per window;
+//     groups of 8 positions where no lane has a fully good window (the first k-1 bases, the tail) are skipped.
+constexpr int FQ_NB = 10;
+constexpr int FQ_QCAP = 256;  // queued candidates per wave
+
+__global__ __launch_bounds__(256) void k_set_bitmap_q(const uint64_t* __restrict__ keys, uint64_t n,
+                                                       uint32_t* __restrict__ bm, int bm_bits) {
+  const uint32_t wmask = (1u << (bm_bits - 5)) - 1;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i];  // first base most significant: the last base is bits [1:0]
+    uint32_t ia = 0;
+#pragma unroll
+    for (int b = 0; b < FQ_NB; ++b) ia |= (uint32_t)((key >> (2 * b)) & 3u) << (2 * (FQ_NB - 1 - b));  // packed order
+    atomicOr(&bm[ia & wmask], 1u << ((ia >> (bm_bits - 5)) & 31u));
+  }
+}
+
+// 32 bits of the packed base stream (prev word's high half | cur) that start 2 bits below the 10-mer ending at base J
+// of `cur`: bits [2, 2 + bm_bits - 5) are the bitmap word's byte address / 4, the 5 bits above them the bit.
+template <int J>
+__device__ __forceinline__ uint32_t fq_window(uint32_t p1, uint32_t c0, uint32_t c1) {
+  constexpr int t = 2 * J + 12;  // 32 + 2 (J - 9) - 2, counted from bit 0 of p1
+  if (t < 32) return __builtin_amdgcn_alignbit(c0, p1, t);
+  if (t == 32) return c0;
+  if (t < 64) return __builtin_amdgcn_alignbit(c1, c0, t - 32);
+  return c1 >> (t - 64);
+}
+
+template <int G>
+__device__ __forceinline__ uint32_t fq_group(const uint32_t* s_bm, uint32_t amask, int ishift, uint32_t p1, uint32_t c0,
+                                             uint32_t c1, uint32_t cand) {
+  uint32_t x[8], w[8];
+#define FQ_X(u) x[u] = fq_window<8 * G + u>(p1, c0, c1)
+  FQ_X(0); FQ_X(1); FQ_X(2); FQ_X(3); FQ_X(4); FQ_X(5); FQ_X(6); FQ_X(7);
+#undef FQ_X
+#pragma unroll
+  for (int u = 0; u < 8; ++u) w[u] = *(const uint32_t*)((const char*)s_bm + (x[u] & amask));
+#pragma unroll
+  for (int u = 0; u < 8; ++u) cand = __builtin_amdgcn_alignbit(w[u] >> ((x[u] >> ishift) & 31u), cand, 1);
+  return cand;
+}
+
+// UW > 0: every read of the (compact) block has UW code words, loaded in one burst.
+// Hit counts go to g_hits (zeroed by the caller) by atomic add -- hits are rare --, so the queue need not be empty when
+// a chunk of reads ends: it is drained when it is full, 256 candidates with all their loads in flight, whichever
+// chunk they came from (entry = chunk turns since the last drain << 28 | lane of the read << 22 | position).
+// k_hits_mask turns the counts into the per-read mask afterwards.
+template <int BLOCK, int UW>
+__global__ __launch_bounds__(BLOCK) void k_filter_q(rfx_reads_view rv, const uint64_t* __restrict__ g_slots, int bits,
+                                                     int has_all_ones, const uint32_t* __restrict__ g_bm, int bm_bits,
+                                                     int k, int last_base_skipped, uint32_t* __restrict__ g_hits) {
+  extern __shared__ uint32_t s_fq[];  // bitmap | per-wave queues
+  const uint32_t bm_words = 1u << (bm_bits - 5);
+  const uint32_t wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  uint32_t* s_bm = s_fq;
+  uint32_t* s_q = s_fq + bm_words + wave * FQ_QCAP;
+  for (uint32_t i = threadIdx.x; i < bm_words; i += BLOCK) s_bm[i] = g_bm[i];
+  __syncthreads();
+  const uint32_t amask = (bm_words - 1) << 2;
+  const int ishift = bm_bits - 5 + 2;
+  const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+  const uint32_t smask = (1u << bits) - 1;
+  const uint32_t n_chunks = (rv.n + BLOCK - 1) / BLOCK;
+  uint32_t qn = 0, it_base = 0;  // wave-uniform
+  // the queued candidates, four per lane at a time: cut the window out of the packed read, probe the set exactly
+  auto drain = [&](uint32_t it_now) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t b0 = 0; b0 < qn; b0 += 4 * WAVE) {
+      uint64_t cur_c[4], prev_c[4], fwd[4], got[4];
+      uint32_t rr[4], pj[4], sl[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t idx = b0 + (uint32_t)u * WAVE + lane;
+        ok[u] = idx < qn;
+        const uint32_t e = ok[u] ? s_q[idx] : 0u;
+        rr[u] = (blockIdx.x + (it_base + (e >> 28)) * gridDim.x) * BLOCK + wave * WAVE + ((e >> 22) & 63u);
+        const uint32_t pos = e & 0x3FFFFFu;
+        pj[u] = pos & 31u;
+        const uint32_t off = ok[u] ? rv_off(rv, rr[u]) + (pos >> 5) : 0u;
+        cur_c[u] = ok[u] ? rv.codes[off] : 0ull;
+        prev_c[u] = ok[u] && (pos >> 5) ? rv.codes[off - 1] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int sh = 2 * ((int)pj[u] - k + 1) + 64;  // 2 .. 126
+        const uint64_t packed = sh >= 64 ? cur_c[u] >> (sh - 64) : (prev_c[u] >> sh) | (cur_c[u] << (64 - sh));
+        uint64_t y = __brevll(packed);  // 2-bit groups reversed: the forward key, first base most significant
+        y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+        fwd[u] = (k == 32 ? y : y >> (64 - 2 * k)) & kmask;
+        sl[u] = set_hash(fwd[u], bits);
+        got[u] = ok[u] ? g_slots[sl[u]] : RFX_EMPTY;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!ok[u]) continue;
+        bool hit;
+        if (fwd[u] == RFX_EMPTY) {
+          hit = has_all_ones != 0;
+        } else {
+          uint64_t v = got[u];
+          uint32_t q = sl[u];
+          while (v != fwd[u] && v != RFX_EMPTY) {  // (linear probing: rarely more than the first slot)
+            q = (q + 1) & smask;
+            v = g_slots[q];
+          }
+          hit = v == fwd[u];
+        }
+        if (hit) atomicAdd(&g_hits[rr[u]], 1u);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    qn = 0;
+    it_base = it_now;
+  };
+  uint64_t ncv[UW > 0 ? UW : 1];
+  uint32_t ngv[UW > 0 ? UW : 1];
+  auto load_ahead = [&](uint32_t chunk_) {
+    const uint32_t r_ = chunk_ * BLOCK + wave * WAVE + lane;
+    const bool live_ = chunk_ < n_chunks && r_ < rv.n;
+    const uint32_t wr_ = live_ ? r_ * (uint32_t)UW : 0u;
+#pragma unroll
+    for (int i = 0; i < (UW > 0 ? UW : 1); ++i) {
+      ncv[i] = live_ && UW > 0 ? rv.codes[wr_ + i] : 0ull;
+      ngv[i] = live_ && UW > 0 ? rv.good[wr_ + i] : 0u;
+    }
+  };
+  if (UW > 0) load_ahead(blockIdx.x);
+  uint32_t it = 0;
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x, ++it) {
+    if (it - it_base == 15u) drain(it);
+    const uint32_t r = chunk * BLOCK + wave * WAVE + lane;
+    const bool live = r < rv.n;
+    // one code word + its good mask: V = "a fully good window ends here", bitmap bit per position, queue the rest
+    auto word = [&](uint32_t wi, uint64_t prev_c, uint64_t cur_c, uint32_t prev_g, uint32_t cur_g) {
+      const uint64_t X = ((uint64_t)cur_g << 32) | prev_g;
+      uint64_t acc = ~0ull, run = X;
+      int off = 0;
+      for (int bit = 0; (k >> bit) != 0; ++bit) {  // run-length doubling, see k_filter_fast
+        if ((k >> bit) & 1) {
+          acc &= run << off;
+          off += 1 << bit;
+        }
+        run &= run << (1 << bit);
+      }
+      const uint32_t V = (uint32_t)(acc >> 32);
+      const uint32_t p1 = (uint32_t)(prev_c >> 32), c0 = (uint32_t)cur_c, c1 = (uint32_t)(cur_c >> 32);
+      uint32_t cand = 0;
+      if (__ballot((V & 0x000000FFu) != 0)) cand = fq_group<0>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
+      if (__ballot((V & 0x0000FF00u) != 0)) cand = fq_group<1>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
+      if (__ballot((V & 0x00FF0000u) != 0)) cand = fq_group<2>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
+      if (__ballot((V & 0xFF000000u) != 0)) cand = fq_group<3>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
+      cand &= V;
+#ifdef FQ_NOPUSH  // experiment: what the lookups alone cost
+      if (cand == 0x12345678u && V == 0x9ABCDEF0u) s_q[0] = cand;
+      cand = 0;
+#endif
+      for (;;) {
+        const unsigned long long act = __ballot(cand != 0);
+        if (!act) break;
+        const uint32_t cnt = (uint32_t)__popcll(act);
+        if (qn + cnt > (uint32_t)FQ_QCAP) drain(it);
+        if (cand) {
+          const uint32_t j = (uint32_t)__ffs(cand) - 1u;
+          cand &= cand - 1u;
+          const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+          s_q[slot] = ((it - it_base) << 28) | (lane << 22) | (wi * 32u + j);
+        }
+        qn += cnt;
+      }
+    };
+    if (UW > 0) {
+      uint64_t cv[UW > 0 ? UW : 1];
+      uint32_t gv[UW > 0 ? UW : 1];
+#pragma unroll
+      for (int i = 0; i < UW; ++i) {  // loaded one turn ahead: the HBM latency is spent under the previous chunk
+        cv[i] = ncv[i];
+        gv[i] = ngv[i];
+      }
+      load_ahead(chunk + gridDim.x);
+      // src/RUFUS.Filter.cpp:203: `i < length()-1` -- the last base is never examined.
+      const uint32_t stop = live ? (last_base_skipped ? rv.ulen - 1 : rv.ulen) : 0u;
+#pragma unroll
+      for (int i = 0; i < UW; ++i) {
+        const uint32_t lo = (uint32_t)i * 32u;
+        uint32_t g = gv[i];
+        if (stop < lo + 32u) g = stop > lo ? g & ((1u << (stop - lo)) - 1u) : 0u;
+        gv[i] = g;
+        word((uint32_t)i, i ? cv[i - 1] : 0ull, cv[i], i ? gv[i - 1] : 0u, g);
+      }
+    } else {
+      const uint32_t wr = live ? rv_off(rv, r) : 0u;
+      const uint32_t len = live ? rv_len(rv, r) : 0u;
+      const uint32_t stop = last_base_skipped ? (len ? len - 1 : 0) : len;
+      uint32_t nw = (stop + 31) >> 5, nw_max = nw;
+#pragma unroll
+      for (int o = 32; o; o >>= 1) nw_max = max(nw_max, (uint32_t)__shfl_xor((int)nw_max, o));
+      uint64_t prev_c = 0;
+      uint32_t prev_g = 0;
+      for (uint32_t wi = 0; wi < nw_max; ++wi) {  // every lane takes part in the ballots of every trip
+        const uint64_t cur_c = wi < nw ? rv.codes[wr + wi] : 0ull;
+        uint32_t cur_g = wi < nw ? rv.good[wr + wi] : 0u;
+        const uint32_t lo = wi << 5;
+        if (stop < lo + 32u) cur_g = stop > lo ? cur_g & ((1u << (stop - lo)) - 1u) : 0u;
+        word(wi, prev_c, cur_c, prev_g, cur_g);
+        prev_c = cur_c;
+        prev_g = cur_g;
+      }
+    }
+  }
+  if (qn) drain(it);
+}
+
+// per-read hit counts -> one bit per read (count >= thresh) and the number of such reads
+__global__ __launch_bounds__(256) void k_hits_mask(const uint32_t* __restrict__ hits, uint32_t n, int thresh,
+                                                    uint64_t* __restrict__ hitmask,
+                                                    unsigned long long* __restrict__ d_nhit) {
+  const uint32_t n_pad = (n + WAVE - 1) & ~(uint32_t)(WAVE - 1);
+  for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < n_pad; r += (uint64_t)gridDim.x * blockDim.x) {
+    const bool pass = r < n && (int)hits[r] >= thresh;
+    const unsigned long long mm = __ballot(pass);
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+      if (hitmask) hitmask[r >> 6] = mm;
+      if (mm) atomicAdd(d_nhit, (unsigned long long)__popcll(mm));
+    }
+  }
+}
+
 // Device-to-device copy of big blocks.  hipMemcpyAsync between a hipMalloc'ed buffer (another runtime's: torch's
 // exchange buffers) and the ctx's VMM-mapped arena took 140 ms per 11 GB segment (~80 GB/s: not a blit kernel);
 // this streams 16 bytes per lane.
@@ -1052,6 +1328,15 @@ void compute_pos(rfx_ctx* c, const uint64_t* keys, uint64_t n, const uint64_t* l
   if (n == 0) return;
   rfx_span sp(c, "k_compute_pos");
   hipLaunchKernelGGL(k_compute_pos, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, lut, ntab, pos);
+}
+
+void records_verify(rfx_ctx* c, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos, uint64_t n,
+                    const uint64_t* lut, int ntab, uint64_t pos_mask, uint32_t min_count, uint32_t max_count,
+                    unsigned long long* d_out) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_records_verify");
+  hipLaunchKernelGGL(k_records_verify, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, counts, pos, n, lut,
+                     ntab, pos_mask, min_count, max_count, d_out);
 }
 
 void check_sorted(rfx_ctx* c, const uint64_t* keys, const uint64_t* pos, uint64_t n, unsigned int* d_bad) {
@@ -1164,6 +1449,55 @@ void filter_big(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int
   const int grid = (int)std::min<uint32_t>(chunks, (uint32_t)c->n_cu);  // one resident workgroup per CU
   hipLaunchKernelGGL(k_filter_big, dim3(grid), dim3(FB_BLOCK), FB_WORDS * 4, c->stream, rv, slots, bits, has_all_ones, bm, k,
                      thresh, last_base_skipped, hits, hitmask, d_nhit);
+}
+
+int filter_q_bits(uint64_t n_keys, int k) {  // 0: the queue filter does not apply
+  if (k < FQ_NB || n_keys > (1u << 18)) return 0;
+  // Small sets: <= 1.5 % of the bits set, 8 .. 32 KB of LDS, many small workgroups.  Beyond 4096 keys always 2^20 bits
+  // (one 1024-thread workgroup per CU = the 16 waves two 512-thread workgroups with 2^19 bits would be, with half
+  // the candidates: a drain costs two dependent memory round trips however few candidates it carries).
+  if (n_keys > 4096) return 20;
+  int b = 16;
+  while (b < 18 && (n_keys * 64 >> b) != 0) ++b;
+  return b;
+}
+
+void set_bitmap_q(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* bm, int bm_bits) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_set_bitmap");
+  hipLaunchKernelGGL(k_set_bitmap_q, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, bm, bm_bits);
+}
+
+void filter_q(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
+              int bm_bits, int k, int thresh, int last_base_skipped, uint32_t* hits /* zeroed, never null */,
+              uint64_t* hitmask, unsigned long long* d_nhit) {
+  if (rv.n == 0) return;
+  const int block = bm_bits >= 20 ? 1024 : bm_bits == 19 ? 512 : 256;
+  const size_t lds = ((size_t)(1u << (bm_bits - 5)) + (size_t)(block / WAVE) * FQ_QCAP) * 4;
+  const int per_cu = std::max<int>(1, std::min<int>(2048 / block, (int)((160 * 1024) / lds)));
+  const uint32_t chunks = (rv.n + block - 1) / block;
+  const int grid = (int)std::min<uint32_t>(chunks, (uint32_t)c->n_cu * per_cu);  // the resident workgroups
+  const bool u5 = rv.ulen && rv.uwpr == 5;
+  rfx_span sp(c, "k_filter");
+#define RFX_FQ(BLOCK, UW, BIT)                                                                                        \
+  do {                                                                                                                \
+    if (lds > 64 * 1024 && !rfxi::lds_opt_in(c, (const void*)k_filter_q<BLOCK, UW>, lds, BIT, "k_filter_q")) return;  \
+    hipLaunchKernelGGL((k_filter_q<BLOCK, UW>), dim3(grid), dim3(BLOCK), lds, c->stream, rv, slots, bits,            \
+                       has_all_ones, bm, bm_bits, k, last_base_skipped, hits);                                       \
+  } while (0)
+  if (block == 1024) {
+    if (u5) RFX_FQ(1024, 5, 6);
+    else RFX_FQ(1024, 0, 7);
+  } else if (block == 512) {
+    if (u5) RFX_FQ(512, 5, 8);
+    else RFX_FQ(512, 0, 9);
+  } else {
+    if (u5) RFX_FQ(256, 5, 10);
+    else RFX_FQ(256, 0, 11);
+  }
+#undef RFX_FQ
+  hipLaunchKernelGGL(k_hits_mask, dim3(grid_for(c, rv.n, 256, 8)), dim3(256), 0, c->stream, hits, rv.n, thresh, hitmask,
+                     d_nhit);
 }
 
 void filter(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,

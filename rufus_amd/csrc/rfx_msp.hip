@@ -60,13 +60,26 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
                                                          uint32_t* __restrict__ ext_a,
                                                          uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
                                                          uint32_t* __restrict__ cnt_rows,
-                                                         unsigned int* __restrict__ flag) {
+                                                         unsigned int* __restrict__ flag, int slab_log2) {
   // Two of each, by phase parity (the second barrier of a phase then only has to cover the addresses).  Tried in
   // round 3 and dropped: reserving phase p's runs while phase p + 1 is hashed and storing p's records one phase late
   // (one barrier per phase, nobody waits for the atomic) -- 126 VGPRs, 94 instead of 90 ms per 1 Gb sample: the other
   // workgroup of the CU already covers the round trip, the kernel is bound by what it issues.
   __shared__ uint32_t s_cnt[2][P1_BINS];
   __shared__ uint64_t s_gbase[2][P1_BINS];  // 64-bit: the exact redo may size a coarse bin by a skewed maximum
+  // HMODE 0 / 3 (the optimistic one-pass scatter): SLABS.  Round 2 reserved one run per coarse bin and phase with a
+  // global atomic BETWEEN two barriers -- the whole workgroup waited out its round trip 19 times per read, and the
+  // records of a phase sat in 24 registers until the addresses were known (-DRFX_TIMING: reserve + barriers 35 %,
+  // stores 24 % of the kernel; hashing alone, -DRFX_P1_NOCLOSE: 48 of 94 ms).  Now a workgroup owns, per coarse bin,
+  // a slab of 2^slab_log2 record slots plus a spare one plus a third whose reservation is in flight: a closing lane
+  // takes slot = atomicAdd(s_fill[bin]) in LDS and stores its record at once; every few phases the bins whose slab
+  // filled up move on (spare -> current, in-flight -> spare, a new reservation is issued and not waited for).  A bin
+  // that gets more than two slabs' worth between two such points falls back to one global atomic per record.  The
+  // unused tails are filled with MSP_EMPTY at the end, k_part2 / k_surv_hist skip those.
+  constexpr bool SLABS = HMODE == 0 || HMODE == 3;
+  static_assert(P1_BINS == 128, "the slab bookkeeping below shifts by log2(P1_BINS) = 7");
+  __shared__ uint32_t s_fill[SLABS ? P1_BINS : 1];
+  __shared__ uint64_t s_slab[SLABS ? 3 : 1][SLABS ? P1_BINS : 1];  // [0] current, [1] spare ([2]: the in-flight one, at the end)
   __shared__ uint32_t s_fine[HMODE == 0 ? 4096 : HMODE == 1 ? 8192 : HMODE == 3 ? 16384 : 1];
   __shared__ uint32_t s_maxlen;
   const uint32_t P = 1u << bin_bits;
@@ -82,6 +95,26 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   if (HMODE == 3)
     for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) s_fine[i] = 0;
   if (threadIdx.x < 2 * P1_BINS) (&s_cnt[0][0])[threadIdx.x] = 0;
+  const uint32_t SLAB = 1u << slab_log2;
+  const uint32_t tick_mask = SLAB >= 128 ? 3u : SLAB >= 64 ? 1u : 0u;  // bins move on every 4 / 2 / 1 phases
+  uint64_t pending = ~0ull;  // threads < P1_BINS: the slab reserved ahead for their bin
+  uint32_t tick = 0;
+  auto reserve_slab = [&](uint32_t b) -> uint64_t {
+    const uint32_t at = atomicAdd(&coarse_cur[b * P1_CUR_STRIDE], SLAB);
+    if ((uint64_t)at + SLAB > cap_a) {  // over capacity: records are dropped, the host redoes the block
+      atomicExch(flag, 1u);
+      return ~0ull;
+    }
+    return (uint64_t)b * cap_a + at;
+  };
+  if (SLABS && threadIdx.x < P1_BINS) {
+    // only the coarse bins this shard's records can fall into have memory behind them
+    const bool used = bin_hi > bin_lo && threadIdx.x >= (bin_lo >> sub_bits) && threadIdx.x <= ((bin_hi - 1) >> sub_bits);
+    s_fill[threadIdx.x] = 0;
+    s_slab[0][threadIdx.x] = used ? reserve_slab(threadIdx.x) : ~0ull;
+    s_slab[1][threadIdx.x] = used ? reserve_slab(threadIdx.x) : ~0ull;
+    pending = used ? reserve_slab(threadIdx.x) : ~0ull;
+  }
   const uint32_t n_chunks = (rv.n + MP1_BLOCK - 1) / MP1_BLOCK;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t r = chunk * MP1_BLOCK + threadIdx.x;
@@ -179,7 +212,27 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
                   }
                   wv[b] = bases | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)side << 58) | ((uint64_t)mp << 59);
                 }
-                br[b] = (coarse << 16) | atomicAdd(&s_cnt[X][coarse], 1u);
+                if (SLABS) {
+                  const uint32_t slot = atomicAdd(&s_fill[coarse], 1u);
+                  if (slot < 2 * SLAB) {
+                    const uint64_t sb = s_slab[slot >> slab_log2][coarse];
+                    if (sb != ~0ull) {
+                      buf_a[sb + (slot & (SLAB - 1))] = wv[b];
+                      if (WIDE) ext_a[sb + (slot & (SLAB - 1))] = xv[b];
+                    }
+                  } else {  // more than two slabs' worth since the bins last moved on: one reservation per record
+                    const uint32_t at = atomicAdd(&coarse_cur[coarse * P1_CUR_STRIDE], 1u);
+                    if (at < cap_a) {
+                      buf_a[(uint64_t)coarse * cap_a + at] = wv[b];
+                      if (WIDE) ext_a[(uint64_t)coarse * cap_a + at] = xv[b];
+                    } else {
+                      atomicExch(flag, 1u);
+                    }
+                  }
+                  ++n_emit;
+                } else {
+                  br[b] = (coarse << 16) | atomicAdd(&s_cnt[X][coarse], 1u);
+                }
               }
               if ((HMODE == 0 || HMODE == 3) && mine) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
               if (HMODE == 1 && mine) atomicAdd(&s_fine[run_bin], 1u);
@@ -198,6 +251,30 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
       }
       TM(0);
       if (HMODE == 1) continue;
+      if (SLABS) {
+        if ((++tick & tick_mask) == 0) {
+          __syncthreads();  // every slot of the interval has been handed out
+          if (threadIdx.x < P1_BINS) {
+            uint32_t f = s_fill[threadIdx.x];
+            if (f >= SLAB) {
+              if (f >= 2 * SLAB) {  // both slabs are full (what came after them went the slow way)
+                s_slab[0][threadIdx.x] = pending;
+                s_slab[1][threadIdx.x] = reserve_slab(threadIdx.x);
+                f = 0;
+              } else {
+                s_slab[0][threadIdx.x] = s_slab[1][threadIdx.x];
+                s_slab[1][threadIdx.x] = pending;
+                f -= SLAB;
+              }
+              pending = reserve_slab(threadIdx.x);  // used at a later turn: nobody waits for this one
+              s_fill[threadIdx.x] = f;
+            }
+          }
+          __syncthreads();
+        }
+        TM(1);
+        continue;
+      }
       uint32_t at_prev = 0, cn_prev = 0;
       auto settle = [&](uint32_t Y) {  // the reserved runs' addresses, for everybody (waits for the atomic)
         if (threadIdx.x < P1_BINS) {
@@ -244,6 +321,16 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     }
   }
   __syncthreads();
+  if (SLABS) {  // the slots nobody took: MSP_EMPTY
+    if (threadIdx.x < P1_BINS) s_slab[2][threadIdx.x] = pending;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 3u * P1_BINS * SLAB; i += blockDim.x) {
+      const uint32_t o = i & (SLAB - 1), bw = i >> slab_log2, b = bw & (P1_BINS - 1), which = bw >> 7;  // P1_BINS = 2^7
+      const uint64_t sb = s_slab[which][b];
+      if (sb != ~0ull && (which == 2 || which * SLAB + o >= s_fill[b])) buf_a[sb + o] = MSP_EMPTY;
+    }
+    __syncthreads();
+  }
   if (HMODE == 0 || HMODE == 3) {
     __shared__ uint32_t s_emit;
     if (threadIdx.x == 0) {
@@ -608,6 +695,7 @@ __global__ __launch_bounds__(L2_BLOCK) void k_surv_hist(const uint64_t* __restri
   __syncthreads();
   for (uint64_t i = a + (uint64_t)jj * L2_BLOCK + threadIdx.x; i < e; i += (uint64_t)W * L2_BLOCK) {
     const uint64_t w = buf_a[i];
+    if (MODE != 0 && w == MSP_EMPTY) continue;  // a slot of a k_msp_part1 slab that nobody took
     const uint32_t sub = MODE == 0 ? (uint32_t)(w >> shift2) & (P2 - 1)
                                    : ((MODE == 1 ? msp_record_binhash<true>(w, k) : msp_record_binhash<false>(w, k)) >> shift2) & (P2 - 1);
     atomicAdd(&s_cnt[sub], 1u);
@@ -719,11 +807,11 @@ int msp_wide(int k) { return k > 25; }
 
 void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
                int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
-               unsigned int* flag, uint32_t* ext_a) {
+               unsigned int* flag, uint32_t* ext_a, int slab_log2) {
   rfx_span sp(c, hmode == 1 ? "k_msp_count" : "k_msp_part1");
 #define RFX_MSP_P1(CANON, HM, WL, WIDE)                                                                             \
   hipLaunchKernelGGL((k_msp_part1<CANON, HM, WL, WIDE>), dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, k, bin_bits, \
-                     bin_lo, bin_hi, buf_a, ext_a, coarse_cur, cap_a, cnt_rows, flag)
+                     bin_lo, bin_hi, buf_a, ext_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2)
 #define RFX_MSP_P1_HM(CANON, WL, WIDE)          \
   do {                                          \
     if (hmode == 0) RFX_MSP_P1(CANON, 0, WL, WIDE);      \

@@ -392,7 +392,8 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
 #pragma unroll
     for (int u = 0; u < L2_PER; ++u) {
       br[u] = ~0u;
-      if (base + threadIdx.x + (uint64_t)u * L2_BLOCK < e) {
+      // (MODE 1 / 2: MSP_EMPTY = a slot of a k_msp_part1 slab that nobody took)
+      if (base + threadIdx.x + (uint64_t)u * L2_BLOCK < e && (MODE == 0 || wv[u] != MSP_EMPTY)) {
         const uint32_t sub = sub_bin_of<MODE>(wv[u], shift2, P2, k);
         br[u] = (sub << 16) | atomicAdd(&s_cnt[sub], 1u);
       }

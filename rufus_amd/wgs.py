@@ -228,8 +228,12 @@ class WgsTrio:
             pos ^= np.where((keys >> np.uint64(b)) & np.uint64(1), self.cols[c - 1 - b], np.uint64(0))
         return pos & np.uint64((1 << self.lsize) - 1) if self.lsize < 64 else pos
 
-    def run(self, samples, keep_shard_records: bool = False):
-        """samples: [subject blocks, control blocks, ...] (lists of capi.ReadBlock)."""
+    def run(self, samples, keep_shard_records: bool = False, verify: bool = False, probe_keys=None):
+        """samples: [subject blocks, control blocks, ...] (lists of capi.ReadBlock).
+
+        verify: every shard's records are checked where they lie before they are freed (rfx_records_verify: strict
+        (pos,key) order, pos == M * key, lower <= count) -> out["verify"]; probe_keys (canonical keys, e.g. the hash
+        list of an earlier run): out["verify"]["probe_found"][sample] = how many of them each sample holds."""
         trace = os.environ.get("RFX_WGS_TRACE")
         t_last = time.perf_counter()
 
@@ -246,6 +250,8 @@ class WgsTrio:
             n_rec = [0] * len(samples)
             keys, kept, recs = [], [], []
             cand = None
+            ver = {"bad_order": 0, "bad_pos": 0, "bad_count": 0, "sum_counts": [0] * len(samples),
+                   "probe_found": [0] * len(samples), "probe_count_out_of_range": 0}
             try:
                 for sh in range(self.passes):
                     recs = []
@@ -258,6 +264,18 @@ class WgsTrio:
                         histos[si] += h
                         n_rec[si] += len(rec)
                         lap(f"pass {sh} sample {si} count ({len(rec)} records)")
+                        if verify:
+                            v = rec.verify(self.lower)
+                            for k_ in ("bad_order", "bad_pos", "bad_count"):
+                                ver[k_] += v[k_]
+                            ver["sum_counts"][si] += v["sum_counts"]
+                            if probe_keys is not None and len(probe_keys):
+                                got = rec.query(np.asarray(probe_keys, dtype=np.uint64))
+                                ver["probe_found"][si] += int((got > 0).sum())
+                                if si == 0:
+                                    ver["probe_count_out_of_range"] += int(((got > 0) & ((got < max(5, self.min_cov)) |
+                                                                                         (got > self.max_cov))).sum())
+                            lap(f"pass {sh} sample {si} verify")
                         if keep_shard_records:
                             continue
                         if si == 0:
@@ -327,7 +345,115 @@ class WgsTrio:
                "hit_masks": masks}
         if keep_shard_records:
             out["shard_records"] = kept
+        if verify:
+            if self.world > 1:
+                v_ = _wire(torch.tensor([ver["bad_order"], ver["bad_pos"], ver["bad_count"], ver["probe_count_out_of_range"]]
+                                        + ver["sum_counts"] + ver["probe_found"], dtype=torch.int64, device=dev), self.group)
+                dist.all_reduce(v_, op=dist.ReduceOp.SUM, group=self.group)
+                v_ = v_.tolist()
+                n_ = len(samples)
+                ver.update(bad_order=v_[0], bad_pos=v_[1], bad_count=v_[2], probe_count_out_of_range=v_[3],
+                           sum_counts=v_[4:4 + n_], probe_found=v_[4 + n_:4 + 2 * n_])
+            out["verify"] = ver
         return out
+
+
+_COMP = bytes.maketrans(b"ACGT", b"TGCA")
+
+
+def expected_snv_kmers(sy: capi.Synth, k: int) -> set:
+    """Canonical k-mers that carry the alt allele of a planted SNV of the subject (k per SNV)."""
+    expect = set()
+    for p, ref, alt in sy.snvs():
+        ctxt = bytearray(sy.genome(p - k + 1, 2 * k - 1))
+        if bytes(ctxt[k - 1:k]) != ref:
+            raise AssertionError("generator: the reference base of an SNV is not the genome's")
+        ctxt[k - 1:k] = alt
+        for i in range(k):
+            km = bytes(ctxt[i:i + k])
+            expect.add(min(km, km[::-1].translate(_COMP)))
+    return expect
+
+
+def valid_windows_of_text(seq: np.ndarray, k: int) -> int:
+    """ACGT-only windows of length k of a (reads x length) uint8 matrix of read text (host arithmetic only)."""
+    ok = np.isin(seq, np.frombuffer(b"ACGTacgt", np.uint8))
+    run = np.zeros(seq.shape[0], dtype=np.int32)
+    tot = 0
+    for j in range(seq.shape[1]):
+        run = np.where(ok[:, j], run + 1, 0)
+        tot += int((run >= k).sum())
+    return tot
+
+
+def self_check(ctx: capi.Context, trio: "WgsTrio", samples, sys_, res, n_pairs, min_q: int = 15,
+               more_passes: bool = True, sample_pairs: int = 1 << 17) -> dict:
+    """What must hold at ANY size, checked on the data of a finished run `res` of `trio` on `samples` (bench.py runs
+    this after its timed region; tests/test_scale_gpu.py at the full size of BASELINE configs[2]).  Raises
+    AssertionError; returns a summary for the bench line.
+
+    1. a second run with every shard's records verified on the device: strict (pos,key) order
+       (jf/include/jellyfish/sorted_dumper.hpp:80-112), pos == M * key, every count >= lower; the sum of the counts
+       equals sum(i * histo[i]); the same record counts, histograms, hash list and pulled pairs as `res`;
+    2. the mutant k-mers: each is held by the subject with MinCov <= count <= MaxDepth and by NO control (looked up
+       in every shard of every sample: merge_files.cc:69-155 + CheckJellyHashList.sh:12 semantics), and they are the
+       alt-allele k-mers of the planted SNVs (a handful of recurrent sequencing errors aside);
+    3. one more shard pass (S + 1) gives the same record counts, histograms, hash list and pulled pairs;
+    4. a sampled block of the subject counted alone with lower = 1: sum(i * histo[i]) == the number of ACGT-only
+       windows, computed on the host from the generator's host twin (text), not from the packed block."""
+    k = trio.k
+    out = {}
+    keys0 = np.asarray(res["mutant_keys"], dtype=np.uint64)
+    rv = trio.run(samples, verify=True, probe_keys=keys0)
+    v = rv["verify"]
+    assert v["bad_order"] == 0 and v["bad_pos"] == 0 and v["bad_count"] == 0, f"records fail their invariants: {v}"
+    assert rv["n_records"] == res["n_records"] and rv["n_pulled"] == res["n_pulled"]
+    assert np.array_equal(rv["mutant_keys"], keys0)
+    for si, h in enumerate(rv["histos"]):
+        assert np.array_equal(h, res["histos"][si])
+        assert int(h[-1]) != 0 or int(sum(int(x) * i for i, x in enumerate(h))) == v["sum_counts"][si], "histogram != records"
+        assert int(h.sum()) == rv["n_records"][si]
+    assert v["probe_found"][0] == len(keys0) and v["probe_count_out_of_range"] == 0, "a mutant k-mer is not the subject's"
+    assert all(x == 0 for x in v["probe_found"][1:]), "a mutant k-mer occurs in a control"
+    out.update(records_verified=int(sum(rv["n_records"])), order_pos_count_violations=0,
+               mutant_in_subject=int(v["probe_found"][0]), mutant_in_controls=int(sum(v["probe_found"][1:])))
+    from .tools import keys_to_text
+    if sys_[0].n_snv and len(samples) > 1:
+        expect = expected_snv_kmers(sys_[0], k)
+        got = set(x.encode() for x in keys_to_text(keys0, k))
+        assert len(got) == len(keys0)
+        extra = got - expect
+        out.update(snv_kmers_expected=len(expect), snv_kmers_found=len(got & expect), not_snv_kmers=len(extra))
+        # (recurrent errors: ~2e-9 per site and base at 30x; allow 25 k-mers for each of 30 such sites per Gb)
+        assert len(extra) <= 25 * 30 * max(1, sys_[0].genome_len // 1_000_000_000), f"{len(extra)} mutant k-mers are no SNV k-mers"
+        if n_pairs * 300 >= 20 * sys_[0].genome_len:      # at >= 20x nearly every SNV k-mer reaches MinCov
+            assert len(got & expect) >= 0.9 * len(expect), f"only {len(got & expect)} of {len(expect)} SNV k-mers found"
+    if more_passes and trio.world == 1:
+        t2 = WgsTrio(ctx, k, trio.size, trio.lower, trio.min_cov, trio.max_cov, trio.thresh, passes=trio.passes + 1)
+        r2 = t2.run(samples)
+        assert r2["n_records"] == res["n_records"] and r2["n_pulled"] == res["n_pulled"]
+        assert np.array_equal(r2["mutant_keys"], keys0)
+        assert all(np.array_equal(a, b) for a, b in zip(r2["histos"], res["histos"]))
+        out["passes_compared"] = [trio.passes, t2.passes]
+    if sample_pairs:
+        n = int(min(sample_pairs, n_pairs))
+        first = (n_pairs - n) // 3
+        seq, _ = sys_[0].text(first, n)
+        want = valid_windows_of_text(seq, k)
+        blk = ctx.synth_reads(sys_[0], first, n, min_q, False, True)
+        t = capi.CountTable(ctx, k, trio.size)
+        try:
+            t.add(blk)
+            rec, h = t.finish(1, want_histo=True)
+            got_w = int(sum(int(x) * i for i, x in enumerate(h)))
+            assert int(h[-1]) == 0 and got_w == want, f"sampled block: {got_w} k-mer instances counted, {want} valid windows"
+            rec.free()
+        finally:
+            t.free()
+            blk.free()
+        out["sampled_block_windows"] = want
+    return out
+
 
 
 def make_sample(ctx: capi.Context, sy: capi.Synth, n_pairs: int, block_pairs: int = 1 << 24, min_q: int = 15,

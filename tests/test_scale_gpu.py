@@ -38,6 +38,45 @@ def test_device_generator_matches_host_twin(ctx, which, first, n_pairs, want_goo
     blk.free()
 
 
+@pytest.mark.parametrize("n_random,k", [(100, 25), (9000, 25), (40000, 25), (100000, 31), (3000, 12)])
+def test_queue_filter_on_compact_blocks(ctx, monkeypatch, n_random, k):
+    """K5 on compact (uniform 150 bp) blocks, every bitmap size / workgroup shape of k_filter_q: per-read hit counts
+    against the oracle's scan (src/RUFUS.Filter.cpp:196-277), and the round-2 kernels and the generic kernel give the
+    same counts.  The set holds EVERY k-mer of some reads, so whole reads are candidates and the per-wave queue
+    overflows and drains in the middle of a read."""
+    sy = capi.Synth.sample(300_000, 0, n_snv=50, seed=99)
+    n_pairs = 5000
+    blk = ctx.synth_reads(sy, 0, n_pairs, MIN_Q, True, True)
+    seq, qual = sy.text(0, n_pairs)
+    reads = [r.tobytes() for r in seq]
+    quals = [q.tobytes() for q in qual]
+    rng = np.random.default_rng(n_random + k)
+    kmers = []
+    for i in rng.integers(0, len(reads), 40):
+        kmers += [reads[i][j:j + k].decode() for j in range(150 - k + 1)]
+    for i in rng.integers(0, len(reads), 400):
+        j = int(rng.integers(0, 150 - k))
+        kmers.append(reads[i][j:j + k].decode())
+    kmers = [x for x in kmers if "N" not in x]
+    kmers += ["".join(rng.choice(list("ACGT"), k)) for _ in range(n_random)]
+    text = ("\n".join(f"{x} 7" for x in kmers) + "\n").encode()
+    fs = oracle.FilterSet(text)
+    mset = capi.MutantSet(ctx, capi.hashlist_keys(text, k), k)
+    for skipped, single in ((True, False), (False, True)):
+        want = np.array([fs.scan(a, b, k, MIN_Q, single_end=single) for a, b in zip(reads, quals)], dtype=np.uint32)
+        hits, mask, nh = mset.filter(blk, 2, skipped)
+        assert np.array_equal(hits, want), np.flatnonzero(hits != want)[:5]
+        bits = tools._mask_bits(mask, len(reads))
+        assert np.array_equal(bits, want >= 2) and nh == int(bits.sum()) and nh > 0
+        for env in ("RFX_FILTER_OLD", "RFX_FILTER_GENERIC"):
+            monkeypatch.setenv(env, "1")
+            hits2, _, _ = mset.filter(blk, 2, skipped)
+            monkeypatch.delenv(env)
+            assert np.array_equal(hits2, want)
+    mset.free()
+    blk.free()
+
+
 def _oracle_trio(sys_, n_pairs, k=K):
     """Oracle records / hash list / pulled pairs of a synthetic trio regenerated as text on the host."""
     fq, recs = [], []
@@ -188,6 +227,49 @@ def test_wgs_slice_properties(ctx):
     sl = [r.tobytes() for r in seq]
     jf = tools.jellyfish_count(ctx, [b"".join(b">r\n" + r + b"\n" for r in sl)], K, SIZE, lower=2)
     assert jf.records.payload() == oracle.count(None, K, SIZE, lower=2, reads=sl).payload()
+    jf.records.free()
+
+
+@pytest.mark.skipif(os.environ.get("RFX_SKIP_FULL") == "1", reason="RFX_SKIP_FULL=1")
+@pytest.mark.parametrize("workload", ["wgs", "tn"])
+def test_full_size_runs_check_themselves(ctx, workload):
+    """BASELINE.json configs[2] (30x trio, 3.1 Gb, 6.2e8 reads per sample, k = 25) and configs[4] (tumor 60x / normal
+    30x, k = 31) at FULL size on the one GPU, planned passes, through wgs.self_check -- the same routine bench.py runs
+    after its timed region: records of every shard verified on the device (strict (pos,key) order, pos = M * key,
+    count >= 2, sum(count) = sum(i * histo[i])), mutant k-mers held by the subject within [MinCov, MaxDepth] and by no
+    control and equal to the planted SNVs' k-mers, S + 1 passes == S passes (record counts, histograms, hash list,
+    pulled pairs), a sampled block's k-mer instances == the ACGT-only windows of the generator's host text; and a
+    40 k-read slice of the subject against the oracle, payload byte for byte."""
+    import torch  # (only for the HBM size)
+    tn = workload == "tn"
+    k = 31 if tn else K
+    G = int(os.environ.get("RFX_FULL_GENOME", 3_100_000_000))
+    covs = [60, 30] if tn else [30, 30, 30]
+    pairs = [G * c // 300 for c in covs]
+    n_snv = max(20, min(1000, G // 3_000_000))
+    sys_ = [capi.Synth.sample(G, w, n_snv=n_snv, seed=12345) for w in range(len(covs))]
+    free0, total = torch.cuda.mem_get_info()
+    used_elsewhere = ctx.mem_stats()["mapped"]          # the arena of this session's ctx is reused, not extra
+    resident = int(sum(pairs) * 2 * 43.2) + pairs[0] * 2 * 20
+    passes = wgs.plan_passes(2 * pairs[0], 150, k, resident + max(0, total - free0 - used_elsewhere), total,
+                             n_samples=len(covs), coverage_hint=covs[0], wide=k > 25)
+    samples = [wgs.make_sample(ctx, sy, n, 1 << 24, MIN_Q, want_good=(i == 0), compact=True)
+               for i, (sy, n) in enumerate(zip(sys_, pairs))]
+    try:
+        trio = wgs.WgsTrio(ctx, k, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes)
+        res = trio.run(samples)
+        chk = wgs.self_check(ctx, trio, samples, sys_, res, pairs[0], MIN_Q)
+        assert chk["order_pos_count_violations"] == 0 and chk["mutant_in_controls"] == 0
+        assert chk["passes_compared"] == [trio.passes, trio.passes + 1]
+        assert res["n_pulled"] > 0 and res["n_mutant"] >= 0.9 * 25 * n_snv
+    finally:
+        for s_ in samples:
+            for b in s_:
+                b.free()
+    seq, _ = sys_[0].text(pairs[0] // 2, 20_000)
+    sl = [r.tobytes() for r in seq]
+    jf = tools.jellyfish_count(ctx, [b"".join(b">r\n" + r + b"\n" for r in sl)], k, SIZE, lower=2)
+    assert jf.records.payload() == oracle.count(None, k, SIZE, lower=2, reads=sl).payload()
     jf.records.free()
 
 

@@ -2724,7 +2724,8 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
   s->ctx = c;
   s->k = k;
   s->n = n;
-  s->bits = std::max(6, ceil_log2(n * 2 + 1));
+  // load below 1/8 (it was 3/8): a wave of the filter waits for the longest probe chain among its candidates
+  s->bits = std::max(6, ceil_log2(n * 8 + 1));
   if (s->bits > 31) {
     snprintf(g_err, sizeof g_err, "rfx_set_build: %llu keys are more than a mutant set holds (2^30)", (unsigned long long)n);
     delete s;
@@ -2772,7 +2773,7 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
     rfxk::set_bitmap(c, dk, n, s->bitmap, s->bm_bits, s->bm_shift);
     if (s->bitmap2) rfxk::set_bitmap_packed(c, dk, n, s->bitmap2);
     if (s->bitmap3) rfxk::set_bitmap_big(c, dk, n, s->bitmap3);
-    if (s->bitmap4) rfxk::set_bitmap_q(c, dk, n, s->bitmap4, s->bm4_bits);
+    if (s->bitmap4) rfxk::set_bitmap_q(c, dk, n, s->bitmap4, s->bm4_bits, k);
     // no synchronisation: upload() staged the keys, everything else is ordered on the ctx stream, and a
     // device error surfaces at the first rfx_filter / rfx_annotate (which wait for their results)
   }
@@ -2803,9 +2804,8 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
   if (n_hit_reads) *n_hit_reads = 0;
   if (r->n == 0) return RFX_OK;
   const uint64_t nmask = ((uint64_t)r->n + 63) / 64;
-  // (the queue filter counts into the array whether the caller wants the counts or not; reads beyond 2^22 bases do not
-  // fit its queue entries)
-  const bool use_q = s->bitmap4 && r->max_len < (1u << 22) && !getenv("RFX_FILTER_GENERIC") && !getenv("RFX_FILTER_OLD");
+  // (the queue filter counts into the array whether the caller wants the counts or not)
+  const bool use_q = s->bitmap4 && !getenv("RFX_FILTER_GENERIC") && !getenv("RFX_FILTER_OLD");
   uint32_t* d_hits = hits_out || use_q ? (uint32_t*)dmalloc(c, (size_t)r->n * 4) : nullptr;
   uint64_t* d_mask = (uint64_t*)dmalloc(c, nmask * 8);
   unsigned long long* d_n = (unsigned long long*)dmalloc(c, 8);

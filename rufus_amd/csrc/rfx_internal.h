@@ -291,7 +291,7 @@ void filter_big(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits
 // k >= 10, <= 2^18 keys: bitmap of 2^16 .. 2^20 bits over a window's last 10 bases (LDS resident), candidates queued per
 // wave and probed by full waves (filter_q_bits: the bitmap's size for a set, 0 = not applicable)
 int filter_q_bits(uint64_t n_keys, int k);
-void set_bitmap_q(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm /* 2^(bm_bits-5) words */, int bm_bits);
+void set_bitmap_q(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm /* 2^(bm_bits-5) words */, int bm_bits, int k);
 void filter_q(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
               int bm_bits, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
               unsigned long long* d_nhit);

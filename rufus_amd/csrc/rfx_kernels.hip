@@ -992,59 +992,96 @@ __global__ __launch_bounds__(FB_BLOCK) void k_filter_big(rfx_reads_view rv, cons
 //     bits above them, so address and bit index are one alignbit + and / shift each: 5 VALU + 1 LDS read per window;
 //     groups of 8 positions where no lane has a fully good window (the first k-1 bases, the tail) are skipped.
 constexpr int FQ_NB = 10;
-constexpr int FQ_QCAP = 256;  // queued candidates per wave
+constexpr int FQ_QCAP = 128;  // queued candidates per wave (12 bytes each: key + read)
 
 __global__ __launch_bounds__(256) void k_set_bitmap_q(const uint64_t* __restrict__ keys, uint64_t n,
-                                                       uint32_t* __restrict__ bm, int bm_bits) {
+                                                       uint32_t* __restrict__ bm, int bm_bits, int two) {
   const uint32_t wmask = (1u << (bm_bits - 5)) - 1;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t key = keys[i];  // first base most significant: the last base is bits [1:0]
     uint32_t ia = 0;
 #pragma unroll
     for (int b = 0; b < FQ_NB; ++b) ia |= (uint32_t)((key >> (2 * b)) & 3u) << (2 * (FQ_NB - 1 - b));  // packed order
-    atomicOr(&bm[ia & wmask], 1u << ((ia >> (bm_bits - 5)) & 31u));
+    uint32_t bitsel = 1u << ((ia >> (bm_bits - 5)) & 31u);
+    // second bit of the same word (k >= 13): chosen by 5 bits of the three bases BEFORE the 10-mer (the kernel takes them
+    // from the stream with one more alignbit): a random window passes both with probability ~1 %, not 4.7 %
+    if (two) {
+      uint32_t ib = 0;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) ib |= (uint32_t)((key >> (2 * (FQ_NB + b))) & 3u) << (2 * (2 - b));  // packed order, 6 bits
+      bitsel |= 1u << (ib >> 1);
+    }
+    atomicOr(&bm[ia & wmask], bitsel);
   }
 }
 
 // 32 bits of the packed base stream (prev word's high half | cur) that start 2 bits below the 10-mer ending at base J
 // of `cur`: bits [2, 2 + bm_bits - 5) are the bitmap word's byte address / 4, the 5 bits above them the bit.
-template <int J>
+template <int J, int BELOW = 2>
 __device__ __forceinline__ uint32_t fq_window(uint32_t p1, uint32_t c0, uint32_t c1) {
-  constexpr int t = 2 * J + 12;  // 32 + 2 (J - 9) - 2, counted from bit 0 of p1
+  constexpr int t = 2 * J + 14 - BELOW;  // 32 + 2 (J - 9) - BELOW, counted from bit 0 of p1
   if (t < 32) return __builtin_amdgcn_alignbit(c0, p1, t);
   if (t == 32) return c0;
   if (t < 64) return __builtin_amdgcn_alignbit(c1, c0, t - 32);
   return c1 >> (t - 64);
 }
 
-template <int G>
+template <int G, bool TWO>
 __device__ __forceinline__ uint32_t fq_group(const uint32_t* s_bm, uint32_t amask, int ishift, uint32_t p1, uint32_t c0,
                                              uint32_t c1, uint32_t cand) {
   uint32_t x[8], w[8];
 #define FQ_X(u) x[u] = fq_window<8 * G + u>(p1, c0, c1)
   FQ_X(0); FQ_X(1); FQ_X(2); FQ_X(3); FQ_X(4); FQ_X(5); FQ_X(6); FQ_X(7);
 #undef FQ_X
+  uint32_t x2[8];
+#define FQ_X2(u) x2[u] = TWO ? fq_window<8 * G + u, 5>(p1, c0, c1) : 0u
+  FQ_X2(0); FQ_X2(1); FQ_X2(2); FQ_X2(3); FQ_X2(4); FQ_X2(5); FQ_X2(6); FQ_X2(7);
+#undef FQ_X2
+  // (the bitmap starts at LDS address 0 -- the kernel checks it --, so the masked window IS the address: going through
+  // the array's symbol costs a v_add_u32 v, 0, v per window that the compiler does not fold)
+  typedef __attribute__((address_space(3))) const uint32_t lds_word;
 #pragma unroll
-  for (int u = 0; u < 8; ++u) w[u] = *(const uint32_t*)((const char*)s_bm + (x[u] & amask));
+  for (int u = 0; u < 8; ++u) w[u] = *(lds_word*)(uintptr_t)(x[u] & amask);
 #pragma unroll
-  for (int u = 0; u < 8; ++u) cand = __builtin_amdgcn_alignbit(w[u] >> ((x[u] >> ishift) & 31u), cand, 1);
+  for (int u = 0; u < 8; ++u) {
+    uint32_t t = w[u] >> ((x[u] >> ishift) & 31u);
+    if (TWO) t &= w[u] >> (x2[u] & 31u);  // (the 5 bits below the 10-mer)
+    cand = __builtin_amdgcn_alignbit(t, cand, 1);
+  }
   return cand;
 }
 
+#ifdef FQ_TIMING
+__device__ unsigned long long g_fq[8];
+}  // namespace
+extern "C" int rfx_debug_fq(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fq), sizeof(g_fq)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fq), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+namespace {
+#endif
 // UW > 0: every read of the (compact) block has UW code words, loaded in one burst.
 // Hit counts go to g_hits (zeroed by the caller) by atomic add -- hits are rare --, so the queue need not be empty when
-// a chunk of reads ends: it is drained when it is full, 256 candidates with all their loads in flight, whichever
-// chunk they came from (entry = chunk turns since the last drain << 28 | lane of the read << 22 | position).
+// a chunk of reads ends: it is drained when it is full, whichever chunk its candidates came from.  An entry is the
+// forward KEY of the window (cut out of the lane's registers when it is queued) + the read: a first version queued
+// (read, position) and let the draining lanes fetch the words again -- by then evicted from L2, a random HBM access per
+// candidate that cost as much as everything else together (43 ms with, 27 ms without the drain at W).
 // k_hits_mask turns the counts into the per-read mask afterwards.
-template <int BLOCK, int UW>
+template <int BLOCK, int UW, bool TWO>
 __global__ __launch_bounds__(BLOCK) void k_filter_q(rfx_reads_view rv, const uint64_t* __restrict__ g_slots, int bits,
                                                      int has_all_ones, const uint32_t* __restrict__ g_bm, int bm_bits,
                                                      int k, int last_base_skipped, uint32_t* __restrict__ g_hits) {
-  extern __shared__ uint32_t s_fq[];  // bitmap | per-wave queues
+#ifdef FQ_TIMING
+  const unsigned long long t_kernel0 = __builtin_amdgcn_s_memtime();
+#endif
+  extern __shared__ uint32_t s_fq[];  // bitmap | per-wave queues: FQ_QCAP keys (64-bit), then FQ_QCAP reads
   const uint32_t bm_words = 1u << (bm_bits - 5);
   const uint32_t wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
   uint32_t* s_bm = s_fq;
-  uint32_t* s_q = s_fq + bm_words + wave * FQ_QCAP;
+  uint64_t* s_qk = (uint64_t*)(s_fq + bm_words) + wave * FQ_QCAP;
+  uint32_t* s_qr = s_fq + bm_words + (BLOCK / WAVE) * FQ_QCAP * 2 + wave * FQ_QCAP;
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_fq != 0u) __builtin_trap();  // see fq_group
   for (uint32_t i = threadIdx.x; i < bm_words; i += BLOCK) s_bm[i] = g_bm[i];
   __syncthreads();
   const uint32_t amask = (bm_words - 1) << 2;
@@ -1052,59 +1089,65 @@ __global__ __launch_bounds__(BLOCK) void k_filter_q(rfx_reads_view rv, const uin
   const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
   const uint32_t smask = (1u << bits) - 1;
   const uint32_t n_chunks = (rv.n + BLOCK - 1) / BLOCK;
-  uint32_t qn = 0, it_base = 0;  // wave-uniform
-  // the queued candidates, four per lane at a time: cut the window out of the packed read, probe the set exactly
-  auto drain = [&](uint32_t it_now) {
+  uint32_t qn = 0;  // wave-uniform
+  // the queued candidates, two per lane at a time: probe the set exactly
+  auto drain = [&]() {
+#ifdef FQ_TIMING
+    const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+    const uint32_t qn0 = qn;
+#endif
+#ifndef FQ_NOFENCE
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t b0 = 0; b0 < qn; b0 += 4 * WAVE) {
-      uint64_t cur_c[4], prev_c[4], fwd[4], got[4];
-      uint32_t rr[4], pj[4], sl[4];
-      bool ok[4];
+#endif
+    for (uint32_t b0 = 0; b0 < qn; b0 += 2 * WAVE) {
+      // Two entries per lane, two adjacent slots of each in flight.  What a drain costs is its SLOWEST lane: a wave waits
+      // out one L2 round trip per probe step of the longest chain among its 128 entries (at the load of 0.375 the set
+      // used to have that was 6 - 8 steps = 5 us per drain, half the kernel); the set now keeps its load below 1/8.
+      uint64_t fwd[2], g0[2], g1[2];
+      uint32_t rr[2], sl[2];
+      bool ok[2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 2; ++u) {
         const uint32_t idx = b0 + (uint32_t)u * WAVE + lane;
         ok[u] = idx < qn;
-        const uint32_t e = ok[u] ? s_q[idx] : 0u;
-        rr[u] = (blockIdx.x + (it_base + (e >> 28)) * gridDim.x) * BLOCK + wave * WAVE + ((e >> 22) & 63u);
-        const uint32_t pos = e & 0x3FFFFFu;
-        pj[u] = pos & 31u;
-        const uint32_t off = ok[u] ? rv_off(rv, rr[u]) + (pos >> 5) : 0u;
-        cur_c[u] = ok[u] ? rv.codes[off] : 0ull;
-        prev_c[u] = ok[u] && (pos >> 5) ? rv.codes[off - 1] : 0ull;
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int sh = 2 * ((int)pj[u] - k + 1) + 64;  // 2 .. 126
-        const uint64_t packed = sh >= 64 ? cur_c[u] >> (sh - 64) : (prev_c[u] >> sh) | (cur_c[u] << (64 - sh));
-        uint64_t y = __brevll(packed);  // 2-bit groups reversed: the forward key, first base most significant
-        y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
-        fwd[u] = (k == 32 ? y : y >> (64 - 2 * k)) & kmask;
+        fwd[u] = ok[u] ? s_qk[idx] : 0ull;
+        rr[u] = ok[u] ? s_qr[idx] : 0u;
         sl[u] = set_hash(fwd[u], bits);
-        got[u] = ok[u] ? g_slots[sl[u]] : RFX_EMPTY;
+        g0[u] = ok[u] ? g_slots[sl[u]] : RFX_EMPTY;
+        g1[u] = ok[u] ? g_slots[(sl[u] + 1) & smask] : RFX_EMPTY;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 2; ++u) {
         if (!ok[u]) continue;
         bool hit;
         if (fwd[u] == RFX_EMPTY) {
           hit = has_all_ones != 0;
         } else {
-          uint64_t v = got[u];
+          uint64_t v0 = g0[u], v1 = g1[u];
           uint32_t q = sl[u];
-          while (v != fwd[u] && v != RFX_EMPTY) {  // (linear probing: rarely more than the first slot)
-            q = (q + 1) & smask;
-            v = g_slots[q];
+          while (v0 != fwd[u] && v0 != RFX_EMPTY && v1 != fwd[u] && v1 != RFX_EMPTY) {  // (rare)
+            q = (q + 2) & smask;
+            v0 = g_slots[q];
+            v1 = g_slots[(q + 1) & smask];
           }
-          hit = v == fwd[u];
+          hit = v0 == fwd[u] || (v0 != RFX_EMPTY && v1 == fwd[u]);
         }
         if (hit) atomicAdd(&g_hits[rr[u]], 1u);
       }
     }
+#ifndef FQ_NOFENCE
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+#endif
     qn = 0;
-    it_base = it_now;
+#ifdef FQ_TIMING
+    if (lane == 0) {
+      atomicAdd(&g_fq[0], __builtin_amdgcn_s_memtime() - tq0);
+      atomicAdd(&g_fq[1], 1ull);
+      atomicAdd(&g_fq[2], (unsigned long long)qn0);
+    }
+#endif
   };
   uint64_t ncv[UW > 0 ? UW : 1];
   uint32_t ngv[UW > 0 ? UW : 1];
@@ -1119,13 +1162,13 @@ __global__ __launch_bounds__(BLOCK) void k_filter_q(rfx_reads_view rv, const uin
     }
   };
   if (UW > 0) load_ahead(blockIdx.x);
-  uint32_t it = 0;
-  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x, ++it) {
-    if (it - it_base == 15u) drain(it);
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t r = chunk * BLOCK + wave * WAVE + lane;
     const bool live = r < rv.n;
-    // one code word + its good mask: V = "a fully good window ends here", bitmap bit per position, queue the rest
-    auto word = [&](uint32_t wi, uint64_t prev_c, uint64_t cur_c, uint32_t prev_g, uint32_t cur_g) {
+    // (before the next chunk's loads are issued: a drain waits for everything in flight)
+    if (qn >= (uint32_t)FQ_QCAP / 2) drain();
+    // one code word + its good mask: V = "a fully good window ends here", bitmap bit(s) per position, queue the rest
+    auto word = [&](uint64_t prev_c, uint64_t cur_c, uint32_t prev_g, uint32_t cur_g) {
       const uint64_t X = ((uint64_t)cur_g << 32) | prev_g;
       uint64_t acc = ~0ull, run = X;
       int off = 0;
@@ -1139,25 +1182,32 @@ __global__ __launch_bounds__(BLOCK) void k_filter_q(rfx_reads_view rv, const uin
       const uint32_t V = (uint32_t)(acc >> 32);
       const uint32_t p1 = (uint32_t)(prev_c >> 32), c0 = (uint32_t)cur_c, c1 = (uint32_t)(cur_c >> 32);
       uint32_t cand = 0;
-      if (__ballot((V & 0x000000FFu) != 0)) cand = fq_group<0>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
-      if (__ballot((V & 0x0000FF00u) != 0)) cand = fq_group<1>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
-      if (__ballot((V & 0x00FF0000u) != 0)) cand = fq_group<2>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
-      if (__ballot((V & 0xFF000000u) != 0)) cand = fq_group<3>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
+      if (__ballot((V & 0x000000FFu) != 0)) cand = fq_group<0, TWO>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
+      if (__ballot((V & 0x0000FF00u) != 0)) cand = fq_group<1, TWO>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
+      if (__ballot((V & 0x00FF0000u) != 0)) cand = fq_group<2, TWO>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
+      if (__ballot((V & 0xFF000000u) != 0)) cand = fq_group<3, TWO>(s_bm, amask, ishift, p1, c0, c1, cand); else cand >>= 8;
       cand &= V;
 #ifdef FQ_NOPUSH  // experiment: what the lookups alone cost
-      if (cand == 0x12345678u && V == 0x9ABCDEF0u) s_q[0] = cand;
+      if (cand == 0x12345678u && V == 0x9ABCDEF0u) s_qr[0] = cand;
       cand = 0;
 #endif
       for (;;) {
         const unsigned long long act = __ballot(cand != 0);
         if (!act) break;
         const uint32_t cnt = (uint32_t)__popcll(act);
-        if (qn + cnt > (uint32_t)FQ_QCAP) drain(it);
+        if (qn + cnt > (uint32_t)FQ_QCAP) drain();
         if (cand) {
-          const uint32_t j = (uint32_t)__ffs(cand) - 1u;
+          const int j = __ffs(cand) - 1;
           cand &= cand - 1u;
+          // window = bases j-k+1 .. j of (prev word, this word): one 128-bit shift, then the 2-bit groups reversed to
+          // get the forward key (first base most significant)
+          const int sh = 2 * (j - k + 1) + 64;  // 2 .. 126
+          const uint64_t packed = sh >= 64 ? cur_c >> (sh - 64) : (prev_c >> sh) | (cur_c << (64 - sh));
+          uint64_t y = __brevll(packed);
+          y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
           const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
-          s_q[slot] = ((it - it_base) << 28) | (lane << 22) | (wi * 32u + j);
+          s_qk[slot] = (k == 32 ? y : y >> (64 - 2 * k)) & kmask;
+          s_qr[slot] = r;
         }
         qn += cnt;
       }
@@ -1179,7 +1229,7 @@ __global__ __launch_bounds__(BLOCK) void k_filter_q(rfx_reads_view rv, const uin
         uint32_t g = gv[i];
         if (stop < lo + 32u) g = stop > lo ? g & ((1u << (stop - lo)) - 1u) : 0u;
         gv[i] = g;
-        word((uint32_t)i, i ? cv[i - 1] : 0ull, cv[i], i ? gv[i - 1] : 0u, g);
+        word(i ? cv[i - 1] : 0ull, cv[i], i ? gv[i - 1] : 0u, g);
       }
     } else {
       const uint32_t wr = live ? rv_off(rv, r) : 0u;
@@ -1195,13 +1245,19 @@ __global__ __launch_bounds__(BLOCK) void k_filter_q(rfx_reads_view rv, const uin
         uint32_t cur_g = wi < nw ? rv.good[wr + wi] : 0u;
         const uint32_t lo = wi << 5;
         if (stop < lo + 32u) cur_g = stop > lo ? cur_g & ((1u << (stop - lo)) - 1u) : 0u;
-        word(wi, prev_c, cur_c, prev_g, cur_g);
+        word(prev_c, cur_c, prev_g, cur_g);
         prev_c = cur_c;
         prev_g = cur_g;
       }
     }
   }
-  if (qn) drain(it);
+  if (qn) drain();
+#ifdef FQ_TIMING
+  if (lane == 0) {
+    atomicAdd(&g_fq[3], __builtin_amdgcn_s_memtime() - t_kernel0);
+    atomicAdd(&g_fq[4], 1ull);
+  }
+#endif
 }
 
 // per-read hit counts -> one bit per read (count >= thresh) and the number of such reads
@@ -1451,6 +1507,11 @@ void filter_big(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int
                      thresh, last_base_skipped, hits, hitmask, d_nhit);
 }
 
+static int filter_q_two(int k) {  // two bits per key in the bitmap word (RFX_FQ_ONE=1: one, for A/B runs)
+  static const bool one = getenv("RFX_FQ_ONE") != nullptr;
+  return k >= FQ_NB + 3 && !one;
+}
+
 int filter_q_bits(uint64_t n_keys, int k) {  // 0: the queue filter does not apply
   if (k < FQ_NB || n_keys > (1u << 18)) return 0;
   // Small sets: <= 1.5 % of the bits set, 8 .. 32 KB of LDS, many small workgroups.  Beyond 4096 keys always 2^20 bits
@@ -1462,10 +1523,11 @@ int filter_q_bits(uint64_t n_keys, int k) {  // 0: the queue filter does not app
   return b;
 }
 
-void set_bitmap_q(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* bm, int bm_bits) {
+void set_bitmap_q(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* bm, int bm_bits, int k) {
   if (n == 0) return;
   rfx_span sp(c, "k_set_bitmap");
-  hipLaunchKernelGGL(k_set_bitmap_q, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, bm, bm_bits);
+  hipLaunchKernelGGL(k_set_bitmap_q, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, bm, bm_bits,
+                     filter_q_two(k));
 }
 
 void filter_q(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
@@ -1473,17 +1535,22 @@ void filter_q(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int b
               uint64_t* hitmask, unsigned long long* d_nhit) {
   if (rv.n == 0) return;
   const int block = bm_bits >= 20 ? 1024 : bm_bits == 19 ? 512 : 256;
-  const size_t lds = ((size_t)(1u << (bm_bits - 5)) + (size_t)(block / WAVE) * FQ_QCAP) * 4;
+  const size_t lds = ((size_t)(1u << (bm_bits - 5)) + (size_t)(block / WAVE) * FQ_QCAP * 3) * 4;
   const int per_cu = std::max<int>(1, std::min<int>(2048 / block, (int)((160 * 1024) / lds)));
   const uint32_t chunks = (rv.n + block - 1) / block;
   const int grid = (int)std::min<uint32_t>(chunks, (uint32_t)c->n_cu * per_cu);  // the resident workgroups
   const bool u5 = rv.ulen && rv.uwpr == 5;
   rfx_span sp(c, "k_filter");
-#define RFX_FQ(BLOCK, UW, BIT)                                                                                        \
-  do {                                                                                                                \
-    if (lds > 64 * 1024 && !rfxi::lds_opt_in(c, (const void*)k_filter_q<BLOCK, UW>, lds, BIT, "k_filter_q")) return;  \
-    hipLaunchKernelGGL((k_filter_q<BLOCK, UW>), dim3(grid), dim3(BLOCK), lds, c->stream, rv, slots, bits,            \
-                       has_all_ones, bm, bm_bits, k, last_base_skipped, hits);                                       \
+#define RFX_FQ2(BLOCK, UW, TWO, BIT)                                                                                       \
+  do {                                                                                                                     \
+    if (lds > 64 * 1024 && !rfxi::lds_opt_in(c, (const void*)k_filter_q<BLOCK, UW, TWO>, lds, BIT, "k_filter_q")) return;  \
+    hipLaunchKernelGGL((k_filter_q<BLOCK, UW, TWO>), dim3(grid), dim3(BLOCK), lds, c->stream, rv, slots, bits,            \
+                       has_all_ones, bm, bm_bits, k, last_base_skipped, hits);                                            \
+  } while (0)
+#define RFX_FQ(BLOCK, UW, BIT)                 \
+  do {                                         \
+    if (filter_q_two(k)) RFX_FQ2(BLOCK, UW, true, BIT); \
+    else RFX_FQ2(BLOCK, UW, false, BIT + 6);    \
   } while (0)
   if (block == 1024) {
     if (u5) RFX_FQ(1024, 5, 6);
@@ -1496,6 +1563,7 @@ void filter_q(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int b
     else RFX_FQ(256, 0, 11);
   }
 #undef RFX_FQ
+#undef RFX_FQ2
   hipLaunchKernelGGL(k_hits_mask, dim3(grid_for(c, rv.n, 256, 8)), dim3(256), 0, c->stream, hits, rv.n, thresh, hitmask,
                      d_nhit);
 }

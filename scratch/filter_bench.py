@@ -25,4 +25,11 @@ for tag in range(REPS):
         hits += nh
     ctx.sync(); dt = time.perf_counter() - t0
     ms = ctx.prof_dict()["k_filter"][0]
+    if os.environ.get("FQ_TIMING"):
+        import ctypes as C
+        buf = (C.c_ulonglong * 8)()
+        capi.lib().rfx_debug_fq.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+        capi.lib().rfx_debug_fq(buf, 1)
+        v = list(buf)
+        print(f"   drain: {v[1]} calls, {v[2]} entries, {v[0] / max(v[1], 1):.0f} memtime ticks per call; kernel {v[3] / max(v[4], 1):.0f} ticks per wave, {v[4]} waves; drain share {v[0] / max(v[3], 1):.3f}")
     print(f"{os.environ.get('TAG','')} reads {n_reads} keys {2*NK}: k_filter {ms:.2f} ms ({61*n_reads/ms/1e9*1e3/8000:.3f} of 8 TB/s), wall {dt*1e3:.0f} ms, hit reads {hits}", flush=True)

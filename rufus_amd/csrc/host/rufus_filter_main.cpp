@@ -21,7 +21,415 @@
 
 using namespace rfxcli;
 
+#ifndef RFX_SINGLE_END
+#include "rfx_sam.hpp"
+// ---- RUFUS.Filter --sam CHRFILE HashList SAM|stdin STUB K MinQ HashCountThreshold Threads -----------------------------
+// SURVEY row N1, filter half.  runRufus.sh:964-967 runs `generator | PassThroughSamCheck.stranded CHR STUB.temp` into two
+// named pipes that RUFUS.Filter reads in lock step: SAM text -> pairing by QNAME -> FASTQ text -> two pipes -> parsed
+// again -> packed.  Here the SAM stream is the filter's own input: helper threads find the fields of every line, put
+// reverse-strand records back the way the feeder prints them (src/PassThroughSamCheck.stranded.cpp:188-223: reverse
+// complement, bases other than ACGTN vanish, quality reversed), pack bases + quality mask and run the scan on EVERY
+// record by itself (k_filter; `i < length()-1` as the paired tool, src/RUFUS.Filter.cpp:203); one thread then walks
+// the pieces in stream order, writes the chromosome log (CHRFILE: "notachr", then the previous RNAME at every change)
+// and pairs the records by name as the feeder does -- a record meets its waiting mate or waits -- and a pair one of
+// whose records was hit is written: the LATER record to STUB.Mutations.Mate1.fastq, the stored one to Mate2, in the
+// order the pairs complete.  The same bytes as the two-process route; no FASTQ text exists for the other pairs.
+// A waiting record is a pointer into its piece (no copy); a piece is recycled LAG pieces later, and only the few
+// records that still wait then (mates far apart, unpaired reads) are copied out.
+namespace samf {
+using namespace rfxsam;
+
+struct Rec {
+  const char *name, *seq, *qual;
+  uint32_t name_len, seq_len, qual_len;
+  uint64_t hash;
+};
+struct SPiece {
+  std::vector<char> text;  // [0, size): SAM lines; behind them the printed form of reverse-strand records
+  size_t size = 0;
+  std::vector<Rec> recs;
+  std::vector<std::string> chr_runs;
+  std::vector<uint64_t> mask;  // hit bit per record
+  std::vector<uint32_t> waited;  // records of this piece that went into the waiting table
+  uint64_t seq = 0;
+};
+struct Owned {
+  Rec r;
+  std::string bytes;
+};
+struct Slot {
+  uint64_t hash = 0;
+  const Rec* rec = nullptr;
+  Owned* owned = nullptr;
+  uint32_t state = 0;  // 0 empty, 1 deleted, 2 live
+  uint32_t hit = 0;
+};
+struct WaitTable {
+  std::vector<Slot> slot;
+  size_t used = 0, filled = 0;
+  WaitTable() : slot(1 << 14) {}
+  void rehash(size_t n) {
+    std::vector<Slot> old;
+    old.swap(slot);
+    slot.assign(n, Slot());
+    filled = used;
+    for (const Slot& s : old)
+      if (s.state == 2) {
+        size_t j = (size_t)s.hash & (n - 1);
+        while (slot[j].state) j = (j + 1) & (n - 1);
+        slot[j] = s;
+      }
+  }
+  long find(uint64_t h, const char* name, size_t n) const {
+    const size_t mask = slot.size() - 1;
+    for (size_t j = (size_t)h & mask;; j = (j + 1) & mask) {
+      const Slot& s = slot[j];
+      if (s.state == 0) return -1;
+      if (s.state == 2 && s.hash == h && s.rec->name_len == n && memcmp(s.rec->name, name, n) == 0) return (long)j;
+    }
+  }
+  void insert(const Rec* r, uint32_t hit) {
+    if ((filled + 1) * 2 > slot.size()) rehash(used * 4 > slot.size() ? slot.size() * 2 : slot.size());
+    const size_t mask = slot.size() - 1;
+    size_t j = (size_t)r->hash & mask;
+    while (slot[j].state == 2) j = (j + 1) & mask;
+    if (slot[j].state == 0) ++filled;
+    slot[j].hash = r->hash;
+    slot[j].rec = r;
+    slot[j].owned = nullptr;
+    slot[j].state = 2;
+    slot[j].hit = hit;
+    ++used;
+  }
+  void erase(long j) {
+    delete slot[(size_t)j].owned;
+    slot[(size_t)j].owned = nullptr;
+    slot[(size_t)j].state = 1;
+    --used;
+  }
+};
+
+static int run(int argc, char** argv) {
+  printf("Call is --sam CHRFILE PreBuiltMutHash SAM|stdin firstpassfile hashsize MinQ HashCountThreshold threads\n");
+  if (argc < 10) {
+    printf("ERROR: expected 9 arguments\n");
+    return 0;
+  }
+  const char* chr_path = argv[2];
+  const char* hashlist = argv[3];
+  const char* sam = argv[4];
+  const std::string stub = argv[5];
+  const int k = atoi(argv[6]), min_q = atoi(argv[7]), thresh = atoi(argv[8]);
+  std::string text;
+  {
+    std::ifstream f(hashlist, std::ios::binary);
+    if (!f.is_open()) {
+      printf("Error, ParentHashFile could not be opened");
+      return 0;
+    }
+    text.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  }
+  const int fd = strcmp(sam, "stdin") == 0 || strcmp(sam, "/dev/stdin") == 0 || strcmp(sam, "-") == 0 ? 0 : ::open(sam, O_RDONLY);
+  if (fd < 0) {
+    printf("Error, MutFile could not be opened");
+    return 0;
+  }
+  FILE* chr = fopen(chr_path, "w");
+  std::ofstream out1((stub + ".Mutations.Mate1.fastq").c_str(), std::ios::binary);
+  std::ofstream out2((stub + ".Mutations.Mate2.fastq").c_str(), std::ios::binary);
+  if (!chr || !out1.is_open() || !out2.is_open()) {
+    printf("ERROR, Output file could not be opened -%s\n", stub.c_str());
+    return 0;
+  }
+  if (k < 1 || k > 32) die("rufus_amd RUFUS.Filter: hash size must be 1..32");
+  const long nk = rfx_hashlist_keys(text.data(), text.size(), k, 0, nullptr, 0);
+  if (nk < 0) die("rufus_amd: cannot parse the hash list");
+  std::vector<uint64_t> keys((size_t)nk + 1);
+  rfx_hashlist_keys(text.data(), text.size(), k, 0, keys.data(), keys.size());
+  printf("\nDone Hash Files\n\t Mutations Hash size is %ld\n", nk);
+  rfx_ctx* ctx = open_ctx();
+  rfx_set* set = rfx_set_build(ctx, keys.data(), (uint64_t)nk, k);
+  if (!set) die(std::string("rufus_amd: ") + rfx_last_error());
+  trace("filter --sam: device open, set built");
+#ifdef F_SETPIPE_SZ
+  (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);
+#endif
+
+  unsigned helpers = (unsigned)std::max(1, atoi(argv[9]));
+  helpers = std::min(helpers, rfx_host_cpus() > 2 ? rfx_host_cpus() - 2 : 1u);
+  if (const char* ev = getenv("RFX_HOST_THREADS")) helpers = (unsigned)std::max(1, atoi(ev));
+  size_t PIECE = 32u << 20;
+  if (const char* ev = getenv("RFX_INGEST_PIECE")) PIECE = (size_t)std::max(1024, atoi(ev));
+  const size_t LAG = 3;
+  const size_t MAX_IN_FLIGHT = 2 * (size_t)helpers + 2 + LAG;
+
+  std::mutex mu, dev_mu;
+  std::condition_variable cv;
+  std::deque<SPiece*> todo, spare;
+  std::map<uint64_t, SPiece*> done;
+  bool input_end = false;
+  uint64_t n_pieces = 0;
+  size_t in_flight = 0;
+  std::thread reader([&] {
+    std::vector<char> carry;
+    bool eof = false;
+    while (!eof) {
+      SPiece* pc = nullptr;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return in_flight < MAX_IN_FLIGHT; });
+        if (!spare.empty()) { pc = spare.front(); spare.pop_front(); }
+        ++in_flight;
+      }
+      if (!pc) pc = new SPiece();
+      size_t fill = carry.size();
+      if (pc->text.size() < fill + PIECE + (1u << 20)) pc->text.resize(fill + PIECE + (1u << 20));
+      memcpy(pc->text.data(), carry.data(), fill);
+      carry.clear();
+      bool have_nl = fill && memchr(pc->text.data(), '\n', fill);
+      while (fill < PIECE || !have_nl) {  // at least PIECE bytes AND one line end
+        if (fill == pc->text.size()) pc->text.resize(fill * 2);
+        // (a recycled buffer is three pieces long -- the room for the printed forms: a regular file would fill it)
+        const size_t room = pc->text.size() - fill, want_more = fill < PIECE ? PIECE + (1u << 20) - fill : (size_t)1 << 20;
+        const ssize_t n = ::read(fd, pc->text.data() + fill, std::min(room, want_more));
+        if (n < 0 && errno == EINTR) continue;
+        if (n < 0) die(std::string("read error on input: ") + strerror(errno));
+        if (n == 0) { eof = true; break; }
+        if (!have_nl && memchr(pc->text.data() + fill, '\n', (size_t)n)) have_nl = true;
+        fill += (size_t)n;
+      }
+      size_t cut = fill;
+      if (!eof) {
+        while (cut > 0 && pc->text[cut - 1] != '\n') --cut;
+        carry.assign(pc->text.data() + cut, pc->text.data() + fill);
+      }
+      pc->size = cut;
+      // room behind the lines for the printed form of every record (reverse strand: its bases and qualities again;
+      // a quality string shorter than its read: a padded copy)
+      if (pc->text.size() < 3 * cut + 64) pc->text.resize(3 * cut + 64);
+      std::lock_guard<std::mutex> g(mu);
+      pc->seq = n_pieces++;
+      todo.push_back(pc);
+      cv.notify_all();
+    }
+    std::lock_guard<std::mutex> g(mu);
+    input_end = true;
+    cv.notify_all();
+  });
+
+  auto helper = [&]() {
+    struct Pinned {
+      void* p = nullptr;
+      size_t cap = 0;
+      void* need(size_t bytes) {
+        if (bytes > cap) {
+          if (p) rfx_host_free(p);
+          cap = bytes + bytes / 4;
+          p = rfx_host_alloc(cap);
+          if (!p) die("rufus_amd: cannot allocate pinned staging memory");
+        }
+        return p;
+      }
+      ~Pinned() { if (p) rfx_host_free(p); }
+    } pin_codes, pin_good, pin_woff, pin_lens;
+    std::vector<uint64_t> so, qo;
+    std::vector<uint32_t> sl;
+    std::string rs, rq;
+    Field f[11];
+    for (;;) {
+      SPiece* pcp;
+      {
+        std::unique_lock<std::mutex> g(mu);
+        cv.wait(g, [&] { return !todo.empty() || input_end; });
+        if (todo.empty()) return;
+        pcp = todo.front();
+        todo.pop_front();
+      }
+      SPiece& pc = *pcp;
+      pc.recs.clear();
+      pc.chr_runs.clear();
+      pc.waited.clear();
+      char* base = pc.text.data();
+      const char *p = base, *e = base + pc.size;
+      char* side = base + pc.size;  // printed forms go here
+      const char* cur = nullptr;
+      size_t cur_len = 0;
+      uint64_t words = 0;
+      while (p < e) {
+        const char* nl = find_nl(p, e);
+        const char* le = nl ? nl : e;
+        if (split_sam(p, le, f)) {  // fewer than 11 fields: skipped, as the feeders do
+          if (!cur || f[2].n != cur_len || memcmp(f[2].p, cur, cur_len) != 0) {
+            pc.chr_runs.emplace_back(f[2].p, f[2].n);
+            cur = f[2].p;
+            cur_len = f[2].n;
+          }
+          Rec r;
+          r.name = f[0].p; r.name_len = (uint32_t)f[0].n;
+          r.seq = f[9].p; r.seq_len = (uint32_t)f[9].n;
+          r.qual = f[10].p; r.qual_len = (uint32_t)f[10].n;
+          if (sam_flag(f[1]) & 16) {
+            revcomp_into(rs, f[9]);
+            reverse_into(rq, f[10]);
+            memcpy(side, rs.data(), rs.size());
+            memcpy(side + rs.size(), rq.data(), rq.size());
+            r.seq = side; r.seq_len = (uint32_t)rs.size();
+            r.qual = side + rs.size(); r.qual_len = (uint32_t)rq.size();
+            side += rs.size() + rq.size();
+          }
+          r.hash = name_hash(r.name, r.name_len);
+          words += (r.seq_len + 31) / 32;
+          pc.recs.push_back(r);
+        }
+        p = nl ? nl + 1 : e;
+      }
+      const size_t n = pc.recs.size();
+      pc.mask.assign((n + 63) / 64, 0);
+      if (n) {
+        so.resize(n); qo.resize(n); sl.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+          const Rec& r = pc.recs[i];
+          so[i] = (uint64_t)(r.seq - base);
+          sl[i] = r.seq_len;
+          if (r.qual_len >= r.seq_len) {
+            qo[i] = (uint64_t)(r.qual - base);
+          } else {  // a quality string shorter than its read: the missing characters are bad ('\0'), as in the file route
+            memcpy(side, r.qual, r.qual_len);
+            memset(side + r.qual_len, 0, r.seq_len - r.qual_len);
+            qo[i] = (uint64_t)(side - base);
+            side += r.seq_len;
+          }
+        }
+        uint64_t* codes = (uint64_t*)pin_codes.need((words + 1) * 8);
+        uint32_t* good = (uint32_t*)pin_good.need((words + 1) * 4);
+        uint32_t* woff = (uint32_t*)pin_woff.need((n + 1) * 4);
+        uint32_t* lens = (uint32_t*)pin_lens.need((n + 1) * 4);
+        woff[0] = 0;
+        if (rfx_pack_spans(base, so.data(), sl.data(), qo.data(), (uint32_t)n, min_q, RFX_PACK_FILTER, codes, nullptr, good,
+                           woff, lens) != RFX_OK)
+          die("rufus_amd: pack failed");
+        std::lock_guard<std::mutex> g(dev_mu);
+        rfx_reads* rd = rfx_reads_upload(ctx, codes, nullptr, good, woff, lens, (uint32_t)n);
+        if (!rd) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
+        uint64_t nh = 0;
+        const int rc = rfx_filter(set, rd, thresh, 1, nullptr, pc.mask.data(), &nh);
+        rfx_reads_free(rd);
+        if (rc) die(std::string("rufus_amd: filter failed: ") + rfx_last_error());
+      }
+      std::lock_guard<std::mutex> g(mu);
+      done[pc.seq] = pcp;
+      cv.notify_all();
+    }
+  };
+  std::vector<std::thread> workers;
+  for (unsigned t = 0; t < helpers; ++t) workers.emplace_back(helper);
+
+  WaitTable waiting;
+  std::deque<SPiece*> live;
+  std::string current = "notachr", o1, o2;
+  unsigned long long n_rec = 0, n_pairs = 0, n_found = 0;
+  auto put_text = [](std::string& o, const char* name, size_t nn, const char* seq, size_t ls, const char* qual, size_t lq) {
+    o.push_back('@');
+    o.append(name, nn);
+    o.push_back('\n');
+    o.append(seq, ls);
+    o.append("\n+\n", 3);
+    o.append(qual, lq);
+    o.push_back('\n');
+  };
+  auto retire = [&](SPiece* pc) {  // what still waits from this piece leaves it
+    for (uint32_t idx : pc->waited) {
+      const Rec* r = &pc->recs[idx];
+      const long at = waiting.find(r->hash, r->name, r->name_len);
+      if (at < 0 || waiting.slot[(size_t)at].rec != r) continue;
+      Owned* o = new Owned();
+      o->bytes.assign(r->name, r->name_len);
+      o->bytes.append(r->seq, r->seq_len);
+      o->bytes.append(r->qual, r->qual_len);
+      o->r = *r;
+      o->r.name = o->bytes.data();
+      o->r.seq = o->bytes.data() + r->name_len;
+      o->r.qual = o->bytes.data() + r->name_len + r->seq_len;
+      waiting.slot[(size_t)at].rec = &o->r;
+      waiting.slot[(size_t)at].owned = o;
+    }
+    std::lock_guard<std::mutex> g(mu);
+    spare.push_back(pc);
+    --in_flight;
+    cv.notify_all();
+  };
+  for (uint64_t want = 0;; ++want) {
+    SPiece* pc;
+    {
+      std::unique_lock<std::mutex> g(mu);
+      cv.wait(g, [&] { return done.count(want) || (input_end && want >= n_pieces); });
+      if (!done.count(want)) break;
+      pc = done[want];
+      done.erase(want);
+    }
+    for (const std::string& name : pc->chr_runs)
+      if (name != current) {
+        fprintf(chr, "%s\n", current.c_str());
+        current = name;
+      }
+    const size_t n = pc->recs.size();
+    for (size_t i = 0; i < n; ++i) {
+      const Rec& r = pc->recs[i];
+      const uint32_t hit = (uint32_t)((pc->mask[i >> 6] >> (i & 63)) & 1);
+      const long at = waiting.find(r.hash, r.name, r.name_len);
+      if (at < 0) {
+        waiting.insert(&r, hit);
+        pc->waited.push_back((uint32_t)i);
+      } else {
+        const Slot& s = waiting.slot[(size_t)at];
+        // (the later record is mate 1 of the pair: the paired tool rejects an empty mate-1 sequence line)
+        if (r.seq_len == 0)
+          die("rufus_amd RUFUS.Filter: empty sequence line (undefined behaviour in the reference) -- rejected");
+        if (hit | s.hit) {
+          put_text(o1, r.name, r.name_len, r.seq, r.seq_len, r.qual, r.qual_len);
+          put_text(o2, r.name, r.name_len, s.rec->seq, s.rec->seq_len, s.rec->qual, s.rec->qual_len);
+          ++n_found;
+        }
+        ++n_pairs;
+        waiting.erase(at);
+      }
+    }
+    n_rec += n;
+    if (!o1.empty()) {
+      out1.write(o1.data(), (std::streamsize)o1.size());
+      out2.write(o2.data(), (std::streamsize)o2.size());
+      o1.clear();
+      o2.clear();
+    }
+    live.push_back(pc);
+    if (live.size() > LAG) {
+      retire(live.front());
+      live.pop_front();
+    }
+    printf("Read in %llu lines: Found %llu \r", n_pairs * 4, n_found);
+  }
+  while (!live.empty()) {
+    retire(live.front());
+    live.pop_front();
+  }
+  fprintf(chr, "%s\n", current.c_str());
+  fclose(chr);
+  reader.join();
+  for (auto& w : workers) w.join();
+  trace("filter --sam: all pieces done");
+  printf("\nSAM records %llu, pairs %llu, pulled %llu\n", n_rec, n_pairs, n_found);
+  rfx_set_free(set);
+  rfx_close(ctx);
+  printf("\nDone running RUFUS.Filter.cpp\n");
+  return 0;
+}
+}  // namespace samf
+#endif
+
 int main(int argc, char** argv) {
+#ifndef RFX_SINGLE_END
+  if (argc > 1 && strcmp(argv[1], "--sam") == 0) return samf::run(argc, argv);
+#endif
 #ifdef RFX_SINGLE_END
   const int need = 8;
   printf("Call is PreBuiltMutHash Mutant.fq|stdin firstpassfile hashsize MinQ HashCountThreshold threads\n");

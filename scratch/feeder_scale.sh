@@ -27,6 +27,16 @@ PY
 rm -f p.mate1.fastq p.mate2.fastq; mkfifo p.mate1.fastq p.mate2.fastq
 s=$(date +%s.%N); ($BIN/PassThroughSamCheck.stranded y.chr p < in.sam &); $BIN/RUFUS.Filter hl p.mate1.fastq p.mate2.fastq out 25 15 1 64 > log.txt; e=$(date +%s.%N)
 python3 -c "print('feeder | RUFUS.Filter (both drop-in, named pipes): %.2f s = %.1f M reads/s' % ($e-$s, 2*$PAIRS/($e-$s)/1e6))"; wc -l out.Mutations.Mate1.fastq
+cp out.Mutations.Mate1.fastq two.m1; cp out.Mutations.Mate2.fastq two.m2
+for src in file pipe; do
+  s=$(date +%s.%N)
+  if [ $src = file ]; then RFX_CLI_TRACE=1 $BIN/RUFUS.Filter --sam s.chr hl in.sam sam 25 15 1 64 > log2.txt 2> trace.txt
+  else cat in.sam | $BIN/RUFUS.Filter --sam s.chr hl stdin sam 25 15 1 64 > log2.txt; fi
+  e=$(date +%s.%N)
+  python3 -c "print('RUFUS.Filter --sam ($src): %.2f s = %.1f M reads/s' % ($e-$s, 2*$PAIRS/($e-$s)/1e6))"
+  cmp sam.Mutations.Mate1.fastq two.m1 && cmp sam.Mutations.Mate2.fastq two.m2 && cmp s.chr y.chr && echo "   same Mutations.Mate1/2.fastq and chr log as the two-process route"
+done
+grep "filter" trace.txt | tail -3
 if [ -x $REF/PassThroughSamCheck.stranded ]; then
   head -n 2000000 in.sam > small.sam
   rm -f p.mate1.fastq p.mate2.fastq; mkfifo p.mate1.fastq p.mate2.fastq

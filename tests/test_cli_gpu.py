@@ -205,6 +205,11 @@ def test_count_sam_input_equals_passthrough_plus_count(testrun, tmp_path, route)
         r = subprocess.run(cmd + ["in.sam"], cwd=d, env=env, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr
     assert _payload(f"{d}/a.Jhash") == _payload(f"{d}/b.Jhash") and len(_payload(f"{d}/b.Jhash")) > 100_000
+    # ... and directly the oracle's count of field 10 of every line (jf mer_overlap_sequence_parser semantics: the
+    # reads are independent sequences), not only the repo's own two-process route
+    import oracle
+    want = oracle.count(None, 25, 100_000_000, lower=2, reads=[ln.split(b"\t")[9] for ln in lines])
+    assert _payload(f"{d}/b.Jhash") == want.payload()
     assert open(f"{d}/a.chr").read() == open(f"{d}/b.chr").read()
     assert open(f"{d}/b.chr").read().split() == ["notachr", "chr1", "chr2", "chr10", "chr1", "chrX", "*"] + \
         open(f"{d}/b.chr").read().split()[7:]
@@ -215,6 +220,72 @@ def test_count_sam_input_equals_passthrough_plus_count(testrun, tmp_path, route)
     # a header line is not a record (the reference tool would read past the end of the line)
     r = subprocess.run(cmd + ["/dev/stdin"], cwd=d, env=env, input=b"@HD\tVN:1.6\n" + sam, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"--sam" in r.stderr
+
+
+@pytest.mark.parametrize("shape", ["sorted", "shuffled"])
+def test_filter_sam_equals_feeder_plus_filter(tmp_path, shape):
+    """SURVEY 8 row N1, filter half: `RUFUS.Filter --sam CHR HashList stdin STUB ...` on the SAM stream = the
+    two-process route of runRufus.sh:964-967 (`PassThroughSamCheck.stranded CHR STUB.temp` -> two FASTQ streams ->
+    `RUFUS.Filter`), byte for byte: Mutations.Mate1/2.fastq and the chromosome log -- against the drop-in pair AND against
+    the reference binaries (oracle/_ref, one thread: input order).  "shuffled": records in random order, names seen
+    three and four times, IUPAC / lower-case bases in reverse-strand reads, qualities shorter than the read, so that
+    thousands of reads wait across many pieces (pieces of 16 KB: the waiting records outlive their piece)."""
+    from tests.test_cli_host import make_sam
+    d = str(tmp_path)
+    rng = np.random.default_rng(5)
+    if shape == "sorted":
+        sam = make_sam(3000, seed=8)
+    else:
+        n = 6000
+        alphabet = np.frombuffer(b"ACGT" * 8 + b"Nacgtn" + b"RY", np.uint8)
+        recs = []
+        for i in range(n):
+            times = 2 if i % 97 else (3 if i % 2 else 4)
+            for t in range(times):
+                L = int(rng.integers(30, 151))
+                seq = bytes(rng.choice(alphabet, L))
+                qual = rng.integers(55, 75, L if i % 53 else max(1, L - 7), dtype=np.uint8)
+                qual[rng.random(len(qual)) < 0.03] = 35                # '#': below MinQ
+                qual = bytes(qual)
+                flag = int(rng.choice([99, 147, 83, 163, 16, 0, 1040, 65]))
+                recs.append(b"\t".join([b"q%d" % i, b"%d" % flag, b"chr%d" % (1 + i % 5), b"%d" % (i + t), b"60", b"*", b"=",
+                                         b"1", b"0", seq, qual, b"XS:i:%d" % t]) + b"\n")
+        sam = b"".join(recs[j] for j in rng.permutation(len(recs)))
+    open(f"{d}/in.sam", "wb").write(sam)
+    # hash list: k-mers of the (upper-case ACGT) stretches of some records, either strand
+    lines = [ln.split(b"\t") for ln in sam.split(b"\n") if ln.count(b"\t") >= 10]
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    kmers = []
+    for j in rng.choice(len(lines), 200 if shape == "sorted" else 1500, replace=False):
+        sq = lines[j][9]
+        ok = [a for a in range(len(sq) - 24) if set(sq[a:a + 25]) <= set(b"ACGT")]
+        for a in (rng.choice(ok, min(3, len(ok)), replace=False) if ok else ()):
+            km = sq[int(a):int(a) + 25]
+            kmers.append(km if rng.random() < 0.5 else km.translate(comp)[::-1])
+    assert len(kmers) > 40
+    open(f"{d}/hl", "wb").write(b"".join(km + b" 9\n" for km in kmers))
+    env = dict(os.environ, RFX_INGEST_PIECE="16384")
+    r = subprocess.run(f"{BIN}/PassThroughSamCheck.stranded two.chr two < in.sam > two.log && "
+                       f"{BIN}/RUFUS.Filter hl two.mate1.fastq two.mate2.fastq two 25 15 1 4", shell=True, cwd=d,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for threads in ("1", "5"):
+        r = subprocess.run([f"{BIN}/RUFUS.Filter", "--sam", "one.chr", "hl", "stdin", "one", "25", "15", "1", threads], cwd=d, env=env,
+                           input=sam, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr
+        for m in (1, 2):
+            got = open(f"{d}/one.Mutations.Mate{m}.fastq", "rb").read()
+            assert got == open(f"{d}/two.Mutations.Mate{m}.fastq", "rb").read() and got.count(b"\n") >= 4 * 15
+        assert open(f"{d}/one.chr", "rb").read() == open(f"{d}/two.chr", "rb").read()
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    if os.path.exists(f"{ref}/RUFUS.Filter") and shape == "sorted":     # (the reference filter needs whole quality lines)
+        r = subprocess.run(f"{ref}/PassThroughSamCheck.stranded ref.chr ref < in.sam > ref.log && "
+                           f"{ref}/RUFUS.Filter hl ref.mate1.fastq ref.mate2.fastq ref 25 15 1 1 > ref.flog", shell=True, cwd=d,
+                           stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr
+        for m in (1, 2):
+            assert open(f"{d}/one.Mutations.Mate{m}.fastq", "rb").read() == open(f"{d}/ref.Mutations.Mate{m}.fastq", "rb").read()
+        assert open(f"{d}/one.chr", "rb").read() == open(f"{d}/ref.chr", "rb").read()
 
 
 def test_count_reads_a_named_pipe_and_several_files(testrun, tmp_path):

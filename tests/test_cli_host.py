@@ -13,6 +13,13 @@ from tests.synth import make_trio
 BIN = os.path.join(ROOT, "rufus_amd", "bin")
 REF = os.path.join(ROOT, "oracle", "_ref")
 
+# The host-only tools are part of the drop-in boundary on the GPU box as well (oracle/_ref ships with the snapshot): every
+# test of this file runs once in the CPU session (-m "not gpu") and once more in the GPU session (-m gpu).
+@pytest.fixture(autouse=True, params=["cpu-session", pytest.param("gpu-session", marks=pytest.mark.gpu)])
+def _both_sessions(request):
+    return request.param
+
+
 needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "PassThroughSamCheck")),
                                reason="oracle/_ref not built (needs /root/reference)")
 

@@ -217,6 +217,24 @@ int rfx_count_set_shard(rfx_table*, int shard, int n_shards);
  * jf/sub_commands/count_main.cc:326-339).  The table is consumed by its finish. */
 int rfx_count_set_passes(rfx_table*, int passes);
 int rfx_count_add(rfx_table*, const rfx_reads*);
+/* Several devices behind ONE executable (runRufus.sh:776-797 calls binaries, so the N GPUs of a node have
+ * to be reachable from `jellyfish count` itself, RUFUS_GPUS=0-7).  N tables, one per device, are fed the SAME read
+ * blocks; table i counts minimizer shard i of N (every instance of a canonical k-mer has the same minimizer: disjoint
+ * k-mer sets, exact counts, no reduce -- the zero-exchange scheme of SURVEY 8(e), "every GPU scans all reads, inserts
+ * only its key range").  Before the survivors are sorted they change hands once (device-to-device, pulled by the
+ * receiver over xGMI) so that table i ends up with slice i of the OUTPUT POSITIONS: rfx_count_finish of table i
+ * returns slice i of the (pos,key)-ordered payload, and the .Jhash is the slices one after the other -- the owner
+ * partition of jf's sorted dumper (jf/include/jellyfish/sorted_dumper.hpp:80-112) without a merge.
+ *   rfx_ctx_allow_peers   before the first allocation of a ctx: the devices that may read its memory directly
+ *   rfx_peers_create(n)   the meeting point of n tables
+ *   rfx_count_set_peers   after rfx_count_set_passes, before the first add: this table is number `index` of the group
+ * The n rfx_count_finish calls must run concurrently (one host thread each): they meet at two barriers; if one fails
+ * they all fail. */
+typedef struct rfx_peers rfx_peers;
+int rfx_ctx_allow_peers(rfx_ctx*, const int* devices, int n);
+rfx_peers* rfx_peers_create(int n);
+void rfx_peers_free(rfx_peers*);
+int rfx_count_set_peers(rfx_table*, rfx_peers*, int index);
 /* Merge pre-aggregated (key,count) pairs (device pointers): owner-side reduce of the multi-GPU
  * exchange, and the rehash path. */
 int rfx_count_add_pairs_dev(rfx_table*, const uint64_t* d_keys, const uint32_t* d_counts, uint64_t n);

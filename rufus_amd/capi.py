@@ -94,6 +94,10 @@ SIGNATURES = {
     "rfx_records_dev_pos": (C.c_void_p, [C.c_void_p]),
     "rfx_records_histo": (C.c_int, [C.c_void_p, u64p]),
     "rfx_records_verify": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u64p]),
+    "rfx_ctx_allow_peers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+    "rfx_peers_create": (C.c_void_p, [C.c_int]),
+    "rfx_peers_free": (None, [C.c_void_p]),
+    "rfx_count_set_peers": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "rfx_records_free": (None, [C.c_void_p]),
     "rfx_merge_unique": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_uint32, u64p, u32p, C.c_uint64,
                                    u64p]),
@@ -476,6 +480,10 @@ class CountTable:
     def set_passes(self, passes: int = 0):
         """Defer the adds: finish() runs `passes` minimizer-shard passes over the (still alive) blocks (0 = plan)."""
         _check(lib().rfx_count_set_passes(self._h, passes), "rfx_count_set_passes")
+
+    def set_peers(self, peers: int, index: int):
+        """Table `index` of a group of tables on several devices (rfx_peers_create); after set_passes, before add."""
+        _check(lib().rfx_count_set_peers(self._h, peers, index), "rfx_count_set_peers")
 
     def set_shard(self, shard: int, n_shards: int):
         """Count only the k-mers of minimizer shard `shard` of `n_shards` (before the first add)."""

@@ -15,6 +15,8 @@
 #include <limits>
 #include <memory>
 
+#include <functional>
+
 #include "rfx_ingest.hpp"
 
 using namespace rfxcli;
@@ -68,9 +70,25 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   while ((1ull << lsize) < size) ++lsize;
   if (lsize < 1) lsize = 1;
 
-  rfx_ctx* ctx = open_ctx();
-  rfx_table* tab = rfx_count_begin(ctx, k, canonical, lsize, 0, 0, 0);
-  if (!tab) die(std::string("rufus_amd: ") + rfx_last_error());
+  // RUFUS_GPUS: one sample over several devices (include/rufus_hip.h rfx_count_set_peers) -- every device
+  // gets every read block and counts its minimizer shard; the survivors change hands by output position; the file is
+  // the devices' slices one after the other.  Needs the super-k-mer path (23 <= k <= 31): else the first device alone.
+  std::vector<int> gpus = gpu_list();
+  if (gpus.size() > 1 && !(k >= 23 && k <= 31)) {
+    fprintf(stderr, "rufus_amd jellyfish: k = %d is counted on one device (RUFUS_GPUS needs 23 <= k <= 31)\n", k);
+    gpus.resize(1);
+  }
+  const int n_gpu = (int)gpus.size();
+  std::vector<rfx_ctx*> ctxs = open_ctxs(gpus);
+  std::vector<rfx_table*> tabs;
+  rfx_peers* peers = n_gpu > 1 ? rfx_peers_create(n_gpu) : nullptr;
+  for (int g = 0; g < n_gpu; ++g) {
+    rfx_table* tb = rfx_count_begin(ctxs[g], k, canonical, lsize, 0, 0, 0);
+    if (!tb) die(std::string("rufus_amd: ") + rfx_last_error());
+    tabs.push_back(tb);
+  }
+  rfx_ctx* ctx = ctxs[0];
+  rfx_table* tab = tabs[0];
   const auto t_init = std::chrono::steady_clock::now();
   trace("count: device open, table made");
 
@@ -112,14 +130,28 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   const bool msp_ok = k >= 23 && k <= 31;  // the super-k-mer path (rfx_count_set_passes needs it)
   bool defer = msp_ok && (any_stream || known_bytes > (16ull << 30) || getenv("RFX_COUNT_PASSES"));
   if (const char* ev = getenv("RFX_COUNT_DEFER")) defer = msp_ok && atoi(ev) != 0;
-  if (defer && rfx_count_set_passes(tab, 0) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
-  std::vector<rfx_reads*> resident;
-  auto sink = [&](rfx_reads* r) {
+  if (n_gpu > 1) defer = true;
+  for (int g = 0; g < n_gpu; ++g) {
+    if (defer && rfx_count_set_passes(tabs[g], 0) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+    if (peers && rfx_count_set_peers(tabs[g], peers, g) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+  }
+  std::vector<std::vector<rfx_reads*>> resident((size_t)n_gpu);
+  auto sink_to = [&](int g, rfx_reads* r) {
     if (!r) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
-    const int rc = rfx_count_add(tab, r);
+    const int rc = rfx_count_add(tabs[g], r);
     if (rc) die(std::string("rufus_amd: count failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
-    if (defer) resident.push_back(r);
+    if (defer) resident[(size_t)g].push_back(r);
     else rfx_reads_free(r);
+  };
+  // a block of packed reads goes to EVERY device (each over its own PCIe link: one thread per device)
+  auto to_all = [&](const std::function<rfx_reads*(rfx_ctx*)>& up) {
+    if (n_gpu == 1) {
+      sink_to(0, up(ctx));
+      return;
+    }
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_gpu; ++g) th.emplace_back([&, g] { sink_to(g, up(ctxs[g])); });
+    for (auto& t : th) t.join();
   };
 
   ReadBatch batch;
@@ -128,7 +160,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     if (batch.n() == 0) return;
     int rc = packed.pack(batch, RFX_PACK_COUNT, 0);
     if (rc) die(std::string("rufus_amd: pack failed: ") + rfx_strerror(rc));
-    sink(packed.upload(ctx, batch.n(), RFX_PACK_COUNT));
+    to_all([&](rfx_ctx* c) { return packed.upload(c, batch.n(), RFX_PACK_COUNT); });
     batch.clear();
   };
   auto sequential = [&](LineReader& in) {  // the reference's grammar: FASTA, multi-line FASTQ
@@ -146,7 +178,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
       if (nthreads > 1 || sam_chr) {
         if (!ingest) {
           ingest.reset(new CountIngest(nthreads, [&](const StageBlock& b) {
-            sink(rfx_reads_upload(ctx, b.codes, b.acgt, nullptr, b.word_off, b.len, b.n_reads));
+            to_all([&](rfx_ctx* c) { return rfx_reads_upload(c, b.codes, b.acgt, nullptr, b.word_off, b.len, b.n_reads); });
           }));
           ingest->set_sam(sam_chr != nullptr);
           if (const char* ev = getenv("RFX_INGEST_PIECE")) ingest->set_piece_bytes((size_t)std::max(1024ll, atoll(ev)));
@@ -223,10 +255,25 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   // scripts/RunJellyForRUFUS.sh:36-38 runs histo only when that file is missing (a 35 GB re-read saved per sample).
   const bool side_histo = getenv("RFX_COUNT_HISTO") != nullptr;
   std::vector<uint64_t> hist(side_histo ? RFX_HISTO_BINS : 0);
-  rfx_records* rec = rfx_count_finish(tab, lower, upper, side_histo ? hist.data() : nullptr);
-  if (!rec) die(std::string("rufus_amd: finish failed: ") + rfx_last_error());
+  std::vector<rfx_records*> recs((size_t)n_gpu, nullptr);
+  if (n_gpu == 1) {
+    recs[0] = rfx_count_finish(tab, lower, upper, side_histo ? hist.data() : nullptr);
+  } else {  // the finishes meet at the survivor exchange: one thread each
+    std::vector<std::vector<uint64_t>> hs((size_t)n_gpu, std::vector<uint64_t>(side_histo ? RFX_HISTO_BINS : 0));
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_gpu; ++g)
+      th.emplace_back([&, g] { recs[(size_t)g] = rfx_count_finish(tabs[g], lower, upper, side_histo ? hs[(size_t)g].data() : nullptr); });
+    for (auto& t : th) t.join();
+    if (side_histo)
+      for (int g = 0; g < n_gpu; ++g)
+        for (int i = 0; i < RFX_HISTO_BINS; ++i) hist[(size_t)i] += hs[(size_t)g][(size_t)i];
+  }
+  for (rfx_records* r : recs)
+    if (!r) die(std::string("rufus_amd: finish failed: ") + rfx_last_error());
+  rfx_records* rec = recs[0];
   trace("count: finished on the device");
-  for (rfx_reads* r : resident) rfx_reads_free(r);
+  for (auto& v : resident)
+    for (rfx_reads* r : v) rfx_reads_free(r);
   std::vector<uint64_t> cols(2 * (size_t)k);
   rfx_jf_matrix(lsize, k, cols.data());
   if (side_histo && rec) {
@@ -237,15 +284,16 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     }
   }
   const int out_fd = prealloc.take();
-  write_jhash(out, rec, cols.data(), canonical, out_counter_len, full_argc, full_argv,
+  write_jhash(out, recs, cols.data(), canonical, out_counter_len, full_argc, full_argv,
               ingest ? ingest->lend_buffers(48u << 20) : std::vector<std::pair<char*, size_t>>(), out_fd,
               prealloc.reached());
   trace("count: output closed");
   if (!timing) leave(0);
   ingest.reset();
-  rfx_records_free(rec);
-  rfx_count_free(tab);
-  rfx_close(ctx);
+  for (rfx_records* r : recs) rfx_records_free(r);
+  for (rfx_table* tb : tabs) rfx_count_free(tb);
+  if (peers) rfx_peers_free(peers);
+  for (rfx_ctx* c : ctxs) rfx_close(c);
   trace("count: closed");
   if (timing) {
     if (FILE* f = fopen(timing, "w")) {
@@ -334,11 +382,8 @@ static int query_main(int argc, char** argv) {
   JhashFile db;
   rfx_records* rec = nullptr;
   const bool sliced = db.open(argv[optind]);
+  if (!sliced) rec = load_records(ctx, argv[optind], db.h);  // (a pipe: header and payload in one pass)
   const JhashHeader& h = db.h;
-  if (!sliced) {
-    JhashHeader h2;
-    rec = load_records(ctx, argv[optind], h2);
-  }
   const int k = h.k;
   const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
   std::vector<uint64_t> keys;

@@ -44,6 +44,49 @@ inline rfx_ctx* open_ctx() {
   return c;
 }
 
+// RUFUS_GPUS="0-7" | "0,2,5" | "0-3,6" (a device may be named twice: two contexts on it, how a one-GPU box tests the
+// multi-device code): the devices `jellyfish count` and `RUFUS.Filter` spread one sample over.  Unset: the one device
+// of RUFUS_GPU (default 0).
+inline std::vector<int> gpu_list() {
+  std::vector<int> out;
+  const char* ev = getenv("RUFUS_GPUS");
+  if (!ev || !*ev) {
+    const char* dev = getenv("RUFUS_GPU");
+    out.push_back(dev ? atoi(dev) : 0);
+    return out;
+  }
+  const char* p = ev;
+  while (*p) {
+    char* end;
+    const long a = strtol(p, &end, 10);
+    if (end == p || a < 0) die(std::string("rufus_amd: cannot parse RUFUS_GPUS='") + ev + "'");
+    long b = a;
+    p = end;
+    if (*p == '-') {
+      b = strtol(p + 1, &end, 10);
+      if (end == p + 1 || b < a) die(std::string("rufus_amd: cannot parse RUFUS_GPUS='") + ev + "'");
+      p = end;
+    }
+    for (long d = a; d <= b; ++d) out.push_back((int)d);
+    if (*p == ',') ++p;
+    else if (*p) die(std::string("rufus_amd: cannot parse RUFUS_GPUS='") + ev + "'");
+  }
+  if (out.empty() || out.size() > 64) die(std::string("rufus_amd: RUFUS_GPUS names no device (or more than 64): '") + ev + "'");
+  return out;
+}
+inline std::vector<rfx_ctx*> open_ctxs(const std::vector<int>& gpus) {
+  std::vector<rfx_ctx*> out;
+  for (int d : gpus) {
+    rfx_ctx* c = rfx_open(d, 0);
+    if (!c) die(std::string("rufus_amd: no MI355X (gfx950) device ") + std::to_string(d) + ": " + rfx_last_error() +
+                " -- there is no CPU fallback");
+    if (gpus.size() > 1 && rfx_ctx_allow_peers(c, gpus.data(), (int)gpus.size()) != RFX_OK)
+      die(std::string("rufus_amd: ") + rfx_last_error());
+    out.push_back(c);
+  }
+  return out;
+}
+
 // Buffered line reader over a file descriptor; works on regular files and on named pipes.
 class LineReader {
   int fd_ = -1;
@@ -317,12 +360,19 @@ inline bool read_jhash(const char* path, JhashHeader& h, std::vector<char>* payl
   return true;
 }
 
+inline bool is_regular_file(const char* path) {
+  struct stat sb;
+  return ::stat(path, &sb) == 0 && S_ISREG(sb.st_mode);
+}
+
 inline rfx_records* load_records(rfx_ctx* c, const char* path, JhashHeader& h) {
   std::vector<char> payload;
-  if (!read_jhash(path, h, nullptr)) die(std::string("Failed to parse header of file '") + path + "'");
+  // a pipe / process substitution can be opened once: header and payload in ONE pass
+  const bool regular = is_regular_file(path);
+  if (!read_jhash(path, h, regular ? nullptr : &payload)) die(std::string("Failed to parse header of file '") + path + "'");
   if (h.format != "binary/sorted") die("Unknown format '" + h.format + "'");
   const size_t rl = (size_t)(2 * h.k + 7) / 8 + (size_t)h.counter_len;
-  if (h.file_size >= h.payload_offset) {  // a regular file: streamed from the descriptor
+  if (regular && h.file_size >= h.payload_offset) {  // a regular file: streamed from the descriptor
     const uint64_t bytes = h.file_size - h.payload_offset;
     if (bytes % rl != 0)
       die("Size of database (" + std::to_string(bytes) + ") must be a multiple of the length of a record (" +
@@ -334,7 +384,7 @@ inline rfx_records* load_records(rfx_ctx* c, const char* path, JhashHeader& h) {
     if (!r) die(std::string("rufus_amd: cannot load '") + path + "': " + rfx_last_error());
     return r;
   }
-  if (!read_jhash(path, h, &payload)) die(std::string("Failed to parse header of file '") + path + "'");
+  if (regular && !read_jhash(path, h, &payload)) die(std::string("Failed to parse header of file '") + path + "'");
   if (payload.size() % rl != 0)
     die("Size of database (" + std::to_string(payload.size()) + ") must be a multiple of the length of a record (" +
         std::to_string(rl) + ")");
@@ -354,8 +404,9 @@ struct JhashFile {
   uint64_t n = 0;
   size_t rl = 0, kb = 0;
 
-  bool open(const char* p) {  // false: not a regular file (the caller loads it whole instead)
+  bool open(const char* p) {  // false: not a regular file (the caller loads it whole instead -- it was not touched)
     path = p;
+    if (!is_regular_file(p)) return false;
     if (!read_jhash(p, h, nullptr)) die(std::string("Failed to parse header of file '") + p + "'");
     if (h.format != "binary/sorted") die("Unknown format '" + h.format + "'");
     kb = (size_t)(2 * h.k + 7) / 8;
@@ -590,14 +641,18 @@ class OutputPrealloc {
 
 // `lend`: page-locked buffers the caller no longer needs (the ingest's staging blocks), used as the drain ring
 // instead of pinning more memory.
-inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols, bool canonical, int counter_len,
-                        int argc, char** argv, const std::vector<std::pair<char*, size_t>>& lend = {}, int open_fd = -1,
-                        uint64_t preallocated = 0) {
+// `recs`: the payload in slices (one record set per device, rfx_count_set_peers: slice i holds the i-th range of output
+// positions), written one after the other; each slice is fetched by its own thread.
+inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs, const uint64_t* cols, bool canonical,
+                        int counter_len, int argc, char** argv, const std::vector<std::pair<char*, size_t>>& lend = {},
+                        int open_fd = -1, uint64_t preallocated = 0) {
+  rfx_records* rec = recs.at(0);
   const int k = rfx_records_k(rec), lsize = rfx_records_lsize(rec);
   std::vector<char> hdr(1 << 16);
   const long hl = rfx_jhash_header(k, lsize, cols, canonical, counter_len, argc, argv, hdr.data(), hdr.size());
   if (hl < 0) die("rufus_amd: header too large");
-  const uint64_t n = rfx_records_size(rec);
+  uint64_t n = 0;
+  for (rfx_records* r : recs) n += rfx_records_size(r);
   const size_t rl = (size_t)(2 * k + 7) / 8 + (size_t)counter_len;
   int fd = open_fd >= 0 ? open_fd : ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);  // open_fd: OutputPrealloc's
   if (fd < 0) fd = ::open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);  // a write-only special file
@@ -617,6 +672,29 @@ inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols
   // the (pre-sized) file when it can be had: buffered write()s to ONE file serialise on its inode lock -- six
   // pwrite threads gave 3.8 GB/s into tmpfs, one thread's worth -- page faults of a mapping do not.
   const uint64_t total = (uint64_t)hl + n * rl;
+  if (::lseek(fd, 0, SEEK_CUR) == (off_t)-1) {  // a pipe (-o /dev/stdout | ...): no offsets, one writer, in order
+    auto put_seq = [&](const char* p, size_t len) {
+      while (len) {
+        const ssize_t w = ::write(fd, p, len);
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) die(std::string("write error on '") + path + "': " + strerror(errno));
+        p += w;
+        len -= (size_t)w;
+      }
+    };
+    put_seq(hdr.data(), (size_t)hl);
+    const uint64_t step = 1ull << 20;
+    std::vector<char> b(step * rl);
+    for (rfx_records* r : recs)
+      for (uint64_t at = 0, cnt = rfx_records_size(r); at < cnt; at += step) {
+        const uint64_t m = std::min<uint64_t>(step, cnt - at);
+        if (rfx_records_payload_range(r, at, m, b.data(), (size_t)m * rl, counter_len) != RFX_OK)
+          die(std::string("rufus_amd: drain failed: ") + rfx_last_error());
+        put_seq(b.data(), (size_t)m * rl);
+      }
+    if (::close(fd) != 0) die(std::string("write error on '") + path + "'");
+    return;
+  }
   char* map = nullptr;
   // blocks preallocated past the end: ext4 keeps them when the size only grows -- grow over them, then cut back
   if (preallocated > total) (void)!::ftruncate(fd, (off_t)preallocated);
@@ -640,6 +718,47 @@ inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols
     put(hdr.data(), (size_t)hl, 0);
   }
   trace("write: header out");
+  if (recs.size() > 1) {  // one fetch thread per slice (= per device), each with its own small ring
+    std::vector<std::thread> th;
+    uint64_t first = 0;
+    for (rfx_records* r : recs) {
+      const uint64_t base = first, cnt = rfx_records_size(r);
+      first += cnt;
+      th.emplace_back([=] {
+        const uint64_t step = 2ull << 20;
+        const int NB = 3;
+        char* b[NB];
+        std::thread w[NB];
+        for (int i = 0; i < NB; ++i)
+          if (!(b[i] = (char*)rfx_host_alloc(step * rl))) die("rufus_amd: out of pinned host memory");
+        for (uint64_t at = 0, i = 0; at < cnt; at += step, ++i) {
+          const uint64_t m = std::min<uint64_t>(step, cnt - at);
+          const int bi = (int)(i % NB);
+          if (w[bi].joinable()) w[bi].join();
+          if (rfx_records_payload_range(r, at, m, b[bi], (size_t)m * rl, counter_len) != RFX_OK)
+            die(std::string("rufus_amd: drain failed: ") + rfx_last_error());
+          const char* src = b[bi];
+          const size_t len = (size_t)m * rl;
+          const off_t off = (off_t)hl + (off_t)((base + at) * rl);
+          if (map) w[bi] = std::thread([=] { memcpy(map + off, src, len); });
+          else w[bi] = std::thread([=] { put(src, len, off); });
+        }
+        for (auto& x : w)
+          if (x.joinable()) x.join();
+        for (int i = 0; i < NB; ++i) rfx_host_free(b[i]);
+      });
+    }
+    for (auto& t : th) t.join();
+    trace("write: payload out (slices)");
+    if (map) {
+      if (munmap(map, (size_t)total) != 0) die(std::string("write error on '") + path + "'");
+      sigaction(SIGBUS, &old_bus, nullptr);
+    } else if (open_fd >= 0) {
+      (void)!::ftruncate(fd, (off_t)total);
+    }
+    if (::close(fd) != 0) die(std::string("write error on '") + path + "'");
+    return;
+  }
   const uint64_t step = 4ull << 20;
   const int NBUF = 8;
   char* buf[NBUF];
@@ -693,6 +812,12 @@ inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols
     (void)!::ftruncate(fd, (off_t)total);  // drop what was preallocated past the end
   }
   if (::close(fd) != 0) die(std::string("write error on '") + path + "'");
+}
+
+inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols, bool canonical, int counter_len,
+                        int argc, char** argv, const std::vector<std::pair<char*, size_t>>& lend = {}, int open_fd = -1,
+                        uint64_t preallocated = 0) {
+  write_jhash(path, std::vector<rfx_records*>{rec}, cols, canonical, counter_len, argc, argv, lend, open_fd, preallocated);
 }
 
 // yaggo's SI suffixes (jf/sub_commands/count_main_cmdline.hpp:104-109): k M G T P E are powers of 1000.

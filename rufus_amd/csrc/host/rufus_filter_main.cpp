@@ -147,9 +147,16 @@ static int run(int argc, char** argv) {
   std::vector<uint64_t> keys((size_t)nk + 1);
   rfx_hashlist_keys(text.data(), text.size(), k, 0, keys.data(), keys.size());
   printf("\nDone Hash Files\n\t Mutations Hash size is %ld\n", nk);
-  rfx_ctx* ctx = open_ctx();
-  rfx_set* set = rfx_set_build(ctx, keys.data(), (uint64_t)nk, k);
-  if (!set) die(std::string("rufus_amd: ") + rfx_last_error());
+  // RUFUS_GPUS: the pieces are dealt to the devices by helper thread (the filter shards by read block)
+  const std::vector<int> gpus = gpu_list();
+  const int n_gpu = (int)gpus.size();
+  std::vector<rfx_ctx*> ctxs = open_ctxs(gpus);
+  std::vector<rfx_set*> sets;
+  for (rfx_ctx* c : ctxs) {
+    rfx_set* st = rfx_set_build(c, keys.data(), (uint64_t)nk, k);
+    if (!st) die(std::string("rufus_amd: ") + rfx_last_error());
+    sets.push_back(st);
+  }
   trace("filter --sam: device open, set built");
 #ifdef F_SETPIPE_SZ
   (void)fcntl(fd, F_SETPIPE_SZ, 1 << 20);
@@ -158,12 +165,14 @@ static int run(int argc, char** argv) {
   unsigned helpers = (unsigned)std::max(1, atoi(argv[9]));
   helpers = std::min(helpers, rfx_host_cpus() > 2 ? rfx_host_cpus() - 2 : 1u);
   if (const char* ev = getenv("RFX_HOST_THREADS")) helpers = (unsigned)std::max(1, atoi(ev));
+  helpers = std::max(helpers, (unsigned)n_gpu);
   size_t PIECE = 32u << 20;
   if (const char* ev = getenv("RFX_INGEST_PIECE")) PIECE = (size_t)std::max(1024, atoi(ev));
   const size_t LAG = 3;
   const size_t MAX_IN_FLIGHT = 2 * (size_t)helpers + 2 + LAG;
 
-  std::mutex mu, dev_mu;
+  std::mutex mu;
+  std::vector<std::mutex> dev_mu((size_t)n_gpu);
   std::condition_variable cv;
   std::deque<SPiece*> todo, spare;
   std::map<uint64_t, SPiece*> done;
@@ -217,7 +226,10 @@ static int run(int argc, char** argv) {
     cv.notify_all();
   });
 
-  auto helper = [&]() {
+  auto helper = [&](unsigned me) {
+    const size_t dev = (size_t)me % (size_t)n_gpu;
+    rfx_ctx* ctx = ctxs[dev];
+    rfx_set* set = sets[dev];
     struct Pinned {
       void* p = nullptr;
       size_t cap = 0;
@@ -308,7 +320,7 @@ static int run(int argc, char** argv) {
         if (rfx_pack_spans(base, so.data(), sl.data(), qo.data(), (uint32_t)n, min_q, RFX_PACK_FILTER, codes, nullptr, good,
                            woff, lens) != RFX_OK)
           die("rufus_amd: pack failed");
-        std::lock_guard<std::mutex> g(dev_mu);
+        std::lock_guard<std::mutex> g(dev_mu[dev]);
         rfx_reads* rd = rfx_reads_upload(ctx, codes, nullptr, good, woff, lens, (uint32_t)n);
         if (!rd) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
         uint64_t nh = 0;
@@ -322,7 +334,8 @@ static int run(int argc, char** argv) {
     }
   };
   std::vector<std::thread> workers;
-  for (unsigned t = 0; t < helpers; ++t) workers.emplace_back(helper);
+  helpers = std::max(helpers, (unsigned)n_gpu);
+  for (unsigned t = 0; t < helpers; ++t) workers.emplace_back(helper, t);
 
   WaitTable waiting;
   std::deque<SPiece*> live;
@@ -418,8 +431,8 @@ static int run(int argc, char** argv) {
   for (auto& w : workers) w.join();
   trace("filter --sam: all pieces done");
   printf("\nSAM records %llu, pairs %llu, pulled %llu\n", n_rec, n_pairs, n_found);
-  rfx_set_free(set);
-  rfx_close(ctx);
+  for (rfx_set* st : sets) rfx_set_free(st);
+  for (rfx_ctx* c : ctxs) rfx_close(c);
   printf("\nDone running RUFUS.Filter.cpp\n");
   return 0;
 }
@@ -494,10 +507,17 @@ int main(int argc, char** argv) {
   printf("\nDone Hash Files\n\t Mutations Hash size is %ld\n", nk);
 
   trace("filter: hash list parsed");
-  rfx_ctx* ctx = open_ctx();
-  rfx_set* set = rfx_set_build(ctx, keys.data(), (uint64_t)nk, k);
+  // RUFUS_GPUS: the pieces are dealt to the devices by worker thread (the filter shards by read block)
+  const std::vector<int> gpus = gpu_list();
+  const int n_gpu = (int)gpus.size();
+  std::vector<rfx_ctx*> ctxs = open_ctxs(gpus);
+  std::vector<rfx_set*> sets;
+  for (rfx_ctx* c : ctxs) {
+    rfx_set* st = rfx_set_build(c, keys.data(), (uint64_t)nk, k);
+    if (!st) die(std::string("rufus_amd: ") + rfx_last_error());
+    sets.push_back(st);
+  }
   trace("filter: device open, set built");
-  if (!set) die(std::string("rufus_amd: ") + rfx_last_error());
 
   // Pipeline (the device scans ~1000x faster than one core parses, so the host side is what counts):
   //   one reader per mate stream cuts it into pieces of PIECE_RECS records (4 lines each, counted blindly like the
@@ -522,6 +542,7 @@ int main(int argc, char** argv) {
     std::condition_variable cv;
     std::deque<Piece*> q;
     bool done = false;
+    bool abort = false;         // mate 1 ended: nobody takes this stream's pieces any more
     const char* map = nullptr;  // regular file: mapped
     size_t map_size = 0;
   };
@@ -566,7 +587,11 @@ int main(int argc, char** argv) {
   auto reader = [&](Stream& S) {
     auto push = [&](Piece* pc) {
       std::unique_lock<std::mutex> g(S.mu);
-      S.cv.wait(g, [&] { return S.q.size() < MAX_AHEAD; });
+      S.cv.wait(g, [&] { return S.q.size() < MAX_AHEAD || S.abort; });
+      if (S.abort) {  // (the reference stops at the end of file 1: what mate 2 still holds is read and dropped)
+        delete pc;
+        return;
+      }
       S.q.push_back(pc);
       S.cv.notify_all();
     };
@@ -646,7 +671,8 @@ int main(int argc, char** argv) {
   for (int i = 0; i < n_streams; ++i) readers[i] = std::thread(reader, std::ref(st[i]));
 
   struct Result { std::string out1, out2; unsigned long long recs = 0, found = 0; bool ready = false; };
-  std::mutex res_mu, dev_mu, take_mu;
+  std::mutex res_mu, take_mu;
+  std::vector<std::mutex> dev_mu((size_t)n_gpu);
   std::condition_variable res_cv;
   std::map<uint64_t, Result> results;
   uint64_t next_seq = 0;
@@ -658,9 +684,16 @@ int main(int argc, char** argv) {
       std::unique_lock<std::mutex> g(st[0].mu);
       st[0].cv.wait(g, [&] { return !st[0].q.empty() || st[0].done; });
       if (st[0].q.empty()) {
-        std::lock_guard<std::mutex> rg(res_mu);
-        input_done = true;
-        res_cv.notify_all();
+        {
+          std::lock_guard<std::mutex> rg(res_mu);
+          input_done = true;
+          res_cv.notify_all();
+        }
+        if (n_streams == 2) {  // a mate-2 reader waiting for room must not wait for ever
+          std::lock_guard<std::mutex> g2(st[1].mu);
+          st[1].abort = true;
+          st[1].cv.notify_all();
+        }
         return false;
       }
       a = st[0].q.front();
@@ -681,7 +714,10 @@ int main(int argc, char** argv) {
     seq = next_seq++;
     return true;
   };
-  auto worker = [&]() {
+  auto worker = [&](unsigned me) {
+    const size_t dev = (size_t)me % (size_t)n_gpu;
+    rfx_ctx* ctx = ctxs[dev];
+    rfx_set* set = sets[dev];
     std::vector<uint64_t> ls[2], ss[2], qs[2], mask;  // line starts, sequence / quality starts
     std::vector<uint32_t> sl[2], hits;
     std::vector<char> fix;  // private copies of quality strings that are shorter than their read
@@ -709,8 +745,11 @@ int main(int argc, char** argv) {
       for (int m = 0; m < n_streams; ++m) {
         const char* t = pc[m]->data;
         const size_t tsize = pc[m]->size;
-        ls[m].resize(4 * n + 1);
-        const size_t found_lines = index_lines(t, t + tsize, ls[m].data(), 4 * n);
+        // (one line start more than the records need: a mate-2 piece may hold more records than mate 1's -- the extra
+        // ones are never looked at, as the reference stops at the end of file 1 -- and the last record's quality line
+        // must end where line 4n starts, not at the end of the piece)
+        ls[m].resize(4 * n + 2);
+        const size_t found_lines = index_lines(t, t + tsize, ls[m].data(), 4 * n + 1);
         for (size_t li = found_lines; li <= 4 * n; ++li) ls[m][li] = tsize;  // (mate 2 ran out: empty lines)
         ss[m].resize(n);
         qs[m].resize(n);
@@ -773,7 +812,7 @@ int main(int argc, char** argv) {
       mask.assign((nr + 63) / 64, 0);
       if (single) hits.assign(nr, 0);
       {
-        std::lock_guard<std::mutex> g(dev_mu);
+        std::lock_guard<std::mutex> g(dev_mu[dev]);
         rfx_reads* rd = rfx_reads_upload(ctx, codes, nullptr, good, woff, lens, (uint32_t)nr);
         if (!rd) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
         uint64_t nh = 0;
@@ -818,8 +857,9 @@ int main(int argc, char** argv) {
   unsigned nthreads = (unsigned)std::max(1, atoi(argv[a]));
   nthreads = std::min(nthreads, rfx_host_cpus());
   if (const char* ev = getenv("RFX_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(ev));
+  nthreads = std::max(nthreads, (unsigned)n_gpu);
   std::vector<std::thread> workers;
-  for (unsigned t = 0; t < nthreads; ++t) workers.emplace_back(worker);
+  for (unsigned t = 0; t < nthreads; ++t) workers.emplace_back(worker, t);
   unsigned long long found = 0, total = 0;
   for (uint64_t want = 0;; ++want) {
     Result res;
@@ -841,8 +881,8 @@ int main(int argc, char** argv) {
   trace("filter: all pieces written");
   for (auto& w : workers) w.join();
   for (int i = 0; i < n_streams; ++i) readers[i].join();
-  rfx_set_free(set);
-  rfx_close(ctx);
+  for (rfx_set* st : sets) rfx_set_free(st);
+  for (rfx_ctx* c : ctxs) rfx_close(c);
   trace("filter: closed");
   printf("\nDone running RUFUS.Filter.cpp\n");
   return 0;

@@ -2,6 +2,8 @@
 // rfx_kernels.hip.  No CPU fallback: rfx_open() fails when no gfx950 device is visible and every
 // other entry point needs a ctx.
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,17 +97,22 @@ bool arena_grow(rfx_ctx* c, size_t need) {
   prop.type = hipMemAllocationTypePinned;
   prop.location.type = hipMemLocationTypeDevice;
   prop.location.id = c->device;
-  hipMemAccessDesc ad = {};
-  ad.location.type = hipMemLocationTypeDevice;
-  ad.location.id = c->device;
-  ad.flags = hipMemAccessFlagsProtReadWrite;
+  // the owner, and the peers that pull survivors out of this arena (rfx_ctx_allow_peers)
+  std::vector<hipMemAccessDesc> ads(1 + c->peer_devices.size());
+  for (size_t i = 0; i < ads.size(); ++i) {
+    ads[i] = hipMemAccessDesc{};
+    ads[i].location.type = hipMemLocationTypeDevice;
+    ads[i].location.id = i ? c->peer_devices[i - 1] : c->device;
+    ads[i].flags = hipMemAccessFlagsProtReadWrite;
+  }
   size_t done = 0;
   while (done < add) {
     hipMemGenericAllocationHandle_t h;
     if (hipMemCreate(&h, ARENA_CHUNK, &prop, 0) != hipSuccess) break;
     char* at = c->arena + c->arena_mapped + done;
     if (hipMemMap(at, ARENA_CHUNK, 0, h, 0) != hipSuccess) { (void)hipMemRelease(h); break; }
-    if (hipMemSetAccess(at, ARENA_CHUNK, &ad, 1) != hipSuccess) {
+    if (hipMemSetAccess(at, ARENA_CHUNK, ads.data(), ads.size()) != hipSuccess &&
+        hipMemSetAccess(at, ARENA_CHUNK, ads.data(), 1) != hipSuccess) {  // (peers refused: copies get staged instead)
       (void)hipMemUnmap(at, ARENA_CHUNK);
       (void)hipMemRelease(h);
       break;
@@ -642,6 +649,25 @@ rfx_ctx* rfx_open(int device, size_t hbm_budget_bytes) {
   if (hipHostMalloc((void**)&c->pin, 4u << 20, hipHostMallocDefault) == hipSuccess) c->pin_cap = 4u << 20;
   else c->pin = nullptr;
   return c;
+}
+
+int rfx_ctx_allow_peers(rfx_ctx* c, const int* devices, int n) {
+  if (!c || n < 0 || (n && !devices)) return RFX_E_INVAL;
+  if (c->arena_mapped || !c->allocs.empty()) {
+    snprintf(g_err, sizeof g_err, "rfx_ctx_allow_peers: call it before the first allocation of the ctx");
+    return RFX_E_INVAL;
+  }
+  (void)hipSetDevice(c->device);
+  c->peer_devices.clear();
+  for (int i = 0; i < n; ++i) {
+    const int d = devices[i];
+    int can = 0;
+    if (d == c->device || std::find(c->peer_devices.begin(), c->peer_devices.end(), d) != c->peer_devices.end()) continue;
+    if (hipDeviceCanAccessPeer(&can, d, c->device) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+    c->peer_devices.push_back(d);
+    if (hipDeviceEnablePeerAccess(d, 0) != hipSuccess) (void)hipGetLastError();  // (hipMalloc'ed blocks; already on: fine)
+  }
+  return RFX_OK;
 }
 
 void rfx_close(rfx_ctx* c) {
@@ -1380,6 +1406,7 @@ struct rfx_finish {
   uint64_t *aw = nullptr, *bw = nullptr, *bsq = nullptr, *bs1 = nullptr;
   uint32_t *ac = nullptr, *bc = nullptr;
   bool segs_dropped = false;  // the leaf phase of a big table is final: its records are already freed
+  uint32_t cb_lo = 0;         // peers: aw / ac hold coarse bins cb_lo .. only (index them through aw0() / ac0())
   rfx_records* big = nullptr;
   std::vector<const uint64_t*> h_ptrs;
   std::vector<uint32_t> h_cur;
@@ -1636,6 +1663,7 @@ static int msp_passes_leaf(rfx_finish* f) {
   const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride(), stride = (size_t)rfxk::p1_cur_stride();
   uint64_t windows = 0;
   for (const rfx_reads* r : *t->deferred) windows += r->windows_of(t->k);
+  const int outer_shard = t->n_shards > 1 ? t->shard : 0, outer_n = t->n_shards > 1 ? t->n_shards : 1;
   int S = t->passes;
   if (S <= 0) {  // plan: the records of a pass (8 B per ~3 k-mers) + scratch beside what is already resident
     size_t free_b = 0, total_b = 0;
@@ -1646,12 +1674,12 @@ static int msp_passes_leaf(rfx_finish* f) {
     // with them.  (Planning with the sum took 5 passes for a 30x sample where 2 fit: measured, 6.3 s of finish.)
     const double surv = (double)windows / 20.0 * 14.0;
     // (8 B per ~3 k-mers; the wide records of k = 26 .. 31 are 12 B)
-    const double records = (double)windows * (rfxk::msp_wide(t->k) ? 3.6 : 2.9) * 1.15;
+    const double records = (double)windows * (rfxk::msp_wide(t->k) ? 3.6 : 2.9) * 1.15 / (double)outer_n;
     S = 1;
     while (S < 256 && records / S + surv > avail) ++S;
     if (const char* ev = getenv("RFX_COUNT_PASSES")) S = std::max(1, atoi(ev));
   }
-  if (S > 256) S = 256;
+  if (S * outer_n > 256) S = std::max(1, 256 / outer_n);
   const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + 2) * 4;
   f->bsq = (uint64_t*)dmalloc(c, zero_bytes);
   if (!f->bsq) return RFX_E_NOMEM;
@@ -1661,9 +1689,11 @@ static int msp_passes_leaf(rfx_finish* f) {
   f->h_cur.assign(ncur + 2, 0);
   f->kmers = 0;
   const rfx_ord_cfg cfg0 = ord_cfg(t, 7);
+  // (an outer shard -- rfx_count_set_shard before rfx_count_set_passes: one device of several, rfx_count_set_peers --
+  // is cut further: pass s of this table is virtual shard outer * S + s of outer_n * S)
   for (int s = 0; s < S; ++s) {
-    t->shard = s;
-    t->n_shards = S;
+    t->shard = outer_shard * S + s;
+    t->n_shards = outer_n * S;
     for (const rfx_reads* r : *t->deferred) {
       if (r->n == 0) continue;
       const int rc = msp_add(t, r);
@@ -1749,8 +1779,8 @@ static int msp_passes_leaf(rfx_finish* f) {
       }
     }
   }
-  t->shard = 0;
-  t->n_shards = 1;
+  t->shard = outer_shard;
+  t->n_shards = outer_n;
   if (!f->aw) {  // no k-mer at all
     f->cap = 1;
     f->aw = (uint64_t*)dmalloc(c, P1 * 8);
@@ -1759,6 +1789,152 @@ static int msp_passes_leaf(rfx_finish* f) {
   }
   t->deferred->clear();
   f->segs_dropped = true;
+  return RFX_OK;
+}
+
+// ---- several devices behind one executable (SURVEY 8(e), row E-cli) ---------------------------------------------------
+// N tables, one per device, are given the SAME read blocks; table i keeps minimizer shard i of N (rfx_count_set_shard's
+// cut, composed with its own shard passes), so the devices count disjoint sets of k-mers -- no partial counts, no
+// reduce.  What has to change hands is the survivors: the leaf leaves them in 128 coarse bins of the output position, and
+// table i takes over coarse bins [i * 128 / N, (i + 1) * 128 / N) of EVERY table (device-to-device copies, pulled by the
+// receiver; xGMI when the arenas were opened with rfx_ctx_allow_peers) before the usual partition + sort -- its records
+// are then slice i of the (pos,key)-ordered payload, and the .Jhash is the slices one after the other.
+// The finishes of the N tables run concurrently on N host threads and meet at two barriers.
+struct rfx_peers {
+  int n = 0;
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  bool failed = false;
+  struct Slot {
+    int device = 0;
+    const uint64_t* aw = nullptr;
+    const uint32_t* ac = nullptr;
+    uint64_t cap = 0;
+    std::vector<uint32_t> fill;  // per coarse bin
+  };
+  std::vector<Slot> slot;
+  bool barrier() {  // false: somebody failed
+    std::unique_lock<std::mutex> g(mu);
+    if (failed) return false;
+    const uint64_t my = gen;
+    if (++arrived == n) {
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+      return true;
+    }
+    cv.wait(g, [&] { return gen != my || failed; });
+    return !failed;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> g(mu);
+    failed = true;
+    cv.notify_all();
+  }
+};
+
+rfx_peers* rfx_peers_create(int n) {
+  if (n < 1 || n > 128) return nullptr;
+  rfx_peers* p = new rfx_peers();
+  p->n = n;
+  p->slot.resize((size_t)n);
+  return p;
+}
+void rfx_peers_free(rfx_peers* p) { delete p; }
+
+int rfx_count_set_peers(rfx_table* t, rfx_peers* p, int index) {
+  if (!t || !p || index < 0 || index >= p->n) return RFX_E_INVAL;
+  if (t->passes < 0 || !t->deferred->empty() || !t->segs->empty() || t->table_active) {
+    snprintf(g_err, sizeof g_err, "rfx_count_set_peers: call rfx_count_set_passes first, and both before the first add");
+    return RFX_E_INVAL;
+  }
+  t->peers = p;
+  t->peer_index = index;
+  return rfx_count_set_shard(t, index, p->n);
+}
+
+// After the leaf phase of table i: publish the survivor store, pull this table's coarse bins from everybody.
+static int peers_exchange(rfx_finish* f, uint32_t* d_cur, size_t ncur) {
+  rfx_table* t = f->t;
+  rfx_ctx* c = t->ctx;
+  rfx_peers* p = t->peers;
+  const int me = t->peer_index, N = p->n;
+  const uint32_t P1 = (uint32_t)rfxk::p1_bins(), stride = (uint32_t)rfxk::p1_cur_stride();
+  {
+    rfx_peers::Slot& s = p->slot[(size_t)me];
+    s.device = c->device;
+    s.aw = f->aw;
+    s.ac = f->ac;
+    s.cap = f->cap;
+    s.fill.assign(P1, 0);
+    for (uint32_t cb = 0; cb < P1; ++cb) s.fill[cb] = (uint32_t)std::min<uint64_t>(f->h_cur[(size_t)cb * stride], f->cap);
+  }
+  if (!p->barrier()) return RFX_E_HIP;
+  const uint32_t lo = (uint32_t)((uint64_t)me * P1 / N), hi = (uint32_t)((uint64_t)(me + 1) * P1 / N);
+  std::vector<uint64_t> tot(P1, 0);
+  uint64_t ncap = 1;
+  for (uint32_t cb = lo; cb < hi; ++cb) {
+    for (int g = 0; g < N; ++g) tot[cb] += p->slot[(size_t)g].fill[cb];
+    ncap = std::max(ncap, tot[cb]);
+  }
+  int rc = RFX_OK;
+  uint64_t *naw = nullptr;
+  uint32_t* nac = nullptr;
+  if (ncap >= (1ull << 32)) rc = RFX_E_RANGE;
+  const uint32_t nb = hi > lo ? hi - lo : 1;
+  if (rc == RFX_OK) {
+    naw = (uint64_t*)dmalloc(c, (size_t)nb * ncap * 8);
+    nac = (uint32_t*)dmalloc(c, (size_t)nb * ncap * 4);
+    if (!naw || !nac) rc = RFX_E_NOMEM;
+  }
+  if (rc == RFX_OK) {
+    std::vector<uint64_t> off(P1, 0);
+    for (int g = 0; g < N && rc == RFX_OK; ++g) {
+      const rfx_peers::Slot& s = p->slot[(size_t)g];
+      for (uint32_t cb = lo; cb < hi && rc == RFX_OK; ++cb) {
+        const uint64_t n = s.fill[cb];
+        if (!n) continue;
+        uint64_t* dw = naw + (size_t)(cb - lo) * ncap + off[cb];
+        uint32_t* dc = nac + (size_t)(cb - lo) * ncap + off[cb];
+        const uint64_t* sw = s.aw + (size_t)cb * s.cap;
+        const uint32_t* sc = s.ac + (size_t)cb * s.cap;
+        hipError_t e;
+        if (s.device == c->device) {  // own share, or another ctx on the same device (how a one-GPU box tests this)
+          e = rfxk::copy_bytes(c, dw, sw, n * 8);
+          if (e == hipSuccess) e = rfxk::copy_bytes(c, dc, sc, n * 4);
+        } else {
+          e = hipMemcpyPeerAsync(dw, c->device, sw, s.device, n * 8, c->stream);
+          if (e == hipSuccess) e = hipMemcpyPeerAsync(dc, c->device, sc, s.device, n * 4, c->stream);
+          if (e != hipSuccess) {  // no peer route: let the runtime stage it
+            (void)hipGetLastError();
+            e = hipMemcpy(dw, sw, n * 8, hipMemcpyDefault);
+            if (e == hipSuccess) e = hipMemcpy(dc, sc, n * 4, hipMemcpyDefault);
+          }
+        }
+        if (e != hipSuccess) rc = hip_fail(e, "rfx peers exchange");
+        off[cb] += n;
+      }
+    }
+    if (rc == RFX_OK && ctx_sync(c) != hipSuccess) rc = RFX_E_HIP;
+  }
+  if (rc != RFX_OK) p->abort();
+  const bool all_ok = p->barrier();  // every pull is complete: the old stores may go
+  if (rc != RFX_OK || !all_ok) {
+    dfree(c, naw);
+    dfree(c, nac);
+    return rc != RFX_OK ? rc : RFX_E_HIP;
+  }
+  dfree(c, f->aw);
+  dfree(c, f->ac);
+  f->aw = naw;
+  f->ac = nac;
+  f->cap = ncap;
+  f->cb_lo = lo;
+  for (uint32_t cb = 0; cb < P1; ++cb) f->h_cur[(size_t)cb * stride] = cb >= lo && cb < hi ? (uint32_t)tot[cb] : 0u;
+  f->h_cur[ncur] = f->h_cur[ncur + 1] = 0;
+  if (upload(c, d_cur, f->h_cur.data(), (ncur + 2) * 4) != hipSuccess) return RFX_E_HIP;
   return RFX_OK;
 }
 
@@ -1773,7 +1949,13 @@ static int msp_emit_queue(rfx_finish* f) {
   uint64_t kmers = 0;
   std::vector<std::vector<uint64_t>> h_bs;
   if (deferred) {
-    const int rc = msp_passes_leaf(f);
+    int rc = msp_passes_leaf(f);
+    if (rc == RFX_OK && t->peers) {
+      uint32_t* d_cur = (uint32_t*)((unsigned long long*)f->bsq + RFX_HISTO_BINS);
+      rc = peers_exchange(f, d_cur, ncur);
+    } else if (rc && t->peers) {
+      t->peers->abort();
+    }
     if (rc) {
       (void)ctx_sync(c);
       msp_emit_drop(f);
@@ -1878,7 +2060,10 @@ static int msp_emit_queue(rfx_finish* f) {
       f->segs_dropped = true;
     }
   }
-  if (f->histo) rfxk::histo_bins(c, f->ac, cur, (uint32_t)cap, d_histo);  // count-of-counts of exactly the survivors
+  // (peers: the store holds coarse bins cb_lo .. only; the kernels index coarse bins absolutely)
+  uint64_t* aw0 = f->aw - (size_t)f->cb_lo * cap;
+  uint32_t* ac0 = f->ac - (size_t)f->cb_lo * cap;
+  if (f->histo) rfxk::histo_bins(c, ac0, cur, (uint32_t)cap, d_histo);  // count-of-counts of exactly the survivors
 
   // ---- survivors -> fine pos bins (<= 1536 expected per bin) -> sorted records ----
   // (a big table has just been waited for: its survivor count is known, the arrays below are exact)
@@ -1905,9 +2090,9 @@ static int msp_emit_queue(rfx_finish* f) {
   uint32_t* fcur2 = bs2 ? (uint32_t*)(bs2 + Pq + 1) : nullptr;
   e = hipMemsetAsync(bs1, 0, z1 + z2, c->stream);
   if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
-  rfxk::surv_hist(c, f->aw, cur, (uint32_t)cap, P2a, cfg1.bin_shift, bs1);
+  rfxk::surv_hist(c, aw0, cur, (uint32_t)cap, P2a, cfg1.bin_shift, bs1);
   rfxk::scan_tail(c, bs1, Pq1);
-  rfxk::part2(c, f->aw, f->bw, bs1, fcur1, P2a, cfg1.bin_shift, cur, (uint32_t)cap, f->ac, f->bc, ~0ull, "k_surv_part2",
+  rfxk::part2(c, aw0, f->bw, bs1, fcur1, P2a, cfg1.bin_shift, cur, (uint32_t)cap, ac0, f->bc, ~0ull, "k_surv_part2",
               nullptr, 0, out_room);
   const uint64_t *sw = f->bw, *sbs = bs1;
   const uint32_t* sc = f->bc;

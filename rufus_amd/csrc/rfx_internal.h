@@ -55,6 +55,7 @@ struct rfx_ctx {
   std::map<size_t, size_t> arena_free;    // offset -> length of free ranges inside [0, arena_mapped)
   bool arena_off = false;                 // VMM unavailable (or RFX_NO_ARENA): size-keyed cache of hipMalloc blocks
   size_t peak_used = 0;
+  std::vector<int> peer_devices;  // rfx_ctx_allow_peers: devices that may read this ctx's memory directly (xGMI)
   // kernels that need more than 64 KB of dynamic LDS opt in once per ctx (= per device: the attribute belongs to the
   // device's copy of the function); a refused opt-in is remembered and fails the next synchronisation
   uint32_t lds_opt_in = 0;
@@ -203,6 +204,8 @@ struct rfx_table {
   int seg_kind;       // what the segments hold: 0 nothing yet, RFX_COUNT_P2L words, RFX_COUNT_MSP records
   std::vector<rfx_pending_add>* pend;
   int shard, n_shards;  // n_shards > 1: keep only the minimizer bins of this shard (rfx_count_set_shard)
+  struct rfx_peers* peers;  // rfx_count_set_peers: table `peer_index` of a group of tables on several devices
+  int peer_index;
   int passes;           // -1: adds count at once; >= 0: adds are deferred, finish runs that many shard passes (0 = plan)
   std::vector<const rfx_reads*>* deferred;  // read blocks of the deferred adds (not owned)
   int pend_error;     // a deferred redo failed: the table cannot be finished

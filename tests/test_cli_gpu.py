@@ -288,6 +288,48 @@ def test_filter_sam_equals_feeder_plus_filter(tmp_path, shape):
         assert open(f"{d}/one.chr", "rb").read() == open(f"{d}/ref.chr", "rb").read()
 
 
+@pytest.mark.parametrize("gpus,k,size", [("0,0", 25, "100M"), ("0,0,0,0,0", 31, "8G"), ("0-0,0,0", 25, "8G")])
+def test_executables_spread_a_sample_over_several_devices(testrun, tmp_path, gpus, k, size):
+    """Row E-cli (runRufus.sh:776-797 calls binaries: the GPUs of a node must be reachable from them): with
+    RUFUS_GPUS naming n devices -- here n contexts on the box's one GPU, the same code path -- `jellyfish count`
+    feeds every device every read block, each counts its minimizer shard, the survivors change hands by output
+    position and the .Jhash is the devices' slices one after the other: the bytes of the one-device run (and of the
+    golden payload).  `RUFUS.Filter` deals its pieces to the devices: the same Mutations.Mate1/2.fastq."""
+    d = str(tmp_path)
+    exp = testrun["expected"]
+    open(f"{d}/c.fq", "wb").write(testrun["Child"][0] + testrun["Child"][1])
+    env = dict(os.environ, RUFUS_GPUS=gpus, RFX_COUNT_HISTO="1")
+    for name, e in (("one", dict(os.environ, RFX_COUNT_HISTO="1")), ("many", env)):
+        r = subprocess.run([f"{BIN}/jellyfish", "count", "--disk", "-m", str(k), "-L", "2", "-s", size, "-t", "4", "-o",
+                            f"{name}.Jhash", "-C", "c.fq"], cwd=d, env=e, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+    assert _payload(f"{d}/one.Jhash") == _payload(f"{d}/many.Jhash") and len(_payload(f"{d}/many.Jhash")) > 100_000
+    assert open(f"{d}/one.Jhash.histo", "rb").read() == open(f"{d}/many.Jhash.histo", "rb").read()
+    if (k, size) == (25, "100M"):
+        assert hashlib.sha256(_payload(f"{d}/many.Jhash")).hexdigest() == exp["samples"]["Child"]["s100M"]["payload_sha256"]
+    # a pipe as the sample (scripts/RunJellyForRUFUS.sh:23-31) and as the output
+    r = subprocess.run(f"cat c.fq | {BIN}/jellyfish count --disk -m {k} -L 2 -s {size} -t 3 -o /dev/stdout -C /dev/stdin | cat > piped.Jhash",
+                       shell=True, cwd=d, env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    assert _payload(f"{d}/piped.Jhash") == _payload(f"{d}/one.Jhash")
+    # a database that is a pipe (process substitution): opened once, header and payload in one pass
+    h = subprocess.run(["bash", "-c", f"{BIN}/jellyfish histo -f <(cat one.Jhash)"], cwd=d, stdout=subprocess.PIPE).stdout
+    assert h == open(f"{d}/one.Jhash.histo", "rb").read()
+    q = subprocess.run(["bash", "-c", f"{BIN}/jellyfish query <(cat one.Jhash) " + "A" * k], cwd=d, stdout=subprocess.PIPE).stdout
+    assert q == subprocess.run([f"{BIN}/jellyfish", "query", "one.Jhash", "A" * k], cwd=d, stdout=subprocess.PIPE).stdout and q
+    if k == 25:
+        open(f"{d}/hl", "w").write(testrun["hashlist"])
+        for i, m in enumerate(testrun["Child"]):
+            open(f"{d}/m{i + 1}.fq", "wb").write(m)
+        for name, e in (("f1", os.environ), ("fn", dict(os.environ, RUFUS_GPUS=gpus))):
+            r = subprocess.run([f"{BIN}/RUFUS.Filter", "hl", "m1.fq", "m2.fq", name, "25", "15", "1", "6"], cwd=d, env=e,
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr
+        for m in (1, 2):
+            a = open(f"{d}/fn.Mutations.Mate{m}.fastq", "rb").read()
+            assert a == open(f"{d}/f1.Mutations.Mate{m}.fastq", "rb").read() and a.count(b"\n") == 4 * 26
+
+
 def test_count_reads_a_named_pipe_and_several_files(testrun, tmp_path):
     d = str(tmp_path)
     os.mkfifo(f"{d}/gen.fq")

@@ -1,6 +1,7 @@
 """Scale path on the GPU: the device generator against its host twin, the multi-block / shard-pass trio
 driver (rufus_amd/wgs.py) against the oracle at sizes the oracle finishes in seconds, and a >= 1 Gb-genome
 trio checked through size-independent properties (BASELINE.json configs[2])."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -372,6 +373,59 @@ def test_table_counts_a_sample_in_shard_passes(ctx, monkeypatch, passes, surv_fr
     t.free()
     for b in blocks:
         b.free()
+
+
+@pytest.mark.parametrize("n_dev,passes,k,surv_frac", [(2, 1, 25, None), (3, 2, 25, "0.002"), (4, 0, 31, None), (8, 1, 27, None)])
+def test_tables_on_several_devices_make_one_sorted_payload(monkeypatch, n_dev, passes, k, surv_frac):
+    """SURVEY 8(e) / row E-cli at the C-ABI: n tables -- here n contexts on the ONE GPU of the box, the code path of n
+    devices (own arena, own stream, copies between contexts) -- are fed the same read blocks; table i counts minimizer
+    shard i (x its own shard passes), the survivors change hands by output position (rfx_count_set_peers), and the n
+    finishes, run concurrently, return slice i of the oracle's (pos,key)-ordered payload: concatenated, THE payload;
+    the histograms add up to the oracle's."""
+    import threading
+    if surv_frac:
+        monkeypatch.setenv("RFX_MSP_SURV_FRAC", surv_frac)
+    sy = capi.Synth.sample(200_000, 0, n_snv=10, seed=77)
+    n_pairs = 20_000
+    seq, _ = sy.text(0, n_pairs)
+    ref = oracle.count(None, k, SIZE, lower=LOWER, reads=[r.tobytes() for r in seq])
+    ctxs = [capi.Context(0) for _ in range(n_dev)]
+    devs = (C.c_int * n_dev)(*([0] * n_dev))
+    for c in ctxs:
+        assert capi.lib().rfx_ctx_allow_peers(c._h, devs, n_dev) == 0
+    peers = capi.lib().rfx_peers_create(n_dev)
+    assert peers
+    tables, blocks = [], []
+    for i, c in enumerate(ctxs):
+        bl = wgs.make_sample(c, sy, n_pairs, 7000, MIN_Q, want_good=False, compact=(i % 2 == 0))
+        t = capi.CountTable(c, k, SIZE)
+        t.set_passes(passes)
+        t.set_peers(peers, i)
+        for b in bl:
+            t.add(b)
+        tables.append(t)
+        blocks.append(bl)
+    out = [None] * n_dev
+
+    def fin(i):
+        out[i] = tables[i].finish(LOWER, want_histo=True)
+
+    th = [threading.Thread(target=fin, args=(i,)) for i in range(n_dev)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join(300)
+    assert all(o is not None for o in out)
+    assert b"".join(rec.payload() for rec, _ in out) == ref.payload()
+    assert sum(len(rec) for rec, _ in out) == len(ref.keys) and sum(1 for rec, _ in out if len(rec)) >= min(n_dev, 2)
+    assert np.array_equal(sum(h for _, h in out), oracle.histo(ref.counts, full=True)[0])
+    for (rec, _), t, bl, c in zip(out, tables, blocks, ctxs):
+        rec.free()
+        t.free()
+        for b in bl:
+            b.free()
+        c.close()
+    capi.lib().rfx_peers_free(peers)
 
 
 @pytest.mark.parametrize("k,passes,refine,bins", [(31, 1, None, None), (31, 3, "18", None), (27, 2, None, "32768"),

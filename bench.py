@@ -449,12 +449,14 @@ def main():
                                 "ms_per_step": f_ms, "algorithmic_bytes_per_step": 61 * reads_filtered // world,
                                 "note": "rank 0's share"} if f_ms else None,
         }
-        pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{args.workload}.json")
-        if os.path.exists(pmc_path):
+        import glob
+        pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_{args.workload}.json")))
+        pmc_path = pmc_files[-1] if pmc_files else ""          # the newest round's counters
+        if pmc_path:
             pmc = json.load(open(pmc_path))
             if pmc.get("genome") in (None, getattr(args, "genome", None)) and "_chain" in pmc:
                 line["roofline"]["traffic"] = pmc["_chain"]["hbm_bytes_per_sample"]
-                line["roofline"]["traffic_source"] = pmc["_chain"].get("source", pmc_path)
+                line["roofline"]["traffic_source"] = os.path.basename(pmc_path) + ": " + pmc["_chain"].get("source", "")
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -37,11 +37,16 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   // `PassThroughSamCheck CHR_FILE | jellyfish count` does (scripts/RunJellyForRUFUS.sh:28-29) -- the sequence of
   // every record counted, the chromosome log written -- without the FASTQ text in between: SURVEY 8 row N1.
   const char* sam_chr = nullptr;
-  enum { OPT_DISK = 1000, OPT_OCL, OPT_TIMING, OPT_TEXT, OPT_SAM };
+  // --spool FILE (not in jellyfish): the bytes of a PIPE input are also written to FILE, so that the
+  // stage that reads the same stream next (RUFUS.Filter on the subject, runRufus.sh:966) reads FILE instead of
+  // running the subject's generator -- `samtools view` of a BAM -- a second time (`RUFUS.Filter --sam CHR HashList FILE ...`).
+  const char* spool_path = nullptr;
+  enum { OPT_DISK = 1000, OPT_OCL, OPT_TIMING, OPT_TEXT, OPT_SAM, OPT_SPOOL };
   static option lo[] = {{"mer-len", 1, 0, 'm'},      {"size", 1, 0, 's'},        {"threads", 1, 0, 't'},
                         {"output", 1, 0, 'o'},       {"counter-len", 1, 0, 'c'}, {"out-counter-len", 1, 0, OPT_OCL},
                         {"canonical", 0, 0, 'C'},    {"disk", 0, 0, OPT_DISK},   {"lower-count", 1, 0, 'L'},
                         {"upper-count", 1, 0, 'U'},  {"timing", 1, 0, OPT_TIMING}, {"text", 0, 0, OPT_TEXT}, {"sam", 1, 0, OPT_SAM},
+                        {"spool", 1, 0, OPT_SPOOL},
                         {"reprobes", 1, 0, 'p'},     {0, 0, 0, 0}};
   optind = 1;
   int ch;
@@ -60,6 +65,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
       case OPT_OCL: out_counter_len = atoi(optarg); break;
       case OPT_TIMING: timing = optarg; break;
       case OPT_SAM: sam_chr = optarg; break;
+      case OPT_SPOOL: spool_path = optarg; break;
       case OPT_TEXT: die("rufus_amd jellyfish: --text output is not on the RUFUS path");
       default: die("Usage: jellyfish count -m K -s SIZE [-C] [-L n] [-U n] [-t T] [-o OUT] [--disk] file...");
     }
@@ -175,12 +181,17 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   {
     for (Input& in : inputs) {
       bool done = false;
-      if (nthreads > 1 || sam_chr) {
+      if (nthreads > 1 || sam_chr || spool_path) {
         if (!ingest) {
           ingest.reset(new CountIngest(nthreads, [&](const StageBlock& b) {
             to_all([&](rfx_ctx* c) { return rfx_reads_upload(c, b.codes, b.acgt, nullptr, b.word_off, b.len, b.n_reads); });
           }));
           ingest->set_sam(sam_chr != nullptr);
+          if (spool_path) {
+            const int sfd = ::open(spool_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (sfd < 0) die(std::string("Can't open spool file '") + spool_path + "'");
+            ingest->set_spool(sfd);
+          }
           if (const char* ev = getenv("RFX_INGEST_PIECE")) ingest->set_piece_bytes((size_t)std::max(1024ll, atoll(ev)));
           trace("count: staging blocks pinned, workers up");
         }
@@ -362,9 +373,15 @@ static int histo_main(int argc, char** argv) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// `jellyfish query [-s FASTA]... DB [mers...]` (jf/sub_commands/query_main.cc:44-51,:110-115), and, SURVEY row N3:
+// SEVERAL databases in one call -- `jellyfish query -s FA -o OUT1 -o OUT2 -o OUT3 DB1 DB2 DB3` writes to OUTi exactly
+// the lines `jellyfish query -s FA DBi` prints.  scripts/Overlap.shorter.sh:265-299 looks the same two k-mer lists up in
+// the subject's and every control's 30x database with one process each (scripts/CheckJellyHashList.sh:12); here the
+// k-mers are parsed, canonicalised and dealt to position ranges once, the device is opened once, and of every database
+// only the ranges that got a k-mer are read.  (One -o, or none, with several databases: one line per k-mer with a
+// count column per database.)  A positional argument after the first that names an existing file is a database.
 static int query_main(int argc, char** argv) {
-  std::vector<const char*> seq_files;
-  const char* out = nullptr;
+  std::vector<const char*> seq_files, outs;
   static option lo[] = {{"sequence", 1, 0, 's'}, {"output", 1, 0, 'o'}, {"load", 0, 0, 'l'}, {"no-load", 0, 0, 'L'},
                         {0, 0, 0, 0}};
   optind = 1;
@@ -372,18 +389,30 @@ static int query_main(int argc, char** argv) {
   while ((ch = getopt_long(argc, argv, "s:o:lL", lo, nullptr)) != -1) {
     switch (ch) {
       case 's': seq_files.push_back(optarg); break;
-      case 'o': out = optarg; break;
+      case 'o': outs.push_back(optarg); break;
       case 'l': case 'L': break;
-      default: die("Usage: jellyfish query [-s FASTA] db [mers...]");
+      default: die("Usage: jellyfish query [-s FASTA] [-o OUT]... db [db...] [mers...]");
     }
   }
   if (optind >= argc) die("Missing database");
+  std::vector<const char*> db_paths{argv[optind]}, mers;
+  for (int i = optind + 1; i < argc; ++i) {
+    if (::access(argv[i], R_OK) == 0) db_paths.push_back(argv[i]);
+    else mers.push_back(argv[i]);
+  }
+  const size_t n_db = db_paths.size();
+  if (outs.size() > 1 && outs.size() != n_db) die("jellyfish query: one -o per database (or a single one)");
   rfx_ctx* ctx = open_ctx();
-  JhashFile db;
-  rfx_records* rec = nullptr;
-  const bool sliced = db.open(argv[optind]);
-  if (!sliced) rec = load_records(ctx, argv[optind], db.h);  // (a pipe: header and payload in one pass)
-  const JhashHeader& h = db.h;
+  std::vector<JhashFile> dbs(n_db);
+  std::vector<rfx_records*> whole(n_db, nullptr);
+  std::vector<bool> sliced(n_db, false);
+  for (size_t d = 0; d < n_db; ++d) {
+    sliced[d] = dbs[d].open(db_paths[d]);
+    if (!sliced[d]) whole[d] = load_records(ctx, db_paths[d], dbs[d].h);  // (a pipe: header and payload in one pass)
+    if (dbs[d].h.k != dbs[0].h.k || dbs[d].h.canonical != dbs[0].h.canonical)
+      die("jellyfish query: the databases of one call must have the same mer length and canonical flag");
+  }
+  const JhashHeader& h = dbs[0].h;
   const int k = h.k;
   const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
   std::vector<uint64_t> keys;
@@ -406,52 +435,75 @@ static int query_main(int argc, char** argv) {
     });
     if (!ok) die("Unsupported format");
   }
-  for (int i = optind + 1; i < argc; ++i) {  // query_from_cmdline
+  for (const char* m : mers) {  // query_from_cmdline
     uint64_t key;
-    if ((int)strlen(argv[i]) != k || !text_to_key(argv[i], (size_t)k, key)) {
-      fprintf(stderr, "Invalid mer '%s'\n", argv[i]);
+    if ((int)strlen(m) != k || !text_to_key(m, (size_t)k, key)) {
+      fprintf(stderr, "Invalid mer '%s'\n", m);
       continue;
     }
     keys.push_back(h.canonical ? std::min(key, revcomp_key(key, k)) : key);
   }
-  std::vector<uint32_t> counts(keys.size() + 1);
-  if (!sliced) {
-    if (rfx_query(rec, keys.data(), keys.size(), counts.data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
-  } else if (!keys.empty() && db.n) {
+  if (keys.size() > 0xFFFFFFFFull) die("rufus_amd jellyfish query: too many k-mers in one call");
+  std::vector<std::vector<uint32_t>> counts(n_db, std::vector<uint32_t>(keys.size() + 1, 0));
+  std::vector<uint64_t> key_pos;  // position of every query, computed once per hash function
+  for (size_t d = 0; d < n_db; ++d) {
+    const JhashHeader& hd = dbs[d].h;
+    JhashFile& db = dbs[d];
+    if (!sliced[d]) {
+      if (rfx_query(whole[d], keys.data(), keys.size(), counts[d].data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+      continue;
+    }
+    if (keys.empty() || !db.n) continue;
     // The database stays on disk: it is cut into position ranges of ~64 M records (RFX_QUERY_SLICE_RECORDS), the
     // queries are dealt to the ranges by their own position, and only ranges that got queries are read -- a few
-    // hundred MB of HBM whatever the database size, and several queries can run side by side
-    // (scripts/Overlap.shorter.sh:265-299 starts them with &).
+    // hundred MB of HBM whatever the database size.
     uint64_t per = 64ull << 20;
     if (const char* ev = getenv("RFX_QUERY_SLICE_RECORDS")) per = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
     const uint64_t S = std::max<uint64_t>(1, (db.n + per - 1) / per);
+    if (key_pos.empty() || d == 0 || hd.lsize != dbs[d - 1].h.lsize || hd.cols != dbs[d - 1].h.cols) {
+      key_pos.resize(keys.size());
+      for (size_t i = 0; i < keys.size(); ++i) key_pos[i] = rfx_jf_pos(hd.cols.data(), hd.k, hd.lsize, keys[i]);
+    }
     std::vector<std::vector<uint32_t>> in_slice(S);
-    if (keys.size() > 0xFFFFFFFFull) die("rufus_amd jellyfish query: too many k-mers in one call");
-    for (size_t i = 0; i < keys.size(); ++i)
-      in_slice[slice_of(rfx_jf_pos(h.cols.data(), h.k, h.lsize, keys[i]), S, h.lsize)].push_back((uint32_t)i);
+    for (size_t i = 0; i < keys.size(); ++i) in_slice[slice_of(key_pos[i], S, hd.lsize)].push_back((uint32_t)i);
     std::vector<uint64_t> sub;
     std::vector<uint32_t> got;
     for (uint64_t sidx = 0; sidx < S; ++sidx) {
       if (in_slice[sidx].empty()) continue;
-      const uint64_t i0 = sidx == 0 ? 0 : db.lower_bound_pos(slice_start(sidx, S, h.lsize));
-      const uint64_t i1 = sidx + 1 == S ? db.n : db.lower_bound_pos(slice_start(sidx + 1, S, h.lsize));
+      const uint64_t i0 = sidx == 0 ? 0 : db.lower_bound_pos(slice_start(sidx, S, hd.lsize));
+      const uint64_t i1 = sidx + 1 == S ? db.n : db.lower_bound_pos(slice_start(sidx + 1, S, hd.lsize));
       if (i1 == i0) continue;  // an empty range: its queries count 0
       rfx_records* part = db.load(ctx, i0, i1);
       sub.clear();
       for (uint32_t qi : in_slice[sidx]) sub.push_back(keys[qi]);
       got.assign(sub.size() + 1, 0);
       if (rfx_query(part, sub.data(), sub.size(), got.data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
-      for (size_t j = 0; j < sub.size(); ++j) counts[in_slice[sidx][j]] = got[j];
+      for (size_t j = 0; j < sub.size(); ++j) counts[d][in_slice[sidx][j]] = got[j];
       rfx_records_free(part);
     }
   }
-  FILE* f = out ? fopen(out, "w") : stdout;
-  if (!f) die(std::string("Error opening output file '") + out + "'");
-  for (size_t i = 0; i < keys.size(); ++i) fprintf(f, "%s %u\n", key_to_text(keys[i], k).c_str(), counts[i]);
-  if (out) fclose(f);
+  if (outs.size() > 1) {  // one file per database: the lines a one-database call prints
+    for (size_t d = 0; d < n_db; ++d) {
+      FILE* f = fopen(outs[d], "w");
+      if (!f) die(std::string("Error opening output file '") + outs[d] + "'");
+      for (size_t i = 0; i < keys.size(); ++i) fprintf(f, "%s %u\n", key_to_text(keys[i], k).c_str(), counts[d][i]);
+      fclose(f);
+    }
+  } else {
+    FILE* f = outs.empty() ? stdout : fopen(outs[0], "w");
+    if (!f) die(std::string("Error opening output file '") + outs[0] + "'");
+    for (size_t i = 0; i < keys.size(); ++i) {
+      fputs(key_to_text(keys[i], k).c_str(), f);
+      for (size_t d = 0; d < n_db; ++d) fprintf(f, " %u", counts[d][i]);
+      fputc('\n', f);
+    }
+    if (!outs.empty()) fclose(f);
+  }
   leave(0);
-  db.close();
-  if (rec) rfx_records_free(rec);
+  for (size_t d = 0; d < n_db; ++d) {
+    dbs[d].close();
+    if (whole[d]) rfx_records_free(whole[d]);
+  }
   rfx_close(ctx);
   return 0;
 }

@@ -113,7 +113,10 @@ class CountIngest {
     uint64_t lo = 0, hi = 0;   // parses the records that START inside the range
     uint64_t fsize = 0;
     uint64_t seq = 0;          // SAM mode: position of the piece in the stream (the chromosome log is stitched in order)
+    uint64_t spool_off = 0;    // set_spool: where the piece's bytes go in the spool file
   };
+  int spool_fd_ = -1;          // set_spool: the stream is also written to this file, piece by piece, by the workers
+  uint64_t spooled_ = 0;
   std::deque<Piece> work_;
   std::deque<int> ready_, free_;
   std::deque<std::vector<char>*> pool_;
@@ -337,6 +340,19 @@ class CountIngest {
       if (pc.fd >= 0) parse_range(pc, buf);
       else if (sam_) parse_piece_sam(pc);
       else parse_piece(pc);
+      if (spool_fd_ >= 0 && pc.fd < 0 && pc.owner) {  // a piece of a pipe: its bytes, at their place in the stream
+        const char* p = pc.b;
+        size_t len = (size_t)(pc.e - pc.b);
+        off_t at = (off_t)pc.spool_off;
+        while (len) {
+          const ssize_t w = ::pwrite(spool_fd_, p, len, at);
+          if (w < 0 && errno == EINTR) continue;
+          if (w <= 0) die(std::string("write error on the spool file: ") + strerror(errno));
+          p += w;
+          len -= (size_t)w;
+          at += w;
+        }
+      }
       {
         std::lock_guard<std::mutex> g(mu_);
         if (pc.owner) pool_.push_back(pc.owner);
@@ -493,6 +509,11 @@ class CountIngest {
 
   // A whole regular file, mapped.  Returns false if it is not strict 4-line FASTQ (nothing consumed).
   void set_sam(bool on) { sam_ = on; }
+  // The bytes of a PIPE input are also written to `fd` (a regular file), so that the stage that reads the same stream
+  // next -- RUFUS.Filter after the subject's count, runRufus.sh:966 after scripts/RunJellyForRUFUS.sh:28 -- need not run
+  // the generator (samtools view of a BAM) a second time.  Written piece by piece by the parser threads (pwrite).
+  void set_spool(int fd) { spool_fd_ = fd; }
+  uint64_t spooled_bytes() const { return spooled_; }
   // PassThroughSamCheck's side file: "notachr", then the name of every run of equal RNAME, in stream order
   std::vector<std::string> chr_log() {
     std::vector<std::string> out{"notachr"};
@@ -643,6 +664,8 @@ class CountIngest {
       {
         Piece pc{d, d + cut, buf};
         pc.seq = next_seq_++;
+        pc.spool_off = spooled_;
+        spooled_ += cut;
         push_piece(pc);
       }
       buf = next;

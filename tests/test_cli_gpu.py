@@ -330,6 +330,86 @@ def test_executables_spread_a_sample_over_several_devices(testrun, tmp_path, gpu
             assert a == open(f"{d}/f1.Mutations.Mate{m}.fastq", "rb").read() and a.count(b"\n") == 4 * 26
 
 
+def test_query_looks_a_kmer_list_up_in_several_databases_at_once(testrun, tmp_path):
+    """SURVEY row N3 (scripts/Overlap.shorter.sh:265-299: the same k-mer lists looked up in the subject's and every
+    control's database, one `jellyfish query` process each): `jellyfish query -s FA -o O1 -o O2 -o O3 DB1 DB2 DB3`
+    writes to Oi the bytes `jellyfish query -s FA DBi` prints -- with the databases cut into many position ranges too --,
+    the counts are the oracle's, and without -o the counts come as columns."""
+    import oracle
+    d = str(tmp_path)
+    names = ("Child", "Mother", "Father")
+    for s in names:
+        open(f"{d}/{s}.fq", "wb").write(testrun[s][0] + testrun[s][1])
+        r = sh([f"{BIN}/jellyfish", "count", "-m", "25", "-L", "2", "-s", "100M", "-t", "4", "-o", f"{s}.Jhash", "-C", f"{s}.fq"], d)
+        assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(2)
+    kmers = [ln.split()[0] for ln in testrun["merge"].splitlines()][:200]
+    recs = testrun["Mother"][0].split(b"\n")
+    kmers += [recs[4 * i + 1][10:35].decode() for i in range(300) if b"N" not in recs[4 * i + 1][10:35]]
+    kmers += ["".join(rng.choice(list("ACGT"), 25)) for _ in range(200)]
+    open(f"{d}/q.fa", "w").write("".join(f">{i}\n{km}\n" for i, km in enumerate(kmers)))
+    single = {}
+    for s in names:
+        r = sh([f"{BIN}/jellyfish", "query", "-s", "q.fa", f"{s}.Jhash"], d)
+        assert r.returncode == 0, r.stderr
+        single[s] = r.stdout
+        assert single[s].count(b"\n") == len(kmers)
+    for env in (os.environ, dict(os.environ, RFX_QUERY_SLICE_RECORDS="777")):
+        r = subprocess.run([f"{BIN}/jellyfish", "query", "-s", "q.fa", "-o", "o1", "-o", "o2", "-o", "o3"] +
+                           [f"{s}.Jhash" for s in names], cwd=d, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0 and r.stdout == b"", r.stderr
+        for i, s in enumerate(names):
+            assert open(f"{d}/o{i + 1}", "rb").read() == single[s]
+    r = sh([f"{BIN}/jellyfish", "query", "-s", "q.fa"] + [f"{s}.Jhash" for s in names] + ["A" * 25], d)
+    assert r.returncode == 0, r.stderr
+    cols = [ln.split() for ln in r.stdout.decode().splitlines()]
+    assert len(cols) == len(kmers) + 1 and all(len(c) == 4 for c in cols)
+    for j, s in enumerate(names):
+        want = [ln.split()[1] for ln in single[s].decode().splitlines()]
+        assert [c[1 + j] for c in cols[:-1]] == want
+        rec = oracle.count([testrun[s][0] + testrun[s][1]], 25, 100_000_000, lower=2)
+        table = dict(zip(rec.keys.tolist(), rec.counts.tolist()))
+        for c in cols[:-1]:
+            key = min(oracle.jf_encode(c[0]), oracle.jf_encode(c[0].translate(str.maketrans("ACGT", "TGCA"))[::-1]))
+            assert int(c[1 + j]) == table.get(key, 0)
+    assert sum(int(c[1]) > 0 for c in cols) > 200
+
+
+def test_subject_stream_is_ingested_once_through_a_spool(tmp_path):
+    """the subject's generator runs ONCE.  `jellyfish count --sam CHR --spool FILE` counts the SAM pipe
+    (scripts/RunJellyForRUFUS.sh:28) and leaves its bytes in FILE (written piece by piece by the parser threads);
+    `RUFUS.Filter --sam CHR HashList FILE ...` then reads FILE instead of a second `samtools view` (runRufus.sh:966).
+    The spool is the stream byte for byte, the count is the no-spool count, and the pulled pairs are those of the
+    reference route (feeder -> two FASTQ streams -> filter) on a second run of the generator."""
+    from tests.test_cli_host import make_sam
+    d = str(tmp_path)
+    sam = make_sam(4000, seed=21)
+    open(f"{d}/in.sam", "wb").write(sam)
+    env = dict(os.environ, RFX_INGEST_PIECE="20000")
+    cmd = [f"{BIN}/jellyfish", "count", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "5", "-C"]
+    r = subprocess.run(cmd + ["--sam", "a.chr", "--spool", "spool.sam", "-o", "a.Jhash", "/dev/stdin"], cwd=d, env=env, input=sam,
+                       stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    assert open(f"{d}/spool.sam", "rb").read() == sam
+    r = subprocess.run(cmd + ["--sam", "b.chr", "-o", "b.Jhash", "in.sam"], cwd=d, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    assert _payload(f"{d}/a.Jhash") == _payload(f"{d}/b.Jhash") and open(f"{d}/a.chr").read() == open(f"{d}/b.chr").read()
+    lines = [ln.split(b"\t") for ln in sam.split(b"\n") if ln.count(b"\t") >= 10]
+    rng = np.random.default_rng(4)
+    kmers = [lines[j][9][30:55] for j in rng.choice(len(lines), 40, replace=False) if set(lines[j][9][30:55]) <= set(b"ACGT")]
+    open(f"{d}/hl", "wb").write(b"".join(km + b" 9\n" for km in kmers))
+    r = subprocess.run([f"{BIN}/RUFUS.Filter", "--sam", "f.chr", "hl", "spool.sam", "one", "25", "15", "1", "4"], cwd=d,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(f"{BIN}/PassThroughSamCheck.stranded two.chr two < in.sam > two.log && "
+                       f"{BIN}/RUFUS.Filter hl two.mate1.fastq two.mate2.fastq two 25 15 1 4", shell=True, cwd=d,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    for m in (1, 2):
+        got = open(f"{d}/one.Mutations.Mate{m}.fastq", "rb").read()
+        assert got == open(f"{d}/two.Mutations.Mate{m}.fastq", "rb").read() and got.count(b"\n") >= 4 * 15
+
+
 def test_count_reads_a_named_pipe_and_several_files(testrun, tmp_path):
     d = str(tmp_path)
     os.mkfifo(f"{d}/gen.fq")

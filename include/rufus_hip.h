@@ -75,7 +75,8 @@ int rfx_pack_reads(const char* seq, const char* qual, const uint64_t* off, uint3
                    uint32_t* len /* n_reads */);
 
 /* The same packing for reads that lie scattered in a text buffer (FASTQ parsed in place): read i = seq_len[i]
- * bytes at base + seq_start[i], qualities (RFX_PACK_FILTER only) as many bytes at base + qual_start[i].
+ * bytes at base + seq_start[i], qualities (RFX_PACK_FILTER only) as many bytes at base + qual_start[i] (byte
+ * distances modulo 2^64: a span may lie in another allocation than `base`, e.g. a rewritten copy of the read).
  * Single-threaded, so that a caller can pack disjoint ranges of one block from several threads: word_off[0] is
  * an INPUT (first word of this range in the block); word_off[1..n] and len[0..n) are written, codes / acgt / good
  * are indexed by those offsets. */

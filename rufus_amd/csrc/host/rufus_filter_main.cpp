@@ -47,6 +47,7 @@ struct Rec {
 struct SPiece {
   std::vector<char> text;  // [0, size): SAM lines; behind them the printed form of reverse-strand records
   size_t size = 0;
+  const char* mapped = nullptr;  // a regular input file: the lines lie in its mapping, `text` only holds the printed forms
   std::vector<Rec> recs;
   std::vector<std::string> chr_runs;
   std::vector<uint64_t> mask;  // hit bit per record
@@ -179,7 +180,52 @@ static int run(int argc, char** argv) {
   bool input_end = false;
   uint64_t n_pieces = 0;
   size_t in_flight = 0;
+  // A regular file (the spool `jellyfish count --spool` left, a SAM file): mapped and cut at line ends, no copy -- one
+  // reader thread copying out of the page cache gave 5.8 GB/s, less than the helpers parse.
+  const char* map = nullptr;
+  size_t map_size = 0;
+  {
+    struct stat sb;
+    if (fd != 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0 && !getenv("RFX_FILTER_NO_MMAP")) {
+      void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+      if (m != MAP_FAILED) {
+        (void)madvise(m, (size_t)sb.st_size, MADV_SEQUENTIAL);
+        map = (const char*)m;
+        map_size = (size_t)sb.st_size;
+      }
+    }
+  }
   std::thread reader([&] {
+    if (map) {
+      size_t at = 0;
+      while (at < map_size) {
+        size_t end = std::min(map_size, at + PIECE);
+        if (end < map_size) {
+          const char* nl = (const char*)memchr(map + end, '\n', map_size - end);
+          end = nl ? (size_t)(nl - map) + 1 : map_size;
+        }
+        SPiece* pc = nullptr;
+        {
+          std::unique_lock<std::mutex> g(mu);
+          cv.wait(g, [&] { return in_flight < MAX_IN_FLIGHT; });
+          if (!spare.empty()) { pc = spare.front(); spare.pop_front(); }
+          ++in_flight;
+        }
+        if (!pc) pc = new SPiece();
+        pc->mapped = map + at;
+        pc->size = end - at;
+        if (pc->text.size() < 2 * pc->size + 64) pc->text.resize(2 * pc->size + 64);  // the printed forms
+        at = end;
+        std::lock_guard<std::mutex> g(mu);
+        pc->seq = n_pieces++;
+        todo.push_back(pc);
+        cv.notify_all();
+      }
+      std::lock_guard<std::mutex> g(mu);
+      input_end = true;
+      cv.notify_all();
+      return;
+    }
     std::vector<char> carry;
     bool eof = false;
     while (!eof) {
@@ -191,6 +237,7 @@ static int run(int argc, char** argv) {
         ++in_flight;
       }
       if (!pc) pc = new SPiece();
+      pc->mapped = nullptr;
       size_t fill = carry.size();
       if (pc->text.size() < fill + PIECE + (1u << 20)) pc->text.resize(fill + PIECE + (1u << 20));
       memcpy(pc->text.data(), carry.data(), fill);
@@ -261,9 +308,11 @@ static int run(int argc, char** argv) {
       pc.recs.clear();
       pc.chr_runs.clear();
       pc.waited.clear();
-      char* base = pc.text.data();
+      // (offsets handed to rfx_pack_spans are byte distances from `base`, modulo 2^64: the printed forms of a mapped
+      // piece lie in another allocation than its lines)
+      const char* base = pc.mapped ? pc.mapped : pc.text.data();
       const char *p = base, *e = base + pc.size;
-      char* side = base + pc.size;  // printed forms go here
+      char* side = pc.mapped ? pc.text.data() : pc.text.data() + pc.size;  // printed forms go here
       const char* cur = nullptr;
       size_t cur_len = 0;
       uint64_t words = 0;
@@ -301,14 +350,14 @@ static int run(int argc, char** argv) {
         so.resize(n); qo.resize(n); sl.resize(n);
         for (size_t i = 0; i < n; ++i) {
           const Rec& r = pc.recs[i];
-          so[i] = (uint64_t)(r.seq - base);
+          so[i] = (uint64_t)((uintptr_t)r.seq - (uintptr_t)base);
           sl[i] = r.seq_len;
           if (r.qual_len >= r.seq_len) {
-            qo[i] = (uint64_t)(r.qual - base);
+            qo[i] = (uint64_t)((uintptr_t)r.qual - (uintptr_t)base);
           } else {  // a quality string shorter than its read: the missing characters are bad ('\0'), as in the file route
             memcpy(side, r.qual, r.qual_len);
             memset(side + r.qual_len, 0, r.seq_len - r.qual_len);
-            qo[i] = (uint64_t)(side - base);
+            qo[i] = (uint64_t)((uintptr_t)side - (uintptr_t)base);
             side += r.seq_len;
           }
         }

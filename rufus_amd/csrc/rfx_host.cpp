@@ -421,8 +421,9 @@ int rfx_pack_spans(const char* base, const uint64_t* seq_start, const uint32_t* 
     word_off[r] = (uint32_t)w;
     len[r] = L;
     if (w + (L + 31) / 32 > 0xFFFFFFFFull) return RFX_E_RANGE;
-    const int rc = g_pack_one((const unsigned char*)base + seq_start[r],
-                              want_filter ? (const signed char*)base + qual_start[r] : nullptr, L, min_q, want_count,
+    // (offsets are byte distances from `base` modulo 2^64: a span may lie in another allocation than `base`)
+    const int rc = g_pack_one((const unsigned char*)((uintptr_t)base + (uintptr_t)seq_start[r]),
+                              want_filter ? (const signed char*)((uintptr_t)base + (uintptr_t)qual_start[r]) : nullptr, L, min_q, want_count,
                               want_filter, codes + w, acgt ? acgt + w : nullptr, good ? good + w : nullptr);
     if (rc) return rc;
     w += (L + 31) / 32;

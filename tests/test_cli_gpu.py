@@ -277,6 +277,14 @@ def test_filter_sam_equals_feeder_plus_filter(tmp_path, shape):
             got = open(f"{d}/one.Mutations.Mate{m}.fastq", "rb").read()
             assert got == open(f"{d}/two.Mutations.Mate{m}.fastq", "rb").read() and got.count(b"\n") >= 4 * 15
         assert open(f"{d}/one.chr", "rb").read() == open(f"{d}/two.chr", "rb").read()
+    # ... and from a regular file (mapped, cut at line ends without a copy; RFX_FILTER_NO_MMAP: read like a pipe)
+    for e in (env, dict(env, RFX_FILTER_NO_MMAP="1")):
+        r = subprocess.run([f"{BIN}/RUFUS.Filter", "--sam", "file.chr", "hl", "in.sam", "file", "25", "15", "1", "3"], cwd=d, env=e,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr
+        for m in (1, 2):
+            assert open(f"{d}/file.Mutations.Mate{m}.fastq", "rb").read() == open(f"{d}/two.Mutations.Mate{m}.fastq", "rb").read()
+        assert open(f"{d}/file.chr", "rb").read() == open(f"{d}/two.chr", "rb").read()
     ref = os.path.join(ROOT, "oracle", "_ref")
     if os.path.exists(f"{ref}/RUFUS.Filter") and shape == "sorted":     # (the reference filter needs whole quality lines)
         r = subprocess.run(f"{ref}/PassThroughSamCheck.stranded ref.chr ref < in.sam > ref.log && "

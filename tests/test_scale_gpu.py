@@ -290,6 +290,10 @@ def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs, k=K):
         samples = [wgs.make_sample(c, sy, p1 - p0, block_pairs, MIN_Q, want_good=(i == 0), first_pair=p0)
                    for i, sy in enumerate(sys_)]
         trio = wgs.WgsTrio(c, k, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes, group=dist.group.WORLD)
+        # the routine bench.py runs after its timed region, here over the two ranks: verified records, probes of the hash
+        # list in every shard of every rank (all-reduced), the sampled block
+        chk = wgs.self_check(c, trio, samples, sys_, trio.run(samples), p1 - p0, MIN_Q, sample_pairs=3000)
+        assert chk["order_pos_count_violations"] == 0 and chk["mutant_in_controls"] == 0 and chk["mutant_in_subject"] > 0
         res = trio.run(samples, keep_shard_records=True)
         recs = [[tuple(a.tolist() for a in shard[si].get()) for shard in res["shard_records"]] for si in range(3)]
         pulled = np.concatenate([np.flatnonzero(_pairs_of(m, b.n)) + off for m, b, off in

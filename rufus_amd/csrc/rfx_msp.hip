@@ -22,6 +22,8 @@
 //                output records (sizes are exact: no compaction pass).
 //
 // The result is the same sorted record list (jf/include/jellyfish/sorted_dumper.hpp:80-112 order).
+#include <type_traits>
+
 #include "rfx_devutil.h"
 #include "rfx_internal.h"
 
@@ -156,10 +158,12 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   #pragma unroll
         for (int i = WL - 3; i >= 0; --i) sfx[i] = min(a[i], sfx[i + 1]);
         uint32_t pm = ~0u;
-  #pragma unroll
-        for (int b = 0; b < P1_S; ++b) {
-          if (p0 + b < lenp) {
-            const bool real = p0 + b < len;
+        // one base of every lane's read.  FAST: the whole phase lies inside every read of the wave (all but the last phase of
+        // uniform reads): no per-lane bounds checks
+        auto base_step = [&](auto fast_tag, const int b) {
+          constexpr bool FAST = decltype(fast_tag)::value;
+          if (FAST || p0 + b < lenp) {
+            const bool real = FAST || p0 + b < len;
             const uint32_t code = real ? (uint32_t)cur_w & 3u : 0u;
             const bool valid = real && (cur_m & 1u);
             cur_w >>= 2;
@@ -238,13 +242,18 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
               if (HMODE == 1 && mine) atomicAdd(&s_fine[run_bin], 1u);
               run_n = 0;
             }
-            if (kvalid) {
-              if (!run_n) run_h = mh;
-              ++run_n;
-            }
+            run_h = kvalid && !run_n ? mh : run_h;  // (selects, not branches: two instructions instead of a saved exec mask)
+            run_n += kvalid ? 1 : 0;
             if (WIDE) hist_hi = (hist_hi << 2) | (uint32_t)(hist >> 62);
             hist = (hist << 2) | code;
           }
+        };
+        if (__all((int)(p0 + P1_S <= len))) {
+  #pragma unroll
+          for (int b = 0; b < P1_S; ++b) base_step(std::true_type(), b);
+        } else {
+  #pragma unroll
+          for (int b = 0; b < P1_S; ++b) base_step(std::false_type(), b);
         }
   #pragma unroll
         for (int i = 0; i < WL - 1; ++i) a[i] = a[i + P1_S];

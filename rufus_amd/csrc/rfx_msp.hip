@@ -179,13 +179,14 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
             // further bit of that hash is then common to the record's k-mers, which is what lets
             // k_slice_tag refine the partition later without separating instances of a k-mer.
             const uint32_t mh = min(sfx[b], pm);
-            if (run_n && (!kvalid || mh != run_h || run_n == MSP_NMAX)) {
+            // (bitwise, not short-circuit: one exec mask instead of three nested ones)
+            if ((run_n != 0) & (!kvalid | (mh != run_h) | (run_n == MSP_NMAX))) {
               // close the run that ended at the previous base: `hist` still ends there
               const uint32_t run_bin = msp_bin(run_h, bin_bits);
   #ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
               const bool mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
   #else
-              const bool mine = run_bin >= bin_lo && run_bin < bin_hi;  // shard passes: other bins are not ours
+              const bool mine = run_bin - bin_lo < bin_hi - bin_lo;  // shard passes: other bins are not ours (unsigned: one compare)
   #endif
               if (HMODE != 1 && mine) {
                 const int L = k + run_n - 1;

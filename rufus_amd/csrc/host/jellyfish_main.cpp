@@ -130,6 +130,8 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     if (!any_stream && known_bytes > min_bytes && !getenv("RFX_NO_PREALLOC"))
       prealloc.start(out, (uint64_t)((double)known_bytes * frac));
   }
+  if (spool_path && (!any_stream || inputs.size() != 1))
+    die("rufus_amd jellyfish count: --spool copies ONE piped input; a regular file can be given to the next stage as it is");
   unsigned nthreads = (unsigned)std::max(1, threads);
   nthreads = std::min(nthreads, rfx_host_cpus());  // -t 40 on a 16-CPU cgroup: 16 parsers
   if (const char* ev = getenv("RFX_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(ev));

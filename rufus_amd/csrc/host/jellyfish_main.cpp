@@ -231,6 +231,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
           }
           head.resize(got);
           done = got == 0 || ingest->feed_stream(in.fd, head);
+          if (!done && spool_path) die("rufus_amd jellyfish count: --spool needs SAM (--sam) or strict 4-line FASTQ on the pipe");
           if (!done) {
             LineReader lr;
             lr.preload(head.data(), head.size());

@@ -418,6 +418,54 @@ def test_subject_stream_is_ingested_once_through_a_spool(tmp_path):
         assert got == open(f"{d}/two.Mutations.Mate{m}.fastq", "rb").read() and got.count(b"\n") >= 4 * 15
 
 
+def test_round3_tools_on_edge_inputs(testrun, tmp_path):
+    """Corners of the round-3 additions: `RUFUS.Filter --sam` on an empty stream, on lines with too few fields, with
+    HashCountThreshold 2 (both against the two-process route); `jellyfish count --spool` on a FASTQ pipe; one of
+    several `jellyfish query` databases given as a pipe; --spool refused where it cannot work."""
+    from tests.test_cli_host import make_sam
+    d = str(tmp_path)
+    sam = make_sam(1500, seed=33)
+    lines = [ln.split(b"\t") for ln in sam.split(b"\n") if ln.count(b"\t") >= 10]
+    kmers = []
+    for f in lines[::40]:
+        sq = f[9]
+        kmers += [sq[a:a + 25] for a in (20, 21, 60) if set(sq[a:a + 25]) <= set(b"ACGT") and len(sq) >= a + 25]
+    open(f"{d}/hl", "wb").write(b"".join(km + b" 9\n" for km in kmers))
+    broken = sam + b"too\tfew\tfields\n" + b"x\t0\tchr1\t1\n"
+    for name, data, thr in (("empty", b"", "1"), ("t2", broken, "2")):
+        open(f"{d}/{name}.sam", "wb").write(data)
+        r = subprocess.run([f"{BIN}/RUFUS.Filter", "--sam", f"{name}.chr", "hl", "stdin", f"{name}", "25", "15", thr, "3"], cwd=d,
+                           input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run(f"{BIN}/PassThroughSamCheck.stranded {name}2.chr {name}2 < {name}.sam > /dev/null && "
+                           f"{BIN}/RUFUS.Filter hl {name}2.mate1.fastq {name}2.mate2.fastq {name}2 25 15 {thr} 3", shell=True, cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode == 0, r.stderr
+        for m in (1, 2):
+            assert open(f"{d}/{name}.Mutations.Mate{m}.fastq", "rb").read() == open(f"{d}/{name}2.Mutations.Mate{m}.fastq", "rb").read()
+        assert open(f"{d}/{name}.chr", "rb").read() == open(f"{d}/{name}2.chr", "rb").read()
+    assert open(f"{d}/empty.chr").read() == "notachr\n" and os.path.getsize(f"{d}/empty.Mutations.Mate1.fastq") == 0
+    assert open(f"{d}/t2.Mutations.Mate1.fastq", "rb").read().count(b"\n") // 4 > 0
+    # --spool on a FASTQ pipe
+    fq = testrun["Mother"][0] + testrun["Mother"][1]
+    cmd = [f"{BIN}/jellyfish", "count", "-m", "25", "-L", "2", "-s", "100M", "-t", "4", "-C"]
+    r = subprocess.run(cmd + ["--spool", "m.spool", "-o", "m1.Jhash", "/dev/stdin"], cwd=d, input=fq, stderr=subprocess.PIPE,
+                       env=dict(os.environ, RFX_INGEST_PIECE="30000"))
+    assert r.returncode == 0, r.stderr
+    assert open(f"{d}/m.spool", "rb").read() == fq
+    open(f"{d}/m.fq", "wb").write(fq)
+    r = subprocess.run(cmd + ["-o", "m2.Jhash", "m.fq"], cwd=d, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and _payload(f"{d}/m1.Jhash") == _payload(f"{d}/m2.Jhash")
+    r = subprocess.run(cmd + ["--spool", "x.spool", "-o", "m3.Jhash", "m.fq"], cwd=d, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"--spool" in r.stderr
+    # several databases, one of them a pipe
+    q = subprocess.run(["bash", "-c", f"{BIN}/jellyfish query m1.Jhash <(cat m2.Jhash) " + fq.split(b"\n")[1][:25].decode()], cwd=d,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert q.returncode == 0, q.stderr
+    f = q.stdout.split()
+    assert len(f) == 3 and f[1] == f[2] and int(f[1]) >= 2
+
+
 def test_count_reads_a_named_pipe_and_several_files(testrun, tmp_path):
     d = str(tmp_path)
     os.mkfifo(f"{d}/gen.fq")

@@ -394,7 +394,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
   __shared__ uint64_t s_pbase[P1_BINS];
   __shared__ uint64_t s_lk[LIST];
   __shared__ uint32_t s_lc[LIST];
-  __shared__ uint32_t s_nd, s_ovf, s_nl;
+  __shared__ uint32_t s_nd, s_ovf, s_nl, s_ns;  // s_nl: packed cache records; s_ns: survivors in the list
   // WIDE: plane value of the cached record (<= 6 bases = 12 bits) | 0x8000 once published; 16 bits so that it fits
   // beside the full-size tables (157 of the 160 KB)
   __shared__ uint16_t s_rx[WIDE ? RC : 1];
@@ -442,6 +442,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         s_nd = 0;
         s_ovf = 0;
         s_nl = 0;
+        s_ns = 0;
       }
       __syncthreads();
       TM(8);
@@ -599,10 +600,8 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         // round trips of a record's k-mers overlap instead of queueing in one lane
         for (uint32_t i = threadIdx.x; i < MSP_NMAX * nrec; i += BLK)
           insert_kmer(s_rk[i >> 2], WIDE ? s_rx[i >> 2] : 0u, (int)(i & 3u), s_rc[i >> 2]);
-        __syncthreads();
-        if (threadIdx.x == 0) s_nl = 0;
       }
-      __syncthreads();
+      __syncthreads();  // (the survivor list has its own counter, s_ns: no reset in between, one barrier instead of two)
       TM(11);
       TMC(20, s_ovf != 0);
       TMC(21, 1);
@@ -611,9 +610,10 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         // Survivors are few (a twelfth of the slots on 30x data): gather them into a dense list first so
         // that w = T * key (7 LDS table reads) and the scattered store run on full waves, not on the
         // odd lane of every wave that scans the table.
-        auto flush = [&]() {
+        // last: the barrier after the round covers the reset of the counters
+        auto flush = [&](bool last) {
           __syncthreads();
-          const uint32_t nl = s_nl;
+          const uint32_t nl = s_ns;
           for (uint32_t i = threadIdx.x; i < nl; i += BLK) {
             uint64_t w = gf2_mul(g_lut, s_lk[i], ntab);  // 14 KB table, L1-resident; only survivors get here
             const uint64_t pos = w >> sel_bits;
@@ -646,9 +646,13 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
           }
           __syncthreads();
           if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
-          if (threadIdx.x == 0) s_nl = 0;
-          __syncthreads();
+          if (threadIdx.x == 0) s_ns = 0;
+          if (!last) __syncthreads();
         };
+        // A bin takes ~17 barriers, and what the kernel does most is wait at them (-DRFX_TIMING, SQ counters: issue is a
+        // third of the time).  When the table holds no more keys than the list has room for -- the usual case -- the scan
+        // needs none: every survivor fits.
+        const bool fits = s_nd <= (uint32_t)LIST;
         for (int base = 0; base < TBL; base += 2 * BLK) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
@@ -656,16 +660,18 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
             const uint64_t key = s_keys[i];
             const uint32_t c = s_cnt[i];
             if (key != RFX_EMPTY && c >= lower && c <= upper) {
-              const uint32_t o = atomicAdd(&s_nl, 1u);
+              const uint32_t o = atomicAdd(&s_ns, 1u);
               s_lk[o] = key;
               s_lc[o] = c;
             }
           }
-          __syncthreads();
-          if (s_nl > LIST - 2 * BLK) flush();  // the next two rounds might not fit
+          if (!fits) {
+            __syncthreads();
+            if (s_ns > LIST - 2 * BLK) flush(false);  // the next two rounds might not fit
+          }
         }
         TM(12);
-        flush();
+        flush(true);
         TM(13);
       }
       __syncthreads();

@@ -258,6 +258,10 @@ int rfx_count_segment_get(rfx_table*, int i, const uint64_t** d_records, const u
                           uint64_t* n_records);
 int rfx_count_add_records_dev(rfx_table*, const uint64_t* d_records, uint64_t n_records, const uint64_t* d_bin_start,
                               uint32_t bins);
+/* The same import without the copy: the table reads d_records (and d_ext) where they are until rfx_count_finish /
+ * rfx_count_free -- the caller keeps them alive that long; only the bin offsets are copied. */
+int rfx_count_adopt_records_dev(rfx_table*, const uint64_t* d_records, const uint32_t* d_ext, uint64_t n_records,
+                                const uint64_t* d_bin_start, uint32_t bins);
 /* k = 26 .. 31: a record is a 64-bit word plus a 32-bit plane entry (the bases of a run beyond the 28 the word
  * holds); the plane is grouped like the records and travels with them. */
 int rfx_count_segment_ext(rfx_table*, int i, const uint32_t** d_ext); /* NULL plane for k <= 25 */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "rfx_records_dev_pos": (C.c_void_p, [C.c_void_p]),
     "rfx_records_histo": (C.c_int, [C.c_void_p, u64p]),
     "rfx_records_verify": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u64p]),
+    "rfx_count_adopt_records_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
     "rfx_ctx_allow_peers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "rfx_peers_create": (C.c_void_p, [C.c_int]),
     "rfx_peers_free": (None, [C.c_void_p]),
@@ -506,6 +507,11 @@ class CountTable:
         """d_ext: the 32-bit plane of the records (k = 26 .. 31), grouped like them."""
         _check(lib().rfx_count_add_records_ext_dev(self._h, d_records, d_ext or None, n_records, d_bin_start, bins),
                "rfx_count_add_records_dev")
+
+    def adopt_records_dev(self, d_records: int, n_records: int, d_bin_start: int, bins: int, d_ext: int = 0):
+        """add_records_dev without the copy: the arrays must stay alive until finish() / free()."""
+        _check(lib().rfx_count_adopt_records_dev(self._h, d_records, d_ext or None, n_records, d_bin_start, bins),
+               "rfx_count_adopt_records_dev")
 
     def segment_ext(self, i: int) -> int:
         """Device pointer of the 32-bit plane of segment i (0 for k <= 25)."""

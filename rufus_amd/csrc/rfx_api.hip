@@ -917,7 +917,7 @@ void rfx_count_free(rfx_table* t) {
   }
   if (t->segs) {
     for (auto& sg : *t->segs) {
-      dfree(t->ctx, sg.inst);
+      if (!sg.borrowed) dfree(t->ctx, sg.inst);
       dfree(t->ctx, sg.bin_start);
     }
     delete t->segs;
@@ -1349,9 +1349,9 @@ static int msp_settle(rfx_table* t, const std::vector<unsigned int>& flags) {
     if (!flags[i]) continue;
     const rfx_pending_add& p = (*t->pend)[i];
     rfx_segment& sg = (*t->segs)[p.seg];
-    dfree(c, sg.inst);
+    if (!sg.borrowed) dfree(c, sg.inst);
     dfree(c, sg.bin_start);
-    dfree(c, sg.ext);
+    if (!sg.borrowed) dfree(c, sg.ext);
     sg.inst = sg.bin_start = nullptr;
     sg.ext = nullptr;
     rfx_segment fresh{};
@@ -2198,9 +2198,9 @@ static rfx_records* msp_emit(rfx_table* t, uint64_t lower, uint64_t upper, uint6
 static void p2l_drop_segments(rfx_table* t) {
   msp_forget_pending(t);
   for (auto& sg : *t->segs) {
-    dfree(t->ctx, sg.inst);
+    if (!sg.borrowed) dfree(t->ctx, sg.inst);
     dfree(t->ctx, sg.bin_start);
-    dfree(t->ctx, sg.ext);
+    if (!sg.borrowed) dfree(t->ctx, sg.ext);
   }
   t->segs->clear();
   t->seg_kind = 0;
@@ -2420,6 +2420,35 @@ int rfx_count_add_records_ext_dev(rfx_table* t, const uint64_t* d_records, const
   if (e != hipSuccess) { dfree(c, inst); dfree(c, bs); dfree(c, ext); return hip_fail(e, "rfx_count_add_records_dev"); }
   if (!t->p2l_bins) t->p2l_bins = bins > 8192 ? 8192 : bins;  // geometry of later rfx_count_add calls
   t->segs->push_back(rfx_segment{inst, n_records, bs, n_records * 4, bins, ext});  // <= 4 k-mers per record
+  t->seg_kind = RFX_COUNT_MSP;
+  return RFX_OK;
+}
+
+// The import without the copy: the table READS the caller's arrays until its finish (or rfx_count_free); only the bin
+// offsets are copied.  What the multi-GPU driver receives from its peers is counted where it landed: two copies of a
+// shard's records alive at the peak (the sender's partition, the receive buffers) instead of three.
+int rfx_count_adopt_records_dev(rfx_table* t, const uint64_t* d_records, const uint32_t* d_ext, uint64_t n_records,
+                                const uint64_t* d_bin_start, uint32_t bins) {
+  if (!t || !d_bin_start || (n_records && !d_records) || bins < 256 || (bins & (bins - 1))) return RFX_E_INVAL;
+  rfx_ctx* c = t->ctx;
+  (void)hipSetDevice(c->device);
+  if (!rfxk::msp_k_ok(t->k) || !t->lut_t || t->table_active || (t->seg_kind && t->seg_kind != RFX_COUNT_MSP)) {
+    snprintf(g_err, sizeof g_err, "rfx_count_adopt_records_dev: the table is not on the MSP path");
+    return RFX_E_INVAL;
+  }
+  if (rfxk::msp_wide(t->k) && n_records && !d_ext) {
+    snprintf(g_err, sizeof g_err, "rfx_count_adopt_records_dev: k = 26 .. 31 records come with their 32-bit plane");
+    return RFX_E_INVAL;
+  }
+  if (n_records == 0) return RFX_OK;
+  uint64_t* bs = (uint64_t*)dmalloc(c, ((size_t)bins + 1) * 8);
+  if (!bs) return RFX_E_NOMEM;
+  const hipError_t e = rfxk::copy_bytes(c, bs, d_bin_start, ((size_t)bins + 1) * 8);
+  if (e != hipSuccess) { dfree(c, bs); return hip_fail(e, "rfx_count_adopt_records_dev"); }
+  if (!t->p2l_bins) t->p2l_bins = bins > 8192 ? 8192 : bins;
+  rfx_segment sg{const_cast<uint64_t*>(d_records), n_records, bs, n_records * 4, bins, const_cast<uint32_t*>(d_ext)};
+  sg.borrowed = true;
+  t->segs->push_back(sg);
   t->seg_kind = RFX_COUNT_MSP;
   return RFX_OK;
 }

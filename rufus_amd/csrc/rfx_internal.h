@@ -120,6 +120,7 @@ struct rfx_segment {  // the k-mer instances of one rfx_count_add call, grouped 
   uint64_t kmers;       // upper bound of the k-mer instances represented (P2L: n)
   uint32_t bins;        // MSP: bins of THIS segment (segments are brought to a common count before the leaf)
   uint32_t* ext = nullptr;  // MSP, k = 26 .. 31: the 32-bit plane of the records (rfx_devutil.h)
+  bool borrowed = false;    // inst / ext belong to the caller (rfx_count_adopt_records_dev): never freed here
 };
 
 struct rfx_reads;

@@ -53,8 +53,8 @@ def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, 
     """Smallest number of shard passes whose transients fit beside the resident reads of ONE rank.
 
     n_reads_total: reads per sample over all ranks.  Per pass, sample and rank: super-k-mer records (8 B per
-    ~3 k-mer instances; 1 / (S x world) of the sample -- three copies alive at the peak of an exchange: the
-    partition, the receive buffers, the import), the refinement scratch (1/8 of the records), the survivor
+    ~3 k-mer instances; 1 / (S x world) of the sample -- two copies alive at the peak of an exchange: the
+    partition and the receive buffers, which the owner counts in place), the refinement scratch (1/8 of the records), the survivor
     arrays (44 B per surviving k-mer: two partition levels + the records), and the subject's candidate records
     of this pass (20 B each; WgsTrio.run counts the subject first and keeps only them)."""
     windows = n_reads_total * max(read_len - k + 1, 0)           # per sample
@@ -64,7 +64,7 @@ def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, 
         # bytes of records per k-mer instance: 8 B per ~3 k-mers; wide (k >= 26) records are 12 B but hold more k-mers
         # (measured on the full-size tumor/normal pair, 1 GPU: peak 255 / 272 / 297 GB at 7 / 6 / 5 passes = 5.0 B per
         # instance all in, the same as k = 25 -- 4.1 here made the plan take 7 where 6 fit)
-        records = (3.2 if wide else 2.7) * windows / share * (3.0 if world > 1 else 1.0)
+        records = (3.2 if wide else 2.7) * windows / share * (2.0 if world > 1 else 1.0)
         # leaf phase of the last sample of a pass: records + scratch, survivor store, the other samples' records
         # (the controls are struck off the subject's candidates one at a time: one set of 20-byte records stays)
         transient = records * 1.125 + 12.0 * distinct / share * 1.3 + (20.0 if n_samples > 1 else 0.0) * distinct / share
@@ -208,19 +208,22 @@ class WgsTrio:
                     ro += recv_l[src]
                     bo += off_rl[src]
                 torch.cuda.synchronize(dev)
+                # the owner counts the runs where they landed (rfx_count_adopt_records_dev: no third copy of the shard's
+                # records); the receive buffers live until the table is finished
                 for run, full, run_e, sbins, n_run in todo:
                     if n_run:
-                        own.add_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), sbins,
-                                            run_e.data_ptr() if wide else 0)
+                        own.adopt_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), sbins,
+                                              run_e.data_ptr() if wide else 0)
                     keep.append((run, full, run_e))
-                self.ctx.sync()             # the imports are copies: the exchange buffers may go
-                keep.clear()
                 del rr
                 t_ = lap("import", t_)
             if trace:
                 print("[wgs] exchange of shard %d: " % shard + ", ".join(f"{k_} {v * 1e3:.0f} ms" for k_, v in tt.items()), flush=True)
             part.free()                     # the send views were this table's memory
-            return own.finish(self.lower, want_histo=True)
+            out = own.finish(self.lower, want_histo=True)
+            self.ctx.sync()
+            keep.clear()
+            return out
         finally:
             own.free()
 

@@ -13,7 +13,7 @@ passes = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 n_pairs = G // 10
 K = int(sys.argv[3]) if len(sys.argv) > 3 else 25
 sys_ = [capi.Synth.sample(G, w, n_snv=max(8, G // 3_100_000), seed=12345) for w in range(3)]
-samples = [wgs.make_sample(ctx, sy, n_pairs, 1 << 24, 15, want_good=(i == 0)) for i, sy in enumerate(sys_)]
+samples = [wgs.make_sample(ctx, sy, n_pairs, 1 << 24, 15, want_good=(i == 0), compact=True) for i, sy in enumerate(sys_)]
 res = {}
 for forced in (True, False):
     if not forced:

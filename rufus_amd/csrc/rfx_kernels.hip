@@ -573,6 +573,63 @@ __global__ __launch_bounds__(256) void k_flag_absent(const uint64_t* __restrict_
   }
 }
 
+// The same for big inputs (a 30x sample's candidates against a control's records: 1.5e9 lookups of ~14 dependent
+// probes each through L2): both lists are in (pos,key) order, so the records of B that can match a tile of 2048
+// candidates are one short range -- between the lower bounds of the tile's first candidate and of the next tile's
+// (k_fa_bounds: one search per tile) -- which is staged in LDS and bisected there.
+constexpr int FA_TILE = 2048, FA_BCAP = 3072;
+
+__global__ __launch_bounds__(256) void k_fa_bounds(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ pos,
+                                                    uint64_t n, const uint64_t* __restrict__ bkeys,
+                                                    const uint64_t* __restrict__ bpos, uint64_t nb, int lsize,
+                                                    uint64_t n_tiles, uint64_t* __restrict__ bounds /* n_tiles + 1 */) {
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= n_tiles; t += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = t * FA_TILE;
+    bounds[t] = i < n ? lower_bound_near(bkeys, bpos, nb, pos[i], keys[i], lsize) : nb;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_flag_absent_tiled(const uint64_t* __restrict__ keys,
+                                                            const uint64_t* __restrict__ pos, uint64_t n,
+                                                            const uint64_t* __restrict__ bkeys,
+                                                            const uint64_t* __restrict__ bpos, uint64_t nb, int lsize,
+                                                            uint64_t n_tiles, const uint64_t* __restrict__ bounds,
+                                                            uint8_t* __restrict__ flags) {
+  __shared__ uint64_t s_bk[FA_BCAP], s_bp[FA_BCAP];
+  for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const uint64_t a0 = t * FA_TILE, a1 = a0 + FA_TILE < n ? a0 + FA_TILE : n;
+    const uint64_t lo = bounds[t], hi = bounds[t + 1] < nb ? bounds[t + 1] + 1 : nb;  // B records that can match the tile
+    const uint32_t nbr = hi - lo <= (uint64_t)FA_BCAP ? (uint32_t)(hi - lo) : 0u;
+    if (hi - lo <= (uint64_t)FA_BCAP) {
+      for (uint32_t j = threadIdx.x; j < nbr; j += blockDim.x) {
+        s_bk[j] = bkeys[lo + j];
+        s_bp[j] = bpos[lo + j];
+      }
+      __syncthreads();
+      for (uint64_t i = a0 + threadIdx.x; i < a1; i += blockDim.x) {
+        if (!flags[i]) continue;
+        const uint64_t k = keys[i], p = pos[i];
+        uint32_t l = 0, h = nbr;
+        while (l < h) {
+          const uint32_t mid = (l + h) >> 1;
+          const uint64_t mp = s_bp[mid];
+          if (mp < p || (mp == p && s_bk[mid] < k)) l = mid + 1;
+          else h = mid;
+        }
+        if (l < nbr && s_bk[l] == k && s_bp[l] == p) flags[i] = 0;
+      }
+      __syncthreads();
+    } else {  // few candidates against many records: every candidate searches for itself
+      for (uint64_t i = a0 + threadIdx.x; i < a1; i += blockDim.x) {
+        if (!flags[i]) continue;
+        const uint64_t k = keys[i], p = pos[i];
+        const uint64_t at = lower_bound_near(bkeys, bpos, nb, p, k, lsize);
+        if (at < nb && bkeys[at] == k) flags[i] = 0;
+      }
+    }
+  }
+}
+
 constexpr int CP_ITEMS = 2048;  // elements per compaction block
 
 __global__ __launch_bounds__(256) void k_compact_count(const uint8_t* __restrict__ flags, uint64_t n,
@@ -1411,6 +1468,17 @@ void flag_absent(rfx_ctx* c, const uint64_t* keys, const uint64_t* pos, uint64_t
                  const uint64_t* bpos, uint64_t nb, int lsize, uint8_t* flags) {
   if (n == 0 || nb == 0) return;
   rfx_span sp(c, "k_flag_absent");
+  const uint64_t n_tiles = (n + FA_TILE - 1) / FA_TILE;
+  const char* tmin = getenv("RFX_K4_TILE_MIN");  // (tests lower it to put small inputs through the tiles)
+  uint64_t* bounds = n >= (tmin ? strtoull(tmin, nullptr, 10) : 1ull << 20) ? (uint64_t*)rfxi::dmalloc(c, (n_tiles + 1) * 8) : nullptr;
+  if (bounds) {  // big inputs: a short range of B per tile, bisected in LDS
+    hipLaunchKernelGGL(k_fa_bounds, dim3(grid_for(c, n_tiles + 1, 256, 8)), dim3(256), 0, c->stream, keys, pos, n, bkeys, bpos,
+                       nb, lsize, n_tiles, bounds);
+    hipLaunchKernelGGL(k_flag_absent_tiled, dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 12)), dim3(256), 0,
+                       c->stream, keys, pos, n, bkeys, bpos, nb, lsize, n_tiles, bounds, flags);
+    rfxi::dfree(c, bounds);  // (stream-ordered)
+    return;
+  }
   hipLaunchKernelGGL(k_flag_absent, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, pos, n, bkeys, bpos,
                      nb, lsize, flags);
 }

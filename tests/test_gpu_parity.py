@@ -697,11 +697,15 @@ def test_synthetic_merge_and_hashlist(ctx, small_trio):
         f.records.free()
 
 
+@pytest.mark.parametrize("route", ["search", "tiles"])
 @pytest.mark.parametrize("seed", [31, 32, 33, 34])
-def test_merge_hashlist_query_on_random_configurations(ctx, seed):
+def test_merge_hashlist_query_on_random_configurations(ctx, seed, route, monkeypatch):
     """Randomised K4 inputs: 2-4 samples of very different sizes drawn from overlapping genomes (so the
     (pos,key) search starts far from or right at its target, hits and misses both), random k, table
-    size, -L, coverage window; merge text, hash list and query against the oracle."""
+    size, -L, coverage window; merge text, hash list and query against the oracle.  "tiles" puts these
+    small inputs through the kernels big inputs take (a range of the control per tile of candidates in LDS)."""
+    if route == "tiles":
+        monkeypatch.setenv("RFX_K4_TILE_MIN", "1")
     rng = np.random.default_rng(seed)
     k = int(rng.choice([15, 21, 25, 31]))
     size = 1 << int(rng.integers(12, min(2 * k, 34)))

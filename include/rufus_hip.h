@@ -354,6 +354,29 @@ int rfx_filter(rfx_set*, const rfx_reads*, int thresh, int last_base_skipped, ui
                uint64_t* hitmask_out, uint64_t* n_hit_reads);
 
 /* ---------------------------------------------------------------------------------------------
+ * N4: coverage model fit (src/ModelDist.cpp; runRufus.sh:849 runs it on every sample's histogram,
+ * :862-868 read MutantMinCov and MutantSC from lines 2 and 4 of HISTO.7.7.model)
+ * ------------------------------------------------------------------------------------------- */
+/* One candidate model: the arguments of testModel / testModelLog (src/ModelDist.cpp:72-74, :200-202). */
+typedef struct rfx_model_params {
+  double sc, stdev, factor, skew, power;
+} rfx_model_params;
+/* Residuals of n_cand (<= 64) candidates against one histogram in one pass: what the reference computes by
+ * n_cand calls of testModelLog (log_resid = 1: sum of (ln histo[i] - ln model[i])^2, src/ModelDist.cpp:72-198) or
+ * testModel (0: sum of (histo[i] - model[i])^2, :200-318) inside its `omp parallel for` (:548-553 and the four
+ * loops after it), i running over [inflection, sc * max_copy).  histo[0..n) as the reference indexes it (entry 0
+ * unused, entry 1 = the first non-empty row of the file).  RFX_E_INVAL / RFX_E_RANGE where the reference would
+ * index outside its tables (sc/2 < 1, fewer than 2 copies, sc * max_copy > n). */
+int rfx_model_residuals(rfx_ctx*, const int64_t* histo, uint32_t n, const rfx_model_params* cand, int n_cand,
+                        int log_resid, int inflection, int max_copy, double* resid_out);
+/* Tables of one model as main() builds them for the output files (src/ModelDist.cpp:716-772; columns are summed
+ * from row 0 there): dist[n][*n_cols + 1] row-major (column 0 is zero, column 1 the half-copy curve, column 1 + j
+ * the j-copy curve; the last column is not normalised, as in the reference) and rowtot[n] = sum of columns
+ * 1..*n_cols - 1 of each row.  *n_cols is set even when dist_cap (in doubles) is too small (RFX_E_RANGE). */
+int rfx_model_tables(rfx_ctx*, uint32_t n, const rfx_model_params* model, uint32_t* n_cols, double* dist,
+                     size_t dist_cap, double* rowtot);
+
+/* ---------------------------------------------------------------------------------------------
  * K6: overlap scoring of the greedy assemblers; K7: per-base mutant k-mer coverage of contigs
  * ------------------------------------------------------------------------------------------- */
 /* Align3 of OverlapSam / Overlap / OverlapRegion (src/OverlapSam.cpp:33-241, src/Overlap.cpp:169-360,

@@ -117,6 +117,10 @@ SIGNATURES = {
     "rfx_ovl_pool_score": (C.c_int, [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_float,
                                      C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rfx_ovl_pool_free": (None, [C.c_void_p]),
+    "rfx_model_residuals": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.POINTER(C.c_double)]),
+    "rfx_model_tables": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double),
+                                   C.c_size_t, C.POINTER(C.c_double)]),
 }
 
 
@@ -597,6 +601,32 @@ def overlap_score(ctx: Context, a: bytes, cands, min_pct: float, min_ovl: int, v
     _check(lib().rfx_overlap_score(ctx._h, a, len(a), arr, lens, nb, min_pct, min_ovl, variant,
                                    out.ctypes.data_as(C.POINTER(C.c_int))), "rfx_overlap_score")
     return out[:nb]
+
+
+def model_residuals(ctx: Context, histo, cands, log_resid: bool, inflection: int, max_copy: int = 5) -> np.ndarray:
+    """Residuals of candidate coverage models (rows of (SC, stdev, factor, skew, power)) against a histogram:
+    testModelLog / testModel of the reference's ModelDist (src/ModelDist.cpp:72-318), all candidates in one pass."""
+    histo = np.ascontiguousarray(histo, dtype=np.int64)
+    cands = np.ascontiguousarray(cands, dtype=np.float64).reshape(-1, 5)
+    out = np.zeros(len(cands), dtype=np.float64)
+    _check(lib().rfx_model_residuals(ctx._h, _p(histo, C.POINTER(C.c_int64)), len(histo), cands.ctypes.data, len(cands),
+                                     int(bool(log_resid)), inflection, max_copy, _p(out, C.POINTER(C.c_double))),
+           "rfx_model_residuals")
+    return out
+
+
+def model_tables(ctx: Context, n: int, model):
+    """(dist[n][cols + 1], rowtot[n]) of one model as ModelDist's main() tabulates it (src/ModelDist.cpp:716-772)."""
+    model = np.ascontiguousarray(model, dtype=np.float64).reshape(5)
+    cols = C.c_uint32(0)
+    rc = lib().rfx_model_tables(ctx._h, n, model.ctypes.data, C.byref(cols), None, 0, None)
+    if rc != -7:  # RFX_E_RANGE: the size query
+        _check(rc, "rfx_model_tables")
+    dist = np.zeros((n, cols.value + 1), dtype=np.float64)
+    rowtot = np.zeros(n, dtype=np.float64)
+    _check(lib().rfx_model_tables(ctx._h, n, model.ctypes.data, C.byref(cols), _p(dist, C.POINTER(C.c_double)), dist.size,
+                                  _p(rowtot, C.POINTER(C.c_double))), "rfx_model_tables")
+    return dist, rowtot
 
 
 class MutantSet:

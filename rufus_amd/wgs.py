@@ -35,6 +35,20 @@ def _device_view32(ptr: int, n: int, device):
     return torch.as_tensor(_DevMem32(ptr, n), device=device)
 
 
+class GroupFailure(capi.RufusError):
+    """A step failed on SOME rank of the group and every rank knows it: all of them raise this at the same
+    checkpoint, so that none is left waiting in a collective.  retry: the failure was a lack of device memory --
+    WgsTrio.run() takes one more pass on every rank and starts over."""
+
+    def __init__(self, msg: str, retry: bool):
+        super().__init__(msg)
+        self.retry = retry
+
+
+def _is_out_of_memory(e: BaseException) -> bool:
+    return "memory" in str(e).lower() or type(e).__name__ == "OutOfMemoryError"
+
+
 def shard_cut(q: int, n: int) -> int:
     """First of the 256 virtual top-level minimizer bins of shard q of n (rfx_count_set_shard's cut)."""
     return -(-q * 256 // n)
@@ -105,24 +119,75 @@ class WgsTrio:
         (RCCL over xGMI), the owner imports the runs and counts complete bins.  No partial counts, no reduce."""
         t = capi.CountTable(self.ctx, self.k, self.size, True, mode=capi.COUNT_MSP)
         try:
-            if self.passes > 1:
-                t.set_shard(shard, self.passes)
-            for b in blocks:
-                t.add(b)
             if self.world == 1 and not (self.group is not None and os.environ.get("RFX_WGS_FORCE_EXCHANGE")):
+                if self.passes > 1:
+                    t.set_shard(shard, self.passes)
+                for b in blocks:
+                    t.add(b)
                 return t.finish(self.lower, want_histo=True)
-            return self._exchange_and_count(t, shard)
+            err = None
+            try:        # local work: a failure here is carried to the first checkpoint of the exchange
+                if self.passes > 1:
+                    t.set_shard(shard, self.passes)
+                self._inject("partition", shard)
+                for b in blocks:
+                    t.add(b)
+            except Exception as e:
+                err = e
+            return self._exchange_and_count(t, shard, err)
         finally:
             t.free()
 
-    def _exchange_and_count(self, part: capi.CountTable, shard: int):
+    def checkpoint(self, err=None):
+        """All ranks: did the step succeed everywhere?  One 8-byte all-reduce (MIN of 2 = fine, 1 = out of device
+        memory, 0 = anything else).  Returns when every rank is fine; otherwise EVERY rank raises GroupFailure here
+        (the rank that failed chains its own exception), retry = all failures were a lack of memory."""
+        if self.world == 1:
+            if err is not None:
+                raise err
+            return
+        import torch
+        import torch.distributed as dist
+        from .dist import _wire
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        code = 2 if err is None else (1 if _is_out_of_memory(err) else 0)
+        t = _wire(torch.tensor([code], dtype=torch.int64, device=dev), self.group)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        worst = int(t.item())
+        if worst == 2:
+            return
+        what = "out of device memory" if worst == 1 else "a step failed"
+        where = f"on this rank ({err})" if err is not None else "on another rank of the group"
+        raise GroupFailure(f"{what} {where}", retry=worst == 1) from err
+
+    def _inject(self, stage: str, shard: int):
+        """Fault injection for the tests of the agreed retry: RFX_WGS_INJECT_OOM="rank:stage:shard" makes that rank
+        fail once with an out-of-memory error at that stage (partition | receive | finish) of that shard."""
+        spec = os.environ.get("RFX_WGS_INJECT_OOM")
+        if not spec or getattr(self, "_injected", False):
+            return
+        r, st, sh = spec.split(":")
+        if int(r) == self.rank and st == stage and int(sh) == shard:
+            self._injected = True
+            raise capi.RufusError(f"injected: out of device memory at {stage} of shard {shard}")
+
+    def _exchange_and_count(self, part: capi.CountTable, shard: int, err=None):
+        """err: what the partition raised on this rank, if anything.  Checkpoints (see checkpoint()): after the
+        partition, in every round after the receive buffers are allocated (before any record travels), and after
+        the owner's count -- a failure between two of them is carried to the next one, never into a collective."""
         import torch
         import torch.distributed as dist
         from .dist import _device_view, _wire, exchange_rows
         W, me, Q = self.world, self.rank, self.passes * self.world
         dev = torch.device("cuda", torch.cuda.current_device())
         vb = [shard_cut(shard * W + g, Q) for g in range(W + 1)]       # owners' ranges in virtual bins
-        segs = part.segments()                                          # synchronises: the arrays are complete
+        segs = []
+        if err is None:
+            try:
+                segs = part.segments()                                  # synchronises: the arrays are complete
+            except Exception as e:
+                err = e
+        self.checkpoint(err)
         # every rank may hold a different number of segments (blocks): agree on the rounds
         n_seg = torch.tensor([len(segs)], dtype=torch.int64, device=dev)
         n_seg = _wire(n_seg, self.group)
@@ -175,14 +240,20 @@ class WgsTrio:
                 rb = torch.empty(sum(off_rl), dtype=torch.int64, device=sb.device)
                 dist.all_to_all_single(rb, sb, off_rl, off_sl, group=self.group)
                 t_ = lap("meta", t_)
-                wr = _wire(rec[int(cuts[0]):int(cuts[-1])], self.group)
-                rr = torch.empty(sum(recv_l), dtype=torch.int64, device=wr.device)
+                rr = re_ = None
+                try:
+                    self._inject("receive", shard)
+                    wr = _wire(rec[int(cuts[0]):int(cuts[-1])], self.group)
+                    rr = torch.empty(sum(recv_l), dtype=torch.int64, device=wr.device)
+                    if wide:
+                        we = _wire(ext[int(cuts[0]):int(cuts[-1])], self.group)
+                        re_ = torch.empty(sum(recv_l), dtype=torch.int32, device=we.device)
+                except Exception as e:
+                    err = e
+                self.checkpoint(err)        # also carries a failed import of the round before
                 t_ = lap("alloc", t_)
                 exchange_rows(rr, wr, recv_l, send_l, self.group)
-                re_ = None
                 if wide:
-                    we = _wire(ext[int(cuts[0]):int(cuts[-1])], self.group)
-                    re_ = torch.empty(sum(recv_l), dtype=torch.int32, device=we.device)
                     exchange_rows(re_, we, recv_l, send_l, self.group)
                     re_ = re_.to(dev)
                 if rr.is_cuda:
@@ -210,22 +281,59 @@ class WgsTrio:
                 torch.cuda.synchronize(dev)
                 # the owner counts the runs where they landed (rfx_count_adopt_records_dev: no third copy of the shard's
                 # records); the receive buffers live until the table is finished
-                for run, full, run_e, sbins, n_run in todo:
-                    if n_run:
-                        own.adopt_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), sbins,
-                                              run_e.data_ptr() if wide else 0)
-                    keep.append((run, full, run_e))
+                try:
+                    for run, full, run_e, sbins, n_run in todo:
+                        if n_run:
+                            own.adopt_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), sbins,
+                                                  run_e.data_ptr() if wide else 0)
+                        keep.append((run, full, run_e))
+                except Exception as e:
+                    err = e
                 del rr
                 t_ = lap("import", t_)
             if trace:
                 print("[wgs] exchange of shard %d: " % shard + ", ".join(f"{k_} {v * 1e3:.0f} ms" for k_, v in tt.items()), flush=True)
             part.free()                     # the send views were this table's memory
-            out = own.finish(self.lower, want_histo=True)
-            self.ctx.sync()
+            out = None
+            if err is None:
+                try:
+                    self._inject("finish", shard)
+                    out = own.finish(self.lower, want_histo=True)
+                    self.ctx.sync()
+                except Exception as e:
+                    err = e
             keep.clear()
+            self.checkpoint(err)
             return out
         finally:
             own.free()
+
+    def _after_count(self, rec, recs, si, sh, cand, ver, verify, probe_keys, keep_shard_records, lap):
+        """What run() does with one sample's records of one pass (verify, candidates / strike-out); returns cand."""
+        if verify:
+            v = rec.verify(self.lower)
+            for k_ in ("bad_order", "bad_pos", "bad_count"):
+                ver[k_] += v[k_]
+            ver["sum_counts"][si] += v["sum_counts"]
+            if probe_keys is not None and len(probe_keys):
+                got = rec.query(np.asarray(probe_keys, dtype=np.uint64))
+                ver["probe_found"][si] += int((got > 0).sum())
+                if si == 0:
+                    ver["probe_count_out_of_range"] += int(((got > 0) & ((got < max(5, self.min_cov)) |
+                                                                         (got > self.max_cov))).sum())
+            lap(f"pass {sh} sample {si} verify")
+        if keep_shard_records:
+            return cand
+        if si == 0:
+            cand = capi.records_subtract(self.ctx, rec, [], max(5, self.min_cov), self.max_cov)
+        else:
+            nxt = capi.records_subtract(self.ctx, cand, [rec])
+            cand.free()
+            cand = nxt
+        rec.free()
+        recs.pop()
+        lap(f"pass {sh} sample {si} candidates ({len(cand)})")
+        return cand
 
     def pos_of(self, keys: np.ndarray) -> np.ndarray:
         """pos = (M * key) & (2^lsize - 1): bit b of the key selects column 2k-1-b."""
@@ -267,34 +375,18 @@ class WgsTrio:
                     # count <= MaxDepth; every control then strikes out what it holds and is freed at once
                     # (rfx_records_subtract) -- one sample's records alive at a time instead of all of them.
                     for si, blocks in enumerate(samples):
-                        rec, h = self.count_shard(blocks, sh)
+                        rec, h = self.count_shard(blocks, sh)       # (its failures are agreed inside)
                         recs.append(rec)
                         histos[si] += h
                         n_rec[si] += len(rec)
                         lap(f"pass {sh} sample {si} count ({len(rec)} records)")
-                        if verify:
-                            v = rec.verify(self.lower)
-                            for k_ in ("bad_order", "bad_pos", "bad_count"):
-                                ver[k_] += v[k_]
-                            ver["sum_counts"][si] += v["sum_counts"]
-                            if probe_keys is not None and len(probe_keys):
-                                got = rec.query(np.asarray(probe_keys, dtype=np.uint64))
-                                ver["probe_found"][si] += int((got > 0).sum())
-                                if si == 0:
-                                    ver["probe_count_out_of_range"] += int(((got > 0) & ((got < max(5, self.min_cov)) |
-                                                                                         (got > self.max_cov))).sum())
-                            lap(f"pass {sh} sample {si} verify")
-                        if keep_shard_records:
-                            continue
-                        if si == 0:
-                            cand = capi.records_subtract(self.ctx, rec, [], max(5, self.min_cov), self.max_cov)
-                        else:
-                            nxt = capi.records_subtract(self.ctx, cand, [rec])
-                            cand.free()
-                            cand = nxt
-                        rec.free()
-                        recs.pop()
-                        lap(f"pass {sh} sample {si} candidates ({len(cand)})")
+                        err = None              # the rest of the iteration is local: on a group its failure is
+                        try:                    # agreed at its end, so that no rank goes on into a collective alone
+                            cand = self._after_count(rec, recs, si, sh, cand, ver, verify, probe_keys, keep_shard_records,
+                                                     lap)
+                        except Exception as e:
+                            err = e
+                        self.checkpoint(err)    # (one rank: raises err)
                     if keep_shard_records:
                         k_, _ = capi.unique_to_subject(self.ctx, recs[0], recs[1:], self.min_cov, self.max_cov)
                         kept.append(recs)
@@ -307,12 +399,18 @@ class WgsTrio:
                     recs = []
                 break
             except capi.RufusError as e:
-                # the pass plan is an estimate: if a pass does not fit after all, take one more pass and start over
-                # (single rank only: the ranks of a group must agree on the passes)
-                if self.world > 1 or self.passes >= 64 or "memory" not in str(e).lower():
+                # the pass plan is an estimate: if a pass does not fit after all, take one more pass and start over.
+                # On a group only a failure every rank knows of (GroupFailure: raised by all ranks at the same
+                # checkpoint of count_shard) can be retried -- all ranks are here then, with the same `passes`.
+                agreed = isinstance(e, GroupFailure) and e.retry
+                if (self.world > 1 and not agreed) or self.passes >= 64 or (self.passes + 1) * self.world > 256 or \
+                        not _is_out_of_memory(e):
                     raise
                 for r in recs + [r_ for shard in kept for r_ in shard] + ([cand] if cand is not None else []):
                     r.free()
+                if self.world > 1:
+                    import torch
+                    torch.cuda.empty_cache()    # the receive buffers of the failed pass go back to the driver
                 self.passes += 1
                 if trace:
                     print(f"[wgs] out of device memory: retrying with {self.passes} passes", flush=True)

@@ -232,3 +232,58 @@ def test_owner_bounds_cover_the_range():
     k = np.array([0, 1, 0x3FFFFFFFFFFFF, 12345678901234], dtype=np.uint64)
     assert rdist.revcomp_keys(rdist.revcomp_keys(k, 25), 25).tolist() == k.tolist()
     assert rdist.revcomp_keys(np.array([0], dtype=np.uint64), 3).tolist() == [63]
+
+
+# ------------------------------------------------------------------------------------------------
+# the checkpoints of the WGS driver: a failure on one rank is raised on every rank, at the same place
+# ------------------------------------------------------------------------------------------------
+def _checkpoint_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rufus_amd import capi, wgs
+        trio = object.__new__(wgs.WgsTrio)          # the protocol needs no device: only the group
+        trio.world, trio.rank, trio.group = world, rank, dist.group.WORLD
+        seen = []
+        trio.checkpoint(None)                       # everyone fine: returns
+        seen.append("fine")
+        for failing, exc in ((1, capi.RufusError("rfx_count_add: out of device memory")),
+                             (0, torch.OutOfMemoryError("HIP out of memory")),
+                             (world - 1, ValueError("something else")),
+                             (None, None)):
+            try:
+                trio.checkpoint(exc if rank == failing else None)
+                seen.append("fine")
+            except wgs.GroupFailure as e:
+                seen.append(("retry" if e.retry else "fatal", e.__cause__ is not None, "memory" in str(e)))
+        # two ranks fail differently in the same step: the worse one decides
+        try:
+            trio.checkpoint(capi.RufusError("out of memory") if rank == 0 else ValueError("x") if rank == 1 else None)
+        except wgs.GroupFailure as e:
+            seen.append("retry" if e.retry else "fatal")
+        q.put((rank, seen))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_failure_on_one_rank_is_raised_on_all_of_them(world):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_checkpoint_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, seen in got.items():
+        assert seen[0] == "fine"
+        assert seen[1] == ("retry", rank == 1, True)             # only the failing rank chains its own exception
+        assert seen[2] == ("retry", rank == 0, True)
+        assert seen[3] == ("fatal", rank == world - 1, False)
+        assert seen[4] == "fine" and seen[5] == "fatal"

@@ -277,10 +277,12 @@ def test_full_size_runs_check_themselves(ctx, workload):
 # ------------------------------------------------------------------------------------------------
 # strong scaling of one trio over ranks: two ranks share the one GPU, exchange over gloo
 # ------------------------------------------------------------------------------------------------
-def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs, k=K):
+def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs, k=K, inject=None):
     import torch
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if inject:
+        os.environ["RFX_WGS_INJECT_OOM"] = inject
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.cuda.set_device(0)
@@ -292,7 +294,9 @@ def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs, k=K):
         trio = wgs.WgsTrio(c, k, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes, group=dist.group.WORLD)
         # the routine bench.py runs after its timed region, here over the two ranks: verified records, probes of the hash
         # list in every shard of every rank (all-reduced), the sampled block
-        chk = wgs.self_check(c, trio, samples, sys_, trio.run(samples), p1 - p0, MIN_Q, sample_pairs=3000)
+        first = trio.run(samples)
+        passes_after_first = trio.passes
+        chk = wgs.self_check(c, trio, samples, sys_, first, p1 - p0, MIN_Q, sample_pairs=3000)
         assert chk["order_pos_count_violations"] == 0 and chk["mutant_in_controls"] == 0 and chk["mutant_in_subject"] > 0
         res = trio.run(samples, keep_shard_records=True)
         recs = [[tuple(a.tolist() for a in shard[si].get()) for shard in res["shard_records"]] for si in range(3)]
@@ -300,27 +304,23 @@ def _wgs_worker(rank, world, port, q, passes, n_pairs, G, block_pairs, k=K):
                                  zip(res["hit_masks"], samples[0],
                                      np.cumsum([0] + [b.n // 2 for b in samples[0]][:-1]))]) + p0
         q.put((rank, recs, [h.tolist() for h in res["histos"]], res["mutant_keys"].tolist(), res["n_pulled"],
-               pulled.tolist(), res["n_records"]))
+               pulled.tolist(), res["n_records"], passes_after_first, first["mutant_keys"].tolist(), first["n_pulled"]))
         c.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("passes,block_pairs,k", [(1, 1 << 20, K), (2, 5000, K), (2, 6000, 31)])
-def test_trio_strong_scaled_over_two_ranks(passes, block_pairs, k):
-    """WgsTrio(group=...): each rank holds half of every sample's pairs; per pass the ranks exchange their
-    super-k-mer records by minimizer-bin owner (flat cut over passes x ranks) and count complete bins.  The
-    union of all (pass, rank) shards is the oracle's record list; histograms, hash list and pulled pairs too."""
+def _two_ranks(passes, block_pairs, k, n_pairs, G, inject=None):
     import socket
     import torch.multiprocessing as mp
-    world, n_pairs, G = 2, 20_000, 200_000
+    world = 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_wgs_worker, args=(r, world, port, q, passes, n_pairs, G, block_pairs, k))
+    procs = [mpc.Process(target=_wgs_worker, args=(r, world, port, q, passes, n_pairs, G, block_pairs, k, inject))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -328,6 +328,35 @@ def test_trio_strong_scaled_over_two_ranks(passes, block_pairs, k):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    return got
+
+
+@pytest.mark.parametrize("inject", ["1:partition:0", "0:receive:0", "1:finish:0", "0:partition:1"])
+def test_two_ranks_agree_on_one_more_pass(inject):
+    """A pass that does not fit on ONE rank (injected: rank:stage:shard, RFX_WGS_INJECT_OOM) is given up by both at
+    the same checkpoint and started over with one more pass on both -- nobody is left inside a collective (round 2
+    could only raise on a group); hash list, histograms and pulled pairs are those of the oracle."""
+    n_pairs, G = 12_000, 150_000
+    passes = 2 if inject.endswith(":1") else 1
+    got = _two_ranks(passes, 4000, K, n_pairs, G, inject)
+    sys_ = [capi.Synth.sample(G, w, n_snv=12, seed=777) for w in range(3)]
+    recs_o, hl_o, pulled_o = _oracle_trio(sys_, n_pairs, K)
+    want = [oracle.jf_encode(ln.split()[0]) for ln in hl_o.splitlines()]
+    for g in got:
+        assert g[7] == passes + 1                                  # both ranks took the extra pass in the first run
+        assert g[8] == want and want and g[9] == len(pulled_o)     # ... and that run's results are right
+        for si in range(3):
+            assert g[2][si] == oracle.histo(recs_o[si].counts, full=True)[0].tolist()
+            assert g[6][si] == len(recs_o[si].keys)
+
+
+@pytest.mark.parametrize("passes,block_pairs,k", [(1, 1 << 20, K), (2, 5000, K), (2, 6000, 31)])
+def test_trio_strong_scaled_over_two_ranks(passes, block_pairs, k):
+    """WgsTrio(group=...): each rank holds half of every sample's pairs; per pass the ranks exchange their
+    super-k-mer records by minimizer-bin owner (flat cut over passes x ranks) and count complete bins.  The
+    union of all (pass, rank) shards is the oracle's record list; histograms, hash list and pulled pairs too."""
+    world, n_pairs, G = 2, 20_000, 200_000
+    got = _two_ranks(passes, block_pairs, k, n_pairs, G)
     sys_ = [capi.Synth.sample(G, w, n_snv=12, seed=777) for w in range(3)]
     recs_o, hl_o, pulled_o = _oracle_trio(sys_, n_pairs, k)
     for si in range(3):

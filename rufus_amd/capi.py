@@ -507,6 +507,20 @@ class CountTable:
             out.append((dr.value or 0, db.value or 0, bins.value, nr.value))
         return out
 
+    def n_segments(self) -> int:
+        """Segments held so far (no synchronisation)."""
+        n = lib().rfx_count_segments(self._h)
+        if n < 0:
+            _check(n, "rfx_count_segments")
+        return n
+
+    def segment(self, i: int):
+        """(d_records, d_bin_start, bins, n_records) of segment i; waits for the adds queued so far."""
+        dr, db, bins, nr = C.c_void_p(0), C.c_void_p(0), C.c_uint32(0), C.c_uint64(0)
+        _check(lib().rfx_count_segment_get(self._h, i, C.byref(dr), C.byref(db), C.byref(bins), C.byref(nr)),
+               "rfx_count_segment_get")
+        return (dr.value or 0, db.value or 0, bins.value, nr.value)
+
     def add_records_dev(self, d_records: int, n_records: int, d_bin_start: int, bins: int, d_ext: int = 0):
         """d_ext: the 32-bit plane of the records (k = 26 .. 31), grouped like them."""
         _check(lib().rfx_count_add_records_ext_dev(self._h, d_records, d_ext or None, n_records, d_bin_start, bins),

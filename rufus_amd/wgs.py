@@ -35,6 +35,27 @@ def _device_view32(ptr: int, n: int, device):
     return torch.as_tensor(_DevMem32(ptr, n), device=device)
 
 
+class _LibraryCall:
+    """fn(*args) on a helper thread (ctypes releases the GIL); .err = what it raised."""
+
+    def __init__(self, fn, *args):
+        import threading
+        self.err = None
+        self._t = threading.Thread(target=self._run, args=(fn, args), daemon=True)
+
+    def _run(self, fn, args):
+        try:
+            fn(*args)
+        except Exception as e:      # carried to the next checkpoint by the caller
+            self.err = e
+
+    def start(self):
+        self._t.start()
+
+    def join(self):
+        self._t.join()
+
+
 class GroupFailure(capi.RufusError):
     """A step failed on SOME rank of the group and every rank knows it: all of them raise this at the same
     checkpoint, so that none is left waiting in a collective.  retry: the failure was a lack of device memory --
@@ -130,13 +151,23 @@ class WgsTrio:
                 if self.passes > 1:
                     t.set_shard(shard, self.passes)
                 self._inject("partition", shard)
-                for b in blocks:
+                # on a group the other blocks are partitioned while the records of the one before travel
+                for b in blocks[:1] if self._overlap() else blocks:
                     t.add(b)
             except Exception as e:
                 err = e
-            return self._exchange_and_count(t, shard, err)
+            return self._exchange_and_count(t, shard, err, blocks)
         finally:
             t.free()
+
+    def _overlap(self) -> bool:
+        """Partition block i + 1 while the records of block i travel?  Yes between devices (RCCL over xGMI moves
+        ~0.3 TB/s, a fraction of what the partition leaves of the HBM bandwidth); no when the "exchange" is a copy
+        inside one device (RFX_WGS_FORCE_EXCHANGE on one rank: the copy runs at HBM speed against the partition's
+        scattered stores -- measured: 66-86 ms per round together, 25 + 5 ms one after the other).  RFX_WGS_OVERLAP=0/1
+        overrides.  Not measured on several GPUs (a one-GPU box cannot): profiles/r03_exchange_big.txt."""
+        ev = os.environ.get("RFX_WGS_OVERLAP")
+        return (ev != "0") if ev is not None else self.world > 1
 
     def checkpoint(self, err=None):
         """All ranks: did the step succeed everywhere?  One 8-byte all-reduce (MIN of 2 = fine, 1 = out of device
@@ -171,49 +202,64 @@ class WgsTrio:
             self._injected = True
             raise capi.RufusError(f"injected: out of device memory at {stage} of shard {shard}")
 
-    def _exchange_and_count(self, part: capi.CountTable, shard: int, err=None):
-        """err: what the partition raised on this rank, if anything.  Checkpoints (see checkpoint()): after the
-        partition, in every round after the receive buffers are allocated (before any record travels), and after
-        the owner's count -- a failure between two of them is carried to the next one, never into a collective."""
+    def _exchange_and_count(self, part: capi.CountTable, shard: int, err, blocks):
+        """One round per block: the records of block i go to the owners of their bins (RCCL, torch's stream) WHILE
+        block i + 1 is partitioned (the library's stream; rfx_count_add waits for a big block's sizes, so it is called
+        from a helper thread -- the library is used by one thread at a time: the main thread makes no library call
+        between the helper's start and its join).  part holds blocks[0] already (all blocks when _overlap() says no);
+        err: what that raised, if anything.
+        Checkpoints (see checkpoint()): before the first round, in every round after the receive buffers are
+        allocated (before any record travels), and after the owner's count -- a failure between two of them is
+        carried to the next one, never into a collective."""
         import torch
         import torch.distributed as dist
         from .dist import _device_view, _wire, exchange_rows
         W, me, Q = self.world, self.rank, self.passes * self.world
         dev = torch.device("cuda", torch.cuda.current_device())
         vb = [shard_cut(shard * W + g, Q) for g in range(W + 1)]       # owners' ranges in virtual bins
-        segs = []
-        if err is None:
-            try:
-                segs = part.segments()                                  # synchronises: the arrays are complete
-            except Exception as e:
-                err = e
         self.checkpoint(err)
-        # every rank may hold a different number of segments (blocks): agree on the rounds
-        n_seg = torch.tensor([len(segs)], dtype=torch.int64, device=dev)
+        # every rank may hold a different number of blocks: agree on the rounds
+        n_seg = torch.tensor([len(blocks)], dtype=torch.int64, device=dev)
         n_seg = _wire(n_seg, self.group)
         dist.all_reduce(n_seg, op=dist.ReduceOp.MAX, group=self.group)
         rounds = int(n_seg.item())
         own = capi.CountTable(self.ctx, self.k, self.size, True, mode=capi.COUNT_MSP)
         trace = os.environ.get("RFX_WGS_TRACE")
-        tt = {"meta": 0.0, "alloc": 0.0, "move": 0.0, "import": 0.0}
+        tt = {"segment": 0.0, "meta": 0.0, "alloc": 0.0, "move": 0.0, "join": 0.0, "import": 0.0}
 
-        def lap(what, t0):
+        def lap(what, t0):      # RFX_WGS_TRACE=host: host wall time only (no device synchronisation: the overlap stays)
             if trace:
-                torch.cuda.synchronize(dev)
+                if trace != "host":
+                    torch.cuda.synchronize(dev)
                 tt[what] += time.perf_counter() - t0
             return time.perf_counter()
+        helper = None
+        overlap = self._overlap()
         try:
             own.set_shard(shard * W + me, Q)
             keep = []
             wide = self.k > 25      # records = 64-bit word + 32-bit plane: the plane travels in a second all-to-all
+            seg_done = 0
             for i in range(rounds):
                 ext = None
-                if i < len(segs):
-                    d_rec, d_bs, bins, n = segs[i]
+                seg = None
+                d_ext = 0
+                t_ = time.perf_counter()
+                if err is None and i < len(blocks):
+                    try:        # block i's segment, if it made one (waits for its partition)
+                        if part.n_segments() > seg_done:
+                            seg = part.segment(seg_done)
+                            d_ext = part.segment_ext(seg_done) if wide else 0
+                            seg_done += 1
+                    except Exception as e:
+                        err = e
+                t_ = lap("segment", t_)
+                helper = None
+                if seg is not None:
+                    d_rec, d_bs, bins, n = seg
                     rec = _device_view(d_rec, n, dev) if n else torch.empty(0, dtype=torch.int64, device=dev)
                     bs_host = _device_view(d_bs, bins + 1, dev).cpu()
                     if wide:
-                        d_ext = part.segment_ext(i)
                         ext = (_device_view32(d_ext, n, dev) if n and d_ext else
                                torch.empty(0, dtype=torch.int32, device=dev))
                 else:                                   # nothing to send in this round
@@ -222,7 +268,6 @@ class WgsTrio:
                     bs_host = torch.zeros(bins + 1, dtype=torch.int64)
                     if wide:
                         ext = torch.empty(0, dtype=torch.int32, device=dev)
-                t_ = time.perf_counter()
                 per = bins // 256
                 cuts = bs_host[torch.tensor([v * per for v in vb])]
                 send_l = (cuts[1:] - cuts[:-1]).tolist()
@@ -250,8 +295,15 @@ class WgsTrio:
                         re_ = torch.empty(sum(recv_l), dtype=torch.int32, device=we.device)
                 except Exception as e:
                     err = e
-                self.checkpoint(err)        # also carries a failed import of the round before
+                self.checkpoint(err)        # also carries a failed import / partition of the round before
                 t_ = lap("alloc", t_)
+                # Only now, with the round's small collectives done: a partition kernel fills every CU for its ~10 ms,
+                # and anything queued behind it on the device waits that long -- measured on one GPU: with the helper
+                # started before the metadata exchange every one of its two all-to-alls took a block's partition time
+                # (16 ms per round, +2.5 s per W trio in 171 rounds).  The bulk transfer can wait; latency cannot.
+                if overlap and i + 1 < len(blocks):
+                    helper = _LibraryCall(part.add, blocks[i + 1])
+                    helper.start()
                 exchange_rows(rr, wr, recv_l, send_l, self.group)
                 if wide:
                     exchange_rows(re_, we, recv_l, send_l, self.group)
@@ -260,6 +312,10 @@ class WgsTrio:
                     torch.cuda.current_stream(rr.device).synchronize()   # the library runs on its own stream
                 rr, rb = rr.to(dev), rb.cpu()
                 t_ = lap("move", t_)
+                if helper is not None:      # the next block is partitioned (or failed to be): the library is ours again
+                    helper.join()
+                    err = err or helper.err
+                t_ = lap("join", t_)
                 # the bin offsets of every source's run go up first, ONE synchronisation of torch's stream covers them
                 # all (round 2 waited once per source), then the imports are queued back to back on the library's stream
                 ro = bo = 0
@@ -306,6 +362,8 @@ class WgsTrio:
             self.checkpoint(err)
             return out
         finally:
+            if helper is not None:      # (left by an exception: nobody else may be inside the library when tables go)
+                helper.join()
             own.free()
 
     def _after_count(self, rec, recs, si, sh, cand, ver, verify, probe_keys, keep_shard_records, lap):

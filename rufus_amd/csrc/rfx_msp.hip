@@ -624,6 +624,8 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
           __syncthreads();
           if (threadIdx.x < P1_BINS) {
             const uint32_t cn = s_pc[threadIdx.x];
+            // (128 cursors shared by every workgroup look like a hot spot; they are not: with the reservation faked --
+            // -DRFX_TIMING experiment, results void -- the flush lost 14 % of its cycles, the kernel 3.5 %)
             const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
             if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
               atomicExch(flag, 1u);

@@ -99,10 +99,15 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   if (threadIdx.x < 2 * P1_BINS) (&s_cnt[0][0])[threadIdx.x] = 0;
   const uint32_t SLAB = 1u << slab_log2;
   const uint32_t tick_mask = SLAB >= 128 ? 3u : SLAB >= 64 ? 1u : 0u;  // bins move on every 4 / 2 / 1 phases
-  uint64_t pending = ~0ull;  // threads < P1_BINS: the slab reserved ahead for their bin
+  // threads < P1_BINS: where the slab reserved ahead for their bin starts (the raw value of the cursor: it is looked at
+  // only when the slab is taken into use, a turn later -- looking at it at once made the two waves of these threads
+  // wait for the atomic, and the workgroup for them at the next barrier, at every turn); P1_NO_SLAB: none
+  constexpr uint32_t P1_NO_SLAB = 0xFFFFFFFFu;
+  uint32_t pending = P1_NO_SLAB;
   uint32_t tick = 0;
-  auto reserve_slab = [&](uint32_t b) -> uint64_t {
-    const uint32_t at = atomicAdd(&coarse_cur[b * P1_CUR_STRIDE], SLAB);
+  auto reserve_raw = [&](uint32_t b) -> uint32_t { return atomicAdd(&coarse_cur[b * P1_CUR_STRIDE], SLAB); };
+  auto slab_at = [&](uint32_t b, uint32_t at) -> uint64_t {
+    if (at == P1_NO_SLAB) return ~0ull;
     if ((uint64_t)at + SLAB > cap_a) {  // over capacity: records are dropped, the host redoes the block
       atomicExch(flag, 1u);
       return ~0ull;
@@ -113,9 +118,9 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     // only the coarse bins this shard's records can fall into have memory behind them
     const bool used = bin_hi > bin_lo && threadIdx.x >= (bin_lo >> sub_bits) && threadIdx.x <= ((bin_hi - 1) >> sub_bits);
     s_fill[threadIdx.x] = 0;
-    s_slab[0][threadIdx.x] = used ? reserve_slab(threadIdx.x) : ~0ull;
-    s_slab[1][threadIdx.x] = used ? reserve_slab(threadIdx.x) : ~0ull;
-    pending = used ? reserve_slab(threadIdx.x) : ~0ull;
+    s_slab[0][threadIdx.x] = used ? slab_at(threadIdx.x, reserve_raw(threadIdx.x)) : ~0ull;
+    s_slab[1][threadIdx.x] = used ? slab_at(threadIdx.x, reserve_raw(threadIdx.x)) : ~0ull;
+    pending = used ? reserve_raw(threadIdx.x) : P1_NO_SLAB;
   }
   const uint32_t n_chunks = (rv.n + MP1_BLOCK - 1) / MP1_BLOCK;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -137,7 +142,25 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     uint32_t a[WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-(WL-1) .. p0+7
 #pragma unroll
     for (int i = 0; i < WL - 1 + P1_S; ++i) a[i] = ~0u;
+    // Reads of up to 160 bases are loaded whole, here: a load in the middle of the chunk has to wait for every record
+    // store issued before it (vmcnt counts loads and stores in one queue), five times per 150 bp read.
+    constexpr int PW = 5;
+    const bool whole = s_maxlen <= PW * 32 + 1;  // (uniform over the workgroup)
+    uint64_t wq[PW];
+    uint32_t mq[PW];
+    if (whole) {
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        wq[i] = (uint32_t)i * 32u < len ? cw[i] : 0;
+        mq[i] = cm ? ((uint32_t)i * 32u < len ? cm[i] : 0u) : ~0u;
+      }
+      // the wait for these loads belongs HERE (an empty asm that "uses" the registers), not at their first use in the loop
+#pragma unroll
+      for (int i = 0; i < PW; ++i) asm volatile("" : "+v"(wq[i]), "+v"(mq[i]));
+    }
     TM_DECL;
+    auto phases = [&](auto whole_tag) {
+    constexpr bool WHOLE = decltype(whole_tag)::value;
     for (uint32_t ph = 0; ph < n_phase; ++ph) {
       TM(3);
       const uint32_t X = ph & 1u;
@@ -148,9 +171,19 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
       for (int b = 0; b < P1_S; ++b) br[b] = ~0u;
       {
         const uint32_t p0 = ph * P1_S;
-        if ((ph & 3) == 0 && p0 < len) {
-          cur_w = cw[p0 >> 5];
-          cur_m = cm ? cm[p0 >> 5] : ~0u;
+        if ((ph & 3) == 0) {
+          if (WHOLE) {  // (past the end of a short read: zeros nobody looks at)
+            cur_w = wq[0];
+            cur_m = mq[0];
+#pragma unroll
+            for (int i = 0; i + 1 < PW; ++i) {
+              wq[i] = wq[i + 1];
+              mq[i] = mq[i + 1];
+            }
+          } else if (p0 < len) {
+            cur_w = cw[p0 >> 5];
+            cur_m = cm ? cm[p0 >> 5] : ~0u;
+          }
         }
         // window minimum = min(suffix minimum of the 14 old hashes, prefix minimum of the new ones)
         uint32_t sfx[WL - 1];
@@ -261,22 +294,22 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
       }
       TM(0);
       if (HMODE == 1) continue;
-      if (SLABS) {
+      if constexpr (SLABS) {
         if ((++tick & tick_mask) == 0) {
           __syncthreads();  // every slot of the interval has been handed out
           if (threadIdx.x < P1_BINS) {
             uint32_t f = s_fill[threadIdx.x];
             if (f >= SLAB) {
               if (f >= 2 * SLAB) {  // both slabs are full (what came after them went the slow way)
-                s_slab[0][threadIdx.x] = pending;
-                s_slab[1][threadIdx.x] = reserve_slab(threadIdx.x);
+                s_slab[0][threadIdx.x] = slab_at(threadIdx.x, pending);
+                s_slab[1][threadIdx.x] = slab_at(threadIdx.x, reserve_raw(threadIdx.x));
                 f = 0;
               } else {
                 s_slab[0][threadIdx.x] = s_slab[1][threadIdx.x];
-                s_slab[1][threadIdx.x] = pending;
+                s_slab[1][threadIdx.x] = slab_at(threadIdx.x, pending);
                 f -= SLAB;
               }
-              pending = reserve_slab(threadIdx.x);  // used at a later turn: nobody waits for this one
+              pending = reserve_raw(threadIdx.x);  // looked at when it is taken into use: nobody waits for this one
               s_fill[threadIdx.x] = f;
             }
           }
@@ -329,10 +362,16 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
       TM(2);
       // (s_gbase[X ^ 1] is rewritten two phases on: a barrier lies between)
     }
+    };
+    // two copies of the loop: the one for whole reads holds no load, so nothing in it waits for the record stores
+    // (vmcnt counts loads and stores in one queue: with a load anywhere in the loop the compiler put an
+    // `s_waitcnt vmcnt(0)` at the top of EVERY phase, and every phase waited for the scattered stores of the one before)
+    if (whole) phases(std::true_type());
+    else phases(std::false_type());
   }
   __syncthreads();
   if (SLABS) {  // the slots nobody took: MSP_EMPTY
-    if (threadIdx.x < P1_BINS) s_slab[2][threadIdx.x] = pending;
+    if (threadIdx.x < P1_BINS) s_slab[2][threadIdx.x] = slab_at(threadIdx.x, pending);
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < 3u * P1_BINS * SLAB; i += blockDim.x) {
       const uint32_t o = i & (SLAB - 1), bw = i >> slab_log2, b = bw & (P1_BINS - 1), which = bw >> 7;  // P1_BINS = 2^7

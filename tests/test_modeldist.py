@@ -121,6 +121,23 @@ def test_executable_writes_the_reference_binarys_files(tmp_path, name):
 
 
 @pytest.mark.gpu
+def test_three_fits_at_once_as_the_pipeline_starts_them(tmp_path):
+    """runRufus.sh:849-853 starts the parents' fits in the background while the proband's runs: three processes on the
+    one device at the same time, each with its own context."""
+    names = ["child", "child1200", "wgs1200"]
+    procs = []
+    for n in names:
+        (tmp_path / (n + ".histo")).write_text(open(os.path.join(GOLD, n + ".histo")).read())
+        procs.append(subprocess.Popen([f"{BIN}/ModelDist", n + ".histo", "25", "150", "8"], cwd=tmp_path,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    for n, pr in zip(names, procs):
+        out, err = pr.communicate(timeout=300)
+        assert pr.returncode == 0, err
+        same_text(out, open(os.path.join(GOLD, n + ".out")).read(), n + ".out")
+        assert header((tmp_path / (n + ".histo.7.7.model")).read_text()) == header(golden(n, ".7.7.model"))
+
+
+@pytest.mark.gpu
 def test_wall_time_beside_the_reference_binary(tmp_path):
     """The executable next to `oracle/_ref/ModelDist` (the reference's source, `g++ -O2 -fopenmp`, its 11 OpenMP
     threads) on this box's host cores, same table; the figures go to gpurun_out/modeldist_wall.txt."""

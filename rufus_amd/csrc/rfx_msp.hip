@@ -108,9 +108,9 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   auto reserve_raw = [&](uint32_t b) -> uint32_t { return atomicAdd(&coarse_cur[b * P1_CUR_STRIDE], SLAB); };
   auto slab_at = [&](uint32_t b, uint32_t at) -> uint64_t {
     if (at == P1_NO_SLAB) return ~0ull;
-    if ((uint64_t)at + SLAB > cap_a) {  // over capacity: records are dropped, the host redoes the block
-      atomicExch(flag, 1u);
-      return ~0ull;
+    if ((uint64_t)at + SLAB > cap_a) {  // over capacity: the host redoes the block; until then records of this bin land
+      atomicExch(flag, 1u);             // on its first slab (inside the bin's memory: no test on the store path)
+      return (uint64_t)b * cap_a;
     }
     return (uint64_t)b * cap_a + at;
   };
@@ -213,15 +213,19 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
             // k_slice_tag refine the partition later without separating instances of a k-mer.
             const uint32_t mh = min(sfx[b], pm);
             // (bitwise, not short-circuit: one exec mask instead of three nested ones)
-            if ((run_n != 0) & (!kvalid | (mh != run_h) | (run_n == MSP_NMAX))) {
-              // close the run that ended at the previous base: `hist` still ends there
-              const uint32_t run_bin = msp_bin(run_h, bin_bits);
+            // The run that ended at the previous base closes (`hist` still ends there), and it is ours (shard passes: other
+            // bins are not; unsigned: one compare).  ONE predicate for the block below: the wave enters it at nearly
+            // every base anyway (one lane in three closes), so what is computed for it outside costs nothing extra, and
+            // every level of nesting less is a saved exec mask, a branch and a restore.
+            const bool closes = (run_n != 0) & (!kvalid | (mh != run_h) | (run_n == MSP_NMAX));
+            const uint32_t run_bin = msp_bin(run_h, bin_bits);
   #ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
-              const bool mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
+            const bool mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
   #else
-              const bool mine = run_bin - bin_lo < bin_hi - bin_lo;  // shard passes: other bins are not ours (unsigned: one compare)
+            const bool mine = run_bin - bin_lo < bin_hi - bin_lo;
   #endif
-              if (HMODE != 1 && mine) {
+            if (closes & mine) {
+              if (HMODE != 1) {
                 const int L = k + run_n - 1;
                 const uint32_t coarse = run_bin >> sub_bits;
                 // the record ends at base e = p0 + b - 1; its minimizer m-mer ends at the last base q <= e with
@@ -252,12 +256,10 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
                 }
                 if (SLABS) {
                   const uint32_t slot = atomicAdd(&s_fill[coarse], 1u);
-                  if (slot < 2 * SLAB) {
+                  if (slot < 2 * SLAB) {  // (a bin of ours always has a slab behind it: slab_at)
                     const uint64_t sb = s_slab[slot >> slab_log2][coarse];
-                    if (sb != ~0ull) {
-                      buf_a[sb + (slot & (SLAB - 1))] = wv[b];
-                      if (WIDE) ext_a[sb + (slot & (SLAB - 1))] = xv[b];
-                    }
+                    buf_a[sb + (slot & (SLAB - 1))] = wv[b];
+                    if (WIDE) ext_a[sb + (slot & (SLAB - 1))] = xv[b];
                   } else {  // more than two slabs' worth since the bins last moved on: one reservation per record
                     const uint32_t at = atomicAdd(&coarse_cur[coarse * P1_CUR_STRIDE], 1u);
                     if (at < cap_a) {
@@ -272,10 +274,10 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
                   br[b] = (coarse << 16) | atomicAdd(&s_cnt[X][coarse], 1u);
                 }
               }
-              if ((HMODE == 0 || HMODE == 3) && mine) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
-              if (HMODE == 1 && mine) atomicAdd(&s_fine[run_bin], 1u);
-              run_n = 0;
+              if (HMODE == 0 || HMODE == 3) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
+              if (HMODE == 1) atomicAdd(&s_fine[run_bin], 1u);
             }
+            run_n = closes ? 0 : run_n;
             run_h = kvalid && !run_n ? mh : run_h;  // (selects, not branches: two instructions instead of a saved exec mask)
             run_n += kvalid ? 1 : 0;
             if (WIDE) hist_hi = (hist_hi << 2) | (uint32_t)(hist >> 62);

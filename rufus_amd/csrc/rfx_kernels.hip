@@ -577,14 +577,18 @@ __global__ __launch_bounds__(256) void k_flag_absent(const uint64_t* __restrict_
 // probes each through L2): both lists are in (pos,key) order, so the records of B that can match a tile of 2048
 // candidates are one short range -- between the lower bounds of the tile's first candidate and of the next tile's
 // (k_fa_bounds: one search per tile) -- which is staged in LDS and bisected there.
-constexpr int FA_TILE = 2048, FA_BCAP = 3072;
+// The tile is sized by the launcher so that the control's range of a tile fits the LDS with room to spare (2048
+// candidates at most, fewer when the control holds more records than there are candidates).
+// Small tiles (16 KB of LDS): eight workgroups per CU take turns at fetching and searching; with 48 KB tiles three did,
+// and the kernel ran at a quarter of the HBM rate.
+constexpr int FA_TILE_MAX = 768, FA_BCAP = 1024, FA_STEPS = 11;  // 2^FA_STEPS > FA_BCAP
 
 __global__ __launch_bounds__(256) void k_fa_bounds(const uint64_t* __restrict__ keys, const uint64_t* __restrict__ pos,
                                                     uint64_t n, const uint64_t* __restrict__ bkeys,
                                                     const uint64_t* __restrict__ bpos, uint64_t nb, int lsize,
-                                                    uint64_t n_tiles, uint64_t* __restrict__ bounds /* n_tiles + 1 */) {
+                                                    uint64_t n_tiles, uint32_t tile, uint64_t* __restrict__ bounds /* n_tiles + 1 */) {
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t <= n_tiles; t += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t i = t * FA_TILE;
+    const uint64_t i = t * tile;
     bounds[t] = i < n ? lower_bound_near(bkeys, bpos, nb, pos[i], keys[i], lsize) : nb;
   }
 }
@@ -593,17 +597,28 @@ __global__ __launch_bounds__(256) void k_flag_absent_tiled(const uint64_t* __res
                                                             const uint64_t* __restrict__ pos, uint64_t n,
                                                             const uint64_t* __restrict__ bkeys,
                                                             const uint64_t* __restrict__ bpos, uint64_t nb, int lsize,
-                                                            uint64_t n_tiles, const uint64_t* __restrict__ bounds,
+                                                            uint64_t n_tiles, uint32_t tile,
+                                                            const uint64_t* __restrict__ bounds,
                                                             uint8_t* __restrict__ flags) {
   __shared__ uint64_t s_bk[FA_BCAP], s_bp[FA_BCAP];
+  // (the bounds of the next tile are fetched a tile ahead: what the loads of a tile need is there when they are issued)
+  uint64_t nx_lo = 0, nx_hi = 0;
+  if (blockIdx.x < n_tiles) {
+    nx_lo = bounds[blockIdx.x];
+    nx_hi = bounds[blockIdx.x + 1];
+  }
   for (uint64_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-    const uint64_t a0 = t * FA_TILE, a1 = a0 + FA_TILE < n ? a0 + FA_TILE : n;
-    const uint64_t lo = bounds[t], hi = bounds[t + 1] < nb ? bounds[t + 1] + 1 : nb;  // B records that can match the tile
+    const uint64_t a0 = t * tile, a1 = a0 + tile < n ? a0 + tile : n;
+    const uint64_t lo = nx_lo, hi = nx_hi < nb ? nx_hi + 1 : nb;  // B records that can match the tile
+    if (t + gridDim.x < n_tiles) {
+      nx_lo = bounds[t + gridDim.x];
+      nx_hi = bounds[t + gridDim.x + 1];
+    }
     const uint32_t nbr = hi - lo <= (uint64_t)FA_BCAP ? (uint32_t)(hi - lo) : 0u;
     if (hi - lo <= (uint64_t)FA_BCAP) {
       // the tile's candidates are fetched together with the control's range: one HBM round trip per tile (a load per
       // candidate inside the search loop, flag first, was seventeen of them one after the other: 81 us per tile)
-      constexpr int PER = FA_TILE / 256;
+      constexpr int PER = FA_TILE_MAX / 256;  // (tile <= FA_TILE_MAX: what lies beyond a1 is not fetched)
       uint64_t ck[PER], cp[PER];
       uint8_t cf[PER];
 #pragma unroll
@@ -619,19 +634,29 @@ __global__ __launch_bounds__(256) void k_flag_absent_tiled(const uint64_t* __res
         s_bp[j] = bpos[lo + j];
       }
       __syncthreads();
+      // the lane's searches advance together, one comparison each per step: eight independent LDS round trips in flight
+      // instead of a chain of 11 x 2 per candidate
+      uint32_t at[PER], len[PER];
 #pragma unroll
       for (int u = 0; u < PER; ++u) {
-        if (!cf[u]) continue;
-        const uint64_t k = ck[u], p = cp[u];
-        uint32_t l = 0, h = nbr;
-        while (l < h) {
-          const uint32_t mid = (l + h) >> 1;
-          const uint64_t mp = s_bp[mid];
-          if (mp < p || (mp == p && s_bk[mid] < k)) l = mid + 1;
-          else h = mid;
-        }
-        if (l < nbr && s_bk[l] == k && s_bp[l] == p) flags[a0 + threadIdx.x + (uint64_t)u * 256] = 0;
+        at[u] = 0;
+        len[u] = cf[u] ? nbr : 0u;
       }
+      for (int step = 0; step < FA_STEPS; ++step) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const bool act = len[u] > 0;
+          const uint32_t half = len[u] >> 1, mid = at[u] + half;
+          const uint64_t mp = s_bp[act ? mid : 0u], mk = s_bk[act ? mid : 0u];
+          const bool less = mp < cp[u] || (mp == cp[u] && mk < ck[u]);
+          at[u] = act && less ? mid + 1 : at[u];
+          len[u] = act ? (less ? len[u] - half - 1 : half) : 0u;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < PER; ++u)
+        if (cf[u] && at[u] < nbr && s_bk[at[u]] == ck[u] && s_bp[at[u]] == cp[u])
+          flags[a0 + threadIdx.x + (uint64_t)u * 256] = 0;
       __syncthreads();
     } else {  // few candidates against many records: every candidate searches for itself
       for (uint64_t i = a0 + threadIdx.x; i < a1; i += blockDim.x) {
@@ -700,17 +725,29 @@ __global__ __launch_bounds__(64) void k_compact_scatter(const uint8_t* __restric
   const uint64_t base = (uint64_t)blockIdx.x * CP_ITEMS;
   uint64_t o = block_off[blockIdx.x];
   const int lane = threadIdx.x;
-  for (uint32_t j = 0; j < CP_ITEMS; j += WAVE) {
-    const uint64_t i = base + j + lane;
-    const bool f = i < n && flags[i] != 0;
-    const unsigned long long m = __ballot(f);
-    if (f) {
-      const uint64_t d = o + __popcll(m & ((1ull << lane) - 1));
-      out_keys[d] = keys[i];
-      out_counts[d] = counts[i];
-      if (out_pos) out_pos[d] = pos[i];
+  // four groups of flags are fetched before any is looked at (one flag load, then the loads it allows, per trip made
+  // a block of mostly-zero flags -- the strike-out against a control -- 64 dependent round trips long)
+  constexpr int G = 4;
+  static_assert(CP_ITEMS % (G * WAVE) == 0, "");
+  for (uint32_t j = 0; j < CP_ITEMS; j += G * WAVE) {
+    bool f[G];
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const uint64_t i = base + j + u * WAVE + lane;
+      f[u] = i < n && flags[i] != 0;
     }
-    o += __popcll(m);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const uint64_t i = base + j + u * WAVE + lane;
+      const unsigned long long m = __ballot(f[u]);
+      if (f[u]) {
+        const uint64_t d = o + __popcll(m & ((1ull << lane) - 1));
+        out_keys[d] = keys[i];
+        out_counts[d] = counts[i];
+        if (out_pos) out_pos[d] = pos[i];
+      }
+      o += __popcll(m);
+    }
   }
 }
 
@@ -1482,14 +1519,17 @@ void flag_absent(rfx_ctx* c, const uint64_t* keys, const uint64_t* pos, uint64_t
                  const uint64_t* bpos, uint64_t nb, int lsize, uint8_t* flags) {
   if (n == 0 || nb == 0) return;
   rfx_span sp(c, "k_flag_absent");
-  const uint64_t n_tiles = (n + FA_TILE - 1) / FA_TILE;
+  // candidates per tile: the control's share of a tile (nb / n records per candidate) should fill ~2/3 of the LDS range
+  uint32_t tile = FA_TILE_MAX;
+  if (nb > n) tile = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(FA_TILE_MAX, (uint64_t)(FA_BCAP * 2 / 3) * n / nb / 64 * 64));
+  const uint64_t n_tiles = (n + tile - 1) / tile;
   const char* tmin = getenv("RFX_K4_TILE_MIN");  // (tests lower it to put small inputs through the tiles)
   uint64_t* bounds = n >= (tmin ? strtoull(tmin, nullptr, 10) : 1ull << 20) ? (uint64_t*)rfxi::dmalloc(c, (n_tiles + 1) * 8) : nullptr;
   if (bounds) {  // big inputs: a short range of B per tile, bisected in LDS
     hipLaunchKernelGGL(k_fa_bounds, dim3(grid_for(c, n_tiles + 1, 256, 8)), dim3(256), 0, c->stream, keys, pos, n, bkeys, bpos,
-                       nb, lsize, n_tiles, bounds);
-    hipLaunchKernelGGL(k_flag_absent_tiled, dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 12)), dim3(256), 0,
-                       c->stream, keys, pos, n, bkeys, bpos, nb, lsize, n_tiles, bounds, flags);
+                       nb, lsize, n_tiles, tile, bounds);
+    hipLaunchKernelGGL(k_flag_absent_tiled, dim3((unsigned)std::min<uint64_t>(n_tiles, (uint64_t)c->n_cu * 16)), dim3(256), 0,
+                       c->stream, keys, pos, n, bkeys, bpos, nb, lsize, n_tiles, tile, bounds, flags);
     rfxi::dfree(c, bounds);  // (stream-ordered)
     return;
   }

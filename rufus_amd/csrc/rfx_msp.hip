@@ -970,7 +970,9 @@ void surv_sort(rfx_ctx* c, const uint64_t* bw, const uint32_t* bc, const uint64_
                const uint64_t* lut_inv, int ntab, int sel_bits, uint64_t* out_keys, uint32_t* out_counts,
                uint64_t* out_pos) {
   rfx_span sp(c, "k_surv_sort");
-  const uint32_t grid = P < (uint32_t)c->n_cu * 2 ? P : (uint32_t)c->n_cu * 2;  // the resident blocks (LDS: two per CU)
+  // the resident blocks: three per CU since a bin waits in registers (42 KB of LDS) -- 29 -> 21 ms per W sample; a fourth
+  // (seven tables, 40 KB) added nothing
+  const uint32_t grid = P < (uint32_t)c->n_cu * 3 ? P : (uint32_t)c->n_cu * 3;
   hipLaunchKernelGGL(k_surv_sort, dim3(grid), dim3(SS_BLOCK), 0, c->stream, bw, bc, bs, P, bin_shift, lut_inv, ntab,
                      sel_bits, out_keys, out_counts, out_pos);
 }

@@ -345,8 +345,18 @@ __global__ __launch_bounds__(512) void k_bin_hist(const uint64_t* __restrict__ s
     const uint64_t a = ps[b], e = ps[b + 1];
     if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    for (uint64_t i = a + (uint64_t)j * blockDim.x + threadIdx.x; i < e; i += (uint64_t)W * blockDim.x)
-      atomicAdd(&s_cnt[sub_bin_of<MODE>(src[i], shift2, P2, k)], 1u);
+    // four loads in flight per lane instead of one (a refinement parent gives a lane ~40 trips): 48 -> 43 ms per W
+    // sample, the 208 GB of records at 4.8 TB/s
+    const uint64_t stride = (uint64_t)W * blockDim.x;
+    uint64_t i = a + (uint64_t)j * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < e; i += 4 * stride) {
+      const uint64_t w0 = src[i], w1 = src[i + stride], w2 = src[i + 2 * stride], w3 = src[i + 3 * stride];
+      atomicAdd(&s_cnt[sub_bin_of<MODE>(w0, shift2, P2, k)], 1u);
+      atomicAdd(&s_cnt[sub_bin_of<MODE>(w1, shift2, P2, k)], 1u);
+      atomicAdd(&s_cnt[sub_bin_of<MODE>(w2, shift2, P2, k)], 1u);
+      atomicAdd(&s_cnt[sub_bin_of<MODE>(w3, shift2, P2, k)], 1u);
+    }
+    for (; i < e; i += stride) atomicAdd(&s_cnt[sub_bin_of<MODE>(src[i], shift2, P2, k)], 1u);
     __syncthreads();
     if (threadIdx.x < P2 && s_cnt[threadIdx.x])
       atomicAdd(&fine_tot[(uint64_t)b * P2 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);

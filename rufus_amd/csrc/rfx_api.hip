@@ -1441,6 +1441,7 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
     uint64_t *cb1 = nullptr, *cb2 = nullptr, *fine1 = nullptr, *fine2 = nullptr;
     uint32_t *ce1 = nullptr, *ce2 = nullptr;  // wide records: scratch for the 32-bit plane
     uint64_t max_chunk = 0;
+    const uint64_t** d_seg = nullptr;  // device: records / bin extents / planes of the group's segments (part2_multi)
   };
   const bool wide = rfxk::msp_wide(t->k);
   std::map<uint32_t, group> groups;
@@ -1490,7 +1491,7 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
   auto drop = [&] {
     for (auto& kv : groups) {
       dfree(c, kv.second.cb1); dfree(c, kv.second.cb2); dfree(c, kv.second.fine1); dfree(c, kv.second.fine2);
-      dfree(c, kv.second.ce1); dfree(c, kv.second.ce2);
+      dfree(c, kv.second.ce1); dfree(c, kv.second.ce2); dfree(c, kv.second.d_seg);
     }
   };
   size_t nleaf = 0;  // segments the leaf sees: one per refined group + the segments already at the target
@@ -1519,6 +1520,23 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
     if (!g.cb1 || !g.fine1 || (g.f2bits && (!g.cb2 || !g.fine2)) || (wide && (!g.ce1 || (g.f2bits && !g.ce2)))) {
       drop();
       return RFX_E_NOMEM;
+    }
+    // The first refinement level reads the slices of ALL the group's segments in one launch per chunk
+    // (rfxk::part2_multi): with a launch per segment (RFX_PART3_PER_SEG=1) a W sample took 646 launches of 2.5 tiles
+    // per workgroup.
+    if (g.segs.size() > 1 && g.segs.size() <= (size_t)rfxk::part2_max_segs && !getenv("RFX_PART3_PER_SEG")) {
+      const size_t ns = g.segs.size();
+      std::vector<const uint64_t*> hp(3 * ns, nullptr);
+      for (size_t x = 0; x < ns; ++x) {
+        const rfx_segment& sg = (*t->segs)[g.segs[x]];
+        hp[x] = sg.inst;
+        hp[ns + x] = sg.bin_start;
+        hp[2 * ns + x] = (const uint64_t*)sg.ext;
+      }
+      g.d_seg = (const uint64_t**)dmalloc(c, 3 * ns * sizeof(void*));
+      if (!g.d_seg) { drop(); return RFX_E_NOMEM; }
+      const hipError_t e = upload(c, g.d_seg, hp.data(), 3 * ns * sizeof(void*));
+      if (e != hipSuccess) { drop(); return hip_fail(e, "msp_leaf_refined"); }
     }
   }
   const uint64_t** d_ptrs = (const uint64_t**)dmalloc(c, 3 * nleaf * sizeof(void*) * (cut.size() - 1));
@@ -1557,9 +1575,15 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
           rfxk::bin_hist(c, (*t->segs)[si].inst, (*t->segs)[si].bin_start + gp0, gnp, chunk, F1, shift1, rec_mode, t->k,
                          g.fine1);
         rfxk::scan_tail(c, g.fine1, n1);
-        for (size_t si : g.segs)
-          rfxk::part2(c, (*t->segs)[si].inst, g.cb1, g.fine1, fcur1, F1, shift1, nullptr, 0, (*t->segs)[si].ext, g.ce1, ~0ull,
-                      "k_part3", (*t->segs)[si].bin_start + gp0, gnp, 0, rec_mode, t->k);
+        if (g.d_seg) {
+          const size_t ns = g.segs.size();
+          rfxk::part2_multi(c, g.d_seg, g.d_seg + ns, wide ? (const uint32_t* const*)(g.d_seg + 2 * ns) : nullptr, (int)ns,
+                            gp0, gnp, chunk, g.cb1, g.fine1, fcur1, F1, shift1, g.ce1, rec_mode, t->k, "k_part3");
+        } else {
+          for (size_t si : g.segs)
+            rfxk::part2(c, (*t->segs)[si].inst, g.cb1, g.fine1, fcur1, F1, shift1, nullptr, 0, (*t->segs)[si].ext, g.ce1,
+                        ~0ull, "k_part3", (*t->segs)[si].bin_start + gp0, gnp, 0, rec_mode, t->k);
+        }
       }
       const uint64_t *leaf_src = g.cb1, *leaf_bs = g.fine1;
       const uint32_t* leaf_ext = g.ce1;

@@ -338,6 +338,11 @@ void part2(rfx_ctx*, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* fin
            int rec_mode = 0 /* 0: sub-bin = bits of the word; 1 / 2: MSP record (canonical / not), sub-bin = bits
                                of its minimizer bin hash (shift2 then counts from bit 0 of that 32-bit hash) */,
            int k = 0, uint64_t fine_base = 0 /* buf_b holds the entries from fine_start value fine_base on */);
+// the same for coarse bins that lie in slices of nseg arrays (device arrays of nseg pointers; nseg <= part2_max_segs)
+constexpr int part2_max_segs = 64;
+void part2_multi(rfx_ctx*, const uint64_t* const* seg_a, const uint64_t* const* seg_cs, const uint32_t* const* seg_pay,
+                 int nseg, uint32_t cs_off, uint32_t n_coarse, uint64_t n_hint, uint64_t* buf_b, const uint64_t* fine_start,
+                 uint32_t* fine_cur, uint32_t P2, int shift2, uint32_t* pay_b, int rec_mode, int k, const char* span);
 // sizes of the P2 sub-bins of every parent bin: fine_tot[parent * P2 + sub] += ...
 void bin_hist(rfx_ctx*, const uint64_t* src, const uint64_t* parent_start, uint32_t n_parents, uint64_t n_hint,
               uint32_t P2, int shift2, int rec_mode, int k, uint64_t* fine_tot);

@@ -366,7 +366,11 @@ __global__ __launch_bounds__(512) void k_bin_hist(const uint64_t* __restrict__ s
 
 // Coarse bin cb of A -> its P2 fine bins in B.  W workgroups share a coarse bin (tiles strided).
 // PAYLOAD: every word carries a 32-bit count that moves with it (survivors of the MSP leaf).
-template <bool PAYLOAD, int MODE>
+// MULTI: coarse bin cb is the concatenation of its slices in nseg arrays (the read blocks of a sample, each partitioned
+// by itself: seg_a[s][seg_cs[s][cs_off + cb] .. seg_cs[s][cs_off + cb + 1])) -- one launch and full tiles instead of a
+// launch per block whose last tile of every bin is mostly empty.
+constexpr int L2_MAX_SEGS = 64;
+template <bool PAYLOAD, int MODE, bool MULTI = false>
 __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__ buf_a, uint64_t* __restrict__ buf_b,
                                                      const uint64_t* __restrict__ fine_start,
                                                      uint32_t* __restrict__ fine_cur, uint32_t P2, int shift2,
@@ -374,19 +378,44 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
                                                      uint32_t cap_a, const uint32_t* __restrict__ pay_a,
                                                      uint32_t* __restrict__ pay_b, uint64_t cap_b,
                                                      const uint64_t* __restrict__ coarse_start, int k,
-                                                     uint64_t fine_base) {
+                                                     uint64_t fine_base,
+                                                     const uint64_t* const* __restrict__ seg_a = nullptr,
+                                                     const uint64_t* const* __restrict__ seg_cs = nullptr,
+                                                     const uint32_t* const* __restrict__ seg_pay = nullptr,
+                                                     int nseg = 0, uint32_t cs_off = 0) {
   __shared__ uint64_t s_stage[L2_TILE];
   __shared__ uint32_t s_pay[PAYLOAD ? L2_TILE : 1];
   __shared__ uint8_t s_sbin[L2_TILE];
   __shared__ uint32_t s_cnt[256], s_start[257];
   __shared__ uint64_t s_gbase[256];
+  __shared__ uint64_t s_soff[MULTI ? L2_MAX_SEGS + 1 : 1];         // where slice s begins in the concatenation
+  __shared__ const uint64_t* s_sptr[MULTI ? L2_MAX_SEGS : 1];      // its first word
+  __shared__ const uint32_t* s_spay[MULTI && PAYLOAD ? L2_MAX_SEGS : 1];
   const uint32_t cb = blockIdx.x / W, j = blockIdx.x - cb * W;
+  if (MULTI) {
+    if (threadIdx.x < (uint32_t)nseg) {
+      const uint64_t* cs = seg_cs[threadIdx.x] + cs_off;
+      const uint64_t b0 = cs[cb], b1 = cs[cb + 1];
+      s_soff[threadIdx.x + 1] = b1 - b0;
+      s_sptr[threadIdx.x] = seg_a[threadIdx.x] + b0;
+      if (PAYLOAD) s_spay[threadIdx.x] = seg_pay[threadIdx.x] + b0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s_soff[0] = 0;
+      for (int s = 0; s < nseg; ++s) s_soff[s + 1] += s_soff[s];
+    }
+    __syncthreads();
+  }
   // coarse bin cb of A: given extents (refinement of an existing partition), fixed-capacity with a fill
   // cursor (fused path), or exactly sized = the extents of its fine bins in B
-  const uint64_t a = coarse_start ? coarse_start[cb] : coarse_cur ? (uint64_t)cb * cap_a : fine_start[(uint64_t)cb * P2];
-  const uint64_t e = coarse_start ? coarse_start[cb + 1]
+  const uint64_t a = MULTI ? 0 : coarse_start ? coarse_start[cb] : coarse_cur ? (uint64_t)cb * cap_a : fine_start[(uint64_t)cb * P2];
+  const uint64_t e = MULTI ? s_soff[nseg] : coarse_start ? coarse_start[cb + 1]
                      : coarse_cur ? a + min(coarse_cur[cb * P1_CUR_STRIDE], cap_a)
                                   : fine_start[(uint64_t)(cb + 1) * P2];
+  // MULTI: the slice a lane's next word lies in (its words come in rising order, so the cursor only moves on)
+  int seg = 0;
+  uint64_t seg_b = 0, seg_e = MULTI ? s_soff[1] : 0;
   if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   for (uint64_t base = a + (uint64_t)j * L2_TILE; base < e; base += (uint64_t)W * L2_TILE) {
@@ -396,8 +425,22 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
 #pragma unroll
     for (int u = 0; u < L2_PER; ++u) {
       const uint64_t i = base + threadIdx.x + (uint64_t)u * L2_BLOCK;
-      wv[u] = i < e ? buf_a[i] : 0;
-      if (PAYLOAD) pv[u] = i < e ? pay_a[i] : 0;
+      if (MULTI) {
+        wv[u] = 0;
+        if (PAYLOAD) pv[u] = 0;
+        if (i < e) {
+          while (i >= seg_e) {  // (i < e = s_soff[nseg]: stops at a slice that holds i, empty slices passed over)
+            ++seg;
+            seg_b = seg_e;
+            seg_e = s_soff[seg + 1];
+          }
+          wv[u] = s_sptr[seg][i - seg_b];
+          if (PAYLOAD) pv[u] = s_spay[seg][i - seg_b];
+        }
+      } else {
+        wv[u] = i < e ? buf_a[i] : 0;
+        if (PAYLOAD) pv[u] = i < e ? pay_a[i] : 0;
+      }
     }
 #pragma unroll
     for (int u = 0; u < L2_PER; ++u) {
@@ -872,6 +915,30 @@ void bin_hist(rfx_ctx* c, const uint64_t* src, const uint64_t* parent_start, uin
   else if (rec_mode == 1) RFX_BH(1);
   else RFX_BH(2);
 #undef RFX_BH
+}
+
+// One launch for the slices of all `nseg` arrays (k_part2<.., MULTI>): seg_a / seg_cs / seg_pay are DEVICE arrays of
+// nseg pointers (records, bin extents, planes or null); coarse bin cb = bins cs_off + cb of every array.
+void part2_multi(rfx_ctx* c, const uint64_t* const* seg_a, const uint64_t* const* seg_cs, const uint32_t* const* seg_pay,
+                 int nseg, uint32_t cs_off, uint32_t n_coarse, uint64_t n_hint, uint64_t* buf_b, const uint64_t* fine_start,
+                 uint32_t* fine_cur, uint32_t P2, int shift2, uint32_t* pay_b, int rec_mode, int k, const char* span) {
+  rfx_span sp(c, span);
+  if (!n_coarse) return;
+  // a handful of tiles per workgroup: the launch ends in a tail one workgroup long
+  const uint64_t tiles = n_hint / n_coarse / L2_TILE + 1;
+  const uint32_t W = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / 6));
+#define RFX_PART2M(PAY, MODE)                                                                                          \
+  hipLaunchKernelGGL((k_part2<PAY, MODE, true>), dim3(n_coarse * W), dim3(L2_BLOCK), 0, c->stream,                     \
+                     (const uint64_t*)nullptr, buf_b, fine_start, fine_cur, P2, shift2, W, (const uint32_t*)nullptr, 0u, \
+                     (const uint32_t*)nullptr, pay_b, ~0ull, (const uint64_t*)nullptr, k, (uint64_t)0, seg_a, seg_cs,  \
+                     seg_pay, nseg, cs_off)
+  if (seg_pay && rec_mode == 0) RFX_PART2M(true, 0);
+  else if (seg_pay && rec_mode == 1) RFX_PART2M(true, 1);
+  else if (seg_pay) RFX_PART2M(true, 2);
+  else if (rec_mode == 0) RFX_PART2M(false, 0);
+  else if (rec_mode == 1) RFX_PART2M(false, 1);
+  else RFX_PART2M(false, 2);
+#undef RFX_PART2M
 }
 
 void tmp_start(rfx_ctx* c, const uint64_t* const* seg_bs, int nseg, uint32_t P, uint64_t* out) {

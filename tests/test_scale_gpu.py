@@ -93,14 +93,19 @@ def _oracle_trio(sys_, n_pairs, k=K):
     return recs, hl, pulled
 
 
-@pytest.mark.parametrize("passes,block_pairs,refine,bins,compact",
-                         [(1, 1 << 20, None, None, False), (3, 7001, None, None, True), (2, 9000, "16", None, False),
-                          (5, 25000, "21", None, False), (3, 11000, "19", "32768", True),
-                          (1, 25000, None, "16384", True)])
-def test_trio_in_blocks_and_passes_matches_oracle(ctx, monkeypatch, passes, block_pairs, refine, bins, compact):
+@pytest.mark.parametrize("passes,block_pairs,refine,bins,compact,per_seg",
+                         [(1, 1 << 20, None, None, False, False), (3, 7001, None, None, True, False),
+                          (2, 9000, "16", None, False, False), (5, 25000, "21", None, False, False),
+                          (3, 11000, "19", "32768", True, False), (1, 25000, None, "16384", True, False),
+                          (2, 9000, "16", None, False, True), (3, 11000, "19", "32768", True, True)])
+def test_trio_in_blocks_and_passes_matches_oracle(ctx, monkeypatch, passes, block_pairs, refine, bins, compact, per_seg):
     """Multi-block samples, shard passes and chunked refinement of the partition give the oracle's records
     (shards interleaved), histogram, hash list and pulled pairs.  bins > 8192 takes the big-block path
-    (scatter, separate histogram pass, exact-size segment) that WGS-size blocks use."""
+    (scatter, separate histogram pass, exact-size segment) that WGS-size blocks use.  per_seg: the refinement
+    with one launch per read block (what samples of more than 64 blocks fall back to) instead of one per chunk
+    over the slices of all blocks."""
+    if per_seg:
+        monkeypatch.setenv("RFX_PART3_PER_SEG", "1")
     if refine:
         monkeypatch.setenv("RFX_MSP_REFINE_BITS", refine)
     if bins:

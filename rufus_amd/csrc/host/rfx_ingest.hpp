@@ -278,6 +278,7 @@ class CountIngest {
     // normally one reservation per piece; a piece with more reads than a staging block holds goes in slices
     const size_t total = start.size();
     size_t at = 0;
+    std::vector<uint32_t> woff_tmp;
     while (at < total) {
       uint32_t n = 0;
       uint64_t w = 0;
@@ -292,12 +293,16 @@ class CountIngest {
       uint64_t w0;
       if (!reserve(n, w, blk, r0, w0)) return;
       StageBlock& b = blocks_[(size_t)blk];
-      b.word_off[r0] = (uint32_t)w0;
-      // rfx_pack_spans writes word_off[r0 .. r0+n]: the last entry is also the neighbour range's first -- reads and
-      // words are reserved together, so both writers store the same value
+      // rfx_pack_spans writes n + 1 offsets, the last one being the neighbour range's first: it gets an array of this
+      // thread's own, and only the range's n entries go into the block (two threads storing the same value into one
+      // entry is still a data race -- ThreadSanitizer, tests/test_tsan_host.py); the entry behind the block's last
+      // read is the consumer's to write
+      woff_tmp.resize((size_t)n + 1);
+      woff_tmp[0] = (uint32_t)w0;
       const int rc = rfx_pack_spans(pc.b, start.data() + at, slen.data() + at, nullptr, n, 0, RFX_PACK_COUNT, b.codes, b.acgt,
-                                    nullptr, b.word_off + r0, b.len + r0);
+                                    nullptr, woff_tmp.data(), b.len + r0);
       if (rc) fail(std::string("rfx_pack_spans: ") + rfx_strerror(rc));
+      memcpy(b.word_off + r0, woff_tmp.data(), (size_t)n * sizeof(uint32_t));
       release(blk);
       at += n;
     }

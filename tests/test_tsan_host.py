@@ -1,0 +1,65 @@
+"""CPU-only race detection: the threaded host pipelines of the drop-in tools built with -fsanitize=thread and run on
+small inputs with many threads and tiny pieces -- the count ingest (rfx_ingest.hpp, tests/host/ingest_harness.cpp), the
+stranded feeder (pass_through_main.cpp) and `RUFUS.Filter --sam` (tests/host/filter_sam_harness.cpp: the tool's main()
+over host stand-ins for the device calls).  A report of ThreadSanitizer fails the test; outputs must equal those of
+the uninstrumented run of tests/test_filter_sam_host.py's generator."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+from tests.test_filter_sam_host import _hash_list, _shuffled_sam
+
+HOST = os.path.join(ROOT, "rufus_amd", "csrc")
+FLAGS = ["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread"]
+
+
+@pytest.fixture(scope="module")
+def tsan_bins(tmp_path_factory):
+    d = tmp_path_factory.mktemp("tsan")
+    probe = d / "probe.cpp"
+    probe.write_text("int main() { return 0; }\n")
+    if subprocess.run(FLAGS + ["-o", str(d / "probe"), str(probe)], stderr=subprocess.DEVNULL).returncode != 0 or \
+            subprocess.run([str(d / "probe")]).returncode != 0:
+        pytest.skip("no usable -fsanitize=thread here")
+    host = os.path.join(HOST, "rfx_host.cpp")
+    subprocess.check_call(FLAGS + ["-o", str(d / "filter"), os.path.join(ROOT, "tests", "host", "filter_sam_harness.cpp"), host])
+    subprocess.check_call(FLAGS + ["-o", str(d / "ingest"), os.path.join(ROOT, "tests", "host", "ingest_harness.cpp"), host])
+    subprocess.check_call(FLAGS + ["-DPTS_MODE=1", "-o", str(d / "feeder"), os.path.join(HOST, "host", "pass_through_main.cpp")])
+    return d
+
+
+def _run(cmd, cwd, env, stdin=None):
+    r = subprocess.run(cmd, cwd=cwd, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", **env), input=stdin,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert b"ThreadSanitizer" not in r.stderr and r.returncode == 0, r.stderr[-3000:]
+    return r.stdout
+
+
+def test_host_pipelines_are_race_free(tsan_bins, tmp_path):
+    d = str(tmp_path)
+    rng = np.random.default_rng(9)
+    sam = _shuffled_sam(rng, 1500)
+    open(f"{d}/in.sam", "wb").write(sam)
+    open(f"{d}/hl", "wb").write(_hash_list(rng, sam, 3000))
+    small = {"RFX_INGEST_PIECE": "4096", "RFX_HOST_THREADS": "6"}
+    _run([str(tsan_bins / "filter"), "--sam", "a.chr", "hl", "stdin", "a", "25", "15", "1", "6"], d, small, sam)
+    _run([str(tsan_bins / "filter"), "--sam", "b.chr", "hl", "in.sam", "b", "25", "15", "1", "6"], d, small)
+    for f in ("Mutations.Mate1.fastq", "Mutations.Mate2.fastq", "chr"):
+        assert open(f"{d}/a.{f}", "rb").read() == open(f"{d}/b.{f}", "rb").read()
+    assert open(f"{d}/a.Mutations.Mate1.fastq", "rb").read().count(b"\n") >= 40
+    _run([str(tsan_bins / "feeder"), "p.chr", "p"], d, {"RFX_PTS_THREADS": "4"}, sam)
+    # the paired tool on the feeder's two streams (two mate readers in lock step, helpers, ordered writer)
+    _run([str(tsan_bins / "filter"), "hl", "p.mate1.fastq", "p.mate2.fastq", "c", "25", "15", "1", "6"], d,
+         {"RFX_INGEST_PIECE": "4096"})
+    assert open(f"{d}/c.Mutations.Mate1.fastq", "rb").read() == open(f"{d}/a.Mutations.Mate1.fastq", "rb").read()
+    seqs = [np.frombuffer(b"ACGTN", np.uint8)[rng.choice(5, int(rng.choice([1, 25, 31, 32, 33, 100, 150, 151])),
+                                                          p=[.24, .25, .25, .25, .01])].tobytes() for _ in range(6000)]
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, s, b"I" * len(s)) for i, s in enumerate(seqs))
+    open(f"{d}/x.fq", "wb").write(fq)
+    outs = [_run([str(tsan_bins / "ingest"), "8", "500", "3000", "20000", "x.fq"], d, {}),
+            _run([str(tsan_bins / "ingest"), "8", "500", "3000", "20000", "x.fq"], d, {"INGEST_MMAP": "1"}),
+            _run([str(tsan_bins / "ingest"), "8", "500", "3000", "20000", "-"], d, {}, fq)]
+    assert len({o.rsplit(b" ", 1)[0] for o in outs}) == 1 and outs[0].startswith(b"ok 6000 ")

@@ -79,7 +79,7 @@ void process_stream(unsigned helpers, Parse parse, Consume consume) {
       if (!pc) pc = new Piece();
       size_t fill = carry.size();
       if (pc->text.size() < fill + PIECE + (1u << 20)) pc->text.resize(fill + PIECE + (1u << 20));
-      memcpy(pc->text.data(), carry.data(), fill);
+      if (fill) memcpy(pc->text.data(), carry.data(), fill);  // (an empty vector may hand out a null pointer)
       carry.clear();
       // a piece = at least PIECE bytes AND at least one line end (a line may be longer than any buffer so far)
       bool have_nl = fill && memchr(pc->text.data(), '\n', fill);

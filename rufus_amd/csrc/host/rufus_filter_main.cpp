@@ -240,7 +240,7 @@ static int run(int argc, char** argv) {
       pc->mapped = nullptr;
       size_t fill = carry.size();
       if (pc->text.size() < fill + PIECE + (1u << 20)) pc->text.resize(fill + PIECE + (1u << 20));
-      memcpy(pc->text.data(), carry.data(), fill);
+      if (fill) memcpy(pc->text.data(), carry.data(), fill);  // (an empty vector may hand out a null pointer)
       carry.clear();
       bool have_nl = fill && memchr(pc->text.data(), '\n', fill);
       while (fill < PIECE || !have_nl) {  // at least PIECE bytes AND one line end

@@ -1,5 +1,5 @@
-"""CPU-only race detection: the threaded host pipelines of the drop-in tools built with -fsanitize=thread and run on
-small inputs with many threads and tiny pieces -- the count ingest (rfx_ingest.hpp, tests/host/ingest_harness.cpp), the
+"""CPU-only race / memory-error detection: the threaded host pipelines of the drop-in tools built with -fsanitize=thread
+(and once more with -fsanitize=address,undefined) and run on small inputs with many threads and tiny pieces -- the count ingest (rfx_ingest.hpp, tests/host/ingest_harness.cpp), the
 stranded feeder (pass_through_main.cpp) and `RUFUS.Filter --sam` (tests/host/filter_sam_harness.cpp: the tool's main()
 over host stand-ins for the device calls).  A report of ThreadSanitizer fails the test; outputs must equal those of
 the uninstrumented run of tests/test_filter_sam_host.py's generator."""
@@ -16,25 +16,27 @@ HOST = os.path.join(ROOT, "rufus_amd", "csrc")
 FLAGS = ["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread"]
 
 
-@pytest.fixture(scope="module")
-def tsan_bins(tmp_path_factory):
-    d = tmp_path_factory.mktemp("tsan")
+@pytest.fixture(scope="module", params=["thread", "address,undefined"])
+def tsan_bins(request, tmp_path_factory):
+    d = tmp_path_factory.mktemp("san")
+    flags = FLAGS[:-1] + ["-fsanitize=" + request.param] + (["-fno-sanitize-recover=all"] if "undefined" in request.param else [])
     probe = d / "probe.cpp"
     probe.write_text("int main() { return 0; }\n")
-    if subprocess.run(FLAGS + ["-o", str(d / "probe"), str(probe)], stderr=subprocess.DEVNULL).returncode != 0 or \
+    if subprocess.run(flags + ["-o", str(d / "probe"), str(probe)], stderr=subprocess.DEVNULL).returncode != 0 or \
             subprocess.run([str(d / "probe")]).returncode != 0:
-        pytest.skip("no usable -fsanitize=thread here")
+        pytest.skip(f"no usable -fsanitize={request.param} here")
     host = os.path.join(HOST, "rfx_host.cpp")
-    subprocess.check_call(FLAGS + ["-o", str(d / "filter"), os.path.join(ROOT, "tests", "host", "filter_sam_harness.cpp"), host])
-    subprocess.check_call(FLAGS + ["-o", str(d / "ingest"), os.path.join(ROOT, "tests", "host", "ingest_harness.cpp"), host])
-    subprocess.check_call(FLAGS + ["-DPTS_MODE=1", "-o", str(d / "feeder"), os.path.join(HOST, "host", "pass_through_main.cpp")])
+    subprocess.check_call(flags + ["-o", str(d / "filter"), os.path.join(ROOT, "tests", "host", "filter_sam_harness.cpp"), host])
+    subprocess.check_call(flags + ["-o", str(d / "ingest"), os.path.join(ROOT, "tests", "host", "ingest_harness.cpp"), host])
+    subprocess.check_call(flags + ["-DPTS_MODE=1", "-o", str(d / "feeder"), os.path.join(HOST, "host", "pass_through_main.cpp")])
     return d
 
 
 def _run(cmd, cwd, env, stdin=None):
-    r = subprocess.run(cmd, cwd=cwd, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", **env), input=stdin,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-    assert b"ThreadSanitizer" not in r.stderr and r.returncode == 0, r.stderr[-3000:]
+    # (the tools skip their teardown on purpose: no leak report)
+    r = subprocess.run(cmd, cwd=cwd, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66", ASAN_OPTIONS="detect_leaks=0",
+                                              **env), input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr and r.returncode == 0, r.stderr[-3000:]
     return r.stdout
 
 

@@ -65,3 +65,56 @@ def test_host_pipelines_are_race_free(tsan_bins, tmp_path):
             _run([str(tsan_bins / "ingest"), "8", "500", "3000", "20000", "x.fq"], d, {"INGEST_MMAP": "1"}),
             _run([str(tsan_bins / "ingest"), "8", "500", "3000", "20000", "-"], d, {}, fq)]
     assert len({o.rsplit(b" ", 1)[0] for o in outs}) == 1 and outs[0].startswith(b"ok 6000 ")
+
+
+def _mutate(b, rng, cap=60000):
+    b = bytearray(b[:int(rng.integers(1, cap))])
+    for _ in range(int(rng.integers(1, 40))):
+        op, p = int(rng.integers(0, 5)), int(rng.integers(0, len(b)))
+        if op == 0:
+            b[p] = int(rng.integers(0, 256))
+        elif op == 1:
+            del b[p:p + int(rng.integers(1, 300))]
+        elif op == 2:
+            b[p:p] = bytes(rng.integers(0, 256, int(rng.integers(1, 50)), dtype=np.uint8))
+        elif op == 3:
+            b[p:p] = b"\n" * int(rng.integers(1, 4))
+        else:
+            b[p:p] = (b"\t", b" ")[int(rng.integers(0, 2))] * int(rng.integers(1, 12))
+        if not b:
+            b = bytearray(b"x")
+    return bytes(b)
+
+
+def test_host_parsers_survive_malformed_input(tsan_bins, tmp_path):
+    """Truncated, spliced and byte-flipped SAM / FASTQ / hash-list text into the ingest, the feeder and both filter
+    front ends: a tool may refuse its input (exit code 1 and a message), it may not crash, hang or trip a sanitizer."""
+    d = str(tmp_path)
+    rng = np.random.default_rng(4)
+    sam = _shuffled_sam(rng, 400)
+    hl = _hash_list(rng, sam, 800)
+    open(f"{d}/hl", "wb").write(hl)
+    _run([str(tsan_bins / "feeder"), "p.chr", "p"], d, {}, sam)
+    m1, m2 = (open(f"{d}/p.mate{m}.fastq", "rb").read() for m in (1, 2))
+    fq = b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b"ACGTN" * 20, b"I" * 100) for i in range(500))
+    seen = set()
+    for it in range(10):
+        open(f"{d}/hl_m", "wb").write(_mutate(hl, rng, len(hl)))
+        open(f"{d}/m1_m", "wb").write(_mutate(m1, rng))
+        open(f"{d}/m2_m", "wb").write(_mutate(m2, rng))
+        bad_sam = _mutate(sam, rng)
+        small = {"RFX_INGEST_PIECE": "2048"}
+        for cmd, stdin, env in (
+                ([str(tsan_bins / "filter"), "--sam", "f.chr", "hl", "stdin", "f", "25", "15", "1", "3"], bad_sam, small),
+                ([str(tsan_bins / "filter"), "--sam", "g.chr", "hl_m", "stdin", "g", "25", "15", "1", "3"], sam, small),
+                ([str(tsan_bins / "filter"), "hl_m", "m1_m", "m2_m", "k", str(int(rng.integers(1, 33))), "15", "1", "3"], None, small),
+                ([str(tsan_bins / "feeder"), "q.chr", "q"], bad_sam, {"RFX_PTS_THREADS": "3"}),
+                ([str(tsan_bins / "ingest"), "4", "200", "1500", "3000", "-"], _mutate(fq, rng), {})):
+            # (a tool that refuses its input exits with its helper threads still running: no thread-leak report)
+            r = subprocess.run(cmd, cwd=d, input=stdin,
+                               env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="report_thread_leaks=0", **env),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+            assert b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr and r.returncode in (0, 1), \
+                (cmd, r.returncode, r.stderr[-2000:])
+            seen.add(r.returncode)
+    assert 0 in seen

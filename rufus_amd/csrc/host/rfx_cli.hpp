@@ -324,7 +324,7 @@ inline bool read_jhash(const char* path, JhashHeader& h, std::vector<char>* payl
   json_u64(js, "counter_len", clen);
   h.k = (int)(key_len / 2);
   h.lsize = 0;
-  while ((1ull << h.lsize) < size) ++h.lsize;
+  while (h.lsize < 63 && (1ull << h.lsize) < size) ++h.lsize;  // (a size field beyond 2^63 must not shift by 64)
   h.counter_len = (int)clen;
   size_t p;
   h.canonical = json_find(js, "canonical", p) && js.compare(p, 4, "true") == 0;
@@ -347,6 +347,8 @@ inline bool read_jhash(const char* path, JhashHeader& h, std::vector<char>* payl
     }
   }
   if ((int)h.cols.size() != 2 * h.k) { fclose(f); return false; }
+  // (a record length of 0 would divide by zero further on; jellyfish writes counter_len 1 .. 8)
+  if (key_len < 2 || key_len > 1024 || clen < 1 || clen > 8) { fclose(f); return false; }
   h.payload_offset = 9 + hlen;
   struct stat sb;
   h.file_size = fstat(fileno(f), &sb) == 0 && S_ISREG(sb.st_mode) ? (uint64_t)sb.st_size : 0;

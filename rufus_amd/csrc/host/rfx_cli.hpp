@@ -641,6 +641,12 @@ class OutputPrealloc {
   }
 };
 
+// Records per fetch of the payload drain (x 2 per device slice, x 4 for the single-slice ring); the host-only test of the
+// writer builds with a small one (tests/host/write_harness.cpp).
+#ifndef RFX_WRITE_STEP
+#define RFX_WRITE_STEP (1ull << 20)
+#endif
+
 // `lend`: page-locked buffers the caller no longer needs (the ingest's staging blocks), used as the drain ring
 // instead of pinning more memory.
 // `recs`: the payload in slices (one record set per device, rfx_count_set_peers: slice i holds the i-th range of output
@@ -685,7 +691,7 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
       }
     };
     put_seq(hdr.data(), (size_t)hl);
-    const uint64_t step = 1ull << 20;
+    const uint64_t step = RFX_WRITE_STEP;
     std::vector<char> b(step * rl);
     for (rfx_records* r : recs)
       for (uint64_t at = 0, cnt = rfx_records_size(r); at < cnt; at += step) {
@@ -727,7 +733,7 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
       const uint64_t base = first, cnt = rfx_records_size(r);
       first += cnt;
       th.emplace_back([=] {
-        const uint64_t step = 2ull << 20;
+        const uint64_t step = 2 * RFX_WRITE_STEP;
         const int NB = 3;
         char* b[NB];
         std::thread w[NB];
@@ -761,7 +767,7 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
     if (::close(fd) != 0) die(std::string("write error on '") + path + "'");
     return;
   }
-  const uint64_t step = 4ull << 20;
+  const uint64_t step = 4 * RFX_WRITE_STEP;
   const int NBUF = 8;
   char* buf[NBUF];
   int kind[NBUF];  // 0 malloc, 1 pinned here, 2 lent

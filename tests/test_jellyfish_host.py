@@ -1,0 +1,150 @@
+"""CPU-only: the drop-in `jellyfish` (count / histo / merge / query / dump) through
+tests/host/jellyfish_harness.cpp -- the tool's own main() over host stand-ins for the device entry points -- so that its
+argument handling, the parallel ingest, the .Jhash reader / writer, the position-range walks of merge and query and the
+several-device plumbing (RUFUS_GPUS) run without a GPU: against the golden fixtures of the reference's testRun trio, the
+oracle, and jellyfish's own md5 known answers.  tests/test_cli_gpu.py runs the same chain through the real executable."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from tests.conftest import ROOT
+
+SRC = [os.path.join(ROOT, "tests", "host", "jellyfish_harness.cpp"), os.path.join(ROOT, "rufus_amd", "csrc", "rfx_host.cpp")]
+
+
+def _build(out, extra):
+    subprocess.check_call(["g++", "-std=c++17", "-pthread", "-o", out] + extra + SRC)
+    return out
+
+
+@pytest.fixture(scope="module")
+def jf(tmp_path_factory):
+    return _build(str(tmp_path_factory.mktemp("jfh") / "jellyfish"), ["-O2"])
+
+
+@pytest.fixture(scope="module", params=["thread", "address,undefined"])
+def jf_san(request, tmp_path_factory):
+    d = tmp_path_factory.mktemp("jfs")
+    probe = d / "probe.cpp"
+    probe.write_text("int main() { return 0; }\n")
+    flags = ["-O1", "-g", "-fsanitize=" + request.param]
+    if subprocess.run(["g++"] + flags + ["-o", str(d / "probe"), str(probe)], stderr=subprocess.DEVNULL).returncode != 0 or \
+            subprocess.run([str(d / "probe")]).returncode != 0:
+        pytest.skip(f"no usable -fsanitize={request.param} here")
+    return _build(str(d / "jellyfish"), flags)
+
+
+def sh(cmd, cwd, env=None, timeout=600, **kw):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0", TSAN_OPTIONS="report_thread_leaks=0", **(env or {})), **kw)
+    assert b"Sanitizer" not in r.stderr and b"runtime error" not in r.stderr, r.stderr[-3000:]
+    return r
+
+
+def _payload(path):
+    blob = open(path, "rb").read()
+    return blob[9 + int(blob[:9]):]
+
+
+def _golden_chain(jf, testrun, d):
+    exp = testrun["expected"]
+    for s in ("Child", "Mother", "Father"):
+        open(f"{d}/{s}.fq", "wb").write(testrun[s][0] + testrun[s][1])
+        r = sh([jf, "count", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "4", "-o", f"{s}.Jhash", "-C", f"{s}.fq"], d)
+        assert r.returncode == 0, r.stderr
+        assert hashlib.sha256(_payload(f"{d}/{s}.Jhash")).hexdigest() == exp["samples"][s]["s100M"]["payload_sha256"]
+        r = sh([jf, "histo", "-f", "-o", f"{s}.Jhash.histo", f"{s}.Jhash"], d)
+        assert r.returncode == 0, r.stderr
+        h = open(f"{d}/{s}.Jhash.histo", "rb").read()
+        assert hashlib.md5(h).hexdigest() == exp["samples"][s]["s100M"]["histo_full_md5"]
+        r = sh([jf, "histo", "-f", f"{s}.Jhash"], d, env={"RFX_HISTO_SLICE_RECORDS": "999"})      # the database in 19 pieces
+        assert r.stdout == h
+    r = sh([jf, "count", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "4", "-o", "side.Jhash", "-C", "Child.fq"], d,
+           env={"RFX_COUNT_HISTO": "1"})
+    assert r.returncode == 0
+    assert hashlib.md5(open(f"{d}/side.Jhash.histo", "rb").read()).hexdigest() == exp["samples"]["Child"]["s100M"]["histo_full_md5"]
+    r = sh([jf, "merge", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d)
+    assert r.returncode == 0 and r.stdout.decode() == testrun["merge"]
+    assert os.path.getsize(f"{d}/mer_counts_merged.jf") > 1000
+    for slices in ("2", "7", "300"):
+        r = sh([jf, "merge", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d, env={"RFX_MERGE_SLICES": slices})
+        assert r.returncode == 0 and r.stdout.decode() == testrun["merge"], (slices, r.stderr)
+    open(f"{d}/q.fa", "w").write("".join(f">{ln.split()[0]}\n{ln.split()[0]}\n" for ln in testrun["merge"].splitlines()))
+    r = sh([jf, "query", "-s", "q.fa", "Child.Jhash"], d)
+    assert r.returncode == 0, r.stderr
+    hl = "".join(ln + "\n" for ln in r.stdout.decode().splitlines() if 5 <= int(ln.split()[1]) <= 140)
+    assert hl == testrun["hashlist"]
+    whole = r.stdout
+    for per in ("1000", "37"):
+        r = sh([jf, "query", "-s", "q.fa", "Child.Jhash"], d, env={"RFX_QUERY_SLICE_RECORDS": per})
+        assert r.returncode == 0 and r.stdout == whole, r.stderr
+    r = sh([jf, "query", "-s", "q.fa", "-o", "o1", "-o", "o2", "-o", "o3", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d,
+           env={"RFX_QUERY_SLICE_RECORDS": "500"})
+    assert r.returncode == 0 and open(f"{d}/o1", "rb").read() == whole, r.stderr
+    for s, o in (("Mother", "o2"), ("Father", "o3")):
+        assert open(f"{d}/{o}", "rb").read() == sh([jf, "query", "-s", "q.fa", f"{s}.Jhash"], d).stdout
+    r = sh([jf, "dump", "-c", "Child.Jhash"], d)
+    lines = r.stdout.decode().splitlines()
+    assert len(lines) == 18356 and lines[0] == "A" * 25 + " 48"
+    r = sh([jf, "query", "Child.Jhash", "T" * 25, "ACGT"], d)
+    assert r.stdout.decode() == "A" * 25 + " 48\n" and b"Invalid mer" in r.stderr
+    sh([jf, "count", "-m", "25", "-s", "1M", "-o", "small.Jhash", "-C", "Father.fq"], d)
+    r = sh([jf, "merge", "Child.Jhash", "small.Jhash"], d)
+    assert r.returncode != 0 and b"different size" in r.stderr
+
+
+def test_golden_chain(jf, testrun, tmp_path):
+    _golden_chain(jf, testrun, str(tmp_path))
+
+
+def test_golden_chain_under_sanitizers(jf_san, testrun, tmp_path):
+    _golden_chain(jf_san, testrun, str(tmp_path))
+
+
+@pytest.mark.parametrize("k,size,extra,kw", [(25, "100M", ["-C", "-L", "2"], dict(lower=2)),
+                                             (31, "8G", ["-C", "-U", "30"], dict(upper=30)),
+                                             (12, "1M", [], dict(canonical=False)),
+                                             (25, "100M", ["-C", "--out-counter-len", "1"], dict())])
+def test_count_routes_match_oracle(jf, small_trio, tmp_path, k, size, extra, kw):
+    """Files, one pipe, wrapped FASTA, several devices (RUFUS_GPUS) and deferred shard passes: the oracle's payload."""
+    from tests.synth import fastq_bytes
+    d = str(tmp_path)
+    fq = [fastq_bytes(small_trio["child"], m) for m in (1, 2)]
+    for m in (0, 1):
+        open(f"{d}/m{m}.fq", "wb").write(fq[m])
+    n = {"100M": 100_000_000, "8G": 8 << 30, "1M": 1_000_000}[size]
+    want = oracle.count(fq, k, n, **kw)
+    clen = 1 if "--out-counter-len" in extra else 4
+    ref = want.payload(clen) if clen != 4 else want.payload()
+    base = [jf, "count", "-m", str(k), "-s", size, "-t", "4"] + extra
+    assert sh(base + ["-o", "a.jf", "m0.fq", "m1.fq"], d).returncode == 0 and _payload(f"{d}/a.jf") == ref
+    r = sh("cat m0.fq m1.fq | " + " ".join(base + ["-o", "b.jf", "/dev/stdin"]), d, shell=True)
+    assert r.returncode == 0 and _payload(f"{d}/b.jf") == ref, r.stderr
+    for gpus in ("0,0", "0-0,0,0,0,0"):
+        r = sh(base + ["-o", "c.jf", "m0.fq", "m1.fq"], d, env={"RUFUS_GPUS": gpus})
+        assert r.returncode == 0 and _payload(f"{d}/c.jf") == ref, r.stderr
+    r = sh(base + ["-o", "e.jf", "m0.fq", "m1.fq"], d, env={"RFX_COUNT_PASSES": "3", "RFX_HOST_THREADS": "7"})
+    assert r.returncode == 0 and _payload(f"{d}/e.jf") == ref, r.stderr
+    r = sh(base + ["-o", "/dev/stdout", "m0.fq", "m1.fq"], d)
+    assert r.returncode == 0 and r.stdout[9 + int(r.stdout[:9]):] == ref
+
+
+def test_count_reproduces_jellyfish_own_md5_kats(jf, tmp_path):
+    """tests/parallel_hashing.sh of jellyfish-2.2.5: `count -m 15 -C -s 2M` (+ `-L2 -U3 --disk`) on the seeded 10 Mb
+    sequence, md5 of `histo` -- through the tool's ingest, writer, reader and histo."""
+    from tests.test_oracle import mt_sequence
+    d = str(tmp_path)
+    seq10m, = mt_sequence(3141592653, [10_000_000])
+    with open(f"{d}/seq10m.fa", "wb") as f:
+        f.write(b">read0\n")
+        for i in range(0, len(seq10m), 70):
+            f.write(seq10m[i:i + 70] + b"\n")
+    for extra, md5 in (([], "864c0b0826854bdc72a85d170549b64b"), (["-L2", "-U3", "--disk"], "94625cd2d59e278f08421a673eb0926a")):
+        r = sh([jf, "count", "-t", "4", "-o", "m15.jf", "-s", "2M", "-C", "-m", "15"] + extra + ["seq10m.fa"], d)
+        assert r.returncode == 0, r.stderr
+        r = sh([jf, "histo", "m15.jf"], d)
+        assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == md5

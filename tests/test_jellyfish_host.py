@@ -148,3 +148,46 @@ def test_count_reproduces_jellyfish_own_md5_kats(jf, tmp_path):
         assert r.returncode == 0, r.stderr
         r = sh([jf, "histo", "m15.jf"], d)
         assert r.returncode == 0 and hashlib.md5(r.stdout).hexdigest() == md5
+
+
+def _sam_of(testrun, rng):
+    lines = []
+    chrs = [b"chr1", b"chr1", b"chr2", b"chr10", b"chr1", b"chrX", b"*"]
+    for m, text in enumerate(testrun["Child"]):
+        recs = text.split(b"\n")
+        for i in range(0, len(recs) - 1, 4):
+            c = chrs[min(len(chrs) - 1, (i // 4) * len(chrs) // (len(recs) // 4))] if m == 0 else chrs[int(rng.integers(0, 3))]
+            lines.append(b"\t".join([recs[i][1:], b"99", c, b"%d" % (i + 1), b"60", b"100M", b"=", b"1", b"0", recs[i + 1],
+                                     recs[i + 3], b"NM:i:0"]))
+    return lines
+
+
+def _count_sam(jf, testrun, d):
+    """`jellyfish count --sam X.chr [--spool FILE]` on SAM text = the oracle's count of field 10 of
+    every line, the chromosome log of the reference's PassThroughSamCheck, the spool a copy of the stream."""
+    lines = _sam_of(testrun, np.random.default_rng(11))
+    sam = b"\n".join(lines) + b"\n"
+    open(f"{d}/in.sam", "wb").write(sam)
+    want = oracle.count(None, 25, 100_000_000, lower=2, reads=[ln.split(b"\t")[9] for ln in lines]).payload()
+    env = {"RFX_INGEST_PIECE": "65536"}
+    cmd = [jf, "count", "--sam", "b.chr", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "6", "-o", "b.Jhash", "-C"]
+    for tail, kw in ((["/dev/stdin"], dict(input=sam)), (["in.sam"], {}), (["--spool", "spool.sam", "/dev/stdin"], dict(input=sam))):
+        r = sh(cmd[:4] + tail[:-1] + cmd[4:] + tail[-1:], d, env=env, **kw)
+        assert r.returncode == 0, r.stderr
+        assert _payload(f"{d}/b.Jhash") == want and len(want) > 100_000
+        assert open(f"{d}/b.chr").read().split()[:7] == ["notachr", "chr1", "chr2", "chr10", "chr1", "chrX", "*"]
+    assert open(f"{d}/spool.sam", "rb").read() == sam
+    ref = os.path.join(ROOT, "oracle", "_ref", "PassThroughSamCheck")
+    if os.path.exists(ref):
+        subprocess.run(f"{ref} ref.chr < in.sam > /dev/null", shell=True, cwd=d, check=True)
+        assert open(f"{d}/ref.chr").read() == open(f"{d}/b.chr").read()
+    r = sh(cmd + ["/dev/stdin"], d, env=env, input=b"@HD\tVN:1.6\n" + sam)
+    assert r.returncode != 0 and b"--sam" in r.stderr
+
+
+def test_count_sam_and_spool(jf, testrun, tmp_path):
+    _count_sam(jf, testrun, str(tmp_path))
+
+
+def test_count_sam_and_spool_under_sanitizers(jf_san, testrun, tmp_path):
+    _count_sam(jf_san, testrun, str(tmp_path))

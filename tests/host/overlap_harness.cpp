@@ -1,11 +1,11 @@
-// Host-only harness for the greedy assemblers of the drop-in tool set (SURVEY 8 rows G1-G6: OverlapSam, Overlap,
+// Host-only harness for the greedy assemblers of the drop-in tool set (SURVEY 8 rows G1-G7: OverlapSam, Overlap,
 // OverlapRegion -- rufus_amd/csrc/host/overlap_sam_main.cpp, overlap_contig_main.cpp, overlap_common.hpp): the tools' own
 // main() with the DEVICE entry points replaced by plain host code, so that the SAM intake, the collapse passes and the
 // greedy merge loops run in the CPU suite and under the sanitizers against the reference binaries.  The stand-in for the
 // scoring kernel is the per-candidate body of Align3 (src/OverlapSam.cpp:47-229, src/Overlap.cpp:176-340) in binary32,
 // the same restatement tests/test_overlap_gpu.py holds the kernel to.  TEST INFRASTRUCTURE, never built into the product.
-//   g++ -O2 -std=c++17 -pthread -ffp-contract=off -DOVL_WHICH=0|1|2 overlap_harness.cpp ../../rufus_amd/csrc/rfx_host.cpp
-//   OVL_WHICH: 0 OverlapSam, 1 Overlap, 2 OverlapRegion
+//   g++ -O2 -std=c++17 -pthread -ffp-contract=off -DOVL_WHICH=0|1|2|3 overlap_harness.cpp ../../rufus_amd/csrc/rfx_host.cpp
+//   OVL_WHICH: 0 OverlapSam, 1 Overlap, 2 OverlapRegion, 3 AnnotateOverlap (row G7: rfx_annotate, src/AnnotateOverlap.cpp:88-134)
 #include <string>
 #include <unordered_set>
 #include <vector>
@@ -14,9 +14,12 @@
 #include "../../rufus_amd/csrc/host/overlap_sam_main.cpp"
 #elif OVL_WHICH == 1
 #include "../../rufus_amd/csrc/host/overlap_contig_main.cpp"
-#else
+#elif OVL_WHICH == 2
 #define REGION
 #include "../../rufus_amd/csrc/host/overlap_contig_main.cpp"
+#else
+#define TAIL_MODE 2
+#include "../../rufus_amd/csrc/host/overlap_tail_main.cpp"
 #endif
 
 struct rfx_ctx { int device; };
@@ -142,7 +145,7 @@ int rfx_ovl_pool_score(rfx_ovl_pool* p, int query, const char* a_explicit, int a
 }
 void rfx_ovl_pool_free(rfx_ovl_pool* p) { delete p; }
 
-#if OVL_WHICH == 0
+#if OVL_WHICH == 0 || OVL_WHICH == 3
 // OverlapSam also scans its reads for mutant k-mers (the same stand-ins as tests/host/filter_sam_harness.cpp)
 rfx_set* rfx_set_build(rfx_ctx*, const uint64_t* fwd_keys, uint64_t n, int k) {
   rfx_set* s = new rfx_set;
@@ -190,6 +193,29 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
     }
   }
   if (n_hit_reads) *n_hit_reads = over;
+  return RFX_OK;
+}
+// coverage of every base by mutant windows: the same scan (good streak >= k, the last base never examined), a hit adds
+// one to each of its k bases; contig after contig
+int rfx_annotate(rfx_set* s, const rfx_reads* r, uint32_t* cov_out) {
+  const int k = s->k;
+  const uint64_t kmask = k >= 32 ? ~0ull : (1ull << (2 * k)) - 1;
+  size_t base = 0;
+  for (size_t x = 0; x < r->len.size(); ++x) {
+    const uint32_t L = r->len[x], w0 = r->woff[x];
+    for (uint32_t i = 0; i < L; ++i) cov_out[base + i] = 0;
+    uint64_t key = 0;
+    int streak = 0;
+    for (uint32_t i = 0; i + 1 < L; ++i) {
+      const uint64_t code = (r->codes[w0 + i / 32] >> (2 * (i % 32))) & 3u;
+      const bool good = (r->good[w0 + i / 32] >> (i % 32)) & 1u;
+      key = ((key << 2) | code) & kmask;
+      streak = good ? streak + 1 : 0;
+      if (streak >= k && s->keys.count(key))
+        for (int j = 0; j < k; ++j) cov_out[base + i - (uint32_t)k + 1 + (uint32_t)j] += 1;
+    }
+    base += L;
+  }
   return RFX_OK;
 }
 #endif

@@ -1,4 +1,4 @@
-"""CPU-only: the greedy assemblers of the drop-in tool set (SURVEY 8 rows G1-G6) through tests/host/overlap_harness.cpp --
+"""CPU-only: the greedy assemblers of the drop-in tool set (SURVEY 8 rows G1-G7) through tests/host/overlap_harness.cpp --
 the tools' own main() (SAM intake, collapse passes, greedy merge loops, output) over a host stand-in for the scoring
 kernel -- against the reference binaries under oracle/_ref, stage by stage, byte for byte: scripts/Overlap.shorter.sh:127-194
 with the reference's arguments, Threads = 1.  Plain and under ASan/UBSan.  tests/test_overlap_gpu.py runs the same chain
@@ -13,7 +13,7 @@ from tests.test_cli_host import BIN, REF
 
 needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "OverlapSam")), reason="oracle/_ref not built")
 SRC = [os.path.join(ROOT, "tests", "host", "overlap_harness.cpp"), os.path.join(ROOT, "rufus_amd", "csrc", "rfx_host.cpp")]
-NAMES = {0: "OverlapSam", 1: "Overlap", 2: "OverlapRegion"}
+NAMES = {0: "OverlapSam", 1: "Overlap", 2: "OverlapRegion", 3: "AnnotateOverlap"}
 
 
 def _build(d, flags):
@@ -52,6 +52,7 @@ def _chain(d, t, w, mincov="1"):
     run("OverlapRegion", [f"{t}.3.fastqd", ".98", "50", "2", f"{t}.4", "NS", "1", "1"])
     run("ReplaceQwithDinFASTQD", [f"{t}.4.fastqd"], f"{t}.overlap.fastqd")
     run("ConvertFASTqD.to.FASTQ", [f"{t}.overlap.fastqd"], f"{t}.overlap.fastq")
+    run("AnnotateOverlap", ["hl", f"{t}.overlap.fastq", f"{t}.asm.hash.fastq"], f"{t}.hashcount.fastq")
 
 
 @needs_ref
@@ -65,9 +66,12 @@ def test_assembly_chain_host_side_matches_reference(tools, tmp_path):
     _chain(d, "ref", REF)
     sizes = {}
     for f in ["sam.fastq", "sam.fastqd", "1.fastqd", "1.fastq", "1.fastqgood.fastq", "1.fastqbad.fastq", "2.fastqd", "3.fastqd",
-              "4.fastqd", "4.fastq", "overlap.fastqd", "overlap.fastq"]:
+              "4.fastqd", "4.fastq", "overlap.fastqd", "overlap.fastq", "hashcount.fastq", "asm.hash.fastq"]:
         a, b = open(f"{d}/ours.{f}", "rb").read(), open(f"{d}/ref.{f}", "rb").read()
         sizes[f] = a.count(b"\n")
         assert a == b, (f, sizes)
     nodes = [sizes[f] // 6 for f in ("sam.fastqd", "1.fastqd", "2.fastqd", "3.fastqd", "4.fastqd")]
     assert nodes[0] > nodes[-1] >= 1, nodes
+    # the contigs carry mutant k-mer coverage: some quality characters above '!'
+    q = open(f"{d}/ours.hashcount.fastq", "rb").read().split(b"\n")[3::4]
+    assert any(max(x) > 33 for x in q if x)

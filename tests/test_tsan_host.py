@@ -26,9 +26,10 @@ def tsan_bins(request, tmp_path_factory):
             subprocess.run([str(d / "probe")]).returncode != 0:
         pytest.skip(f"no usable -fsanitize={request.param} here")
     host = os.path.join(HOST, "rfx_host.cpp")
-    subprocess.check_call(flags + ["-o", str(d / "filter"), os.path.join(ROOT, "tests", "host", "filter_sam_harness.cpp"), host])
-    subprocess.check_call(flags + ["-o", str(d / "ingest"), os.path.join(ROOT, "tests", "host", "ingest_harness.cpp"), host])
-    subprocess.check_call(flags + ["-DPTS_MODE=1", "-o", str(d / "feeder"), os.path.join(HOST, "host", "pass_through_main.cpp")])
+    jobs = [subprocess.Popen(flags + ["-o", str(d / "filter"), os.path.join(ROOT, "tests", "host", "filter_sam_harness.cpp"), host]),
+            subprocess.Popen(flags + ["-o", str(d / "ingest"), os.path.join(ROOT, "tests", "host", "ingest_harness.cpp"), host]),
+            subprocess.Popen(flags + ["-DPTS_MODE=1", "-o", str(d / "feeder"), os.path.join(HOST, "host", "pass_through_main.cpp")])]
+    assert all(j.wait() == 0 for j in jobs)
     return d
 
 

@@ -14,7 +14,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librufus_hip.so")
+LIB_PATH = os.environ.get("RFX_LIB") or os.path.join(_HERE, "librufus_hip.so")  # (RFX_LIB: an experiment's build, scratch/build_variants.sh)
 
 HISTO_BINS = 10002
 PACK_COUNT, PACK_FILTER = 1, 2

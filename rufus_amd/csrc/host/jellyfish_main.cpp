@@ -399,8 +399,17 @@ static int query_main(int argc, char** argv) {
   }
   if (optind >= argc) die("Missing database");
   std::vector<const char*> db_paths{argv[optind]}, mers;
+  // (the reference takes `db mers...`; further databases are an extension -- an argument spelt like a mer stays a mer
+  // even if the working directory holds a file of that name)
+  auto looks_like_mer = [](const char* a) {
+    const size_t n = strlen(a);
+    if (n == 0 || n > 32) return false;
+    for (size_t i = 0; i < n; ++i)
+      if (!strchr("ACGTacgt", a[i])) return false;
+    return true;
+  };
   for (int i = optind + 1; i < argc; ++i) {
-    if (::access(argv[i], R_OK) == 0) db_paths.push_back(argv[i]);
+    if (!looks_like_mer(argv[i]) && ::access(argv[i], R_OK) == 0) db_paths.push_back(argv[i]);
     else mers.push_back(argv[i]);
   }
   const size_t n_db = db_paths.size();
@@ -448,7 +457,9 @@ static int query_main(int argc, char** argv) {
   }
   if (keys.size() > 0xFFFFFFFFull) die("rufus_amd jellyfish query: too many k-mers in one call");
   std::vector<std::vector<uint32_t>> counts(n_db, std::vector<uint32_t>(keys.size() + 1, 0));
-  std::vector<uint64_t> key_pos;  // position of every query, computed once per hash function
+  std::vector<uint64_t> key_pos;  // position of every query, computed once per hash function:
+  int key_pos_lsize = -1;         // the function key_pos holds now -- NOT that of the database before this one, which
+  std::vector<uint64_t> key_pos_cols;  // may have been piped or empty and never have touched key_pos
   for (size_t d = 0; d < n_db; ++d) {
     const JhashHeader& hd = dbs[d].h;
     JhashFile& db = dbs[d];
@@ -463,9 +474,11 @@ static int query_main(int argc, char** argv) {
     uint64_t per = 64ull << 20;
     if (const char* ev = getenv("RFX_QUERY_SLICE_RECORDS")) per = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
     const uint64_t S = std::max<uint64_t>(1, (db.n + per - 1) / per);
-    if (key_pos.empty() || d == 0 || hd.lsize != dbs[d - 1].h.lsize || hd.cols != dbs[d - 1].h.cols) {
+    if (key_pos.size() != keys.size() || hd.lsize != key_pos_lsize || hd.cols != key_pos_cols) {
       key_pos.resize(keys.size());
       for (size_t i = 0; i < keys.size(); ++i) key_pos[i] = rfx_jf_pos(hd.cols.data(), hd.k, hd.lsize, keys[i]);
+      key_pos_lsize = hd.lsize;
+      key_pos_cols.assign(hd.cols.begin(), hd.cols.end());
     }
     std::vector<std::vector<uint32_t>> in_slice(S);
     for (size_t i = 0; i < keys.size(); ++i) in_slice[slice_of(key_pos[i], S, hd.lsize)].push_back((uint32_t)i);

@@ -191,7 +191,7 @@ void* dmalloc(rfx_ctx* c, size_t bytes) {
   if (bytes == 0) bytes = 256;
   if (arena_init(c)) {
     if (c->budget && c->used + bytes > c->budget) {
-      snprintf(g_err, sizeof g_err, "hbm budget exceeded: %zu + %zu > %zu", c->used, bytes, c->budget);
+      snprintf(g_err, sizeof g_err, "out of device memory: hbm budget exceeded: %zu + %zu > %zu", c->used, bytes, c->budget);
       return nullptr;
     }
     return arena_alloc(c, bytes);
@@ -205,7 +205,7 @@ void* dmalloc(rfx_ctx* c, size_t bytes) {
   }
   if (c->budget && c->used + bytes > c->budget) pool_release(c);
   if (c->budget && c->used + bytes > c->budget) {
-    snprintf(g_err, sizeof g_err, "hbm budget exceeded: %zu + %zu > %zu", c->used, bytes, c->budget);
+    snprintf(g_err, sizeof g_err, "out of device memory: hbm budget exceeded: %zu + %zu > %zu", c->used, bytes, c->budget);
     return nullptr;
   }
   void* p = nullptr;
@@ -918,6 +918,7 @@ void rfx_count_free(rfx_table* t) {
   if (t->segs) {
     for (auto& sg : *t->segs) {
       if (!sg.borrowed) dfree(t->ctx, sg.inst);
+      if (!sg.borrowed) dfree(t->ctx, sg.ext);  // (the planes: until round 4 this leaked them for k = 26 .. 31)
       dfree(t->ctx, sg.bin_start);
     }
     delete t->segs;
@@ -1209,7 +1210,9 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   return RFX_OK;
 }
 
-constexpr uint64_t MSP_KMERS_PER_RECORD_MAX = 4;  // a record holds <= 4 k-mers (rfx_msp.hip MSP_NMAX)
+// Super-k-mer records per window (k-mer instance) on ordinary sequence: 2 / (w + 1) for a window of w m-mers, plus
+// one per read end -- 0.175 for k <= 25 (w = 11), 0.125 for k = 26 .. 31 (w = 16); with 20 % on top for the estimates.
+static double msp_records_per_window(int k) { return k <= 25 ? 0.21 : 0.15; }
 
 static int msp_add(rfx_table* t, const rfx_reads* r) {
   rfx_ctx* c = t->ctx;
@@ -1232,7 +1235,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   const bool big = g.windows >= (1ull << 29) || P > 8192;  // >= ~4 M reads: worth one synchronisation for exact sizes
   const bool wide = rfxk::msp_wide(t->k);                  // k = 26 .. 31: the records' 32-bit plane travels along
   const double share = (double)(g.bin_hi - g.bin_lo) / (double)P;
-  uint64_t cap_b = (uint64_t)((double)g.windows * 0.4 * share * (share < 1 ? 1.05 : 1.0)) + 65536;
+  uint64_t cap_b = (uint64_t)((double)g.windows * msp_records_per_window(t->k) * share * (share < 1 ? 1.05 : 1.0)) + 65536;
   if (cap_b > g.windows) cap_b = g.windows;
   const uint64_t even = cap_b / g.c_n;
   // k_msp_part1 hands out the coarse bins in slabs per workgroup (rfx_msp.hip): 1/32 of what a workgroup puts into a
@@ -1309,7 +1312,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
       dfree(c, ext_a);
       dfree(c, cur);
       // (k-mer instances behind the records: the shard's share of the windows -- sizes the survivor arrays)
-      t->segs->push_back(rfx_segment{inst, total, bin_start, std::min<uint64_t>(g.windows, total * MSP_KMERS_PER_RECORD_MAX), P, ext});
+      t->segs->push_back(rfx_segment{inst, total, bin_start, std::min<uint64_t>((uint64_t)((double)g.windows * share) + 1, total * (uint64_t)rfxk::msp_nmax_of(t->k)), P, ext});
       t->seg_kind = RFX_COUNT_MSP;
       return RFX_OK;
     }
@@ -1543,6 +1546,21 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
   if (!d_ptrs) { drop(); return RFX_E_NOMEM; }
   int geo = (kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1)) >> to_bits <= 12288 ? 1 : 0;
   if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
+  // the leaf's workgroups stage their survivors here before they scatter them into the coarse pos bins
+  uint64_t max_chunk_all = 0;  // records of the largest chunk, all groups together
+  for (size_t ci = 0; ci + 1 < cut.size(); ++ci) {
+    uint64_t ch = 0;
+    for (auto& kv : groups)
+      for (size_t si : kv.second.segs)
+        ch += h_bs[si][(size_t)cut[ci + 1] * (kv.second.b / bmin)] - h_bs[si][(size_t)cut[ci] * (kv.second.b / bmin)];
+    max_chunk_all = std::max(max_chunk_all, ch);
+  }
+  uint32_t lgrid = 1, lchunk = 1;
+  rfxk::msp_leaf_plan(c, (uint32_t)std::min<size_t>((size_t)max_np * Ftot, 1u << 30), geo, max_chunk_all, &lgrid, &lchunk);
+  const size_t n_stage = (size_t)lgrid * lchunk;
+  uint64_t* stage_k = (uint64_t*)dmalloc(c, n_stage * 8);
+  uint32_t* stage_c = (uint32_t*)dmalloc(c, n_stage * 4);
+  if (!stage_k || !stage_c) { drop(); dfree(c, d_ptrs); dfree(c, stage_k); dfree(c, stage_c); return RFX_E_NOMEM; }
   for (size_t ci = 0; ci + 1 < cut.size(); ++ci) {
     const uint32_t p0 = cut[ci], np = cut[ci + 1] - cut[ci];
     const size_t n2 = (size_t)np * Ftot;
@@ -1608,13 +1626,16 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
     if (!chunk_all) continue;
     const uint64_t** d = d_ptrs + 3 * nleaf * ci;
     const hipError_t e = upload(c, d, ptrs.data(), 3 * nleaf * sizeof(void*));
-    if (e != hipSuccess) { drop(); dfree(c, d_ptrs); return hip_fail(e, "msp_leaf_refined"); }
+    if (e != hipSuccess) { drop(); dfree(c, d_ptrs); dfree(c, stage_k); dfree(c, stage_c); return hip_fail(e, "msp_leaf_refined"); }
     rfxk::msp_leaf(c, d, d + nleaf, (int)nleaf, ptrs[0], ptrs[nleaf], (uint32_t)n2, t->k, t->canonical, t->lut_t, t->ntab,
                    sel_bits, 2 * t->k - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur, (uint32_t)f->cap,
-                   cur + ncur, cur + ncur + 1, geo, (const uint32_t* const*)(d + 2 * nleaf), (const uint32_t*)ptrs[2 * nleaf]);
+                   cur + ncur, cur + ncur + 1, geo, (const uint32_t* const*)(d + 2 * nleaf), (const uint32_t*)ptrs[2 * nleaf],
+                   stage_k, stage_c, std::min<uint32_t>(lgrid, (uint32_t)n2), lchunk);
   }
   drop();  // stream-ordered pool
   dfree(c, d_ptrs);
+  dfree(c, stage_k);
+  dfree(c, stage_c);
   return RFX_OK;
 }
 
@@ -1635,15 +1656,12 @@ static int msp_prepare_leaf(rfx_table* t, int* to_bits_out, bool* refine_out, st
   int to_bits = ceil_log2(pmax);
   // (a shard pass fills only its share of the bins: density as if every shard were present)
   const uint64_t kfull = kmers * (uint64_t)(t->n_shards > 1 ? t->n_shards : 1);
-  // (wide records, k = 26 .. 31, were counted with the half-size leaf until their plane cache became 16 bits wide:
-  // RFX_MSP_WIDE_HALF=1 brings that back for comparison)
-  const uint64_t per_bin = rfxk::msp_wide(t->k) && getenv("RFX_MSP_WIDE_HALF") ? 12288 : 24576;
+  const uint64_t per_bin = 24576;
   while (to_bits < 28 && (kfull >> to_bits) > per_bin) ++to_bits;
   // When the partition has to be refined anyway, one more bit costs nothing (as long as it does not take another
   // level of <= 8 bits): bins of half the size go through the half-size leaf, two workgroups per CU, which hides
-  // the barriers of one behind the other -- 117 -> 108 ms per sample on the 1 Gb slice.  (Wide records stay with
-  // the full-size leaf: their plane cache needs the room.)
-  if (!rfxk::msp_wide(t->k) && !getenv("RFX_MSP_NO_HALF") && pmin < (1u << to_bits) && to_bits < 28) {
+  // the barriers of one behind the other -- 117 -> 108 ms per sample on the 1 Gb slice.
+  if (!getenv("RFX_MSP_NO_HALF") && pmin < (1u << to_bits) && to_bits < 28) {
     const int lo = ceil_log2(pmin), hi = ceil_log2(pmax);
     auto levels = [](int d) { return d <= 0 ? 0 : (d + 7) / 8; };
     if (levels(to_bits + 1 - lo) == levels(to_bits - lo) && levels(to_bits + 1 - hi) == std::max(levels(to_bits - hi), 1))
@@ -1697,8 +1715,8 @@ static int msp_passes_leaf(rfx_finish* f) {
     // their sort at the end (12 + 12 + 20 B each) runs when no pass records are left, so it does not add up
     // with them.  (Planning with the sum took 5 passes for a 30x sample where 2 fit: measured, 6.3 s of finish.)
     const double surv = (double)windows / 20.0 * 14.0;
-    // (8 B per ~3 k-mers; the wide records of k = 26 .. 31 are 12 B)
-    const double records = (double)windows * (rfxk::msp_wide(t->k) ? 3.6 : 2.9) * 1.15 / (double)outer_n;
+    // (12 B per record)
+    const double records = (double)windows * msp_records_per_window(t->k) * 12.0 * 1.05 / (double)outer_n;
     S = 1;
     while (S < 256 && records / S + surv > avail) ++S;
     if (const char* ev = getenv("RFX_COUNT_PASSES")) S = std::max(1, atoi(ev));
@@ -2051,10 +2069,20 @@ static int msp_emit_queue(rfx_finish* f) {
     // instances per bin, +3 % at 15 K)
     int geo = kfull / P < 8192 ? 1 : 0;
     if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
+    uint64_t n_rec_all = 0;
+    for (auto& sg : *t->segs) n_rec_all += sg.n;
+    uint32_t lgrid = 1, lchunk = 1;
+    rfxk::msp_leaf_plan(c, P, geo, n_rec_all, &lgrid, &lchunk);
+    const size_t n_stage = (size_t)lgrid * lchunk;
+    uint64_t* stage_k = (uint64_t*)dmalloc(c, n_stage * 8);
+    uint32_t* stage_c = (uint32_t*)dmalloc(c, n_stage * 4);
+    if (!stage_k || !stage_c) { dfree(c, stage_k); dfree(c, stage_c); return fail(RFX_E_NOMEM); }
     rfxk::msp_leaf(c, f->d_inst, f->d_inst + nseg, nseg, f->h_ptrs[0], f->h_ptrs[nseg], P, t->k, t->canonical, t->lut_t,
                    t->ntab, cfg0.sel_bits, cfg0.c_bits - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur,
                    (uint32_t)cap, cur + ncur, cur + ncur + 1, geo, (const uint32_t* const*)(f->d_inst + 2 * nseg),
-                   (const uint32_t*)f->h_ptrs[2 * nseg]);
+                   (const uint32_t*)f->h_ptrs[2 * nseg], stage_k, stage_c, lgrid, lchunk);
+    dfree(c, stage_k);  // stream-ordered pool
+    dfree(c, stage_c);
   } else {
     {
       const int rc = msp_leaf_refined(f, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
@@ -2422,13 +2450,14 @@ int rfx_count_add_records_ext_dev(rfx_table* t, const uint64_t* d_records, const
   if (!t || !d_bin_start || (n_records && !d_records) || bins < 256 || (bins & (bins - 1))) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
-  if (!rfxk::msp_k_ok(t->k) || !t->lut_t || t->table_active || (t->seg_kind && t->seg_kind != RFX_COUNT_MSP)) {
+  if (!rfxk::msp_k_ok(t->k) || !t->lut_t || t->table_active || (t->seg_kind && t->seg_kind != RFX_COUNT_MSP) ||
+      (t->mode != RFX_COUNT_AUTO && t->mode != RFX_COUNT_MSP)) {
     snprintf(g_err, sizeof g_err, "rfx_count_add_records_dev: the table is not on the MSP path");
     return RFX_E_INVAL;
   }
   const bool wide = rfxk::msp_wide(t->k);
   if (wide && n_records && !d_ext) {
-    snprintf(g_err, sizeof g_err, "rfx_count_add_records_dev: k = 26 .. 31 records come with their 32-bit plane "
+    snprintf(g_err, sizeof g_err, "rfx_count_add_records_dev: records come with their 32-bit plane "
                                   "(rfx_count_add_records_ext_dev)");
     return RFX_E_INVAL;
   }
@@ -2443,7 +2472,7 @@ int rfx_count_add_records_ext_dev(rfx_table* t, const uint64_t* d_records, const
     e = rfxk::copy_bytes(c, ext, d_ext, n_records * 4);
   if (e != hipSuccess) { dfree(c, inst); dfree(c, bs); dfree(c, ext); return hip_fail(e, "rfx_count_add_records_dev"); }
   if (!t->p2l_bins) t->p2l_bins = bins > 8192 ? 8192 : bins;  // geometry of later rfx_count_add calls
-  t->segs->push_back(rfx_segment{inst, n_records, bs, n_records * 4, bins, ext});  // <= 4 k-mers per record
+  t->segs->push_back(rfx_segment{inst, n_records, bs, n_records * (uint64_t)rfxk::msp_nmax_of(t->k), bins, ext});
   t->seg_kind = RFX_COUNT_MSP;
   return RFX_OK;
 }
@@ -2456,12 +2485,13 @@ int rfx_count_adopt_records_dev(rfx_table* t, const uint64_t* d_records, const u
   if (!t || !d_bin_start || (n_records && !d_records) || bins < 256 || (bins & (bins - 1))) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
-  if (!rfxk::msp_k_ok(t->k) || !t->lut_t || t->table_active || (t->seg_kind && t->seg_kind != RFX_COUNT_MSP)) {
+  if (!rfxk::msp_k_ok(t->k) || !t->lut_t || t->table_active || (t->seg_kind && t->seg_kind != RFX_COUNT_MSP) ||
+      (t->mode != RFX_COUNT_AUTO && t->mode != RFX_COUNT_MSP)) {
     snprintf(g_err, sizeof g_err, "rfx_count_adopt_records_dev: the table is not on the MSP path");
     return RFX_E_INVAL;
   }
   if (rfxk::msp_wide(t->k) && n_records && !d_ext) {
-    snprintf(g_err, sizeof g_err, "rfx_count_adopt_records_dev: k = 26 .. 31 records come with their 32-bit plane");
+    snprintf(g_err, sizeof g_err, "rfx_count_adopt_records_dev: records come with their 32-bit plane");
     return RFX_E_INVAL;
   }
   if (n_records == 0) return RFX_OK;
@@ -2470,7 +2500,8 @@ int rfx_count_adopt_records_dev(rfx_table* t, const uint64_t* d_records, const u
   const hipError_t e = rfxk::copy_bytes(c, bs, d_bin_start, ((size_t)bins + 1) * 8);
   if (e != hipSuccess) { dfree(c, bs); return hip_fail(e, "rfx_count_adopt_records_dev"); }
   if (!t->p2l_bins) t->p2l_bins = bins > 8192 ? 8192 : bins;
-  rfx_segment sg{const_cast<uint64_t*>(d_records), n_records, bs, n_records * 4, bins, const_cast<uint32_t*>(d_ext)};
+  rfx_segment sg{const_cast<uint64_t*>(d_records), n_records, bs, n_records * (uint64_t)rfxk::msp_nmax_of(t->k), bins,
+                 const_cast<uint32_t*>(d_ext)};
   sg.borrowed = true;
   t->segs->push_back(sg);
   t->seg_kind = RFX_COUNT_MSP;
@@ -2930,6 +2961,11 @@ rfx_records* rfx_records_subtract(rfx_ctx* c, const rfx_records* a, const rfx_re
   (void)hipSetDevice(c->device);
   for (int i = 0; i < n_others; ++i)
     if (!others[i] || !same_function(a, others[i])) { snprintf(g_err, sizeof g_err, "rfx_records_subtract: databases of different hash functions"); return nullptr; }
+  // (several contexts / devices per process are a supported configuration: records of another one would be
+  // dereferenced on this one's stream)
+  if (a->ctx != c) { snprintf(g_err, sizeof g_err, "rfx_records_subtract: the records belong to another context"); return nullptr; }
+  for (int i = 0; i < n_others; ++i)
+    if (others[i]->ctx != c) { snprintf(g_err, sizeof g_err, "rfx_records_subtract: the records belong to another context"); return nullptr; }
   pin_guard guard(c);
   if (a->n == 0) return records_alloc(c, a->k, a->lsize, a->cols, 0);
   const uint64_t nblk = (a->n + 2047) / 2048;

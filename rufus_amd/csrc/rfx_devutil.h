@@ -36,8 +36,15 @@ constexpr int MSP_WL = 11;
 constexpr int MSP_WL_WIDE = 16;
 __host__ __device__ __forceinline__ int msp_wl(int k) { return k <= 25 ? MSP_WL : MSP_WL_WIDE; }
 __host__ __device__ __forceinline__ int msp_m(int k) { return k - (msp_wl(k) - 1); }
-constexpr int MSP_NMAX = 4;   // k-mers per record: k + 3 <= 28 bases = 56 bits (k <= 25; beyond that see msp_record_binhash)
-constexpr uint64_t MSP_EMPTY = ~0ull;  // no record looks like this: the minimizer offset (bits 63:59) stays below 18
+constexpr uint64_t MSP_EMPTY = ~0ull;  // no record looks like this: n - 1 (bits 63:60) stays below 15
+
+// k-mers per record: a whole super-k-mer (all consecutive k-mers of a read that share the minimizer: at most as
+// many as a k-mer has m-mers), capped by what the record can carry -- n - 1 < 15 (15 = MSP_EMPTY's) and
+// k + n - 1 <= 43 bases (28 in the word, 15 in the plane).  k <= 25: 11; k = 26 .. 29: 15; k = 30: 14; k = 31: 13.
+__host__ __device__ __forceinline__ int msp_nmax(int k) {
+  const int w = msp_wl(k), c = 44 - k;
+  return w < 15 ? (w < c ? w : c) : (15 < c ? 15 : c);
+}
 
 // One multiply each: 32-bit integer multiplies are quarter rate, and k_msp_part1 hashes every base.
 // The xor keeps the all-A m-mer (c = 0) from hashing to 0 = always the minimum.
@@ -50,10 +57,10 @@ __device__ __forceinline__ uint32_t mmer_hash(uint32_t c) {
 // minimum then carries the position of the minimizer along for free, and ties between equal m-mers of
 // one window are broken consistently.  Only the upper 27 bits decide the bin.
 constexpr uint32_t MSP_HMASK = ~31u;
-// The minimum of 15 hashes crowds towards 0: spread it again before taking the top bits.
+// The minimum of 11 .. 16 hashes crowds towards 0: spread it again before taking the top bits.
 __device__ __forceinline__ uint32_t msp_binhash(uint32_t minh) { return (minh & MSP_HMASK) * 0xC2B2AE3Du; }
 __device__ __forceinline__ uint32_t msp_bin(uint32_t minh, int bin_bits) {
-  return msp_binhash(minh) >> (32 - bin_bits);  // msp_record_binhash() (rfx_devutil.h) repeats this from the record
+  return msp_binhash(minh) >> (32 - bin_bits);  // msp_record_binhash() repeats this from the record
 }
 
 __device__ __forceinline__ uint64_t revcomp_bases(uint64_t s, int nbases) {
@@ -62,19 +69,24 @@ __device__ __forceinline__ uint64_t revcomp_bases(uint64_t s, int nbases) {
   return y >> (64 - 2 * nbases);
 }
 
+// ---- super-k-mer record (round 4: one record = one WHOLE super-k-mer, for every k of the MSP path) -------------------
+// A run of n consecutive k-mers of a read that share their minimizer (L = k + n - 1 bases) travels as a 64-bit word + a
+// 32-bit plane (SoA: the partition kernels move the plane as a payload and never look at it):
+//   word  [63:60] n - 1          [59:56] mpos = offset of the minimizer m-mer from the first base HELD IN THE WORD
+//         [55:0]  min(L, 28) bases of the run, first base most significant (right-aligned when L < 28)
+//   plane the other L - 28 bases; [31] side (k >= 29 only)
+// The minimizer lies inside every k-mer of the run, so inside its first k-mer: for k <= 28 the FIRST 28 bases always
+// hold it and the plane holds bases 28 .. L-1.  k = 29 .. 31: when the m-mer does not end within the first 28 bases
+// (side = 1) the word holds bases s .. s+27 with s = k - 28 -- the last 28 of the first k-mer -- and the plane the s
+// bases before them followed by the bases after them.  Either way every partition level gets its bits from the word
+// alone (ONE m-mer hash: msp_record_binhash); only the leaf puts the run back together (msp_record_run).
+// Until round 3 a record held <= 4 k-mers (8 bytes for k <= 25: 42 records per 150 bp read, 336 B; now 22, 264 B).
+__device__ __forceinline__ int msp_record_n(uint64_t x) { return (int)(x >> 60) + 1; }
 
-// The bin hash of a super-k-mer record, re-derived from the record itself: bits [63:59] hold the offset of
-// its minimizer m-mer (common to all its k-mers), so one m-mer hash gives every further partition bit.
-// Record: [63:59] minimizer offset, [58] side, [57:56] k-mers - 1, [55:0] bases, first base most significant.
-// k <= 25: the k + n - 1 <= 28 bases of the run fit, side = 0, done.  k = 26 .. 31 ("wide"): a run has up to
-// 34 bases; the word holds 28 of them -- the LAST 28 (side 0) or the FIRST 28 (side 1), whichever contains the
-// minimizer m-mer (m <= 16: one of the two always does) -- and the other <= 6 bases travel in a parallel
-// 32-bit plane.  The minimizer offset counts from the first base IN THE WORD, so every partition kernel gets
-// its bits from the 64-bit word alone; only the leaf puts the run back together.
 template <bool CANON>
 __device__ __forceinline__ uint32_t msp_record_binhash(uint64_t x, int k) {
-  const int n = (int)((x >> 56) & 3u) + 1, m = msp_m(k);
-  const int L = min(k + n - 1, 28), mpos = (int)(x >> 59);
+  const int n = msp_record_n(x), m = msp_m(k);
+  const int L = min(k + n - 1, 28), mpos = (int)(x >> 56) & 15;
   const uint32_t mmask = m >= 16 ? ~0u : (1u << (2 * m)) - 1;
   const uint32_t f = (uint32_t)((x & ((1ull << 56) - 1)) >> (2 * (L - m - mpos))) & mmask;
   uint32_t c = f;
@@ -84,6 +96,58 @@ __device__ __forceinline__ uint32_t msp_record_binhash(uint64_t x, int k) {
     c = min(f, y >> (32 - 2 * m));
   }
   return msp_binhash(mmer_hash(c));
+}
+
+// Word and plane of the run that is the low 2L bits of (hi:lo) (first base most significant); mpos = offset of its
+// minimizer m-mer from the run's first base.
+__device__ __forceinline__ void msp_record_make(uint64_t lo, uint32_t hi, int k, int n, uint32_t mpos, uint64_t& word,
+                                                uint32_t& plane) {
+  const int L = k + n - 1, m = msp_m(k);
+  const uint64_t m56 = (1ull << 56) - 1;
+  uint64_t bases;
+  uint32_t mp = mpos;
+  if (L <= 28) {
+    bases = lo & ((1ull << (2 * L)) - 1);
+    plane = 0;
+  } else if (k <= 28 || (int)mpos + m <= 28) {  // the first 28 bases; the plane gets the last x
+    const int x = L - 28;
+    bases = ((lo >> (2 * x)) | ((uint64_t)hi << (64 - 2 * x))) & m56;
+    plane = (uint32_t)lo & ((1u << (2 * x)) - 1);
+  } else {  // k >= 29, side 1: bases s .. s+27; the plane gets the s before them and the t after them
+    const int s = k - 28, t = L - 28 - s;
+    const uint64_t v = t ? (lo >> (2 * t)) | ((uint64_t)hi << (64 - 2 * t)) : lo;   // run >> 2t: 56 + 2s <= 62 bits
+    bases = v & m56;
+    const uint32_t head = (uint32_t)(v >> 56) & ((1u << (2 * s)) - 1);
+    plane = (head << (2 * t)) | ((uint32_t)lo & ((1u << (2 * t)) - 1)) | 0x80000000u;
+    mp = mpos - (uint32_t)s;
+  }
+  word = bases | ((uint64_t)mp << 56) | ((uint64_t)(n - 1) << 60);
+}
+
+// The run of a record back as the low 2L bits of (hi:lo).
+__device__ __forceinline__ void msp_record_run(uint64_t x, uint32_t xe, int k, uint64_t& lo, uint64_t& hi) {
+  const int n = msp_record_n(x), L = k + n - 1;
+  const uint64_t S = x & ((1ull << 56) - 1);
+  lo = S;
+  hi = 0;
+  if (L <= 28) return;
+  if (k <= 28 || !(xe >> 31)) {
+    const int x2 = 2 * (L - 28);
+    lo = (S << x2) | (xe & 0x7FFFFFFFu);
+    hi = S >> (64 - x2);
+  } else {
+    const int s = k - 28, t = L - 28 - s;
+    const uint64_t head = (xe >> (2 * t)) & ((1u << (2 * s)) - 1), tail = xe & ((1u << (2 * t)) - 1);
+    const uint64_t mid = S | (head << 56);  // head:S, 56 + 2s <= 62 bits
+    lo = t ? (mid << (2 * t)) | tail : mid;
+    hi = t ? mid >> (64 - 2 * t) : 0;
+  }
+}
+
+// k-mer q (0 = the first) of a run of n k-mers given as (hi:lo)
+__device__ __forceinline__ uint64_t msp_run_kmer(uint64_t lo, uint64_t hi, int k, int n, int q) {
+  const int sh = 2 * (n - 1 - q);
+  return (sh ? (lo >> sh) | (hi << (64 - sh)) : lo) & ((1ull << (2 * k)) - 1);
 }
 
 constexpr int P1_BINS = 128;
@@ -118,6 +182,10 @@ __device__ __forceinline__ void wave_scan256(const uint32_t* s_cnt, uint32_t* s_
   if (l == 63) s_start[n] = inc;
 }
 
+__device__ __forceinline__ uint32_t leaf_hash32(uint64_t w) {
+  const uint32_t h = (uint32_t)w ^ (uint32_t)(w >> 19) ^ (uint32_t)(w >> 37);
+  return h * 0x9E3779B1u;
+}
 __device__ __forceinline__ uint32_t leaf_hash(uint64_t w) {
   uint32_t h = (uint32_t)w ^ (uint32_t)(w >> 19) ^ (uint32_t)(w >> 37);
   h *= 0x9E3779B1u;

@@ -349,7 +349,8 @@ void bin_hist(rfx_ctx*, const uint64_t* src, const uint64_t* parent_start, uint3
 // MSP path (rfx_msp.hip)
 int msp_k_ok(int k);
 int msp_part1_block();  // threads = reads per chunk of k_msp_part1
-int msp_wide(int k);  // k = 26 .. 31: records are a 64-bit word + a 32-bit plane (rfx_devutil.h)
+int msp_nmax_of(int k);   // k-mers a record holds at most (rfx_devutil.h msp_nmax)
+int msp_wide(int k);  // 1 (round 4: every record is a 64-bit word + a 32-bit plane, rfx_devutil.h)
 void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
                int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
                unsigned int* flag, uint32_t* ext_a = nullptr,
@@ -361,7 +362,10 @@ void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* 
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err,
               int geo /* 0: 1024 threads + 8192 slots, 1: 512 + 4096 (two per CU) */,
-              const uint32_t* const* seg_ext = nullptr, const uint32_t* ext0 = nullptr /* wide records: the planes */);
+              const uint32_t* const* seg_ext, const uint32_t* ext0 /* the records' planes */,
+              uint64_t* stage_k, uint32_t* stage_c /* grid * chunk entries each: survivors staged per workgroup */,
+              uint32_t grid, uint32_t chunk /* from msp_leaf_plan */);
+void msp_leaf_plan(rfx_ctx*, uint32_t P, int geo, uint64_t n_records, uint32_t* grid, uint32_t* chunk);
 void surv_hist(rfx_ctx*, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,
                uint64_t* fine_tot, int rec_mode = 0 /* 1 / 2: super-k-mer records, see part2 */, int k = 0,
                uint64_t n_hint = 0);

@@ -5,10 +5,10 @@
 // instance.  Consecutive k-mers of a read overlap in k-1 bases, so here they travel together:
 //
 //   k_msp_part1  reads -> for every k-mer the minimum of hash(canonical m-mer) over its 11 m-mers
-//                (m = k-10); the minimizer picks one of P bins.  Runs of <= 4 consecutive k-mers with
-//                the same bin become ONE 8-byte record (k+3 bases, run length, position of the minimizer).
-//                ~3.4 k-mers per record -> 2.4 B per instance.  128 coarse bins; every phase (8 bases of
-//                512 reads) reserves one run per bin and the lanes store their records into it.
+//                (m = k-10; k >= 26: 16 m-mers, m = k-15); the minimizer picks one of P bins.  A super-k-mer --
+//                ALL consecutive k-mers of the read with the same minimizer, up to 11 (k <= 25) -- becomes ONE
+//                record: 64-bit word + 32-bit plane (rfx_devutil.h).  ~5.7 k-mers per record -> 2.1 B per
+//                instance.  128 coarse bins, filled in per-workgroup slabs.
 //   k_part2      coarse -> fine bins (same kernel as P2L; the bin is re-derived from the record: ONE m-mer
 //                hash, because the record says where its minimizer sits -- so a partition can be refined
 //                to any depth by plain streaming passes, whatever the size of the sample)
@@ -22,6 +22,7 @@
 //                output records (sizes are exact: no compaction pass).
 //
 // The result is the same sorted record list (jf/include/jellyfish/sorted_dumper.hpp:80-112 order).
+#include <algorithm>
 #include <type_traits>
 
 #include "rfx_devutil.h"
@@ -55,8 +56,8 @@ namespace {
 // = 105 / 93 / 90 / 132 / 123 / 110 (768 was the choice of round 1, made on a cache-resident 1 M-read sample when
 // the kernel still fit 80 VGPRs; forcing 6 waves per SIMD, `__launch_bounds__(768, 6)`, gives 89).
 constexpr int MP1_BLOCK = 512;
-// WL: m-mers per k-mer; WIDE: k = 26 .. 31, runs of up to 34 bases = 64-bit word + 32-bit plane (rfx_devutil.h).
-template <bool CANON, int HMODE, int WL, bool WIDE>
+// WL: m-mers per k-mer (11: k <= 25; 16: k = 26 .. 31).  A record = 64-bit word + 32-bit plane (rfx_devutil.h).
+template <bool CANON, int HMODE, int WL>
 __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int k, int bin_bits, uint32_t bin_lo,
                                                          uint32_t bin_hi, uint64_t* __restrict__ buf_a,
                                                          uint32_t* __restrict__ ext_a,
@@ -67,8 +68,9 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   // round 3 and dropped: reserving phase p's runs while phase p + 1 is hashed and storing p's records one phase late
   // (one barrier per phase, nobody waits for the atomic) -- 126 VGPRs, 94 instead of 90 ms per 1 Gb sample: the other
   // workgroup of the CU already covers the round trip, the kernel is bound by what it issues.
-  __shared__ uint32_t s_cnt[2][P1_BINS];
-  __shared__ uint64_t s_gbase[2][P1_BINS];  // 64-bit: the exact redo may size a coarse bin by a skewed maximum
+  constexpr bool SLABS = HMODE == 0 || HMODE == 3;
+  __shared__ uint32_t s_cnt[SLABS ? 1 : 2][SLABS ? 1 : P1_BINS];
+  __shared__ uint64_t s_gbase[SLABS ? 1 : 2][SLABS ? 1 : P1_BINS];  // 64-bit: the exact redo may size a coarse bin by a skewed maximum
   // HMODE 0 / 3 (the optimistic one-pass scatter): SLABS.  Round 2 reserved one run per coarse bin and phase with a
   // global atomic BETWEEN two barriers -- the whole workgroup waited out its round trip 19 times per read, and the
   // records of a phase sat in 24 registers until the addresses were known (-DRFX_TIMING: reserve + barriers 35 %,
@@ -78,17 +80,27 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   // filled up move on (spare -> current, in-flight -> spare, a new reservation is issued and not waited for).  A bin
   // that gets more than two slabs' worth between two such points falls back to one global atomic per record.  The
   // unused tails are filled with MSP_EMPTY at the end, k_part2 / k_surv_hist skip those.
-  constexpr bool SLABS = HMODE == 0 || HMODE == 3;
   static_assert(P1_BINS == 128, "the slab bookkeeping below shifts by log2(P1_BINS) = 7");
   __shared__ uint32_t s_fill[SLABS ? P1_BINS : 1];
   __shared__ uint64_t s_slab[SLABS ? 3 : 1][SLABS ? P1_BINS : 1];  // [0] current, [1] spare ([2]: the in-flight one, at the end)
   __shared__ uint32_t s_fine[HMODE == 0 ? 4096 : HMODE == 1 ? 8192 : HMODE == 3 ? 16384 : 1];
   __shared__ uint32_t s_maxlen;
+  // SLABS (round 4): CLOSE QUEUE.  With whole super-k-mers one lane in six closes a run at any base, so the ~60
+  // instructions that turn a closed run into a record (word + plane, bin, slab slot, two stores, fine histogram) ran at
+  // nearly every base with a sixth of the lanes live.  A closing lane now only pushes (history, length, where the
+  // minimizer sits: 3 dwords) onto its wave's ring in LDS -- ballot + mbcnt, no atomic -- and whenever 64 are queued the
+  // WHOLE wave pops one each.  (At four k-mers per record, one lane in three, this was measured in round 3 and gained
+  // nothing; the bin is re-derived from the record here, so the ring holds 12 bytes per entry: 12 KB per workgroup.)
+  constexpr int QN = 128;  // entries per wave: < 64 left after a drain + <= 64 pushed by one base
+  __shared__ uint32_t s_q[SLABS ? MP1_BLOCK / 64 : 1][SLABS ? 3 * QN : 1];
+  uint32_t* const sq = SLABS ? s_q[threadIdx.x >> 6] : nullptr;
+  uint32_t q_head = 0, q_tail = 0;  // (wave-uniform)
   const uint32_t P = 1u << bin_bits;
   const int sub_bits = bin_bits - 7;  // P1_BINS = 2^7 coarse bins
   const int m = k - (WL - 1);
   const uint32_t mmask = m >= 16 ? ~0u : (1u << (2 * m)) - 1;
   const int rmshift = 2 * (m - 1);
+  const int nmax = msp_nmax(k);
   uint32_t n_emit = 0;  // records this thread stored (or dropped over capacity)
   if (HMODE == 0)
     for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) s_fine[i] = 0;
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     for (uint32_t i = threadIdx.x; i < 8192; i += blockDim.x) s_fine[i] = 0;
   if (HMODE == 3)
     for (uint32_t i = threadIdx.x; i < 16384; i += blockDim.x) s_fine[i] = 0;
-  if (threadIdx.x < 2 * P1_BINS) (&s_cnt[0][0])[threadIdx.x] = 0;
+  if (!SLABS && threadIdx.x < 2 * P1_BINS) (&s_cnt[0][0])[threadIdx.x] = 0;
   const uint32_t SLAB = 1u << slab_log2;
   const uint32_t tick_mask = SLAB >= 128 ? 3u : SLAB >= 64 ? 1u : 0u;  // bins move on every 4 / 2 / 1 phases
   // threads < P1_BINS: where the slab reserved ahead for their bin starts (the raw value of the cursor: it is looked at
@@ -122,6 +134,40 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     s_slab[1][threadIdx.x] = used ? slab_at(threadIdx.x, reserve_raw(threadIdx.x)) : ~0ull;
     pending = used ? reserve_raw(threadIdx.x) : P1_NO_SLAB;
   }
+  // the wave's first `cnt` queued runs -> records -> slabs (lane l takes entry q_head + l)
+  auto drain = [&](uint32_t cnt) {
+    const uint32_t l = threadIdx.x & 63u;
+    if (l < cnt) {
+      const uint32_t idx = (q_head + l) & (QN - 1);
+      const uint64_t h64 = (uint64_t)sq[idx] | ((uint64_t)sq[QN + idx] << 32);
+      const uint32_t meta = sq[2 * QN + idx];
+      const int n = (int)((meta >> 22) & 15u);
+      const uint32_t back = meta >> 26;
+      uint64_t w;
+      uint32_t x;
+      msp_record_make(h64, meta & 0x3FFFFFu, k, n, (uint32_t)(k + n - 1 - m) - back, w, x);
+      // the bin, from the record: the same bits msp_bin(run_h) gave when the lane decided the run was this shard's
+      const uint32_t run_bin = msp_record_binhash<CANON>(w, k) >> (32 - bin_bits);
+      const uint32_t coarse = run_bin >> sub_bits;
+      const uint32_t slot = atomicAdd(&s_fill[coarse], 1u);
+      if (slot < 2 * SLAB) {  // (a bin of ours always has a slab behind it: slab_at)
+        const uint64_t sb = s_slab[slot >> slab_log2][coarse];
+        buf_a[sb + (slot & (SLAB - 1))] = w;
+        ext_a[sb + (slot & (SLAB - 1))] = x;
+      } else {  // more than two slabs' worth since the bins last moved on: one reservation per record
+        const uint32_t at = atomicAdd(&coarse_cur[coarse * P1_CUR_STRIDE], 1u);
+        if (at < cap_a) {
+          buf_a[(uint64_t)coarse * cap_a + at] = w;
+          ext_a[(uint64_t)coarse * cap_a + at] = x;
+        } else {
+          atomicExch(flag, 1u);
+        }
+      }
+      ++n_emit;
+      atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
+    }
+    q_head += cnt;
+  };
   const uint32_t n_chunks = (rv.n + MP1_BLOCK - 1) / MP1_BLOCK;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
     const uint32_t r = chunk * MP1_BLOCK + threadIdx.x;
@@ -165,7 +211,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
       TM(3);
       const uint32_t X = ph & 1u;
       uint64_t wv[P1_S];
-      uint32_t xv[WIDE ? P1_S : 1];
+      uint32_t xv[P1_S];
       uint32_t br[P1_S];  // (coarse bin << 16) | rank, or ~0: no record closed at this base
 #pragma unroll
       for (int b = 0; b < P1_S; ++b) br[b] = ~0u;
@@ -195,9 +241,13 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
         // uniform reads): no per-lane bounds checks
         auto base_step = [&](auto fast_tag, const int b) {
           constexpr bool FAST = decltype(fast_tag)::value;
-          if (FAST || p0 + b < lenp) {
+          const bool act = FAST || p0 + b < lenp;  // (the queue below is the wave's: it is worked outside the per-lane test)
+          uint32_t code = 0;
+          bool kvalid = false, closes = false, mine = false;
+          uint32_t mh = 0, run_bin = 0;
+          if (act) {
             const bool real = FAST || p0 + b < len;
-            const uint32_t code = real ? (uint32_t)cur_w & 3u : 0u;
+            code = real ? (uint32_t)cur_w & 3u : 0u;
             const bool valid = real && (cur_m & 1u);
             cur_w >>= 2;
             cur_m >>= 1;
@@ -207,80 +257,56 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
             a[WL - 1 + b] = h;
             pm = min(pm, h);
             filled = valid ? filled + 1 : 0;
-            const bool kvalid = filled >= k;
+            kvalid = filled >= k;
             // A run = consecutive k-mers with the same minimizer HASH (not merely the same bin): every
             // further bit of that hash is then common to the record's k-mers, which is what lets
-            // k_slice_tag refine the partition later without separating instances of a k-mer.
-            const uint32_t mh = min(sfx[b], pm);
+            // the partition be refined later without separating instances of a k-mer.
+            mh = min(sfx[b], pm);
             // (bitwise, not short-circuit: one exec mask instead of three nested ones)
             // The run that ended at the previous base closes (`hist` still ends there), and it is ours (shard passes: other
-            // bins are not; unsigned: one compare).  ONE predicate for the block below: the wave enters it at nearly
-            // every base anyway (one lane in three closes), so what is computed for it outside costs nothing extra, and
-            // every level of nesting less is a saved exec mask, a branch and a restore.
-            const bool closes = (run_n != 0) & (!kvalid | (mh != run_h) | (run_n == MSP_NMAX));
-            const uint32_t run_bin = msp_bin(run_h, bin_bits);
+            // bins are not; unsigned: one compare).
+            closes = (run_n != 0) & (!kvalid | (mh != run_h) | (run_n == nmax));
+            run_bin = msp_bin(run_h, bin_bits);
   #ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
-            const bool mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
+            mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
   #else
-            const bool mine = run_bin - bin_lo < bin_hi - bin_lo;
+            mine = run_bin - bin_lo < bin_hi - bin_lo;
   #endif
-            if (closes & mine) {
-              if (HMODE != 1) {
-                const int L = k + run_n - 1;
-                const uint32_t coarse = run_bin >> sub_bits;
-                // the record ends at base e = p0 + b - 1; its minimizer m-mer ends at the last base q <= e with
-                // q = run_h (mod 32) -- inside the record, so e - q < 32.  mpos = first base of the m-mer
-                // counted from the record's first base: 0 .. L - m <= 17.
+          }
+          if constexpr (SLABS) {
+            const bool push = closes & mine;
+            const unsigned long long bal = __ballot(push);
+            if (bal) {
+              if (push) {
+                const uint32_t idx =
+                    (q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))) &
+                    (QN - 1);
+                // the run ends at base e = p0 + b - 1; its minimizer m-mer ends at the last base q <= e with
+                // q = run_h (mod 32) -- inside the run's LAST k-mer, so back = e - q <= k - m < 16
                 const uint32_t back = (p0 + (uint32_t)b - 1u - run_h) & 31u;
-                const uint32_t mpos = (uint32_t)(L - m) - back;
-                if (!WIDE || L <= 28) {
-                  wv[b] = (hist & ((1ull << (2 * L)) - 1)) | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)mpos << 59);
-                  if (WIDE) xv[b] = 0;
-                } else {  // 29 .. 34 bases: the word takes the 28 that contain the minimizer, the plane the other x
-                  const int x = L - 28;
-                  const uint64_t m56 = (1ull << 56) - 1;
-                  uint64_t bases;
-                  uint32_t side, mp;
-                  if (mpos >= (uint32_t)x) {  // the LAST 28 bases hold it: the plane gets the first x (S >> 56)
-                    bases = hist & m56;
-                    xv[b] = (uint32_t)((hist >> 56) | ((uint64_t)hist_hi << 8)) & ((1u << (2 * x)) - 1);
-                    side = 0;
-                    mp = mpos - (uint32_t)x;
-                  } else {  // the FIRST 28 (S >> 2x); the plane gets the last x
-                    bases = ((hist >> (2 * x)) | ((uint64_t)hist_hi << (64 - 2 * x))) & m56;
-                    xv[b] = (uint32_t)hist & ((1u << (2 * x)) - 1);
-                    side = 1;
-                    mp = mpos;
-                  }
-                  wv[b] = bases | ((uint64_t)(run_n - 1) << 56) | ((uint64_t)side << 58) | ((uint64_t)mp << 59);
-                }
-                if (SLABS) {
-                  const uint32_t slot = atomicAdd(&s_fill[coarse], 1u);
-                  if (slot < 2 * SLAB) {  // (a bin of ours always has a slab behind it: slab_at)
-                    const uint64_t sb = s_slab[slot >> slab_log2][coarse];
-                    buf_a[sb + (slot & (SLAB - 1))] = wv[b];
-                    if (WIDE) ext_a[sb + (slot & (SLAB - 1))] = xv[b];
-                  } else {  // more than two slabs' worth since the bins last moved on: one reservation per record
-                    const uint32_t at = atomicAdd(&coarse_cur[coarse * P1_CUR_STRIDE], 1u);
-                    if (at < cap_a) {
-                      buf_a[(uint64_t)coarse * cap_a + at] = wv[b];
-                      if (WIDE) ext_a[(uint64_t)coarse * cap_a + at] = xv[b];
-                    } else {
-                      atomicExch(flag, 1u);
-                    }
-                  }
-                  ++n_emit;
-                } else {
-                  br[b] = (coarse << 16) | atomicAdd(&s_cnt[X][coarse], 1u);
-                }
+                sq[idx] = (uint32_t)hist;
+                sq[QN + idx] = (uint32_t)(hist >> 32);
+                sq[2 * QN + idx] = (hist_hi & 0x3FFFFFu) | ((uint32_t)run_n << 22) | (back << 26);
               }
-              if (HMODE == 0 || HMODE == 3) atomicAdd(&s_fine[run_bin >> 1], 1u << ((run_bin & 1u) * 16));
-              if (HMODE == 1) atomicAdd(&s_fine[run_bin], 1u);
+              q_tail += (uint32_t)__popcll(bal);
+              if (q_tail - q_head >= 64u) drain(64u);
             }
+          } else if (closes & mine) {
+            if (HMODE != 1) {
+              const int L = k + run_n - 1;
+              const uint32_t coarse = run_bin >> sub_bits;
+              const uint32_t back = (p0 + (uint32_t)b - 1u - run_h) & 31u;
+              const uint32_t mpos = (uint32_t)(L - m) - back;
+              msp_record_make(hist, hist_hi, k, run_n, mpos, wv[b], xv[b]);
+              br[b] = (coarse << 16) | atomicAdd(&s_cnt[X][coarse], 1u);
+            }
+            if (HMODE == 1) atomicAdd(&s_fine[run_bin], 1u);
+          }
+          if (act) {
             run_n = closes ? 0 : run_n;
             run_h = kvalid && !run_n ? mh : run_h;  // (selects, not branches: two instructions instead of a saved exec mask)
             run_n += kvalid ? 1 : 0;
-            if (WIDE) hist_hi = (hist_hi << 2) | (uint32_t)(hist >> 62);
+            hist_hi = (hist_hi << 2) | (uint32_t)(hist >> 62);
             hist = (hist << 2) | code;
           }
         };
@@ -350,7 +376,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
           if (brx[b] != ~0u) {
             if (base[b] != ~0ull) {
               buf_a[base[b] + (brx[b] & 0xFFFFu)] = wvx[b];
-              if (WIDE) ext_a[base[b] + (brx[b] & 0xFFFFu)] = xvx[b];
+              ext_a[base[b] + (brx[b] & 0xFFFFu)] = xvx[b];
             }
             ++n_emit;
           }
@@ -371,6 +397,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     if (whole) phases(std::true_type());
     else phases(std::false_type());
   }
+  if constexpr (SLABS) drain(q_tail - q_head);  // what is left in the wave's queue (< 64)
   __syncthreads();
   if (SLABS) {  // the slots nobody took: MSP_EMPTY
     if (threadIdx.x < P1_BINS) s_slab[2][threadIdx.x] = slab_at(threadIdx.x, pending);
@@ -409,42 +436,70 @@ __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
   return (uint32_t)((key * 0xD6E8FEB86659FD93ull) >> 32);
 }
 
-constexpr int MSP_ILP = 8;
-constexpr int MSP_RC_PROBES = 8;  // a record that finds no cache slot within this many probes bypasses the cache
+constexpr uint32_t MSP_LEAF_STAGE(int geo) { return geo ? 8192u : 16384u; }  // survivors a workgroup stages before it scatters them
+constexpr int MSP_ILP = 4;        // records a lane loads before its first probe (a bin holds ~3 per lane)
+#ifndef RFX_RC_PROBES
+#define RFX_RC_PROBES 16
+#endif
+#ifndef RFX_RC_SHRINK
+#define RFX_RC_SHRINK 2
+#endif
+constexpr int MSP_RC_PROBES = RFX_RC_PROBES;  // a record that finds no cache slot within this many probes bypasses the cache
+constexpr unsigned long long MSP_RK_MUL = 0x9E3779B97F4A7C15ull;  // record cache key = word ^ plane * this (odd: injective in the plane)
+constexpr uint32_t MSP_RC_UNLISTED = 0x80000000u;  // record cache count: the record found no room in the k-mer map
 
-// One workgroup per fine minimizer bin.  A bin (or part of it) whose distinct k-mers overflow the LDS
-// table is split in two by a hash bit and each half retried -- results already appended stay valid.
-// GEO 0: one 1024-thread workgroup per CU (8192-slot table, 4096-slot record cache);
-// GEO 1: half of everything, two workgroups per CU -- for bins of ~8 K instances.
-// WIDE (k = 26 .. 31): a record is a 64-bit word + the <= 6 bases in the 32-bit plane; the cache
-// matches both (the plane value is published after the word: a reader that comes too early counts its record
-// directly -- the cache is best effort anyway).
-template <bool CANON, int GEO, bool WIDE>
+// One workgroup per fine minimizer bin (round 4: rebuilt around three barriers per bin).
+//
+//   A  every record of the bin goes into a small cache keyed by the record (word + plane): reads that cover the same
+//      stretch of genome cut it into the same super-k-mers, so at sequencing depth most records are copies and cost one
+//      CAS + one add.  The lane that takes a fresh slot also books the record's n k-mers in a dense map
+//      (s_kmap[..] = slot << 4 | q; one LDS add reserves the n entries).
+//   B  one k-mer per lane over the map: cut k-mer q out of the cached run, canonical form, one returning CAS into the
+//      k-mer table, count += multiplicity of the record.  Every instance of a k-mer has the same minimizer, so the
+//      counts are final.
+//   C  the table is scanned once: survivors (lower <= count <= upper) go as (key, count) to a staging chunk of the
+//      workgroup in global memory, every slot and the cache are cleared on the way (no separate clearing pass).
+//   F  only when the staging chunk (CH entries, > the table's fill limit) could not take another bin -- every ~20 bins
+//      on 30x data with the 8192-entry chunk of a big input: w = T * key, and the chunk
+//      is scattered into the 128 coarse pos bins -- until round 3 every bin paid for this (four barriers, seven table
+//      reads per survivor and the round trip of 128 global atomics: 25 % of the kernel).
+//
+// A bin (or part of it) whose distinct k-mers overflow the table is split in two by a hash bit and each half retried.
+// GEO 0: one 1024-thread workgroup per CU (8192-slot table); GEO 1: half of everything, two workgroups per CU.
+template <bool CANON, int GEO>
 __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     const uint64_t* const* __restrict__ seg_inst, const uint64_t* const* __restrict__ seg_bs, int nseg,
     const uint64_t* __restrict__ inst0, const uint64_t* __restrict__ bs0, const uint32_t* const* __restrict__ seg_ext,
     const uint32_t* __restrict__ ext0, uint32_t P, int k,
     const uint64_t* __restrict__ g_lut, int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi,
     uint64_t lower, uint64_t upper, uint64_t* __restrict__ out_w, uint32_t* __restrict__ out_c,
-    uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err) {
+    uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err,
+    uint64_t* __restrict__ stage_k, uint32_t* __restrict__ stage_c, uint32_t CH) {
   constexpr int TBL_LOG2 = GEO ? 12 : 13, TBL = 1 << TBL_LOG2, BLK = GEO ? 512 : 1024, FILL = TBL * 3 / 4;
-  constexpr int RC_LOG2 = TBL_LOG2 - 1, RC = 1 << RC_LOG2, LIST = RC;
+  constexpr int RC_LOG2 = TBL_LOG2 - (GEO ? RFX_RC_SHRINK : 2), RC = 1 << RC_LOG2, KMAP = TBL;
+  static_assert(RC <= 4096, "a k-mer map entry is slot << 4 | q in 16 bits");
   __shared__ __attribute__((aligned(16))) unsigned long long s_keys[TBL];
   __shared__ uint32_t s_cnt[TBL];
+  // record cache.  A record is 96 bits, an LDS compare-and-swap takes 64: the slot's key is word ^ plane * odd -- two
+  // records with the same word and different planes (an error in the last bases of a long run: a few per bin) get
+  // different keys, and a probe stays ONE returning CAS.  Every record that lands on a slot adds 1 and folds its plane
+  // into the slot's minimum and maximum, three adds nobody waits for: min == max proves that all of them were the
+  // same record (same key + same plane = same word).  Two different records under one key -- a 64-bit coincidence,
+  // not seen yet -- void the cached pass of the bin, which is then counted without the cache.
+  __shared__ unsigned long long s_rk[RC];
+  __shared__ uint32_t s_rc[RC], s_rmin[RC], s_rmax[RC];
+  __shared__ uint32_t s_mixed[2];
+  __shared__ uint16_t s_kmap[KMAP];
   __shared__ uint32_t s_pc[P1_BINS];
   __shared__ uint64_t s_pbase[P1_BINS];
-  __shared__ uint64_t s_lk[LIST];
-  __shared__ uint32_t s_lc[LIST];
-  __shared__ uint32_t s_nd, s_ovf, s_nl, s_ns;  // s_nl: packed cache records; s_ns: survivors in the list
-  // WIDE: plane value of the cached record (<= 6 bases = 12 bits) | 0x8000 once published; 16 bits so that it fits
-  // beside the full-size tables (157 of the 160 KB)
-  __shared__ uint16_t s_rx[WIDE ? RC : 1];
-  unsigned long long* s_rk = (unsigned long long*)s_lk;  // the record cache lives in the (then idle) survivor list
-  uint32_t* s_rc = s_lc;
-  const uint64_t kmask = (1ull << (2 * k)) - 1;
+  // by parity of the pass: distinct keys, overflow, k-mer map fill, survivors of the scan (zeroed for the NEXT pass by
+  // thread 0 after the first barrier of a pass: nobody reads the other parity's between that barrier and the next pass)
+  __shared__ uint32_t s_nd[2], s_ovf[2], s_nk[2], s_ns[2];
+  uint64_t* const stk = stage_k + (size_t)blockIdx.x * CH;
+  uint32_t* const stc = stage_c + (size_t)blockIdx.x * CH;
 
   uint64_t pre[MSP_ILP];
-  uint32_t prex[WIDE ? MSP_ILP : 1];
+  uint32_t prex[MSP_ILP];
   uint64_t pre_a = 0, pre_e = 0;
   auto prefetch = [&](uint32_t b) {
     if (b >= P) return;
@@ -454,10 +509,85 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     for (int u = 0; u < MSP_ILP; ++u) {
       const uint64_t i = pre_a + threadIdx.x + (uint64_t)u * BLK;
       pre[u] = i < pre_e ? inst0[i] : MSP_EMPTY;
-      if (WIDE) prex[u] = i < pre_e ? ext0[i] : 0u;
+      prex[u] = i < pre_e ? ext0[i] : 0u;
     }
   };
   prefetch(blockIdx.x);
+  for (int i = threadIdx.x; i < TBL; i += BLK) {
+    s_keys[i] = RFX_EMPTY;
+    s_cnt[i] = 0;
+  }
+  for (int i = threadIdx.x; i < RC; i += BLK) {
+    s_rk[i] = MSP_EMPTY;
+    s_rc[i] = 0;
+    s_rmin[i] = ~0u;
+    s_rmax[i] = 0;
+  }
+  if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
+  if (threadIdx.x < 2) s_nd[threadIdx.x] = s_ovf[threadIdx.x] = s_nk[threadIdx.x] = s_ns[threadIdx.x] = s_mixed[threadIdx.x] = 0;
+  uint32_t used = 0;  // entries of the staging chunk in use (the same in every thread)
+  uint32_t X = 0;     // parity of the pass
+  __syncthreads();
+
+  // F: staged survivors -> w = T * key -> the 128 coarse pos bins
+  auto flush = [&]() {
+    // (four entries in flight per lane: one at a time, a lane waited for its key and then for the seven table reads, ten
+    // times over -- the flush of a chunk took as long as two bins)
+    for (uint32_t i0 = threadIdx.x; i0 < used; i0 += 4 * BLK) {
+      uint64_t kv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kv[u] = i0 + u * BLK < used ? stk[i0 + u * BLK] : 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kv[u] = gf2_mul(g_lut, kv[u], ntab);  // 14 KB table, L1-resident; only survivors get here
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * BLK < used) {
+          uint64_t w = kv[u];
+          const uint64_t pos = w >> sel_bits;
+          if (pos >= pos_lo && pos < pos_hi) atomicAdd(&s_pc[(uint32_t)(w >> shift1)], 1u);
+          else w = RFX_EMPTY;
+          stk[i0 + u * BLK] = w;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < P1_BINS) {
+      const uint32_t cn = s_pc[threadIdx.x];
+      const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
+      if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
+        atomicExch(flag, 1u);
+        s_pbase[threadIdx.x] = ~0ull;
+      } else {
+        s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at;
+      }
+      s_pc[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i0 = threadIdx.x; i0 < used; i0 += 4 * BLK) {
+      uint64_t wv[4];
+      uint32_t cv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool in = i0 + u * BLK < used;
+        wv[u] = in ? stk[i0 + u * BLK] : RFX_EMPTY;
+        cv[u] = in ? stc[i0 + u * BLK] : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t w = wv[u];
+        if (w == RFX_EMPTY) continue;
+        const uint32_t cb = (uint32_t)(w >> shift1);
+        const uint32_t o = atomicAdd(&s_pc[cb], 1u);
+        if (s_pbase[cb] != ~0ull) {
+          out_w[s_pbase[cb] + o] = w;
+          out_c[s_pbase[cb] + o] = cv[u];
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
+    used = 0;
+    // (the next use of s_pc / the chunk lies behind the barriers of the next pass)
+  };
 
   for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
     const uint64_t a0 = pre_a, e0 = pre_e;
@@ -465,260 +595,189 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     // sub-range (r, j): k-mers whose top r bits of split_hash equal j; depth-first over the halves
     int r = 0;
     uint32_t j = 0;
-    bool failed = false;
+    bool failed = false, nocache = false;
     TM_DECL;
     for (;;) {
       TM(15);
-      for (int i = threadIdx.x; i < TBL; i += BLK) {
-        s_keys[i] = RFX_EMPTY;
-        s_cnt[i] = 0;
-      }
-      for (int i = threadIdx.x; i < RC; i += BLK) {
-        s_rk[i] = MSP_EMPTY;
-        s_rc[i] = 0;
-        if (WIDE) s_rx[i] = 0;
-      }
-      if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
-      if (threadIdx.x == 0) {
-        s_nd = 0;
-        s_ovf = 0;
-        s_nl = 0;
-        s_ns = 0;
-      }
-      __syncthreads();
-      TM(8);
-      // k-mer q of record x into the table, counted `mult` times.
-      auto insert_kmer = [&](uint64_t x, uint32_t xe, int q, uint32_t mult) {
-        const int n = (int)((x >> 56) & 3u) + 1;
-        if (q >= n) return;
-        const uint64_t S = x & ((1ull << 56) - 1);
-        uint64_t fwd, key;
-        if (!WIDE) {
-          fwd = (S >> (2 * (n - 1 - q))) & kmask;
-          key = fwd;
-          if (CANON) {
-            const uint64_t rc = (revcomp_bases(S, k + n - 1) >> (2 * q)) & kmask;
-            key = rc < fwd ? rc : fwd;
-          }
-        } else {  // put the run back together (up to 68 bits), then cut the k-mer out
-          const int L = k + n - 1, xx = L - 28;
-          uint64_t lo = S, hi = 0;
-          if (xx > 0) {
-            if ((x >> 58) & 1u) {  // side 1: the word holds the FIRST 28 bases, the plane the last xx
-              lo = (S << (2 * xx)) | xe;
-              hi = S >> (64 - 2 * xx);
-            } else {               // side 0: the word holds the LAST 28, the plane the first xx
-              lo = S | ((uint64_t)xe << 56);
-              hi = xe >> 8;
-            }
-          }
-          const int sh = 2 * (n - 1 - q);
-          fwd = (sh ? (lo >> sh) | (hi << (64 - sh)) : lo) & kmask;
-          key = fwd;
-          if (CANON) {
-            const uint64_t rc = revcomp_bases(fwd, k);
-            key = rc < fwd ? rc : fwd;
-          }
+      // forward k-mer `fwd` into the table, counted `mult` times
+      auto insert_fwd = [&](uint64_t fwd, uint32_t mult) {
+        uint64_t key = fwd;
+        if (CANON) {
+          const uint64_t rc = revcomp_bases(fwd, k);
+          key = rc < fwd ? rc : fwd;
         }
         if (r > 0 && (split_hash(key) >> (32 - r)) != j) return;
         // The probe is ONE returning CAS: it yields "was empty, now mine", "already mine" or "someone
         // else's" without a separate read-and-branch for the new-key case.  New keys are only counted
-        // (no returned ticket: one wave-aggregated LDS add); the count is looked at before every
-        // insert, so at most one key per thread can follow FILL, which the TBL - FILL
-        // spare slots absorb -- probing always terminates.  A skipped insert voids the pass.
-        if (__hip_atomic_load(&s_nd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)FILL) {
-          s_ovf = 1;
+        // (no returned ticket); the count is looked at before every insert, so at most one key per thread can
+        // follow FILL, which the TBL - FILL spare slots absorb -- probing always terminates.  A skipped insert voids
+        // the pass.
+        if (__hip_atomic_load(&s_nd[X], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (uint32_t)FILL) {
+          s_ovf[X] = 1;
           return;
         }
-        uint32_t slot = leaf_hash(key) >> (LEAF_TBL_LOG2 - TBL_LOG2);
+        // double hashing (an odd step from other bits of the hash): a wave probes as long as its unluckiest lane, and
+        // linear probing's clusters give that lane long walks at the 40-50 % load of a full bin
+        const uint32_t hk = leaf_hash32(key);
+        uint32_t slot = hk >> (32 - TBL_LOG2);
+        const uint32_t step = ((hk >> 3) | 1u) & (TBL - 1);
         for (;;) {
           unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
           if (old == RFX_EMPTY) {
-            atomicAdd(&s_nd, 1u);
+            atomicAdd(&s_nd[X], 1u);
             old = key;
           }
           if (old == key) {
             atomicAdd(&s_cnt[slot], mult);
             break;
           }
-          slot = (slot + 1) & (TBL - 1);
+          slot = (slot + step) & (TBL - 1);
         }
       };
-      auto insert_record = [&](uint64_t x, uint32_t xe, uint32_t mult) {
-        for (int q = 0; q < MSP_NMAX; ++q) insert_kmer(x, xe, q, mult);
+      auto insert_record = [&](uint64_t x, uint32_t xe, uint32_t mult) {  // all k-mers of a record, one after the other
+        uint64_t lo, hi;
+        msp_record_run(x, xe, k, lo, hi);
+        const int n = msp_record_n(x);
+        for (int q = 0; q < n; ++q) insert_fwd(msp_run_kmer(lo, hi, k, n, q), mult);
       };
-      // Phase A: identical records first.  Reads that cover the same stretch of genome cut it into the
-      // same records (run boundaries follow the minimizers, not the read), so at sequencing depth most
-      // records of a bin are copies: one cheap insert of the 8-byte record into a small cache, and only
-      // the distinct ones pay for k-mer extraction and up to four table inserts (phase B).  The cache is
-      // best effort: a record that finds no slot within MSP_RC_PROBES goes straight to the table.
+      // ---- A: records -> cache (+ k-mer map) ----
       for (int sg = 0; sg < nseg; ++sg) {
         const uint64_t a = sg == 0 ? a0 : seg_bs[sg][bin], e = sg == 0 ? e0 : seg_bs[sg][bin + 1];
         const uint64_t* __restrict__ src = sg == 0 ? inst0 : seg_inst[sg];
-        const uint32_t* __restrict__ srcx = WIDE ? (sg == 0 ? ext0 : seg_ext[sg]) : nullptr;
+        const uint32_t* __restrict__ srcx = sg == 0 ? ext0 : seg_ext[sg];
         for (uint64_t base = a; base < e; base += (uint64_t)MSP_ILP * BLK) {
           uint64_t rec[MSP_ILP];
-          uint32_t recx[WIDE ? MSP_ILP : 1];
+          uint32_t recx[MSP_ILP];
           if (sg == 0 && base == a && !prefetched_next) {
 #pragma unroll
             for (int u = 0; u < MSP_ILP; ++u) {
               rec[u] = pre[u];
-              if (WIDE) recx[u] = prex[u];
+              recx[u] = prex[u];
             }
           } else {
 #pragma unroll
             for (int u = 0; u < MSP_ILP; ++u) {
               const uint64_t i = base + threadIdx.x + (uint64_t)u * BLK;
               rec[u] = i < e ? src[i] : MSP_EMPTY;
-              if (WIDE) recx[u] = i < e ? srcx[i] : 0u;
+              recx[u] = i < e ? srcx[i] : 0u;
             }
           }
 #pragma unroll
           for (int u = 0; u < MSP_ILP; ++u) {
             const uint64_t x = rec[u];
-            const uint32_t xe = WIDE ? recx[u] : 0u;
+            const uint32_t xe = recx[u];
             if (x == MSP_EMPTY) continue;
-            uint32_t h = (uint32_t)x ^ (uint32_t)(x >> 23) ^ (uint32_t)(x >> 41) ^ (WIDE ? xe * 0x85EBCA6Bu : 0u);
-            h = (h * 0x9E3779B1u) >> (32 - RC_LOG2);
-            bool cached = false;
-            for (int p = 0; p < MSP_RC_PROBES; ++p) {
-              const unsigned long long old = atomicCAS(&s_rk[h], (unsigned long long)MSP_EMPTY, (unsigned long long)x);
-              if (!WIDE) {
-                if (old == MSP_EMPTY || old == x) {
-                  atomicAdd(&s_rc[h], 1u);
-                  cached = true;
+            uint32_t h = (uint32_t)x ^ (uint32_t)(x >> 23) ^ (uint32_t)(x >> 41) ^ (xe * 0x85EBCA6Bu);
+            h *= 0x9E3779B1u;
+            const uint32_t hstep = ((h >> 5) | 1u) & (RC - 1);
+            h >>= 32 - RC_LOG2;
+            // The probe loop only FINDS the slot -- it runs as long as the slowest lane of the wave probes, so nothing
+            // else lives in it (the booking of a new record's k-mers, inside it, made phase A 2.4 x slower).
+            int state = 0;  // 1: slot taken (h), 2: found, 0: count the record directly
+            const unsigned long long ck = x ^ ((unsigned long long)xe * MSP_RK_MUL);
+            if (!nocache && ck != MSP_EMPTY) {
+              for (int p = 0; p < MSP_RC_PROBES; ++p) {
+                const unsigned long long old = atomicCAS(&s_rk[h], (unsigned long long)MSP_EMPTY, ck);
+                if (old == MSP_EMPTY || old == ck) {
+                  state = old == ck ? 2 : 1;
                   break;
                 }
-              } else if (old == MSP_EMPTY) {  // mine: publish the plane value
-                __hip_atomic_store(&s_rx[h], (uint16_t)(xe | 0x8000u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                atomicAdd(&s_rc[h], 1u);
-                cached = true;
-                break;
-              } else if (old == x) {
-                const uint32_t px = __hip_atomic_load(&s_rx[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (px == (xe | 0x8000u)) {
-                  atomicAdd(&s_rc[h], 1u);
-                  cached = true;
-                  break;
-                }
-                if (px == 0) break;  // not published yet: count this one directly
+                h = (h + hstep) & (RC - 1);
               }
-              h = (h + 1) & (RC - 1);
             }
-            if (!cached) insert_record(x, xe, 1u);
+            if (state) {
+              atomicAdd(&s_rc[h], 1u);
+              atomicMin(&s_rmin[h], xe);
+              atomicMax(&s_rmax[h], xe);
+            }
+            TMC(22, 1);
+            TMC(23, state == 0);
+            if (state == 1) {  // book the record's k-mers in the map
+              const uint32_t n = (uint32_t)msp_record_n(x);
+              const uint32_t kb = atomicAdd(&s_nk[X], n);
+              if (kb + n <= (uint32_t)KMAP) {
+#pragma unroll
+                for (uint32_t q = 0; q < 15; ++q)  // (no loop: the wave would run it as often as its longest record asks)
+                  if (q < n) s_kmap[kb + q] = (uint16_t)((h << 4) | q);
+              } else {  // no room in the map: B looks for these in the cache itself (what is left of the map: no entry)
+                for (uint32_t q = kb; q < (uint32_t)KMAP; ++q) s_kmap[q] = 0xFFFFu;
+                atomicOr(&s_rc[h], MSP_RC_UNLISTED);
+              }
+            }
+            if (state == 0) insert_record(x, xe, 1u);
           }
         }
       }
-      if (!prefetched_next) {  // the next bin's loads fly while this one is emitted
+      if (!prefetched_next) {  // the next bin's loads fly while this one is counted
         prefetch(bin + gridDim.x);
         prefetched_next = true;
       }
       __syncthreads();
       TM(9);
-      {  // Phase B: pack the cache (in place, through registers), then one dense pass over the distinct records
-        uint64_t ex[RC / BLK];
-        uint32_t ec[RC / BLK];
-        uint32_t exx[WIDE ? RC / BLK : 1];
-#pragma unroll
-        for (int h = 0; h < RC / BLK; ++h) {
-          ex[h] = s_rk[h * BLK + threadIdx.x];
-          ec[h] = s_rc[h * BLK + threadIdx.x];
-          if (WIDE) exx[h] = s_rx[h * BLK + threadIdx.x];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int h = 0; h < RC / BLK; ++h)
-          if (ex[h] != MSP_EMPTY) {
-            const uint32_t o = atomicAdd(&s_nl, 1u);
-            s_rk[o] = ex[h];
-            s_rc[o] = ec[h];
-            if (WIDE) s_rx[o] = (uint16_t)(exx[h] & 0x7FFFu);
-          }
-        __syncthreads();
-        const uint32_t nrec = s_nl;
-        TM(10);
-        // one k-mer per thread: four times the parallelism of one record per thread, and the table
-        // round trips of a record's k-mers overlap instead of queueing in one lane
-        for (uint32_t i = threadIdx.x; i < MSP_NMAX * nrec; i += BLK)
-          insert_kmer(s_rk[i >> 2], WIDE ? s_rx[i >> 2] : 0u, (int)(i & 3u), s_rc[i >> 2]);
+      // ---- B: one k-mer per lane ----
+      if (threadIdx.x == 0) s_nd[X ^ 1] = s_ovf[X ^ 1] = s_nk[X ^ 1] = s_ns[X ^ 1] = s_mixed[X ^ 1] = 0;
+      const uint32_t nk_all = s_nk[X], nk = min(nk_all, (uint32_t)KMAP);
+      for (uint32_t i = threadIdx.x; i < nk; i += BLK) {
+        const uint32_t e = s_kmap[i];
+        if (e == 0xFFFFu) continue;
+        const uint32_t slot = e >> 4, q = e & 15u;
+        const uint32_t xe = s_rmax[slot];
+        const uint64_t x = s_rk[slot] ^ ((uint64_t)xe * MSP_RK_MUL);
+        if (q == 0 && s_rmin[slot] != xe) s_mixed[X] = 1;  // two different records met in this slot
+        uint64_t lo, hi;
+        msp_record_run(x, xe, k, lo, hi);
+        insert_fwd(msp_run_kmer(lo, hi, k, msp_record_n(x), (int)q), s_rc[slot]);
       }
-      __syncthreads();  // (the survivor list has its own counter, s_ns: no reset in between, one barrier instead of two)
-      TM(11);
-      TMC(20, s_ovf != 0);
-      TMC(21, 1);
-      const bool ovf = s_ovf != 0;
-      if (!ovf) {
-        // Survivors are few (a twelfth of the slots on 30x data): gather them into a dense list first so
-        // that w = T * key (7 LDS table reads) and the scattered store run on full waves, not on the
-        // odd lane of every wave that scans the table.
-        // last: the barrier after the round covers the reset of the counters
-        auto flush = [&](bool last) {
-          __syncthreads();
-          const uint32_t nl = s_ns;
-          for (uint32_t i = threadIdx.x; i < nl; i += BLK) {
-            uint64_t w = gf2_mul(g_lut, s_lk[i], ntab);  // 14 KB table, L1-resident; only survivors get here
-            const uint64_t pos = w >> sel_bits;
-            if (pos >= pos_lo && pos < pos_hi) atomicAdd(&s_pc[(uint32_t)(w >> shift1)], 1u);
-            else w = RFX_EMPTY;
-            s_lk[i] = w;
-          }
-          __syncthreads();
-          if (threadIdx.x < P1_BINS) {
-            const uint32_t cn = s_pc[threadIdx.x];
-            // (128 cursors shared by every workgroup look like a hot spot; they are not: with the reservation faked --
-            // -DRFX_TIMING experiment, results void -- the flush lost 14 % of its cycles, the kernel 3.5 %)
-            const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
-            if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
-              atomicExch(flag, 1u);
-              s_pbase[threadIdx.x] = ~0ull;
-            } else {
-              s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at;
-            }
-            s_pc[threadIdx.x] = 0;
-          }
-          __syncthreads();
-          for (uint32_t i = threadIdx.x; i < nl; i += BLK) {
-            const uint64_t w = s_lk[i];
-            if (w == RFX_EMPTY) continue;
-            const uint32_t cb = (uint32_t)(w >> shift1);
-            const uint32_t o = atomicAdd(&s_pc[cb], 1u);
-            if (s_pbase[cb] != ~0ull) {
-              out_w[s_pbase[cb] + o] = w;
-              out_c[s_pbase[cb] + o] = s_lc[i];
-            }
-          }
-          __syncthreads();
-          if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
-          if (threadIdx.x == 0) s_ns = 0;
-          if (!last) __syncthreads();
-        };
-        // A bin takes ~17 barriers, and what the kernel does most is wait at them (-DRFX_TIMING, SQ counters: issue is a
-        // third of the time).  When the table holds no more keys than the list has room for -- the usual case -- the scan
-        // needs none: every survivor fits.
-        const bool fits = s_nd <= (uint32_t)LIST;
-        for (int base = 0; base < TBL; base += 2 * BLK) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int i = base + h * BLK + threadIdx.x;
-            const uint64_t key = s_keys[i];
-            const uint32_t c = s_cnt[i];
-            if (key != RFX_EMPTY && c >= lower && c <= upper) {
-              const uint32_t o = atomicAdd(&s_ns, 1u);
-              s_lk[o] = key;
-              s_lc[o] = c;
-            }
-          }
-          if (!fits) {
-            __syncthreads();
-            if (s_ns > LIST - 2 * BLK) flush(false);  // the next two rounds might not fit
+      if (nk_all > (uint32_t)KMAP) {  // (rare) records that found no room in the map
+        for (int i = threadIdx.x; i < RC; i += BLK) {
+          const uint32_t c = s_rc[i];
+          if (c & MSP_RC_UNLISTED) {
+            const uint32_t xe = s_rmax[i];
+            if (s_rmin[i] != xe) s_mixed[X] = 1;
+            insert_record(s_rk[i] ^ ((uint64_t)xe * MSP_RK_MUL), xe, c & ~MSP_RC_UNLISTED);
           }
         }
-        TM(12);
-        flush(true);
-        TM(13);
       }
       __syncthreads();
-      if (ovf) {  // split this sub-range
+      TM(11);
+      const bool mixed = s_mixed[X] != 0;     // (the pass is void: once more, without the cache)
+      const bool ovf = s_ovf[X] != 0 || mixed;  // from here on: "nothing of this pass leaves"
+      const bool split = s_ovf[X] != 0 && !mixed;
+      TMC(20, split);
+      TMC(24, mixed);
+      TMC(21, 1);
+      // ---- C: survivors out, everything cleared ----
+      for (int i = threadIdx.x; i < TBL; i += BLK) {
+        const uint64_t key = s_keys[i];
+        if (key == RFX_EMPTY) continue;
+        const uint32_t c = s_cnt[i];
+        s_keys[i] = RFX_EMPTY;
+        s_cnt[i] = 0;
+        if (!ovf && c >= lower && c <= upper) {
+          const uint32_t o = used + atomicAdd(&s_ns[X], 1u);
+          stk[o] = key;
+          stc[o] = c;
+        }
+      }
+      for (int i = threadIdx.x; i < RC; i += BLK) {
+        s_rk[i] = MSP_EMPTY;
+        s_rc[i] = 0;
+        s_rmin[i] = ~0u;
+        s_rmax[i] = 0;
+      }
+      __syncthreads();
+      TM(12);
+      used += s_ns[X];
+      X ^= 1u;
+      if (used > CH - (uint32_t)FILL) {  // the chunk could not take a full table any more
+        flush();
+        TM(13);
+      }
+      if (mixed) {  // the same sub-range again
+        nocache = true;
+        continue;
+      }
+      if (split) {  // split this sub-range
         if (r >= LEAF_RMAX) {
           failed = true;
           break;
@@ -735,8 +794,8 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
       }
     }
     if (failed && threadIdx.x == 0) atomicExch(err, 1u);
-    __syncthreads();
   }
+  if (used) flush();
 }
 
 // Fine bin sizes of the entries in fixed-capacity coarse bins: fine_tot[cb * P2 + sub] += ...  (64-bit
@@ -882,61 +941,62 @@ namespace rfxk {
 int msp_k_ok(int k) { return k >= 23 && k <= 31; }
 int msp_part1_block() { return MP1_BLOCK; }  // m = k-10 in 13..15 (an m-mer fits 32 bits); k+3 bases fit 56 bits
 
-int msp_wide(int k) { return k > 25; }
+int msp_nmax_of(int k) { return msp_nmax(k); }
+int msp_wide(int) { return 1; }  // (round 4) every record is a 64-bit word + a 32-bit plane
 
 void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
                int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
                unsigned int* flag, uint32_t* ext_a, int slab_log2) {
   rfx_span sp(c, hmode == 1 ? "k_msp_count" : "k_msp_part1");
-#define RFX_MSP_P1(CANON, HM, WL, WIDE)                                                                             \
-  hipLaunchKernelGGL((k_msp_part1<CANON, HM, WL, WIDE>), dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, k, bin_bits, \
+#define RFX_MSP_P1(CANON, HM, WL)                                                                             \
+  hipLaunchKernelGGL((k_msp_part1<CANON, HM, WL>), dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, k, bin_bits, \
                      bin_lo, bin_hi, buf_a, ext_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2)
-#define RFX_MSP_P1_HM(CANON, WL, WIDE)          \
+#define RFX_MSP_P1_HM(CANON, WL)          \
   do {                                          \
-    if (hmode == 0) RFX_MSP_P1(CANON, 0, WL, WIDE);      \
-    else if (hmode == 1) RFX_MSP_P1(CANON, 1, WL, WIDE); \
-    else if (hmode == 3) RFX_MSP_P1(CANON, 3, WL, WIDE); \
-    else RFX_MSP_P1(CANON, 2, WL, WIDE);                 \
+    if (hmode == 0) RFX_MSP_P1(CANON, 0, WL);      \
+    else if (hmode == 1) RFX_MSP_P1(CANON, 1, WL); \
+    else if (hmode == 3) RFX_MSP_P1(CANON, 3, WL); \
+    else RFX_MSP_P1(CANON, 2, WL);                 \
   } while (0)
-  if (!msp_wide(k)) {
-    if (canonical) RFX_MSP_P1_HM(true, MSP_WL, false);
-    else RFX_MSP_P1_HM(false, MSP_WL, false);
+  if (msp_wl(k) == MSP_WL) {
+    if (canonical) RFX_MSP_P1_HM(true, MSP_WL);
+    else RFX_MSP_P1_HM(false, MSP_WL);
   } else {
-    if (canonical) RFX_MSP_P1_HM(true, MSP_WL_WIDE, true);
-    else RFX_MSP_P1_HM(false, MSP_WL_WIDE, true);
+    if (canonical) RFX_MSP_P1_HM(true, MSP_WL_WIDE);
+    else RFX_MSP_P1_HM(false, MSP_WL_WIDE);
   }
 #undef RFX_MSP_P1_HM
 #undef RFX_MSP_P1
+}
+
+// Grid and staging chunk of a leaf launch over P bins holding ~n_records records: a workgroup per ~4096 records at least
+// (a small input does not pay for 2048 staging chunks), the full chunk only where it is amortised over many bins.
+void msp_leaf_plan(rfx_ctx* c, uint32_t P, int geo, uint64_t n_records, uint32_t* grid, uint32_t* chunk) {
+  const uint32_t per_cu = geo ? 8 : 4;  // (1..8 per CU measured: no difference)
+  uint64_t g = std::min<uint64_t>(P, (uint64_t)c->n_cu * per_cu);
+  g = std::min<uint64_t>(g, std::max<uint64_t>(1, n_records >> 12));
+  *grid = (uint32_t)std::max<uint64_t>(g, 1);
+  const uint32_t fill = (geo ? 4096u : 8192u) * 3 / 4;
+  *chunk = n_records >= (1ull << 24) ? MSP_LEAF_STAGE(geo) : fill + 1024u;
 }
 
 void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err,
-              int geo, const uint32_t* const* seg_ext, const uint32_t* ext0) {
+              int geo, const uint32_t* const* seg_ext, const uint32_t* ext0, uint64_t* stage_k, uint32_t* stage_c,
+              uint32_t grid, uint32_t chunk) {
   rfx_span sp(c, "k_msp_leaf");
-  const bool wide = msp_wide(k);
-
-  const uint32_t per_cu = geo ? 8 : 4;  // (1..8 per CU measured: no difference)
-  const uint32_t grid = P < (uint32_t)c->n_cu * per_cu ? P : (uint32_t)c->n_cu * per_cu;
-#define RFX_MSP_LEAF(CANON, GEO, WIDE)                                                                                 \
-  hipLaunchKernelGGL((k_msp_leaf<CANON, GEO, WIDE>), dim3(grid), dim3(GEO ? 512 : 1024), 0, c->stream, seg_inst, seg_bs,  \
-                     nseg, inst0, bs0, seg_ext, ext0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, \
-                     out_w, out_c, cur, cap, flag, err)
-  if (wide) {
-    if (canonical) {
-      if (geo) RFX_MSP_LEAF(true, 1, true);
-      else RFX_MSP_LEAF(true, 0, true);
-    } else {
-      if (geo) RFX_MSP_LEAF(false, 1, true);
-      else RFX_MSP_LEAF(false, 0, true);
-    }
-  } else if (canonical) {
-    if (geo) RFX_MSP_LEAF(true, 1, false);
-    else RFX_MSP_LEAF(true, 0, false);
+#define RFX_MSP_LEAF(CANON, GEO)                                                                                        \
+  hipLaunchKernelGGL((k_msp_leaf<CANON, GEO>), dim3(grid), dim3(GEO ? 512 : 1024), 0, c->stream, seg_inst, seg_bs, nseg, \
+                     inst0, bs0, seg_ext, ext0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w,  \
+                     out_c, cur, cap, flag, err, stage_k, stage_c, chunk)
+  if (canonical) {
+    if (geo) RFX_MSP_LEAF(true, 1);
+    else RFX_MSP_LEAF(true, 0);
   } else {
-    if (geo) RFX_MSP_LEAF(false, 1, false);
-    else RFX_MSP_LEAF(false, 0, false);
+    if (geo) RFX_MSP_LEAF(false, 1);
+    else RFX_MSP_LEAF(false, 0);
   }
 #undef RFX_MSP_LEAF
 }

@@ -138,12 +138,12 @@ class HipBackend:
 
     # -- minimizer-shard path ----------------------------------------------------------------------
     def msp_capable(self) -> bool:
-        return 23 <= self.k <= 25     # record export / import between ranks: one 64-bit word per record
+        return 23 <= self.k <= 31     # record export / import between ranks: a 64-bit word + a 32-bit plane per record
 
     def partition(self, block):
-        """(records int64[n], bin_start int64[bins+1], keep): the block's super-k-mer records grouped by
-        minimizer bin, as zero-copy views of the library's device memory; `keep` owns that memory --
-        call keep.free() once the tensors are no longer needed (after the exchange)."""
+        """(records int64[n], bin_start int64[bins+1], keep, planes int32[n]): the block's super-k-mer records (64-bit
+        word + 32-bit plane each) grouped by minimizer bin, as zero-copy views of the library's device memory; `keep`
+        owns that memory -- call keep.free() once the tensors are no longer needed (after the exchange)."""
         t = capi.CountTable(self.ctx, self.k, self.size, True, self.capacity, mode=capi.COUNT_MSP)
         try:
             t.add(block)
@@ -154,19 +154,23 @@ class HipBackend:
         if not segs:                         # no k-mer at all
             t.free()
             return (torch.empty(0, dtype=torch.int64, device=self.device),
-                    torch.zeros(257, dtype=torch.int64, device=self.device), None)
+                    torch.zeros(257, dtype=torch.int64, device=self.device), None,
+                    torch.empty(0, dtype=torch.int32, device=self.device))
         d_rec, d_bs, bins, n = segs[0]       # segments() has synchronised: the arrays are complete
+        d_ext = t.segment_ext(0)
         rec = _device_view(d_rec, n, self.device) if n else torch.empty(0, dtype=torch.int64, device=self.device)
-        return rec, _device_view(d_bs, bins + 1, self.device), t
+        ext = (_device_view32(d_ext, n, self.device) if n and d_ext
+               else torch.empty(0, dtype=torch.int32, device=self.device))
+        return rec, _device_view(d_bs, bins + 1, self.device), t, ext
 
     def count_records(self, runs, lower: int):
-        """runs: [(records, bin_start)] received from every rank for this owner's bins -> (records of
+        """runs: [(records, bin_start, planes)] received from every rank for this owner's bins -> (records of
         the shard in (pos,key) order, histogram)."""
         t = capi.CountTable(self.ctx, self.k, self.size, True, self.capacity, mode=capi.COUNT_MSP)
         try:
             torch.cuda.synchronize(self.device)
-            for rec, bs in runs:
-                t.add_records_dev(rec.data_ptr(), rec.numel(), bs.data_ptr(), bs.numel() - 1)
+            for rec, bs, ext in runs:
+                t.add_records_dev(rec.data_ptr(), rec.numel(), bs.data_ptr(), bs.numel() - 1, ext.data_ptr() if rec.numel() else 0)
             self.ctx.sync()                      # the copies are done: the tensors may go
             return t.finish(lower, want_histo=True)
         finally:
@@ -221,6 +225,15 @@ class _DevMem:
 
 def _device_view(ptr: int, n: int, device) -> torch.Tensor:
     return torch.as_tensor(_DevMem(ptr, n), device=device)
+
+
+class _DevMem32:
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def _device_view32(ptr: int, n: int, device) -> torch.Tensor:
+    return torch.as_tensor(_DevMem32(ptr, n), device=device)
 
 
 def bin_owner_bounds(bins: int, world: int):
@@ -294,10 +307,9 @@ def exchange_partials(keys: torch.Tensor, counts: torch.Tensor, pos: torch.Tenso
     return rk.to(dev), rc.to(dev)
 
 
-def exchange_records_begin(records: torch.Tensor, bin_start: torch.Tensor, group):
-    """Deal the bins to their owners: the (small) size and offset exchanges happen here, the record
-    all-to-all is only STARTED (async) -- the caller can partition the next sample meanwhile.  Finish
-    with exchange_records_end()."""
+def exchange_records_begin(records: torch.Tensor, bin_start: torch.Tensor, group, planes: torch.Tensor | None = None):
+    """Deal the bins to their owners: the (small) size and offset exchanges happen here, then the records travel
+    (and, in a second exchange of the same shape, their 32-bit planes if given).  Finish with exchange_records_end()."""
     world, me = dist.get_world_size(group), dist.get_rank(group)
     dev = records.device
     bins = bin_start.numel() - 1
@@ -322,13 +334,18 @@ def exchange_records_begin(records: torch.Tensor, bin_start: torch.Tensor, group
     wr = _wire(records[:int(cuts[-1])], group)
     rr = torch.empty(sum(recv_l), dtype=records.dtype, device=wr.device)
     exchange_rows(rr, wr, recv_l, send_l, group)       # (in pieces, see exchange_rows: no longer asynchronous)
+    re_ = None
+    if planes is not None:
+        we = _wire(planes[:int(cuts[-1])], group)
+        re_ = torch.empty(sum(recv_l), dtype=planes.dtype, device=we.device)
+        exchange_rows(re_, we, recv_l, send_l, group)
     return {"work": None, "rr": rr, "wr": wr, "rb": rb, "recv_l": recv_l, "len_rl": len_rl, "world": world, "me": me,
-            "dev": dev}
+            "dev": dev, "re": re_}
 
 
 def exchange_records_end(st):
-    """Wait for the record all-to-all.  Returns [(records_from_rank, bin_start_full)] for this rank's bins,
-    one entry per source rank; bin_start_full has the sender's bin count + 1 entries (empty outside the
+    """Wait for the record all-to-all.  Returns [(records_from_rank, bin_start_full[, planes_from_rank])] for this
+    rank's bins, one entry per source rank; bin_start_full has the sender's bin count + 1 entries (empty outside the
     owned range) so that the run can be imported as it is."""
     if st["work"] is not None:
         st["work"].wait()
@@ -346,14 +363,17 @@ def exchange_records_end(st):
         full = torch.zeros(sbins + 1, dtype=torch.int64)
         full[lo:lo + nb + 1] = loc
         full[lo + nb + 1:] = loc[-1]
-        runs.append((rr[ro:ro + recv_l[src]].to(dev), full.to(dev)))
+        run = (rr[ro:ro + recv_l[src]].to(dev), full.to(dev))
+        if st.get("re") is not None:
+            run += (st["re"][ro:ro + recv_l[src]].to(dev),)
+        runs.append(run)
         ro += recv_l[src]
         bo += len_rl[src]
     return runs
 
 
-def exchange_records(records: torch.Tensor, bin_start: torch.Tensor, group):
-    return exchange_records_end(exchange_records_begin(records, bin_start, group))
+def exchange_records(records: torch.Tensor, bin_start: torch.Tensor, group, planes: torch.Tensor | None = None):
+    return exchange_records_end(exchange_records_begin(records, bin_start, group, planes))
 
 
 def merge_shards(shards):
@@ -406,7 +426,7 @@ class TrioShard:
         if self.shard_by == "minimizer":
             part = self.be.partition(block)
             records, bin_start = part[0], part[1]
-            runs = exchange_records(records, bin_start, self.group)
+            runs = exchange_records(records, bin_start, self.group, part[3] if len(part) > 3 else None)
             if len(part) > 2 and part[2] is not None:
                 part[2].free()
             rec, histo = self.be.count_records(runs, self.lower)
@@ -455,7 +475,7 @@ class TrioShard:
             for blk in blocks:
                 part = self.be.partition(blk)          # (records, bin_start[, owner of their memory])
                 keep = part[2] if len(part) > 2 else None
-                started.append((exchange_records_begin(part[0], part[1], self.group), keep))
+                started.append((exchange_records_begin(part[0], part[1], self.group, part[3] if len(part) > 3 else None), keep))
             local = []
             for st, keep in started:
                 runs = exchange_records_end(st)

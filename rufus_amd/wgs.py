@@ -96,10 +96,9 @@ def plan_passes(n_reads_total: int, read_len: int, k: int, resident_bytes: int, 
     distinct = windows / max(coverage_hint * (read_len - k + 1) / read_len, 1.0)
     for s in range(1, 257 // world):
         share = s * world
-        # bytes of records per k-mer instance: 8 B per ~3 k-mers; wide (k >= 26) records are 12 B but hold more k-mers
-        # (measured on the full-size tumor/normal pair, 1 GPU: peak 255 / 272 / 297 GB at 7 / 6 / 5 passes = 5.0 B per
-        # instance all in, the same as k = 25 -- 4.1 here made the plan take 7 where 6 fit)
-        records = (3.2 if wide else 2.7) * windows / share * (2.0 if world > 1 else 1.0)
+        # bytes of records per k-mer instance: a record (12 B) is a whole super-k-mer -- 5.7 k-mers for k <= 25
+        # (window of 11 m-mers), 8 for k = 26 .. 31 (window of 16); until round 3: 8 B per ~3 k-mers
+        records = (1.6 if wide else 2.2) * windows / share * (2.0 if world > 1 else 1.0)
         # leaf phase of the last sample of a pass: records + scratch, survivor store, the other samples' records
         # (the controls are struck off the subject's candidates one at a time: one set of 20-byte records stays)
         transient = records * 1.125 + 12.0 * distinct / share * 1.3 + (20.0 if n_samples > 1 else 0.0) * distinct / share
@@ -238,7 +237,7 @@ class WgsTrio:
         try:
             own.set_shard(shard * W + me, Q)
             keep = []
-            wide = self.k > 25      # records = 64-bit word + 32-bit plane: the plane travels in a second all-to-all
+            wide = True             # records = 64-bit word + 32-bit plane: the plane travels in a second all-to-all
             seg_done = 0
             for i in range(rounds):
                 ext = None

@@ -33,7 +33,7 @@ from rufus_amd.dist import bin_owner_bounds
 for world in (2, 8):
     for it in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        rec, bs, keep = be.partition(blk)
+        rec, bs, keep, ext = be.partition(blk)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         bins = bs.numel() - 1
         b = bin_owner_bounds(bins, world)
@@ -42,7 +42,7 @@ for world in (2, 8):
         full = torch.zeros(bins + 1, dtype=torch.int64)
         full[b[0]:b[1] + 1] = bsh[b[0]:b[1] + 1] - bsh[b[0]]
         full[b[1] + 1:] = hi - lo
-        runs = [(rec[lo:hi].clone(), full.to(rec.device)) for _ in range(world)]
+        runs = [(rec[lo:hi].clone(), full.to(rec.device), ext[lo:hi].clone()) for _ in range(world)]
         keep.free()
         torch.cuda.synchronize(); t2 = time.perf_counter()
         out, histo = be.count_records(runs, bench.LOWER)

@@ -29,4 +29,4 @@ for name, d in (("k_msp_part1", p1), ("k_msp_leaf", lf)):
     print(name)
     for k_, x in d.items():
         print(f"   {k_:32s} {x:16d}  {100.0 * x / tot:5.1f} %")
-print("leaf rounds", v[21], "overflowed", v[20])
+print("leaf rounds", v[21], "overflowed", v[20], "records", v[22], "uncached", v[23], "mixed", v[24])

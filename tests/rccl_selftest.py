@@ -20,8 +20,8 @@ trio = make_trio(genome_len=40_000, n_pairs=3000, n_snv=5, seed=8)
 seq, qual, off = flat_reads(trio["child"])
 blk = ctx.upload(capi.PackedReads(seq, off, qual, 15, capi.PACK_COUNT | capi.PACK_FILTER))
 be = rdist.HipBackend(ctx, 25, 8 << 30)
-rec, bs, keep = be.partition(blk)
-runs = rdist.exchange_records(rec, bs, dist.group.WORLD)
+rec, bs, keep, ext = be.partition(blk)
+runs = rdist.exchange_records(rec, bs, dist.group.WORLD, ext)
 keep.free()
 out, histo = be.count_records(runs, 2)
 reads = [x.tobytes() for m in (0, 1) for x in trio["child"].s[m]]

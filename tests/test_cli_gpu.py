@@ -381,6 +381,23 @@ def test_query_looks_a_kmer_list_up_in_several_databases_at_once(testrun, tmp_pa
             key = min(oracle.jf_encode(c[0]), oracle.jf_encode(c[0].translate(str.maketrans("ACGT", "TGCA"))[::-1]))
             assert int(c[1 + j]) == table.get(key, 0)
     assert sum(int(c[1]) > 0 for c in cols) > 200
+    # A database that is PIPED (loaded whole, never sliced) and has another table size, between two regular ones of one
+    # size: the third must not be looked up with positions computed for a hash function it does not have (ADVICE r3:
+    # the recompute test compared with the database before, which had never touched the positions).
+    r = sh([f"{BIN}/jellyfish", "count", "-m", "25", "-L", "2", "-s", "1M", "-t", "4", "-o", "Mother.small.Jhash", "-C", "Mother.fq"], d)
+    assert r.returncode == 0, r.stderr
+    os.mkfifo(f"{d}/pipe.Jhash")
+    feeder = subprocess.Popen(["sh", "-c", "cat Mother.small.Jhash > pipe.Jhash"], cwd=d)
+    r = subprocess.run([f"{BIN}/jellyfish", "query", "-s", "q.fa", "-o", "p1", "-o", "p2", "-o", "p3", "Child.Jhash", "pipe.Jhash",
+                        "Father.Jhash"], cwd=d, env=dict(os.environ, RFX_QUERY_SLICE_RECORDS="777"), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE)
+    assert feeder.wait() == 0 and r.returncode == 0, r.stderr
+    assert open(f"{d}/p1", "rb").read() == single["Child"] and open(f"{d}/p3", "rb").read() == single["Father"]
+    assert open(f"{d}/p2", "rb").read() == single["Mother"]     # (counts do not depend on the table size)
+    # an argument spelt like a mer stays a mer, even if a file of that name exists
+    open(f"{d}/{'A' * 25}", "w").write("x")
+    r = sh([f"{BIN}/jellyfish", "query", "Child.Jhash", "A" * 25], d)
+    assert r.returncode == 0 and r.stdout.decode().split()[0] == "A" * 25, r.stderr
 
 
 def test_subject_stream_is_ingested_once_through_a_spool(tmp_path):

@@ -547,13 +547,15 @@ def test_msp_record_segments_export_and_import(ctx, small_trio, monkeypatch):
         (d_rec, d_bs, nb, nrec), = t.segments()
         assert nb == int(bins) and nrec > 0
         rec = torch.empty(nrec, dtype=torch.int64, device="cuda")
+        ext = torch.empty(nrec, dtype=torch.int32, device="cuda")      # a record = 64-bit word + 32-bit plane
         bs = torch.empty(nb + 1, dtype=torch.int64, device="cuda")
         torch.cuda.synchronize()
         ctx.memcpy_dev(rec.data_ptr(), d_rec, nrec * 8)
+        ctx.memcpy_dev(ext.data_ptr(), t.segment_ext(0), nrec * 4)
         ctx.memcpy_dev(bs.data_ptr(), d_bs, (nb + 1) * 8)
         ctx.sync()
         assert int(bs[-1]) == nrec and bool((bs[1:] >= bs[:-1]).all())
-        exported.append((rec, bs.cpu()))
+        exported.append((rec, bs.cpu(), ext))
         blk.free()
         t.free()
     monkeypatch.delenv("RFX_P2L_BINS")
@@ -561,16 +563,16 @@ def test_msp_record_segments_export_and_import(ctx, small_trio, monkeypatch):
     got = []
     for owner in range(2):
         t = capi.CountTable(ctx, k, size, mode=capi.COUNT_MSP)
-        for rec, bs in exported:
+        for rec, bs, ext in exported:
             nb = len(bs) - 1
             b = rdist.bin_owner_bounds(nb, 2)
             lo, hi = int(bs[b[owner]]), int(bs[b[owner + 1]])
             full = torch.zeros(nb + 1, dtype=torch.int64)
             full[b[owner]:b[owner + 1] + 1] = bs[b[owner]:b[owner + 1] + 1] - lo
             full[b[owner + 1] + 1:] = hi - lo
-            run, full = rec[lo:hi].clone(), full.cuda()
+            run, runx, full = rec[lo:hi].clone(), ext[lo:hi].clone(), full.cuda()
             torch.cuda.synchronize()
-            t.add_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), nb)
+            t.add_records_dev(run.data_ptr(), run.numel(), full.data_ptr(), nb, runx.data_ptr())
             ctx.sync()
         out = t.finish(1)
         got.append(out.get())
@@ -579,10 +581,15 @@ def test_msp_record_segments_export_and_import(ctx, small_trio, monkeypatch):
     assert len(got[0][0]) and len(got[1][0]) and not set(got[0][0].tolist()) & set(got[1][0].tolist())
     keys, counts, pos = rdist.merge_shards([(g[0], g[1].astype(np.uint64), g[2]) for g in got])
     assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts) and np.array_equal(pos, ref.pos)
-    # a table that is not on the MSP path refuses records
-    t = capi.CountTable(ctx, 31, size)
+    # records come with their planes
+    t = capi.CountTable(ctx, k, size, mode=capi.COUNT_MSP)
     with pytest.raises(capi.RufusError):
         t.add_records_dev(exported[0][0].data_ptr(), 1, exported[0][1].cuda().data_ptr(), 256)
+    t.free()
+    # a table that is not on the MSP path refuses records
+    t = capi.CountTable(ctx, 31, size, mode=capi.COUNT_P2L)
+    with pytest.raises(capi.RufusError):
+        t.add_records_dev(exported[0][0].data_ptr(), 1, exported[0][1].cuda().data_ptr(), 256, exported[0][2].data_ptr())
     t.free()
 
 

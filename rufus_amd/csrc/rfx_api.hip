@@ -1184,28 +1184,25 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
   if (cap_a >= (1ull << 32)) return fail(RFX_E_RANGE);
   // only the shard's coarse bins exist: the kernels index coarse bins absolutely, so they get the
   // address coarse bin 0 would have
-  buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
+  // (the coarse bins hold word and plane side by side, 12 bytes a slot: rfx_devutil.h msp_rec12)
+  buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 12);
   inst = (uint64_t*)dmalloc(c, cap_b * 8);
-  const bool wide = rfxk::msp_wide(t->k);
-  uint32_t* ext_a = wide ? (uint32_t*)dmalloc(c, cap_a * g.c_n * 4) : nullptr;
-  uint32_t* ext = wide ? (uint32_t*)dmalloc(c, cap_b * 4) : nullptr;
-  if (!buf_a || !inst || (wide && (!ext_a || !ext))) { dfree(c, ext_a); dfree(c, ext); return fail(RFX_E_NOMEM); }
-  uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;
-  uint32_t* ext_a0 = wide ? ext_a - (size_t)g.c_lo * cap_a : nullptr;
+  uint32_t* ext = (uint32_t*)dmalloc(c, cap_b * 4);
+  if (!buf_a || !inst || !ext) { dfree(c, ext); return fail(RFX_E_NOMEM); }
+  char* rec_a0 = (char*)buf_a - (size_t)g.c_lo * cap_a * 12;
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1) * 4, c->stream));
   HIPCHK(hipMemsetAsync(fine_cur, 0, (size_t)P * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr, cur + g.ncur, ext_a0);
-  rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, ext_a0, ext, cap_b,
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, rec_a0, cur, (uint32_t)cap_a, nullptr, cur + g.ncur);
+  rfxk::part2(c, (const uint64_t*)rec_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, ext, cap_b,
               "k_part2", nullptr, 0, cap_b, g.rec_mode, t->k);
   unsigned int flag = 1;
-  if (queue_read(c, &flag, cur + g.ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) { dfree(c, ext_a); dfree(c, ext); return fail(RFX_E_HIP); }
+  if (queue_read(c, &flag, cur + g.ncur, 4) != hipSuccess || ctx_sync(c) != hipSuccess) { dfree(c, ext); return fail(RFX_E_HIP); }
   if (flag) {
     snprintf(g_err, sizeof g_err, "MSP: exact partition overflowed (internal error)");
-    dfree(c, ext_a); dfree(c, ext);
+    dfree(c, ext);
     return fail(RFX_E_HIP);
   }
   drop();
-  dfree(c, ext_a);
   *seg = rfx_segment{inst, total, bin_start, g.windows, P, ext};
   return RFX_OK;
 }
@@ -1255,12 +1252,10 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
     // records, then wait for the record count and the capacity flag and give the segment exactly the memory
     // it needs (at WGS scale the 30 % slack of an estimate is tens of GB) -- and nothing stays pending.
     for (int attempt = 0;; ++attempt) {
-      uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
-      uint32_t* ext_a = wide ? (uint32_t*)dmalloc(c, cap_a * g.c_n * 4) : nullptr;
-      if (!buf_a || (wide && !ext_a)) { dfree(c, buf_a); dfree(c, ext_a); dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
-      uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;  // the address coarse bin 0 would have
-      uint32_t* ext_a0 = wide ? ext_a - (size_t)g.c_lo * cap_a : nullptr;
-      auto fail = [&](int rc) { dfree(c, buf_a); dfree(c, ext_a); dfree(c, cur); dfree(c, bin_start); return rc; };
+      char* buf_a = (char*)dmalloc(c, cap_a * g.c_n * 12);  // 12-byte slots: word and plane side by side
+      if (!buf_a) { dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
+      char* buf_a0 = buf_a - (size_t)g.c_lo * cap_a * 12;  // the address coarse bin 0 would have
+      auto fail = [&](int rc) { dfree(c, buf_a); dfree(c, cur); dfree(c, bin_start); return rc; };
       hipError_t e = hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream);
       if (e == hipSuccess) e = hipMemsetAsync(bin_start, 0, ((size_t)P + 1) * 8, c->stream);
       if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
@@ -1269,12 +1264,12 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
       uint32_t* cnt = getenv("RFX_MSP_REC_HIST") ? nullptr : (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
       if (cnt) {
         rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 3, g.G, buf_a0, cur, (uint32_t)cap_a, cnt,
-                        cur + g.ncur, ext_a0, slab_log2);
+                        cur + g.ncur, slab_log2);
         rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
       } else {
         rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr,
-                        cur + g.ncur, ext_a0);
-        rfxk::surv_hist(c, buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
+                        cur + g.ncur);
+        rfxk::surv_hist(c, (const uint64_t*)buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
         rfxk::scan_tail(c, bin_start, P);
       }
       uint64_t total = 0;
@@ -1290,14 +1285,13 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
         if (need <= cap_a && cnt) {  // ... or only a 16-bit counter of the fused histogram wrapped: count the records
           e = hipMemsetAsync(bin_start, 0, ((size_t)P + 1) * 8, c->stream);
           if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
-          rfxk::surv_hist(c, buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
+          rfxk::surv_hist(c, (const uint64_t*)buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
           rfxk::scan_tail(c, bin_start, P);
           e = queue_read(c, &total, bin_start + P, 8);
           if (e == hipSuccess) e = ctx_sync(c);
           if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
         } else {
           dfree(c, buf_a);
-          dfree(c, ext_a);
           if (attempt >= 3 || need >= (1ull << 32) - 65536) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
           cap_a = need + need / 64 + 1024;
           continue;
@@ -1306,10 +1300,9 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
       uint64_t* inst = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
       uint32_t* ext = wide ? (uint32_t*)dmalloc(c, (total ? total : 1) * 4) : nullptr;
       if (!inst || (wide && !ext)) { dfree(c, inst); dfree(c, ext); return fail(RFX_E_NOMEM); }
-      rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, ext_a0, ext, total,
+      rfxk::part2(c, (const uint64_t*)buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, ext, total,
                   "k_part2", nullptr, 0, total, g.rec_mode, t->k);
       dfree(c, buf_a);
-      dfree(c, ext_a);
       dfree(c, cur);
       // (k-mer instances behind the records: the shard's share of the windows -- sizes the survivor arrays)
       t->segs->push_back(rfx_segment{inst, total, bin_start, std::min<uint64_t>((uint64_t)((double)g.windows * share) + 1, total * (uint64_t)rfxk::msp_nmax_of(t->k)), P, ext});
@@ -1318,22 +1311,20 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
     }
   }
   uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
-  uint64_t* buf_a = (uint64_t*)dmalloc(c, cap_a * g.c_n * 8);
+  char* buf_a = (char*)dmalloc(c, cap_a * g.c_n * 12);  // 12-byte slots: word and plane side by side
   uint64_t* inst = (uint64_t*)dmalloc(c, cap_b * 8);
-  uint32_t* ext_a = wide ? (uint32_t*)dmalloc(c, cap_a * g.c_n * 4) : nullptr;
-  uint32_t* ext = wide ? (uint32_t*)dmalloc(c, cap_b * 4) : nullptr;
-  auto drop = [&] { dfree(c, cnt); dfree(c, buf_a); dfree(c, ext_a); };
-  if (!cnt || !buf_a || !inst || (wide && (!ext_a || !ext))) {
+  uint32_t* ext = (uint32_t*)dmalloc(c, cap_b * 4);
+  auto drop = [&] { dfree(c, cnt); dfree(c, buf_a); };
+  if (!cnt || !buf_a || !inst || !ext) {
     drop(); dfree(c, cur); dfree(c, bin_start); dfree(c, inst); dfree(c, ext);
     return RFX_E_NOMEM;
   }
-  uint64_t* buf_a0 = buf_a - (size_t)g.c_lo * cap_a;  // the address coarse bin 0 would have (see msp_partition_exact)
-  uint32_t* ext_a0 = wide ? ext_a - (size_t)g.c_lo * cap_a : nullptr;
+  char* buf_a0 = buf_a - (size_t)g.c_lo * cap_a * 12;  // the address coarse bin 0 would have (see msp_partition_exact)
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur, ext_a0,
+  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur,
                   slab_log2);
   rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
-  rfxk::part2(c, buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, ext_a0, ext, cap_b,
+  rfxk::part2(c, (const uint64_t*)buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, ext, cap_b,
               "k_part2", nullptr, 0, cap_b, g.rec_mode, t->k);
   rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
   drop();

@@ -83,6 +83,20 @@ __device__ __forceinline__ uint64_t revcomp_bases(uint64_t s, int nbases) {
 // Until round 3 a record held <= 4 k-mers (8 bytes for k <= 25: 42 records per 150 bp read, 336 B; now 22, 264 B).
 __device__ __forceinline__ int msp_record_n(uint64_t x) { return (int)(x >> 60) + 1; }
 
+// The COARSE bins k_msp_part1 fills hold word and plane side by side, 12 bytes: one store per record.  The kernel is
+// bound by how many lane-stores the memory pipeline takes (every record goes to another line: 2.5 cycles per lane-store
+// and CU, measured) -- with two arrays the stores were 38 % of it.  k_part2 reads them back as 12-byte loads (a wave's
+// 64 records are 768 contiguous bytes) and writes the two arrays every later level works on.
+struct __attribute__((packed, aligned(4))) msp_rec12 {
+  uint32_t lo, hi, x;
+};
+__device__ __forceinline__ void msp_rec12_store(msp_rec12* a, uint64_t i, uint64_t w, uint32_t x) {
+  a[i] = msp_rec12{(uint32_t)w, (uint32_t)(w >> 32), x};
+}
+__device__ __forceinline__ uint64_t msp_rec12_word(const msp_rec12* a, uint64_t i) {  // (the histogram fallback needs no plane)
+  return (uint64_t)a[i].lo | ((uint64_t)a[i].hi << 32);
+}
+
 template <bool CANON>
 __device__ __forceinline__ uint32_t msp_record_binhash(uint64_t x, int k) {
   const int n = msp_record_n(x), m = msp_m(k);
@@ -128,13 +142,10 @@ __device__ __forceinline__ void msp_record_make(uint64_t lo, uint32_t hi, int k,
 __device__ __forceinline__ void msp_record_run(uint64_t x, uint32_t xe, int k, uint64_t& lo, uint64_t& hi) {
   const int n = msp_record_n(x), L = k + n - 1;
   const uint64_t S = x & ((1ull << 56) - 1);
-  lo = S;
-  hi = 0;
-  if (L <= 28) return;
-  if (k <= 28 || !(xe >> 31)) {
-    const int x2 = 2 * (L - 28);
-    lo = (S << x2) | (xe & 0x7FFFFFFFu);
-    hi = S >> (64 - x2);
+  if (k <= 28 || !(xe >> 31)) {  // (no branch on the run's length: the leaf runs this with every lane on another record)
+    const int x2 = 2 * max(L - 28, 0);
+    lo = (S << x2) | (xe & 0x7FFFFFFFu);   // (the plane of a run of <= 28 bases is 0)
+    hi = (S >> 1) >> (63 - x2);
   } else {
     const int s = k - 28, t = L - 28 - s;
     const uint64_t head = (xe >> (2 * t)) & ((1u << (2 * s)) - 1), tail = xe & ((1u << (2 * t)) - 1);

@@ -351,9 +351,11 @@ int msp_k_ok(int k);
 int msp_part1_block();  // threads = reads per chunk of k_msp_part1
 int msp_nmax_of(int k);   // k-mers a record holds at most (rfx_devutil.h msp_nmax)
 int msp_wide(int k);  // 1 (round 4: every record is a 64-bit word + a 32-bit plane, rfx_devutil.h)
+// rec_a: the coarse bins, 12 bytes per slot (word + plane side by side, rfx_devutil.h msp_rec12): what part2 / surv_hist
+// take as `buf_a` when rec_mode != 0 and the coarse bins are fixed-capacity (coarse_cur != null)
 void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
-               int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
-               unsigned int* flag, uint32_t* ext_a = nullptr,
+               int hmode, int grid, void* rec_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
+               unsigned int* flag,
                int slab_log2 = 4 /* hmode 0 / 3: a workgroup fills slabs of 2^slab_log2 records per coarse bin; cap_a
                                     must leave room for msp_part1_slack(grid, slab_log2) unused slots per bin */);
 inline uint64_t msp_part1_slack(int grid, int slab_log2) { return (uint64_t)grid * 3u << slab_log2; }

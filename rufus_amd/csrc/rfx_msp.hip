@@ -59,8 +59,7 @@ constexpr int MP1_BLOCK = 512;
 // WL: m-mers per k-mer (11: k <= 25; 16: k = 26 .. 31).  A record = 64-bit word + 32-bit plane (rfx_devutil.h).
 template <bool CANON, int HMODE, int WL>
 __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int k, int bin_bits, uint32_t bin_lo,
-                                                         uint32_t bin_hi, uint64_t* __restrict__ buf_a,
-                                                         uint32_t* __restrict__ ext_a,
+                                                         uint32_t bin_hi, msp_rec12* __restrict__ rec_a,
                                                          uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
                                                          uint32_t* __restrict__ cnt_rows,
                                                          unsigned int* __restrict__ flag, int slab_log2) {
@@ -101,6 +100,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   const uint32_t mmask = m >= 16 ? ~0u : (1u << (2 * m)) - 1;
   const int rmshift = 2 * (m - 1);
   const int nmax = msp_nmax(k);
+  const bool all_mine = bin_lo == 0 && bin_hi == (1u << bin_bits);
   uint32_t n_emit = 0;  // records this thread stored (or dropped over capacity)
   if (HMODE == 0)
     for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) s_fine[i] = 0;
@@ -152,13 +152,14 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
       const uint32_t slot = atomicAdd(&s_fill[coarse], 1u);
       if (slot < 2 * SLAB) {  // (a bin of ours always has a slab behind it: slab_at)
         const uint64_t sb = s_slab[slot >> slab_log2][coarse];
-        buf_a[sb + (slot & (SLAB - 1))] = w;
-        ext_a[sb + (slot & (SLAB - 1))] = x;
+#ifdef RFX_P1_NOSTORE  // experiment: everything but the record stores (results void)
+        if (w == 0x123456789ull)
+#endif
+          msp_rec12_store(rec_a, sb + (slot & (SLAB - 1)), w, x);
       } else {  // more than two slabs' worth since the bins last moved on: one reservation per record
         const uint32_t at = atomicAdd(&coarse_cur[coarse * P1_CUR_STRIDE], 1u);
         if (at < cap_a) {
-          buf_a[(uint64_t)coarse * cap_a + at] = w;
-          ext_a[(uint64_t)coarse * cap_a + at] = x;
+          msp_rec12_store(rec_a, (uint64_t)coarse * cap_a + at, w, x);
         } else {
           atomicExch(flag, 1u);
         }
@@ -265,13 +266,21 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
             // (bitwise, not short-circuit: one exec mask instead of three nested ones)
             // The run that ended at the previous base closes (`hist` still ends there), and it is ours (shard passes: other
             // bins are not; unsigned: one compare).
-            closes = (run_n != 0) & (!kvalid | (mh != run_h) | (run_n == nmax));
-            run_bin = msp_bin(run_h, bin_bits);
-  #ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
-            mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
-  #else
-            mine = run_bin - bin_lo < bin_hi - bin_lo;
+            // (a run cannot outgrow the window: its minimizer lies in every one of its k-mers -- the cap only matters
+            // where the record format holds fewer k-mers than a window has m-mers, k >= 30)
+            closes = (run_n != 0) & (!kvalid | (mh != run_h) | (nmax < WL && run_n == nmax));
+            mine = true;
+  #ifdef RFX_P1_NOCLOSE
+            mine = bin_lo == 12345u;
   #endif
+            if (SLABS ? !all_mine : true) {  // (one pass, one device: every bin is this table's -- a multiply less per base)
+              run_bin = msp_bin(run_h, bin_bits);
+  #ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
+              mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
+  #else
+              mine = run_bin - bin_lo < bin_hi - bin_lo;
+  #endif
+            }
           }
           if constexpr (SLABS) {
             const bool push = closes & mine;
@@ -375,8 +384,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
         for (int b = 0; b < P1_S; ++b)
           if (brx[b] != ~0u) {
             if (base[b] != ~0ull) {
-              buf_a[base[b] + (brx[b] & 0xFFFFu)] = wvx[b];
-              ext_a[base[b] + (brx[b] & 0xFFFFu)] = xvx[b];
+              msp_rec12_store(rec_a, base[b] + (brx[b] & 0xFFFFu), wvx[b], xvx[b]);
             }
             ++n_emit;
           }
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     for (uint32_t i = threadIdx.x; i < 3u * P1_BINS * SLAB; i += blockDim.x) {
       const uint32_t o = i & (SLAB - 1), bw = i >> slab_log2, b = bw & (P1_BINS - 1), which = bw >> 7;  // P1_BINS = 2^7
       const uint64_t sb = s_slab[which][b];
-      if (sb != ~0ull && (which == 2 || which * SLAB + o >= s_fill[b])) buf_a[sb + o] = MSP_EMPTY;
+      if (sb != ~0ull && (which == 2 || which * SLAB + o >= s_fill[b])) msp_rec12_store(rec_a, sb + o, MSP_EMPTY, 0u);
     }
     __syncthreads();
   }
@@ -452,9 +460,9 @@ constexpr uint32_t MSP_RC_UNLISTED = 0x80000000u;  // record cache count: the re
 //
 //   A  every record of the bin goes into a small cache keyed by the record (word + plane): reads that cover the same
 //      stretch of genome cut it into the same super-k-mers, so at sequencing depth most records are copies and cost one
-//      CAS + one add.  The lane that takes a fresh slot also books the record's n k-mers in a dense map
-//      (s_kmap[..] = slot << 4 | q; one LDS add reserves the n entries).
-//   B  one k-mer per lane over the map: cut k-mer q out of the cached run, canonical form, one returning CAS into the
+//      CAS + three adds nobody waits for.  The lane that takes a fresh slot also books the record's n k-mers in a dense
+//      map, two to an entry (s_kmap[..] = slot << 3 | pair; one LDS add reserves the entries).
+//   B  two k-mers per lane over the map: cut k-mer q out of the cached run, canonical form, one returning CAS into the
 //      k-mer table, count += multiplicity of the record.  Every instance of a k-mer has the same minimizer, so the
 //      counts are final.
 //   C  the table is scanned once: survivors (lower <= count <= upper) go as (key, count) to a staging chunk of the
@@ -477,7 +485,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     uint64_t* __restrict__ stage_k, uint32_t* __restrict__ stage_c, uint32_t CH) {
   constexpr int TBL_LOG2 = GEO ? 12 : 13, TBL = 1 << TBL_LOG2, BLK = GEO ? 512 : 1024, FILL = TBL * 3 / 4;
   constexpr int RC_LOG2 = TBL_LOG2 - (GEO ? RFX_RC_SHRINK : 2), RC = 1 << RC_LOG2, KMAP = TBL;
-  static_assert(RC <= 4096, "a k-mer map entry is slot << 4 | q in 16 bits");
+  static_assert(RC <= 8192, "a k-mer map entry is slot << 3 | pair in 16 bits");
   __shared__ __attribute__((aligned(16))) unsigned long long s_keys[TBL];
   __shared__ uint32_t s_cnt[TBL];
   // record cache.  A record is 96 bits, an LDS compare-and-swap takes 64: the slot's key is word ^ plane * odd -- two
@@ -621,18 +629,17 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         const uint32_t hk = leaf_hash32(key);
         uint32_t slot = hk >> (32 - TBL_LOG2);
         const uint32_t step = ((hk >> 3) | 1u) & (TBL - 1);
+        // (the loop only finds the slot -- it runs as long as the wave's unluckiest lane probes; what follows a hit
+        // comes after it, once)
+        bool fresh = false;
         for (;;) {
-          unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
-          if (old == RFX_EMPTY) {
-            atomicAdd(&s_nd[X], 1u);
-            old = key;
-          }
-          if (old == key) {
-            atomicAdd(&s_cnt[slot], mult);
-            break;
-          }
+          const unsigned long long old = atomicCAS(&s_keys[slot], (unsigned long long)RFX_EMPTY, (unsigned long long)key);
+          fresh = old == RFX_EMPTY;
+          if (fresh || old == key) break;
           slot = (slot + step) & (TBL - 1);
         }
+        atomicAdd(&s_cnt[slot], mult);
+        if (fresh) atomicAdd(&s_nd[X], 1u);
       };
       auto insert_record = [&](uint64_t x, uint32_t xe, uint32_t mult) {  // all k-mers of a record, one after the other
         uint64_t lo, hi;
@@ -692,13 +699,13 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
             }
             TMC(22, 1);
             TMC(23, state == 0);
-            if (state == 1) {  // book the record's k-mers in the map
-              const uint32_t n = (uint32_t)msp_record_n(x);
-              const uint32_t kb = atomicAdd(&s_nk[X], n);
-              if (kb + n <= (uint32_t)KMAP) {
+            if (state == 1) {  // book the record's k-mers in the map, two to an entry
+              const uint32_t np = ((uint32_t)msp_record_n(x) + 1u) >> 1;
+              const uint32_t kb = atomicAdd(&s_nk[X], np);
+              if (kb + np <= (uint32_t)KMAP) {
 #pragma unroll
-                for (uint32_t q = 0; q < 15; ++q)  // (no loop: the wave would run it as often as its longest record asks)
-                  if (q < n) s_kmap[kb + q] = (uint16_t)((h << 4) | q);
+                for (uint32_t q = 0; q < 8; ++q)  // (no loop: the wave would run it as often as its longest record asks)
+                  if (q < np) s_kmap[kb + q] = (uint16_t)((h << 3) | q);
               } else {  // no room in the map: B looks for these in the cache itself (what is left of the map: no entry)
                 for (uint32_t q = kb; q < (uint32_t)KMAP; ++q) s_kmap[q] = 0xFFFFu;
                 atomicOr(&s_rc[h], MSP_RC_UNLISTED);
@@ -714,19 +721,22 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
       }
       __syncthreads();
       TM(9);
-      // ---- B: one k-mer per lane ----
+      // ---- B: two k-mers per lane ----
       if (threadIdx.x == 0) s_nd[X ^ 1] = s_ovf[X ^ 1] = s_nk[X ^ 1] = s_ns[X ^ 1] = s_mixed[X ^ 1] = 0;
       const uint32_t nk_all = s_nk[X], nk = min(nk_all, (uint32_t)KMAP);
       for (uint32_t i = threadIdx.x; i < nk; i += BLK) {
         const uint32_t e = s_kmap[i];
         if (e == 0xFFFFu) continue;
-        const uint32_t slot = e >> 4, q = e & 15u;
+        const uint32_t slot = e >> 3, q = (e & 7u) << 1;
         const uint32_t xe = s_rmax[slot];
         const uint64_t x = s_rk[slot] ^ ((uint64_t)xe * MSP_RK_MUL);
         if (q == 0 && s_rmin[slot] != xe) s_mixed[X] = 1;  // two different records met in this slot
         uint64_t lo, hi;
         msp_record_run(x, xe, k, lo, hi);
-        insert_fwd(msp_run_kmer(lo, hi, k, msp_record_n(x), (int)q), s_rc[slot]);
+        const int n = msp_record_n(x);
+        const uint32_t mult = s_rc[slot];
+        insert_fwd(msp_run_kmer(lo, hi, k, n, (int)q), mult);
+        if ((int)q + 1 < n) insert_fwd(msp_run_kmer(lo, hi, k, n, (int)q + 1), mult);
       }
       if (nk_all > (uint32_t)KMAP) {  // (rare) records that found no room in the map
         for (int i = threadIdx.x; i < RC; i += BLK) {
@@ -812,7 +822,7 @@ __global__ __launch_bounds__(L2_BLOCK) void k_surv_hist(const uint64_t* __restri
   if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   for (uint64_t i = a + (uint64_t)jj * L2_BLOCK + threadIdx.x; i < e; i += (uint64_t)W * L2_BLOCK) {
-    const uint64_t w = buf_a[i];
+    const uint64_t w = MODE == 0 ? buf_a[i] : msp_rec12_word((const msp_rec12*)buf_a, i);  // (records: k_msp_part1's 12-byte slots)
     if (MODE != 0 && w == MSP_EMPTY) continue;  // a slot of a k_msp_part1 slab that nobody took
     const uint32_t sub = MODE == 0 ? (uint32_t)(w >> shift2) & (P2 - 1)
                                    : ((MODE == 1 ? msp_record_binhash<true>(w, k) : msp_record_binhash<false>(w, k)) >> shift2) & (P2 - 1);
@@ -945,12 +955,12 @@ int msp_nmax_of(int k) { return msp_nmax(k); }
 int msp_wide(int) { return 1; }  // (round 4) every record is a 64-bit word + a 32-bit plane
 
 void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
-               int hmode, int grid, uint64_t* buf_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
-               unsigned int* flag, uint32_t* ext_a, int slab_log2) {
+               int hmode, int grid, void* rec_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
+               unsigned int* flag, int slab_log2) {
   rfx_span sp(c, hmode == 1 ? "k_msp_count" : "k_msp_part1");
 #define RFX_MSP_P1(CANON, HM, WL)                                                                             \
   hipLaunchKernelGGL((k_msp_part1<CANON, HM, WL>), dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, k, bin_bits, \
-                     bin_lo, bin_hi, buf_a, ext_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2)
+                     bin_lo, bin_hi, (msp_rec12*)rec_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2)
 #define RFX_MSP_P1_HM(CANON, WL)          \
   do {                                          \
     if (hmode == 0) RFX_MSP_P1(CANON, 0, WL);      \

@@ -437,6 +437,11 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
           wv[u] = s_sptr[seg][i - seg_b];
           if (PAYLOAD) pv[u] = s_spay[seg][i - seg_b];
         }
+      } else if (MODE != 0 && PAYLOAD && coarse_cur) {  // k_msp_part1's coarse bins: word and plane side by side
+        msp_rec12 rr{0u, 0u, 0u};
+        if (i < e) rr = ((const msp_rec12*)buf_a)[i];
+        wv[u] = (uint64_t)rr.lo | ((uint64_t)rr.hi << 32);
+        pv[u] = rr.x;
       } else {
         wv[u] = i < e ? buf_a[i] : 0;
         if (PAYLOAD) pv[u] = i < e ? pay_a[i] : 0;
@@ -890,9 +895,12 @@ void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* f
 #define RFX_PART2(PAY, MODE)                                                                                          \
   hipLaunchKernelGGL((k_part2<PAY, MODE>), dim3(nc * W), dim3(L2_BLOCK), 0, c->stream, buf_a, buf_b, fine_start,       \
                      fine_cur, P2, shift2, W, coarse_cur, cap_a, pay_a, pay_b, cap_b, coarse_start, k, fine_base)
-  if (pay_a && rec_mode == 0) RFX_PART2(true, 0);  // payload: counts of survivors / the plane of wide records
-  else if (pay_a && rec_mode == 1) RFX_PART2(true, 1);
-  else if (pay_a) RFX_PART2(true, 2);
+  // payload: counts of survivors / the plane of super-k-mer records (coming out of k_msp_part1's coarse bins it sits
+  // beside the word: pay_a is null then)
+  const bool pay = pay_a || (rec_mode != 0 && pay_b);
+  if (pay && rec_mode == 0) RFX_PART2(true, 0);
+  else if (pay && rec_mode == 1) RFX_PART2(true, 1);
+  else if (pay) RFX_PART2(true, 2);
   else if (rec_mode == 0) RFX_PART2(false, 0);
   else if (rec_mode == 1) RFX_PART2(false, 1);
   else RFX_PART2(false, 2);

@@ -49,7 +49,11 @@ __host__ __device__ __forceinline__ int msp_nmax(int k) {
 // One multiply each: 32-bit integer multiplies are quarter rate, and k_msp_part1 hashes every base.
 // The xor keeps the all-A m-mer (c = 0) from hashing to 0 = always the minimum.
 __device__ __forceinline__ uint32_t mmer_hash(uint32_t c) {
+#ifdef RFX_P1_NOMUL  // experiment (results void): what the 32-bit multiply costs
+  c = (c ^ 0x5BD1E995u) + (c << 7);
+#else
   c = (c ^ 0x5BD1E995u) * 0x9E3779B1u;
+#endif
   return c ^ (c >> 15);
 }
 

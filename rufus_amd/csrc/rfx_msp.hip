@@ -182,10 +182,18 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     __syncthreads();
     atomicMax(&s_maxlen, lenp);
     __syncthreads();
+#ifdef RFX_P1_HALF  // experiment (results void): half of every read -- what is per chunk, what per base?
+    const uint32_t n_phase = (s_maxlen + P1_S - 1) / P1_S / 2;
+#else
     const uint32_t n_phase = (s_maxlen + P1_S - 1) / P1_S;
-    uint32_t fm = 0, rm = 0, cur_m = 0, run_h = 0, hist_hi = 0;
-    uint64_t hist = 0, cur_w = 0;
-    int filled = 0, run_n = 0;
+#endif
+    // Per-lane state between phases: the rolling m-mer and its reverse complement, the hash window, what is left of the
+    // 32 bases in flight, the last 64 + 64 bases (`hist`: the newest in the low bits), the base from which k-mers are
+    // valid again (`ok_from`: k past the last invalid one), whether the k-mer ending at the phase's last base was
+    // valid and its minimizer (`prev_kv`, `prev_mh`: the run in progress), and where that run began (`run_s`: the
+    // last base of its first k-mer).
+    uint32_t fm = 0, rm = 0, cur_m = 0, prev_mh = 0, prev_kv = 0, run_s = 0, ok_from = (uint32_t)k - 1u;
+    uint64_t hist = 0, hist_hi = 0, cur_w = 0;
     uint32_t a[WL - 1 + P1_S];  // hashes of the m-mers ending at bases p0-(WL-1) .. p0+7
 #pragma unroll
     for (int i = 0; i < WL - 1 + P1_S; ++i) a[i] = ~0u;
@@ -232,100 +240,134 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
             cur_m = cm ? cm[p0 >> 5] : ~0u;
           }
         }
-        // window minimum = min(suffix minimum of the 14 old hashes, prefix minimum of the new ones)
+        // ---- round 4: run boundaries are found for the eight bases of a phase at once ----
+        // Until then every base carried the run state through ~35 instructions (valid-base counter, run length, four
+        // compares, selects): 38 of the kernel's 57 ms per 1 Gb sample with the record stores out of the way.  Now a base
+        // costs the hash and two minima; what depends on validity and on "same minimizer as the base before" is
+        // worked out once per phase on 8-bit masks.
+        // (1) which of the 8 k-mers ending here are valid: from the first invalid base on none is (k > 8)
+        uint32_t vm8 = cur_m & 0xFFu;
+        cur_m >>= 8;
+        if (!__all((int)(p0 + P1_S <= len))) vm8 &= p0 < len ? (len - p0 >= 8u ? 0xFFu : (1u << (len - p0)) - 1u) : 0u;
+        const uint32_t inv = ~vm8 & 0xFFu;
+        const uint32_t fi = inv ? (uint32_t)__ffs((int)inv) - 1u : 8u;
+        const uint32_t lo_b = ok_from > p0 ? min(ok_from - p0, 8u) : 0u;
+        const uint32_t kvmask = ((1u << fi) - 1u) & ~((1u << lo_b) - 1u);  // bit b: the k-mer ending at p0 + b is valid
+        if (inv) ok_from = p0 + (31u - (uint32_t)__clz((int)inv)) + (uint32_t)k;
+        // (2) the 8 bases join the history (first base most significant: the packed word has it least significant)
+        const uint32_t w16 = (uint32_t)cur_w & 0xFFFFu;
+        cur_w >>= 16;
+        {
+          uint32_t y = __brev(w16) >> 16;
+          y = ((y & 0xAAAAu) >> 1) | ((y & 0x5555u) << 1);
+          hist_hi = (hist_hi << 16) | (hist >> 48);
+          hist = (hist << 16) | y;
+        }
+        // (3) hashes and window minima; bit b of eqmask: same minimizer as the k-mer before
+        // window minimum = min(suffix minimum of the old hashes, prefix minimum of the new ones)
         uint32_t sfx[WL - 1];
         sfx[WL - 2] = a[WL - 2];
   #pragma unroll
         for (int i = WL - 3; i >= 0; --i) sfx[i] = min(a[i], sfx[i + 1]);
-        uint32_t pm = ~0u;
-        // one base of every lane's read.  FAST: the whole phase lies inside every read of the wave (all but the last phase of
-        // uniform reads): no per-lane bounds checks
-        auto base_step = [&](auto fast_tag, const int b) {
-          constexpr bool FAST = decltype(fast_tag)::value;
-          const bool act = FAST || p0 + b < lenp;  // (the queue below is the wave's: it is worked outside the per-lane test)
-          uint32_t code = 0;
-          bool kvalid = false, closes = false, mine = false;
-          uint32_t mh = 0, run_bin = 0;
-          if (act) {
-            const bool real = FAST || p0 + b < len;
-            code = real ? (uint32_t)cur_w & 3u : 0u;
-            const bool valid = real && (cur_m & 1u);
-            cur_w >>= 2;
-            cur_m >>= 1;
-            fm = ((fm << 2) | code) & mmask;
-            rm = (rm >> 2) | ((3u - code) << rmshift);
-            const uint32_t h = (mmer_hash(CANON ? min(fm, rm) : fm) & MSP_HMASK) | ((p0 & 24u) | (uint32_t)b);
-            a[WL - 1 + b] = h;
-            pm = min(pm, h);
-            filled = valid ? filled + 1 : 0;
-            kvalid = filled >= k;
-            // A run = consecutive k-mers with the same minimizer HASH (not merely the same bin): every
-            // further bit of that hash is then common to the record's k-mers, which is what lets
-            // the partition be refined later without separating instances of a k-mer.
-            mh = min(sfx[b], pm);
-            // (bitwise, not short-circuit: one exec mask instead of three nested ones)
-            // The run that ended at the previous base closes (`hist` still ends there), and it is ours (shard passes: other
-            // bins are not; unsigned: one compare).
-            // (a run cannot outgrow the window: its minimizer lies in every one of its k-mers -- the cap only matters
-            // where the record format holds fewer k-mers than a window has m-mers, k >= 30)
-            closes = (run_n != 0) & (!kvalid | (mh != run_h) | (nmax < WL && run_n == nmax));
-            mine = true;
-  #ifdef RFX_P1_NOCLOSE
-            mine = bin_lo == 12345u;
-  #endif
-            if (SLABS ? !all_mine : true) {  // (one pass, one device: every bin is this table's -- a multiply less per base)
-              run_bin = msp_bin(run_h, bin_bits);
-  #ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
-              mine = run_bin == 0xFFFFFFFFu && bin_lo == 12345u;
-  #else
-              mine = run_bin - bin_lo < bin_hi - bin_lo;
-  #endif
-            }
-          }
-          if constexpr (SLABS) {
-            const bool push = closes & mine;
-            const unsigned long long bal = __ballot(push);
-            if (bal) {
-              if (push) {
-                const uint32_t idx =
-                    (q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))) &
-                    (QN - 1);
-                // the run ends at base e = p0 + b - 1; its minimizer m-mer ends at the last base q <= e with
-                // q = run_h (mod 32) -- inside the run's LAST k-mer, so back = e - q <= k - m < 16
-                const uint32_t back = (p0 + (uint32_t)b - 1u - run_h) & 31u;
-                sq[idx] = (uint32_t)hist;
-                sq[QN + idx] = (uint32_t)(hist >> 32);
-                sq[2 * QN + idx] = (hist_hi & 0x3FFFFFu) | ((uint32_t)run_n << 22) | (back << 26);
-              }
-              q_tail += (uint32_t)__popcll(bal);
-              if (q_tail - q_head >= 64u) drain(64u);
-            }
-          } else if (closes & mine) {
-            if (HMODE != 1) {
-              const int L = k + run_n - 1;
-              const uint32_t coarse = run_bin >> sub_bits;
-              const uint32_t back = (p0 + (uint32_t)b - 1u - run_h) & 31u;
-              const uint32_t mpos = (uint32_t)(L - m) - back;
-              msp_record_make(hist, hist_hi, k, run_n, mpos, wv[b], xv[b]);
-              br[b] = (coarse << 16) | atomicAdd(&s_cnt[X][coarse], 1u);
-            }
-            if (HMODE == 1) atomicAdd(&s_fine[run_bin], 1u);
-          }
-          if (act) {
-            run_n = closes ? 0 : run_n;
-            run_h = kvalid && !run_n ? mh : run_h;  // (selects, not branches: two instructions instead of a saved exec mask)
-            run_n += kvalid ? 1 : 0;
-            hist_hi = (hist_hi << 2) | (uint32_t)(hist >> 62);
-            hist = (hist << 2) | code;
-          }
-        };
-        if (__all((int)(p0 + P1_S <= len))) {
+        uint32_t pm = ~0u, eqmask = 0, mhv[P1_S];
   #pragma unroll
-          for (int b = 0; b < P1_S; ++b) base_step(std::true_type(), b);
-        } else {
-  #pragma unroll
-          for (int b = 0; b < P1_S; ++b) base_step(std::false_type(), b);
+        for (int b = 0; b < P1_S; ++b) {
+          const uint32_t code = (w16 >> (2 * b)) & 3u;
+          fm = ((fm << 2) | code) & mmask;
+          rm = (rm >> 2) | ((3u ^ code) << rmshift);
+          const uint32_t h = (mmer_hash(CANON ? min(fm, rm) : fm) & MSP_HMASK) | ((p0 & 24u) | (uint32_t)b);
+          a[WL - 1 + b] = h;
+          pm = min(pm, h);
+          // A run = consecutive k-mers with the same minimizer HASH (not merely the same bin): every further bit of
+          // that hash is then common to the record's k-mers, which is what lets the partition be refined later
+          // without separating instances of a k-mer.
+          mhv[b] = min(sfx[b], pm);
+          eqmask |= (mhv[b] == (b ? mhv[b - 1] : prev_mh) ? 1u : 0u) << b;
         }
+        // (4) a run goes on from base b - 1 to b if both k-mers are valid and share the minimizer; where it does not, the
+        // run of b - 1 ends (bit b of `ends`) and / or one begins at b (bit b of `starts`)
+        const uint32_t KV = (kvmask << 1) | prev_kv;  // bit b: the k-mer ending at p0 + b - 1 is valid
+        uint32_t cont = KV & (KV >> 1) & eqmask;
+        uint32_t ends = KV & ~cont & 0xFFu, starts = kvmask & ~cont;
+        if (nmax < WL) {  // k >= 26: a record holds fewer k-mers than a window has m-mers -- the run is cut at the cap
+          // (at most once per phase: nmax > 8; and only if the run in progress did not begin in this phase)
+          const uint32_t cb = run_s + (uint32_t)nmax - p0;  // (wraps to a big number when the cap lies behind)
+          if (cb < 8u && ((cont >> cb) & 1u) && (starts & ((2u << cb) - 1u)) == 0) {
+            ends |= 1u << cb;
+            starts |= 1u << cb;
+          }
+        }
+        // (5) the runs that end in this phase.  SLABS: a lane walks the set bits of its `ends` -- the wave makes as many
+        // turns as its busiest lane has boundaries (3-4 of 8 bases), where a copy of the push per base ran 8 times; what a
+        // turn needs of the minimizer (its position mod 32, for `back`; its bin, for "is this run the table's") is laid
+        // out per phase: five bits per base in `qpack`, one in `minemask`.
+        if constexpr (SLABS) {
+          uint64_t qpack = prev_mh & 31u;  // 5 bits per run end: position (mod 32) of the minimizer of the run ending at p0 + b - 1
+  #pragma unroll
+          for (int b = 1; b < P1_S; ++b) qpack |= (uint64_t)(mhv[b - 1] & 31u) << (5 * b);
+          uint32_t pend = ends;
+  #ifdef RFX_P1_NOCLOSE  // experiment: what the hashing and the sliding minimum cost without the record path
+          if (bin_lo != 12345u) pend = 0;
+  #endif
+          if (!all_mine) {  // (one pass, one device: every bin is this table's)
+            uint32_t minemask = 0;
+  #pragma unroll
+            for (int b = 0; b < P1_S; ++b)
+              minemask |= (msp_bin(b ? mhv[b - 1] : prev_mh, bin_bits) - bin_lo < bin_hi - bin_lo ? 1u : 0u) << b;
+            pend &= minemask;  // (shard passes: other bins are not ours; unsigned: one compare)
+          }
+          for (;;) {
+            const bool push = pend != 0;
+            const unsigned long long bal = __ballot(push);
+            if (!bal) break;
+            if (push) {
+              const uint32_t b = (uint32_t)__ffs((int)pend) - 1u;
+              pend &= pend - 1u;
+              // the run's k-mers end at bases rs .. e = p0 + b - 1 (rs: the last start before b, in this phase or
+              // before); its minimizer m-mer ends at the last base q <= e with q = qpack[b] (mod 32) -- inside the
+              // run's LAST k-mer, so back = e - q <= k - m < 16.  The history holds 8 - b bases behind e.
+              const uint32_t ms = starts & ((1u << b) - 1u);
+              const uint32_t rs = ms ? p0 + 31u - (uint32_t)__clz((int)ms) : run_s;
+              const uint32_t e = p0 + b - 1u;
+              const uint32_t back = (e - (uint32_t)(qpack >> (5u * b))) & 31u;
+              const uint32_t sh = 2u * (P1_S - b);  // 2 .. 16
+              const uint64_t hl = (hist >> sh) | (hist_hi << (64u - sh));
+              const uint32_t idx =
+                  (q_tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))) &
+                  (QN - 1);
+              sq[idx] = (uint32_t)hl;
+              sq[QN + idx] = (uint32_t)(hl >> 32);
+              sq[2 * QN + idx] = ((uint32_t)(hist_hi >> sh) & 0x3FFFFFu) | ((e - rs + 1u) << 22) | (back << 26);
+            }
+            q_tail += (uint32_t)__popcll(bal);
+            if (q_tail - q_head >= 64u) drain(64u);
+          }
+          if (starts) run_s = p0 + 31u - (uint32_t)__clz((int)starts);
+        } else {
+          // the exact redo (rare): base by base, b a constant in each copy
+  #pragma unroll
+          for (int b = 0; b < P1_S; ++b) {
+            const uint32_t run_h = b ? mhv[b - 1] : prev_mh;  // minimizer of the run that ends at p0 + b - 1
+            const bool closes = (ends >> b) & 1u;
+            const uint32_t run_bin = msp_bin(run_h, bin_bits);
+            const bool mine = run_bin - bin_lo < bin_hi - bin_lo;
+            const uint32_t e = p0 + (uint32_t)b - 1u;
+            const int sh = 2 * (P1_S - b);  // (a constant once the loop is unrolled; 2 .. 16)
+            if (closes & mine) {
+              if (HMODE != 1) {
+                const int n = (int)(e - run_s + 1u), L = k + n - 1;
+                const uint32_t coarse = run_bin >> sub_bits;
+                const uint32_t mpos = (uint32_t)(L - m) - ((e - run_h) & 31u);
+                msp_record_make((hist >> sh) | (hist_hi << (64 - sh)), (uint32_t)(hist_hi >> sh), k, n, mpos, wv[b], xv[b]);
+                br[b] = (coarse << 16) | atomicAdd(&s_cnt[X][coarse], 1u);
+              }
+              if (HMODE == 1) atomicAdd(&s_fine[run_bin], 1u);
+            }
+            run_s = ((starts >> b) & 1u) ? p0 + (uint32_t)b : run_s;
+          }
+        }
+        prev_mh = mhv[P1_S - 1];
+        prev_kv = (kvmask >> (P1_S - 1)) & 1u;
   #pragma unroll
         for (int i = 0; i < WL - 1; ++i) a[i] = a[i + P1_S];
       }

@@ -11,7 +11,9 @@
 // the HIP kernels behind include/rufus_hip.h.  No CPU fallback.
 #include <getopt.h>
 
+#include <atomic>
 #include <chrono>
+#include <mutex>
 #include <limits>
 #include <memory>
 
@@ -76,9 +78,10 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   while ((1ull << lsize) < size) ++lsize;
   if (lsize < 1) lsize = 1;
 
-  // RUFUS_GPUS: one sample over several devices (include/rufus_hip.h rfx_count_set_peers) -- every device
-  // gets every read block and counts its minimizer shard; the survivors change hands by output position; the file is
-  // the devices' slices one after the other.  Needs the super-k-mer path (23 <= k <= 31): else the first device alone.
+  // RUFUS_GPUS: one sample over several devices (include/rufus_hip.h rfx_count_set_peers) -- a device
+  // gets every N-th read block and partitions it; the owners of the minimizer bins pull their records, the survivors
+  // change hands by output position; the file is the devices' slices one after the other.  Needs the super-k-mer path
+  // (23 <= k <= 31): else the first device alone.
   std::vector<int> gpus = gpu_list();
   if (gpus.size() > 1 && !(k >= 23 && k <= 31)) {
     fprintf(stderr, "rufus_amd jellyfish: k = %d is counted on one device (RUFUS_GPUS needs 23 <= k <= 31)\n", k);
@@ -151,10 +154,21 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     if (defer) resident[(size_t)g].push_back(r);
     else rfx_reads_free(r);
   };
-  // a block of packed reads goes to EVERY device (each over its own PCIe link: one thread per device)
+  // Several devices: block b of packed reads goes to device b mod N -- each device partitions its blocks, the owners of
+  // the minimizer bins pull their record runs at finish (rfx_count_set_peers).  RFX_PEERS_REPLICATE=1: round 3's scheme,
+  // every block to EVERY device (each over its own PCIe link: one thread per device).
+  const bool replicate = getenv("RFX_PEERS_REPLICATE") != nullptr;
+  std::atomic<uint64_t> next_block{0};
   auto to_all = [&](const std::function<rfx_reads*(rfx_ctx*)>& up) {
     if (n_gpu == 1) {
       sink_to(0, up(ctx));
+      return;
+    }
+    if (!replicate) {
+      const int g = (int)(next_block.fetch_add(1) % (uint64_t)n_gpu);
+      static std::mutex dev_mu[128];  // (one upload at a time per device: the table of a device is not re-entrant)
+      std::lock_guard<std::mutex> lk(dev_mu[g]);
+      sink_to(g, up(ctxs[g]));
       return;
     }
     std::vector<std::thread> th;

@@ -1681,6 +1681,142 @@ static int msp_prepare_leaf(rfx_table* t, int* to_bits_out, bool* refine_out, st
 
 static int msp_add(rfx_table* t, const rfx_reads* r);
 
+// ---- several devices behind one executable (SURVEY 8(e), row E-cli) ---------------------------------------------------
+// N tables, one per device, behind ONE process (runRufus.sh starts binaries: no Python, no RCCL).  Round 4: the scheme
+// of `north_star` -- table i is given read blocks i, i + N, ... only (1/N of the uploads, 1/N of the hashing); in
+// shard pass s every table partitions ITS blocks restricted to the pass, and the bins of a pass are cut into N owner
+// ranges (virtual shard s * N + g of S * N: the cut of rfx_count_set_shard, the same on every device): after a barrier
+// table g PULLS the record runs of its range from every table (hipMemcpyPeerAsync -- xGMI when the arenas were opened
+// with rfx_ctx_allow_peers; its own run is read where it lies), a second barrier lets the partitions go, and the leaf
+// counts complete bins -- no partial counts, no reduce.  (RFX_PEERS_REPLICATE=1: round 3's fallback scheme -- every
+// table is given every block and keeps minimizer shard i of N; nothing but survivors changes hands.)
+// Either way the survivors change hands once more, by OUTPUT position: the leaf leaves them in 128 coarse pos bins, and
+// table i takes over coarse bins [i * 128 / N, (i + 1) * 128 / N) of every table before the usual partition + sort --
+// its records are then slice i of the (pos,key)-ordered payload, and the .Jhash is the slices one after the other.
+// The finishes of the N tables run concurrently on N host threads and meet at barriers.
+struct rfx_peers {
+  int n = 0;
+  bool sharded = true;  // read-block shard + record pull (false: RFX_PEERS_REPLICATE)
+  std::mutex mu;
+  std::condition_variable cv;
+  int arrived = 0;
+  uint64_t gen = 0;
+  bool failed = false;
+  struct Seg {  // a published partition of one read block (restricted to the pass)
+    const uint64_t* inst = nullptr;
+    const uint32_t* ext = nullptr;
+    uint32_t bins = 0;
+    std::vector<uint64_t> bs;  // host copy of its bin extents
+  };
+  struct Slot {
+    int device = 0;
+    const uint64_t* aw = nullptr;
+    const uint32_t* ac = nullptr;
+    uint64_t cap = 0;
+    std::vector<uint32_t> fill;  // per coarse bin
+    int passes = 0;              // sharded: the shard passes this table planned (all take the maximum)
+    std::vector<Seg> segs;       // sharded: this table's partitions of the pass in flight
+  };
+  std::vector<Slot> slot;
+  bool barrier() {  // false: somebody failed
+    std::unique_lock<std::mutex> g(mu);
+    if (failed) return false;
+    const uint64_t my = gen;
+    if (++arrived == n) {
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+      return true;
+    }
+    cv.wait(g, [&] { return gen != my || failed; });
+    return !failed;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> g(mu);
+    failed = true;
+    cv.notify_all();
+  }
+};
+
+// Sharded peers, pass s of S: publish this table's partitions, pull the record runs of this table's owner range from
+// every table, leave them as the table's segments.  `own` receives the table's own partitions: the run of its own
+// range is counted where it lies, so they stay until the pass's leaf is through.
+static int peers_pull_records(rfx_table* t, int s, int S, std::vector<rfx_segment>& own) {
+  rfx_ctx* c = t->ctx;
+  rfx_peers* p = t->peers;
+  const int me = t->peer_index, N = p->n, V = S * N;
+  int rc = msp_resolve(t);  // the capacity flags of the adds: a flagged block is redone before anybody reads it
+  rfx_peers::Slot& mine = p->slot[(size_t)me];
+  mine.device = c->device;
+  mine.segs.clear();
+  if (rc == RFX_OK) {
+    mine.segs.resize(t->segs->size());
+    for (size_t i = 0; i < t->segs->size() && rc == RFX_OK; ++i) {
+      const rfx_segment& sg = (*t->segs)[i];
+      rfx_peers::Seg& ps = mine.segs[i];
+      ps.inst = sg.inst;
+      ps.ext = sg.ext;
+      ps.bins = sg.bins;
+      ps.bs.assign((size_t)sg.bins + 1, 0);
+      if (hipMemcpyAsync(ps.bs.data(), sg.bin_start, ((size_t)sg.bins + 1) * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        rc = RFX_E_HIP;
+    }
+    if (rc == RFX_OK && ctx_sync(c) != hipSuccess) rc = RFX_E_HIP;
+  }
+  if (rc != RFX_OK) p->abort();
+  if (!p->barrier()) return rc != RFX_OK ? rc : RFX_E_HIP;  // (everybody's partitions of the pass are published)
+  own.swap(*t->segs);
+  t->segs->clear();
+  auto cut = [&](uint32_t bins, int q) { return (uint32_t)(((uint64_t)q * 256 + (uint64_t)V - 1) / (uint64_t)V) * (bins / 256); };
+  for (int g = 0; g < N && rc == RFX_OK; ++g) {
+    const rfx_peers::Slot& sl = p->slot[(size_t)g];
+    for (size_t i = 0; i < sl.segs.size() && rc == RFX_OK; ++i) {
+      const rfx_peers::Seg& ps = sl.segs[i];
+      const uint32_t lo = cut(ps.bins, s * N + me), hi = cut(ps.bins, s * N + me + 1);
+      const uint64_t a = ps.bs[lo], n = ps.bs[hi] - a;
+      if (!n) continue;
+      // bin extents of the pulled run: empty outside [lo, hi)
+      std::vector<uint64_t> bs((size_t)ps.bins + 1);
+      const uint64_t base = g == me ? 0 : a;  // (the own run stays where it is: absolute extents)
+      for (uint32_t b = 0; b <= ps.bins; ++b) bs[b] = (b < lo ? ps.bs[lo] : b > hi ? ps.bs[hi] : ps.bs[b]) - base;
+      uint64_t* d_bs = (uint64_t*)dmalloc(c, ((size_t)ps.bins + 1) * 8);
+      if (!d_bs) { rc = RFX_E_NOMEM; break; }
+      if (upload(c, d_bs, bs.data(), ((size_t)ps.bins + 1) * 8) != hipSuccess) { dfree(c, d_bs); rc = RFX_E_HIP; break; }
+      // (k-mer instances behind the run: sizes the leaf's bins and the survivor store)
+      const uint64_t kmers = n * (uint64_t)(t->k <= 25 ? 6 : 9);
+      if (g == me) {
+        rfx_segment sg{const_cast<uint64_t*>(ps.inst), n, d_bs, kmers, ps.bins, const_cast<uint32_t*>(ps.ext)};
+        sg.borrowed = true;
+        t->segs->push_back(sg);
+        continue;
+      }
+      uint64_t* inst = (uint64_t*)dmalloc(c, n * 8);
+      uint32_t* ext = (uint32_t*)dmalloc(c, n * 4);
+      if (!inst || !ext) { dfree(c, inst); dfree(c, ext); dfree(c, d_bs); rc = RFX_E_NOMEM; break; }
+      hipError_t e;
+      if (sl.device == c->device) {  // another ctx on the same device (how a one-GPU box tests this)
+        e = rfxk::copy_bytes(c, inst, ps.inst + a, n * 8);
+        if (e == hipSuccess) e = rfxk::copy_bytes(c, ext, ps.ext + a, n * 4);
+      } else {
+        e = hipMemcpyPeerAsync(inst, c->device, ps.inst + a, sl.device, n * 8, c->stream);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(ext, c->device, ps.ext + a, sl.device, n * 4, c->stream);
+        if (e != hipSuccess) {  // no peer route: let the runtime stage it
+          (void)hipGetLastError();
+          e = hipMemcpy(inst, ps.inst + a, n * 8, hipMemcpyDefault);
+          if (e == hipSuccess) e = hipMemcpy(ext, ps.ext + a, n * 4, hipMemcpyDefault);
+        }
+      }
+      if (e != hipSuccess) { dfree(c, inst); dfree(c, ext); dfree(c, d_bs); rc = hip_fail(e, "rfx peers record pull"); break; }
+      t->segs->push_back(rfx_segment{inst, n, d_bs, kmers, ps.bins, ext});
+    }
+  }
+  if (rc == RFX_OK && ctx_sync(c) != hipSuccess) rc = RFX_E_HIP;
+  if (rc != RFX_OK) p->abort();
+  if (!p->barrier()) return rc != RFX_OK ? rc : RFX_E_HIP;  // (every pull is complete: the partitions may go)
+  // what nobody reads any more: everything of the own partitions but the arrays the own run lies in
+  return RFX_OK;
+}
+
 // Deferred adds (rfx_count_set_passes): the read blocks stayed with the caller, nothing was partitioned yet.
 // S minimizer-shard passes over them: partition the shard's runs of every block, refine + count (the leaf
 // appends the shard's survivors to the coarse pos bins), free the records, next shard.  Only 1/S of the
@@ -1713,6 +1849,16 @@ static int msp_passes_leaf(rfx_finish* f) {
     if (const char* ev = getenv("RFX_COUNT_PASSES")) S = std::max(1, atoi(ev));
   }
   if (S * outer_n > 256) S = std::max(1, 256 / outer_n);
+  const bool sharded = t->peers && t->peers->sharded;
+  if (sharded) {  // every table takes the same number of passes: the most anybody planned
+    rfx_peers* p = t->peers;
+    if (t->passes <= 0) S = std::max(1, std::min(256 / p->n, 2 * S));  // (partition + pulled runs: the records twice)
+    p->slot[(size_t)t->peer_index].passes = S;
+    if (!p->barrier()) return RFX_E_HIP;
+    for (int g = 0; g < p->n; ++g) S = std::max(S, p->slot[(size_t)g].passes);
+    if (S * p->n > 256) S = std::max(1, 256 / p->n);
+    if (!p->barrier()) return RFX_E_HIP;  // (nobody overwrites its slot before everybody has read it)
+  }
   const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + 2) * 4;
   f->bsq = (uint64_t*)dmalloc(c, zero_bytes);
   if (!f->bsq) return RFX_E_NOMEM;
@@ -1732,7 +1878,24 @@ static int msp_passes_leaf(rfx_finish* f) {
       const int rc = msp_add(t, r);
       if (rc) return rc;
     }
-    if (t->segs->empty()) continue;
+    // sharded peers: this table's partitions of the pass (other tables read them; the own run is counted where it lies)
+    struct own_segments : std::vector<rfx_segment> {
+      rfx_ctx* c;
+      explicit own_segments(rfx_ctx* c_) : c(c_) {}
+      void drop() {
+        for (auto& sg : *this) { dfree(c, sg.inst); dfree(c, sg.bin_start); dfree(c, sg.ext); }
+        clear();
+      }
+      ~own_segments() { drop(); }
+    } own(c);
+    auto drop_own = [&] { own.drop(); };
+    if (sharded) {
+      const int rc = peers_pull_records(t, s, S, own);
+      if (rc) { drop_own(); return rc; }
+      t->shard = (outer_shard * S + s) * t->peers->n + t->peer_index;  // (the density the leaf's bin count is planned for)
+      t->n_shards = outer_n * S * t->peers->n;
+    }
+    if (t->segs->empty()) { drop_own(); continue; }
     int to_bits = 0;
     bool refine = false;
     uint64_t kmers = 0;
@@ -1789,6 +1952,7 @@ static int msp_passes_leaf(rfx_finish* f) {
       HIPCHK(upload(c, cur, cur_prev.data(), (ncur + 2) * 4));
     }
     p2l_drop_segments(t);
+    drop_own();
     cur_prev = f->h_cur;
     if (s == 0 && S > 1) {  // now sized for all passes: the shards are equal shares of a hash space
       uint64_t mx = 0;
@@ -1825,53 +1989,11 @@ static int msp_passes_leaf(rfx_finish* f) {
   return RFX_OK;
 }
 
-// ---- several devices behind one executable (SURVEY 8(e), row E-cli) ---------------------------------------------------
-// N tables, one per device, are given the SAME read blocks; table i keeps minimizer shard i of N (rfx_count_set_shard's
-// cut, composed with its own shard passes), so the devices count disjoint sets of k-mers -- no partial counts, no
-// reduce.  What has to change hands is the survivors: the leaf leaves them in 128 coarse bins of the output position, and
-// table i takes over coarse bins [i * 128 / N, (i + 1) * 128 / N) of EVERY table (device-to-device copies, pulled by the
-// receiver; xGMI when the arenas were opened with rfx_ctx_allow_peers) before the usual partition + sort -- its records
-// are then slice i of the (pos,key)-ordered payload, and the .Jhash is the slices one after the other.
-// The finishes of the N tables run concurrently on N host threads and meet at two barriers.
-struct rfx_peers {
-  int n = 0;
-  std::mutex mu;
-  std::condition_variable cv;
-  int arrived = 0;
-  uint64_t gen = 0;
-  bool failed = false;
-  struct Slot {
-    int device = 0;
-    const uint64_t* aw = nullptr;
-    const uint32_t* ac = nullptr;
-    uint64_t cap = 0;
-    std::vector<uint32_t> fill;  // per coarse bin
-  };
-  std::vector<Slot> slot;
-  bool barrier() {  // false: somebody failed
-    std::unique_lock<std::mutex> g(mu);
-    if (failed) return false;
-    const uint64_t my = gen;
-    if (++arrived == n) {
-      arrived = 0;
-      ++gen;
-      cv.notify_all();
-      return true;
-    }
-    cv.wait(g, [&] { return gen != my || failed; });
-    return !failed;
-  }
-  void abort() {
-    std::lock_guard<std::mutex> g(mu);
-    failed = true;
-    cv.notify_all();
-  }
-};
-
 rfx_peers* rfx_peers_create(int n) {
   if (n < 1 || n > 128) return nullptr;
   rfx_peers* p = new rfx_peers();
   p->n = n;
+  p->sharded = getenv("RFX_PEERS_REPLICATE") == nullptr;
   p->slot.resize((size_t)n);
   return p;
 }
@@ -1885,6 +2007,10 @@ int rfx_count_set_peers(rfx_table* t, rfx_peers* p, int index) {
   }
   t->peers = p;
   t->peer_index = index;
+  if (p->sharded) {  // the table is given ITS read blocks; who counts what is settled pass by pass at finish
+    t->mode = RFX_COUNT_MSP;
+    return RFX_OK;
+  }
   return rfx_count_set_shard(t, index, p->n);
 }
 
@@ -1976,7 +2102,8 @@ static int msp_emit_queue(rfx_finish* f) {
   rfx_ctx* c = t->ctx;
   const uint32_t P1 = (uint32_t)rfxk::p1_bins();
   const size_t ncur = (size_t)P1 * rfxk::p1_cur_stride();
-  const bool deferred = !t->deferred->empty();
+  // (a table of a group takes the passes route even without a read block of its own: the others wait for it)
+  const bool deferred = !t->deferred->empty() || (t->peers && t->passes >= 0 && t->segs->empty());
   int to_bits = 0;
   bool refine = false;
   uint64_t kmers = 0;
@@ -2524,7 +2651,8 @@ rfx_finish* rfx_count_finish_begin(rfx_table* t, uint64_t lower, uint64_t upper,
   f->lower = lower;
   f->upper = upper;
   f->histo = histo;
-  if (!t->pend_error && !t->table_active && ((!t->segs->empty() && t->seg_kind == RFX_COUNT_MSP) || !t->deferred->empty())) {
+  if (!t->pend_error && !t->table_active &&
+      ((!t->segs->empty() && t->seg_kind == RFX_COUNT_MSP) || !t->deferred->empty() || (t->peers && t->passes >= 0))) {
     if (msp_emit_queue(f) != RFX_OK) f->failed = true;  // nothing waited for: the work is only queued
   } else {
     f->ready = rfx_count_finish(t, lower, upper, histo);  // paths without a queued form finish here
@@ -2555,6 +2683,8 @@ rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint
     return nullptr;
   }
   if (!t->deferred->empty() && !t->table_active) return msp_emit(t, lower, upper, histo);
+  // (a table of a device group that was given no read block still takes part: the others wait for it at the barriers)
+  if (t->peers && t->passes >= 0 && t->segs->empty() && !t->table_active) return msp_emit(t, lower, upper, histo);
   if (!t->segs->empty()) {
     if (!t->table_active) {
       if (t->seg_kind == RFX_COUNT_MSP) return msp_emit(t, lower, upper, histo);

@@ -300,18 +300,20 @@ def test_filter_sam_equals_feeder_plus_filter(tmp_path, shape):
 def test_executables_spread_a_sample_over_several_devices(testrun, tmp_path, gpus, k, size):
     """Row E-cli (runRufus.sh:776-797 calls binaries: the GPUs of a node must be reachable from them): with
     RUFUS_GPUS naming n devices -- here n contexts on the box's one GPU, the same code path -- `jellyfish count`
-    feeds every device every read block, each counts its minimizer shard, the survivors change hands by output
-    position and the .Jhash is the devices' slices one after the other: the bytes of the one-device run (and of the
-    golden payload).  `RUFUS.Filter` deals its pieces to the devices: the same Mutations.Mate1/2.fastq."""
+    deals the read blocks to the devices in turn, each partitions its blocks, the owners of the minimizer bins pull
+    their records, the survivors change hands by output position and the .Jhash is the devices' slices one after the
+    other: the bytes of the one-device run (and of the golden payload).  `RUFUS.Filter` deals its pieces to the devices: the same Mutations.Mate1/2.fastq."""
     d = str(tmp_path)
     exp = testrun["expected"]
     open(f"{d}/c.fq", "wb").write(testrun["Child"][0] + testrun["Child"][1])
-    env = dict(os.environ, RUFUS_GPUS=gpus, RFX_COUNT_HISTO="1")
-    for name, e in (("one", dict(os.environ, RFX_COUNT_HISTO="1")), ("many", env)):
+    # (small ingest pieces: the sample comes as several read blocks, dealt to the devices in turn)
+    env = dict(os.environ, RUFUS_GPUS=gpus, RFX_COUNT_HISTO="1", RFX_INGEST_PIECE="200000")
+    for name, e in (("one", dict(os.environ, RFX_COUNT_HISTO="1")), ("many", env), ("repl", dict(env, RFX_PEERS_REPLICATE="1"))):
         r = subprocess.run([f"{BIN}/jellyfish", "count", "--disk", "-m", str(k), "-L", "2", "-s", size, "-t", "4", "-o",
                             f"{name}.Jhash", "-C", "c.fq"], cwd=d, env=e, stderr=subprocess.PIPE)
         assert r.returncode == 0, r.stderr
     assert _payload(f"{d}/one.Jhash") == _payload(f"{d}/many.Jhash") and len(_payload(f"{d}/many.Jhash")) > 100_000
+    assert _payload(f"{d}/one.Jhash") == _payload(f"{d}/repl.Jhash")      # (round 3's scheme: every device every block)
     assert open(f"{d}/one.Jhash.histo", "rb").read() == open(f"{d}/many.Jhash.histo", "rb").read()
     if (k, size) == (25, "100M"):
         assert hashlib.sha256(_payload(f"{d}/many.Jhash")).hexdigest() == exp["samples"]["Child"]["s100M"]["payload_sha256"]

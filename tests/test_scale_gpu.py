@@ -413,16 +413,24 @@ def test_table_counts_a_sample_in_shard_passes(ctx, monkeypatch, passes, surv_fr
         b.free()
 
 
-@pytest.mark.parametrize("n_dev,passes,k,surv_frac", [(2, 1, 25, None), (3, 2, 25, "0.002"), (4, 0, 31, None), (8, 1, 27, None)])
-def test_tables_on_several_devices_make_one_sorted_payload(monkeypatch, n_dev, passes, k, surv_frac):
+@pytest.mark.parametrize("n_dev,passes,k,surv_frac,replicate",
+                         [(2, 1, 25, None, False), (3, 2, 25, "0.002", False), (4, 0, 31, None, False), (8, 1, 27, None, False),
+                          (5, 1, 25, None, False), (3, 2, 25, "0.002", True), (4, 0, 31, None, True)])
+def test_tables_on_several_devices_make_one_sorted_payload(monkeypatch, n_dev, passes, k, surv_frac, replicate):
     """SURVEY 8(e) / row E-cli at the C-ABI: n tables -- here n contexts on the ONE GPU of the box, the code path of n
-    devices (own arena, own stream, copies between contexts) -- are fed the same read blocks; table i counts minimizer
-    shard i (x its own shard passes), the survivors change hands by output position (rfx_count_set_peers), and the n
-    finishes, run concurrently, return slice i of the oracle's (pos,key)-ordered payload: concatenated, THE payload;
-    the histograms add up to the oracle's."""
+    devices (own arena, own stream, copies between contexts).  Table i is given read blocks i, i + n, ... ONLY
+    (runRufus.sh:776-797, `north_star`: shard by read block): in every shard pass it partitions its blocks, the owners
+    of the pass's minimizer-bin ranges pull their record runs from every table, count complete bins, and the
+    survivors change hands by output position (rfx_count_set_peers).  The n finishes, run concurrently, return slice i
+    of the oracle's (pos,key)-ordered payload: concatenated, THE payload; the histograms add up to the oracle's; a
+    table's k_msp_part1 launches are those of ITS blocks (x passes), not of the sample's.  With five tables and three
+    blocks two tables hold no read at all and still take part.  replicate: round 3's fallback scheme
+    (RFX_PEERS_REPLICATE=1 -- every table is given every block and keeps minimizer shard i)."""
     import threading
     if surv_frac:
         monkeypatch.setenv("RFX_MSP_SURV_FRAC", surv_frac)
+    if replicate:
+        monkeypatch.setenv("RFX_PEERS_REPLICATE", "1")
     sy = capi.Synth.sample(200_000, 0, n_snv=10, seed=77)
     n_pairs = 20_000
     seq, _ = sy.text(0, n_pairs)
@@ -434,11 +442,20 @@ def test_tables_on_several_devices_make_one_sorted_payload(monkeypatch, n_dev, p
     peers = capi.lib().rfx_peers_create(n_dev)
     assert peers
     tables, blocks = [], []
+    per_block = 7000                                    # pairs per block: three blocks
+    n_blocks = -(-n_pairs // per_block)
     for i, c in enumerate(ctxs):
-        bl = wgs.make_sample(c, sy, n_pairs, 7000, MIN_Q, want_good=False, compact=(i % 2 == 0))
+        bl = wgs.make_sample(c, sy, n_pairs, per_block, MIN_Q, want_good=False, compact=(i % 2 == 0))
+        assert len(bl) == n_blocks
+        if not replicate:                               # table i: blocks i, i + n, ...
+            for j, b in enumerate(bl):
+                if j % n_dev != i:
+                    b.free()
+            bl = [b for j, b in enumerate(bl) if j % n_dev == i]
         t = capi.CountTable(c, k, SIZE)
         t.set_passes(passes)
         t.set_peers(peers, i)
+        c.prof(True)
         for b in bl:
             t.add(b)
         tables.append(t)
@@ -457,6 +474,11 @@ def test_tables_on_several_devices_make_one_sorted_payload(monkeypatch, n_dev, p
     assert b"".join(rec.payload() for rec, _ in out) == ref.payload()
     assert sum(len(rec) for rec, _ in out) == len(ref.keys) and sum(1 for rec, _ in out if len(rec)) >= min(n_dev, 2)
     assert np.array_equal(sum(h for _, h in out), oracle.histo(ref.counts, full=True)[0])
+    if not replicate:   # a device hashes ITS reads only: one k_msp_part1 launch per own block and pass, none without a block
+        launches = [c.prof_dict().get("k_msp_part1", (0.0, 0))[1] for c in ctxs]
+        for i, (n_l, bl) in enumerate(zip(launches, blocks)):
+            assert (n_l == 0) == (len(bl) == 0) and n_l % max(len(bl), 1) == 0, (i, launches)
+        assert len(set(n_l // len(bl) for n_l, bl in zip(launches, blocks) if bl)) == 1, launches   # the same number of passes
     for (rec, _), t, bl, c in zip(out, tables, blocks, ctxs):
         rec.free()
         t.free()

@@ -46,6 +46,19 @@ K2_CHAIN = ("k_msp_part1", "k_msp_count", "k_bin_offsets", "k_rec_hist", "k_part
             "k_bin_count", "k_bin_scatter", "k_part1", "k_leaf", "k_leaf_compact", "k_count_reads")
 
 
+def kernel_source_fingerprint():
+    """sha256 (16 hex digits) over the sources the device code is built from: what a PMC profile must have been taken on
+    to be quoted by this build (profiles/summarize_pmc.py writes it into the JSON)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "rufus_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def algorithmic_bytes_per_read(L=READ_LEN, k=K):
     """ceil(L/4) code bytes + ceil(L/8) mask bytes + (L-k+1) windows x
     (8 B key read + 4 B count read + 4 B count write)."""
@@ -57,11 +70,10 @@ def cpu_baseline():
     of the synthetic trio, regenerated as text by the generator's host twin): the oracle's C++ port for
     count (lock-free CAS hash table, mirrors jf/include/jellyfish/large_hash_array.hpp:708-744) and set
     difference, the REAL reference binary oracle/_ref/RUFUS.Filter (built from /root/reference/src in the
-    build container) for the filter; at T = 1, 8, the CPUs the cgroup lets the process use (rfx_host_cpus: the GPU
-    box gives its container 16 CPUs' worth of time on 256 hardware threads) and nproc-2 (runRufus.sh:796,:967).
+    build container) for the filter; at T = 1, 8 and the CPUs the cgroup lets the process use (rfx_host_cpus: the GPU
+    box gives its container 16 CPUs' worth of time on 256 hardware threads).
     The filter leg runs on the first 60 k pairs of the subject and is scaled to the leg's read count: the
-    reference forks its OpenMP team once per 60 pairs (src/RUFUS.Filter.cpp:196), which at 254 threads takes
-    minutes per million pairs -- measured on the 256-core box, it is why the first version of this leg timed out."""
+    reference forks its OpenMP team once per 60 pairs (src/RUFUS.Filter.cpp:196)."""
     import oracle
     from rufus_amd import capi
     from tests.synth import synth_fastq
@@ -70,7 +82,9 @@ def cpu_baseline():
     out = {"unit": "reads/s", "kind": "port", "by_threads": {}, "usable_cpus": usable}
     exe = os.path.join(ROOT, "oracle", "_ref", "RUFUS.Filter")
     n_filter = 60_000
-    for T in sorted({1, min(8, ncpu), usable, max(1, ncpu - 2)}):
+    # (until round 3 a fourth leg ran at nproc - 2 = 254 threads, runRufus.sh:796,:967's choice: on the GPU box that
+    # measures its container's 16-CPU quota -- 3.9 k reads/s -- and cost 90 s of every run; dropped)
+    for T in sorted({1, min(8, ncpu), usable}):
         n_pairs = int(min(1_000_000, 40_000 * T ** 0.8))     # ~ equal wall time per leg
         G = n_pairs * 10
         sys_ = [capi.Synth.sample(G, w, n_snv=max(4, G // 1_000_000), seed=SEED) for w in range(3)]
@@ -325,6 +339,9 @@ def main():
     ap.add_argument("--e2e-pairs", type=int, default=32_000_000,
                     help="read pairs per sample of the end-to-end leg (refused when the text would not fit the container's memory)")
     ap.add_argument("--inner", action="store_true", help="(internal) the GPU part only, run by the launcher below")
+    ap.add_argument("--one-device", action="store_true",
+                    help="dry run of --gpus N on a one-GPU box: all ranks share device 0 (RFX_BENCH_BACKEND=gloo if RCCL refuses); "
+                         "the line is marked, its value is not a scaling measurement")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline()))
@@ -359,9 +376,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.one_device:     # dry run of the N-rank path on a one-GPU box: every rank on device 0
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("RFX_BENCH_BACKEND", "nccl")    # (gloo: when RCCL refuses two ranks on one device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=None if args.one_device else torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     ctx = capi.Context(local)   # raises without a gfx950 GPU: no CPU fallback
     step, reads_per_step, reads_per_launch, reads_filtered, desc, scaling, extra = (
@@ -435,6 +458,8 @@ def main():
                        "mutant_kmers": int(res["n_mutant"]), "pulled_pairs": int(res["n_pulled"]),
                        "records_per_sample": [int(x) for x in res["n_records"]], **extra,
                        "checked": checks is not None, "checks": checks,
+                       **({"one_device_dry_run": f"{world} ranks share device 0 over {dist.get_backend()}: the N-rank path is "
+                                                 "exercised, the value is NOT a scaling measurement"} if args.one_device and world > 1 else {}),
                        "hbm_peak_bytes": ctx.mem_stats()["peak"], "hbm_mapped_bytes": ctx.mem_stats()["mapped"]},
             "roofline": {"bound": "hbm", "kernel": "count chain of one sample: " + "+".join(k2), "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
@@ -449,14 +474,23 @@ def main():
                                 "ms_per_step": f_ms, "algorithmic_bytes_per_step": 61 * reads_filtered // world,
                                 "note": "rank 0's share"} if f_ms else None,
         }
+        # HBM traffic of the chain: PMC counters cannot be collected inside this run (rocprofv3 wraps the process), so the
+        # line quotes the newest profiles/rNN_pmc_<workload>.json -- but only if it was taken on THIS build: the file
+        # carries the fingerprint of the kernel sources it was measured with (kernel_source_fingerprint(); the snapshot a
+        # GPU box gets has no .git to ask), and a stale one is refused (traffic stays null, the reason is in the line).
         import glob
         pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_pmc_{args.workload}.json")))
         pmc_path = pmc_files[-1] if pmc_files else ""          # the newest round's counters
         if pmc_path:
             pmc = json.load(open(pmc_path))
-            if pmc.get("genome") in (None, getattr(args, "genome", None)) and "_chain" in pmc:
+            fp = kernel_source_fingerprint()
+            if pmc.get("kernel_sources_sha16") != fp:
+                line["roofline"]["traffic_source"] = (f"{os.path.basename(pmc_path)} refused: taken on kernel sources "
+                                                      f"{pmc.get('kernel_sources_sha16')}, this build is {fp}")
+            elif pmc.get("genome") in (None, getattr(args, "genome", None)) and "_chain" in pmc:
                 line["roofline"]["traffic"] = pmc["_chain"]["hbm_bytes_per_sample"]
-                line["roofline"]["traffic_source"] = os.path.basename(pmc_path) + ": " + pmc["_chain"].get("source", "")
+                line["roofline"]["traffic_source"] = (os.path.basename(pmc_path) + f" (commit {pmc.get('commit')}, kernel sources "
+                                                      f"{fp}): " + pmc["_chain"].get("source", ""))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -60,6 +60,13 @@ def main():
                                    "launches of the count chain of the profiled bench command / sample chains"}
         if len(sys.argv) > 5:
             out["genome"] = int(sys.argv[5])
+    # what build this was measured on: bench.py quotes the traffic only when its own kernel sources have this fingerprint
+    # (the round-3 file was taken before the last kernel change and quoted regardless)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["kernel_sources_sha16"] = bench.kernel_source_fingerprint()
+    out["commit"] = os.environ.get("RFX_COMMIT", "unknown (set RFX_COMMIT=$(git rev-parse HEAD) when profiling)")
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     if "_chain" in out:
         print(f"count chain: {out['_chain']['hbm_bytes_per_sample'] / 1e6:.1f} MB per sample over {samples} samples")

@@ -579,3 +579,42 @@ def test_records_load_fd_streams_a_file_in_chunks(ctx, tmp_path):
             os.close(fd)
     for x in blocks + [t, rec]:
         x.free()
+
+
+def test_bench_two_ranks_share_the_device(tmp_path):
+    """Readiness for a multi-GPU node: `bench.py --gpus 2 --one-device` runs the N-rank path -- rank
+    g holds its share of every sample, partition of block i + 1 under the exchange of block i, records to the bin
+    owners through dist.exchange_rows (grouped isend / irecv in pieces), histogram all-reduce, hash list all-gather --
+    with a REAL second rank, both on the box's one GPU: over RCCL if it accepts two ranks on one device, else over
+    gloo.  Same mutant k-mers, pulled pairs and record counts as the one-rank run of the same genome."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    flags = ["--genome", "60000000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-end-to-end", "--no-check"]
+    one = subprocess.run([sys.executable, "bench.py", "--inner"] + flags, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert one.returncode == 0, one.stderr[-2000:]
+    ref = json.loads(one.stdout.decode().strip().splitlines()[-1])
+    line, used = None, None
+    for backend in ("nccl", "gloo"):
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        env = dict(os.environ, RFX_BENCH_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        try:
+            p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--one-device"] + flags,
+                               cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        except subprocess.TimeoutExpired:
+            continue
+        out = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+        if p.returncode == 0 and out:
+            line, used = json.loads(out[-1]), backend
+            break
+    assert line is not None, "neither RCCL nor gloo ran two ranks on the one device"
+    print(f"two ranks on one device over {used}: {line['value'] / 1e6:.0f} M reads/s")
+    assert line["n_gpus"] == 2 and used in line["config"]["one_device_dry_run"]
+    for key in ("mutant_kmers", "pulled_pairs", "records_per_sample"):
+        assert line["config"][key] == ref["config"][key], key

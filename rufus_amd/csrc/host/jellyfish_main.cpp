@@ -43,12 +43,18 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   // stage that reads the same stream next (RUFUS.Filter on the subject, runRufus.sh:966) reads FILE instead of
   // running the subject's generator -- `samtools view` of a BAM -- a second time (`RUFUS.Filter --sam CHR HashList FILE ...`).
   const char* spool_path = nullptr;
-  enum { OPT_DISK = 1000, OPT_OCL, OPT_TIMING, OPT_TEXT, OPT_SAM, OPT_SPOOL };
+  // --keep-packed FILE [--keep-minq Q] (not in jellyfish; SURVEY 8 row N2, with --sam): the parser threads also leave the
+  // records as RUFUS.Filter would see them -- printed orientation, packed for MinQ Q (default 15), name hash, place in
+  // the stream -- in FILE (rfx_packed_cache.hpp; put it in /dev/shm): `RUFUS.Filter --packed FILE CHR HashList SPOOL ...`
+  // scans that instead of parsing the stream a second time.
+  const char* keep_path = nullptr;
+  int keep_minq = 15;
+  enum { OPT_DISK = 1000, OPT_OCL, OPT_TIMING, OPT_TEXT, OPT_SAM, OPT_SPOOL, OPT_KEEP, OPT_KEEPQ };
   static option lo[] = {{"mer-len", 1, 0, 'm'},      {"size", 1, 0, 's'},        {"threads", 1, 0, 't'},
                         {"output", 1, 0, 'o'},       {"counter-len", 1, 0, 'c'}, {"out-counter-len", 1, 0, OPT_OCL},
                         {"canonical", 0, 0, 'C'},    {"disk", 0, 0, OPT_DISK},   {"lower-count", 1, 0, 'L'},
                         {"upper-count", 1, 0, 'U'},  {"timing", 1, 0, OPT_TIMING}, {"text", 0, 0, OPT_TEXT}, {"sam", 1, 0, OPT_SAM},
-                        {"spool", 1, 0, OPT_SPOOL},
+                        {"spool", 1, 0, OPT_SPOOL},  {"keep-packed", 1, 0, OPT_KEEP}, {"keep-minq", 1, 0, OPT_KEEPQ},
                         {"reprobes", 1, 0, 'p'},     {0, 0, 0, 0}};
   optind = 1;
   int ch;
@@ -68,6 +74,8 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
       case OPT_TIMING: timing = optarg; break;
       case OPT_SAM: sam_chr = optarg; break;
       case OPT_SPOOL: spool_path = optarg; break;
+      case OPT_KEEP: keep_path = optarg; break;
+      case OPT_KEEPQ: keep_minq = atoi(optarg); break;
       case OPT_TEXT: die("rufus_amd jellyfish: --text output is not on the RUFUS path");
       default: die("Usage: jellyfish count -m K -s SIZE [-C] [-L n] [-U n] [-t T] [-o OUT] [--disk] file...");
     }
@@ -133,6 +141,8 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     if (!any_stream && known_bytes > min_bytes && !getenv("RFX_NO_PREALLOC"))
       prealloc.start(out, (uint64_t)((double)known_bytes * frac));
   }
+  if (keep_path && (!sam_chr || inputs.size() != 1))
+    die("rufus_amd jellyfish count: --keep-packed goes with --sam and ONE input (a pipe with --spool, or a SAM file)");
   if (spool_path && (!any_stream || inputs.size() != 1))
     die("rufus_amd jellyfish count: --spool copies ONE piped input; a regular file can be given to the next stage as it is");
   unsigned nthreads = (unsigned)std::max(1, threads);
@@ -197,7 +207,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   {
     for (Input& in : inputs) {
       bool done = false;
-      if (nthreads > 1 || sam_chr || spool_path) {
+      if (nthreads > 1 || sam_chr || spool_path || keep_path) {
         if (!ingest) {
           ingest.reset(new CountIngest(nthreads, [&](const StageBlock& b) {
             to_all([&](rfx_ctx* c) { return rfx_reads_upload(c, b.codes, b.acgt, nullptr, b.word_off, b.len, b.n_reads); });
@@ -207,6 +217,11 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
             const int sfd = ::open(spool_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
             if (sfd < 0) die(std::string("Can't open spool file '") + spool_path + "'");
             ingest->set_spool(sfd);
+          }
+          if (keep_path) {
+            const int kfd = ::open(keep_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (kfd < 0) die(std::string("Can't open the packed-read cache '") + keep_path + "'");
+            ingest->set_keep_packed(kfd, keep_minq);
           }
           if (const char* ev = getenv("RFX_INGEST_PIECE")) ingest->set_piece_bytes((size_t)std::max(1024ll, atoll(ev)));
           trace("count: staging blocks pinned, workers up");

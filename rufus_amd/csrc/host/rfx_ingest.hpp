@@ -30,6 +30,9 @@
 
 #include "rfx_cli.hpp"
 
+#include "rfx_sam.hpp"
+#include "rfx_packed_cache.hpp"
+
 namespace rfxcli {
 
 // The stream cutter's line count.  Fast pass: newlines of [p, e) and how many of them are blank lines (a '\n' at a
@@ -117,6 +120,11 @@ class CountIngest {
   };
   int spool_fd_ = -1;          // set_spool: the stream is also written to this file, piece by piece, by the workers
   uint64_t spooled_ = 0;
+  // set_keep_packed (`jellyfish count --sam .. --keep-packed FILE`): every SAM piece also leaves a chunk
+  // of the packed-read cache `RUFUS.Filter --packed` scans (rfx_packed_cache.hpp) -- the records as the filter would
+  // see them, packed once, here, by the threads that parse the text anyway
+  int cache_fd_ = -1, cache_minq_ = 0;
+  std::atomic<uint64_t> cache_at_{0};
   std::deque<Piece> work_;
   std::deque<int> ready_, free_;
   std::deque<std::vector<char>*> pool_;
@@ -238,6 +246,7 @@ class CountIngest {
     start.reserve(1 << 17);
     slen.reserve(1 << 17);
     std::vector<std::string> runs;
+    rfxcache::ChunkBuilder cache;
     const char *p = pc.b, *e = pc.e;
     const char* cur_chr = nullptr;
     size_t cur_len = 0;
@@ -265,7 +274,29 @@ class CountIngest {
       const char* sq_e = nt >= 10 ? tab[9] : le;
       start.push_back((uint64_t)(sq - pc.b));
       slen.push_back((uint32_t)(sq_e - sq));
+      if (cache_fd_ >= 0 && nt >= 10) {  // (fewer than 11 fields: no record for the filter -- the feeders skip the line)
+        const char* ql = tab[9] + 1;
+        const char* ql_e = (const char*)memchr(ql, '\t', (size_t)(le - ql));
+        if (!ql_e) ql_e = le;
+        cache.add(pc.b, p, le, p, tab[0], tab[0] + 1, tab[1], sq, sq_e, ql, ql_e);
+      }
       p = nl ? nl + 1 : e;
+    }
+    if (cache_fd_ >= 0) {
+      std::vector<char> chunk;
+      cache.finish(pc.seq, pc.spool_off, runs, cache_minq_, chunk);
+      const uint64_t at = cache_at_.fetch_add(chunk.size());
+      const char* w = chunk.data();
+      size_t len = chunk.size();
+      off_t o = (off_t)at;
+      while (len) {
+        const ssize_t n = ::pwrite(cache_fd_, w, len, o);
+        if (n < 0 && errno == EINTR) continue;
+        if (n <= 0) die(std::string("write error on the packed-read cache: ") + strerror(errno));
+        w += n;
+        len -= (size_t)n;
+        o += n;
+      }
     }
     {
       std::lock_guard<std::mutex> g(mu_);
@@ -518,6 +549,14 @@ class CountIngest {
   // next -- RUFUS.Filter after the subject's count, runRufus.sh:966 after scripts/RunJellyForRUFUS.sh:28 -- need not run
   // the generator (samtools view of a BAM) a second time.  Written piece by piece by the parser threads (pwrite).
   void set_spool(int fd) { spool_fd_ = fd; }
+  void set_keep_packed(int fd, int min_q) {
+    cache_fd_ = fd;
+    cache_minq_ = min_q;
+    rfxcache::FileHeader h;
+    h.min_q = min_q;
+    if (::pwrite(fd, &h, sizeof h, 0) != (ssize_t)sizeof h) die("write error on the packed-read cache");
+    cache_at_ = sizeof h;
+  }
   uint64_t spooled_bytes() const { return spooled_; }
   // PassThroughSamCheck's side file: "notachr", then the name of every run of equal RNAME, in stream order
   std::vector<std::string> chr_log() {
@@ -542,6 +581,7 @@ class CountIngest {
       } else cut = record_start(want, b, e);
       Piece pc{at, cut, nullptr};
       pc.seq = next_seq_++;
+      pc.spool_off = (uint64_t)(at - b);  // (a regular file is its own spool)
       push_piece(pc);
       at = cut;
       drain(false);

@@ -22,7 +22,10 @@
 using namespace rfxcli;
 
 #ifndef RFX_SINGLE_END
+#include <unordered_set>
+
 #include "rfx_sam.hpp"
+#include "rfx_packed_cache.hpp"
 // ---- RUFUS.Filter --sam CHRFILE HashList SAM|stdin STUB K MinQ HashCountThreshold Threads -----------------------------
 // SURVEY row N1, filter half.  runRufus.sh:964-967 runs `generator | PassThroughSamCheck.stranded CHR STUB.temp` into two
 // named pipes that RUFUS.Filter reads in lock step: SAM text -> pairing by QNAME -> FASTQ text -> two pipes -> parsed
@@ -485,12 +488,180 @@ static int run(int argc, char** argv) {
   printf("\nDone running RUFUS.Filter.cpp\n");
   return 0;
 }
+
+// `RUFUS.Filter --packed CACHE CHRFILE PreBuiltMutHash SPOOL firstpassfile hashsize MinQ HashCountThreshold threads`
+// (rfx_packed_cache.hpp): the subject's records were packed once, by `jellyfish count --sam ..
+// --keep-packed CACHE`.  Here they are uploaded as they lie in CACHE and scanned; only the lines of the names with a hit
+// are gathered from SPOOL (the stream's bytes: `--spool`, or the SAM file itself) and go through the text route above.
+static int run_packed(int argc, char** argv) {
+  printf("Call is --packed CACHE CHRFILE PreBuiltMutHash SPOOL firstpassfile hashsize MinQ HashCountThreshold threads\n");
+  if (argc < 11) {
+    printf("ERROR: expected 10 arguments\n");
+    return 0;
+  }
+  const char *cache_path = argv[2], *chr_path = argv[3], *hashlist = argv[4], *spool = argv[5];
+  const int k = atoi(argv[7]), min_q = atoi(argv[8]), thresh = atoi(argv[9]);
+  auto text_route = [&](const char* sam_path, const char* chr_to) {  // the ordinary --sam route on `sam_path`
+    std::vector<std::string> a{argv[0], "--sam", chr_to, hashlist, sam_path, argv[6], argv[7], argv[8], argv[9], argv[10]};
+    std::vector<char*> av;
+    for (std::string& x : a) av.push_back(&x[0]);
+    return run((int)av.size(), av.data());
+  };
+  // the cache and the spool, mapped
+  struct Map {
+    const char* p = nullptr;
+    size_t n = 0;
+    bool open(const char* path) {
+      const int fd = ::open(path, O_RDONLY);
+      struct stat sb;
+      if (fd < 0 || fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) { if (fd >= 0) ::close(fd); return false; }
+      n = (size_t)sb.st_size;
+      if (n) {
+        void* m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { ::close(fd); return false; }
+        p = (const char*)m;
+      }
+      ::close(fd);
+      return true;
+    }
+  } cm, sm;
+  std::vector<rfxcache::ChunkView> chunks;
+  int cached_q = 0;
+  if (!sm.open(spool)) {
+    printf("Error, MutFile could not be opened");
+    return 0;
+  }
+  if (!cm.open(cache_path) || !rfxcache::read_chunks(cm.p, cm.n, cached_q, chunks) || cached_q != min_q) {
+    // no cache, a cache of another stream length, or packed for another MinQ: the text decides
+    fprintf(stderr, "rufus_amd RUFUS.Filter: %s is not a usable packed-read cache for MinQ %d: scanning the text\n", cache_path, min_q);
+    return text_route(spool, chr_path);
+  }
+  std::string text;
+  {
+    std::ifstream f(hashlist, std::ios::binary);
+    if (!f.is_open()) {
+      printf("Error, ParentHashFile could not be opened");
+      return 0;
+    }
+    text.assign(std::istreambuf_iterator<char>(f), std::istreambuf_iterator<char>());
+  }
+  if (k < 1 || k > 32) die("rufus_amd RUFUS.Filter: hash size must be 1..32");
+  const long nk = rfx_hashlist_keys(text.data(), text.size(), k, 0, nullptr, 0);
+  if (nk < 0) die("rufus_amd: cannot parse the hash list");
+  std::vector<uint64_t> keys((size_t)nk + 1);
+  rfx_hashlist_keys(text.data(), text.size(), k, 0, keys.data(), keys.size());
+  std::unordered_set<uint64_t> hit_names;
+  uint64_t n_rec = 0, n_hit = 0, n_always = 0;
+  {
+    const std::vector<int> gpus = gpu_list();
+    std::vector<rfx_ctx*> ctxs = open_ctxs(gpus);
+    std::vector<rfx_set*> sets;
+    for (rfx_ctx* c : ctxs) {
+      rfx_set* st = rfx_set_build(c, keys.data(), (uint64_t)nk, k);
+      if (!st) die(std::string("rufus_amd: ") + rfx_last_error());
+      sets.push_back(st);
+    }
+    trace("filter --packed: device open, set built");
+    // chunk i goes to device i mod N; one thread per device uploads and scans (the arrays lie in the cache as the
+    // upload wants them: no parsing, no packing)
+    std::mutex mu;
+    std::vector<std::thread> th;
+    for (size_t d = 0; d < ctxs.size(); ++d)
+      th.emplace_back([&, d] {
+        std::vector<uint64_t> mask;
+        std::vector<uint64_t> local;
+        uint64_t rec = 0, hit = 0, always = 0;
+        for (size_t i = d; i < chunks.size(); i += ctxs.size()) {
+          const rfxcache::ChunkView& v = chunks[i];
+          const uint32_t n = v.h->n;
+          if (!n) continue;
+          mask.assign(((size_t)n + 63) / 64, 0);
+          rfx_reads* rd = rfx_reads_upload(ctxs[d], v.codes, nullptr, v.good, v.word_off, v.len, n);
+          if (!rd) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
+          uint64_t nh = 0;
+          const int rc = rfx_filter(sets[d], rd, thresh, 1, nullptr, mask.data(), &nh);
+          rfx_reads_free(rd);
+          if (rc) die(std::string("rufus_amd: filter failed: ") + rfx_last_error());
+          for (uint32_t r = 0; r < n; ++r) {
+            const bool al = v.flags[r] & rfxcache::REC_ALWAYS;
+            if (al || ((mask[r >> 6] >> (r & 63)) & 1)) {
+              local.push_back(v.hash[r]);
+              if (al) ++always; else ++hit;
+            }
+          }
+          rec += n;
+        }
+        std::lock_guard<std::mutex> g(mu);
+        hit_names.insert(local.begin(), local.end());
+        n_rec += rec;
+        n_hit += hit;
+        n_always += always;
+      });
+    for (auto& t : th) t.join();
+    for (rfx_set* st : sets) rfx_set_free(st);
+    for (rfx_ctx* c : ctxs) rfx_close(c);
+  }
+  trace("filter --packed: cache scanned");
+  // every line whose name (hash) has a hit, in stream order
+  std::string mini;
+  uint64_t n_lines = 0;
+  for (const rfxcache::ChunkView& v : chunks)
+    for (uint32_t r = 0; r < v.h->n; ++r)
+      if (hit_names.count(v.hash[r])) {
+        const uint64_t at = v.h->stream_off + v.line_off[r];
+        if (at + v.line_len[r] > sm.n) die("rufus_amd RUFUS.Filter --packed: the cache does not belong to this spool (a line lies behind its end)");
+        mini.append(sm.p + at, v.line_len[r]);
+        mini.push_back('\n');
+        ++n_lines;
+      }
+  printf("\npacked cache: %llu records scanned, %llu hit, %llu left to the text route outright; %llu lines gathered\n",
+         (unsigned long long)n_rec, (unsigned long long)n_hit, (unsigned long long)n_always, (unsigned long long)n_lines);
+  // the chromosome log of the WHOLE stream (src/PassThroughSamCheck.stranded.cpp: "notachr", then every run of RNAME)
+  {
+    FILE* chr = fopen(chr_path, "w");
+    if (!chr) {
+      printf("ERROR, Output file could not be opened -%s\n", chr_path);
+      return 0;
+    }
+    std::string current = "notachr";
+    for (const rfxcache::ChunkView& v : chunks) {
+      const char *p = v.runs, *e = v.runs + v.h->runs_bytes;
+      while (p < e) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(e - p));
+        if (!nl) nl = e;
+        if (current.size() != (size_t)(nl - p) || memcmp(current.data(), p, current.size()) != 0) {
+          fprintf(chr, "%s\n", current.c_str());
+          current.assign(p, (size_t)(nl - p));
+        }
+        p = nl + 1;
+      }
+    }
+    fprintf(chr, "%s\n", current.c_str());
+    fclose(chr);
+  }
+  // the gathered lines through the text route (a file the route can map; its own chromosome log is not the stream's)
+  const char* tmpdir = access("/dev/shm", W_OK) == 0 ? "/dev/shm" : "/tmp";
+  std::string tmp = std::string(tmpdir) + "/rfx_packed_XXXXXX";
+  const int tfd = mkstemp(&tmp[0]);
+  if (tfd < 0) die("rufus_amd RUFUS.Filter --packed: cannot create a temporary file");
+  for (size_t at = 0; at < mini.size();) {
+    const ssize_t w = ::write(tfd, mini.data() + at, mini.size() - at);
+    if (w < 0 && errno == EINTR) continue;
+    if (w <= 0) die("rufus_amd RUFUS.Filter --packed: write error on the temporary file");
+    at += (size_t)w;
+  }
+  ::close(tfd);
+  const int rc = text_route(tmp.c_str(), "/dev/null");
+  ::unlink(tmp.c_str());
+  return rc;
+}
 }  // namespace samf
 #endif
 
 int main(int argc, char** argv) {
 #ifndef RFX_SINGLE_END
   if (argc > 1 && strcmp(argv[1], "--sam") == 0) return samf::run(argc, argv);
+  if (argc > 1 && strcmp(argv[1], "--packed") == 0) return samf::run_packed(argc, argv);
 #endif
 #ifdef RFX_SINGLE_END
   const int need = 8;

@@ -8,6 +8,8 @@
 #include <algorithm>
 #include <map>
 #include <numeric>
+#include <condition_variable>
+#include <mutex>
 #include <unordered_map>
 
 #include "../../rufus_amd/csrc/host/jellyfish_main.cpp"
@@ -17,13 +19,23 @@ struct rfx_reads {
   std::vector<uint64_t> codes;
   std::vector<uint32_t> acgt, woff, len;
 };
-struct rfx_peers { int n; };
+// (round 4: the tool deals the read blocks to the devices in turn; the tables of a group pool their counts at finish --
+// RFX_PEERS_REPLICATE=1: every table is given every block, nothing to pool)
+struct rfx_peers {
+  int n;
+  bool replicate = getenv("RFX_PEERS_REPLICATE") != nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  int merged = 0;
+  std::unordered_map<uint64_t, uint64_t> total;
+};
 struct rfx_table {
   int k, canonical, lsize;
   uint64_t pos_lo, pos_hi;
   std::vector<uint64_t> cols;
   std::unordered_map<uint64_t, uint64_t> counts;
   int peer_index = 0, peer_n = 1;
+  rfx_peers* peers = nullptr;
 };
 struct rfx_records {
   int k, lsize;
@@ -73,7 +85,11 @@ rfx_reads* rfx_reads_upload(rfx_ctx*, const uint64_t* codes, const uint32_t* acg
 }
 void rfx_reads_free(rfx_reads* r) { delete r; }
 
-rfx_peers* rfx_peers_create(int n) { return new rfx_peers{n}; }
+rfx_peers* rfx_peers_create(int n) {
+  rfx_peers* p = new rfx_peers;
+  p->n = n;
+  return p;
+}
 void rfx_peers_free(rfx_peers* p) { delete p; }
 
 rfx_table* rfx_count_begin(rfx_ctx*, int k, int canonical, int lsize, uint64_t, uint64_t pos_lo, uint64_t pos_hi) {
@@ -95,6 +111,7 @@ int rfx_count_set_passes(rfx_table*, int) { return RFX_OK; }
 int rfx_count_set_peers(rfx_table* t, rfx_peers* p, int index) {
   t->peer_index = index;
   t->peer_n = p->n;
+  t->peers = p;
   return RFX_OK;
 }
 // every k-mer of every read: jf/include/jellyfish/mer_iterator.hpp:59-88 (a base that is not ACGT restarts the window)
@@ -121,6 +138,14 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
 void rfx_count_free(rfx_table* t) { delete t; }
 
 rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {
+  if (t->peers && !t->peers->replicate) {  // the group's tables hold disjoint read blocks: pool the counts, then all go on
+    rfx_peers* p = t->peers;
+    std::unique_lock<std::mutex> g(p->mu);
+    for (const auto& e : t->counts) p->total[e.first] += e.second;
+    if (++p->merged == p->n) p->cv.notify_all();
+    p->cv.wait(g, [&] { return p->merged >= p->n; });
+    t->counts = p->total;
+  }
   std::vector<std::pair<uint64_t, uint32_t>> kv;
   const uint64_t hi = t->pos_hi ? t->pos_hi : (t->lsize >= 64 ? ~0ull : 1ull << t->lsize);
   for (const auto& e : t->counts) {

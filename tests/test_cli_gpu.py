@@ -437,6 +437,77 @@ def test_subject_stream_is_ingested_once_through_a_spool(tmp_path):
         assert got == open(f"{d}/two.Mutations.Mate{m}.fastq", "rb").read() and got.count(b"\n") >= 4 * 15
 
 
+def test_subject_is_parsed_once_and_filtered_from_the_packed_cache(tmp_path):
+    """SURVEY 8 row N2, for real: `jellyfish count --sam CHR --spool SPOOL --keep-packed CACHE` packs every record once --
+    as RUFUS.Filter would see it -- while it counts; `RUFUS.Filter --packed CACHE CHR HashList SPOOL ...` scans the
+    cache and touches text only for the names with a hit (scripts/RunJellyForRUFUS.sh:28 + runRufus.sh:966 without the
+    second parse).  Mutations.Mate1/2 and the chromosome log are byte for byte those of the text route (`--sam`) and of
+    the reference route (stranded feeder -> two FASTQ files -> filter) -- on a stream with reverse-strand records,
+    names that come three times, a record whose bases the feeder would drop (IUPAC), a short quality string, records
+    out of coordinate order; the count is the count without the cache.  A cache packed for another MinQ is not used."""
+    from tests.test_cli_host import make_sam
+    d = str(tmp_path)
+    rng = np.random.default_rng(11)
+    lines = [ln for ln in make_sam(3000, seed=23).split(b"\n") if ln]
+    f = [ln.split(b"\t") for ln in lines]
+    # awkward records: an IUPAC base on a reverse-strand record, a quality string shorter than its read, a third record
+    # of a name, an empty mate far away in the stream
+    for j in (40, 41, 900):
+        if int(f[j][1]) & 16:
+            f[j][9] = f[j][9][:70] + b"R" + f[j][9][71:]
+    f[100][10] = f[100][10][:90]
+    f.append(list(f[200]))
+    f.append([b"lonely"] + f[300][1:])
+    order = np.arange(len(f))
+    sub = order[1000:1400].copy()
+    rng.shuffle(sub)
+    order[1000:1400] = sub
+    sam = b"".join(b"\t".join(f[i]) + b"\n" for i in order)
+    open(f"{d}/in.sam", "wb").write(sam)
+    env = dict(os.environ, RFX_INGEST_PIECE="40000")
+    cmd = [f"{BIN}/jellyfish", "count", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "5", "-C"]
+    r = subprocess.run(cmd + ["--sam", "a.chr", "--spool", "spool.sam", "--keep-packed", "cache.bin", "-o", "a.Jhash", "/dev/stdin"],
+                       cwd=d, env=env, input=sam, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    assert open(f"{d}/spool.sam", "rb").read() == sam and os.path.getsize(f"{d}/cache.bin") > len(lines) * 60
+    r = subprocess.run(cmd + ["--sam", "b.chr", "-o", "b.Jhash", "in.sam"], cwd=d, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and _payload(f"{d}/a.Jhash") == _payload(f"{d}/b.Jhash")
+    # the cache of a SAM FILE (no pipe, no spool: the file is its own spool)
+    r = subprocess.run(cmd + ["--sam", "c.chr", "--keep-packed", "cache2.bin", "-o", "c.Jhash", "in.sam"], cwd=d, env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 0 and _payload(f"{d}/c.Jhash") == _payload(f"{d}/b.Jhash")
+    fields = [ln.split(b"\t") for ln in sam.split(b"\n") if ln.count(b"\t") >= 10]
+    kmers = [fields[j][9][30:55] for j in rng.choice(len(fields), 60, replace=False) if set(fields[j][9][30:55]) <= set(b"ACGT")]
+    kmers += [fields[j][9][60:85] for j in (40, 100) if set(fields[j][9][60:85]) <= set(b"ACGT")]
+    open(f"{d}/hl", "wb").write(b"".join(km + b" 9\n" for km in kmers))
+    runs = {"packed": ["--packed", "cache.bin", "packed.chr", "hl", "spool.sam", "packed", "25", "15", "1", "4"],
+            "packed2": ["--packed", "cache2.bin", "packed2.chr", "hl", "in.sam", "packed2", "25", "15", "1", "4"],
+            "otherq": ["--packed", "cache.bin", "otherq.chr", "hl", "spool.sam", "otherq", "25", "20", "1", "4"],
+            "text": ["--sam", "text.chr", "hl", "spool.sam", "text", "25", "15", "1", "4"],
+            "text20": ["--sam", "text20.chr", "hl", "spool.sam", "text20", "25", "20", "1", "4"]}
+    out = {}
+    for name, a in runs.items():
+        r = subprocess.run([f"{BIN}/RUFUS.Filter"] + a, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0, r.stderr
+        out[name] = r
+    r = subprocess.run(f"{BIN}/PassThroughSamCheck.stranded ref.chr ref < in.sam > ref.log && "
+                       f"{BIN}/RUFUS.Filter hl ref.mate1.fastq ref.mate2.fastq ref 25 15 1 4", shell=True, cwd=d,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    for m in (1, 2):
+        want = open(f"{d}/text.Mutations.Mate{m}.fastq", "rb").read()
+        assert want == open(f"{d}/ref.Mutations.Mate{m}.fastq", "rb").read() and want.count(b"\n") >= 4 * 20
+        assert open(f"{d}/packed.Mutations.Mate{m}.fastq", "rb").read() == want
+        assert open(f"{d}/packed2.Mutations.Mate{m}.fastq", "rb").read() == want
+        assert open(f"{d}/otherq.Mutations.Mate{m}.fastq", "rb").read() == open(f"{d}/text20.Mutations.Mate{m}.fastq", "rb").read()
+    for name in ("packed", "packed2", "otherq"):
+        assert open(f"{d}/{name}.chr", "rb").read() == open(f"{d}/text.chr", "rb").read() == open(f"{d}/ref.chr", "rb").read()
+    # the scan ran on the cache, and only a fraction of the lines was touched as text
+    msg = out["packed"].stdout.decode()
+    got = [int(x) for x in msg.split("packed cache: ")[1].replace(",", " ").replace(";", " ").split() if x.isdigit()]
+    assert got[0] == len(fields) and 0 < got[3] < len(fields) // 2 and got[2] >= 3, msg    # (a 20 kb genome: every k-mer hits ~17 reads)
+    assert b"not a usable packed-read cache" in out["otherq"].stderr and b"packed cache:" not in out["otherq"].stdout
+
+
 def test_round3_tools_on_edge_inputs(testrun, tmp_path):
     """Corners of the round-3 additions: `RUFUS.Filter --sam` on an empty stream, on lines with too few fields, with
     HashCountThreshold 2 (both against the two-process route); `jellyfish count --spool` on a FASTQ pipe; one of

@@ -187,9 +187,10 @@ int rfx_synth_genome(const rfx_synth*, uint64_t first, uint64_t n, char* out);
 rfx_table* rfx_count_begin(rfx_ctx*, int k, int canonical, int lsize, uint64_t capacity_slots, uint64_t pos_lo,
                            uint64_t pos_hi);
 /* Three exact implementations sit behind rfx_count_add(); results are identical.
- *  RFX_COUNT_MSP   (23 <= k <= 31) cuts reads into super-k-mers (runs of consecutive k-mers sharing a
- *                  minimizer bin, 8 bytes per <= 4 k-mers), partitions those, counts every bin in LDS and
- *                  sorts only the surviving (key,count) pairs into (pos,key) order.  Fastest, least HBM.
+ *  RFX_COUNT_MSP   (23 <= k <= 31) cuts reads into super-k-mers (ALL consecutive k-mers of a read that share their
+ *                  minimizer: one record of 12 bytes -- a 64-bit word + a 32-bit plane -- per ~5.7 k-mers at k = 25),
+ *                  partitions those, counts every bin in LDS and sorts only the surviving (key,count) pairs into
+ *                  (pos,key) order.  Fastest, least HBM.
  *  RFX_COUNT_P2L   (2k <= 62) partitions one 8-byte sortable word per k-mer instance by (pos,key) prefix
  *                  and counts + sorts every bin in LDS.
  *  RFX_COUNT_TABLE inserts into an open-addressed table in HBM (any k, grows by rehash; also what
@@ -219,18 +220,23 @@ int rfx_count_set_shard(rfx_table*, int shard, int n_shards);
 int rfx_count_set_passes(rfx_table*, int passes);
 int rfx_count_add(rfx_table*, const rfx_reads*);
 /* Several devices behind ONE executable (runRufus.sh:776-797 calls binaries, so the N GPUs of a node have
- * to be reachable from `jellyfish count` itself, RUFUS_GPUS=0-7).  N tables, one per device, are fed the SAME read
- * blocks; table i counts minimizer shard i of N (every instance of a canonical k-mer has the same minimizer: disjoint
- * k-mer sets, exact counts, no reduce -- the zero-exchange scheme of SURVEY 8(e), "every GPU scans all reads, inserts
- * only its key range").  Before the survivors are sorted they change hands once (device-to-device, pulled by the
- * receiver over xGMI) so that table i ends up with slice i of the OUTPUT POSITIONS: rfx_count_finish of table i
- * returns slice i of the (pos,key)-ordered payload, and the .Jhash is the slices one after the other -- the owner
- * partition of jf's sorted dumper (jf/include/jellyfish/sorted_dumper.hpp:80-112) without a merge.
+ * to be reachable from `jellyfish count` itself, RUFUS_GPUS=0-7).  N tables, one per device.  Each is given ITS read
+ * blocks only -- block b goes to table b mod N: the sample is sharded by read block, a device uploads and hashes 1/N of
+ * it.  At finish, pass by pass, every table partitions its blocks; the minimizer bins of a pass are cut into N owner
+ * ranges (the cut of rfx_count_set_shard, the same on every device) and table g PULLS the record runs of its range
+ * from every table (device-to-device, xGMI) before it counts them: every instance of a canonical k-mer has the same
+ * minimizer, so an owner sees complete bins -- exact counts, no partial sums, no reduce (runRufus.sh shards by
+ * chromosome on the CPU; here by read block and minimizer owner).  Before the survivors are sorted they change hands
+ * once more so that table i ends up with slice i of the OUTPUT POSITIONS: rfx_count_finish of table i returns slice i
+ * of the (pos,key)-ordered payload, and the .Jhash is the slices one after the other -- the owner partition of jf's
+ * sorted dumper (jf/include/jellyfish/sorted_dumper.hpp:80-112) without a merge.  A table that was given no block
+ * still takes part.  (RFX_PEERS_REPLICATE=1 in the environment when the group is created: round 3's fallback -- every
+ * table is given EVERY block and keeps minimizer shard i of N; only survivors change hands.)
  *   rfx_ctx_allow_peers   before the first allocation of a ctx: the devices that may read its memory directly
  *   rfx_peers_create(n)   the meeting point of n tables
  *   rfx_count_set_peers   after rfx_count_set_passes, before the first add: this table is number `index` of the group
- * The n rfx_count_finish calls must run concurrently (one host thread each): they meet at two barriers; if one fails
- * they all fail. */
+ * The n rfx_count_finish calls must run concurrently (one host thread each): they meet at barriers (two to agree on the
+ * number of passes, two per pass, two for the survivors); if one fails they all fail. */
 typedef struct rfx_peers rfx_peers;
 int rfx_ctx_allow_peers(rfx_ctx*, const int* devices, int n);
 rfx_peers* rfx_peers_create(int n);
@@ -249,10 +255,11 @@ int rfx_count_stats(rfx_table*, uint64_t* distinct, uint64_t* capacity, uint64_t
  *                            any pending capacity check; < 0 on error, 0 if the table is not on the MSP path.
  *   rfx_count_segment_get    device pointers of segment i: records grouped by bin, bin_start[bins+1].
  *                            Valid until the next add/finish/free on the table.
- *   rfx_count_add_records_dev  append a copy of records grouped the same way (bin b = bin_start[b]..
+ *   rfx_count_add_records_ext_dev  append a copy of records grouped the same way (bin b = bin_start[b]..
  *                            bin_start[b+1]); `bins` is a power of two >= 256 and the table must be MSP
- *                            capable (23 <= k <= 25; k = 26 .. 31 through rfx_count_add_records_ext_dev).  All segments of a table must come from the same
- *                            k / canonical setting; bins may differ (finish refines to a common count). */
+ *                            capable (23 <= k <= 31).  A record is a 64-bit word AND a 32-bit plane entry
+ *                            (rfx_count_segment_ext): both arrays travel.  All segments of a table must come from
+ *                            the same k / canonical setting; bins may differ (finish refines to a common count). */
 int rfx_count_segments(rfx_table*);
 int rfx_count_segment_get(rfx_table*, int i, const uint64_t** d_records, const uint64_t** d_bin_start, uint32_t* bins,
                           uint64_t* n_records);
@@ -262,9 +269,10 @@ int rfx_count_add_records_dev(rfx_table*, const uint64_t* d_records, uint64_t n_
  * rfx_count_free -- the caller keeps them alive that long; only the bin offsets are copied. */
 int rfx_count_adopt_records_dev(rfx_table*, const uint64_t* d_records, const uint32_t* d_ext, uint64_t n_records,
                                 const uint64_t* d_bin_start, uint32_t bins);
-/* k = 26 .. 31: a record is a 64-bit word plus a 32-bit plane entry (the bases of a run beyond the 28 the word
- * holds); the plane is grouped like the records and travels with them. */
-int rfx_count_segment_ext(rfx_table*, int i, const uint32_t** d_ext); /* NULL plane for k <= 25 */
+/* A record is a 64-bit word plus a 32-bit plane entry (the bases of a super-k-mer beyond the 28 the word holds: up to
+ * 35 bases at k = 25, 43 at k = 31); the plane is grouped like the words and travels with them.  (Until round 3 only
+ * k = 26 .. 31 had a plane; rfx_count_add_records_dev -- words alone -- now always fails.) */
+int rfx_count_segment_ext(rfx_table*, int i, const uint32_t** d_ext);
 int rfx_count_add_records_ext_dev(rfx_table*, const uint64_t* d_records, const uint32_t* d_ext, uint64_t n_records,
                                   const uint64_t* d_bin_start, uint32_t bins);
 void rfx_count_free(rfx_table*);

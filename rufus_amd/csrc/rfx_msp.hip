@@ -539,7 +539,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
   __shared__ unsigned long long s_rk[RC];
   __shared__ uint32_t s_rc[RC], s_rmin[RC], s_rmax[RC];
   __shared__ uint32_t s_mixed[2];
-  __shared__ uint16_t s_kmap[KMAP];
+  __shared__ __attribute__((aligned(16))) uint16_t s_kmap[KMAP];
   __shared__ uint32_t s_pc[P1_BINS];
   __shared__ uint64_t s_pbase[P1_BINS];
   // by parity of the pass: distinct keys, overflow, k-mer map fill, survivors of the scan (zeroed for the NEXT pass by
@@ -580,7 +580,25 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
   __syncthreads();
 
   // F: staged survivors -> w = T * key -> the 128 coarse pos bins
+  // The 8 x 256-entry table of T (14-16 KB) is read from LDS: it borrows the k-mer map and the record cache's key array,
+  // both idle between two bins (the cache's keys are put back to "empty" at the end); from global memory seven gathers
+  // per survivor cost what scattered stores cost.  78.0 instead of 81 ms per 1 Gb sample.
+  // (Measured and not kept, round 4: the flush in ONE pass over the chunk -- per-workgroup slabs in the coarse bins that
+  // carry over from launch to launch, no count pass, no reservation between two barriers -- and eight instead of four
+  // staged entries in flight per lane: 78 ms both.  With the flush skipped altogether the kernel takes 62 ms.)
+  static_assert(KMAP * 2 >= 4 * 256 * 8 && RC * 8 >= 4 * 256 * 8, "the T table borrows s_kmap (tables 0-3) and s_rk (4-7)");
   auto flush = [&]() {
+    uint64_t* const lut_lo = (uint64_t*)s_kmap;
+    uint64_t* const lut_hi = (uint64_t*)s_rk;
+    for (int i = threadIdx.x; i < ntab * 256; i += BLK) (i < 1024 ? lut_lo[i] : lut_hi[i - 1024]) = g_lut[i];
+    __syncthreads();
+    auto t_mul = [&](uint64_t key) {
+      uint64_t r = 0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t < ntab) r ^= (t < 4 ? lut_lo : lut_hi - 1024)[t * 256 + (uint32_t)((key >> (8 * t)) & 255u)];
+      return r;
+    };
     // (four entries in flight per lane: one at a time, a lane waited for its key and then for the seven table reads, ten
     // times over -- the flush of a chunk took as long as two bins)
     for (uint32_t i0 = threadIdx.x; i0 < used; i0 += 4 * BLK) {
@@ -588,7 +606,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
 #pragma unroll
       for (int u = 0; u < 4; ++u) kv[u] = i0 + u * BLK < used ? stk[i0 + u * BLK] : 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) kv[u] = gf2_mul(g_lut, kv[u], ntab);  // 14 KB table, L1-resident; only survivors get here
+      for (int u = 0; u < 4; ++u) kv[u] = t_mul(kv[u]);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
         if (i0 + u * BLK < used) {
@@ -635,6 +653,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     }
     __syncthreads();
     if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < 1024 && i < (ntab - 4) * 256; i += BLK) s_rk[i] = MSP_EMPTY;  // the borrowed cache keys
     used = 0;
     // (the next use of s_pc / the chunk lies behind the barriers of the next pass)
   };
@@ -822,7 +841,11 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
       used += s_ns[X];
       X ^= 1u;
       if (used > CH - (uint32_t)FILL) {  // the chunk could not take a full table any more
+#ifdef RFX_LEAF_NOFLUSH  // experiment (results void): what the flush costs
+        used = 0;
+#else
         flush();
+#endif
         TM(13);
       }
       if (mixed) {  // the same sub-range again

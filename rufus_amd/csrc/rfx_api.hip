@@ -2665,6 +2665,7 @@ rfx_records* rfx_count_finish_end(rfx_finish* f) {
   if (!f) return nullptr;
   (void)hipSetDevice(f->t->ctx->device);
   rfx_records* r = f->failed ? nullptr : (f->ready ? f->ready : msp_emit_finish(f));
+  if (!r && f->t->peers) f->t->peers->abort();
   if (f->queued) {  // an error path left an attempt in flight: let it drain before its buffers go
     (void)ctx_sync(f->t->ctx);
     msp_emit_drop(f);
@@ -2674,8 +2675,16 @@ rfx_records* rfx_count_finish_end(rfx_finish* f) {
   return r;
 }
 
+static rfx_records* count_finish_inner(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo);
 rfx_records* rfx_count_finish(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {
   if (!t) return nullptr;
+  rfx_records* r = count_finish_inner(t, lower, upper, histo);
+  // a table of a device group that fails -- wherever: a pending re-partition, out of memory before the first barrier --
+  // must not leave the finishes of the other tables waiting at a barrier
+  if (!r && t->peers) t->peers->abort();
+  return r;
+}
+static rfx_records* count_finish_inner(rfx_table* t, uint64_t lower, uint64_t upper, uint64_t* histo) {
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
   if (t->pend_error) {

@@ -524,7 +524,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     const uint64_t* __restrict__ g_lut, int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi,
     uint64_t lower, uint64_t upper, uint64_t* __restrict__ out_w, uint32_t* __restrict__ out_c,
     uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err,
-    uint64_t* __restrict__ stage_k, uint32_t* __restrict__ stage_c, uint32_t CH) {
+    uint64_t* __restrict__ stage_k, uint32_t* __restrict__ stage_c, uint32_t CH, int force_mixed) {
   constexpr int TBL_LOG2 = GEO ? 12 : 13, TBL = 1 << TBL_LOG2, BLK = GEO ? 512 : 1024, FILL = TBL * 3 / 4;
   constexpr int RC_LOG2 = TBL_LOG2 - (GEO ? RFX_RC_SHRINK : 2), RC = 1 << RC_LOG2, KMAP = TBL;
   static_assert(RC <= 8192, "a k-mer map entry is slot << 3 | pair in 16 bits");
@@ -811,7 +811,9 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
       }
       __syncthreads();
       TM(11);
-      const bool mixed = s_mixed[X] != 0;     // (the pass is void: once more, without the cache)
+      // (the pass is void: once more, without the cache.  force_mixed -- RFX_LEAF_FORCE_MIXED, a test knob: the recount
+      // route is taken by every third bin, a 64-bit coincidence of two records being too rare to wait for)
+      const bool mixed = s_mixed[X] != 0 || (force_mixed && !nocache && bin % 3u == 1u);
       const bool ovf = s_ovf[X] != 0 || mixed;  // from here on: "nothing of this pass leaves"
       const bool split = s_ovf[X] != 0 && !mixed;
       TMC(20, split);
@@ -1062,10 +1064,11 @@ void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const
               int geo, const uint32_t* const* seg_ext, const uint32_t* ext0, uint64_t* stage_k, uint32_t* stage_c,
               uint32_t grid, uint32_t chunk) {
   rfx_span sp(c, "k_msp_leaf");
+  const int force_mixed = getenv("RFX_LEAF_FORCE_MIXED") != nullptr;
 #define RFX_MSP_LEAF(CANON, GEO)                                                                                        \
   hipLaunchKernelGGL((k_msp_leaf<CANON, GEO>), dim3(grid), dim3(GEO ? 512 : 1024), 0, c->stream, seg_inst, seg_bs, nseg, \
                      inst0, bs0, seg_ext, ext0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w,  \
-                     out_c, cur, cap, flag, err, stage_k, stage_c, chunk)
+                     out_c, cur, cap, flag, err, stage_k, stage_c, chunk, force_mixed)
   if (canonical) {
     if (geo) RFX_MSP_LEAF(true, 1);
     else RFX_MSP_LEAF(true, 0);

@@ -446,6 +446,8 @@ def test_three_count_paths_agree_on_random_configurations(ctx, seed, monkeypatch
         monkeypatch.setenv("RFX_MSP_GEO", str(int(rng.integers(0, 2))))
     if rng.random() < 0.2:     # exact two-pass sizing instead of the optimistic one
         monkeypatch.setenv("RFX_P2L_EXACT", "1")
+    if seed % 3 == 0:          # MSP leaf: every third bin takes the recount-without-the-record-cache route (what two
+        monkeypatch.setenv("RFX_LEAF_FORCE_MIXED", "1")   # different records under one 64-bit cache key would trigger)
     genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(rng.integers(2000, 60000)))]
     seqs = []
     for _ in range(int(rng.integers(500, 6000))):

@@ -18,6 +18,7 @@ timeout 1200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O
 F=$(find $O/pmc_fetch -name "f_counter_collection.csv" | head -1); W=$(find $O/pmc_write -name "w_counter_collection.csv" | head -1)
 python profiles/summarize_pmc.py "$F" "$W" $O/r04_pmc_wgs.json 3 3100000000 > $O/r04_pmc_summary_wgs.txt
 rm -rf $O/pmc_fetch $O/pmc_write
+cp $O/r04_pmc_wgs.json profiles/r04_pmc_wgs.json   # (the bench line below quotes it: it was taken on this very build)
 head -40 $O/r04_pmc_summary_wgs.txt
 fi
 if [ "${SQ:-1}" = 1 ]; then

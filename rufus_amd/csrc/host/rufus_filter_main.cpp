@@ -47,10 +47,35 @@ struct Rec {
   uint32_t name_len, seq_len, qual_len;
   uint64_t hash;
 };
+// Where the printed forms of a piece's records go (reverse strand: bases and qualities again; a quality string shorter
+// than its read: a padded copy): blocks taken as they are needed and kept for the next piece -- most records are
+// forward-strand and need none.  (Until round 4 every piece buffer had room for the worst case behind its lines,
+// zero-filled by vector::resize: 96 MB touched per 32 MB piece, 8 GB at Threads = 40.)
+struct SideArena {
+  static constexpr size_t BLOCK = (size_t)4 << 20;
+  std::vector<std::pair<std::unique_ptr<char[]>, size_t>> blocks;
+  size_t cur = 0, used = 0;
+  void reset() { cur = used = 0; }
+  char* take(size_t n) {  // n bytes that stay where they are until the next reset()
+    while (cur < blocks.size() && used + n > blocks[cur].second) {
+      ++cur;
+      used = 0;
+    }
+    if (cur == blocks.size()) {
+      const size_t cap = std::max(BLOCK, n);
+      blocks.emplace_back(std::unique_ptr<char[]>(new char[cap]), cap);
+      used = 0;
+    }
+    char* p = blocks[cur].first.get() + used;
+    used += n;
+    return p;
+  }
+};
 struct SPiece {
-  std::vector<char> text;  // [0, size): SAM lines; behind them the printed form of reverse-strand records
+  std::vector<char> text;  // [0, size): SAM lines (pipe route)
   size_t size = 0;
-  const char* mapped = nullptr;  // a regular input file: the lines lie in its mapping, `text` only holds the printed forms
+  const char* mapped = nullptr;  // a regular input file: the lines lie in its mapping
+  SideArena side;               // the printed form of reverse-strand records
   std::vector<Rec> recs;
   std::vector<std::string> chr_runs;
   std::vector<uint64_t> mask;  // hit bit per record
@@ -217,7 +242,6 @@ static int run(int argc, char** argv) {
         if (!pc) pc = new SPiece();
         pc->mapped = map + at;
         pc->size = end - at;
-        if (pc->text.size() < 2 * pc->size + 64) pc->text.resize(2 * pc->size + 64);  // the printed forms
         at = end;
         std::lock_guard<std::mutex> g(mu);
         pc->seq = n_pieces++;
@@ -248,7 +272,6 @@ static int run(int argc, char** argv) {
       bool have_nl = fill && memchr(pc->text.data(), '\n', fill);
       while (fill < PIECE || !have_nl) {  // at least PIECE bytes AND one line end
         if (fill == pc->text.size()) pc->text.resize(fill * 2);
-        // (a recycled buffer is three pieces long -- the room for the printed forms: a regular file would fill it)
         const size_t room = pc->text.size() - fill, want_more = fill < PIECE ? PIECE + (1u << 20) - fill : (size_t)1 << 20;
         const ssize_t n = ::read(fd, pc->text.data() + fill, std::min(room, want_more));
         if (n < 0 && errno == EINTR) continue;
@@ -263,9 +286,6 @@ static int run(int argc, char** argv) {
         carry.assign(pc->text.data() + cut, pc->text.data() + fill);
       }
       pc->size = cut;
-      // room behind the lines for the printed form of every record (reverse strand: its bases and qualities again;
-      // a quality string shorter than its read: a padded copy)
-      if (pc->text.size() < 3 * cut + 64) pc->text.resize(3 * cut + 64);
       std::lock_guard<std::mutex> g(mu);
       pc->seq = n_pieces++;
       todo.push_back(pc);
@@ -311,11 +331,11 @@ static int run(int argc, char** argv) {
       pc.recs.clear();
       pc.chr_runs.clear();
       pc.waited.clear();
-      // (offsets handed to rfx_pack_spans are byte distances from `base`, modulo 2^64: the printed forms of a mapped
-      // piece lie in another allocation than its lines)
+      // (offsets handed to rfx_pack_spans are byte distances from `base`, modulo 2^64: the printed forms lie in other
+      // allocations than the lines)
       const char* base = pc.mapped ? pc.mapped : pc.text.data();
       const char *p = base, *e = base + pc.size;
-      char* side = pc.mapped ? pc.text.data() : pc.text.data() + pc.size;  // printed forms go here
+      pc.side.reset();
       const char* cur = nullptr;
       size_t cur_len = 0;
       uint64_t words = 0;
@@ -335,11 +355,11 @@ static int run(int argc, char** argv) {
           if (sam_flag(f[1]) & 16) {
             revcomp_into(rs, f[9]);
             reverse_into(rq, f[10]);
+            char* side = pc.side.take(rs.size() + rq.size());
             memcpy(side, rs.data(), rs.size());
             memcpy(side + rs.size(), rq.data(), rq.size());
             r.seq = side; r.seq_len = (uint32_t)rs.size();
             r.qual = side + rs.size(); r.qual_len = (uint32_t)rq.size();
-            side += rs.size() + rq.size();
           }
           r.hash = name_hash(r.name, r.name_len);
           words += (r.seq_len + 31) / 32;
@@ -358,10 +378,10 @@ static int run(int argc, char** argv) {
           if (r.qual_len >= r.seq_len) {
             qo[i] = (uint64_t)((uintptr_t)r.qual - (uintptr_t)base);
           } else {  // a quality string shorter than its read: the missing characters are bad ('\0'), as in the file route
+            char* side = pc.side.take(r.seq_len);
             memcpy(side, r.qual, r.qual_len);
             memset(side + r.qual_len, 0, r.seq_len - r.qual_len);
             qo[i] = (uint64_t)((uintptr_t)side - (uintptr_t)base);
-            side += r.seq_len;
           }
         }
         uint64_t* codes = (uint64_t*)pin_codes.need((words + 1) * 8);

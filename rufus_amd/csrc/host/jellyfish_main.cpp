@@ -327,9 +327,15 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     }
   }
   const int out_fd = prealloc.take();
+  if (getenv("RFX_CLI_TRACE")) {
+    char msg[128];
+    snprintf(msg, sizeof msg, "write: %.1f GB preallocated, %.1f GB in the mapping's page table", (double)prealloc.reached() / 1e9,
+             (double)prealloc.populated() / 1e9);
+    trace(msg);
+  }
   write_jhash(out, recs, cols.data(), canonical, out_counter_len, full_argc, full_argv,
               ingest ? ingest->lend_buffers(48u << 20) : std::vector<std::pair<char*, size_t>>(), out_fd,
-              prealloc.reached());
+              prealloc.reached(), prealloc.take_mapping());
   trace("count: output closed");
   if (!timing) leave(0);
   ingest.reset();

@@ -608,25 +608,48 @@ inline void trace(const char* what) {
 // roughly how much it will write starts a background thread that fallocate()s the file beyond its (zero) size while
 // the tool is still busy with its input; write_jhash() then sizes the file exactly (which frees any excess) and
 // only copies.  Everything here is best effort: an unsupported or failed fallocate just leaves pages for later.
+// Round 4: the same thread also enters the pages into the page table of the shared mapping write_jhash() will copy
+// through (madvise(MADV_POPULATE_WRITE), Linux >= 5.14; for that the file is given its guessed size at once and cut to the
+// real one at the end): 8.7 M first-touch faults of a 35.7 GB payload were what the copy threads spent their time on
+// (profiles/r04_cli_w_sample.txt: 3.6 s for the payload = 9.9 GB/s, "waited 2.9 s for buffers").  RFX_NO_PREMAP=1: off.
 class OutputPrealloc {
   int fd_ = -1;
   std::thread th_;
   std::atomic<bool> stop_{false};
-  std::atomic<uint64_t> reached_{0};
+  std::atomic<uint64_t> reached_{0}, populated_{0};
+  char* map_ = nullptr;
+  size_t map_len_ = 0;
 
  public:
   void start(const char* path, uint64_t bytes) {
     fd_ = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
     if (fd_ < 0 || bytes == 0) return;
+    if (!getenv("RFX_NO_PREMAP") && ::ftruncate(fd_, (off_t)bytes) == 0) {
+      void* m = mmap(nullptr, (size_t)bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);
+      if (m != MAP_FAILED) {
+        map_ = (char*)m;
+        map_len_ = (size_t)bytes;
+      } else {
+        (void)!::ftruncate(fd_, 0);
+      }
+    }
     th_ = std::thread([this, bytes] {
       const uint64_t step = 256ull << 20;
+      bool populate = map_ != nullptr;
       for (uint64_t at = 0; at < bytes && !stop_.load(std::memory_order_relaxed); at += step) {
-        if (::fallocate(fd_, FALLOC_FL_KEEP_SIZE, (off_t)at, (off_t)std::min(step, bytes - at)) != 0) break;
-        reached_ = at + std::min(step, bytes - at);
+        const uint64_t len = std::min(step, bytes - at);
+        if (::fallocate(fd_, FALLOC_FL_KEEP_SIZE, (off_t)at, (off_t)len) != 0) break;
+        reached_ = at + len;
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+        if (populate && ::madvise(map_ + at, (size_t)len, MADV_POPULATE_WRITE) != 0) populate = false;  // (an older kernel: faults later)
+        if (populate) populated_ = at + len;
       }
     });
   }
-  uint64_t reached() const { return reached_; }  // bytes allocated so far (valid after take())
+  uint64_t reached() const { return reached_; }      // bytes allocated so far (valid after take())
+  uint64_t populated() const { return populated_; }  // .. and entered into the mapping's page table
   // stops the thread; the descriptor (or -1: the writer opens the file itself and reports the error) goes to the caller
   int take() {
     stop_ = true;
@@ -635,8 +658,17 @@ class OutputPrealloc {
     fd_ = -1;
     return fd;
   }
+  // after take(): the shared mapping of the file's first .second bytes (the file has that size), or {nullptr, 0}; the
+  // caller unmaps it
+  std::pair<char*, size_t> take_mapping() {
+    std::pair<char*, size_t> m{map_, map_len_};
+    map_ = nullptr;
+    map_len_ = 0;
+    return m;
+  }
   ~OutputPrealloc() {
     const int fd = take();
+    if (map_) munmap(map_, map_len_);
     if (fd >= 0) ::close(fd);
   }
 };
@@ -653,7 +685,7 @@ class OutputPrealloc {
 // positions), written one after the other; each slice is fetched by its own thread.
 inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs, const uint64_t* cols, bool canonical,
                         int counter_len, int argc, char** argv, const std::vector<std::pair<char*, size_t>>& lend = {},
-                        int open_fd = -1, uint64_t preallocated = 0) {
+                        int open_fd = -1, uint64_t preallocated = 0, std::pair<char*, size_t> premap = {nullptr, 0}) {
   rfx_records* rec = recs.at(0);
   const int k = rfx_records_k(rec), lsize = rfx_records_lsize(rec);
   std::vector<char> hdr(1 << 16);
@@ -704,11 +736,20 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
     return;
   }
   char* map = nullptr;
-  // blocks preallocated past the end: ext4 keeps them when the size only grows -- grow over them, then cut back
-  if (preallocated > total) (void)!::ftruncate(fd, (off_t)preallocated);
-  if (n && ::ftruncate(fd, (off_t)total) == 0) {
-    void* m = mmap(nullptr, (size_t)total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    if (m != MAP_FAILED) map = (char*)m;
+  size_t map_len = (size_t)total;  // what munmap() is given
+  if (premap.first && n && premap.second >= total) {
+    // OutputPrealloc's mapping (its pages are in the page table already); the file is cut to its size at the end
+    map = premap.first;
+    map_len = premap.second;
+  } else {
+    if (premap.first) munmap(premap.first, premap.second);  // the guess was too small: map again at the real size
+    premap = {nullptr, 0};
+    // blocks preallocated past the end: ext4 keeps them when the size only grows -- grow over them, then cut back
+    if (preallocated > total) (void)!::ftruncate(fd, (off_t)preallocated);
+    if (n && ::ftruncate(fd, (off_t)total) == 0) {
+      void* m = mmap(nullptr, (size_t)total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      if (m != MAP_FAILED) map = (char*)m;
+    }
   }
   struct sigaction old_bus;
   if (map) {  // a full file system shows up as SIGBUS on the mapping, not as a failed write(): report it the same way
@@ -759,8 +800,9 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
     for (auto& t : th) t.join();
     trace("write: payload out (slices)");
     if (map) {
-      if (munmap(map, (size_t)total) != 0) die(std::string("write error on '") + path + "'");
+      if (munmap(map, map_len) != 0) die(std::string("write error on '") + path + "'");
       sigaction(SIGBUS, &old_bus, nullptr);
+      if (premap.first && ::ftruncate(fd, (off_t)total) != 0) die(std::string("write error on '") + path + "'");
     } else if (open_fd >= 0) {
       (void)!::ftruncate(fd, (off_t)total);
     }
@@ -814,8 +856,9 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
     else if (kind[i] == 0) free(buf[i]);
   }
   if (map) {
-    if (munmap(map, (size_t)total) != 0) die(std::string("write error on '") + path + "'");
+    if (munmap(map, map_len) != 0) die(std::string("write error on '") + path + "'");
     sigaction(SIGBUS, &old_bus, nullptr);
+    if (premap.first && ::ftruncate(fd, (off_t)total) != 0) die(std::string("write error on '") + path + "'");  // the guessed size -> the real one
   } else if (open_fd >= 0) {
     (void)!::ftruncate(fd, (off_t)total);  // drop what was preallocated past the end
   }
@@ -824,8 +867,8 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
 
 inline void write_jhash(const char* path, rfx_records* rec, const uint64_t* cols, bool canonical, int counter_len,
                         int argc, char** argv, const std::vector<std::pair<char*, size_t>>& lend = {}, int open_fd = -1,
-                        uint64_t preallocated = 0) {
-  write_jhash(path, std::vector<rfx_records*>{rec}, cols, canonical, counter_len, argc, argv, lend, open_fd, preallocated);
+                        uint64_t preallocated = 0, std::pair<char*, size_t> premap = {nullptr, 0}) {
+  write_jhash(path, std::vector<rfx_records*>{rec}, cols, canonical, counter_len, argc, argv, lend, open_fd, preallocated, premap);
 }
 
 // yaggo's SI suffixes (jf/sub_commands/count_main_cmdline.hpp:104-109): k M G T P E are powers of 1000.

@@ -13,6 +13,20 @@ e=$(date +%s.%N)
 python3 -c "print('jellyfish count rc=$rc: wall %.1f s = %.1f M reads/s' % ($e-$s, 2*$PAIRS/($e-$s)/1e6))"
 cat $O/count.trace
 ls -la $D/child.Jhash
+if [ -n "$AB" ]; then  # the same count without the pre-populated output mapping (round 3's writer)
+  s=$(date +%s.%N); RFX_NO_PREMAP=1 RFX_CLI_TRACE=1 timeout 900 $BIN/jellyfish count --disk -m $KK -L 2 -s 8G -t 64 -o $D/child2.Jhash -C $D/child.fq 2> $O/count_nopremap.trace; rc=$?; e=$(date +%s.%N)
+  python3 -c "print('RFX_NO_PREMAP=1 jellyfish count rc=$rc: wall %.1f s' % ($e-$s))"; cat $O/count_nopremap.trace
+  python3 -c "
+import sys
+a, b = open('$D/child.Jhash', 'rb'), open('$D/child2.Jhash', 'rb')
+for f in (a, b): f.seek(9 + int(f.read(9)))      # (the headers hold the command lines: the output names differ)
+same = True
+while same:
+    x, y = a.read(1 << 26), b.read(1 << 26)
+    same = x == y
+    if not x: break
+print('payloads identical' if same else 'PAYLOADS DIFFER')"; rm -f $D/child2.Jhash
+fi
 python3 - <<PY
 import os
 sz = os.path.getsize("$D/child.Jhash"); blob = open("$D/child.Jhash","rb").read(9); hl = int(blob)

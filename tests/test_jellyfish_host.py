@@ -191,3 +191,25 @@ def test_count_sam_and_spool(jf, testrun, tmp_path):
 
 def test_count_sam_and_spool_under_sanitizers(jf_san, testrun, tmp_path):
     _count_sam(jf_san, testrun, str(tmp_path))
+
+
+def test_output_pages_are_prepared_while_the_input_is_read(jf_san, testrun, tmp_path):
+    """rfx_cli.hpp OutputPrealloc + write_jhash: a background thread allocates the output's pages and enters them into the
+    shared mapping the payload is copied through, from a GUESS of the size -- far too large (the mapping is used, the
+    file cut back), far too small (mapped again at the real size), mapping switched off, no preallocation at all: the
+    same file every time, nothing left allocated past its end; under ThreadSanitizer / ASan+UBSan."""
+    d = str(tmp_path)
+    open(f"{d}/c.fq", "wb").write(testrun["Child"][0] + testrun["Child"][1])
+    cmd = [jf_san, "count", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "4", "-C"]
+    r = sh(cmd + ["-o", "plain.Jhash", "c.fq"], d, env={"RFX_NO_PREALLOC": "1"})
+    assert r.returncode == 0, r.stderr
+    want = _payload(f"{d}/plain.Jhash")
+    assert hashlib.sha256(want).hexdigest() == testrun["expected"]["samples"]["Child"]["s100M"]["payload_sha256"]
+    for name, env in (("big", {"RFX_PREALLOC_FRAC": "3.0"}), ("small", {"RFX_PREALLOC_FRAC": "0.0005"}),
+                      ("nomap", {"RFX_PREALLOC_FRAC": "3.0", "RFX_NO_PREMAP": "1"}), ("exact", {"RFX_PREALLOC_FRAC": "0.19"})):
+        r = sh(cmd + ["-o", f"{name}.Jhash", "c.fq"], d, env=dict(env, RFX_PREALLOC_MIN="0", RFX_CLI_TRACE="1"))
+        assert r.returncode == 0, r.stderr
+        blob = open(f"{d}/{name}.Jhash", "rb").read()
+        assert blob[9 + int(blob[:9]):] == want and len(blob) == 9 + int(blob[:9]) + len(want), name
+        assert os.stat(f"{d}/{name}.Jhash").st_blocks * 512 < len(blob) + (1 << 20), name
+        assert b"preallocated" in r.stderr

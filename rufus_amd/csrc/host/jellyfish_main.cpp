@@ -133,6 +133,8 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   }
   // ~11 bytes of output per distinct solid k-mer: 0.18 of the FASTQ bytes at 30x, less on shallow or filtered input
   OutputPrealloc prealloc;
+  double prealloc_frac = 0;
+  size_t prealloc_min = 0;
   {
     size_t min_bytes = 256u << 20;  // RFX_PREALLOC_MIN / RFX_PREALLOC_FRAC: the tests reach both sides of the guess
     double frac = 0.19;
@@ -140,6 +142,12 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     if (const char* ev = getenv("RFX_PREALLOC_FRAC")) frac = atof(ev);
     if (!any_stream && known_bytes > min_bytes && !getenv("RFX_NO_PREALLOC"))
       prealloc.start(out, (uint64_t)((double)known_bytes * frac));
+    // a piped input (scripts/RunJellyForRUFUS.sh:28: samtools view | ... | jellyfish count /dev/fd/0): the guess follows
+    // the bytes that have come in (profiles/r03_cli_w_trio.txt: 8.5 s of page faults after the device had finished)
+    else if (any_stream && inputs.size() == 1 && !getenv("RFX_NO_PREALLOC"))
+      prealloc.start_growing(out);
+    prealloc_frac = frac;
+    prealloc_min = min_bytes;
   }
   if (keep_path && (!sam_chr || inputs.size() != 1))
     die("rufus_amd jellyfish count: --keep-packed goes with --sam and ONE input (a pipe with --spool, or a SAM file)");
@@ -224,6 +232,10 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
             ingest->set_keep_packed(kfd, keep_minq);
           }
           if (const char* ev = getenv("RFX_INGEST_PIECE")) ingest->set_piece_bytes((size_t)std::max(1024ll, atoll(ev)));
+          if (prealloc.growing())
+            ingest->on_stream_bytes = [&prealloc, prealloc_frac, prealloc_min](uint64_t so_far) {
+              if (so_far > prealloc_min) prealloc.want((uint64_t)((double)so_far * prealloc_frac));
+            };
           trace("count: staging blocks pinned, workers up");
         }
         if (in.regular) {
@@ -292,6 +304,12 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   }
   const auto t_count = std::chrono::steady_clock::now();
   trace("count: input parsed and queued");
+  if (getenv("RFX_CLI_TRACE")) {
+    char msg[160];
+    snprintf(msg, sizeof msg, "write: output pages wanted %llu, allocated %llu, in the page table %llu",
+             (unsigned long long)prealloc.wanted(), (unsigned long long)prealloc.reached(), (unsigned long long)prealloc.populated());
+    trace(msg);
+  }
 
   // RFX_COUNT_HISTO=1 (opt-in, not jellyfish behaviour): also write OUT.histo, byte for byte what
   // `jellyfish histo -f -o OUT.histo OUT` would -- the count has the histogram anyway, and
@@ -329,8 +347,8 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   const int out_fd = prealloc.take();
   if (getenv("RFX_CLI_TRACE")) {
     char msg[128];
-    snprintf(msg, sizeof msg, "write: %.1f GB preallocated, %.1f GB in the mapping's page table", (double)prealloc.reached() / 1e9,
-             (double)prealloc.populated() / 1e9);
+    snprintf(msg, sizeof msg, "write: %llu bytes preallocated, %llu in the mapping's page table",
+             (unsigned long long)prealloc.reached(), (unsigned long long)prealloc.populated());
     trace(msg);
   }
   write_jhash(out, recs, cols.data(), canonical, out_counter_len, full_argc, full_argv,

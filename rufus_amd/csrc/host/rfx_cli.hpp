@@ -609,46 +609,85 @@ inline void trace(const char* what) {
 // the tool is still busy with its input; write_jhash() then sizes the file exactly (which frees any excess) and
 // only copies.  Everything here is best effort: an unsupported or failed fallocate just leaves pages for later.
 // Round 4: the same thread also enters the pages into the page table of the shared mapping write_jhash() will copy
-// through (madvise(MADV_POPULATE_WRITE), Linux >= 5.14; for that the file is given its guessed size at once and cut to the
+// through (madvise(MADV_POPULATE_WRITE), Linux >= 5.14; for that the file is given its guessed size and cut to the
 // real one at the end): 8.7 M first-touch faults of a 35.7 GB payload were what the copy threads spent their time on
 // (profiles/r04_cli_w_sample.txt: 3.6 s for the payload = 9.9 GB/s, "waited 2.9 s for buffers").  RFX_NO_PREMAP=1: off.
+// A piped input has no size to guess from: start_growing() + want(bytes) follow the stream (the file grows under a
+// mapping of a fixed, large piece of address space; pages past the end of a file are simply not there yet).
 class OutputPrealloc {
   int fd_ = -1;
   std::thread th_;
   std::atomic<bool> stop_{false};
-  std::atomic<uint64_t> reached_{0}, populated_{0};
+  std::atomic<uint64_t> reached_{0}, populated_{0}, target_{0};
+  bool growing_ = false;
   char* map_ = nullptr;
   size_t map_len_ = 0;
 
- public:
-  void start(const char* path, uint64_t bytes) {
-    fd_ = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
-    if (fd_ < 0 || bytes == 0) return;
-    if (!getenv("RFX_NO_PREMAP") && ::ftruncate(fd_, (off_t)bytes) == 0) {
-      void* m = mmap(nullptr, (size_t)bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);
-      if (m != MAP_FAILED) {
-        map_ = (char*)m;
-        map_len_ = (size_t)bytes;
-      } else {
-        (void)!::ftruncate(fd_, 0);
+  void run() {
+    // (64 MB: a populate holds the address space's lock for reading while it runs -- ~15 ms per step --, and the
+    // device runtime takes it for writing whenever it maps memory)
+    uint64_t step = 64ull << 20;
+    if (const char* ev = getenv("RFX_PREALLOC_STEP")) step = std::max<uint64_t>(2ull << 20, strtoull(ev, nullptr, 10) & ~((2ull << 20) - 1));
+    bool populate = map_ != nullptr;
+    uint64_t at = 0;
+    while (!stop_.load(std::memory_order_relaxed)) {
+      uint64_t tgt = target_.load(std::memory_order_relaxed);
+      if (growing_) tgt &= ~((2ull << 20) - 1);  // (a step begins on a page boundary: madvise() wants that)
+      if (at >= tgt) {
+        if (!growing_) break;
+        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        continue;
       }
-    }
-    th_ = std::thread([this, bytes] {
-      const uint64_t step = 256ull << 20;
-      bool populate = map_ != nullptr;
-      for (uint64_t at = 0; at < bytes && !stop_.load(std::memory_order_relaxed); at += step) {
-        const uint64_t len = std::min(step, bytes - at);
-        if (::fallocate(fd_, FALLOC_FL_KEEP_SIZE, (off_t)at, (off_t)len) != 0) break;
-        reached_ = at + len;
+      const uint64_t len = std::min(step, tgt - at);
+      if (growing_ && map_ && ::ftruncate(fd_, (off_t)(at + len)) != 0) break;  // (the mapping's pages exist up to the file's size)
+      if (::fallocate(fd_, FALLOC_FL_KEEP_SIZE, (off_t)at, (off_t)len) != 0) break;
+      reached_ = at + len;
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23
 #endif
-        if (populate && ::madvise(map_ + at, (size_t)len, MADV_POPULATE_WRITE) != 0) populate = false;  // (an older kernel: faults later)
-        if (populate) populated_ = at + len;
-      }
-    });
+      if (populate && ::madvise(map_ + at, (size_t)len, MADV_POPULATE_WRITE) != 0) populate = false;  // (an older kernel: faults later)
+      if (populate) populated_ = at + len;
+      at += len;
+    }
   }
-  uint64_t reached() const { return reached_; }      // bytes allocated so far (valid after take())
+  void map(size_t bytes) {
+    if (getenv("RFX_NO_PREMAP")) return;
+    void* m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd_, 0);
+    if (m == MAP_FAILED) return;
+    map_ = (char*)m;
+    map_len_ = bytes;
+  }
+
+ public:
+  // the output will be about `bytes` long
+  void start(const char* path, uint64_t bytes) {
+    fd_ = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd_ < 0 || bytes == 0) return;
+    if (::ftruncate(fd_, (off_t)bytes) == 0) map((size_t)bytes);
+    if (!map_) (void)!::ftruncate(fd_, 0);
+    target_ = bytes;
+    th_ = std::thread([this] { run(); });
+  }
+  // nobody knows yet: want() says how long it will be at least, as often as that changes
+  void start_growing(const char* path) {
+    fd_ = ::open(path, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    struct stat st;
+    if (fd_ < 0) return;
+    if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) {  // (-o /dev/stdout, a named pipe: nothing to prepare; the writer opens it)
+      ::close(fd_);
+      fd_ = -1;
+      return;
+    }
+    growing_ = true;
+    map((size_t)1 << 40);
+    th_ = std::thread([this] { run(); });
+  }
+  void want(uint64_t bytes) {
+    if (growing_ && bytes > target_.load(std::memory_order_relaxed)) target_ = bytes;
+  }
+  bool growing() const { return growing_; }
+  uint64_t wanted() const { return target_; }
+  uint64_t reached() const { return reached_; }      // bytes allocated so far
   uint64_t populated() const { return populated_; }  // .. and entered into the mapping's page table
   // stops the thread; the descriptor (or -1: the writer opens the file itself and reports the error) goes to the caller
   int take() {
@@ -658,8 +697,8 @@ class OutputPrealloc {
     fd_ = -1;
     return fd;
   }
-  // after take(): the shared mapping of the file's first .second bytes (the file has that size), or {nullptr, 0}; the
-  // caller unmaps it
+  // after take(): the shared mapping of the file from its first byte on, .second bytes of address space (the file may be
+  // shorter: write_jhash() sizes it), or {nullptr, 0}; the caller unmaps it
   std::pair<char*, size_t> take_mapping() {
     std::pair<char*, size_t> m{map_, map_len_};
     map_ = nullptr;
@@ -737,8 +776,11 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
   }
   char* map = nullptr;
   size_t map_len = (size_t)total;  // what munmap() is given
-  if (premap.first && n && premap.second >= total) {
-    // OutputPrealloc's mapping (its pages are in the page table already); the file is cut to its size at the end
+  struct stat st_now;
+  if (premap.first && n && premap.second >= total && fstat(fd, &st_now) == 0 &&
+      ((uint64_t)st_now.st_size >= total || ::ftruncate(fd, (off_t)total) == 0)) {
+    // OutputPrealloc's mapping (its pages are in the page table already, as far as the guess went); the file is cut to
+    // its size at the end
     map = premap.first;
     map_len = premap.second;
   } else {

@@ -118,6 +118,7 @@ class CountIngest {
     uint64_t seq = 0;          // SAM mode: position of the piece in the stream (the chromosome log is stitched in order)
     uint64_t spool_off = 0;    // set_spool: where the piece's bytes go in the spool file
   };
+  uint64_t stream_bytes_ = 0;  // feed_stream: bytes read so far
   int spool_fd_ = -1;          // set_spool: the stream is also written to this file, piece by piece, by the workers
   uint64_t spooled_ = 0;
   // set_keep_packed (`jellyfish count --sam .. --keep-packed FILE`): every SAM piece also leaves a chunk
@@ -549,6 +550,8 @@ class CountIngest {
   // next -- RUFUS.Filter after the subject's count, runRufus.sh:966 after scripts/RunJellyForRUFUS.sh:28 -- need not run
   // the generator (samtools view of a BAM) a second time.  Written piece by piece by the parser threads (pwrite).
   void set_spool(int fd) { spool_fd_ = fd; }
+  // feed_stream(): called by the reading thread with the number of bytes the stream has delivered so far
+  std::function<void(uint64_t)> on_stream_bytes;
   void set_keep_packed(int fd, int min_q) {
     cache_fd_ = fd;
     cache_minq_ = min_q;
@@ -673,6 +676,7 @@ class CountIngest {
         }
         if (n == 0) eof = true;
         else fill += (size_t)n;
+        if (n > 0 && on_stream_bytes) on_stream_bytes(stream_bytes_ += (uint64_t)n);
         need_more = false;
       }
       // last record boundary inside [0, fill): count the new lines (32 bytes per step), then walk to the newline

@@ -626,7 +626,6 @@ def test_count_cli_parallel_ingest_and_shard_passes(tmp_path):
     assert run("nopre.jf", "reads.fq", {"RFX_NO_PREALLOC": "1", "RFX_CLEAN_EXIT": "1"}) == ref
     # (round 4: the preallocating thread also populates the mapping the payload is copied through; without that)
     assert run("nomap.jf", "reads.fq", {"RFX_PREALLOC_MIN": "0", "RFX_PREALLOC_FRAC": "3.0", "RFX_NO_PREMAP": "1"}) == ref
-    assert open(f"{d}/nomap.jf", "rb").read()[9:] == open(f"{d}/pre.jf", "rb").read()[9:]
     # k = 31 (the tumor/normal config): eager and deferred (shard passes inside the table) agree with the oracle
     ref31 = oracle.count(None, 31, 8 << 30, lower=2, reads=[x.tobytes() for x in seq]).payload()
     for extra in ({}, {"RFX_COUNT_DEFER": "1", "RFX_COUNT_PASSES": "3"}):

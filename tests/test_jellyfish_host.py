@@ -213,3 +213,18 @@ def test_output_pages_are_prepared_while_the_input_is_read(jf_san, testrun, tmp_
         assert blob[9 + int(blob[:9]):] == want and len(blob) == 9 + int(blob[:9]) + len(want), name
         assert os.stat(f"{d}/{name}.Jhash").st_blocks * 512 < len(blob) + (1 << 20), name
         assert b"preallocated" in r.stderr
+    # a piped input: the guess follows the bytes that have come in (the file grows under a mapping of address space)
+    blob = open(f"{d}/c.fq", "rb").read()
+    for name, env in (("pipe_big", {"RFX_PREALLOC_FRAC": "3.0"}), ("pipe_small", {"RFX_PREALLOC_FRAC": "0.0005"}),
+                      ("pipe_nomap", {"RFX_PREALLOC_FRAC": "3.0", "RFX_NO_PREMAP": "1"}), ("pipe_none", {"RFX_NO_PREALLOC": "1"})):
+        r = sh(cmd + ["-o", f"{name}.Jhash", "/dev/stdin"], d, env=dict(env, RFX_PREALLOC_MIN="0", RFX_CLI_TRACE="1", RFX_INGEST_PIECE="65536"),
+               input=blob)
+        assert r.returncode == 0, r.stderr
+        got = open(f"{d}/{name}.Jhash", "rb").read()
+        assert got[9 + int(got[:9]):] == want and len(got) == 9 + int(got[:9]) + len(want), name
+        assert os.stat(f"{d}/{name}.Jhash").st_blocks * 512 < len(got) + (1 << 20), name
+        if name == "pipe_big":
+            ready = int(r.stderr.split(b"bytes preallocated, ")[1].split(b" in the mapping")[0])
+            assert ready >= 0, r.stderr                  # (how far the background thread got is a matter of timing)
+    r = sh(cmd + ["-o", "/dev/stdout", "/dev/stdin"], d, env={"RFX_PREALLOC_MIN": "0"}, input=blob)   # nothing to prepare for a pipe
+    assert r.returncode == 0 and r.stdout[9 + int(r.stdout[:9]):] == want

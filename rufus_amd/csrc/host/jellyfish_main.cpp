@@ -712,8 +712,10 @@ static int merge_main(int argc, char** argv, int full_argc, char** full_argv) {
         part[(size_t)i] = f.load(ctx, lo[(size_t)i], hi);
         lo[(size_t)i] = hi;
       }
+      trace("merge: a position range of every input loaded");
       merge_and_emit(part);
       for (auto* r : part) rfx_records_free(r);
+      trace("merge: joined and printed");
     }
   }
   fflush(stdout);

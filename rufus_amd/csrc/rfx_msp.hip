@@ -486,7 +486,11 @@ __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
   return (uint32_t)((key * 0xD6E8FEB86659FD93ull) >> 32);
 }
 
-constexpr uint32_t MSP_LEAF_STAGE(int geo) { return geo ? 8192u : 16384u; }  // survivors a workgroup stages before it scatters them
+// Distinct keys a counting pass can end with WITHOUT being void: a thread looks at the count before every insert, so up to
+// one key per thread can follow the limit FILL - 1 (see insert_fwd) -- and with lower = 1 every one of them is a survivor.
+constexpr uint32_t MSP_LEAF_PASS_MAX(int geo) { return (geo ? 4096u : 8192u) * 3 / 4 + (geo ? 512u : 1024u); }
+// survivors a workgroup stages before it scatters them (big inputs): room for 5120 / 9216 + one pass
+constexpr uint32_t MSP_LEAF_STAGE(int geo) { return (geo ? 5120u : 9216u) + MSP_LEAF_PASS_MAX(geo); }
 constexpr int MSP_ILP = 4;        // records a lane loads before its first probe (a bin holds ~3 per lane)
 #ifndef RFX_RC_PROBES
 #define RFX_RC_PROBES 16
@@ -526,6 +530,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err,
     uint64_t* __restrict__ stage_k, uint32_t* __restrict__ stage_c, uint32_t CH, int force_mixed) {
   constexpr int TBL_LOG2 = GEO ? 12 : 13, TBL = 1 << TBL_LOG2, BLK = GEO ? 512 : 1024, FILL = TBL * 3 / 4;
+  static_assert(MSP_LEAF_PASS_MAX(GEO) >= (uint32_t)(FILL + BLK) && FILL + BLK <= TBL, "what a pass can leave behind fits the chunk and the table");
   constexpr int RC_LOG2 = TBL_LOG2 - (GEO ? RFX_RC_SHRINK : 2), RC = 1 << RC_LOG2, KMAP = TBL;
   static_assert(RC <= 8192, "a k-mer map entry is slot << 3 | pair in 16 bits");
   __shared__ __attribute__((aligned(16))) unsigned long long s_keys[TBL];
@@ -842,7 +847,12 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
       TM(12);
       used += s_ns[X];
       X ^= 1u;
-      if (used > CH - (uint32_t)FILL) {  // the chunk could not take a full table any more
+      // The chunk must be able to take whatever the next pass can leave: FILL - 1 + BLK keys, not FILL.  (Until late in
+      // round 4 the test was `used > CH - FILL`: a pass that ended between FILL and FILL + BLK distinct keys, all of them
+      // survivors, could write past the workgroup's chunk into its neighbour's -- a handful of garbage keys per 10^8
+      // records with -L 1 on a sparse sample, found by tests/test_scale_gpu.py::test_wgs_slice_properties.)
+      if (used > CH && threadIdx.x == 0) atomicExch(err, 1u);  // (cannot happen: fail loudly rather than corrupt)
+      if (used > CH - MSP_LEAF_PASS_MAX(GEO)) {  // the chunk could not take another pass
 #ifdef RFX_LEAF_NOFLUSH  // experiment (results void): what the flush costs
         used = 0;
 #else
@@ -1054,7 +1064,8 @@ void msp_leaf_plan(rfx_ctx* c, uint32_t P, int geo, uint64_t n_records, uint32_t
   g = std::min<uint64_t>(g, std::max<uint64_t>(1, n_records >> 12));
   *grid = (uint32_t)std::max<uint64_t>(g, 1);
   const uint32_t fill = (geo ? 4096u : 8192u) * 3 / 4;
-  *chunk = n_records >= (1ull << 24) ? MSP_LEAF_STAGE(geo) : fill + 1024u;
+  (void)fill;
+  *chunk = n_records >= (1ull << 24) ? MSP_LEAF_STAGE(geo) : MSP_LEAF_PASS_MAX(geo) + 512u;
 }
 
 void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,

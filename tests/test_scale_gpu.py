@@ -187,8 +187,22 @@ def test_wgs_slice_properties(ctx):
     t.add(blk)
     rec, h = t.finish(1, want_histo=True)
     assert int(sum(int(x) * i for i, x in enumerate(h))) == want
+    # .. and the same records whenever it is counted (with lower = 1 every distinct k-mer is a survivor: 2.3e8 of them
+    # through the leaf's staging chunks -- round 4: a workgroup could write past its chunk, a handful of garbage keys per run)
+    keys, counts, _ = rec.get()
+    assert int(counts.sum(dtype=np.uint64)) == want
     rec.free()
     t.free()
+    for _ in range(2):
+        t = capi.CountTable(ctx, K, SIZE)
+        t.add(blk)
+        rec = t.finish(1)
+        k2, c2, _ = rec.get()
+        assert np.array_equal(k2, keys) and np.array_equal(c2, counts)
+        rec.free()
+        t.free()
+        del k2, c2
+    del keys, counts
     blk.free()
     # -- the trio, one pass and two passes
     samples = [wgs.make_sample(ctx, sy, n_pairs, 1 << 24, MIN_Q, want_good=(i == 0)) for i, sy in enumerate(sys_)]

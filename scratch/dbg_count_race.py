@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rufus_amd import capi
 from tests.test_scale_gpu import _valid_windows
 
-K, SIZE, MIN_Q = 25, 8 << 30, 15
+K, SIZE, MIN_Q = int(os.environ.get("DBG_K", 25)), 8 << 30, 15
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 dirty = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 lower = int(sys.argv[3]) if len(sys.argv) > 3 else 1

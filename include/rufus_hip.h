@@ -323,6 +323,13 @@ int rfx_records_histo(const rfx_records*, uint64_t* histo /* RFX_HISTO_BINS */);
  * (jf/include/jellyfish/rectangular_binary_matrix.hpp:206-243), out[2] = counts outside [min_count, max_count],
  * out[3] = sum of the counts.  A correct set gives 0, 0, 0. */
 int rfx_records_verify(const rfx_records*, uint32_t min_count, uint32_t max_count, uint64_t out[4]);
+/* A checksum of the record MULTISET that does not depend on how the count was cut into shard passes, devices or slices
+ * (sums over the slices add up, mod 2^64): out[0] = sum of mix(key) * count, out[1] = sum of mix(key), mix = the
+ * splitmix64 finaliser (x += 0x9E3779B97F4A7C15; x = (x ^ x >> 30) * 0xBF58476D1CE4E5B9; x = (x ^ x >> 27) *
+ * 0x94D049BB133111EB; x ^ x >> 31).  The full-size runs compare it between S and S + 1 passes (there is no .Jhash of a
+ * real jellyfish to hold a 3e9-record table against: same (key, count) pairs from two different cuts of the work is the
+ * strongest statement available); the parity tests hold it against the oracle's records. */
+int rfx_records_checksum(const rfx_records*, uint64_t out[2]);
 void rfx_records_free(rfx_records*);
 
 /* ---------------------------------------------------------------------------------------------

@@ -122,6 +122,17 @@ def jf_pos(cols: np.ndarray, key: int, lsize: int) -> int:
     return int(lib().orc_jf_times(_u64p(cols), len(cols), int(key))) & ((1 << lsize) - 1)
 
 
+def multiset_checksum(keys, counts) -> tuple:
+    with np.errstate(over="ignore"):
+        x = np.asarray(keys, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+        a = (x * np.asarray(counts, dtype=np.uint64)).sum(dtype=np.uint64)
+        b = x.sum(dtype=np.uint64)
+    return int(a), int(b)
+
+
 # ------------------------------------------------------------------------------------------------
 # count  (jf/sub_commands/count_main.cc:148-180, :214-353)
 # ------------------------------------------------------------------------------------------------
@@ -145,6 +156,12 @@ class Records:
         v = np.minimum(self.counts, np.uint64(cap)).astype("<u8").view(np.uint8).reshape(n, 8)
         out[:, kb:] = v[:, :counter_len]
         return out.tobytes()
+
+    def checksum(self) -> tuple:
+        """include/rufus_hip.h rfx_records_checksum restated: (sum of mix(key) * count, sum of mix(key)) mod 2^64,
+        mix = the splitmix64 finaliser.  (Not a reference function: the shard-independent fingerprint of the record
+        multiset that the full-size runs compare between different cuts of the work.)"""
+        return multiset_checksum(self.keys, self.counts)
 
     def dump_text(self) -> str:
         """``jellyfish dump -c``: ``KMER COUNT`` per record in file order."""

@@ -94,6 +94,7 @@ SIGNATURES = {
     "rfx_records_dev_pos": (C.c_void_p, [C.c_void_p]),
     "rfx_records_histo": (C.c_int, [C.c_void_p, u64p]),
     "rfx_records_verify": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, u64p]),
+    "rfx_records_checksum": (C.c_int, [C.c_void_p, u64p]),
     "rfx_count_adopt_records_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
     "rfx_ctx_allow_peers": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "rfx_peers_create": (C.c_void_p, [C.c_int]),
@@ -423,6 +424,12 @@ class Records:
         o = np.zeros(4, dtype=np.uint64)
         _check(lib().rfx_records_verify(self._h, min_count, max_count, _p(o, u64p)), "rfx_records_verify")
         return {"bad_order": int(o[0]), "bad_pos": int(o[1]), "bad_count": int(o[2]), "sum_counts": int(o[3])}
+
+    def checksum(self) -> tuple:
+        """(sum of mix(key) * count, sum of mix(key)) mod 2^64 -- rfx_records_checksum: adds up over shards / slices."""
+        o = np.zeros(2, dtype=np.uint64)
+        _check(lib().rfx_records_checksum(self._h, _p(o, u64p)), "rfx_records_checksum")
+        return int(o[0]), int(o[1])
 
     def query(self, keys: np.ndarray) -> np.ndarray:
         keys = np.ascontiguousarray(keys, dtype=np.uint64)

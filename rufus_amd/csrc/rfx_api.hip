@@ -3004,6 +3004,24 @@ int rfx_records_verify(const rfx_records* r, uint32_t min_count, uint32_t max_co
   return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_verify");
 }
 
+int rfx_records_checksum(const rfx_records* r, uint64_t out[2]) {
+  if (!r || !out) return RFX_E_INVAL;
+  rfx_ctx* c = r->ctx;
+  (void)hipSetDevice(c->device);
+  out[0] = out[1] = 0;
+  if (r->n == 0) return RFX_OK;
+  unsigned long long* d = (unsigned long long*)dmalloc(c, 2 * 8);
+  if (!d) return RFX_E_NOMEM;
+  hipError_t e = hipMemsetAsync(d, 0, 2 * 8, c->stream);
+  if (e == hipSuccess) {
+    rfxk::records_checksum(c, r->keys, r->counts, r->n, d);
+    e = queue_read(c, out, d, 2 * 8);
+  }
+  if (e == hipSuccess) e = ctx_sync(c);
+  dfree(c, d);
+  return e == hipSuccess ? RFX_OK : hip_fail(e, "rfx_records_checksum");
+}
+
 // ---------------------------------------------------------------------------------------------
 static int same_function(const rfx_records* a, const rfx_records* b) {
   return a->k == b->k && a->lsize == b->lsize && memcmp(a->cols, b->cols, sizeof(uint64_t) * 2 * a->k) == 0;

@@ -270,6 +270,7 @@ void check_sorted(rfx_ctx*, const uint64_t* keys, const uint64_t* pos, uint64_t 
 void records_verify(rfx_ctx*, const uint64_t* keys, const uint32_t* counts, const uint64_t* pos, uint64_t n,
                     const uint64_t* lut, int ntab, uint64_t pos_mask, uint32_t min_count, uint32_t max_count,
                     unsigned long long* d_out /* 4 counters, see k_records_verify */);
+void records_checksum(rfx_ctx*, const uint64_t* keys, const uint32_t* counts, uint64_t n, unsigned long long* d_out);
 void flag_range(rfx_ctx*, const uint32_t* counts, uint64_t n, uint32_t lo, uint32_t hi, uint8_t* flags);
 void flag_absent(rfx_ctx*, const uint64_t* keys, const uint64_t* pos, uint64_t n, const uint64_t* bkeys,
                  const uint64_t* bpos, uint64_t nb, int lsize, uint8_t* flags);

@@ -491,6 +491,35 @@ __global__ __launch_bounds__(256) void k_records_verify(const uint64_t* __restri
   }
 }
 
+// A checksum of the record MULTISET, independent of how the count was cut into shard passes, devices or slices:
+// out[0] += sum of mix(key) * count, out[1] += sum of mix(key) (mod 2^64; mix = the splitmix64 finaliser).  Two runs hold
+// the same (key, count) pairs iff (with overwhelming probability) both sums agree.
+__device__ __forceinline__ uint64_t checksum_mix(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void k_records_checksum(const uint64_t* __restrict__ keys,
+                                                           const uint32_t* __restrict__ counts, uint64_t n,
+                                                           unsigned long long* __restrict__ out) {
+  unsigned long long a = 0, b = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t m = checksum_mix(keys[i]);
+    a += m * counts[i];
+    b += m;
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+  }
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    atomicAdd(&out[0], a);
+    atomicAdd(&out[1], b);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K4: set difference on sorted records
 // ---------------------------------------------------------------------------------------------
@@ -1501,6 +1530,11 @@ void records_verify(rfx_ctx* c, const uint64_t* keys, const uint32_t* counts, co
   rfx_span sp(c, "k_records_verify");
   hipLaunchKernelGGL(k_records_verify, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, counts, pos, n, lut,
                      ntab, pos_mask, min_count, max_count, d_out);
+}
+
+void records_checksum(rfx_ctx* c, const uint64_t* keys, const uint32_t* counts, uint64_t n, unsigned long long* out) {
+  rfx_span sp(c, "k_records_checksum");
+  hipLaunchKernelGGL(k_records_checksum, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, counts, n, out);
 }
 
 void check_sorted(rfx_ctx* c, const uint64_t* keys, const uint64_t* pos, uint64_t n, unsigned int* d_bad) {

@@ -372,6 +372,7 @@ class WgsTrio:
             for k_ in ("bad_order", "bad_pos", "bad_count"):
                 ver[k_] += v[k_]
             ver["sum_counts"][si] += v["sum_counts"]
+            ver["checksum"][si] = [(a + b) % (1 << 64) for a, b in zip(ver["checksum"][si], rec.checksum())]
             if probe_keys is not None and len(probe_keys):
                 got = rec.query(np.asarray(probe_keys, dtype=np.uint64))
                 ver["probe_found"][si] += int((got > 0).sum())
@@ -424,7 +425,8 @@ class WgsTrio:
             keys, kept, recs = [], [], []
             cand = None
             ver = {"bad_order": 0, "bad_pos": 0, "bad_count": 0, "sum_counts": [0] * len(samples),
-                   "probe_found": [0] * len(samples), "probe_count_out_of_range": 0}
+                   "probe_found": [0] * len(samples), "probe_count_out_of_range": 0,
+                   "checksum": [[0, 0] for _ in samples]}   # rfx_records_checksum, summed over the shards
             try:
                 for sh in range(self.passes):
                     recs = []
@@ -561,7 +563,8 @@ def self_check(ctx: capi.Context, trio: "WgsTrio", samples, sys_, res, n_pairs, 
     2. the mutant k-mers: each is held by the subject with MinCov <= count <= MaxDepth and by NO control (looked up
        in every shard of every sample: merge_files.cc:69-155 + CheckJellyHashList.sh:12 semantics), and they are the
        alt-allele k-mers of the planted SNVs (a handful of recurrent sequencing errors aside);
-    3. one more shard pass (S + 1) gives the same record counts, histograms, hash list and pulled pairs;
+    3. one more shard pass (S + 1) gives the same record counts, histograms, hash list and pulled pairs -- and the same
+       multiset of (key, count) records (rfx_records_checksum summed over the shards);
     4. a sampled block of the subject counted alone with lower = 1: sum(i * histo[i]) == the number of ACGT-only
        windows, computed on the host from the generator's host twin (text), not from the packed block."""
     k = trio.k
@@ -600,11 +603,14 @@ def self_check(ctx: capi.Context, trio: "WgsTrio", samples, sys_, res, n_pairs, 
             assert len(got & expect) >= 0.9 * len(expect), f"only {len(got & expect)} of {len(expect)} SNV k-mers found"
     if more_passes and trio.world == 1:
         t2 = WgsTrio(ctx, k, trio.size, trio.lower, trio.min_cov, trio.max_cov, trio.thresh, passes=trio.passes + 1)
-        r2 = t2.run(samples)
+        r2 = t2.run(samples, verify=True)
         assert r2["n_records"] == res["n_records"] and r2["n_pulled"] == res["n_pulled"]
         assert np.array_equal(r2["mutant_keys"], keys0)
         assert all(np.array_equal(a, b) for a, b in zip(r2["histos"], res["histos"]))
+        # the same (key, count) pairs, every one of them, from two different cuts of the work (rfx_records_checksum)
+        assert r2["verify"]["checksum"] == v["checksum"], "S and S + 1 shard passes do not hold the same records"
         out["passes_compared"] = [trio.passes, t2.passes]
+        out["multiset_checksums"] = ["%016x" % c[0] for c in v["checksum"]]
     if sample_pairs:
         n = int(min(sample_pairs, n_pairs))
         first = (n_pairs - n) // 3

@@ -472,6 +472,7 @@ def test_three_count_paths_agree_on_random_configurations(ctx, seed, monkeypatch
         rec, h = t.finish(lower, upper, want_histo=True)
         assert rec.payload() == ref.payload(), (mode, k, size, canonical, lower, upper)
         assert np.array_equal(h, oracle.histo(ref.counts, full=True)[0])
+        assert rec.checksum() == ref.checksum()
         rec.free()
         t.free()
 
@@ -486,6 +487,7 @@ def test_msp_shard_passes_partition_the_count(ctx, small_trio, n_shards):
     ref = oracle.count(None, k, size, lower=2, reads=reads)
     blk = ctx.upload(capi.PackedReads.from_reads(reads))
     shards, hsum = [], np.zeros(capi.HISTO_BINS, dtype=np.uint64)
+    cs = [0, 0]
     for sh in range(n_shards):
         t = capi.CountTable(ctx, k, size)
         t.set_shard(sh, n_shards)
@@ -494,6 +496,7 @@ def test_msp_shard_passes_partition_the_count(ctx, small_trio, n_shards):
         assert nb >= 256 and nrec > 0
         rec, h = t.finish(2, want_histo=True)
         shards.append(tuple(x.astype(np.uint64) for x in rec.get()))
+        cs = [(a + b) % (1 << 64) for a, b in zip(cs, rec.checksum())]
         hsum += h
         rec.free()
         t.free()
@@ -501,6 +504,7 @@ def test_msp_shard_passes_partition_the_count(ctx, small_trio, n_shards):
     keys, counts, pos = rdist.merge_shards(shards)
     assert np.array_equal(keys, ref.keys) and np.array_equal(counts, ref.counts) and np.array_equal(pos, ref.pos)
     assert sum(len(s_[0]) for s_ in shards) == len(ref.keys)          # disjoint
+    assert tuple(cs) == ref.checksum()      # rfx_records_checksum: the shards' sums add up to the whole multiset's
     assert np.array_equal(hsum, oracle.histo(ref.counts, full=True)[0])
     t = capi.CountTable(ctx, 32, size)
     with pytest.raises(capi.RufusError):

@@ -632,3 +632,15 @@ def test_bench_two_ranks_share_the_device(tmp_path):
     assert line["n_gpus"] == 2 and used in line["config"]["one_device_dry_run"]
     for key in ("mutant_kmers", "pulled_pairs", "records_per_sample"):
         assert line["config"][key] == ref["config"][key], key
+
+
+def test_every_cut_of_a_count_leaves_the_same_records(ctx):
+    """tests/soak_determinism.py: one-pass MSP (three times), both leaf geometries, the recount route, refined bins, 2 / 3 / 5
+    shard passes, passes deferred into the table, device groups of 2 and 3 (sharded by read block) and P2L must leave the
+    same record multiset (rfx_records_checksum + record count) -- on a sparse sample (2 M reads of a 1 Gb genome, 2.3e8
+    records with -L 1), a 30x and a 60x one, k = 25 / 31, -L 1 / 2: twelve configurations x 15 cuts, far beyond the
+    oracle.  (Round 4's staging-chunk overrun made exactly this differ from run to run.)"""
+    from tests import soak_determinism
+    lines = []
+    bad = soak_determinism.run(ctx, say=lines.append)
+    assert bad == 0 and len(lines) == 12, "\n".join(lines)

@@ -24,7 +24,8 @@ bad = 0
 for seed in range(lo, hi):
     for name, fn, needs_mp in (("count", T.test_three_count_paths_agree_on_random_configurations, True),
                                ("filter", T.test_filter_matches_oracle_on_random_configurations, False),
-                               ("k4", T.test_merge_hashlist_query_on_random_configurations, False)):
+                               ("k4 search", lambda c, sd, mp: T.test_merge_hashlist_query_on_random_configurations(c, sd, "search", mp), True),
+                               ("k4 tiles", lambda c, sd, mp: T.test_merge_hashlist_query_on_random_configurations(c, sd, "tiles", mp), True)):
         mp = MP()
         try:
             fn(ctx, seed, mp) if needs_mp else fn(ctx, seed)

@@ -210,6 +210,18 @@ int rfx_count_set_mode(rfx_table*, int mode);
  * the shard of a k-mer is the same for every sample, so count -> set difference can run shard by shard
  * when a sample's records do not fit the HBM at once, or on every GPU over all reads without any exchange. */
 int rfx_count_set_shard(rfx_table*, int shard, int n_shards);
+/* Shard passes hash every read once per pass: what cuts a read into super-k-mers is the same work whichever shard's
+ * runs are kept.  rfx_count_set_early(t, 1) on a table of shard s < S - 1: while a BIG block (>= 2^29 windows) is
+ * added, the runs of shard s + 1 are kept too -- the one k_msp_part1 launch covers both shards' bins (and, when those
+ * are all the bins, no longer asks whose a run is) -- and partitioned into segments of their own, held aside (at the
+ * cost of their memory: 12 bytes per record of shard s + 1) until rfx_count_adopt_early(t_next, t) hands them to the
+ * table of shard s + 1 of the same sample; that table is then NOT given those blocks.  Applies only where the boundary
+ * between the two shards is a boundary of coarse bins (S = 2, 4, ...; otherwise the add is an ordinary one:
+ * rfx_count_early_segments() says how many blocks went early, in the order they were added).  The WGS driver uses it
+ * for as many blocks of the subject as the headroom of the device allows (rufus_amd/wgs.py). */
+int rfx_count_set_early(rfx_table*, int on);
+int rfx_count_early_segments(const rfx_table*);
+int rfx_count_adopt_early(rfx_table* next_shard, rfx_table* from);
 /* Bounded-HBM counting of a whole sample (MSP path, call before the first add): rfx_count_add() only
  * REMEMBERS the read blocks -- they must stay alive until finish -- and rfx_count_finish() runs `passes`
  * minimizer-shard passes over them (0: planned from the free HBM, 1 if everything fits): per pass the shard's

@@ -72,6 +72,9 @@ SIGNATURES = {
     "rfx_count_finish_begin": (C.c_void_p, [C.c_void_p, C.c_uint64, C.c_uint64, u64p]),
     "rfx_count_finish_end": (C.c_void_p, [C.c_void_p]),
     "rfx_count_set_shard": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "rfx_count_set_early": (C.c_int, [C.c_void_p, C.c_int]),
+    "rfx_count_early_segments": (C.c_int, [C.c_void_p]),
+    "rfx_count_adopt_early": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rfx_count_segments": (C.c_int, [C.c_void_p]),
     "rfx_count_segment_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_uint32), u64p]),
@@ -500,6 +503,17 @@ class CountTable:
     def set_shard(self, shard: int, n_shards: int):
         """Count only the k-mers of minimizer shard `shard` of `n_shards` (before the first add)."""
         _check(lib().rfx_count_set_shard(self._h, shard, n_shards), "rfx_count_set_shard")
+
+    def set_early(self, on: bool = True):
+        """Big blocks added from now on are also cut for shard s + 1 (rfx_count_set_early): one hashing pass for two shards."""
+        _check(lib().rfx_count_set_early(self._h, int(on)), "rfx_count_set_early")
+
+    def early_segments(self) -> int:
+        return int(lib().rfx_count_early_segments(self._h))
+
+    def adopt_early(self, other: "CountTable"):
+        """Take the early segments `other` (the table of the shard before this one) holds for this shard."""
+        _check(lib().rfx_count_adopt_early(self._h, other._h), "rfx_count_adopt_early")
 
     def segments(self):
         """[(d_records, d_bin_start, bins, n_records)] of the MSP record segments held (device pointers)."""

@@ -892,6 +892,7 @@ rfx_table* rfx_count_begin(rfx_ctx* c, int k, int canonical, int lsize, uint64_t
   t->lut_tinv = hc->lut_tinv;
   t->ntab = hc->ntab;
   t->segs = new std::vector<rfx_segment>();
+  t->early = new std::vector<rfx_segment>();
   t->pend = new std::vector<rfx_pending_add>();
   t->deferred = new std::vector<const rfx_reads*>();
   t->passes = -1;
@@ -922,6 +923,14 @@ void rfx_count_free(rfx_table* t) {
       dfree(t->ctx, sg.bin_start);
     }
     delete t->segs;
+  }
+  if (t->early) {  // early segments nobody adopted
+    for (auto& sg : *t->early) {
+      dfree(t->ctx, sg.inst);
+      dfree(t->ctx, sg.ext);
+      dfree(t->ctx, sg.bin_start);
+    }
+    delete t->early;
   }
   delete t;
 }
@@ -1251,8 +1260,23 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
     // Big block: scatter into the coarse bins (no fused histogram: up to 32768 bins), histogram pass over the
     // records, then wait for the record count and the capacity flag and give the segment exactly the memory
     // it needs (at WGS scale the 30 % slack of an estimate is tens of GB) -- and nothing stays pending.
+    // rfx_count_set_early: the records of the NEXT shard are cut in the same launch (hashing is the same work whether a
+    // run is kept or dropped -- and with every bin kept the kernel does not even ask whose a run is) and partitioned
+    // into a segment of their own; the shards' ranges are adjacent, so are their coarse bins.
+    msp_geom g2 = g;
+    bool early = false;
+    if (t->early_on && t->n_shards > 1 && t->shard + 1 < t->n_shards && wide) {
+      const uint32_t ns = (uint32_t)t->n_shards, sh1 = (uint32_t)t->shard + 1;
+      g2.bin_lo = g.bin_hi;
+      g2.bin_hi = (((sh1 + 1) * 256 + ns - 1) / ns) * (g.P / 256);
+      // (only when the boundary between the two shards is a boundary of coarse bins: no coarse bin holds records of both)
+      early = g2.bin_hi > g2.bin_lo && g.bin_hi > g.bin_lo && g.bin_hi % g.P2 == 0;
+    }
+    const uint32_t p1_hi = early ? g2.bin_hi : g.bin_hi;
+    const uint32_t c_n_all = p1_hi > g.bin_lo ? (p1_hi - 1) / g.P2 - g.c_lo + 1 : 1;  // coarse bins of the launch
+    const uint32_t c_mid = g.bin_hi / g.P2;                                             // first coarse bin of the next shard
     for (int attempt = 0;; ++attempt) {
-      char* buf_a = (char*)dmalloc(c, cap_a * g.c_n * 12);  // 12-byte slots: word and plane side by side
+      char* buf_a = (char*)dmalloc(c, cap_a * c_n_all * 12);  // 12-byte slots: word and plane side by side
       if (!buf_a) { dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
       char* buf_a0 = buf_a - (size_t)g.c_lo * cap_a * 12;  // the address coarse bin 0 would have
       auto fail = [&](int rc) { dfree(c, buf_a); dfree(c, cur); dfree(c, bin_start); return rc; };
@@ -1263,18 +1287,19 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
       // them wrapped are the records read once more for it
       uint32_t* cnt = getenv("RFX_MSP_REC_HIST") ? nullptr : (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
       if (cnt) {
-        rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 3, g.G, buf_a0, cur, (uint32_t)cap_a, cnt,
+        rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, p1_hi, 3, g.G, buf_a0, cur, (uint32_t)cap_a, cnt,
                         cur + g.ncur, slab_log2);
         rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
       } else {
-        rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr,
+        rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, p1_hi, 2, g.G, buf_a0, cur, (uint32_t)cap_a, nullptr,
                         cur + g.ncur);
         rfxk::surv_hist(c, (const uint64_t*)buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
         rfxk::scan_tail(c, bin_start, P);
       }
-      uint64_t total = 0;
+      uint64_t total = 0, n_own = 0;  // n_own: records of this table's shard (= total without the early cut)
       std::vector<uint32_t> h_cur(g.ncur + 1, 0);
       e = queue_read(c, &total, bin_start + P, 8);
+      if (e == hipSuccess && early) e = queue_read(c, &n_own, bin_start + g.bin_hi, 8);
       if (e == hipSuccess) e = queue_read(c, h_cur.data(), cur, (g.ncur + 1) * 4);
       if (e == hipSuccess) e = ctx_sync(c);
       dfree(c, cnt);
@@ -1288,6 +1313,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
           rfxk::surv_hist(c, (const uint64_t*)buf_a0, cur, (uint32_t)cap_a, P2, 32 - g.bin_bits, bin_start, g.rec_mode, t->k, cap_b);
           rfxk::scan_tail(c, bin_start, P);
           e = queue_read(c, &total, bin_start + P, 8);
+          if (e == hipSuccess && early) e = queue_read(c, &n_own, bin_start + g.bin_hi, 8);
           if (e == hipSuccess) e = ctx_sync(c);
           if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
         } else {
@@ -1296,6 +1322,38 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
           cap_a = need + need / 64 + 1024;
           continue;
         }
+      }
+      if (early) {
+        // two segments out of one set of coarse bins: this shard's bins lie below bin_hi and hold the first n_own
+        // records of the bin order, the next shard's the rest -- its bin extents are rebased to an array of its own
+        const uint64_t n_next = total - n_own;
+        uint64_t* inst = (uint64_t*)dmalloc(c, (n_own ? n_own : 1) * 8);
+        uint32_t* ext = (uint32_t*)dmalloc(c, (n_own ? n_own : 1) * 4);
+        uint64_t* inst2 = (uint64_t*)dmalloc(c, (n_next ? n_next : 1) * 8);
+        uint32_t* ext2 = (uint32_t*)dmalloc(c, (n_next ? n_next : 1) * 4);
+        uint64_t* bs2 = (uint64_t*)dmalloc(c, ((size_t)P + 1) * 8);
+        uint32_t* cur2 = (uint32_t*)dmalloc(c, (g.ncur + 1) * 4);
+        auto drop2 = [&] { dfree(c, inst); dfree(c, ext); dfree(c, inst2); dfree(c, ext2); dfree(c, bs2); dfree(c, cur2); };
+        if (!inst || !ext || !inst2 || !ext2 || !bs2 || !cur2) { drop2(); return fail(RFX_E_NOMEM); }
+        const size_t split = (size_t)c_mid * rfxk::p1_cur_stride();  // coarse cursors below / from the boundary
+        e = hipMemcpyAsync(cur2, cur, (g.ncur + 1) * 4, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess && split) e = hipMemsetAsync(cur2, 0, split * 4, c->stream);
+        if (e == hipSuccess && g.ncur > split) e = hipMemsetAsync(cur + split, 0, (g.ncur - split) * 4, c->stream);
+        if (e != hipSuccess) { drop2(); return fail(hip_fail(e, "msp_add")); }
+        rfxk::split_bins(c, bin_start, P, n_own, bs2);
+        rfxk::part2(c, (const uint64_t*)buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, ext,
+                    n_own, "k_part2", nullptr, 0, n_own, g.rec_mode, t->k);
+        rfxk::part2(c, (const uint64_t*)buf_a0, inst2, bs2, fine_cur, P2, 32 - g.bin_bits, cur2, (uint32_t)cap_a, nullptr, ext2,
+                    n_next, "k_part2", nullptr, 0, n_next, g.rec_mode, t->k);
+        dfree(c, buf_a);
+        dfree(c, cur);
+        dfree(c, cur2);
+        const double share2 = (double)(g2.bin_hi - g2.bin_lo) / (double)P;
+        const uint64_t nmax = (uint64_t)rfxk::msp_nmax_of(t->k);
+        t->segs->push_back(rfx_segment{inst, n_own, bin_start, std::min<uint64_t>((uint64_t)((double)g.windows * share) + 1, n_own * nmax), P, ext});
+        t->early->push_back(rfx_segment{inst2, n_next, bs2, std::min<uint64_t>((uint64_t)((double)g.windows * share2) + 1, n_next * nmax), P, ext2});
+        t->seg_kind = RFX_COUNT_MSP;
+        return RFX_OK;
       }
       uint64_t* inst = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
       uint32_t* ext = wide ? (uint32_t*)dmalloc(c, (total ? total : 1) * 4) : nullptr;
@@ -2479,6 +2537,35 @@ int rfx_count_set_shard(rfx_table* t, int shard, int n_shards) {
   t->shard = shard;
   t->n_shards = n_shards;
   if (n_shards > 1) t->mode = RFX_COUNT_MSP;
+  return RFX_OK;
+}
+
+int rfx_count_set_early(rfx_table* t, int on) {
+  if (!t) return RFX_E_INVAL;
+  if (on && (t->n_shards < 2 || t->shard + 1 >= t->n_shards)) {
+    snprintf(g_err, sizeof g_err, "rfx_count_set_early: a table of shard s < S - 1 of S > 1 (rfx_count_set_shard) can cut the next shard's records");
+    return RFX_E_INVAL;
+  }
+  t->early_on = on != 0;
+  return RFX_OK;
+}
+
+int rfx_count_early_segments(const rfx_table* t) { return t && t->early ? (int)t->early->size() : 0; }
+
+int rfx_count_adopt_early(rfx_table* dst, rfx_table* src) {
+  if (!dst || !src || dst == src || dst->ctx != src->ctx) return RFX_E_INVAL;
+  if (dst->n_shards != src->n_shards || dst->shard != src->shard + 1 || dst->k != src->k || dst->canonical != src->canonical ||
+      dst->lsize != src->lsize || memcmp(dst->cols, src->cols, sizeof dst->cols) != 0 || dst->table_active ||
+      (dst->seg_kind && dst->seg_kind != RFX_COUNT_MSP) || (dst->p2l_bins && dst->p2l_bins != src->p2l_bins) ||
+      dst->passes >= 0 || dst->peers) {
+    snprintf(g_err, sizeof g_err, "rfx_count_adopt_early: the adopting table must be shard s + 1 of the same count (k, size, shards, bins)");
+    return RFX_E_INVAL;
+  }
+  if (src->early->empty()) return RFX_OK;
+  dst->p2l_bins = src->p2l_bins;
+  for (auto& sg : *src->early) dst->segs->push_back(sg);
+  src->early->clear();
+  dst->seg_kind = RFX_COUNT_MSP;
   return RFX_OK;
 }
 

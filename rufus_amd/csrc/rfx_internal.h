@@ -211,6 +211,10 @@ struct rfx_table {
   std::vector<const rfx_reads*>* deferred;  // read blocks of the deferred adds (not owned)
   int pend_error;     // a deferred redo failed: the table cannot be finished
   std::vector<rfx_segment>* segs;
+  // rfx_count_set_early: while this table (shard s of S) partitions a big block it also partitions the block's records of
+  // shard s + 1 -- ONE k_msp_part1 launch for both -- into segments kept here until a table of shard s + 1 adopts them
+  int early_on;
+  std::vector<rfx_segment>* early;
   uint64_t* lut_t;     // device LUT of T (key -> sortable word), null when M is rank deficient
   uint64_t* lut_tinv;  // device LUT of T^-1
 };
@@ -382,6 +386,7 @@ void tmp_start(rfx_ctx*, const uint64_t* const* seg_bs, int nseg, uint32_t P, ui
 void leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg, const uint64_t* inst0,
           const uint64_t* bs0, uint32_t P, const rfx_ord_cfg&, uint64_t lower, uint64_t upper,
           const uint64_t* tmp_start, uint64_t* tmp_w, uint32_t* tmp_counts, uint64_t* n_surv, unsigned int* err);
+void split_bins(rfx_ctx*, uint64_t* bs, uint32_t P, uint64_t n_own, uint64_t* bs2);
 void scan_tail(rfx_ctx*, uint64_t* v, uint64_t n);  // exclusive scan in place, v[n] = total
 void leaf_compact(rfx_ctx*, const uint64_t* tmp_w, const uint32_t* tmp_counts, const uint64_t* tmp_start,
                   const uint64_t* out_off, uint32_t P, const uint64_t* lut_inv, int ntab, int sel_bits,

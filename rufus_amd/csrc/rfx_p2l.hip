@@ -701,6 +701,18 @@ __global__ __launch_bounds__(256) void k_leaf_compact(const uint64_t* __restrict
   }
 }
 
+// Bin extents of one partition cut in two at record n_own (rfx_count_set_early: the bins below the cut are one table's
+// segment, the bins above it another's): bs keeps the first part (later bins empty at its end), bs2 gets the second,
+// rebased to its own array (earlier bins empty at its start).
+__global__ __launch_bounds__(256) void k_split_bins(uint64_t* __restrict__ bs, uint32_t P, uint64_t n_own,
+                                                     uint64_t* __restrict__ bs2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i > P) return;
+  const uint64_t v = bs[i];
+  bs2[i] = v > n_own ? v - n_own : 0;
+  bs[i] = v < n_own ? v : n_own;
+}
+
 // exclusive scan of v[0..n) in place, v[n] = total (one block): every thread owns a contiguous chunk,
 // the 1024 chunk sums are scanned with wave shuffles (two levels) -- a handful of barriers for any n
 __global__ __launch_bounds__(1024) void k_scan_tail(uint64_t* __restrict__ v, uint64_t n) {
@@ -961,6 +973,10 @@ void leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* se
   const uint32_t grid = P < (uint32_t)c->n_cu * 4 ? P : (uint32_t)c->n_cu * 4;
   hipLaunchKernelGGL(k_leaf, dim3(grid), dim3(LEAF_BLOCK), 0, c->stream, seg_inst, seg_bs, nseg, inst0, bs0, P, cfg,
                      lower, upper, tmp_start_, tmp_w, tmp_counts, n_surv, err);
+}
+
+void split_bins(rfx_ctx* c, uint64_t* bs, uint32_t P, uint64_t n_own, uint64_t* bs2) {
+  hipLaunchKernelGGL(k_split_bins, dim3((P + 1 + 255) / 256), dim3(256), 0, c->stream, bs, P, n_own, bs2);
 }
 
 void scan_tail(rfx_ctx* c, uint64_t* v, uint64_t n) {

@@ -644,3 +644,88 @@ def test_every_cut_of_a_count_leaves_the_same_records(ctx):
     lines = []
     bad = soak_determinism.run(ctx, say=lines.append)
     assert bad == 0 and len(lines) == 12, "\n".join(lines)
+
+
+@pytest.mark.parametrize("k", [25, 31])
+def test_a_block_is_hashed_once_for_two_shards(ctx, k):
+    """rfx_count_set_early / rfx_count_adopt_early: while the table of shard s adds a big block it cuts the runs of shard
+    s + 1 in the same k_msp_part1 launch and keeps them as segments the table of shard s + 1 adopts -- that table is then
+    not given the block.  Same record multiset (rfx_records_checksum + record count, against the one-pass count) for
+    S = 2 and for shards 1 -> 2 of S = 4; k_msp_part1 launches: one per block instead of two; a block too small for
+    the big path and a shard boundary inside a coarse bin (shards 1 | 2 of S = 3) are ordinary adds; an un-adopted early segment is freed
+    with its table."""
+    sy = capi.Synth.sample(30_000_000, 0, n_snv=50, seed=2718)
+    big = wgs.make_sample(ctx, sy, 2_300_000, 2_300_000, MIN_Q, want_good=False, compact=True)       # 5.8e8 windows: the big path
+    small = wgs.make_sample(ctx, sy, 200_000, 200_000, MIN_Q, want_good=False, compact=True, first_pair=2_300_000)
+    assert len(big) == 1 and len(small) == 1
+
+    def finish(t):
+        rec = t.finish(LOWER)
+        out = (rec.checksum(), len(rec))
+        rec.free()
+        t.free()
+        return out
+
+    def whole():
+        t = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+        t.add(big[0])
+        t.add(small[0])
+        return finish(t)
+
+    (ref_cs, ref_n) = whole()
+
+    def launches():
+        return ctx.prof_dict().get("k_msp_part1", (0.0, 0))[1]
+
+    for S, s in ((2, 0), (4, 1), (3, 0), (3, 1)):
+        tabs = []
+        for sh in range(S):
+            t = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+            t.set_shard(sh, S)
+            tabs.append(t)
+        with pytest.raises(capi.RufusError):
+            tabs[S - 1].set_early()                                   # the last shard has no next one
+        ctx.prof(True)
+        ctx.prof_reset()
+        tabs[s].set_early()
+        tabs[s].add(big[0])
+        tabs[s].add(small[0])
+        went_early = tabs[s].early_segments()                         # (the small block follows a big one: same bins, same path)
+        assert went_early == (0 if (S, s) == (3, 1) else 2)           # shards 1 | 2 of 3 meet at 171 / 256: inside a coarse bin
+        with pytest.raises(capi.RufusError):
+            tabs[(s + 2) % S if S > 2 else s].adopt_early(tabs[s])    # not the next shard
+        tabs[s + 1].adopt_early(tabs[s])
+        assert tabs[s].early_segments() == 0
+        if not went_early:
+            tabs[s + 1].add(big[0])
+            tabs[s + 1].add(small[0])
+        for sh in range(S):
+            if sh not in (s, s + 1):
+                tabs[sh].add(big[0])
+                tabs[sh].add(small[0])
+        assert launches() == 2 * S - went_early                       # one launch less: the block was hashed once for two shards
+        cs, n = [0, 0], 0
+        for t in tabs:
+            c1, n1 = finish(t)
+            cs, n = [(a + b) % (1 << 64) for a, b in zip(cs, c1)], n + n1
+        assert (tuple(cs), n) == (ref_cs, ref_n), (S, s)
+    ctx.prof(False)
+    # a block too small for the big path is an ordinary add
+    t = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+    t.set_shard(0, 2)
+    t.set_early()
+    t.add(small[0])
+    assert t.early_segments() == 0
+    t.free()
+    # early segments nobody adopts go with their table
+    used0 = ctx.mem_stats()["used"]
+    t = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+    t.set_shard(0, 2)
+    t.set_early()
+    t.add(big[0])
+    assert t.early_segments() == 1
+    t.free()
+    ctx.sync()
+    assert ctx.mem_stats()["used"] == used0
+    for b in big + small:
+        b.free()

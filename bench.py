@@ -404,8 +404,17 @@ def main():
     # stay on for the whole timed region; on the 4 ms S1 step only during the last timed step.
     ctx.prof_filter(K2_CHAIN + ("k_filter",))
     ctx.prof(True)
-    for _ in range(args.warmup):
+    for w_ in range(args.warmup):
         res = step()
+        # After the first (untimed) step the peak of a step is known: what the device has left beside it (up to 85 % of its
+        # memory) may hold records cut AHEAD for the next shard pass -- blocks hashed once for two passes
+        # (rfx_count_set_early, rufus_amd/wgs.py _count_shard_local).  Same work, same results (the self-check compares the
+        # record multisets with a run of S + 1 plain passes); RFX_BENCH_NO_EARLY=1: off.
+        if w_ == 0 and "_trio" in extra and world == 1 and extra.get("passes", 1) > 1 and not os.environ.get("RFX_BENCH_NO_EARLY"):
+            head = int(0.85 * extra["hbm_total"]) - int(ctx.mem_stats()["peak"])
+            if head > (2 << 30):
+                extra["_trio"].early_budget = head
+                extra["early_cut_budget_bytes"] = head
     live_all = args.workload != "s1"
     ctx.prof(live_all)
     ctx.prof_reset()

@@ -122,6 +122,8 @@ class WgsTrio:
         self.lower, self.min_cov, self.max_cov, self.thresh = lower, min_cov, max_cov, thresh
         self.passes = passes
         self.group = group
+        self.early_budget = 0       # bytes of device memory that may hold records cut ahead for the next shard pass
+        self._early, self._early_left = {}, 0
         if group is not None:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -130,21 +132,66 @@ class WgsTrio:
         if self.passes * self.world > 256:
             raise ValueError("passes x ranks must not exceed the 256 virtual minimizer bins")
 
-    def count_shard(self, blocks, shard: int):
+    def _count_shard_local(self, blocks, shard: int, si):
+        """One device: the table of this (sample, shard).  Shard passes hash every block once per pass; with
+        `early_budget` bytes of headroom (bench.py: what the device has left beside the peak of a step) the blocks are, as
+        far as that goes, hashed ONCE for this shard and the next (rfx_count_set_early): the next shard's records wait
+        in a table of their own (self._early) and that pass is given only the other blocks."""
+        held = self._early.pop((si, shard), None) if si is not None else None
+        if held is not None:
+            t, done = held
+        else:
+            t, done = capi.CountTable(self.ctx, self.k, self.size, True, mode=capi.COUNT_MSP), frozenset()
+            if self.passes > 1:
+                t.set_shard(shard, self.passes)
+        nxt = None
+        try:
+            todo = [i for i in range(len(blocks)) if i not in done]
+            ahead = set()
+            if si is not None and self.passes > 1 and shard + 1 < self.passes and self._early_left > 0:
+                t.set_early(True)
+                cost = 0
+                while todo and self._early_left > cost:     # (cost: what the block before took)
+                    used0, n0 = self.ctx.mem_stats()["used"], t.early_segments()
+                    i = todo.pop(0)
+                    t.add(blocks[i])
+                    if t.early_segments() == n0:            # not a block for the early cut (small, or the shards meet
+                        break                               # inside a coarse bin): neither will the others be
+                    ahead.add(i)
+                    # (the block's own segment came with it: the early half is the next shard's share of the growth)
+                    cost = (self.ctx.mem_stats()["used"] - used0) // 2
+                    self._early_left -= cost
+                t.set_early(False)
+            for i in todo:
+                t.add(blocks[i])
+            if ahead:
+                nxt = capi.CountTable(self.ctx, self.k, self.size, True, mode=capi.COUNT_MSP)
+                nxt.set_shard(shard + 1, self.passes)
+                nxt.adopt_early(t)
+                self._early[(si, shard + 1)] = (nxt, frozenset(ahead))
+                nxt = None
+            return t.finish(self.lower, want_histo=True)
+        finally:
+            if nxt is not None:
+                nxt.free()
+            t.free()
+
+    def _drop_early(self):
+        for t, _ in self._early.values():
+            t.free()
+        self._early = {}
+
+    def count_shard(self, blocks, shard: int, si=None):
         """Records (in (pos,key) order) + histogram of the k-mers of minimizer shard `shard` of `passes` --
         on N ranks: of this rank's 1/N of that shard.  The cut is flat over passes x ranks virtual shards
         (q = shard * N + rank of passes * N), so a pass is a contiguous range of bins split among the ranks:
         every rank partitions ITS blocks restricted to the pass (rfx_count_set_shard(shard, passes)), the
         records of owner g's bins are one contiguous run per segment -> one all_to_all_single per segment
         (RCCL over xGMI), the owner imports the runs and counts complete bins.  No partial counts, no reduce."""
+        if self.world == 1 and not (self.group is not None and os.environ.get("RFX_WGS_FORCE_EXCHANGE")):
+            return self._count_shard_local(blocks, shard, si)
         t = capi.CountTable(self.ctx, self.k, self.size, True, mode=capi.COUNT_MSP)
         try:
-            if self.world == 1 and not (self.group is not None and os.environ.get("RFX_WGS_FORCE_EXCHANGE")):
-                if self.passes > 1:
-                    t.set_shard(shard, self.passes)
-                for b in blocks:
-                    t.add(b)
-                return t.finish(self.lower, want_histo=True)
             err = None
             try:        # local work: a failure here is carried to the first checkpoint of the exchange
                 if self.passes > 1:
@@ -432,6 +479,8 @@ class WgsTrio:
             n_rec = [0] * len(samples)
             keys, kept, recs = [], [], []
             cand = None
+            self._drop_early()
+            self._early_left = int(self.early_budget) if self.world == 1 and not keep_shard_records else 0
             ver = {"bad_order": 0, "bad_pos": 0, "bad_count": 0, "sum_counts": [0] * len(samples),
                    "probe_found": [0] * len(samples), "probe_count_out_of_range": 0,
                    "checksum": [[0, 0] for _ in samples]}   # rfx_records_checksum, summed over the shards
@@ -442,7 +491,7 @@ class WgsTrio:
                     # count <= MaxDepth; every control then strikes out what it holds and is freed at once
                     # (rfx_records_subtract) -- one sample's records alive at a time instead of all of them.
                     for si, blocks in enumerate(samples):
-                        rec, h = self.count_shard(blocks, sh)       # (its failures are agreed inside)
+                        rec, h = self.count_shard(blocks, sh, si)   # (its failures are agreed inside)
                         recs.append(rec)
                         histos[si] += h
                         n_rec[si] += len(rec)
@@ -480,6 +529,8 @@ class WgsTrio:
                     raise
                 for r in recs + [r_ for shard in kept for r_ in shard] + ([cand] if cand is not None else []):
                     r.free()
+                self._drop_early()
+                self.early_budget = 0       # (the headroom was not there after all)
                 if self.world > 1:
                     import torch
                     torch.cuda.empty_cache()    # the receive buffers of the failed pass go back to the driver

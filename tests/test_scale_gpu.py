@@ -235,10 +235,25 @@ def test_wgs_slice_properties(ctx):
     for r in recs:
         r.free()
     del res1
-    res2 = wgs.WgsTrio(ctx, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=2).run(samples)
+    res2 = wgs.WgsTrio(ctx, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=2).run(samples, verify=True)
     assert res2["n_records"] == n_rec1 and res2["n_pulled"] == pulled1
     assert np.array_equal(res2["mutant_keys"], keys1)
     assert all(np.array_equal(a, b) for a, b in zip(res2["histos"], h1))
+    # .. and two passes with blocks hashed ONCE for both (WgsTrio.early_budget: room for the second pass's records of
+    # about two and a half samples' blocks here): fewer k_msp_part1 launches, the same record multisets
+    trio = wgs.WgsTrio(ctx, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=2)
+    trio.early_budget = 14 << 30
+    ctx.prof(True)
+    ctx.prof_reset()
+    res3 = trio.run(samples, verify=True)
+    n_launch = ctx.prof_dict()["k_msp_part1"][1]
+    ctx.prof(False)
+    n_blocks = sum(len(s) for s in samples)
+    assert n_blocks < n_launch < 2 * n_blocks and not trio._early
+    assert res3["n_records"] == n_rec1 and res3["n_pulled"] == pulled1 and np.array_equal(res3["mutant_keys"], keys1)
+    assert all(np.array_equal(a, b) for a, b in zip(res3["histos"], h1))
+    assert res3["verify"]["checksum"] == res2["verify"]["checksum"] and res3["verify"]["bad_order"] == 0
+    print(f"k_msp_part1 launches: {n_launch} with blocks cut ahead, {2 * n_blocks} without")
     for s in samples:
         for b in s:
             b.free()

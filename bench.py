@@ -411,7 +411,7 @@ def main():
         # (rfx_count_set_early, rufus_amd/wgs.py _count_shard_local).  Same work, same results (the self-check compares the
         # record multisets with a run of S + 1 plain passes); RFX_BENCH_NO_EARLY=1: off.
         if w_ == 0 and "_trio" in extra and world == 1 and extra.get("passes", 1) > 1 and not os.environ.get("RFX_BENCH_NO_EARLY"):
-            head = int(0.85 * extra["hbm_total"]) - int(ctx.mem_stats()["peak"])
+            head = int(0.85 * min(extra["hbm_total"], extra["hbm_free_at_start"])) - int(ctx.mem_stats()["peak"])
             if head > (2 << 30):
                 extra["_trio"].early_budget = head
                 extra["early_cut_budget_bytes"] = head

@@ -162,6 +162,8 @@ class WgsTrio:
                     cost = (self.ctx.mem_stats()["used"] - used0) // 2
                     self._early_left -= cost
                 t.set_early(False)
+                if ahead:
+                    self._inject("early", shard)     # (tests: the headroom turns out not to be there)
             for i in todo:
                 t.add(blocks[i])
             if ahead:
@@ -239,7 +241,8 @@ class WgsTrio:
 
     def _inject(self, stage: str, shard: int):
         """Fault injection for the tests of the agreed retry: RFX_WGS_INJECT_OOM="rank:stage:shard" makes that rank
-        fail once with an out-of-memory error at that stage (partition | receive | finish) of that shard."""
+        fail once with an out-of-memory error at that stage (partition | receive | finish; early: after blocks were cut
+        ahead on one device) of that shard."""
         spec = os.environ.get("RFX_WGS_INJECT_OOM")
         if not spec or getattr(self, "_injected", False):
             return
@@ -530,10 +533,14 @@ class WgsTrio:
                 for r in recs + [r_ for shard in kept for r_ in shard] + ([cand] if cand is not None else []):
                     r.free()
                 self._drop_early()
-                self.early_budget = 0       # (the headroom was not there after all)
                 if self.world > 1:
                     import torch
                     torch.cuda.empty_cache()    # the receive buffers of the failed pass go back to the driver
+                if self.early_budget > 0:       # the headroom for blocks cut ahead was not there after all: the same
+                    self.early_budget = 0       # passes once more without them
+                    if trace:
+                        print("[wgs] out of device memory: retrying without blocks cut ahead", flush=True)
+                    continue
                 self.passes += 1
                 if trace:
                     print(f"[wgs] out of device memory: retrying with {self.passes} passes", flush=True)

@@ -254,6 +254,17 @@ def test_wgs_slice_properties(ctx):
     assert all(np.array_equal(a, b) for a, b in zip(res3["histos"], h1))
     assert res3["verify"]["checksum"] == res2["verify"]["checksum"] and res3["verify"]["bad_order"] == 0
     print(f"k_msp_part1 launches: {n_launch} with blocks cut ahead, {2 * n_blocks} without")
+    # .. and when the headroom turns out not to be there (an out-of-memory error with blocks cut ahead): the same two
+    # passes once more without them, not a third pass
+    os.environ["RFX_WGS_INJECT_OOM"] = "0:early:0"
+    try:
+        trio = wgs.WgsTrio(ctx, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=2)
+        trio.early_budget = 14 << 30
+        res4 = trio.run(samples)
+    finally:
+        del os.environ["RFX_WGS_INJECT_OOM"]
+    assert trio.passes == 2 and trio.early_budget == 0 and not trio._early
+    assert res4["n_records"] == n_rec1 and np.array_equal(res4["mutant_keys"], keys1)
     for s in samples:
         for b in s:
             b.free()

@@ -406,13 +406,13 @@ def main():
     ctx.prof(True)
     for w_ in range(args.warmup):
         res = step()
-        # After the first (untimed) step the peak of a step is known: what the device has left beside it (up to 88 % of its
+        # After the first (untimed) step the peak of a step is known: what the device has left beside it (up to 86 % of its
         # memory) may hold records cut AHEAD for the next shard pass -- blocks hashed once for two passes
         # (rfx_count_set_early, rufus_amd/wgs.py _count_shard_local).  Same results (the self-check compares the
         # record multisets with a run of S + 1 plain passes); RFX_BENCH_NO_EARLY=1: off.
         if w_ == 0 and "_trio" in extra and world == 1 and extra.get("passes", 1) > 1 and not os.environ.get("RFX_BENCH_NO_EARLY"):
-            # (88 %: should a step not fit after all, WgsTrio.run drops the blocks cut ahead and repeats it -- same passes)
-            head = int(0.88 * min(extra["hbm_total"], extra["hbm_free_at_start"])) - int(ctx.mem_stats()["peak"])
+            # (86 %: should a step not fit after all, WgsTrio.run drops the blocks cut ahead and repeats it -- same passes)
+            head = int(0.86 * min(extra["hbm_total"], extra["hbm_free_at_start"])) - int(ctx.mem_stats()["peak"])
             if head > (2 << 30):
                 extra["_trio"].early_budget = head
                 extra["early_cut_budget_bytes"] = head

@@ -123,7 +123,7 @@ class WgsTrio:
         self.passes = passes
         self.group = group
         self.early_budget = 0       # bytes of device memory that may hold records cut ahead for the next shard pass
-        self._early, self._early_left = {}, 0
+        self._early, self._early_left, self._early_cost = {}, 0, 0
         if group is not None:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -150,7 +150,7 @@ class WgsTrio:
             ahead = set()
             if si is not None and self.passes > 1 and shard + 1 < self.passes and self._early_left > 0:
                 t.set_early(True)
-                cost = 0
+                cost = self._early_cost
                 while todo and self._early_left > cost:     # (cost: what the block before took)
                     used0, n0 = self.ctx.mem_stats()["used"], t.early_segments()
                     i = todo.pop(0)
@@ -159,7 +159,7 @@ class WgsTrio:
                         break                               # inside a coarse bin): neither will the others be
                     ahead.add(i)
                     # (the block's own segment came with it: the early half is the next shard's share of the growth)
-                    cost = (self.ctx.mem_stats()["used"] - used0) // 2
+                    cost = self._early_cost = (self.ctx.mem_stats()["used"] - used0) // 2
                     self._early_left -= cost
                 t.set_early(False)
                 if ahead:
@@ -441,11 +441,18 @@ class WgsTrio:
             lap(f"pass {sh} sample {si} kept ({len(rec)})")
             return rec
         raw = getattr(self, "_cand_raw", False)
+        raw_bytes = len(cand) * 20 if raw else 0
         nxt = (capi.records_subtract(self.ctx, cand, [rec], max(5, self.min_cov), self.max_cov) if raw else
                capi.records_subtract(self.ctx, cand, [rec]))
         self._cand_raw = False
         cand.free()
         cand = nxt
+        # The step's peak is the count of the FIRST control of a pass (the subject's records wait beside it); from here on
+        # the pass runs that much lower, and so may hold that much more of the next pass's records cut ahead -- provided the
+        # samples they belong to are counted BEFORE the first control of that pass (run() reverses the controls' order on
+        # odd passes).  Two passes only: with more, what is held overlaps from pass to pass.
+        if raw and self.passes == 2 and sh == 0 and self.early_budget > 0:
+            self._early_left += raw_bytes
         rec.free()
         recs.pop()
         lap(f"pass {sh} sample {si} candidates ({len(cand)})")
@@ -493,7 +500,14 @@ class WgsTrio:
                     # The subject (sample 0) is counted first and only its CANDIDATES stay: the records with MinCov <=
                     # count <= MaxDepth; every control then strikes out what it holds and is freed at once
                     # (rfx_records_subtract) -- one sample's records alive at a time instead of all of them.
-                    for si, blocks in enumerate(samples):
+                    # (odd passes take the controls in reverse: the control counted last in one pass -- whose records of
+                    # the next pass may have been cut ahead in the room the subject's records left, see _after_count --
+                    # is the first control of the next)
+                    order = list(range(len(samples)))
+                    if sh % 2 == 1 and not keep_shard_records:
+                        order = order[:1] + order[:0:-1]
+                    for si in order:
+                        blocks = samples[si]
                         rec, h = self.count_shard(blocks, sh, si)   # (its failures are agreed inside)
                         recs.append(rec)
                         histos[si] += h

@@ -321,7 +321,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)   # (the second one runs with the blocks cut ahead: the arena grows there)
     ap.add_argument("--workload", choices=("wgs", "tn", "s1"), default="wgs",
                     help="wgs: 30x trio, k=25 (configs[2]); tn: tumor 60x / normal 30x, k=31 (configs[4]); s1: configs[1]")
     ap.add_argument("--k", type=int, default=0, help="k-mer length (default 25; 31 for tn)")

@@ -391,7 +391,29 @@ __global__ __launch_bounds__(L2_BLOCK) void k_part2(const uint64_t* __restrict__
   __shared__ uint64_t s_soff[MULTI ? L2_MAX_SEGS + 1 : 1];         // where slice s begins in the concatenation
   __shared__ const uint64_t* s_sptr[MULTI ? L2_MAX_SEGS : 1];      // its first word
   __shared__ const uint32_t* s_spay[MULTI && PAYLOAD ? L2_MAX_SEGS : 1];
+  // Workgroup i runs on XCD i % 8, each with an L2 of its own: the W workgroups of a coarse bin append to the SAME 256
+  // output runs (neighbouring reservations: the partial lines where two of them meet merge in an L2 only if both writers
+  // sit behind it), so they are given ids that land on one XCD.
+#ifndef RFX_P2_NO_XCD  // (W, ms per sample: k_part2 94 -> 77, k_part3 94 -> 68, k_surv_part2 22 -> 16)
+  uint32_t cb = blockIdx.x / W, j = blockIdx.x - cb * W;
+  if (MULTI || coarse_start) {
+    // a refinement: every parent bin has records, and the fine bins of neighbouring parents are neighbours in memory too --
+    // XCD x takes a contiguous range of ids: [x * per + min(x, rem), ..), per + 1 of them for x < rem (a bijection for any grid)
+    const uint32_t xcd = blockIdx.x & 7u, per = gridDim.x >> 3, rem = gridDim.x & 7u;
+    const uint32_t bid = xcd * per + (xcd < rem ? xcd : rem) + (blockIdx.x >> 3);
+    cb = bid / W;
+    j = bid - cb * W;
+  } else if (((gridDim.x / W) & 7u) == 0 && gridDim.x % W == 0) {
+    // the 128 coarse bins of k_msp_part1 / of the leaf's survivors: a shard pass fills only a contiguous part of them (handing
+    // XCD x the bins [16 x, 16 x + 16) left half the chip without work at W), so bin cb goes to XCD cb % 8, its W workgroups
+    // are that XCD's slots W * (cb / 8) ..
+    const uint32_t slot = blockIdx.x >> 3;
+    cb = (slot / W) * 8u + (blockIdx.x & 7u);
+    j = slot - (slot / W) * W;
+  }
+#else
   const uint32_t cb = blockIdx.x / W, j = blockIdx.x - cb * W;
+#endif
   if (MULTI) {
     if (threadIdx.x < (uint32_t)nseg) {
       const uint64_t* cs = seg_cs[threadIdx.x] + cs_off;

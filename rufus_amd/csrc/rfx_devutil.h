@@ -171,7 +171,10 @@ constexpr int P1_STAGE = P2_BLOCK * P1_S;     // words staged per phase
 constexpr int P1_CUR_STRIDE = 64;             // fused path: one 256 B line per coarse-bin cursor (L2 atomics
                                               // on one line serialise; 128 cursors in 4 lines cost 0.2 ms)
 constexpr int L2_BLOCK = 1024;
-constexpr int L2_PER = 8;                     // words per lane per tile
+#ifndef RFX_L2_PER
+#define RFX_L2_PER 8
+#endif
+constexpr int L2_PER = RFX_L2_PER;            // words per lane per tile
 constexpr int L2_TILE = L2_BLOCK * L2_PER;
 
 // exclusive scan of up to 256 LDS counters by wave 0 (4 per lane); returns the total in s_start[n]

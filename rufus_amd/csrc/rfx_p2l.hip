@@ -921,7 +921,10 @@ void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* f
   // Workgroups per coarse bin: as many as are resident at once (two per CU), each looping over its share
   // of the 8192-entry tiles (measured on one box, 4 / 8 / 16 per bin: 0.120 / 0.125 / 0.131 ms for the MSP
   // records, 0.470 / 0.471 / 0.478 ms for the P2L words); fewer when the input has only a few tiles.
-  uint32_t W = nc >= 2048 ? 1 : std::max(1u, (uint32_t)c->n_cu * 2 / nc);
+#ifndef RFX_P2_WMUL
+#define RFX_P2_WMUL 8  // (16 workgroups per coarse bin instead of 4 now that they share an L2: k_part2 77 -> 64 ms per W sample)
+#endif
+  uint32_t W = nc >= 2048 ? 1 : std::max(1u, (uint32_t)c->n_cu * RFX_P2_WMUL / nc);
   if (n_hint && nc < 2048) {
     const uint64_t tiles = (n_hint / nc + L2_TILE - 1) / L2_TILE;
     W = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(W, (tiles + 1) / 2));
@@ -968,7 +971,10 @@ void part2_multi(rfx_ctx* c, const uint64_t* const* seg_a, const uint64_t* const
   if (!n_coarse) return;
   // a handful of tiles per workgroup: the launch ends in a tail one workgroup long
   const uint64_t tiles = n_hint / n_coarse / L2_TILE + 1;
-  const uint32_t W = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / 6));
+#ifndef RFX_P3_TDIV
+#define RFX_P3_TDIV 3
+#endif
+  const uint32_t W = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(16, tiles / RFX_P3_TDIV));
 #define RFX_PART2M(PAY, MODE)                                                                                          \
   hipLaunchKernelGGL((k_part2<PAY, MODE, true>), dim3(n_coarse * W), dim3(L2_BLOCK), 0, c->stream,                     \
                      (const uint64_t*)nullptr, buf_b, fine_start, fine_cur, P2, shift2, W, (const uint32_t*)nullptr, 0u, \

@@ -41,7 +41,7 @@ READ_LEN = 150
 SEED = 12345
 
 # every launch of the count -> sorted-records stage, whichever path rfx_count_add/finish took
-K2_CHAIN = ("k_msp_part1", "k_msp_count", "k_bin_offsets", "k_rec_hist", "k_part2", "k_bin_hist", "k_part3", "k_part4", "k_msp_leaf",
+K2_CHAIN = ("k_msp_part1", "k_msp_map", "k_msp_replay", "k_msp_count", "k_bin_offsets", "k_rec_hist", "k_part2", "k_bin_hist", "k_part3", "k_part4", "k_msp_leaf",
             "k_surv_hist", "k_surv_part2", "k_surv_part3", "k_surv_sort", "k_histo",
             "k_bin_count", "k_bin_scatter", "k_part1", "k_leaf", "k_leaf_compact", "k_count_reads")
 
@@ -301,6 +301,8 @@ def run_wgs(args, ctx, rank, world, dist, torch):
     t_gen = time.perf_counter() - t0
     trio = wgs.WgsTrio(ctx, k, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes,
                        group=dist.group.WORLD if world > 1 else None)
+    if os.environ.get("RFX_BENCH_MAP_BUDGET"):     # (profiling runs without a warm-up step: the run-map pool from the start)
+        trio.map_budget = int(float(os.environ["RFX_BENCH_MAP_BUDGET"]))
     step = lambda: trio.run(samples)  # noqa: E731
     reads = [2 * n for n in pairs]
     what = (f"tumor {covs[0]}x / normal {covs[1]}x pair (BASELINE configs[4])" if tn
@@ -406,16 +408,27 @@ def main():
     ctx.prof(True)
     for w_ in range(args.warmup):
         res = step()
-        # After the first (untimed) step the peak of a step is known: what the device has left beside it (up to 86 % of its
-        # memory) may hold records cut AHEAD for the next shard pass -- blocks hashed once for two passes
-        # (rfx_count_set_early, rufus_amd/wgs.py _count_shard_local).  Same results (the self-check compares the
-        # record multisets with a run of S + 1 plain passes); RFX_BENCH_NO_EARLY=1: off.
+        # After the first (untimed) step the peak of a step is known: what the device has left beside it (up to 93 % of its
+        # memory) may hold RUN MAPS -- 32 bytes per read that the first shard pass over a block leaves so that the later
+        # passes rebuild their records from reads + map instead of hashing the block again (rfx_runmaps_*,
+        # rufus_amd/wgs.py _count_shard_local).  Same results (the self-check compares the record multisets with a run of
+        # S + 1 plain passes).  RFX_BENCH_EARLY=1: round 4's scheme instead (blocks cut ahead for the next pass, 132 bytes
+        # per read: rfx_count_set_early); RFX_BENCH_NO_EARLY=1: neither.
         if w_ == 0 and "_trio" in extra and world == 1 and extra.get("passes", 1) > 1 and not os.environ.get("RFX_BENCH_NO_EARLY"):
-            # (86 %: should a step not fit after all, WgsTrio.run drops the blocks cut ahead and repeats it -- same passes)
-            head = int(0.86 * min(extra["hbm_total"], extra["hbm_free_at_start"])) - int(ctx.mem_stats()["peak"])
+            # (should a step not fit after all, WgsTrio.run drops the maps and repeats it -- same passes)
+            frac = float(os.environ.get("RFX_BENCH_HEADROOM", "0.86" if os.environ.get("RFX_BENCH_EARLY") else "0.93"))
+            head = int(frac * min(extra["hbm_total"], extra["hbm_free_at_start"])) - int(ctx.mem_stats()["peak"])
             if head > (2 << 30):
-                extra["_trio"].early_budget = head
-                extra["early_cut_budget_bytes"] = head
+                if os.environ.get("RFX_BENCH_EARLY"):
+                    extra["_trio"].early_budget = head
+                    extra["early_cut_budget_bytes"] = head
+                else:
+                    # the pool holds two samples' maps (WgsTrio.run orders the passes so that no more are alive)
+                    per_sample = max(sum(((b.n * 32 + 255) & ~255) + ((b.n // 32 + 4097) * 4 + 255 & ~255) for b in s_)
+                                     for s_ in extra["_samples"])
+                    pool = min(head, 2 * per_sample + (1 << 20))
+                    extra["_trio"].map_budget = pool
+                    extra["run_map_budget_bytes"] = pool
     live_all = args.workload != "s1"
     ctx.prof(live_all)
     ctx.prof_reset()
@@ -437,6 +450,7 @@ def main():
         t_chk = time.perf_counter()
         checks = wgs.self_check(ctx, extra["_trio"], extra["_samples"], extra["_sys"], res, extra["_pairs"][0], MIN_Q)
         checks["seconds"] = round(time.perf_counter() - t_chk, 1)
+    trio_ = extra.get("_trio")
     extra = {k_: v for k_, v in extra.items() if not k_.startswith("_")}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -467,6 +481,7 @@ def main():
                        "reads_filtered_per_step": reads_filtered, "parallelism": f"read-block shard x{world}",
                        "mutant_kmers": int(res["n_mutant"]), "pulled_pairs": int(res["n_pulled"]),
                        "records_per_sample": [int(x) for x in res["n_records"]], **extra,
+                       **({"blocks_replayed_from_run_maps_per_step": int(trio_.replayed_blocks)} if trio_ is not None else {}),
                        "checked": checks is not None, "checks": checks,
                        **({"one_device_dry_run": f"{world} ranks share device 0 over {dist.get_backend()}: the N-rank path is "
                                                  "exercised, the value is NOT a scaling measurement"} if args.one_device and world > 1 else {}),

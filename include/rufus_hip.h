@@ -222,6 +222,28 @@ int rfx_count_set_shard(rfx_table*, int shard, int n_shards);
 int rfx_count_set_early(rfx_table*, int on);
 int rfx_count_early_segments(const rfx_table*);
 int rfx_count_adopt_early(rfx_table* next_shard, rfx_table* from);
+/* Hash every base ONCE over all shard passes (the reference hashes a k-mer once: jf/sub_commands/count_main.cc:148-180;
+ * its spill-and-merge analogue, jf/include/jellyfish/hash_counter.hpp:182-202, does not re-read the input either).  A
+ * store of RUN MAPS is shared by the tables of one sample's shard passes (rfx_count_set_runmaps on each, before its
+ * adds): the first table that adds a big block (>= 2^29 windows, reads of <= 160 bases, its shard at most half of the
+ * bins) also writes the block's map -- 32 bytes per read that say how the read falls into super-k-mers and where
+ * their minimizers sit -- and every later table of another shard rebuilds ITS records from reads + map (k_msp_replay)
+ * instead of hashing the block again: the same records, bit for bit.  budget_bytes bounds the maps held (0: no bound);
+ * a block beyond it is hashed by every pass as before.  rfx_runmaps_drop frees one block's map (after the last
+ * pass has added it); the store must be freed before the read blocks it was made from.  rfx_count_set_passes tables
+ * make and use a store of their own when the device has room.  rfx_count_replayed: blocks a table added by replay. */
+typedef struct rfx_runmaps rfx_runmaps;
+rfx_runmaps* rfx_runmaps_create(rfx_ctx*, uint64_t budget_bytes);
+/* the same with ONE device allocation of pool_bytes made now, out of which the maps are cut: a store that serves many
+ * samples one after the other (the WGS driver) does not leave the device memory in pieces; NULL when it does not fit */
+rfx_runmaps* rfx_runmaps_create_pooled(rfx_ctx*, uint64_t pool_bytes);
+void rfx_runmaps_free(rfx_runmaps*);
+uint64_t rfx_runmaps_bytes(const rfx_runmaps*);
+int rfx_runmaps_blocks(const rfx_runmaps*);
+int rfx_runmaps_drop(rfx_runmaps*, const rfx_reads*);
+int rfx_runmaps_clear(rfx_runmaps*); /* every map of the store */
+int rfx_count_set_runmaps(rfx_table*, rfx_runmaps*);
+uint64_t rfx_count_replayed(const rfx_table*);
 /* Bounded-HBM counting of a whole sample (MSP path, call before the first add): rfx_count_add() only
  * REMEMBERS the read blocks -- they must stay alive until finish -- and rfx_count_finish() runs `passes`
  * minimizer-shard passes over them (0: planned from the free HBM, 1 if everything fits): per pass the shard's

@@ -75,6 +75,15 @@ SIGNATURES = {
     "rfx_count_set_early": (C.c_int, [C.c_void_p, C.c_int]),
     "rfx_count_early_segments": (C.c_int, [C.c_void_p]),
     "rfx_count_adopt_early": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rfx_runmaps_create": (C.c_void_p, [C.c_void_p, C.c_uint64]),
+    "rfx_runmaps_create_pooled": (C.c_void_p, [C.c_void_p, C.c_uint64]),
+    "rfx_runmaps_free": (None, [C.c_void_p]),
+    "rfx_runmaps_bytes": (C.c_uint64, [C.c_void_p]),
+    "rfx_runmaps_blocks": (C.c_int, [C.c_void_p]),
+    "rfx_runmaps_drop": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rfx_runmaps_clear": (C.c_int, [C.c_void_p]),
+    "rfx_count_set_runmaps": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rfx_count_replayed": (C.c_uint64, [C.c_void_p]),
     "rfx_count_segments": (C.c_int, [C.c_void_p]),
     "rfx_count_segment_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
                                         C.POINTER(C.c_uint32), u64p]),
@@ -474,6 +483,35 @@ class Records:
             self._h = None
 
 
+class RunMaps:
+    """Run maps of one sample's read blocks (rfx_runmaps_*): written by the first shard pass that adds a big block,
+    replayed by the later ones instead of hashing the block again.  Free it before the blocks."""
+
+    def __init__(self, ctx: Context, budget_bytes: int = 0, pooled: bool = False):
+        """pooled: the budget is allocated now, in one piece, and the maps are cut out of it."""
+        self.ctx = ctx
+        self._h = (lib().rfx_runmaps_create_pooled if pooled else lib().rfx_runmaps_create)(ctx._h, int(budget_bytes))
+        if not self._h:
+            raise RufusError("rfx_runmaps_create failed: " + lib().rfx_last_error().decode())
+
+    def bytes(self) -> int:
+        return int(lib().rfx_runmaps_bytes(self._h)) if self._h else 0
+
+    def blocks(self) -> int:
+        return int(lib().rfx_runmaps_blocks(self._h)) if self._h else 0
+
+    def drop(self, reads: "ReadBlock"):
+        _check(lib().rfx_runmaps_drop(self._h, reads._h), "rfx_runmaps_drop")
+
+    def clear(self):
+        _check(lib().rfx_runmaps_clear(self._h), "rfx_runmaps_clear")
+
+    def free(self):
+        if self._h:
+            lib().rfx_runmaps_free(self._h)
+            self._h = None
+
+
 class CountTable:
     """``jellyfish count`` state: exact canonical k-mer counts in an HBM hash table."""
 
@@ -514,6 +552,13 @@ class CountTable:
     def adopt_early(self, other: "CountTable"):
         """Take the early segments `other` (the table of the shard before this one) holds for this shard."""
         _check(lib().rfx_count_adopt_early(self._h, other._h), "rfx_count_adopt_early")
+
+    def set_runmaps(self, store: "RunMaps"):
+        """Share a store of run maps with the tables of the sample's other shard passes (rfx_count_set_runmaps)."""
+        _check(lib().rfx_count_set_runmaps(self._h, store._h if store is not None else None), "rfx_count_set_runmaps")
+
+    def replayed(self) -> int:
+        return int(lib().rfx_count_replayed(self._h))
 
     def segments(self):
         """[(d_records, d_bin_start, bins, n_records)] of the MSP record segments held (device pointers)."""

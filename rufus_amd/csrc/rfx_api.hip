@@ -1120,6 +1120,40 @@ struct msp_geom {
   int rec_mode;  // rfxk::part2 / bin_hist mode of this table's records
 };
 
+// memory of a run map: the store's pool when it has one, else the arena
+static void* runmaps_alloc(rfx_runmaps* s, size_t bytes) {
+  if (!s->pool) return dmalloc(s->ctx, bytes);
+  bytes = (bytes + 255) & ~(size_t)255;
+  for (auto it = s->pool_free.begin(); it != s->pool_free.end(); ++it)
+    if (it->second >= bytes) {
+      const size_t off = it->first, len = it->second;
+      s->pool_free.erase(it);
+      if (len > bytes) s->pool_free[off + bytes] = len - bytes;
+      return s->pool + off;
+    }
+  return nullptr;
+}
+static void runmaps_release(rfx_runmaps* s, void* p, size_t bytes) {
+  if (!p) return;
+  if (!s->pool) { dfree(s->ctx, p); return; }
+  bytes = (bytes + 255) & ~(size_t)255;
+  size_t off = (size_t)((char*)p - s->pool), len = bytes;
+  auto next = s->pool_free.lower_bound(off);
+  if (next != s->pool_free.begin()) {
+    auto prev = std::prev(next);
+    if (prev->first + prev->second == off) {
+      off = prev->first;
+      len += prev->second;
+      s->pool_free.erase(prev);
+    }
+  }
+  if (next != s->pool_free.end() && off + len == next->first) {
+    len += next->second;
+    s->pool_free.erase(next);
+  }
+  s->pool_free[off] = len;
+}
+
 static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   rfx_ctx* c = t->ctx;
   g.windows = r->windows_of(t->k);
@@ -1275,18 +1309,85 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
     const uint32_t p1_hi = early ? g2.bin_hi : g.bin_hi;
     const uint32_t c_n_all = p1_hi > g.bin_lo ? (p1_hi - 1) / g.P2 - g.c_lo + 1 : 1;  // coarse bins of the launch
     const uint32_t c_mid = g.bin_hi / g.P2;                                             // first coarse bin of the next shard
+    // Run maps (rfx_msp.hip): with S > 1 shard passes a big block is hashed ONCE, into its map (by the first pass that
+    // adds it); every pass, that one included, cuts its records from reads + map.
+    rfx_runmap_entry* have = nullptr;
+    int G_rep = 0, G_ovf = 0;
+    if (t->runmaps && t->n_shards > 1 && !early && r->max_len <= 160 && g.bin_hi - g.bin_lo <= 16384u &&
+        !getenv("RFX_MSP_REC_HIST") && !getenv("RFX_NO_RUNMAP")) {
+      rfx_runmaps* st = t->runmaps;
+      auto it = st->m.find(r);
+      if (it != st->m.end()) {
+        rfx_runmap_entry& en = it->second;
+        if (en.k == t->k && en.canonical == t->canonical && en.n_reads == r->n && en.codes == r->codes) have = &en;
+      } else {
+        const uint32_t ovf_cap = r->n / 32 + 4096;
+        const size_t map_bytes = (size_t)r->n * 32, ovf_bytes = ((size_t)ovf_cap + 1) * 4;
+        if (!st->budget || st->bytes + map_bytes + ovf_bytes <= st->budget) {
+          void* map_dev = runmaps_alloc(st, map_bytes);
+          uint32_t* map_ovf = (uint32_t*)runmaps_alloc(st, ovf_bytes);
+          uint32_t n_ovf = 0;
+          bool ok = map_dev && map_ovf && hipMemsetAsync(map_ovf, 0, 4, c->stream) == hipSuccess;
+          if (ok) {
+            rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 0, 0, 4, rfxk::msp_map_grid(c, r->n), nullptr, nullptr, 0, nullptr, nullptr, 0, map_dev,
+                            map_ovf, ovf_cap);
+            ok = queue_read(c, &n_ovf, map_ovf, 4) == hipSuccess && ctx_sync(c) == hipSuccess;
+          }
+          if (ok && n_ovf <= ovf_cap) {
+            rfx_runmap_entry en;
+            en.map = map_dev;
+            en.ovf = map_ovf;
+            en.n_ovf = n_ovf;
+            en.n_reads = r->n;
+            en.codes = r->codes;
+            en.k = t->k;
+            en.canonical = t->canonical;
+            en.map_bytes = map_bytes;
+            en.ovf_bytes = ovf_bytes;
+            en.bytes = map_bytes + ovf_bytes;
+            st->bytes += en.bytes;
+            have = &(st->m[r] = en);
+          } else {  // no room (or more reads without a map than the list holds): the passes hash the block as before
+            if (map_dev) runmaps_release(st, map_dev, map_bytes);
+            if (map_ovf) runmaps_release(st, map_ovf, ovf_bytes);
+            if (hipGetLastError() != hipSuccess) { dfree(c, cur); dfree(c, bin_start); return RFX_E_HIP; }
+          }
+        }
+      }
+    }
+    if (have) {  // (a chunk of 512 reads puts ~90 records into a coarse bin between two turns of the slabs)
+      G_rep = rfxk::msp_replay_grid(c, r->n);
+      G_ovf = have->n_ovf ? (int)std::min<uint32_t>(512, ((have->n_ovf + 511) / 512 + 7) & ~7u) : 0;
+      slab_log2 = std::max(slab_log2, 7);
+      cap_a = even + even / 16 + 16384 + rfxk::msp_part1_slack(G_rep + G_ovf, slab_log2);
+      if (cap_a >= (1ull << 32)) return RFX_E_RANGE;
+    }
+    auto drop_map = [&] {};
     for (int attempt = 0;; ++attempt) {
       char* buf_a = (char*)dmalloc(c, cap_a * c_n_all * 12);  // 12-byte slots: word and plane side by side
-      if (!buf_a) { dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
+      if (!buf_a) { drop_map(); dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
       char* buf_a0 = buf_a - (size_t)g.c_lo * cap_a * 12;  // the address coarse bin 0 would have
-      auto fail = [&](int rc) { dfree(c, buf_a); dfree(c, cur); dfree(c, bin_start); return rc; };
+      auto fail = [&](int rc) { drop_map(); dfree(c, buf_a); dfree(c, cur); dfree(c, bin_start); return rc; };
       hipError_t e = hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream);
       if (e == hipSuccess) e = hipMemsetAsync(bin_start, 0, ((size_t)P + 1) * 8, c->stream);
       if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
       // the exact fine histogram comes with the scatter (16-bit LDS counters, 64 KB per workgroup); only if one of
       // them wrapped are the records read once more for it
-      uint32_t* cnt = getenv("RFX_MSP_REC_HIST") ? nullptr : (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
-      if (cnt) {
+      const uint32_t rows = have ? (uint32_t)(G_rep + G_ovf) : (uint32_t)g.G;
+      uint32_t* cnt = getenv("RFX_MSP_REC_HIST") ? nullptr : (uint32_t*)dmalloc(c, (size_t)rows * P * 4);
+      if (have && !cnt) return fail(RFX_E_NOMEM);
+      if (have) {
+        rfxk::msp_replay(c, rv, have->map, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, G_rep, buf_a0, cur, (uint32_t)cap_a, cnt,
+                         cur + g.ncur, slab_log2);
+        if (have->n_ovf) {  // the reads whose runs did not fit a map: hashed as ever
+          rfx_reads_view rvo = rv;
+          rvo.idx = have->ovf + 1;
+          rvo.n = have->n_ovf;
+          rfxk::msp_part1(c, rvo, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 3, G_ovf, buf_a0, cur, (uint32_t)cap_a,
+                          cnt + (size_t)G_rep * P, cur + g.ncur, slab_log2);
+        }
+        rfxk::bin_totals(c, cnt, rows, P, bin_start);
+      } else if (cnt) {
         rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, p1_hi, 3, g.G, buf_a0, cur, (uint32_t)cap_a, cnt,
                         cur + g.ncur, slab_log2);
         rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
@@ -1318,7 +1419,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
           if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
         } else {
           dfree(c, buf_a);
-          if (attempt >= 3 || need >= (1ull << 32) - 65536) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
+          if (attempt >= 3 || need >= (1ull << 32) - 65536) { drop_map(); dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
           cap_a = need + need / 64 + 1024;
           continue;
         }
@@ -1355,6 +1456,7 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
         t->seg_kind = RFX_COUNT_MSP;
         return RFX_OK;
       }
+      if (have) ++t->replayed;
       uint64_t* inst = (uint64_t*)dmalloc(c, (total ? total : 1) * 8);
       uint32_t* ext = wide ? (uint32_t*)dmalloc(c, (total ? total : 1) * 4) : nullptr;
       if (!inst || (wide && !ext)) { dfree(c, inst); dfree(c, ext); return fail(RFX_E_NOMEM); }
@@ -1916,6 +2018,29 @@ static int msp_passes_leaf(rfx_finish* f) {
     for (int g = 0; g < p->n; ++g) S = std::max(S, p->slot[(size_t)g].passes);
     if (S * p->n > 256) S = std::max(1, 256 / p->n);
     if (!p->barrier()) return RFX_E_HIP;  // (nobody overwrites its slot before everybody has read it)
+  }
+  // S > 1: the first pass leaves run maps (rfx_msp.hip) as far as the device has room beside a pass, the later passes
+  // replay them instead of hashing the reads again.  (Sharded peers run one pass per table from two devices on.)
+  struct own_runmaps {
+    rfx_table* t;
+    rfx_runmaps* s = nullptr;
+    explicit own_runmaps(rfx_table* t_) : t(t_) {}
+    ~own_runmaps() {
+      if (s) {
+        t->runmaps = nullptr;
+        rfx_runmaps_free(s);
+      }
+    }
+  } own_maps(t);
+  if (S > 1 && !t->runmaps && !sharded && !getenv("RFX_NO_RUNMAP")) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const double avail = 0.88 * ((double)free_b + (double)(c->arena_mapped - std::min(c->arena_mapped, c->used)));
+    const double pass = (double)windows * msp_records_per_window(t->k) * 12.0 * 1.05 / (double)outer_n / S + (double)windows / 20.0 * 14.0;
+    if (avail - pass > (double)(256u << 20)) {
+      own_maps.s = rfx_runmaps_create(c, (uint64_t)((avail - pass) * 0.8));
+      t->runmaps = own_maps.s;
+    }
   }
   const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + 2) * 4;
   f->bsq = (uint64_t*)dmalloc(c, zero_bytes);
@@ -2568,6 +2693,71 @@ int rfx_count_adopt_early(rfx_table* dst, rfx_table* src) {
   dst->seg_kind = RFX_COUNT_MSP;
   return RFX_OK;
 }
+
+// ---- run maps ------------------------------------------------------------------------------------------------------
+rfx_runmaps* rfx_runmaps_create(rfx_ctx* c, uint64_t budget_bytes) {
+  if (!c) return nullptr;
+  rfx_runmaps* s = new rfx_runmaps();
+  s->ctx = c;
+  s->budget = budget_bytes;
+  return s;
+}
+
+static void runmaps_drop_entry(rfx_runmaps* s, std::map<const rfx_reads*, rfx_runmap_entry>::iterator it) {
+  runmaps_release(s, it->second.map, it->second.map_bytes);
+  runmaps_release(s, it->second.ovf, it->second.ovf_bytes);
+  s->bytes -= std::min<uint64_t>(s->bytes, it->second.bytes);
+  s->m.erase(it);
+}
+
+rfx_runmaps* rfx_runmaps_create_pooled(rfx_ctx* c, uint64_t pool_bytes) {
+  if (!c || !pool_bytes) return nullptr;
+  (void)hipSetDevice(c->device);
+  rfx_runmaps* s = new rfx_runmaps();
+  s->ctx = c;
+  s->budget = pool_bytes;
+  s->pool = (char*)dmalloc(c, pool_bytes);
+  if (!s->pool) {
+    delete s;
+    return nullptr;
+  }
+  s->pool_free[0] = pool_bytes;
+  return s;
+}
+
+void rfx_runmaps_free(rfx_runmaps* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->ctx->device);
+  while (!s->m.empty()) runmaps_drop_entry(s, s->m.begin());
+  dfree(s->ctx, s->pool);
+  delete s;
+}
+
+uint64_t rfx_runmaps_bytes(const rfx_runmaps* s) { return s ? s->bytes : 0; }
+int rfx_runmaps_blocks(const rfx_runmaps* s) { return s ? (int)s->m.size() : 0; }
+
+int rfx_runmaps_drop(rfx_runmaps* s, const rfx_reads* r) {
+  if (!s || !r) return RFX_E_INVAL;
+  (void)hipSetDevice(s->ctx->device);
+  auto it = s->m.find(r);
+  if (it != s->m.end()) runmaps_drop_entry(s, it);
+  return RFX_OK;
+}
+
+int rfx_runmaps_clear(rfx_runmaps* s) {
+  if (!s) return RFX_E_INVAL;
+  (void)hipSetDevice(s->ctx->device);
+  while (!s->m.empty()) runmaps_drop_entry(s, s->m.begin());
+  return RFX_OK;
+}
+
+int rfx_count_set_runmaps(rfx_table* t, rfx_runmaps* s) {
+  if (!t || (s && s->ctx != t->ctx)) return RFX_E_INVAL;
+  t->runmaps = s;
+  return RFX_OK;
+}
+
+uint64_t rfx_count_replayed(const rfx_table* t) { return t ? t->replayed : 0; }
 
 int rfx_count_set_passes(rfx_table* t, int passes) {
   if (!t || passes < 0 || passes > 256) return RFX_E_INVAL;

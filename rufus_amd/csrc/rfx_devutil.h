@@ -165,6 +165,7 @@ __device__ __forceinline__ uint64_t msp_run_kmer(uint64_t lo, uint64_t hi, int k
   return (sh ? (lo >> sh) | (hi << (64 - sh)) : lo) & ((1ull << (2 * k)) - 1);
 }
 
+constexpr uint32_t RMAP_ENTRIES = 27;  // entries a read's run map holds (rfx_msp.hip, k_msp_replay)
 constexpr int P1_BINS = 128;
 constexpr int P1_S = 8;                       // bases per phase
 constexpr int P1_STAGE = P2_BLOCK * P1_S;     // words staged per phase

@@ -124,6 +124,29 @@ struct rfx_segment {  // the k-mer instances of one rfx_count_add call, grouped 
 };
 
 struct rfx_reads;
+// Run maps (rfx_msp.hip): what the ONE hashing launch over a big read block leaves; every shard pass cuts its records
+// from reads + map.  A store is shared by the tables of a sample's shard passes (rfx_count_set_runmaps) or made by a table
+// for the passes it runs itself (rfx_count_set_passes).
+struct rfx_runmap_entry {
+  void* map = nullptr;       // device: 32 B per read
+  uint32_t* ovf = nullptr;   // device: [0] count, [1 ..] the reads without a map
+  uint32_t n_ovf = 0;
+  uint32_t n_reads = 0;
+  const uint64_t* codes = nullptr;  // (of the block the map was made from: a block freed and another in its place is not it)
+  int k = 0, canonical = 0;
+  size_t bytes = 0, map_bytes = 0, ovf_bytes = 0;
+};
+struct rfx_runmaps {
+  rfx_ctx* ctx = nullptr;
+  uint64_t budget = 0;  // bytes of maps the store may hold (0: no limit)
+  uint64_t bytes = 0;
+  std::map<const rfx_reads*, rfx_runmap_entry> m;
+  // pooled store (rfx_runmaps_create_pooled): ONE device allocation made with the store, the maps are cut out of it
+  // (first fit) -- at 90 % of the HBM gigabyte-sized maps that come and go between the transients of a pass would
+  // otherwise leave the arena in pieces
+  char* pool = nullptr;
+  std::map<size_t, size_t> pool_free;  // offset -> length
+};
 struct rfx_pending_add {  // an MSP partition whose capacity flag has not been read back yet
   const rfx_reads* r;    // needed for the exact redo, so rfx_reads_free settles the add first
   uint32_t* cur;         // device: coarse cursors, flag at cur[ncur]
@@ -145,6 +168,8 @@ struct rfx_reads_view {
   uint32_t ulen, uwpr;
   const uint64_t* nbits;
   const uint32_t* nrank;
+  // k_msp_part1 only: when set, the launch covers reads idx[0 .. n-1] of the block instead of reads 0 .. n-1
+  const uint32_t* idx = nullptr;
 };
 #ifdef __HIPCC__
 __device__ __forceinline__ uint32_t rv_len(const rfx_reads_view& rv, uint32_t r) { return rv.ulen ? rv.ulen : rv.len[r]; }
@@ -215,6 +240,8 @@ struct rfx_table {
   // shard s + 1 -- ONE k_msp_part1 launch for both -- into segments kept here until a table of shard s + 1 adopts them
   int early_on;
   std::vector<rfx_segment>* early;
+  rfx_runmaps* runmaps;      // rfx_count_set_runmaps (not owned), or the table's own during its deferred passes
+  uint64_t replayed;         // big blocks added from their run map (statistics: rfx_count_replayed)
   uint64_t* lut_t;     // device LUT of T (key -> sortable word), null when M is rank deficient
   uint64_t* lut_tinv;  // device LUT of T^-1
 };
@@ -362,7 +389,17 @@ void msp_part1(rfx_ctx*, const rfx_reads_view&, int k, int canonical, int bin_bi
                int hmode, int grid, void* rec_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
                unsigned int* flag,
                int slab_log2 = 4 /* hmode 0 / 3: a workgroup fills slabs of 2^slab_log2 records per coarse bin; cap_a
-                                    must leave room for msp_part1_slack(grid, slab_log2) unused slots per bin */);
+                                    must leave room for msp_part1_slack(grid, slab_log2) unused slots per bin */,
+               void* map_out = nullptr /* hmode 4 (no records, bins ignored): the block's run map, 32 B per read (rfx_msp.hip) */,
+               uint32_t* map_ovf = nullptr /* [0]: reads without a map (zeroed by the caller), [1 ..]: their indices */,
+               uint32_t map_ovf_cap = 0);
+// a shard pass of a block from its reads + run map: what msp_part1(hmode 3) leaves, without hashing (reads <= 160 bases,
+// bin_hi - bin_lo <= 16384); msp_replay_grid: its workgroups (two per CU)
+int msp_replay_grid(rfx_ctx*, uint32_t n_reads);
+int msp_map_grid(rfx_ctx*, uint32_t n_reads);
+void msp_replay(rfx_ctx*, const rfx_reads_view&, const void* map, int k, int canonical, int bin_bits, uint32_t bin_lo,
+                uint32_t bin_hi, int grid, void* rec_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
+                unsigned int* flag, int slab_log2);
 inline uint64_t msp_part1_slack(int grid, int slab_log2) { return (uint64_t)grid * 3u << slab_log2; }
 void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,

@@ -57,12 +57,19 @@ namespace {
 // the kernel still fit 80 VGPRs; forcing 6 waves per SIMD, `__launch_bounds__(768, 6)`, gives 89).
 constexpr int MP1_BLOCK = 512;
 // WL: m-mers per k-mer (11: k <= 25; 16: k = 26 .. 31).  A record = 64-bit word + 32-bit plane (rfx_devutil.h).
+//       4: no record at all -- the launch leaves the block's RUN MAP (see k_msp_replay below): per read 32 bytes that say
+//          how it falls into super-k-mers and where their minimizers sit.  With S > 1 shard passes every pass's records
+//          are then cut from reads + map without hashing a base again.  (The hashing, the sliding minimum and the run
+//          boundaries of this kernel; no close queue, no slabs, no histogram, no "whose bin".)
 template <bool CANON, int HMODE, int WL>
 __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int k, int bin_bits, uint32_t bin_lo,
                                                          uint32_t bin_hi, msp_rec12* __restrict__ rec_a,
                                                          uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
                                                          uint32_t* __restrict__ cnt_rows,
-                                                         unsigned int* __restrict__ flag, int slab_log2) {
+                                                         unsigned int* __restrict__ flag, int slab_log2,
+                                                         uint4* __restrict__ map_out, uint32_t* __restrict__ map_ovf,
+                                                         uint32_t map_ovf_cap) {
+  constexpr bool MAPONLY = HMODE == 4;
   // Two of each, by phase parity (the second barrier of a phase then only has to cover the addresses).  Tried in
   // round 3 and dropped: reserving phase p's runs while phase p + 1 is hashed and storing p's records one phase late
   // (one barrier per phase, nobody waits for the atomic) -- 126 VGPRs, 94 instead of 90 ms per 1 Gb sample: the other
@@ -82,7 +89,9 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   static_assert(P1_BINS == 128, "the slab bookkeeping below shifts by log2(P1_BINS) = 7");
   __shared__ uint32_t s_fill[SLABS ? P1_BINS : 1];
   __shared__ uint64_t s_slab[SLABS ? 3 : 1][SLABS ? P1_BINS : 1];  // [0] current, [1] spare ([2]: the in-flight one, at the end)
-  __shared__ uint32_t s_fine[HMODE == 0 ? 4096 : HMODE == 1 ? 8192 : HMODE == 3 ? 16384 : 1];
+  // (HMODE 4: the lane's 32 map bytes are staged here, stride 9 dwords: no two lanes of a wave on a bank)
+  __shared__ uint32_t s_fine[HMODE == 0 ? 4096 : HMODE == 1 ? 8192 : HMODE == 3 ? 16384 : HMODE == 4 ? MP1_BLOCK * 9 : 1];
+  uint8_t* const mapb = MAPONLY ? (uint8_t*)(s_fine + threadIdx.x * 9u) : nullptr;
   __shared__ uint32_t s_maxlen;
   // SLABS (round 4): CLOSE QUEUE.  With whole super-k-mers one lane in six closes a run at any base, so the ~60
   // instructions that turn a closed run into a record (word + plane, bin, slab slot, two stores, fine histogram) ran at
@@ -171,17 +180,24 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   };
   const uint32_t n_chunks = (rv.n + MP1_BLOCK - 1) / MP1_BLOCK;
   for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const uint32_t r = chunk * MP1_BLOCK + threadIdx.x;
-    const bool live = r < rv.n;
+    const uint32_t r0 = chunk * MP1_BLOCK + threadIdx.x;
+    const bool live = r0 < rv.n;
+    const uint32_t r = live && rv.idx ? rv.idx[r0] : r0;  // (rv.idx: a list of reads, e.g. those without a run map)
     const uint32_t len = live ? rv_len(rv, r) : 0;
     const uint32_t lenp = live ? len + 1 : 0;  // one virtual invalid base closes the last run
     const uint32_t roff = live ? rv_off(rv, r) : 0;
     const uint64_t* cw = rv.codes + roff;
     const uint32_t* cm = live ? rv_acgt(rv, r, roff) : nullptr;  // nullptr: all of the read is A/C/G/T (compact blocks)
+    // HMODE 4: entries so far, the k-mer end position the next entry begins at, the entries' shard-half flags
+    uint32_t mcnt = 0, mpos = (uint32_t)k - 1u, mflags = 0;
     if (threadIdx.x == 0) s_maxlen = 0;
     __syncthreads();
     atomicMax(&s_maxlen, lenp);
     __syncthreads();
+    if constexpr (MAPONLY) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ((uint32_t*)mapb)[i] = ~0u;
+    }
 #ifdef RFX_P1_HALF  // experiment (results void): half of every read -- what is per chunk, what per base?
     const uint32_t n_phase = (s_maxlen + P1_S - 1) / P1_S / 2;
 #else
@@ -301,7 +317,40 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
         // turns as its busiest lane has boundaries (3-4 of 8 bases), where a copy of the push per base ran 8 times; what a
         // turn needs of the minimizer (its position mod 32, for `back`; its bin, for "is this run the table's") is laid
         // out per phase: five bits per base in `qpack`, one in `minemask`.
-        if constexpr (SLABS) {
+        if constexpr (MAPONLY) {
+          // every run that ends in this phase becomes an entry of the map: a lane walks the set bits of its `ends`
+          uint64_t qpack = prev_mh & 31u;  // 5 bits per run end: position (mod 32) of the minimizer of the run ending at p0 + b - 1
+          uint32_t halves = msp_binhash(prev_mh) >> 31;  // bit b: that run's bin lies in the upper half of the bin space
+  #pragma unroll
+          for (int b = 1; b < P1_S; ++b) {
+            qpack |= (uint64_t)(mhv[b - 1] & 31u) << (5 * b);
+            halves |= (msp_binhash(mhv[b - 1]) >> 31) << b;
+          }
+          uint32_t pend = ends;
+          while (__ballot(pend != 0)) {
+            if (pend) {
+              const uint32_t b = (uint32_t)__ffs((int)pend) - 1u;
+              pend &= pend - 1u;
+              const uint32_t ms = starts & ((1u << b) - 1u);
+              const uint32_t rs = ms ? p0 + 31u - (uint32_t)__clz((int)ms) : run_s;
+              const uint32_t e = p0 + b - 1u;
+              const uint32_t back = (e - (uint32_t)(qpack >> (5u * b))) & 31u;
+              // entry: low nibble n - 1 (15: a gap), high nibble `back` (a gap: its length - 1).  K-mer end positions no run
+              // covers (invalid bases) are gaps.  A run longer than a record holds (k >= 26) goes in pieces, as the records do.
+              for (uint32_t g = rs - mpos; g != 0;) {
+                const uint32_t l = min(g, 16u);
+                if (mcnt < RMAP_ENTRIES) mapb[mcnt] = (uint8_t)(0xFu | ((l - 1u) << 4));
+                ++mcnt;
+                g -= l;
+              }
+              if (mcnt < RMAP_ENTRIES) mapb[mcnt] = (uint8_t)((e - rs) | (back << 4));
+              if (mcnt < 32u) mflags |= ((halves >> b) & 1u) << mcnt;
+              ++mcnt;
+              mpos = e + 1u;
+            }
+          }
+          if (starts) run_s = p0 + 31u - (uint32_t)__clz((int)starts);
+        } else if constexpr (SLABS) {
           uint64_t qpack = prev_mh & 31u;  // 5 bits per run end: position (mod 32) of the minimizer of the run ending at p0 + b - 1
   #pragma unroll
           for (int b = 1; b < P1_S; ++b) qpack |= (uint64_t)(mhv[b - 1] & 31u) << (5 * b);
@@ -372,7 +421,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
         for (int i = 0; i < WL - 1; ++i) a[i] = a[i + P1_S];
       }
       TM(0);
-      if (HMODE == 1) continue;
+      if (HMODE == 1 || HMODE == 4) continue;
       if constexpr (SLABS) {
         if ((++tick & tick_mask) == 0) {
           __syncthreads();  // every slot of the interval has been handed out
@@ -446,6 +495,21 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
     // `s_waitcnt vmcnt(0)` at the top of EVERY phase, and every phase waited for the scattered stores of the one before)
     if (whole) phases(std::true_type());
     else phases(std::false_type());
+    if constexpr (MAPONLY) {
+      if (live) {
+        uint32_t d[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) d[i] = ((const uint32_t*)mapb)[i];
+        // dword 7: the entries' half flags (27 bits), their number in the top 5 (31: more than the map holds -- no map)
+        d[7] = mcnt <= RMAP_ENTRIES ? (mflags & ((1u << RMAP_ENTRIES) - 1u)) | (mcnt << 27) : ~0u;
+        map_out[2 * (size_t)r] = make_uint4(d[0], d[1], d[2], d[3]);
+        map_out[2 * (size_t)r + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+        if (mcnt > RMAP_ENTRIES) {  // (~1 % of 150 bp reads: the passes hash these the ordinary way)
+          const uint32_t at = atomicAdd(&map_ovf[0], 1u);
+          if (at < map_ovf_cap) map_ovf[1 + at] = r;
+        }
+      }
+    }
   }
   if constexpr (SLABS) drain(q_tail - q_head);  // what is left in the wave's queue (< 64)
   __syncthreads();
@@ -480,6 +544,207 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
   }
   if (HMODE == 1)
     for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) cnt_rows[(uint64_t)blockIdx.x * P + b] = s_fine[b];
+}
+
+// ---- shard passes without hashing: the run map --------------------------------------------------------------------
+// With S > 1 shard passes every pass used to hash every base (the minimizer of a k-mer says whose it is) -- at W two runs
+// of k_msp_part1 were half of what the chain issued.  Now every big block is hashed ONCE (the reference hashes a k-mer
+// once too: jf/sub_commands/count_main.cc:148-180), by k_msp_part1<.., HMODE 4>, which leaves per read 32 bytes:
+//   bytes 0 .. 26   one entry per stretch of consecutive k-mer end positions, from position k - 1 on:
+//                   low nibble n - 1 (the run's k-mers), high nibble `back` (its last k-mer ends `back` bases behind the end
+//                   of the minimizer m-mer) -- or low nibble 15: a gap of (high nibble) + 1 positions (invalid bases)
+//   dword 7         bits 0 .. 26: entry i's bin lies in the upper half of the bin space (two shard passes: a pass skips
+//                   the other's runs without building them); bits 27 .. 31: the number of entries, 31 = the read has more
+//                   than 27 (~1 % of 150 bp reads) and is on the block's list of reads every pass hashes the ordinary
+//                   way (k_msp_part1 over rv.idx)
+// k_msp_replay cuts the records of ITS bins from reads + map: a lane per read walks its entries, cuts the run out
+// of the read (staged in LDS with the base order reversed: a run is then a bit field, first base most significant,
+// as msp_record_make wants it), re-derives the bin from the record (as the close queue of k_msp_part1 does) and stores
+// into the same slabs / counts the same fine histogram as HMODE 3 -- everything behind it is unchanged.
+// Reads of up to 160 bases (5 code words).  ~10 wave-instructions per 64 bases where the hashing pass issues 62.
+// 8-bit histogram counters (a workgroup puts ~45 records into a fine bin at W; a counter that wraps leaves the sum short
+// and the host counts the records instead); two 512-thread workgroups per CU.
+// The entries are walked without a loop over the ones to skip: per chunk a lane turns its 27 entries into end positions
+// (byte-wise prefix sums of their lengths, SWAR on the 7 dwords) and a bit mask of the runs of this pass's half; a turn
+// takes the next set bit.  (The first version stepped over gaps and the other half's runs one by one: 36 wave-
+// instructions per 64 bases and pass, 30 of them scalar loop control -- more than half of what the hashing costs.)
+constexpr int RP_STRIDE = 25;  // dwords per lane: 10 of read, 7 of entries, 7 of end positions, 1 that keeps the stride odd
+template <bool CANON>
+__global__ __launch_bounds__(MP1_BLOCK) void k_msp_replay(rfx_reads_view rv, const uint4* __restrict__ map, int k, int bin_bits,
+                                                          uint32_t bin_lo, uint32_t bin_hi, msp_rec12* __restrict__ rec_a,
+                                                          uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
+                                                          uint32_t* __restrict__ cnt_rows, unsigned int* __restrict__ flag,
+                                                          int slab_log2) {
+  static_assert(P1_BINS == 128, "the slab bookkeeping below shifts by log2(P1_BINS) = 7");
+  __shared__ uint32_t s_fill[P1_BINS];
+  __shared__ uint64_t s_slab[3][P1_BINS];
+  __shared__ uint32_t s_fine[4096];  // 8-bit counters of bins bin_lo .. bin_lo + 16383 (a shard pass holds at most half of 32768)
+  __shared__ uint32_t s_rd[MP1_BLOCK * RP_STRIDE + 4];
+  __shared__ uint32_t s_sum, s_emit;
+  const uint32_t P = 1u << bin_bits;
+  const int sub_bits = bin_bits - 7;
+  const int m = msp_m(k);
+  const uint32_t mmask = m >= 16 ? ~0u : (1u << (2 * m)) - 1;
+  // which half of the bin space this pass's bins lie in (2: both -- the entries' flags do not help)
+  const uint32_t half_sel = bin_lo >= P / 2 ? 1u : bin_hi <= P / 2 ? 0u : 2u;
+  uint32_t n_emit = 0;
+  for (uint32_t i = threadIdx.x; i < 4096; i += blockDim.x) s_fine[i] = 0;
+  // (the slabs: as in k_msp_part1, see there)
+  const uint32_t SLAB = 1u << slab_log2;
+  constexpr uint32_t P1_NO_SLAB = 0xFFFFFFFFu;
+  uint32_t pending = P1_NO_SLAB;
+  auto reserve_raw = [&](uint32_t b) -> uint32_t { return atomicAdd(&coarse_cur[b * P1_CUR_STRIDE], SLAB); };
+  auto slab_at = [&](uint32_t b, uint32_t at) -> uint64_t {
+    if (at == P1_NO_SLAB) return ~0ull;
+    if ((uint64_t)at + SLAB > cap_a) {
+      atomicExch(flag, 1u);
+      return (uint64_t)b * cap_a;
+    }
+    return (uint64_t)b * cap_a + at;
+  };
+  if (threadIdx.x < P1_BINS) {
+    const bool used = bin_hi > bin_lo && threadIdx.x >= (bin_lo >> sub_bits) && threadIdx.x <= ((bin_hi - 1) >> sub_bits);
+    s_fill[threadIdx.x] = 0;
+    s_slab[0][threadIdx.x] = used ? slab_at(threadIdx.x, reserve_raw(threadIdx.x)) : ~0ull;
+    s_slab[1][threadIdx.x] = used ? slab_at(threadIdx.x, reserve_raw(threadIdx.x)) : ~0ull;
+    pending = used ? reserve_raw(threadIdx.x) : P1_NO_SLAB;
+  }
+  __syncthreads();
+  uint32_t* const rd = s_rd + threadIdx.x * RP_STRIDE;
+  const uint8_t* const ent8 = (const uint8_t*)(rd + 10);
+  const uint8_t* const end8 = (const uint8_t*)(rd + 17);
+  const uint32_t n_chunks = (rv.n + MP1_BLOCK - 1) / MP1_BLOCK;
+  // the next chunk's map and read are on their way while this one is cut
+  uint4 nq0 = make_uint4(0, 0, 0, 0), nq1 = make_uint4(0, 0, 0, 31u << 27);
+  uint64_t nw[5] = {0, 0, 0, 0, 0};
+  auto fetch = [&](uint32_t chunk) {
+    const uint32_t r = chunk * MP1_BLOCK + threadIdx.x;
+    nq1.w = 31u << 27;  // (no read: no entry)
+    if (chunk < n_chunks && r < rv.n) {
+      nq0 = map[2 * (size_t)r];
+      nq1 = map[2 * (size_t)r + 1];
+      const uint32_t len = rv_len(rv, r);
+      const uint64_t* cw = rv.codes + rv_off(rv, r);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) nw[i] = (uint32_t)i * 32u < len ? cw[i] : 0;
+    }
+  };
+  fetch(blockIdx.x);
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // base i of the read -> bit pair 159 - i of the staged 320 bits
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      uint64_t y = __brevll(nw[4 - j]);
+      y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+      rd[2 * j] = (uint32_t)y;
+      rd[2 * j + 1] = (uint32_t)(y >> 32);
+    }
+    const uint32_t q[7] = {nq0.x, nq0.y, nq0.z, nq0.w, nq1.x, nq1.y, nq1.z};
+    const uint32_t flags = nq1.w;
+    uint32_t cnt = flags >> 27;
+    if (cnt == 31u) cnt = 0;  // no map: the read is on the list of the ordinary launch that follows
+    fetch(chunk + gridDim.x);
+    // end positions of the entries (as offsets from k - 2: byte i = sum of the lengths of entries 0 .. i) and which are gaps
+    uint32_t gaps = 0, tot = 0;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const uint32_t lo = q[j] & 0x0F0F0F0Fu, hi = (q[j] >> 4) & 0x0F0F0F0Fu;
+      const uint32_t g = ((lo + 0x01010101u) >> 4) & 0x01010101u;  // 1 in the bytes whose low nibble is 15: a gap
+      const uint32_t gm = (g << 8) - g;                              // 0xFF there
+      uint32_t p = ((hi & gm) | (lo & ~gm)) + 0x01010101u;           // the entries' lengths: (high nibble | n - 1) + 1
+      p += p << 8;
+      p += p << 16;
+      p += tot * 0x01010101u;  // (a read has at most 160 positions: no byte overflows before the last entry)
+      tot = p >> 24;
+      rd[10 + j] = q[j];
+      rd[17 + j] = p;
+      gaps |= ((g * 0x01020408u) >> 24) << (4 * j);
+    }
+    // (a lane reads only what it wrote itself: no barrier)
+    uint32_t mine = ~gaps & ((1u << cnt) - 1u);
+    if (half_sel != 2u) mine &= half_sel ? flags : ~flags;
+    while (__ballot(mine != 0)) {
+      if (mine) {
+        const uint32_t i = (uint32_t)__ffs((int)mine) - 1u;
+        mine &= mine - 1u;
+        const uint32_t en = ent8[i];
+        const int n = (int)(en & 15u) + 1;
+        const uint32_t back = en >> 4;
+        const uint32_t e = (uint32_t)k - 2u + end8[i];  // the run's last k-mer ends at base e
+        // bases e - L + 1 .. e = bit pairs 159 - e .. 159 - e + L - 1 of the staged read, base e least significant
+        const uint32_t o = 2u * (159u - e), dw = o >> 5, sh = o & 31u;
+        const uint32_t d0 = rd[dw], d1 = rd[dw + 1], d2 = rd[dw + 2], d3 = rd[dw + 3];  // (past the read: the entries, never used -- 2L bits are)
+        const uint64_t lo = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+        // the bin, from the minimizer m-mer itself: it ends `back` bases before e (back + m <= 31 bases: inside `lo`)
+        const uint32_t f = (uint32_t)(lo >> (2u * back)) & mmask;
+        uint32_t c = f;
+        if (CANON) {
+          uint32_t y = __brev(~f);
+          y = ((y & 0xAAAAAAAAu) >> 1) | ((y & 0x55555555u) << 1);
+          c = min(f, y >> (32 - 2 * m));
+        }
+        const uint32_t run_bin = msp_binhash(mmer_hash(c)) >> (32 - bin_bits);
+        if (run_bin - bin_lo < bin_hi - bin_lo) {  // (more than two passes: the half says little, the bin everything)
+          const uint32_t hi = __builtin_amdgcn_alignbit(d3, d2, sh) & 0x3FFFFFu;
+          uint64_t w;
+          uint32_t x;
+          msp_record_make(lo, hi, k, n, (uint32_t)(k + n - 1 - m) - back, w, x);
+          const uint32_t coarse = run_bin >> sub_bits;
+          const uint32_t slot = atomicAdd(&s_fill[coarse], 1u);
+          if (slot < 2 * SLAB) {
+            const uint64_t sb = s_slab[slot >> slab_log2][coarse];
+            msp_rec12_store(rec_a, sb + (slot & (SLAB - 1)), w, x);
+          } else {  // more than two slabs' worth in one chunk: one reservation per record
+            const uint32_t at = atomicAdd(&coarse_cur[coarse * P1_CUR_STRIDE], 1u);
+            if (at < cap_a) msp_rec12_store(rec_a, (uint64_t)coarse * cap_a + at, w, x);
+            else atomicExch(flag, 1u);
+          }
+          ++n_emit;
+          const uint32_t fb = run_bin - bin_lo;
+          atomicAdd(&s_fine[fb >> 2], 1u << ((fb & 3u) * 8));
+        }
+      }
+    }
+  // once per chunk (512 reads put ~90 records into each of a pass's coarse bins at S = 2) the bins whose slab filled up move on
+    __syncthreads();
+    if (threadIdx.x < P1_BINS) {
+      uint32_t f = s_fill[threadIdx.x];
+      if (f >= SLAB) {
+        if (f >= 2 * SLAB) {
+          s_slab[0][threadIdx.x] = slab_at(threadIdx.x, pending);
+          s_slab[1][threadIdx.x] = slab_at(threadIdx.x, reserve_raw(threadIdx.x));
+          f = 0;
+        } else {
+          s_slab[0][threadIdx.x] = s_slab[1][threadIdx.x];
+          s_slab[1][threadIdx.x] = slab_at(threadIdx.x, pending);
+          f -= SLAB;
+        }
+        pending = reserve_raw(threadIdx.x);
+        s_fill[threadIdx.x] = f;
+      }
+    }
+    __syncthreads();
+  }
+  // the slots nobody took: MSP_EMPTY
+  if (threadIdx.x < P1_BINS) s_slab[2][threadIdx.x] = slab_at(threadIdx.x, pending);
+  if (threadIdx.x == 0) s_sum = s_emit = 0;
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < 3u * P1_BINS * SLAB; i += blockDim.x) {
+    const uint32_t o = i & (SLAB - 1), bw = i >> slab_log2, b = bw & (P1_BINS - 1), which = bw >> 7;
+    const uint64_t sb = s_slab[which][b];
+    if (sb != ~0ull && (which == 2 || which * SLAB + o >= s_fill[b])) msp_rec12_store(rec_a, sb + o, MSP_EMPTY, 0u);
+  }
+  uint32_t sum = 0;
+  for (uint32_t b = threadIdx.x; b < P; b += blockDim.x) {
+    const uint32_t fb = b - bin_lo;
+    const uint32_t v = fb < bin_hi - bin_lo ? (s_fine[fb >> 2] >> ((fb & 3u) * 8)) & 0xFFu : 0u;
+    cnt_rows[(uint64_t)blockIdx.x * P + b] = v;
+    sum += v;
+  }
+  atomicAdd(&s_sum, sum);  // a wrapped 8-bit counter (carry into the neighbour or out of the word) leaves the sum short
+  atomicAdd(&s_emit, n_emit);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_sum != s_emit) atomicExch(flag, 1u);
 }
 
 __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
@@ -1033,16 +1298,18 @@ int msp_wide(int) { return 1; }  // (round 4) every record is a 64-bit word + a 
 
 void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
                int hmode, int grid, void* rec_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
-               unsigned int* flag, int slab_log2) {
-  rfx_span sp(c, hmode == 1 ? "k_msp_count" : "k_msp_part1");
+               unsigned int* flag, int slab_log2, void* map_out, uint32_t* map_ovf, uint32_t map_ovf_cap) {
+  rfx_span sp(c, hmode == 1 ? "k_msp_count" : hmode == 4 ? "k_msp_map" : "k_msp_part1");
 #define RFX_MSP_P1(CANON, HM, WL)                                                                             \
   hipLaunchKernelGGL((k_msp_part1<CANON, HM, WL>), dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, k, bin_bits, \
-                     bin_lo, bin_hi, (msp_rec12*)rec_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2)
+                     bin_lo, bin_hi, (msp_rec12*)rec_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2, (uint4*)map_out, \
+                     map_ovf, map_ovf_cap)
 #define RFX_MSP_P1_HM(CANON, WL)          \
   do {                                          \
     if (hmode == 0) RFX_MSP_P1(CANON, 0, WL);      \
     else if (hmode == 1) RFX_MSP_P1(CANON, 1, WL); \
     else if (hmode == 3) RFX_MSP_P1(CANON, 3, WL); \
+    else if (hmode == 4) RFX_MSP_P1(CANON, 4, WL); \
     else RFX_MSP_P1(CANON, 2, WL);                 \
   } while (0)
   if (msp_wl(k) == MSP_WL) {
@@ -1054,6 +1321,28 @@ void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int b
   }
 #undef RFX_MSP_P1_HM
 #undef RFX_MSP_P1
+}
+
+int msp_map_grid(rfx_ctx* c, uint32_t n_reads) {  // (k_msp_part1 HMODE 4: 69 VGPRs, 18 KB of LDS: three workgroups per CU)
+  const uint32_t chunks = (n_reads + MP1_BLOCK - 1) / MP1_BLOCK;
+  return (int)std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)c->n_cu * 3, (chunks + 7) & ~7u));
+}
+
+int msp_replay_grid(rfx_ctx* c, uint32_t n_reads) {
+  const uint32_t chunks = (n_reads + MP1_BLOCK - 1) / MP1_BLOCK;
+  return (int)std::max<uint32_t>(8, std::min<uint32_t>((uint32_t)c->n_cu * 2, (chunks + 7) & ~7u));
+}
+
+void msp_replay(rfx_ctx* c, const rfx_reads_view& rv, const void* map, int k, int canonical, int bin_bits, uint32_t bin_lo,
+                uint32_t bin_hi, int grid, void* rec_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
+                unsigned int* flag, int slab_log2) {
+  rfx_span sp(c, "k_msp_replay");
+  if (canonical)
+    hipLaunchKernelGGL(k_msp_replay<true>, dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, (const uint4*)map, k, bin_bits, bin_lo,
+                       bin_hi, (msp_rec12*)rec_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2);
+  else
+    hipLaunchKernelGGL(k_msp_replay<false>, dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, (const uint4*)map, k, bin_bits, bin_lo,
+                       bin_hi, (msp_rec12*)rec_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2);
 }
 
 // Grid and staging chunk of a leaf launch over P bins holding ~n_records records: a workgroup per ~4096 records at least

@@ -124,6 +124,14 @@ class WgsTrio:
         self.group = group
         self.early_budget = 0       # bytes of device memory that may hold records cut ahead for the next shard pass
         self._early, self._early_left, self._early_cost = {}, 0, 0
+        # bytes of device memory that may hold RUN MAPS (32 B per read; rfx_runmaps_*): the first shard pass over a block
+        # leaves one, the later passes rebuild their records from reads + map instead of hashing the block again
+        # (one store for the trio, ONE piece of device memory of that size, kept from run to run: at 90 % of the HBM maps
+        # allocated between the transients of a pass left the arena in pieces.)  With maps the passes are ordered so that
+        # at most two samples' maps are alive: run().
+        self.map_budget = 0
+        self._store = None
+        self.replayed_blocks = 0    # blocks added by replay in the last run()
         if group is not None:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -145,10 +153,22 @@ class WgsTrio:
             if self.passes > 1:
                 t.set_shard(shard, self.passes)
         nxt = None
+        store = self._store if si is not None and self.passes > 1 else None
         try:
+            if store is not None:       # (run maps instead of blocks cut ahead: 32 instead of 132 bytes per read)
+                t.set_runmaps(store)
+                last = shard == self.passes - 1
+                for b in blocks:
+                    t.add(b)
+                    if last:
+                        store.drop(b)
+                self.replayed_blocks += t.replayed()
+                if shard == 0:
+                    self._inject("maps", shard)      # (tests: the headroom turns out not to be there)
+                return t.finish(self.lower, want_histo=True)
             todo = [i for i in range(len(blocks)) if i not in done]
             ahead = set()
-            if si is not None and self.passes > 1 and shard + 1 < self.passes and self._early_left > 0:
+            if si is not None and self.passes > 1 and shard + 1 < self.passes and self._early_left > 0 and not self.map_budget:
                 t.set_early(True)
                 cost = self._early_cost
                 while todo and self._early_left > cost:     # (cost: what the block before took)
@@ -182,6 +202,18 @@ class WgsTrio:
         for t, _ in self._early.values():
             t.free()
         self._early = {}
+        if self._store is not None:
+            self._store.clear()
+
+    def _drop_store(self):
+        if self._store is not None:
+            self._store.free()
+            self._store = None
+
+    def close(self):
+        """Give back what the driver holds between runs (the pool of the run maps)."""
+        self._drop_early()
+        self._drop_store()
 
     def count_shard(self, blocks, shard: int, si=None):
         """Records (in (pos,key) order) + histogram of the k-mers of minimizer shard `shard` of `passes` --
@@ -488,38 +520,59 @@ class WgsTrio:
             histos = [np.zeros(capi.HISTO_BINS, dtype=np.uint64) for _ in samples]
             n_rec = [0] * len(samples)
             keys, kept, recs = [], [], []
-            cand = None
+            cand, cands, shard_recs = None, {}, {}
             self._drop_early()
             self._early_left = int(self.early_budget) if self.world == 1 and not keep_shard_records else 0
+            self.replayed_blocks = 0
+            use_maps = self.map_budget > 0 and self.world == 1 and self.passes > 1 and not keep_shard_records
+            if not use_maps:
+                self._drop_store()
+            elif self._store is None:
+                try:
+                    self._store = capi.RunMaps(self.ctx, int(self.map_budget), pooled=True)
+                except capi.RufusError:         # no room for the pool: the passes hash as before
+                    self.map_budget, use_maps = 0, False
             ver = {"bad_order": 0, "bad_pos": 0, "bad_count": 0, "sum_counts": [0] * len(samples),
                    "probe_found": [0] * len(samples), "probe_count_out_of_range": 0,
                    "checksum": [[0, 0] for _ in samples]}   # rfx_records_checksum, summed over the shards
             try:
-                for sh in range(self.passes):
-                    recs = []
-                    # The subject (sample 0) is counted first and only its CANDIDATES stay: the records with MinCov <=
-                    # count <= MaxDepth; every control then strikes out what it holds and is freed at once
-                    # (rfx_records_subtract) -- one sample's records alive at a time instead of all of them.
-                    # (odd passes take the controls in reverse: the control counted last in one pass -- whose records of
-                    # the next pass may have been cut ahead in the room the subject's records left, see _after_count --
-                    # is the first control of the next)
-                    order = list(range(len(samples)))
-                    if sh % 2 == 1 and not keep_shard_records:
-                        order = order[:1] + order[:0:-1]
-                    for si in order:
-                        blocks = samples[si]
-                        rec, h = self.count_shard(blocks, sh, si)   # (its failures are agreed inside)
-                        recs.append(rec)
-                        histos[si] += h
-                        n_rec[si] += len(rec)
-                        lap(f"pass {sh} sample {si} count ({len(rec)} records)")
-                        err = None              # the rest of the iteration is local: on a group its failure is
-                        try:                    # agreed at its end, so that no rank goes on into a collective alone
-                            cand = self._after_count(rec, recs, si, sh, cand, ver, verify, probe_keys, keep_shard_records,
-                                                     lap)
-                        except Exception as e:
-                            err = e
-                        self.checkpoint(err)    # (one rank: raises err)
+                # The subject (sample 0) is counted first and only its CANDIDATES stay: the records with MinCov <=
+                # count <= MaxDepth; every control then strikes out what it holds and is freed at once
+                # (rfx_records_subtract) -- one sample's records alive at a time instead of all of them.
+                # Order of the (pass, sample) steps.  Plain: pass by pass (odd passes take the controls in reverse: the
+                # control counted last in one pass -- whose records of the next pass may have been cut ahead in the room
+                # the subject's records left, see _after_count -- is the first control of the next).  With run maps:
+                # subject and first control pass by pass, then every further control through all its passes at once --
+                # the candidates a shard has left after the first control are few, so they can wait, and never more
+                # than two samples' maps are alive (the pool is sized for that: bench.py).
+                P, ns = self.passes, len(samples)
+                if use_maps and ns > 2:
+                    steps = [(sh, si) for sh in range(P) for si in (0, 1)] + [(sh, si) for si in range(2, ns) for sh in range(P)]
+                else:
+                    steps = [(sh, si) for sh in range(P)
+                             for si in (list(range(ns)) if sh % 2 == 0 or keep_shard_records else [0] + list(range(ns - 1, 0, -1)))]
+                last_step = {sh: max(i for i, (sh_, _) in enumerate(steps) if sh_ == sh) for sh in range(P)}
+                shard_recs.update({sh: [] for sh in range(P)})
+                for i_step, (sh, si) in enumerate(steps):
+                    recs = shard_recs[sh]
+                    cand = cands.pop(sh, None)
+                    blocks = samples[si]
+                    rec, h = self.count_shard(blocks, sh, si)   # (its failures are agreed inside)
+                    recs.append(rec)
+                    histos[si] += h
+                    n_rec[si] += len(rec)
+                    lap(f"pass {sh} sample {si} count ({len(rec)} records)")
+                    err = None              # the rest of the iteration is local: on a group its failure is
+                    try:                    # agreed at its end, so that no rank goes on into a collective alone
+                        cand = self._after_count(rec, recs, si, sh, cand, ver, verify, probe_keys, keep_shard_records, lap)
+                    except Exception as e:
+                        err = e
+                    self.checkpoint(err)    # (one rank: raises err)
+                    if i_step != last_step[sh]:
+                        if cand is not None:
+                            cands[sh] = cand
+                        cand = None
+                        continue
                     if keep_shard_records:
                         k_, _ = capi.unique_to_subject(self.ctx, recs[0], recs[1:], self.min_cov, self.max_cov)
                         kept.append(recs)
@@ -534,6 +587,7 @@ class WgsTrio:
                         cand = None
                     lap(f"pass {sh} set difference ({len(k_)} k-mers)")
                     keys.append(k_)
+                    shard_recs[sh] = []
                     recs = []
                 break
             except capi.RufusError as e:
@@ -541,19 +595,25 @@ class WgsTrio:
                 # On a group only a failure every rank knows of (GroupFailure: raised by all ranks at the same
                 # checkpoint of count_shard) can be retried -- all ranks are here then, with the same `passes`.
                 agreed = isinstance(e, GroupFailure) and e.retry
+                self._drop_early()              # (run maps / early tables of the failed attempt, whatever follows)
                 if (self.world > 1 and not agreed) or self.passes >= 64 or (self.passes + 1) * self.world > 256 or \
                         not _is_out_of_memory(e):
                     raise
-                for r in recs + [r_ for shard in kept for r_ in shard] + ([cand] if cand is not None else []):
+                held = [r_ for rr in shard_recs.values() for r_ in rr]
+                held += [r_ for r_ in recs if r_ not in held]
+                held += [r_ for shard in kept for r_ in shard if r_ not in held]
+                held += [c_ for c_ in [cand] + list(cands.values()) if c_ is not None and c_ not in held]
+                for r in held:
                     r.free()
                 self._drop_early()
                 if self.world > 1:
                     import torch
                     torch.cuda.empty_cache()    # the receive buffers of the failed pass go back to the driver
-                if self.early_budget > 0:       # the headroom for blocks cut ahead was not there after all: the same
-                    self.early_budget = 0       # passes once more without them
+                if self.early_budget > 0 or self.map_budget > 0:    # the headroom for run maps / blocks cut ahead was not
+                    self._drop_store()
+                    self.early_budget = self.map_budget = 0           # there after all: the same passes once more without
                     if trace:
-                        print("[wgs] out of device memory: retrying without blocks cut ahead", flush=True)
+                        print("[wgs] out of device memory: retrying without run maps / blocks cut ahead", flush=True)
                     continue
                 self.passes += 1
                 if trace:

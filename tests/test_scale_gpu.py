@@ -265,6 +265,41 @@ def test_wgs_slice_properties(ctx):
         del os.environ["RFX_WGS_INJECT_OOM"]
     assert trio.passes == 2 and trio.early_budget == 0 and not trio._early
     assert res4["n_records"] == n_rec1 and np.array_equal(res4["mutant_keys"], keys1)
+    # .. and two passes with RUN MAPS (WgsTrio.map_budget: a pool for two samples' maps): every block is hashed once, into
+    # its map, and both passes cut their records from reads + map (plus a small launch per block and pass over the reads
+    # without a map) -- the same record multisets; the third sample's maps take the room of the first's
+    trio = wgs.WgsTrio(ctx, K, SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=2)
+    trio.map_budget = 2 * sum(b.n * 33 + (1 << 20) for b in samples[0])     # (32 B per read + the list of reads without a map)
+    ctx.prof(True)
+    ctx.prof_reset()
+    res5 = trio.run(samples, verify=True)
+    prof = ctx.prof_dict()
+    ctx.prof(False)
+    assert trio.replayed_blocks == 2 * n_blocks and prof["k_msp_replay"][1] == 2 * n_blocks and prof["k_msp_map"][1] == n_blocks
+    assert prof.get("k_msp_part1", (0, 0))[1] <= 2 * n_blocks           # (only the small launches over the reads without a map)
+    assert res5["n_records"] == n_rec1 and res5["n_pulled"] == pulled1 and np.array_equal(res5["mutant_keys"], keys1)
+    assert all(np.array_equal(a, b) for a, b in zip(res5["histos"], h1))
+    assert res5["verify"]["checksum"] == res2["verify"]["checksum"] and res5["verify"]["bad_order"] == 0
+    res5 = trio.run(samples)                                            # (the pool is kept from run to run)
+    assert trio.replayed_blocks == 2 * n_blocks and np.array_equal(res5["mutant_keys"], keys1)
+    # half the room: the maps that fit are replayed, the other blocks are hashed twice
+    trio.close()
+    trio.map_budget //= 2
+    res5 = trio.run(samples, verify=True)
+    assert 0 < trio.replayed_blocks < 2 * n_blocks and res5["verify"]["checksum"] == res2["verify"]["checksum"]
+    # the headroom turns out not to be there: the same two passes without maps
+    trio.close()
+    os.environ["RFX_WGS_INJECT_OOM"] = "0:maps:0"
+    try:
+        trio._injected = False
+        trio.map_budget = 1 << 30
+        res6 = trio.run(samples)
+    finally:
+        del os.environ["RFX_WGS_INJECT_OOM"]
+    assert trio.passes == 2 and trio.map_budget == 0 and trio._store is None and trio.replayed_blocks == 0
+    assert res6["n_records"] == n_rec1 and np.array_equal(res6["mutant_keys"], keys1)
+    used_before = ctx.mem_stats()["used"]
+    trio.close()
     for s in samples:
         for b in s:
             b.free()
@@ -755,3 +790,151 @@ def test_a_block_is_hashed_once_for_two_shards(ctx, k):
     assert ctx.mem_stats()["used"] == used0
     for b in big + small:
         b.free()
+
+
+def _shard_tables(ctx, k, S, blocks, store=None):
+    """One table per shard of S over `blocks`: [(checksum, n_records, replayed)] per shard."""
+    out = []
+    for sh in range(S):
+        t = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+        t.set_shard(sh, S)
+        if store is not None:
+            t.set_runmaps(store)
+        for b in blocks:
+            t.add(b)
+        rec = t.finish(LOWER)
+        out.append((tuple(rec.checksum()), len(rec), t.replayed()))
+        rec.free()
+        t.free()
+    return out
+
+
+@pytest.mark.parametrize("k,compact", [(25, True), (31, True), (27, False)])
+def test_later_shard_passes_replay_the_run_map(ctx, k, compact):
+    """rfx_runmaps_* / k_msp_replay: with a store of run maps a big block is hashed once (k_msp_map, by the first shard
+    pass that adds it) and EVERY pass cuts its records from reads + map -- the SAME records per shard as the passes
+    that hash (rfx_records_checksum + record count per shard, S = 2, 3, 4); one hashing launch per block instead of S
+    (plus the small k_msp_part1 launches over the ~1 % of reads whose runs do not fit a map), S replays; a store
+    without room means hashing as before; a pooled store serves the same; the store's memory goes back with it."""
+    sy = capi.Synth.sample(30_000_000, 0, n_snv=50, seed=2718)
+    big = wgs.make_sample(ctx, sy, 2_300_000, 2_300_000, MIN_Q, want_good=False, compact=compact)    # 5.8e8 windows: the big path
+    small = wgs.make_sample(ctx, sy, 200_000, 200_000, MIN_Q, want_good=False, compact=compact, first_pair=2_300_000)
+    blocks = big + small
+    used0 = None
+    for S in (2, 3, 4):
+        ref = _shard_tables(ctx, k, S, blocks)
+        assert all(r[2] == 0 for r in ref)
+        if used0 is None:
+            used0 = ctx.mem_stats()["used"]     # (the ctx keeps the lookup tables of (k, size) from the first table on)
+        store = capi.RunMaps(ctx)
+        ctx.prof(True)
+        ctx.prof_reset()
+        got = _shard_tables(ctx, k, S, blocks, store)
+        prof = ctx.prof_dict()
+        ctx.prof(False)
+        assert [g[:2] for g in got] == [r[:2] for r in ref], (S, k)
+        # (the small block follows a big one into the same table: same bins, same path -- it gets a map too)
+        assert [g[2] for g in got] == [2] * S
+        assert prof["k_msp_replay"][1] == 2 * S and prof["k_msp_map"][1] == 2
+        # both blocks hashed once, into their maps; beside every replay one small launch over the reads without a map
+        assert prof.get("k_msp_part1", (0, 0))[1] <= 2 * S
+        n_all = big[0].n + small[0].n
+        assert store.blocks() == 2 and 2 * n_all * 32 > store.bytes() >= n_all * 32
+        store.free()
+        ctx.sync()
+        assert ctx.mem_stats()["used"] == used0
+    # no room in the store: every pass hashes; a pool that holds the small block's map only
+    store = capi.RunMaps(ctx, budget_bytes=1 << 20)
+    got = _shard_tables(ctx, k, 2, blocks, store)
+    assert store.blocks() == 0 and [g[2] for g in got] == [0, 0]
+    store.free()
+    store = capi.RunMaps(ctx, budget_bytes=small[0].n * 32 + (1 << 20), pooled=True)
+    got = _shard_tables(ctx, k, 2, blocks, store)
+    assert store.blocks() == 1 and [g[2] for g in got] == [1, 1] and [g[:2] for g in got] == [r[:2] for r in _shard_tables(ctx, k, 2, blocks)]
+    store.clear()
+    assert store.blocks() == 0 and store.bytes() == 0
+    store.free()
+    ctx.sync()
+    assert ctx.mem_stats()["used"] == used0
+    # a map dropped before the last pass: that pass makes it anew
+    store = capi.RunMaps(ctx)
+    t0 = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+    t0.set_shard(0, 3)
+    t0.set_runmaps(store)
+    t0.add(big[0])
+    assert store.blocks() == 1 and t0.replayed() == 1
+    t0.free()
+    store.drop(big[0])
+    assert store.blocks() == 0 and store.bytes() == 0
+    store.free()
+    for b in blocks:
+        b.free()
+
+
+@pytest.mark.parametrize("k", [25, 31, 23])
+def test_run_map_on_ragged_reads_matches_oracle(ctx, monkeypatch, k):
+    """The run map on what a sequencer does not make: reads of every length from 0 to 160 (shorter than k, one k-mer, a
+    whole number of 8-base phases and not), N runs, IUPAC codes, lower case, homopolymers and short tandem repeats (ties between
+    equal minimizers; many short runs: reads whose entries do not fit the map's 27 and go the ordinary way), in one table
+    that runs its shard passes itself (rfx_count_set_passes, S = 2 .. 5) -- the oracle's payload, with and without maps;
+    a block with a read of more than 160 bases gets no map.  RFX_P2L_BINS forces the path of big blocks."""
+    monkeypatch.setenv("RFX_P2L_BINS", "32768")
+    rng = np.random.default_rng(1000 + k)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    genome = acgt[rng.integers(0, 4, 60_000)]
+    reads = []
+    for i in range(40_000):
+        L = int(rng.integers(0, 161)) if i % 4 else 150
+        p = int(rng.integers(0, len(genome) - 160))
+        r = genome[p:p + L].copy()
+        if L and rng.random() < 0.03:
+            r[rng.integers(0, L, int(rng.integers(1, 4)))] = acgt[rng.integers(0, 4)]    # errors
+        if L and rng.random() < 0.15:
+            q = int(rng.integers(0, L))
+            r[q:q + int(rng.integers(1, 40))] = ord("N") if rng.random() < 0.7 else ord("R")
+        s = r.tobytes()
+        if rng.random() < 0.05:
+            s = s.lower()
+        reads.append(s)
+    for unit in (b"A", b"AC", b"ACG", b"ACGTT", b"AACCGGTTACGTAGC"):      # repeats: every window ties / many short runs
+        for L in (150, 160, 97):
+            reads += [(unit * 200)[j:j + L] for j in range(len(unit))] * 3
+    ref = oracle.count(None, k, SIZE, lower=LOWER, reads=reads)
+    blk = ctx.upload(capi.PackedReads.from_reads(reads))
+    for passes in (2, 3, 5):
+        for no_map in (False, True):
+            if no_map:
+                monkeypatch.setenv("RFX_NO_RUNMAP", "1")
+            else:
+                monkeypatch.delenv("RFX_NO_RUNMAP", raising=False)
+            ctx.prof(True)
+            ctx.prof_reset()
+            t = capi.CountTable(ctx, k, SIZE)
+            t.set_passes(passes)
+            t.add(blk)
+            rec, h = t.finish(LOWER, want_histo=True)
+            prof = ctx.prof_dict()
+            ctx.prof(False)
+            assert rec.payload() == ref.payload(), (passes, no_map)
+            assert np.array_equal(h, oracle.histo(ref.counts, full=True)[0])
+            assert prof.get("k_msp_replay", (0, 0))[1] == (0 if no_map else passes)
+            assert prof.get("k_msp_map", (0, 0))[1] == (0 if no_map else 1)
+            rec.free()
+            t.free()
+    monkeypatch.delenv("RFX_NO_RUNMAP", raising=False)
+    blk.free()
+    # a read of 161 bases: the block gets no map, the passes hash it
+    reads2 = reads[:5000] + [genome[100:261].tobytes()]
+    ref2 = oracle.count(None, k, SIZE, lower=LOWER, reads=reads2)
+    blk = ctx.upload(capi.PackedReads.from_reads(reads2))
+    ctx.prof(True)
+    ctx.prof_reset()
+    t = capi.CountTable(ctx, k, SIZE)
+    t.set_passes(2)
+    t.add(blk)
+    rec = t.finish(LOWER)
+    assert "k_msp_replay" not in ctx.prof_dict() and rec.payload() == ref2.payload()
+    ctx.prof(False)
+    rec.free()
+    t.free()
+    blk.free()

@@ -61,8 +61,13 @@ __device__ __forceinline__ uint32_t mmer_hash(uint32_t c) {
 // minimum then carries the position of the minimizer along for free, and ties between equal m-mers of
 // one window are broken consistently.  Only the upper 27 bits decide the bin.
 constexpr uint32_t MSP_HMASK = ~31u;
-// The minimum of 11 .. 16 hashes crowds towards 0: spread it again before taking the top bits.
-__device__ __forceinline__ uint32_t msp_binhash(uint32_t minh) { return (minh & MSP_HMASK) * 0xC2B2AE3Du; }
+// The minimum of 11 .. 16 hashes crowds towards 0: spread it again before taking the top bits.  The TOP bit -- which half
+// of the bin space, i.e. which of two shard passes -- is bit 5 of the hash itself (the lowest bit that is not position; as
+// even as any): k_msp_part1 HMODE 4 notes it for every run of a read and would pay eight multiplies per phase for it.
+constexpr uint32_t MSP_HALF_BIT = 32u;
+__device__ __forceinline__ uint32_t msp_binhash(uint32_t minh) {
+  return (((minh & MSP_HMASK) * 0xC2B2AE3Du) >> 1) | ((minh & MSP_HALF_BIT) << 26);
+}
 __device__ __forceinline__ uint32_t msp_bin(uint32_t minh, int bin_bits) {
   return msp_binhash(minh) >> (32 - bin_bits);  // msp_record_binhash() repeats this from the record
 }

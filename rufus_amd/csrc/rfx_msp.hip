@@ -318,14 +318,14 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
         // turn needs of the minimizer (its position mod 32, for `back`; its bin, for "is this run the table's") is laid
         // out per phase: five bits per base in `qpack`, one in `minemask`.
         if constexpr (MAPONLY) {
-          // every run that ends in this phase becomes an entry of the map: a lane walks the set bits of its `ends`
-          uint64_t qpack = prev_mh & 31u;  // 5 bits per run end: position (mod 32) of the minimizer of the run ending at p0 + b - 1
-          uint32_t halves = msp_binhash(prev_mh) >> 31;  // bit b: that run's bin lies in the upper half of the bin space
+          // every run that ends in this phase becomes an entry of the map: a lane walks the set bits of its `ends`.  Per
+          // run end six bits of the minimizer's hash are laid out ahead: its position (mod 32) and MSP_HALF_BIT, the
+          // half of the bin space the run's bin lies in (bases 0 .. 4 in one word, 5 .. 7 in another: 32-bit shifts).
+          uint32_t qa = prev_mh & 63u, qb = 0;
   #pragma unroll
-          for (int b = 1; b < P1_S; ++b) {
-            qpack |= (uint64_t)(mhv[b - 1] & 31u) << (5 * b);
-            halves |= (msp_binhash(mhv[b - 1]) >> 31) << b;
-          }
+          for (int b = 1; b < 5; ++b) qa |= (mhv[b - 1] & 63u) << (6 * b);
+  #pragma unroll
+          for (int b = 5; b < P1_S; ++b) qb |= (mhv[b - 1] & 63u) << (6 * (b - 5));
           uint32_t pend = ends;
           while (__ballot(pend != 0)) {
             if (pend) {
@@ -334,17 +334,22 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
               const uint32_t ms = starts & ((1u << b) - 1u);
               const uint32_t rs = ms ? p0 + 31u - (uint32_t)__clz((int)ms) : run_s;
               const uint32_t e = p0 + b - 1u;
-              const uint32_t back = (e - (uint32_t)(qpack >> (5u * b))) & 31u;
+              const uint32_t q6 = b < 5u ? qa >> (6u * b) : qb >> (6u * b - 30u);
+              const uint32_t back = (e - q6) & 31u;
               // entry: low nibble n - 1 (15: a gap), high nibble `back` (a gap: its length - 1).  K-mer end positions no run
               // covers (invalid bases) are gaps.  A run longer than a record holds (k >= 26) goes in pieces, as the records do.
-              for (uint32_t g = rs - mpos; g != 0;) {
-                const uint32_t l = min(g, 16u);
-                if (mcnt < RMAP_ENTRIES) mapb[mcnt] = (uint8_t)(0xFu | ((l - 1u) << 4));
-                ++mcnt;
-                g -= l;
+              // (Entries beyond the map's 27 land on bytes that the flags overwrite: no test on the way.)
+              if (rs != mpos) {
+                for (uint32_t g = rs - mpos; g != 0;) {
+                  const uint32_t l = min(g, 16u);
+                  mapb[min(mcnt, 31u)] = (uint8_t)(0xFu | ((l - 1u) << 4));
+                  ++mcnt;
+                  g -= l;
+                }
               }
-              if (mcnt < RMAP_ENTRIES) mapb[mcnt] = (uint8_t)((e - rs) | (back << 4));
-              if (mcnt < 32u) mflags |= ((halves >> b) & 1u) << mcnt;
+              const uint32_t at = min(mcnt, 31u);
+              mapb[at] = (uint8_t)((e - rs) | (back << 4));
+              mflags |= ((q6 >> 5) & 1u) << at;
               ++mcnt;
               mpos = e + 1u;
             }
@@ -663,44 +668,68 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_replay(rfx_reads_view rv, con
     // (a lane reads only what it wrote itself: no barrier)
     uint32_t mine = ~gaps & ((1u << cnt) - 1u);
     if (half_sel != 2u) mine &= half_sel ? flags : ~flags;
+    // two runs per turn, stage by stage: their LDS round trips (entry, read words, slab slot) overlap instead of queueing up
     while (__ballot(mine != 0)) {
-      if (mine) {
-        const uint32_t i = (uint32_t)__ffs((int)mine) - 1u;
-        mine &= mine - 1u;
-        const uint32_t en = ent8[i];
-        const int n = (int)(en & 15u) + 1;
-        const uint32_t back = en >> 4;
-        const uint32_t e = (uint32_t)k - 2u + end8[i];  // the run's last k-mer ends at base e
+      bool on[2];
+      uint32_t en[2], pe[2], d[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        on[u] = mine != 0;
+        const uint32_t i = on[u] ? (uint32_t)__ffs((int)mine) - 1u : 0u;
+        mine &= mine - 1u;  // (0 stays 0)
+        en[u] = ent8[i];
+        pe[u] = end8[i];
+      }
+      uint32_t sh[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t e = (uint32_t)k - 2u + pe[u];  // the run's last k-mer ends at base e
         // bases e - L + 1 .. e = bit pairs 159 - e .. 159 - e + L - 1 of the staged read, base e least significant
-        const uint32_t o = 2u * (159u - e), dw = o >> 5, sh = o & 31u;
-        const uint32_t d0 = rd[dw], d1 = rd[dw + 1], d2 = rd[dw + 2], d3 = rd[dw + 3];  // (past the read: the entries, never used -- 2L bits are)
-        const uint64_t lo = (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+        const uint32_t o = 2u * (159u - e), dw = o >> 5;
+        sh[u] = o & 31u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[u][j] = rd[dw + j];  // (past the read: the entries, never used -- 2L bits are)
+      }
+      uint64_t lo[2];
+      uint32_t run_bin[2], slot[2];
+      bool put[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t back = en[u] >> 4;
+        lo[u] = (uint64_t)__builtin_amdgcn_alignbit(d[u][1], d[u][0], sh[u]) |
+                ((uint64_t)__builtin_amdgcn_alignbit(d[u][2], d[u][1], sh[u]) << 32);
         // the bin, from the minimizer m-mer itself: it ends `back` bases before e (back + m <= 31 bases: inside `lo`)
-        const uint32_t f = (uint32_t)(lo >> (2u * back)) & mmask;
+        const uint32_t f = (uint32_t)(lo[u] >> (2u * back)) & mmask;
         uint32_t c = f;
         if (CANON) {
           uint32_t y = __brev(~f);
           y = ((y & 0xAAAAAAAAu) >> 1) | ((y & 0x55555555u) << 1);
           c = min(f, y >> (32 - 2 * m));
         }
-        const uint32_t run_bin = msp_binhash(mmer_hash(c)) >> (32 - bin_bits);
-        if (run_bin - bin_lo < bin_hi - bin_lo) {  // (more than two passes: the half says little, the bin everything)
-          const uint32_t hi = __builtin_amdgcn_alignbit(d3, d2, sh) & 0x3FFFFFu;
+        run_bin[u] = msp_binhash(mmer_hash(c)) >> (32 - bin_bits);
+        put[u] = on[u] && run_bin[u] - bin_lo < bin_hi - bin_lo;  // (more than two passes: the half says little, the bin everything)
+        slot[u] = put[u] ? atomicAdd(&s_fill[run_bin[u] >> sub_bits], 1u) : 0u;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (put[u]) {
+          const int n = (int)(en[u] & 15u) + 1;
+          const uint32_t back = en[u] >> 4;
+          const uint32_t hi = __builtin_amdgcn_alignbit(d[u][3], d[u][2], sh[u]) & 0x3FFFFFu;
           uint64_t w;
           uint32_t x;
-          msp_record_make(lo, hi, k, n, (uint32_t)(k + n - 1 - m) - back, w, x);
-          const uint32_t coarse = run_bin >> sub_bits;
-          const uint32_t slot = atomicAdd(&s_fill[coarse], 1u);
-          if (slot < 2 * SLAB) {
-            const uint64_t sb = s_slab[slot >> slab_log2][coarse];
-            msp_rec12_store(rec_a, sb + (slot & (SLAB - 1)), w, x);
+          msp_record_make(lo[u], hi, k, n, (uint32_t)(k + n - 1 - m) - back, w, x);
+          const uint32_t coarse = run_bin[u] >> sub_bits;
+          if (slot[u] < 2 * SLAB) {
+            const uint64_t sb = s_slab[slot[u] >> slab_log2][coarse];
+            msp_rec12_store(rec_a, sb + (slot[u] & (SLAB - 1)), w, x);
           } else {  // more than two slabs' worth in one chunk: one reservation per record
             const uint32_t at = atomicAdd(&coarse_cur[coarse * P1_CUR_STRIDE], 1u);
             if (at < cap_a) msp_rec12_store(rec_a, (uint64_t)coarse * cap_a + at, w, x);
             else atomicExch(flag, 1u);
           }
           ++n_emit;
-          const uint32_t fb = run_bin - bin_lo;
+          const uint32_t fb = run_bin[u] - bin_lo;
           atomicAdd(&s_fine[fb >> 2], 1u << ((fb & 3u) * 8));
         }
       }

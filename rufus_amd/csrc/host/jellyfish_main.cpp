@@ -151,6 +151,8 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   }
   if (keep_path && (!sam_chr || inputs.size() != 1))
     die("rufus_amd jellyfish count: --keep-packed goes with --sam and ONE input (a pipe with --spool, or a SAM file)");
+  if (keep_path && any_stream && !spool_path)  // (the cache points into the stream: without a copy of it there is nothing to point into)
+    die("rufus_amd jellyfish count: --keep-packed of a piped input needs --spool FILE (the cache refers to lines of the stream)");
   if (spool_path && (!any_stream || inputs.size() != 1))
     die("rufus_amd jellyfish count: --spool copies ONE piped input; a regular file can be given to the next stage as it is");
   unsigned nthreads = (unsigned)std::max(1, threads);
@@ -291,6 +293,8 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
       if (in.fd > 0) ::close(in.fd);
     }
   }
+  // the packed-read cache is a cache only from here on: its header now says how many chunks describe how long a stream
+  if (keep_path && ingest) ingest->finish_keep_packed(inputs[0].regular ? inputs[0].size : ingest->spooled_bytes());
   if (sam_chr) {
     FILE* cf = fopen(sam_chr, "w");
     if (!cf) {  // src/PassThroughSamCheck.cpp:37-44

@@ -614,6 +614,41 @@ inline void trace(const char* what) {
 // (profiles/r04_cli_w_sample.txt: 3.6 s for the payload = 9.9 GB/s, "waited 2.9 s for buffers").  RFX_NO_PREMAP=1: off.
 // A piped input has no size to guess from: start_growing() + want(bytes) follow the stream (the file grows under a
 // mapping of a fixed, large piece of address space; pages past the end of a file are simply not there yet).
+// An output that was given a size before its content exists (OutputPrealloc) must not survive its writer's death: the
+// reference scripts take a non-empty file for a finished one (`[ ! -s X.Jhash ]`, runRufus.sh:806,816; exit codes are
+// not looked at).  The descriptor is registered here until write_jhash() has written everything: exit() (die()) and
+// SIGINT / SIGTERM / SIGHUP cut the file back to 0 bytes.  (ftruncate and _exit are async-signal-safe.)
+struct UnfinishedOutput {
+  static std::atomic<int>& fd() {
+    static std::atomic<int> f{-1};
+    return f;
+  }
+  static void cut() {
+    const int f = fd().exchange(-1);
+    if (f >= 0) (void)!::ftruncate(f, 0);
+  }
+  static void on_signal(int sig) {
+    cut();
+    _exit(128 + sig);
+  }
+  static void watch(int f) {
+    static bool installed = false;
+    if (!installed) {
+      installed = true;
+      atexit(cut);
+      struct sigaction sa;
+      memset(&sa, 0, sizeof sa);
+      sa.sa_handler = on_signal;
+      for (int sig : {SIGINT, SIGTERM, SIGHUP}) sigaction(sig, &sa, nullptr);
+    }
+    fd() = f;
+  }
+  static void done(int f) {
+    int want = f;
+    fd().compare_exchange_strong(want, -1);
+  }
+};
+
 class OutputPrealloc {
   int fd_ = -1;
   std::thread th_;
@@ -665,6 +700,7 @@ class OutputPrealloc {
     if (fd_ < 0 || bytes == 0) return;
     if (::ftruncate(fd_, (off_t)bytes) == 0) map((size_t)bytes);
     if (!map_) (void)!::ftruncate(fd_, 0);
+    else UnfinishedOutput::watch(fd_);
     target_ = bytes;
     th_ = std::thread([this] { run(); });
   }
@@ -680,6 +716,7 @@ class OutputPrealloc {
     }
     growing_ = true;
     map((size_t)1 << 40);
+    if (map_) UnfinishedOutput::watch(fd_);
     th_ = std::thread([this] { run(); });
   }
   void want(uint64_t bytes) {
@@ -708,7 +745,10 @@ class OutputPrealloc {
   ~OutputPrealloc() {
     const int fd = take();
     if (map_) munmap(map_, map_len_);
-    if (fd >= 0) ::close(fd);
+    if (fd >= 0) {  // (never handed to a writer: whatever size it was given, it holds nothing)
+      UnfinishedOutput::cut();
+      ::close(fd);
+    }
   }
 };
 
@@ -848,6 +888,7 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
     } else if (open_fd >= 0) {
       (void)!::ftruncate(fd, (off_t)total);
     }
+    UnfinishedOutput::done(fd);
     if (::close(fd) != 0) die(std::string("write error on '") + path + "'");
     return;
   }
@@ -904,6 +945,7 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
   } else if (open_fd >= 0) {
     (void)!::ftruncate(fd, (off_t)total);  // drop what was preallocated past the end
   }
+  UnfinishedOutput::done(fd);
   if (::close(fd) != 0) die(std::string("write error on '") + path + "'");
 }
 

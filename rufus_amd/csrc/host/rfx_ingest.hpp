@@ -246,11 +246,11 @@ class CountIngest {
     std::vector<uint32_t> slen;
     start.reserve(1 << 17);
     slen.reserve(1 << 17);
-    std::vector<std::string> runs;
+    std::vector<std::string> runs, cache_runs;
     rfxcache::ChunkBuilder cache;
     const char *p = pc.b, *e = pc.e;
-    const char* cur_chr = nullptr;
-    size_t cur_len = 0;
+    const char *cur_chr = nullptr, *cache_chr = nullptr;
+    size_t cur_len = 0, cache_chr_len = 0;
     while (p < e) {
       const char* nl = find_nl(p, e);
       const char* le = nl ? nl : e;
@@ -276,6 +276,13 @@ class CountIngest {
       start.push_back((uint64_t)(sq - pc.b));
       slen.push_back((uint32_t)(sq_e - sq));
       if (cache_fd_ >= 0 && nt >= 10) {  // (fewer than 11 fields: no record for the filter -- the feeders skip the line)
+        // the filter's chromosome log lists the lines it is given (rufus_filter_main.cpp, split_sam): the cache keeps
+        // runs of its own, of these lines only
+        if (!cache_chr || chr_len != cache_chr_len || memcmp(chr, cache_chr, chr_len) != 0) {
+          cache_runs.emplace_back(chr, chr_len);
+          cache_chr = chr;
+          cache_chr_len = chr_len;
+        }
         const char* ql = tab[9] + 1;
         const char* ql_e = (const char*)memchr(ql, '\t', (size_t)(le - ql));
         if (!ql_e) ql_e = le;
@@ -285,7 +292,7 @@ class CountIngest {
     }
     if (cache_fd_ >= 0) {
       std::vector<char> chunk;
-      cache.finish(pc.seq, pc.spool_off, runs, cache_minq_, chunk);
+      cache.finish(pc.seq, pc.spool_off, cache_runs, cache_minq_, chunk);
       const uint64_t at = cache_at_.fetch_add(chunk.size());
       const char* w = chunk.data();
       size_t len = chunk.size();
@@ -559,6 +566,18 @@ class CountIngest {
     h.min_q = min_q;
     if (::pwrite(fd, &h, sizeof h, 0) != (ssize_t)sizeof h) die("write error on the packed-read cache");
     cache_at_ = sizeof h;
+  }
+  // after the last feed_*(): the header once more, now with what makes the file a cache (rfx_packed_cache.hpp)
+  void finish_keep_packed(uint64_t stream_bytes) {
+    if (cache_fd_ < 0) return;
+    rfxcache::FileHeader h;
+    h.min_q = cache_minq_;
+    h.n_chunks = next_seq_;
+    h.stream_bytes = stream_bytes;
+    h.done = rfxcache::DONE_MAGIC;
+    if (::pwrite(cache_fd_, &h, sizeof h, 0) != (ssize_t)sizeof h || ::close(cache_fd_) != 0)
+      die(std::string("write error on the packed-read cache: ") + strerror(errno));
+    cache_fd_ = -1;
   }
   uint64_t spooled_bytes() const { return spooled_; }
   // PassThroughSamCheck's side file: "notachr", then the name of every run of equal RNAME, in stream order

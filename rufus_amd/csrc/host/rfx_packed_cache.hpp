@@ -33,11 +33,18 @@ constexpr uint64_t FILE_MAGIC = 0x31484341434B5052ull;   // "RPKCACH1"
 constexpr uint64_t CHUNK_MAGIC = 0x314B4E5548434B50ull;  // "PKCHUNK1"
 constexpr uint8_t REC_ALWAYS = 1;  // not packed exactly: always handed to the text route
 
+constexpr uint64_t DONE_MAGIC = 0x454E4F4448434143ull;   // "CACHDONE": the producer finished the file
+// The header is written twice: at the start without `done`, and again when the count has parsed the whole stream --
+// with the number of chunks and the length of the stream they describe.  A cache whose producer died on the way, or one
+// left over from another stream, is then NOT a cache (read_chunks), however many well-formed chunks it holds.
 struct FileHeader {
   uint64_t magic = FILE_MAGIC;
   int32_t min_q = 0;
   uint32_t reserved = 0;
-  uint64_t pad[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t done = 0;          // DONE_MAGIC once the producer has written everything
+  uint64_t n_chunks = 0;      // pieces of the stream = chunks in the file
+  uint64_t stream_bytes = 0;  // length of the stream (spool file / SAM file) the line offsets refer to
+  uint64_t pad[3] = {0, 0, 0};
 };
 
 // A chunk = one piece of the stream.  Arrays follow the header in this order, each padded to 8 bytes:
@@ -170,12 +177,13 @@ struct ChunkView {
   const char* runs = nullptr;
 };
 
-// Chunks of a mapped cache file in stream order; false: not a cache / truncated.
-inline bool read_chunks(const char* base, size_t size, int& min_q, std::vector<ChunkView>& out) {
+// Chunks of a mapped cache file in stream order; false: not a cache, not finished by its producer, truncated, not the
+// cache of a stream of `stream_bytes` bytes, or inconsistent in itself (every offset the reader follows is checked here).
+inline bool read_chunks(const char* base, size_t size, uint64_t stream_bytes, int& min_q, std::vector<ChunkView>& out) {
   if (size < sizeof(FileHeader)) return false;
   FileHeader fh;
   memcpy(&fh, base, sizeof fh);
-  if (fh.magic != FILE_MAGIC) return false;
+  if (fh.magic != FILE_MAGIC || fh.done != DONE_MAGIC || fh.stream_bytes != stream_bytes) return false;
   min_q = fh.min_q;
   size_t at = sizeof fh;
   while (at + sizeof(ChunkHeader) <= size) {
@@ -196,9 +204,16 @@ inline bool read_chunks(const char* base, size_t size, int& min_q, std::vector<C
     v.good = (const uint32_t*)(base + o); o += pad8(words * 4);
     v.runs = base + o; o += pad8(h->runs_bytes);
     if (o != at + h->bytes) return false;
+    // what the device and the gather will follow: word offsets inside the chunk's words, lines inside the stream
+    if (n && (v.word_off[0] != 0 || v.word_off[n] != words)) return false;
+    for (size_t r = 0; r < n; ++r) {
+      if (v.word_off[r] > v.word_off[r + 1] || (uint64_t)(v.word_off[r + 1] - v.word_off[r]) * 32 < v.len[r]) return false;
+      if (h->stream_off + (uint64_t)v.line_off[r] + v.line_len[r] > stream_bytes) return false;
+    }
     out.push_back(v);
     at += h->bytes;
   }
+  if (out.size() != fh.n_chunks) return false;  // the producer wrote more (or fewer) than the file holds
   std::sort(out.begin(), out.end(), [](const ChunkView& a, const ChunkView& b) { return a.h->seq < b.h->seq; });
   for (size_t i = 0; i < out.size(); ++i)
     if (out[i].h->seq != i) return false;  // a piece is missing

@@ -551,8 +551,8 @@ static int run_packed(int argc, char** argv) {
     printf("Error, MutFile could not be opened");
     return 0;
   }
-  if (!cm.open(cache_path) || !rfxcache::read_chunks(cm.p, cm.n, cached_q, chunks) || cached_q != min_q) {
-    // no cache, a cache of another stream length, or packed for another MinQ: the text decides
+  if (!cm.open(cache_path) || !rfxcache::read_chunks(cm.p, cm.n, sm.n, cached_q, chunks) || cached_q != min_q) {
+    // no cache, one its producer did not finish, a cache of another stream (length), or packed for another MinQ: the text decides
     fprintf(stderr, "rufus_amd RUFUS.Filter: %s is not a usable packed-read cache for MinQ %d: scanning the text\n", cache_path, min_q);
     return text_route(spool, chr_path);
   }
@@ -628,9 +628,17 @@ static int run_packed(int argc, char** argv) {
   for (const rfxcache::ChunkView& v : chunks)
     for (uint32_t r = 0; r < v.h->n; ++r)
       if (hit_names.count(v.hash[r])) {
-        const uint64_t at = v.h->stream_off + v.line_off[r];
-        if (at + v.line_len[r] > sm.n) die("rufus_amd RUFUS.Filter --packed: the cache does not belong to this spool (a line lies behind its end)");
-        mini.append(sm.p + at, v.line_len[r]);
+        const uint64_t at = v.h->stream_off + v.line_off[r];  // (inside the spool: read_chunks checked every line)
+        // the line must be the record the chunk was made from: same QNAME (a cache left over from another stream of
+        // the same length would otherwise hand the text route the wrong lines without anybody noticing)
+        const char* ln = sm.p + at;
+        const char* tab = (const char*)memchr(ln, '\t', v.line_len[r]);
+        if (!tab || rfxsam::name_hash(ln, (size_t)(tab - ln)) != v.hash[r]) {
+          fprintf(stderr, "rufus_amd RUFUS.Filter: %s does not describe %s (a line is not the record it was packed from): scanning the text\n",
+                  cache_path, spool);
+          return text_route(spool, chr_path);
+        }
+        mini.append(ln, v.line_len[r]);
         mini.push_back('\n');
         ++n_lines;
       }

@@ -1866,6 +1866,7 @@ struct rfx_peers {
     const uint64_t* inst = nullptr;
     const uint32_t* ext = nullptr;
     uint32_t bins = 0;
+    uint64_t kmers = 0;  // the k-mer instances behind its records (rfx_segment::kmers)
     std::vector<uint64_t> bs;  // host copy of its bin extents
   };
   struct Slot {
@@ -1896,6 +1897,21 @@ struct rfx_peers {
     failed = true;
     cv.notify_all();
   }
+  // After a failure between two barriers: every table comes here once its own stream is idle, and leaves when all have
+  // -- until then somebody may still be copying out of somebody's partitions (barrier() lets go at once after abort()).
+  int drained = 0;
+  uint64_t drain_gen = 0;
+  void drain() {
+    std::unique_lock<std::mutex> g(mu);
+    const uint64_t my = drain_gen;
+    if (++drained == n) {
+      drained = 0;
+      ++drain_gen;
+      cv.notify_all();
+      return;
+    }
+    cv.wait(g, [&] { return drain_gen != my; });
+  }
 };
 
 // Sharded peers, pass s of S: publish this table's partitions, pull the record runs of this table's owner range from
@@ -1917,6 +1933,7 @@ static int peers_pull_records(rfx_table* t, int s, int S, std::vector<rfx_segmen
       ps.inst = sg.inst;
       ps.ext = sg.ext;
       ps.bins = sg.bins;
+      ps.kmers = sg.kmers;
       ps.bs.assign((size_t)sg.bins + 1, 0);
       if (hipMemcpyAsync(ps.bs.data(), sg.bin_start, ((size_t)sg.bins + 1) * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess)
         rc = RFX_E_HIP;
@@ -1942,8 +1959,14 @@ static int peers_pull_records(rfx_table* t, int s, int S, std::vector<rfx_segmen
       uint64_t* d_bs = (uint64_t*)dmalloc(c, ((size_t)ps.bins + 1) * 8);
       if (!d_bs) { rc = RFX_E_NOMEM; break; }
       if (upload(c, d_bs, bs.data(), ((size_t)ps.bins + 1) * 8) != hipSuccess) { dfree(c, d_bs); rc = RFX_E_HIP; break; }
-      // (k-mer instances behind the run: sizes the leaf's bins and the survivor store)
-      const uint64_t kmers = n * (uint64_t)(t->k <= 25 ? 6 : 9);
+      // k-mer instances behind the run (sizes the leaf's bins and the survivor store): the run's share of what its
+      // segment holds, never more than its records can carry.  (Until round 4: n x the AVERAGE k-mers per record of
+      // ordinary sequence -- on low-complexity data, where records run to their full length, up to 1.8 x too few:
+      // bins planned too coarse, extra split passes or RFX_E_FULL, on this path only.)
+      const uint64_t nmax = (uint64_t)rfxk::msp_nmax_of(t->k);
+      const uint64_t n_all = ps.bs[ps.bins];  // (the records the segment really holds: rfx_segment::n may be a capacity)
+      uint64_t kmers = n_all ? (uint64_t)((double)ps.kmers * (double)n / (double)n_all) + 1 : n * nmax;
+      kmers = std::min(kmers, n * nmax);
       if (g == me) {
         rfx_segment sg{const_cast<uint64_t*>(ps.inst), n, d_bs, kmers, ps.bins, const_cast<uint32_t*>(ps.ext)};
         sg.borrowed = true;
@@ -1970,9 +1993,14 @@ static int peers_pull_records(rfx_table* t, int s, int S, std::vector<rfx_segmen
       t->segs->push_back(rfx_segment{inst, n, d_bs, kmers, ps.bins, ext});
     }
   }
-  if (rc == RFX_OK && ctx_sync(c) != hipSuccess) rc = RFX_E_HIP;
+  if (ctx_sync(c) != hipSuccess && rc == RFX_OK) rc = RFX_E_HIP;  // (a failed puller waits for its own copies too)
   if (rc != RFX_OK) p->abort();
-  if (!p->barrier()) return rc != RFX_OK ? rc : RFX_E_HIP;  // (every pull is complete: the partitions may go)
+  if (!p->barrier()) {  // somebody failed: nobody frees a partition before everybody's pulls have stopped
+    (void)ctx_sync(c);
+    p->drain();
+    return rc != RFX_OK ? rc : RFX_E_HIP;
+  }
+  // (every pull is complete: the partitions may go)
   // what nobody reads any more: everything of the own partitions but the arrays the own run lies in
   return RFX_OK;
 }

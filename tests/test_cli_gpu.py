@@ -428,8 +428,12 @@ def test_subject_stream_is_ingested_once_through_a_spool(tmp_path):
     r = subprocess.run([f"{BIN}/RUFUS.Filter", "--sam", "f.chr", "hl", "spool.sam", "one", "25", "15", "1", "4"], cwd=d,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr
-    r = subprocess.run(f"{BIN}/PassThroughSamCheck.stranded two.chr two < in.sam > two.log && "
-                       f"{BIN}/RUFUS.Filter hl two.mate1.fastq two.mate2.fastq two 25 15 1 4", shell=True, cwd=d,
+    # the reference route: the REFERENCE's stranded feeder and filter (oracle/_ref, one thread: input order)
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.exists(f"{ref}/RUFUS.Filter"):
+        pytest.skip("oracle/_ref not built")
+    r = subprocess.run(f"{ref}/PassThroughSamCheck.stranded two.chr two < in.sam > two.log && "
+                       f"{ref}/RUFUS.Filter hl two.mate1.fastq two.mate2.fastq two 25 15 1 1", shell=True, cwd=d,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr
     for m in (1, 2):
@@ -493,6 +497,42 @@ def test_subject_is_parsed_once_and_filtered_from_the_packed_cache(tmp_path):
                        f"{BIN}/RUFUS.Filter hl ref.mate1.fastq ref.mate2.fastq ref 25 15 1 4", shell=True, cwd=d,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr
+    # .. and the REFERENCE's own feeder + filter (oracle/_ref, one thread: input order) on the same stream without the
+    # record whose quality string is shorter than its read -- there src/RUFUS.Filter.cpp:205 indexes past the string's end
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    if os.path.exists(f"{refdir}/RUFUS.Filter"):
+        f_ok = [list(x) for x in f]
+        f_ok[100][10] = f_ok[100][10] + f_ok[100][10][:len(f_ok[100][9]) - len(f_ok[100][10])]
+        open(f"{d}/ok.sam", "wb").write(b"".join(b"\t".join(f_ok[i]) + b"\n" for i in order))
+        r = subprocess.run(f"{refdir}/PassThroughSamCheck.stranded okref.chr okref < ok.sam > okref.log && "
+                           f"{refdir}/RUFUS.Filter hl okref.mate1.fastq okref.mate2.fastq okref 25 15 1 1 && "
+                           f"{BIN}/RUFUS.Filter --sam oktext.chr hl ok.sam oktext 25 15 1 4", shell=True, cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr
+        for m in (1, 2):
+            assert open(f"{d}/oktext.Mutations.Mate{m}.fastq", "rb").read() == open(f"{d}/okref.Mutations.Mate{m}.fastq", "rb").read()
+        assert open(f"{d}/oktext.chr", "rb").read() == open(f"{d}/okref.chr", "rb").read()
+    # a cache its producer did not finish (no "done" word in the header), and the cache of ANOTHER stream of the same length
+    # (two lines swapped): neither is used -- the text route gives the same files
+    blob = bytearray(open(f"{d}/cache.bin", "rb").read())
+    blob[16:24] = bytes(8)
+    open(f"{d}/undone.bin", "wb").write(blob)
+    swapped = list(order)
+    same = [i for i in range(len(swapped)) if len(b"\t".join(f[swapped[i]])) == len(b"\t".join(f[swapped[500]]))]
+    assert len(same) > 100                      # the lines of one length, rotated by one place: every offset stays a line start
+    for x, y in zip(same, same[1:] + same[:1]):
+        swapped[x] = int(order[y])
+    sam2 = b"".join(b"\t".join(f[i]) + b"\n" for i in swapped)
+    assert len(sam2) == len(sam) and sam2 != sam
+    open(f"{d}/other.sam", "wb").write(sam2)
+    r = subprocess.run(cmd + ["--sam", "o.chr", "--keep-packed", "other.bin", "-o", "o.Jhash", "other.sam"], cwd=d, env=env, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr
+    for name, cache in (("undone", "undone.bin"), ("other", "other.bin")):
+        r = subprocess.run([f"{BIN}/RUFUS.Filter", "--packed", cache, f"{name}.chr", "hl", "spool.sam", name, "25", "15", "1", "4"], cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        assert r.returncode == 0 and b"scanning the text" in r.stderr, r.stderr
+        for m in (1, 2):
+            assert open(f"{d}/{name}.Mutations.Mate{m}.fastq", "rb").read() == open(f"{d}/text.Mutations.Mate{m}.fastq", "rb").read()
     for m in (1, 2):
         want = open(f"{d}/text.Mutations.Mate{m}.fastq", "rb").read()
         assert want == open(f"{d}/ref.Mutations.Mate{m}.fastq", "rb").read() and want.count(b"\n") >= 4 * 20

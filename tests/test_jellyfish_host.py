@@ -228,3 +228,38 @@ def test_output_pages_are_prepared_while_the_input_is_read(jf_san, testrun, tmp_
             assert ready >= 0, r.stderr                  # (how far the background thread got is a matter of timing)
     r = sh(cmd + ["-o", "/dev/stdout", "/dev/stdin"], d, env={"RFX_PREALLOC_MIN": "0"}, input=blob)   # nothing to prepare for a pipe
     assert r.returncode == 0 and r.stdout[9 + int(r.stdout[:9]):] == want
+
+
+def test_a_count_that_dies_leaves_an_empty_output(jf, testrun, tmp_path):
+    """The output is given a size (and mapped) while the input is still parsed; the reference scripts take a non-empty
+    .Jhash for a finished one (`[ ! -s X.Jhash ]`, runRufus.sh:806,816: exit codes are not looked at).  A count that
+    dies on its input (a SAM line with too few fields, far into the stream) or is killed (SIGTERM while it waits for a
+    pipe) therefore cuts the file back to nothing (rfx_cli.hpp UnfinishedOutput)."""
+    import signal
+    import time
+    d = str(tmp_path)
+    rng = np.random.default_rng(8)
+    sam = b"\n".join(_sam_of(testrun, rng)) + b"\n"
+    bad = sam + b"r\t0\tchr1\n" + sam
+    open(f"{d}/bad.sam", "wb").write(bad)
+    cmd = [jf, "count", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "4", "-C"]
+    env = {"RFX_PREALLOC_MIN": "0", "RFX_PREALLOC_FRAC": "3.0", "RFX_INGEST_PIECE": "65536"}
+    r = sh(cmd + ["--sam", "x.chr", "-o", "file.Jhash", "bad.sam"], d, env=env)
+    assert r.returncode != 0 and b"fewer than 10" in r.stderr
+    assert os.path.getsize(f"{d}/file.Jhash") == 0
+    r = sh(cmd + ["--sam", "x.chr", "-o", "pipe.Jhash", "/dev/stdin"], d, env=env, input=bad)
+    assert r.returncode != 0 and os.path.getsize(f"{d}/pipe.Jhash") == 0
+    # killed while the stream is still open: the file had grown under the mapping
+    p = subprocess.Popen(cmd + ["--sam", "x.chr", "-o", "killed.Jhash", "/dev/stdin"], cwd=d, stdin=subprocess.PIPE,
+                         stderr=subprocess.PIPE, env=dict(os.environ, **env))
+    p.stdin.write(sam * 3)
+    p.stdin.flush()
+    for _ in range(100):
+        if os.path.exists(f"{d}/killed.Jhash") and os.path.getsize(f"{d}/killed.Jhash") > 0:
+            break
+        time.sleep(0.05)
+    grown = os.path.getsize(f"{d}/killed.Jhash")
+    p.send_signal(signal.SIGTERM)
+    p.wait(timeout=60)
+    p.stdin.close()
+    assert p.returncode != 0 and os.path.getsize(f"{d}/killed.Jhash") == 0, grown

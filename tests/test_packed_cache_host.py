@@ -17,6 +17,7 @@ from tests.test_jellyfish_host import _build, _payload, sh
 
 FILE_MAGIC = 0x31484341434B5052
 CHUNK_MAGIC = 0x314B4E5548434B50
+DONE_MAGIC = 0x454E4F4448434143      # "CACHDONE": written last, with the chunk count and the stream's length
 COMP = bytes.maketrans(b"ACGTN", b"TGCAN")
 
 
@@ -31,8 +32,8 @@ def pad8(x):
 
 def read_cache(blob):
     """-> (min_q, [chunk dict]) in stream order; the layout of rfx_packed_cache.hpp:36-53."""
-    magic, min_q = struct.unpack_from("<Qi", blob, 0)
-    assert magic == FILE_MAGIC
+    magic, min_q, _, done, n_chunks, stream_bytes = struct.unpack_from("<QiIQQQ", blob, 0)
+    assert magic == FILE_MAGIC and done == DONE_MAGIC
     at, chunks = 64, []
     while at + 48 <= len(blob):
         magic, seq, stream_off, nbytes, n, n_words, runs_bytes, _ = struct.unpack_from("<QQQQIIII", blob, at)
@@ -51,7 +52,8 @@ def read_cache(blob):
         at += nbytes
     assert not any(blob[at:]), "bytes behind the last chunk"
     chunks.sort(key=lambda c: c["seq"])
-    assert [c["seq"] for c in chunks] == list(range(len(chunks)))
+    assert [c["seq"] for c in chunks] == list(range(len(chunks))) and len(chunks) == n_chunks
+    read_cache.stream_bytes = stream_bytes
     return min_q, chunks
 
 
@@ -84,6 +86,7 @@ def test_keep_packed_holds_every_record_as_the_filter_would_see_it(jf, tmp_path,
 
     got_q, chunks = read_cache(open(f"{d}/cache.bin", "rb").read())
     assert got_q == min_q and len(chunks) >= 4
+    assert read_cache.stream_bytes == len(sam)          # the header's last word: how long a stream the chunks describe
     recs = [x for x in f if len(x) > 10]
     i = 0
     by_name = {}
@@ -134,3 +137,6 @@ def test_keep_packed_is_refused_where_it_cannot_work(jf, tmp_path):
     assert r.returncode != 0 and b"--keep-packed" in r.stderr
     r = sh(cmd + ["--sam", "x.chr", "--keep-packed", "c.bin", "in.sam", "in.sam"], d)    # two inputs
     assert r.returncode != 0 and b"--keep-packed" in r.stderr
+    r = subprocess.run(cmd + ["--sam", "x.chr", "--keep-packed", "c.bin", "/dev/stdin"], cwd=d,   # a pipe without --spool:
+                       input=open(f"{d}/in.sam", "rb").read(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)   # the cache would
+    assert r.returncode != 0 and b"--spool" in r.stderr                                   # point into nothing

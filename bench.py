@@ -452,10 +452,20 @@ def main():
         checks["seconds"] = round(time.perf_counter() - t_chk, 1)
     trio_ = extra.get("_trio")
     extra = {k_: v for k_, v in extra.items() if not k_.startswith("_")}
+    multi = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # what the first real SCALE run is checked by at a glance: every rank's view of the group and what it exchanged
+        mine = torch.tensor([rank, local, dist.get_world_size(), int(getattr(trio_, "exchange_sent", 0)),
+                             int(getattr(trio_, "exchange_received", 0))], dtype=torch.int64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        multi = {"backend": dist.get_backend(), "rccl_world_size": dist.get_world_size(),
+                 "per_rank": [{"rank": int(x[0]), "device": int(x[1]), "rccl_world_size": int(x[2]),
+                               "record_bytes_sent_per_step": int(x[3]), "record_bytes_received_per_step": int(x[4])}
+                              for x in (y.tolist() for y in allr)]}
 
     if rank == 0:
         # K2+K3 (count -> sorted records) is the dominant stage: a chain of launches per sample (super-k-mer
@@ -483,6 +493,7 @@ def main():
                        "records_per_sample": [int(x) for x in res["n_records"]], **extra,
                        **({"blocks_replayed_from_run_maps_per_step": int(trio_.replayed_blocks)} if trio_ is not None else {}),
                        "checked": checks is not None, "checks": checks,
+                       **({"multi_gpu": multi} if multi else {}),
                        **({"one_device_dry_run": f"{world} ranks share device 0 over {dist.get_backend()}: the N-rank path is "
                                                  "exercised, the value is NOT a scaling measurement"} if args.one_device and world > 1 else {}),
                        "hbm_peak_bytes": ctx.mem_stats()["peak"], "hbm_mapped_bytes": ctx.mem_stats()["mapped"]},

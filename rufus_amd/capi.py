@@ -75,6 +75,7 @@ SIGNATURES = {
     "rfx_count_set_early": (C.c_int, [C.c_void_p, C.c_int]),
     "rfx_count_early_segments": (C.c_int, [C.c_void_p]),
     "rfx_count_adopt_early": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rfx_mem_reserve": (C.c_int, [C.c_void_p, C.c_uint64]),
     "rfx_runmaps_create": (C.c_void_p, [C.c_void_p, C.c_uint64]),
     "rfx_runmaps_create_pooled": (C.c_void_p, [C.c_void_p, C.c_uint64]),
     "rfx_runmaps_free": (None, [C.c_void_p]),

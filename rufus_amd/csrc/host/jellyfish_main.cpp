@@ -167,12 +167,30 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     if (peers && rfx_count_set_peers(tabs[g], peers, g) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
   }
   std::vector<std::vector<rfx_reads*>> resident((size_t)n_gpu);
+  // A sample counted in shard passes at finish needs ~3 bytes of device memory per byte of packed reads beside them
+  // (records of a pass, survivors): it is mapped while the input is still parsed, a few GiB per uploaded block -- in a fresh
+  // process mapping 130 GB took 0.6 s of the time between "input parsed" and "finished on the device".
+  std::vector<uint64_t> reserved((size_t)n_gpu, 0);
   auto sink_to = [&](int g, rfx_reads* r) {
     if (!r) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
     const int rc = rfx_count_add(tabs[g], r);
     if (rc) die(std::string("rufus_amd: count failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
-    if (defer) resident[(size_t)g].push_back(r);
-    else rfx_reads_free(r);
+    if (defer) {
+      resident[(size_t)g].push_back(r);
+      if (!getenv("RFX_NO_RESERVE")) {
+        uint64_t used = 0, peak = 0, mapped = 0;
+        rfx_ctx* c = n_gpu == 1 ? ctx : ctxs[g];
+        if (rfx_mem_stats(c, &used, &peak, &mapped) == RFX_OK) {
+          const uint64_t want = std::min<uint64_t>(used * 4, 200ull << 30);
+          if (want > reserved[(size_t)g] + (4ull << 30)) {  // (in steps of >= 4 GiB; a refusal is no error: mapped when needed)
+            if (rfx_mem_reserve(c, want) == RFX_OK) reserved[(size_t)g] = want;
+            else reserved[(size_t)g] = ~0ull >> 1;
+          }
+        }
+      }
+    } else {
+      rfx_reads_free(r);
+    }
   };
   // Several devices: block b of packed reads goes to device b mod N -- each device partitions its blocks, the owners of
   // the minimizer bins pull their record runs at finish (rfx_count_set_peers).  RFX_PEERS_REPLICATE=1: round 3's scheme,

@@ -707,6 +707,20 @@ void rfx_host_free(void* p) {
   if (p) (void)hipHostFree(p);
 }
 
+int rfx_mem_reserve(rfx_ctx* c, uint64_t bytes) {
+  if (!c) return RFX_E_INVAL;
+  (void)hipSetDevice(c->device);
+  if (!arena_init(c)) return RFX_OK;  // (no arena: nothing to prepare)
+  if (c->arena_mapped >= bytes) return RFX_OK;
+  size_t tail = 0;
+  if (!c->arena_free.empty()) {
+    auto last = std::prev(c->arena_free.end());
+    if (last->first + last->second == c->arena_mapped) tail = last->second;
+  }
+  // (arena_grow maps so that a free range of `need` bytes ends at the new high-water mark)
+  return arena_grow(c, tail + (size_t)(bytes - c->arena_mapped)) ? RFX_OK : RFX_E_NOMEM;
+}
+
 int rfx_mem_stats(rfx_ctx* c, uint64_t* used, uint64_t* peak, uint64_t* mapped) {
   if (!c) return RFX_E_NODEVICE;
   if (used) *used = c->used;
@@ -924,6 +938,7 @@ void rfx_count_free(rfx_table* t) {
     }
     delete t->segs;
   }
+  if (t->runmaps && t->runmaps_owned) rfx_runmaps_free(t->runmaps);
   if (t->early) {  // early segments nobody adopted
     for (auto& sg : *t->early) {
       dfree(t->ctx, sg.inst);
@@ -1154,6 +1169,54 @@ static void runmaps_release(rfx_runmaps* s, void* p, size_t bytes) {
   s->pool_free[off] = len;
 }
 
+// The run map of read block r in the table's store: the one that is there, or (make) a new one -- ONE hashing launch
+// (k_msp_part1 HMODE 4) + a wait for the number of reads that went without a map.  nullptr: no store, not a block for maps
+// (reads of more than 160 bases), no room, or a failure (*rc set then).
+static rfx_runmap_entry* runmap_get(rfx_table* t, const rfx_reads* r, bool make, int* rc) {
+  rfx_ctx* c = t->ctx;
+  rfx_runmaps* st = t->runmaps;
+  *rc = RFX_OK;
+  if (!st || r->max_len > 160 || r->n == 0 || getenv("RFX_NO_RUNMAP")) return nullptr;
+  auto it = st->m.find(r);
+  if (it != st->m.end()) {
+    rfx_runmap_entry& en = it->second;
+    return en.k == t->k && en.canonical == t->canonical && en.n_reads == r->n && en.codes == r->codes ? &en : nullptr;
+  }
+  if (!make) return nullptr;
+  const uint32_t ovf_cap = r->n / 32 + 4096;
+  const size_t map_bytes = (size_t)r->n * 32, ovf_bytes = ((size_t)ovf_cap + 1) * 4;
+  if (st->budget && st->bytes + map_bytes + ovf_bytes > st->budget) return nullptr;
+  void* map_dev = runmaps_alloc(st, map_bytes);
+  uint32_t* map_ovf = (uint32_t*)runmaps_alloc(st, ovf_bytes);
+  uint32_t n_ovf = 0;
+  bool ok = map_dev && map_ovf && hipMemsetAsync(map_ovf, 0, 4, c->stream) == hipSuccess;
+  if (ok) {
+    rfxk::msp_part1(c, r->view(), t->k, t->canonical, 15, 0, 0, 4, rfxk::msp_map_grid(c, r->n), nullptr, nullptr, 0, nullptr, nullptr, 0,
+                    map_dev, map_ovf, ovf_cap);
+    ok = queue_read(c, &n_ovf, map_ovf, 4) == hipSuccess && ctx_sync(c) == hipSuccess;
+  }
+  if (ok && n_ovf <= ovf_cap) {
+    rfx_runmap_entry en;
+    en.map = map_dev;
+    en.ovf = map_ovf;
+    en.n_ovf = n_ovf;
+    en.n_reads = r->n;
+    en.codes = r->codes;
+    en.k = t->k;
+    en.canonical = t->canonical;
+    en.map_bytes = map_bytes;
+    en.ovf_bytes = ovf_bytes;
+    en.bytes = map_bytes + ovf_bytes;
+    st->bytes += en.bytes;
+    return &(st->m[r] = en);
+  }
+  // no room (or more reads without a map than the list holds): the passes hash the block as before
+  if (map_dev) runmaps_release(st, map_dev, map_bytes);
+  if (map_ovf) runmaps_release(st, map_ovf, ovf_bytes);
+  if (hipGetLastError() != hipSuccess) *rc = RFX_E_HIP;
+  return nullptr;
+}
+
 static bool msp_geometry(rfx_table* t, const rfx_reads* r, msp_geom& g) {
   rfx_ctx* c = t->ctx;
   g.windows = r->windows_of(t->k);
@@ -1313,47 +1376,10 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
     // adds it); every pass, that one included, cuts its records from reads + map.
     rfx_runmap_entry* have = nullptr;
     int G_rep = 0, G_ovf = 0;
-    if (t->runmaps && t->n_shards > 1 && !early && r->max_len <= 160 && g.bin_hi - g.bin_lo <= 16384u &&
-        !getenv("RFX_MSP_REC_HIST") && !getenv("RFX_NO_RUNMAP")) {
-      rfx_runmaps* st = t->runmaps;
-      auto it = st->m.find(r);
-      if (it != st->m.end()) {
-        rfx_runmap_entry& en = it->second;
-        if (en.k == t->k && en.canonical == t->canonical && en.n_reads == r->n && en.codes == r->codes) have = &en;
-      } else {
-        const uint32_t ovf_cap = r->n / 32 + 4096;
-        const size_t map_bytes = (size_t)r->n * 32, ovf_bytes = ((size_t)ovf_cap + 1) * 4;
-        if (!st->budget || st->bytes + map_bytes + ovf_bytes <= st->budget) {
-          void* map_dev = runmaps_alloc(st, map_bytes);
-          uint32_t* map_ovf = (uint32_t*)runmaps_alloc(st, ovf_bytes);
-          uint32_t n_ovf = 0;
-          bool ok = map_dev && map_ovf && hipMemsetAsync(map_ovf, 0, 4, c->stream) == hipSuccess;
-          if (ok) {
-            rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, 0, 0, 4, rfxk::msp_map_grid(c, r->n), nullptr, nullptr, 0, nullptr, nullptr, 0, map_dev,
-                            map_ovf, ovf_cap);
-            ok = queue_read(c, &n_ovf, map_ovf, 4) == hipSuccess && ctx_sync(c) == hipSuccess;
-          }
-          if (ok && n_ovf <= ovf_cap) {
-            rfx_runmap_entry en;
-            en.map = map_dev;
-            en.ovf = map_ovf;
-            en.n_ovf = n_ovf;
-            en.n_reads = r->n;
-            en.codes = r->codes;
-            en.k = t->k;
-            en.canonical = t->canonical;
-            en.map_bytes = map_bytes;
-            en.ovf_bytes = ovf_bytes;
-            en.bytes = map_bytes + ovf_bytes;
-            st->bytes += en.bytes;
-            have = &(st->m[r] = en);
-          } else {  // no room (or more reads without a map than the list holds): the passes hash the block as before
-            if (map_dev) runmaps_release(st, map_dev, map_bytes);
-            if (map_ovf) runmaps_release(st, map_ovf, ovf_bytes);
-            if (hipGetLastError() != hipSuccess) { dfree(c, cur); dfree(c, bin_start); return RFX_E_HIP; }
-          }
-        }
-      }
+    if (t->runmaps && t->n_shards > 1 && !early && g.bin_hi - g.bin_lo <= 16384u && !getenv("RFX_MSP_REC_HIST")) {
+      int mrc = RFX_OK;
+      have = runmap_get(t, r, true, &mrc);
+      if (mrc) { dfree(c, cur); dfree(c, bin_start); return mrc; }
     }
     if (have) {  // (a chunk of 512 reads puts ~90 records into a coarse bin between two turns of the slabs)
       G_rep = rfxk::msp_replay_grid(c, r->n);
@@ -1470,7 +1496,24 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
       return RFX_OK;
     }
   }
-  uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)g.G * P * 4);
+  // (shard passes of a block that has a run map -- the drop-in `jellyfish count` hashes its 4 M-read blocks as they
+  // arrive: rfx_count_add of a table with rfx_count_set_passes -- cut their records from reads + map here too)
+  rfx_runmap_entry* have = nullptr;
+  int G_rep = g.G, G_ovf = 0;
+  if (t->runmaps && t->n_shards > 1 && g.bin_hi - g.bin_lo <= 16384u) {
+    int mrc = RFX_OK;
+    have = runmap_get(t, r, true, &mrc);
+    if (mrc) { dfree(c, cur); dfree(c, bin_start); return mrc; }
+    if (have) {
+      G_rep = rfxk::msp_replay_grid(c, r->n);
+      G_ovf = have->n_ovf ? (int)std::min<uint32_t>(64, ((have->n_ovf + 511) / 512 + 7) & ~7u) : 0;
+      slab_log2 = std::max(slab_log2, 7);
+      cap_a = even + even / 4 + 16384 + rfxk::msp_part1_slack(G_rep + G_ovf, slab_log2);
+      if (cap_a >= (1ull << 32)) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
+    }
+  }
+  const uint32_t rows = (uint32_t)(G_rep + G_ovf);
+  uint32_t* cnt = (uint32_t*)dmalloc(c, (size_t)rows * P * 4);
   char* buf_a = (char*)dmalloc(c, cap_a * g.c_n * 12);  // 12-byte slots: word and plane side by side
   uint64_t* inst = (uint64_t*)dmalloc(c, cap_b * 8);
   uint32_t* ext = (uint32_t*)dmalloc(c, cap_b * 4);
@@ -1481,9 +1524,22 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
   }
   char* buf_a0 = buf_a - (size_t)g.c_lo * cap_a * 12;  // the address coarse bin 0 would have (see msp_partition_exact)
   HIPCHK(hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream));
-  rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur,
-                  slab_log2);
-  rfxk::bin_totals(c, cnt, (uint32_t)g.G, P, bin_start);
+  if (have) {
+    rfxk::msp_replay(c, rv, have->map, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, G_rep, buf_a0, cur, (uint32_t)cap_a, cnt,
+                     cur + g.ncur, slab_log2);
+    if (have->n_ovf) {  // the reads whose runs did not fit a map: hashed as ever
+      rfx_reads_view rvo = rv;
+      rvo.idx = have->ovf + 1;
+      rvo.n = have->n_ovf;
+      rfxk::msp_part1(c, rvo, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, G_ovf, buf_a0, cur, (uint32_t)cap_a,
+                      cnt + (size_t)G_rep * P, cur + g.ncur, slab_log2);
+    }
+    ++t->replayed;
+  } else {
+    rfxk::msp_part1(c, rv, t->k, t->canonical, g.bin_bits, g.bin_lo, g.bin_hi, 0, g.G, buf_a0, cur, (uint32_t)cap_a, cnt, cur + g.ncur,
+                    slab_log2);
+  }
+  rfxk::bin_totals(c, cnt, rows, P, bin_start);
   rfxk::part2(c, (const uint64_t*)buf_a0, inst, bin_start, fine_cur, P2, 32 - g.bin_bits, cur, (uint32_t)cap_a, nullptr, ext, cap_b,
               "k_part2", nullptr, 0, cap_b, g.rec_mode, t->k);
   rfxk::flag_if_gt(c, bin_start + P, cap_b, cur + g.ncur);  // more records than the bin array holds
@@ -2049,25 +2105,27 @@ static int msp_passes_leaf(rfx_finish* f) {
   }
   // S > 1: the first pass leaves run maps (rfx_msp.hip) as far as the device has room beside a pass, the later passes
   // replay them instead of hashing the reads again.  (Sharded peers run one pass per table from two devices on.)
-  struct own_runmaps {
+  struct own_runmaps {  // the table's own store (made by its deferred adds, or here) goes when the passes are over
     rfx_table* t;
-    rfx_runmaps* s = nullptr;
     explicit own_runmaps(rfx_table* t_) : t(t_) {}
-    ~own_runmaps() {
-      if (s) {
+    void drop() {
+      if (t->runmaps && t->runmaps_owned) {
+        rfx_runmaps_free(t->runmaps);
         t->runmaps = nullptr;
-        rfx_runmaps_free(s);
+        t->runmaps_owned = 0;
       }
     }
+    ~own_runmaps() { drop(); }
   } own_maps(t);
+  if (S == 1 || sharded) own_maps.drop();  // (one pass: the fused kernel hashes and cuts at once; the maps were for nothing)
   if (S > 1 && !t->runmaps && !sharded && !getenv("RFX_NO_RUNMAP")) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
     const double avail = 0.88 * ((double)free_b + (double)(c->arena_mapped - std::min(c->arena_mapped, c->used)));
     const double pass = (double)windows * msp_records_per_window(t->k) * 12.0 * 1.05 / (double)outer_n / S + (double)windows / 20.0 * 14.0;
     if (avail - pass > (double)(256u << 20)) {
-      own_maps.s = rfx_runmaps_create(c, (uint64_t)((avail - pass) * 0.8));
-      t->runmaps = own_maps.s;
+      t->runmaps = rfx_runmaps_create(c, (uint64_t)((avail - pass) * 0.8));
+      t->runmaps_owned = t->runmaps != nullptr;
     }
   }
   const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + 2) * 4;
@@ -2612,6 +2670,24 @@ int rfx_count_add(rfx_table* t, const rfx_reads* r) {
   if (t->passes >= 0) {  // rfx_count_set_passes: counted at finish, shard pass by shard pass
     if (r->windows_of(t->k) >= (1ull << 32)) return RFX_E_RANGE;
     t->deferred->push_back(r);
+    // The block is HASHED now -- its run map (rfx_msp.hip) --, while the caller is still parsing input and the device has
+    // nothing to do: if the sample then takes more than one shard pass, the passes only cut records from reads + map
+    // (`jellyfish count` of a 30x sample: 0.3 s less between "input parsed" and "finished on the device").  Maps of up to
+    // an eighth of the device's memory (32 B per read against the 68 of the block itself); one pass: they are dropped unused.
+    if (!t->peers && rfxk::msp_k_ok(t->k) && t->lut_t && (!t->runmaps || t->runmaps_owned) && !getenv("RFX_NO_RUNMAP")) {
+      if (!t->runmaps) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b) {
+          t->runmaps = rfx_runmaps_create(c, total_b / 8);
+          t->runmaps_owned = t->runmaps != nullptr;
+        }
+      }
+      if (t->runmaps) {
+        int mrc = RFX_OK;
+        (void)runmap_get(t, r, true, &mrc);
+        if (mrc) return mrc;
+      }
+    }
     return RFX_OK;
   }
   if (t->mode != RFX_COUNT_TABLE && !t->table_active && t->lut_t) {  // P2L needs 2k <= 62 and full-rank M
@@ -2781,6 +2857,8 @@ int rfx_runmaps_clear(rfx_runmaps* s) {
 
 int rfx_count_set_runmaps(rfx_table* t, rfx_runmaps* s) {
   if (!t || (s && s->ctx != t->ctx)) return RFX_E_INVAL;
+  if (t->runmaps && t->runmaps_owned) rfx_runmaps_free(t->runmaps);
+  t->runmaps_owned = 0;
   t->runmaps = s;
   return RFX_OK;
 }

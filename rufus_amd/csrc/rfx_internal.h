@@ -240,7 +240,8 @@ struct rfx_table {
   // shard s + 1 -- ONE k_msp_part1 launch for both -- into segments kept here until a table of shard s + 1 adopts them
   int early_on;
   std::vector<rfx_segment>* early;
-  rfx_runmaps* runmaps;      // rfx_count_set_runmaps (not owned), or the table's own during its deferred passes
+  rfx_runmaps* runmaps;      // rfx_count_set_runmaps (not owned), or the table's own (deferred adds / passes)
+  int runmaps_owned;
   uint64_t replayed;         // big blocks added from their run map (statistics: rfx_count_replayed)
   uint64_t* lut_t;     // device LUT of T (key -> sortable word), null when M is rank deficient
   uint64_t* lut_tinv;  // device LUT of T^-1

@@ -132,6 +132,9 @@ class WgsTrio:
         self.map_budget = 0
         self._store = None
         self.replayed_blocks = 0    # blocks added by replay in the last run()
+        # bytes of super-k-mer records this rank sent to / received from OTHER ranks in the last run() (the record
+        # exchange of count_shard: RCCL all-to-all over xGMI; what stays on the rank is not counted)
+        self.exchange_sent = self.exchange_received = 0
         if group is not None:
             import torch.distributed as dist
             self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -385,6 +388,9 @@ class WgsTrio:
                 if overlap and i + 1 < len(blocks):
                     helper = _LibraryCall(part.add, blocks[i + 1])
                     helper.start()
+                per_rec = 12 if wide else 8
+                self.exchange_sent += per_rec * (sum(send_l) - send_l[me])
+                self.exchange_received += per_rec * (sum(recv_l) - recv_l[me])
                 exchange_rows(rr, wr, recv_l, send_l, self.group)
                 if wide:
                     exchange_rows(re_, we, recv_l, send_l, self.group)
@@ -524,6 +530,7 @@ class WgsTrio:
             self._drop_early()
             self._early_left = int(self.early_budget) if self.world == 1 and not keep_shard_records else 0
             self.replayed_blocks = 0
+            self.exchange_sent = self.exchange_received = 0
             use_maps = self.map_budget > 0 and self.world == 1 and self.passes > 1 and not keep_shard_records
             if not use_maps:
                 self._drop_store()

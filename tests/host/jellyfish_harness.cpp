@@ -108,6 +108,13 @@ rfx_table* rfx_count_begin(rfx_ctx*, int k, int canonical, int lsize, uint64_t, 
   return t;
 }
 int rfx_count_set_passes(rfx_table*, int) { return RFX_OK; }
+int rfx_mem_stats(rfx_ctx*, uint64_t* used, uint64_t* peak, uint64_t* mapped) {
+  if (used) *used = 0;
+  if (peak) *peak = 0;
+  if (mapped) *mapped = 0;
+  return RFX_OK;
+}
+int rfx_mem_reserve(rfx_ctx*, uint64_t) { return RFX_OK; }
 int rfx_count_set_peers(rfx_table* t, rfx_peers* p, int index) {
   t->peer_index = index;
   t->peer_n = p->n;

@@ -693,6 +693,16 @@ def test_bench_two_ranks_share_the_device(tmp_path):
     assert line["n_gpus"] == 2 and used in line["config"]["one_device_dry_run"]
     for key in ("mutant_kmers", "pulled_pairs", "records_per_sample"):
         assert line["config"][key] == ref["config"][key], key
+    # what the first real multi-GPU run is checked by: every rank's view of the group and the records it exchanged --
+    # half of a rank's super-k-mer records leave for the other rank's bins, as many arrive, and what one sends the other gets
+    mg = line["config"]["multi_gpu"]
+    assert mg["rccl_world_size"] == 2 and [r["rank"] for r in mg["per_rank"]] == [0, 1]
+    assert all(r["rccl_world_size"] == 2 and r["device"] == 0 for r in mg["per_rank"])
+    sent = [r["record_bytes_sent_per_step"] for r in mg["per_rank"]]
+    got = [r["record_bytes_received_per_step"] for r in mg["per_rank"]]
+    assert sent[0] == got[1] and sent[1] == got[0] and min(sent) > 0
+    n_reads = line["config"]["reads_counted_per_step"]
+    assert 0.35 * 264 * n_reads / 2 < sum(sent) / 2 < 0.65 * 264 * n_reads / 2      # ~22 records of 12 B per read, half of them leave
 
 
 def test_every_cut_of_a_count_leaves_the_same_records(ctx):

@@ -310,7 +310,9 @@ def run_wgs(args, ctx, rank, world, dist, torch):
     desc = (f"synthetic {what}: genome {G} bp, {'/'.join(map(str, reads))} x {READ_LEN} bp reads per sample, on each of "
             f"{world} GPU(s) {len(samples[0])} resident blocks of the subject ({resident / 1e9:.0f} GB of packed reads in "
             f"HBM, generated on the device in {t_gen:.1f} s), {n_snv} SNVs, seed {SEED}, k={k}, -s 8G -L {LOWER}, MinCov "
-            f"{MIN_COV}, MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}; {passes} minimizer-shard pass(es) per step")
+            f"{MIN_COV}, MaxHashDepth {MAX_DEPTH}, MinQ {MIN_Q}, thresh {THRESH}; {passes} minimizer-shard pass(es) per step "
+            f"(per-shard (pos,key)-sorted records, struck out shard by shard: no cross-shard payload of a sample is assembled -- "
+            f"the drop-in `jellyfish count` does that, end_to_end)")
     args.k = k
     args.n_samples = len(covs)
     return (step, sum(reads), sum(reads) // len(reads) // world, reads[0], desc, "strong",

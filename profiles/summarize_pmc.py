@@ -43,7 +43,7 @@ def main():
                   "hbm_bytes_per_launch": int((2 * fv + wv) * 1024)}
     # The count -> sorted-records chain of one sample (what bench.py prices against the roofline): every
     # launch between two k_msp_part1 launches that belongs to rfx_count_add / rfx_count_finish.
-    chain = ["k_msp_part1", "k_msp_count", "k_col_sums", "k_bin_group_sums", "k_bin_offsets", "k_scan_tail", "k_part2",
+    chain = ["k_msp_part1", "k_msp_replay", "k_msp_count", "k_col_sums", "k_bin_group_sums", "k_bin_offsets", "k_scan_tail", "k_part2",
              "k_flag_if_gt", "k_slice_tag", "k_bin_hist",
              "k_msp_leaf", "k_surv_hist", "k_surv_sort", "k_histo_bins", "k_bin_count", "k_part1", "k_leaf", "k_leaf_compact",
              "k_bin_scatter", "k_tmp_start"]

@@ -52,6 +52,21 @@ def test_jellyfish_md5_kats():
     assert hashlib.md5(txt.encode()).hexdigest() == "d93b7678037814c256d1d9120a0e6422"
 
 
+def test_jellyfish_md5_kat_of_a_subset_count():
+    """tests/subset_hashing.sh inside jellyfish-2.2.5.tar.gz: `count -m 10 -C --if seq1m_0.fa --if seq1m_2.fa seq1m_1.fa
+    seq1m_0.fa seq1m_3.fa seq1m_2.fa` counts, over the four inputs, only the k-mers that occur in the --if files
+    (jf/sub_commands/count_main.cc: the --if k-mers are loaded with count 0, the counting pass only updates what is
+    there); md5 of its `jellyfish histo`.  (-s 6M asks for more slots than 4^10: jellyfish cuts the table to 2k bits;
+    the histogram does not depend on it.  The script's other line, -m 35, is beyond the 32 bases of a 64-bit key.)"""
+    seq1m = mt_sequence(1040104553, [1_000_000] * 5)
+    everything = oracle.count(None, 10, 1 << 20, reads=[seq1m[1], seq1m[0], seq1m[3], seq1m[2]])
+    subset = oracle.count(None, 10, 1 << 20, reads=[seq1m[0], seq1m[2]])
+    keep = np.isin(everything.keys, subset.keys)
+    assert 0 < int(keep.sum()) < len(everything.keys)
+    txt = oracle.histo(everything.counts[keep])[1]
+    assert hashlib.md5(txt.encode()).hexdigest() == "8eb6d4a50aeba178e4847c2da71dbb70"
+
+
 def test_testrun_count_merge_hashlist(testrun):
     exp = testrun["expected"]
     recs = {}

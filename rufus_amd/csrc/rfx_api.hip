@@ -1798,7 +1798,7 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
       if (chunk) {
         for (size_t si : g.segs)
           rfxk::bin_hist(c, (*t->segs)[si].inst, (*t->segs)[si].bin_start + gp0, gnp, chunk, F1, shift1, rec_mode, t->k,
-                         g.fine1);
+                         g.fine1, (*t->segs)[si].ext);
         rfxk::scan_tail(c, g.fine1, n1);
         if (g.d_seg) {
           const size_t ns = g.segs.size();
@@ -1816,7 +1816,7 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
         uint32_t* fcur2 = (uint32_t*)(g.fine2 + n2 + 1);
         HIPCHK(hipMemsetAsync(g.fine2, 0, (n2 + 1) * 8 + n2 * 4, c->stream));
         if (chunk) {
-          rfxk::bin_hist(c, g.cb1, g.fine1, (uint32_t)n1, chunk, F2, shift2, rec_mode, t->k, g.fine2);
+          rfxk::bin_hist(c, g.cb1, g.fine1, (uint32_t)n1, chunk, F2, shift2, rec_mode, t->k, g.fine2, g.ce1);
           rfxk::scan_tail(c, g.fine2, n2);
           rfxk::part2(c, g.cb1, g.cb2, g.fine2, fcur2, F2, shift2, nullptr, 0, g.ce1, g.ce2, ~0ull, "k_part4", g.fine1,
                       (uint32_t)n1, 0, rec_mode, t->k);

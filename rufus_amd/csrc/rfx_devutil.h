@@ -92,6 +92,21 @@ __device__ __forceinline__ uint64_t revcomp_bases(uint64_t s, int nbases) {
 // Until round 3 a record held <= 4 k-mers (8 bytes for k <= 25: 42 records per 150 bp read, 336 B; now 22, 264 B).
 __device__ __forceinline__ int msp_record_n(uint64_t x) { return (int)(x >> 60) + 1; }
 
+// k <= 25: a run has at most 35 bases, the plane at most 14 bits -- bits 14 .. 29 carry 16 bits of the record's minimizer
+// bin hash (bits 3 .. 18), stamped where the record is made.  The refinement's sizing pass (k_bin_hist) then reads the
+// 4-byte planes instead of the 8-byte words and hashes nothing: half its bytes (27 -> 14 ms per W sample).  The leaf
+// masks the stamp off (msp_plane_bits); every partition level moves the plane untouched.
+constexpr int MSP_STAMP_SHIFT = 14, MSP_STAMP_LO = 3, MSP_STAMP_BITS = 16;
+__host__ __device__ __forceinline__ bool msp_stamped(int k) { return k <= 25; }
+__device__ __forceinline__ uint32_t msp_stamp(uint32_t binhash, int k) {
+  return msp_stamped(k) ? ((binhash >> MSP_STAMP_LO) & ((1u << MSP_STAMP_BITS) - 1u)) << MSP_STAMP_SHIFT : 0u;
+}
+__device__ __forceinline__ uint32_t msp_plane_bits(uint32_t xe, int k) { return msp_stamped(k) ? xe & ((1u << MSP_STAMP_SHIFT) - 1u) : xe; }
+// (binhash >> shift) & (P2 - 1) from a stamped plane; usable when MSP_STAMP_LO <= shift and shift + log2(P2) <= 19
+__device__ __forceinline__ uint32_t msp_stamp_sub(uint32_t xe, int shift, uint32_t P2) {
+  return (xe >> (MSP_STAMP_SHIFT + shift - MSP_STAMP_LO)) & (P2 - 1);
+}
+
 // The COARSE bins k_msp_part1 fills hold word and plane side by side, 12 bytes: one store per record.  The kernel is
 // bound by how many lane-stores the memory pipeline takes (every record goes to another line: 2.5 cycles per lane-store
 // and CU, measured) -- with two arrays the stores were 38 % of it.  k_part2 reads them back as 12-byte loads (a wave's

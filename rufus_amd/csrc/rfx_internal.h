@@ -378,7 +378,8 @@ void part2_multi(rfx_ctx*, const uint64_t* const* seg_a, const uint64_t* const* 
                  uint32_t* fine_cur, uint32_t P2, int shift2, uint32_t* pay_b, int rec_mode, int k, const char* span);
 // sizes of the P2 sub-bins of every parent bin: fine_tot[parent * P2 + sub] += ...
 void bin_hist(rfx_ctx*, const uint64_t* src, const uint64_t* parent_start, uint32_t n_parents, uint64_t n_hint,
-              uint32_t P2, int shift2, int rec_mode, int k, uint64_t* fine_tot);
+              uint32_t P2, int shift2, int rec_mode, int k, uint64_t* fine_tot,
+              const uint32_t* ext = nullptr /* the records' planes: k <= 25, they carry the bin-hash bits (rfx_devutil.h msp_stamp) */);
 // MSP path (rfx_msp.hip)
 int msp_k_ok(int k);
 int msp_part1_block();  // threads = reads per chunk of k_msp_part1

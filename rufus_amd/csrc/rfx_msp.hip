@@ -156,7 +156,9 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
       uint32_t x;
       msp_record_make(h64, meta & 0x3FFFFFu, k, n, (uint32_t)(k + n - 1 - m) - back, w, x);
       // the bin, from the record: the same bits msp_bin(run_h) gave when the lane decided the run was this shard's
-      const uint32_t run_bin = msp_record_binhash<CANON>(w, k) >> (32 - bin_bits);
+      const uint32_t bh = msp_record_binhash<CANON>(w, k);
+      x |= msp_stamp(bh, k);
+      const uint32_t run_bin = bh >> (32 - bin_bits);
       const uint32_t coarse = run_bin >> sub_bits;
       const uint32_t slot = atomicAdd(&s_fill[coarse], 1u);
       if (slot < 2 * SLAB) {  // (a bin of ours always has a slab behind it: slab_at)
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
                 const uint32_t coarse = run_bin >> sub_bits;
                 const uint32_t mpos = (uint32_t)(L - m) - ((e - run_h) & 31u);
                 msp_record_make((hist >> sh) | (hist_hi << (64 - sh)), (uint32_t)(hist_hi >> sh), k, n, mpos, wv[b], xv[b]);
+                xv[b] |= msp_stamp(msp_binhash(run_h), k);
                 br[b] = (coarse << 16) | atomicAdd(&s_cnt[X][coarse], 1u);
               }
               if (HMODE == 1) atomicAdd(&s_fine[run_bin], 1u);
@@ -691,7 +694,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_replay(rfx_reads_view rv, con
         for (int j = 0; j < 4; ++j) d[u][j] = rd[dw + j];  // (past the read: the entries, never used -- 2L bits are)
       }
       uint64_t lo[2];
-      uint32_t run_bin[2], slot[2];
+      uint32_t run_bin[2], slot[2], bh[2];
       bool put[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -706,7 +709,8 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_replay(rfx_reads_view rv, con
           y = ((y & 0xAAAAAAAAu) >> 1) | ((y & 0x55555555u) << 1);
           c = min(f, y >> (32 - 2 * m));
         }
-        run_bin[u] = msp_binhash(mmer_hash(c)) >> (32 - bin_bits);
+        bh[u] = msp_binhash(mmer_hash(c));
+        run_bin[u] = bh[u] >> (32 - bin_bits);
         put[u] = on[u] && run_bin[u] - bin_lo < bin_hi - bin_lo;  // (more than two passes: the half says little, the bin everything)
         slot[u] = put[u] ? atomicAdd(&s_fill[run_bin[u] >> sub_bits], 1u) : 0u;
       }
@@ -719,6 +723,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_replay(rfx_reads_view rv, con
           uint64_t w;
           uint32_t x;
           msp_record_make(lo[u], hi, k, n, (uint32_t)(k + n - 1 - m) - back, w, x);
+          x |= msp_stamp(bh[u], k);
           const uint32_t coarse = run_bin[u] >> sub_bits;
           if (slot[u] < 2 * SLAB) {
             const uint64_t sb = s_slab[slot[u] >> slab_log2][coarse];
@@ -785,7 +790,10 @@ __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
 constexpr uint32_t MSP_LEAF_PASS_MAX(int geo) { return (geo ? 4096u : 8192u) * 3 / 4 + (geo ? 512u : 1024u); }
 // survivors a workgroup stages before it scatters them (big inputs): room for 5120 / 9216 + one pass
 constexpr uint32_t MSP_LEAF_STAGE(int geo) { return (geo ? 5120u : 9216u) + MSP_LEAF_PASS_MAX(geo); }
-constexpr int MSP_ILP = 4;        // records a lane loads before its first probe (a bin holds ~3 per lane)
+#ifndef MSP_ILP_OVERRIDE
+#define MSP_ILP_OVERRIDE 4
+#endif
+constexpr int MSP_ILP = MSP_ILP_OVERRIDE;  // records a lane loads before its first probe (a bin holds ~3 per lane)
 #ifndef RFX_RC_PROBES
 #define RFX_RC_PROBES 16
 #endif
@@ -850,15 +858,23 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
   uint64_t pre[MSP_ILP];
   uint32_t prex[MSP_ILP];
   uint64_t pre_a = 0, pre_e = 0;
+  // The extents of a bin are fetched one bin earlier than its records (round 5): prefetch() used to load bs0[b] and wait
+  // for it before it could issue the record loads -- an exposed round trip to memory per bin (~6 % of the kernel; that
+  // the leaf feels such waits showed when a mask applied to the prefetched planes at load time cost 7 %).
+  uint64_t nx_a = blockIdx.x < P ? bs0[blockIdx.x] : 0, nx_e = blockIdx.x < P ? bs0[blockIdx.x + 1] : 0;
   auto prefetch = [&](uint32_t b) {
     if (b >= P) return;
-    pre_a = bs0[b];
-    pre_e = bs0[b + 1];
+    pre_a = nx_a;
+    pre_e = nx_e;
+    if (b + gridDim.x < P) {  // (used by the next prefetch: nobody waits for these here)
+      nx_a = bs0[b + gridDim.x];
+      nx_e = bs0[b + gridDim.x + 1];
+    }
 #pragma unroll
     for (int u = 0; u < MSP_ILP; ++u) {
       const uint64_t i = pre_a + threadIdx.x + (uint64_t)u * BLK;
       pre[u] = i < pre_e ? inst0[i] : MSP_EMPTY;
-      prex[u] = i < pre_e ? ext0[i] : 0u;
+      prex[u] = i < pre_e ? ext0[i] : 0u;  // (the stamp is masked off where the plane is used: here it would wait for the load)
     }
   };
   prefetch(blockIdx.x);
@@ -1032,7 +1048,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
 #pragma unroll
           for (int u = 0; u < MSP_ILP; ++u) {
             const uint64_t x = rec[u];
-            const uint32_t xe = recx[u];
+            const uint32_t xe = msp_plane_bits(recx[u], k);
             if (x == MSP_EMPTY) continue;
             uint32_t h = (uint32_t)x ^ (uint32_t)(x >> 23) ^ (uint32_t)(x >> 41) ^ (xe * 0x85EBCA6Bu);
             h *= 0x9E3779B1u;

@@ -364,6 +364,39 @@ __global__ __launch_bounds__(512) void k_bin_hist(const uint64_t* __restrict__ s
   }
 }
 
+// The same from the records' STAMPED planes (rfx_devutil.h msp_stamp: k <= 25): 4 bytes per record instead of 8, no hash.
+__global__ __launch_bounds__(512) void k_bin_hist_stamp(const uint32_t* __restrict__ ext, const uint64_t* __restrict__ ps,
+                                                         uint32_t n_parents, uint32_t W, uint32_t P2, int shift2,
+                                                         unsigned long long* __restrict__ fine_tot) {
+  __shared__ uint32_t s_cnt[256];
+  for (uint32_t blk = blockIdx.x; blk < n_parents * W; blk += gridDim.x) {
+    const uint32_t b = blk / W, j = blk - b * W;
+    const uint64_t a = ps[b], e = ps[b + 1];
+    if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    // four planes per load (a dwordx4 needs no more than the 4-byte alignment it has), two loads in flight per lane
+    const uint64_t stride = (uint64_t)W * blockDim.x * 4;
+    uint64_t i = a + ((uint64_t)j * blockDim.x + threadIdx.x) * 4;
+    for (; i + stride + 4 <= e; i += 2 * stride) {
+      const uint4 v0 = *(const uint4*)(ext + i), v1 = *(const uint4*)(ext + i + stride);
+      atomicAdd(&s_cnt[msp_stamp_sub(v0.x, shift2, P2)], 1u);
+      atomicAdd(&s_cnt[msp_stamp_sub(v0.y, shift2, P2)], 1u);
+      atomicAdd(&s_cnt[msp_stamp_sub(v0.z, shift2, P2)], 1u);
+      atomicAdd(&s_cnt[msp_stamp_sub(v0.w, shift2, P2)], 1u);
+      atomicAdd(&s_cnt[msp_stamp_sub(v1.x, shift2, P2)], 1u);
+      atomicAdd(&s_cnt[msp_stamp_sub(v1.y, shift2, P2)], 1u);
+      atomicAdd(&s_cnt[msp_stamp_sub(v1.z, shift2, P2)], 1u);
+      atomicAdd(&s_cnt[msp_stamp_sub(v1.w, shift2, P2)], 1u);
+    }
+    for (; i < e; i += stride)
+      for (uint64_t q = i; q < i + 4 && q < e; ++q) atomicAdd(&s_cnt[msp_stamp_sub(ext[q], shift2, P2)], 1u);
+    __syncthreads();
+    if (threadIdx.x < P2 && s_cnt[threadIdx.x])
+      atomicAdd(&fine_tot[(uint64_t)b * P2 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    __syncthreads();
+  }
+}
+
 // Coarse bin cb of A -> its P2 fine bins in B.  W workgroups share a coarse bin (tiles strided).
 // PAYLOAD: every word carries a 32-bit count that moves with it (survivors of the MSP leaf).
 // MULTI: coarse bin cb is the concatenation of its slices in nseg arrays (the read blocks of a sample, each partitioned
@@ -945,7 +978,7 @@ void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* f
 }
 
 void bin_hist(rfx_ctx* c, const uint64_t* src, const uint64_t* parent_start, uint32_t n_parents, uint64_t n_hint,
-              uint32_t P2, int shift2, int rec_mode, int k, uint64_t* fine_tot) {
+              uint32_t P2, int shift2, int rec_mode, int k, uint64_t* fine_tot, const uint32_t* ext) {
   rfx_span sp(c, "k_bin_hist");
   if (!n_parents) return;
   const uint32_t resident = (uint32_t)c->n_cu * 4;
@@ -953,6 +986,13 @@ void bin_hist(rfx_ctx* c, const uint64_t* src, const uint64_t* parent_start, uin
   const uint64_t per = n_hint / n_parents / 2048 + 1;  // a workgroup should see a few thousand entries
   if (W > per) W = (uint32_t)per;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)n_parents * W, (uint64_t)resident * 8);
+  // super-k-mer records whose planes carry bits 3 .. 18 of the bin hash (k <= 25), when those are the bits asked for
+  if (rec_mode != 0 && ext && msp_stamped(k) && shift2 >= MSP_STAMP_LO && shift2 + (32 - __builtin_clz(P2 - 1 ? P2 - 1 : 1)) <= MSP_STAMP_LO + MSP_STAMP_BITS &&
+      !getenv("RFX_NO_STAMP_HIST")) {
+    hipLaunchKernelGGL(k_bin_hist_stamp, dim3(grid), dim3(512), 0, c->stream, ext, parent_start, n_parents, W, P2, shift2,
+                       (unsigned long long*)fine_tot);
+    return;
+  }
 #define RFX_BH(MODE)                                                                                               \
   hipLaunchKernelGGL(k_bin_hist<MODE>, dim3(grid), dim3(512), 0, c->stream, src, parent_start, n_parents, W, P2, shift2, \
                      k, (unsigned long long*)fine_tot)

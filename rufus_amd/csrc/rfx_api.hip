@@ -1180,7 +1180,13 @@ static rfx_runmap_entry* runmap_get(rfx_table* t, const rfx_reads* r, bool make,
   auto it = st->m.find(r);
   if (it != st->m.end()) {
     rfx_runmap_entry& en = it->second;
-    return en.k == t->k && en.canonical == t->canonical && en.n_reads == r->n && en.codes == r->codes ? &en : nullptr;
+    if (en.k == t->k && en.canonical == t->canonical && en.n_reads == r->n && en.codes == r->codes)
+      return en.map ? &en : nullptr;  // (no map: the block was tried and is no block for one -- nobody tries again)
+    // the entry of ANOTHER block that lived at this address (or of another k): gone
+    runmaps_release(st, en.map, en.map_bytes);
+    runmaps_release(st, en.ovf, en.ovf_bytes);
+    st->bytes -= std::min<uint64_t>(st->bytes, en.bytes);
+    st->m.erase(it);
   }
   if (!make) return nullptr;
   const uint32_t ovf_cap = r->n / 32 + 4096;
@@ -1214,6 +1220,14 @@ static rfx_runmap_entry* runmap_get(rfx_table* t, const rfx_reads* r, bool make,
   if (map_dev) runmaps_release(st, map_dev, map_bytes);
   if (map_ovf) runmaps_release(st, map_ovf, ovf_bytes);
   if (hipGetLastError() != hipSuccess) *rc = RFX_E_HIP;
+  if (ok && n_ovf > ovf_cap) {  // (its reads fall into more runs than a map holds: remembered, so that no later pass hashes it for nothing)
+    rfx_runmap_entry none;
+    none.n_reads = r->n;
+    none.codes = r->codes;
+    none.k = t->k;
+    none.canonical = t->canonical;
+    st->m[r] = none;
+  }
   return nullptr;
 }
 
@@ -2838,7 +2852,12 @@ void rfx_runmaps_free(rfx_runmaps* s) {
 }
 
 uint64_t rfx_runmaps_bytes(const rfx_runmaps* s) { return s ? s->bytes : 0; }
-int rfx_runmaps_blocks(const rfx_runmaps* s) { return s ? (int)s->m.size() : 0; }
+int rfx_runmaps_blocks(const rfx_runmaps* s) {
+  int n = 0;
+  if (s)
+    for (auto& kv : s->m) n += kv.second.map != nullptr;
+  return n;
+}
 
 int rfx_runmaps_drop(rfx_runmaps* s, const rfx_reads* r) {
   if (!s || !r) return RFX_E_INVAL;

@@ -948,3 +948,37 @@ def test_run_map_on_ragged_reads_matches_oracle(ctx, monkeypatch, k):
     rec.free()
     t.free()
     blk.free()
+
+
+def test_a_block_whose_reads_do_not_fit_run_maps_is_hashed_by_every_pass(ctx, monkeypatch):
+    """Short tandem repeats cut a read into more super-k-mers than a run map's 27 entries hold (equal m-mer hashes: the
+    minimizer moves with every base).  A block of such reads puts more of them on the list of reads without a map than
+    the list holds -- the map is dropped and every shard pass hashes the block as before; a block with a few of them keeps
+    its map and the listed reads go through the ordinary kernel beside every replay.  The oracle's payload either way."""
+    monkeypatch.setenv("RFX_P2L_BINS", "32768")
+    rng = np.random.default_rng(77)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    units = [bytes(acgt[rng.integers(0, 4, int(rng.integers(1, 7)))]) for _ in range(400)]
+    repeats = [(u * 160)[:150] for u in units for _ in range(50)]                 # 20 000 reads, all of them beyond a map
+    genome = acgt[rng.integers(0, 4, 50_000)]
+    plain = [genome[p:p + 150].tobytes() for p in rng.integers(0, len(genome) - 150, 30_000)]
+    for reads, expect_replay in ((repeats, False), (plain + repeats[:600], True)):
+        ref = oracle.count(None, K, SIZE, lower=LOWER, reads=reads)
+        blk = ctx.upload(capi.PackedReads.from_reads(reads))
+        ctx.prof(True)
+        ctx.prof_reset()
+        t = capi.CountTable(ctx, K, SIZE)
+        t.set_passes(2)
+        t.add(blk)
+        rec = t.finish(LOWER)
+        prof = ctx.prof_dict()
+        ctx.prof(False)
+        assert rec.payload() == ref.payload()
+        assert prof["k_msp_map"][1] == 1                                            # hashed once for its map ..
+        if expect_replay:                                                           # .. which holds: two replays, the listed reads beside them
+            assert prof["k_msp_replay"][1] == 2 and prof["k_msp_part1"][1] == 2
+        else:                                                                       # .. which is dropped: two ordinary passes
+            assert "k_msp_replay" not in prof and prof["k_msp_part1"][1] >= 2
+        rec.free()
+        t.free()
+        blk.free()

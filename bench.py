@@ -159,10 +159,10 @@ def end_to_end(n_pairs=32_000_000):
     d = tempfile.mkdtemp(prefix="rfx_e2e_", dir=base)
     out = {"reads_per_sample": 2 * n_pairs, "threads": int(T), "stages_s": {}}
 
-    def run(name, args, stdout=None, stdin=None):
+    def run(name, args, stdout=None, stdin=None, env=None):
         t0 = time.perf_counter()
         p = subprocess.run(args, cwd=d, stdout=open(os.path.join(d, stdout), "wb") if stdout else subprocess.DEVNULL,
-                           stderr=subprocess.PIPE, stdin=stdin, timeout=900)
+                           stderr=subprocess.PIPE, stdin=stdin, timeout=900, env=dict(os.environ, **env) if env else None)
         if p.returncode != 0:
             raise RuntimeError(f"{name}: rc {p.returncode}: {p.stderr.decode()[-300:]}")
         if os.environ.get("RFX_CLI_TRACE"):            # the tools' phase marks, for whoever asked for them
@@ -182,9 +182,15 @@ def end_to_end(n_pairs=32_000_000):
         t0 = time.perf_counter()
         for name in ("child", "mother", "father"):
             files = ["c.m1.fq", "c.m2.fq"] if name == "child" else [f"{name}.fq"]   # (the filter wants the mates apart)
+            # RFX_COUNT_HISTO=1: the count also leaves NAME.Jhash.histo -- the bytes of `jellyfish histo -f` --,
+            # and scripts/RunJellyForRUFUS.sh:36-38 runs histo only `if [ ! -s $GEN.Jhash.histo ]`: so does this leg
             run("jellyfish count", [f"{B}/jellyfish", "count", "--disk", "-m", str(K), "-L", str(LOWER), "-s", "8G", "-t", T,
-                                    "-o", f"{name}.Jhash", "-C"] + files)
-            run("jellyfish histo", [f"{B}/jellyfish", "histo", "-f", "-o", f"{name}.Jhash.histo", f"{name}.Jhash"])
+                                    "-o", f"{name}.Jhash", "-C"] + files, env={"RFX_COUNT_HISTO": "1"})
+            hp = os.path.join(d, f"{name}.Jhash.histo")
+            if not (os.path.exists(hp) and os.path.getsize(hp) > 0):
+                run("jellyfish histo", [f"{B}/jellyfish", "histo", "-f", "-o", f"{name}.Jhash.histo", f"{name}.Jhash"])
+            else:
+                out["histo"] = "written by jellyfish count (RFX_COUNT_HISTO=1): RunJellyForRUFUS.sh:36 skips its own histo run then"
         run("jellyfish merge", [f"{B}/jellyfish", "merge", "child.Jhash", "mother.Jhash", "father.Jhash"], stdout="merge.txt")
         t1 = time.perf_counter()
         with open(os.path.join(d, "merge.txt")) as f, open(os.path.join(d, "q.fa"), "w") as q:

@@ -787,13 +787,22 @@ __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
 
 // Distinct keys a counting pass can end with WITHOUT being void: a thread looks at the count before every insert, so up to
 // one key per thread can follow the limit FILL - 1 (see insert_fwd) -- and with lower = 1 every one of them is a survivor.
-constexpr uint32_t MSP_LEAF_PASS_MAX(int geo) { return (geo ? 4096u : 8192u) * 3 / 4 + (geo ? 512u : 1024u); }
+// Threads of the half-size leaf workgroup (GEO 1).  Round 5: 768, not 512 -- the 79 KB of LDS tables allow two workgroups
+// per CU whatever their size, so 2 x 12 waves (six per SIMD: 76 VGPRs fit) hide more of each other's LDS round trips than
+// 2 x 8, and a bin's ~1630 records are three per lane instead of four (phase A is a chain of one probe loop per record).
+// 1 Gb slice, ms per sample: 512 / 640 / 768 / 896 / 1024 threads = 87 / 128 / 78 / 115 / 80 (640 and 896 split their
+// waves unevenly over the four SIMDs; 1024 needs 64 VGPRs and spills).
+#ifndef RFX_LEAF_BLK
+#define RFX_LEAF_BLK 768
+#endif
+constexpr uint32_t MSP_LEAF_BLK(int geo) { return geo ? (uint32_t)RFX_LEAF_BLK : 1024u; }
+constexpr uint32_t MSP_LEAF_PASS_MAX(int geo) { return (geo ? 4096u : 8192u) * 3 / 4 + MSP_LEAF_BLK(geo); }
 // survivors a workgroup stages before it scatters them (big inputs): room for 5120 / 9216 + one pass
 constexpr uint32_t MSP_LEAF_STAGE(int geo) { return (geo ? 5120u : 9216u) + MSP_LEAF_PASS_MAX(geo); }
 #ifndef MSP_ILP_OVERRIDE
-#define MSP_ILP_OVERRIDE 4
+#define MSP_ILP_OVERRIDE 3
 #endif
-constexpr int MSP_ILP = MSP_ILP_OVERRIDE;  // records a lane loads before its first probe (a bin holds ~3 per lane)
+constexpr int MSP_ILP = MSP_ILP_OVERRIDE;  // records a lane loads before its first probe (a bin holds ~2 per lane of 768, 1.6 of 1024)
 #ifndef RFX_RC_PROBES
 #define RFX_RC_PROBES 16
 #endif
@@ -823,7 +832,11 @@ constexpr uint32_t MSP_RC_UNLISTED = 0x80000000u;  // record cache count: the re
 // A bin (or part of it) whose distinct k-mers overflow the table is split in two by a hash bit and each half retried.
 // GEO 0: one 1024-thread workgroup per CU (8192-slot table); GEO 1: half of everything, two workgroups per CU.
 template <bool CANON, int GEO>
-__global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
+#ifdef RFX_LEAF_WPE  // experiment: waves per SIMD the compiler must make room for (registers)
+__global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) __attribute__((amdgpu_waves_per_eu(RFX_LEAF_WPE, RFX_LEAF_WPE))) void k_msp_leaf(
+#else
+__global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) void k_msp_leaf(
+#endif
     const uint64_t* const* __restrict__ seg_inst, const uint64_t* const* __restrict__ seg_bs, int nseg,
     const uint64_t* __restrict__ inst0, const uint64_t* __restrict__ bs0, const uint32_t* const* __restrict__ seg_ext,
     const uint32_t* __restrict__ ext0, uint32_t P, int k,
@@ -831,7 +844,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
     uint64_t lower, uint64_t upper, uint64_t* __restrict__ out_w, uint32_t* __restrict__ out_c,
     uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err,
     uint64_t* __restrict__ stage_k, uint32_t* __restrict__ stage_c, uint32_t CH, int force_mixed) {
-  constexpr int TBL_LOG2 = GEO ? 12 : 13, TBL = 1 << TBL_LOG2, BLK = GEO ? 512 : 1024, FILL = TBL * 3 / 4;
+  constexpr int TBL_LOG2 = GEO ? 12 : 13, TBL = 1 << TBL_LOG2, BLK = (int)MSP_LEAF_BLK(GEO), FILL = TBL * 3 / 4;
   static_assert(MSP_LEAF_PASS_MAX(GEO) >= (uint32_t)(FILL + BLK) && FILL + BLK <= TBL, "what a pass can leave behind fits the chunk and the table");
   constexpr int RC_LOG2 = TBL_LOG2 - (GEO ? RFX_RC_SHRINK : 2), RC = 1 << RC_LOG2, KMAP = TBL;
   static_assert(RC <= 8192, "a k-mer map entry is slot << 3 | pair in 16 bits");
@@ -1095,6 +1108,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         prefetch(bin + gridDim.x);
         prefetched_next = true;
       }
+      TM(16);  // (-DRFX_TIMING: what follows up to the next probe is the wait at the barrier)
       __syncthreads();
       TM(9);
       // ---- B: two k-mers per lane ----
@@ -1124,6 +1138,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
           }
         }
       }
+      TM(17);  // (-DRFX_TIMING: what follows up to the next probe is the wait at the barrier)
       __syncthreads();
       TM(11);
       // (the pass is void: once more, without the cache.  force_mixed -- RFX_LEAF_FORCE_MIXED, a test knob: the recount
@@ -1153,6 +1168,7 @@ __global__ __launch_bounds__(GEO ? 512 : 1024) void k_msp_leaf(
         s_rmin[i] = ~0u;
         s_rmax[i] = 0;
       }
+      TM(18);  // (-DRFX_TIMING: what follows up to the next probe is the wait at the barrier)
       __syncthreads();
       TM(12);
       used += s_ns[X];
@@ -1411,7 +1427,7 @@ void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const
   rfx_span sp(c, "k_msp_leaf");
   const int force_mixed = getenv("RFX_LEAF_FORCE_MIXED") != nullptr;
 #define RFX_MSP_LEAF(CANON, GEO)                                                                                        \
-  hipLaunchKernelGGL((k_msp_leaf<CANON, GEO>), dim3(grid), dim3(GEO ? 512 : 1024), 0, c->stream, seg_inst, seg_bs, nseg, \
+  hipLaunchKernelGGL((k_msp_leaf<CANON, GEO>), dim3(grid), dim3(MSP_LEAF_BLK(GEO)), 0, c->stream, seg_inst, seg_bs, nseg, \
                      inst0, bs0, seg_ext, ext0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w,  \
                      out_c, cur, cap, flag, err, stage_k, stage_c, chunk, force_mixed)
   if (canonical) {

@@ -29,4 +29,7 @@ for name, d in (("k_msp_part1", p1), ("k_msp_leaf", lf)):
     print(name)
     for k_, x in d.items():
         print(f"   {k_:32s} {x:16d}  {100.0 * x / tot:5.1f} %")
+tot = sum(lf.values()) + v[16] + v[17] + v[18] or 1
+print("   wave 0: A %.1f %% + wait %.1f %%, B %.1f %% + wait %.1f %%, C %.1f %% + wait %.1f %%, flush %.1f %%" % tuple(
+    100.0 * x / tot for x in (v[16], v[9], v[17], v[11], v[18], v[12], v[13])))
 print("leaf rounds", v[21], "overflowed", v[20], "records", v[22], "uncached", v[23], "mixed", v[24])

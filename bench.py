@@ -432,9 +432,24 @@ def main():
                     extra["early_cut_budget_bytes"] = head
                 else:
                     # the pool holds two samples' maps (WgsTrio.run orders the passes so that no more are alive)
-                    per_sample = max(sum(((b.n * 32 + 255) & ~255) + ((b.n // 32 + 4097) * 4 + 255 & ~255) for b in s_)
-                                     for s_ in extra["_samples"])
-                    pool = min(head, 2 * per_sample + (1 << 20))
+                    sizes = sorted((sum(((b.n * 32 + 255) & ~255) + ((b.n // 32 + 4097) * 4 + 255 & ~255) for b in s_)
+                                    for s_ in extra["_samples"]), reverse=True)
+                    need = sum(sizes[:2]) + (1 << 20)
+                    # When the maps do not fit beside S passes, S + 1 passes with every block mapped beat S passes with some
+                    # blocks hashed S times (configs[4]: 3 passes 576 M reads/s, 4 passes 608 M): one more pass if ITS
+                    # transients (estimated: they shrink like S / (S + 1)) leave the room.
+                    S = extra["passes"]
+                    if head < 0.75 * need and not args.passes and S < 16:      # (a few blocks without a map: not worth a pass)
+                        st = ctx.mem_stats()
+                        peak1 = st["used"] + (st["peak"] - st["used"]) * S // (S + 1)
+                        head1 = int(frac * min(extra["hbm_total"], extra["hbm_free_at_start"])) - int(peak1)
+                        if head1 >= 0.85 * need:
+                            extra["_trio"].passes = S + 1
+                            extra["passes"] = S + 1
+                            extra["passes_note"] = f"{S} passes fit the records; {S + 1} leave room for every block's run map"
+                            desc = desc.replace(f"; {S} minimizer-shard pass(es) per step", f"; {S + 1} minimizer-shard pass(es) per step")
+                            head = head1
+                    pool = min(head, need)
                     extra["_trio"].map_budget = pool
                     extra["run_map_budget_bytes"] = pool
     live_all = args.workload != "s1"

@@ -23,6 +23,7 @@ super-k-mer records, the records travel to the owner of their minimizer bin (RCC
 owners count complete bins; histograms all-reduce, mutant k-mers all-gather, every rank filters its blocks.
 """
 import argparse
+import filecmp
 import json
 import os
 import subprocess
@@ -214,6 +215,45 @@ def end_to_end(n_pairs=32_000_000):
         out["mutant_kmers"] = n_hl
         out["count_to_filter_s"] = round(t_path, 2)
         out["value"] = 3 * 2 * n_pairs / t_path
+        # ---- runRufus.sh -pj (--Parallelize_Jelly, runRufus.sh:305,766-782): the three RunJellyForRUFUS.sh at once, each
+        # with its share of the threads; here the three drop-in counts share the one GPU (samples of this size fit side by side;
+        # a full-size trio wants a device each: RUFUS_GPUS).  Reported beside `value`, never instead of it.
+        # (runRufus.sh:769 gives each Threads / 3; Threads = the CPUs this container may use, cgroup quota included)
+        tj = os.environ.get("RFX_E2E_PJ_T") or str(max(1, int(capi.lib().rfx_host_cpus()) // 3))
+        t1 = time.perf_counter()
+        procs = []
+        for name in ("child", "mother", "father"):
+            files = ["c.m1.fq", "c.m2.fq"] if name == "child" else [f"{name}.fq"]
+            procs.append((name, subprocess.Popen(
+                [f"{B}/jellyfish", "count", "--disk", "-m", str(K), "-L", str(LOWER), "-s", "8G", "-t", tj, "-o", f"pj.{name}.Jhash",
+                 "-C"] + files, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=dict(os.environ, RFX_COUNT_HISTO="1"))))
+        outs = [(name, p, p.communicate(timeout=900)[1]) for name, p in procs]
+        errs = [(name, p.returncode, e) for name, p, e in outs if p.returncode != 0]
+        t_pj = time.perf_counter() - t1
+        if os.environ.get("RFX_CLI_TRACE"):
+            for name, p, e in outs:
+                sys.stderr.write(f"--- jellyfish count (-pj) {name}\n" + e.decode())
+        if errs:
+            raise RuntimeError(f"jellyfish count (-pj) {errs[0][0]}: rc {errs[0][1]}: {errs[0][2].decode()[-300:]}")
+        for name in ("child", "mother", "father"):
+            if not filecmp.cmp(os.path.join(d, name + ".Jhash.histo"), os.path.join(d, "pj." + name + ".Jhash.histo"), shallow=False):
+                raise RuntimeError(f"-pj: {name}.Jhash.histo differs from the one-at-a-time count's")
+            with open(os.path.join(d, name + ".Jhash"), "rb") as fa, open(os.path.join(d, "pj." + name + ".Jhash"), "rb") as fb:
+                for f in (fa, fb):                     # (the header holds argv and the time of day: payloads are compared)
+                    f.seek(9 + int(f.read(9)))
+                while True:
+                    a, b = fa.read(1 << 26), fb.read(1 << 26)
+                    if a != b:
+                        raise RuntimeError(f"-pj: the records of {name}.Jhash differ from the one-at-a-time count's")
+                    if not a:
+                        break
+            os.unlink(os.path.join(d, f"pj.{name}.Jhash"))
+        t_seq = out["stages_s"]["jellyfish count"]
+        out["parallel_jelly"] = {"flag": "runRufus.sh -pj: the three counts at once, -t " + tj + " each, one GPU shared",
+                                 "jellyfish count x 3_s": round(t_pj, 3),
+                                 "count_to_filter_s": round(t_path - t_seq + t_pj, 2),
+                                 "value": 3 * 2 * n_pairs / (t_path - t_seq + t_pj),
+                                 "outputs": "records and .histo byte-identical to the one-at-a-time files"}
         out["unit"] = "reads/s (3 samples counted, subject filtered; FASTQ text in tmpfs -> .Jhash, .histo, HashList, Mutations.Mate*.fastq)"
         # ---- overlap chain on the pulled pairs: a position-sorted SAM from the generator's own coordinates ----
         from tests.synth import _PHI, _U, _mix64, _scale32

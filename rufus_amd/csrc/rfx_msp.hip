@@ -29,19 +29,35 @@
 #include "rfx_internal.h"
 
 #ifdef RFX_TIMING
-__device__ unsigned long long g_tm[32];
+// (a row per workgroup: with ONE row every probe of every workgroup met on the same cache line and the kernels took 2 x as long)
+__device__ unsigned long long g_tm[2048][32];
+#define TM_ROW g_tm[blockIdx.x & 2047u]
 #define TM_DECL unsigned long long tm_prev = __builtin_amdgcn_s_memtime()
-#define TM(i) do { if (threadIdx.x == 0) { const unsigned long long tm_now = __builtin_amdgcn_s_memtime(); atomicAdd(&g_tm[i], tm_now - tm_prev); tm_prev = tm_now; } } while (0)
+#define TM(i) do { if (threadIdx.x == 0) { const unsigned long long tm_now = __builtin_amdgcn_s_memtime(); atomicAdd(&TM_ROW[i], tm_now - tm_prev); tm_prev = tm_now; } } while (0)
 extern "C" int rfx_debug_timing(unsigned long long* out, int reset) {
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tm), sizeof(g_tm)) != hipSuccess) return -1;
-  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_tm), z, sizeof(z)) != hipSuccess) return -1; }
+  static unsigned long long h[2048][32];
+  if (out) {
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tm), sizeof(g_tm)) != hipSuccess) return -1;
+    for (int i = 0; i < 32; ++i) {
+      out[i] = 0;
+      for (int w = 0; w < 2048; ++w) out[i] += h[w][i];
+    }
+  }
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_tm)) != hipSuccess || hipMemset(p, 0, sizeof(g_tm)) != hipSuccess) return -1;
+  }
   return 0;
 }
-#define TMC(i, c) do { if (threadIdx.x == 0 && (c)) atomicAdd(&g_tm[i], 1ull); } while (0)
+#define TMC(i, c) do { if (threadIdx.x == 0 && (c)) atomicAdd(&TM_ROW[i], 1ull); } while (0)
+#define TMF_DECL unsigned long long tf_prev = __builtin_amdgcn_s_memtime()
+#define TMF(i) do { if (threadIdx.x == 0) { const unsigned long long tf_now = __builtin_amdgcn_s_memtime(); atomicAdd(&TM_ROW[i], tf_now - tf_prev); tf_prev = tf_now; } } while (0)
 #else
 #define TM_DECL
 #define TM(i)
 #define TMC(i, c)
+#define TMF_DECL
+#define TMF(i)
 #endif
 
 namespace {
@@ -796,9 +812,14 @@ __device__ __forceinline__ uint32_t split_hash(uint64_t key) {
 #define RFX_LEAF_BLK 768
 #endif
 constexpr uint32_t MSP_LEAF_BLK(int geo) { return geo ? (uint32_t)RFX_LEAF_BLK : 1024u; }
+#ifndef RFX_LEAF_WPE
+#define RFX_LEAF_WPE (2 * RFX_LEAF_BLK / 256)
+#endif
+constexpr int MSP_LEAF_WPE(int geo) { return geo ? RFX_LEAF_WPE : 4; }  // waves per SIMD the registers must leave room for
 constexpr uint32_t MSP_LEAF_PASS_MAX(int geo) { return (geo ? 4096u : 8192u) * 3 / 4 + MSP_LEAF_BLK(geo); }
-// survivors a workgroup stages before it scatters them (big inputs): room for 5120 / 9216 + one pass
-constexpr uint32_t MSP_LEAF_STAGE(int geo) { return (geo ? 5120u : 9216u) + MSP_LEAF_PASS_MAX(geo); }
+// survivors a workgroup stages before it scatters them (big inputs): flushed from 3840 / 7680 on -- a round of the flush
+// sorts at most TBL = 4096 / 8192 of them through the k-mer table's arrays, and a bin adds ~400 -- + room for one pass
+constexpr uint32_t MSP_LEAF_STAGE(int geo) { return (geo ? 3840u : 7680u) + MSP_LEAF_PASS_MAX(geo); }
 #ifndef MSP_ILP_OVERRIDE
 #define MSP_ILP_OVERRIDE 3
 #endif
@@ -831,12 +852,10 @@ constexpr uint32_t MSP_RC_UNLISTED = 0x80000000u;  // record cache count: the re
 //
 // A bin (or part of it) whose distinct k-mers overflow the table is split in two by a hash bit and each half retried.
 // GEO 0: one 1024-thread workgroup per CU (8192-slot table); GEO 1: half of everything, two workgroups per CU.
+// (waves_per_eu: two 768-thread workgroups per CU are six waves per SIMD = 80 registers; left to itself the compiler takes 84
+// since the flush sorts its chunk, and only ONE workgroup fits)
 template <bool CANON, int GEO>
-#ifdef RFX_LEAF_WPE  // experiment: waves per SIMD the compiler must make room for (registers)
-__global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) __attribute__((amdgpu_waves_per_eu(RFX_LEAF_WPE, RFX_LEAF_WPE))) void k_msp_leaf(
-#else
-__global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) void k_msp_leaf(
-#endif
+__global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) __attribute__((amdgpu_waves_per_eu(MSP_LEAF_WPE(GEO), MSP_LEAF_WPE(GEO)))) void k_msp_leaf(
     const uint64_t* const* __restrict__ seg_inst, const uint64_t* const* __restrict__ seg_bs, int nseg,
     const uint64_t* __restrict__ inst0, const uint64_t* __restrict__ bs0, const uint32_t* const* __restrict__ seg_ext,
     const uint32_t* __restrict__ ext0, uint32_t P, int k,
@@ -860,7 +879,7 @@ __global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) void k_msp_leaf(
   __shared__ uint32_t s_rc[RC], s_rmin[RC], s_rmax[RC];
   __shared__ uint32_t s_mixed[2];
   __shared__ __attribute__((aligned(16))) uint16_t s_kmap[KMAP];
-  __shared__ uint32_t s_pc[P1_BINS];
+  __shared__ uint32_t s_pc[P1_BINS], s_pst[P1_BINS], s_nfl;
   __shared__ uint64_t s_pbase[P1_BINS];
   // by parity of the pass: distinct keys, overflow, k-mer map fill, survivors of the scan (zeroed for the NEXT pass by
   // thread 0 after the first barrier of a pass: nobody reads the other parity's between that barrier and the next pass)
@@ -915,11 +934,12 @@ __global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) void k_msp_leaf(
   // carry over from launch to launch, no count pass, no reservation between two barriers -- and eight instead of four
   // staged entries in flight per lane: 78 ms both.  With the flush skipped altogether the kernel takes 62 ms.)
   static_assert(KMAP * 2 >= 4 * 256 * 8 && RC * 8 >= 4 * 256 * 8, "the T table borrows s_kmap (tables 0-3) and s_rk (4-7)");
+  constexpr int NE = (TBL + BLK - 1) / BLK;  // staged entries a lane carries through one round (<= TBL entries) of the flush
   auto flush = [&]() {
     uint64_t* const lut_lo = (uint64_t*)s_kmap;
     uint64_t* const lut_hi = (uint64_t*)s_rk;
-    for (int i = threadIdx.x; i < ntab * 256; i += BLK) (i < 1024 ? lut_lo[i] : lut_hi[i - 1024]) = g_lut[i];
-    __syncthreads();
+    TMF_DECL;
+    TMC(31, 1);
     auto t_mul = [&](uint64_t key) {
       uint64_t r = 0;
 #pragma unroll
@@ -927,63 +947,95 @@ __global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) void k_msp_leaf(
         if (t < ntab) r ^= (t < 4 ? lut_lo : lut_hi - 1024)[t * 256 + (uint32_t)((key >> (8 * t)) & 255u)];
       return r;
     };
-    // (four entries in flight per lane: one at a time, a lane waited for its key and then for the seven table reads, ten
-    // times over -- the flush of a chunk took as long as two bins)
-    for (uint32_t i0 = threadIdx.x; i0 < used; i0 += 4 * BLK) {
-      uint64_t kv[4];
+    // Round 5: the chunk leaves SORTED by coarse bin.  Until then every lane stored its entries where their bins' cursors
+    // pointed: a wave's store went to 64 places, and the scatter -- 2 % of the kernel's instructions -- took 8 % of its
+    // time (-DRFX_TIMING; that the next loads waited behind those stores was the first suspect: entries kept in
+    // registers from the count to the scatter changed nothing).  Now a round of at most TBL entries is counted per bin,
+    // placed in bin order in the k-mer table's own arrays (idle between two bins, every slot empty), and written out by
+    // consecutive lanes to consecutive addresses: a bin's ~30 entries are 4 cache lines, not 30 stores.
+    for (uint32_t base = 0; base < used; base += (uint32_t)TBL) {
+      const uint32_t n_in = min((uint32_t)TBL, used - base);
+      uint64_t kv[NE];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) kv[u] = i0 + u * BLK < used ? stk[i0 + u * BLK] : 0;
+      for (int u = 0; u < NE; ++u) {
+        const uint32_t i = threadIdx.x + (uint32_t)u * BLK;
+        kv[u] = i < n_in ? stk[base + i] : RFX_EMPTY;
+      }
+      if (base == 0) {
+        for (int i = threadIdx.x; i < ntab * 256; i += BLK) (i < 1024 ? lut_lo[i] : lut_hi[i - 1024]) = g_lut[i];
+        __syncthreads();
+      }
+      TMF(25);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) kv[u] = t_mul(kv[u]);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (i0 + u * BLK < used) {
-          uint64_t w = kv[u];
+      for (int u = 0; u < NE; ++u) {
+        if (kv[u] != RFX_EMPTY) {
+          uint64_t w = t_mul(kv[u]);
           const uint64_t pos = w >> sel_bits;
           if (pos >= pos_lo && pos < pos_hi) atomicAdd(&s_pc[(uint32_t)(w >> shift1)], 1u);
           else w = RFX_EMPTY;
-          stk[i0 + u * BLK] = w;
+          kv[u] = w;
         }
-    }
-    __syncthreads();
-    if (threadIdx.x < P1_BINS) {
-      const uint32_t cn = s_pc[threadIdx.x];
-      const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
-      if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
-        atomicExch(flag, 1u);
-        s_pbase[threadIdx.x] = ~0ull;
-      } else {
-        s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at;
+        if (u & 1) __builtin_amdgcn_sched_barrier(0);  // (two products in flight, not NE: 8 table reads each)
       }
-      s_pc[threadIdx.x] = 0;
-    }
-    __syncthreads();
-    for (uint32_t i0 = threadIdx.x; i0 < used; i0 += 4 * BLK) {
-      uint64_t wv[4];
-      uint32_t cv[4];
+      uint32_t cv[NE];  // (asked for here: they arrive while the cursors are fetched)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const bool in = i0 + u * BLK < used;
-        wv[u] = in ? stk[i0 + u * BLK] : RFX_EMPTY;
-        cv[u] = in ? stc[i0 + u * BLK] : 0u;
+      for (int u = 0; u < NE; ++u) cv[u] = kv[u] != RFX_EMPTY ? stc[base + threadIdx.x + (uint32_t)u * BLK] : 0u;
+      TMF(26);
+      __syncthreads();
+      TMF(27);
+      if (threadIdx.x < P1_BINS) {  // (two waves) room in the coarse bins; where a bin starts in the sorted round
+        static_assert(P1_BINS == 128, "the scan below is two waves wide");
+        const uint32_t cn = s_pc[threadIdx.x];
+        const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
+        uint32_t incl = cn;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t up = __shfl_up(incl, d, 64);
+          if ((int)(threadIdx.x & 63u) >= d) incl += up;
+        }
+        uint32_t low = s_pc[threadIdx.x & 63u];  // the first wave's total, for the second
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) low += __shfl_xor(low, d, 64);
+        const uint32_t start = incl - cn + (threadIdx.x >= 64 ? low : 0u);
+        s_pst[threadIdx.x] = start;
+        if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
+          atomicExch(flag, 1u);
+          s_pbase[threadIdx.x] = ~0ull;
+        } else {
+          s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at - start;  // (+ the entry's place in the round)
+        }
+        if (threadIdx.x == P1_BINS - 1) s_nfl = start + cn;
       }
+      __syncthreads();
+      TMF(28);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint64_t w = wv[u];
+      for (int u = 0; u < NE; ++u) {
+        const uint64_t w = kv[u];
         if (w == RFX_EMPTY) continue;
-        const uint32_t cb = (uint32_t)(w >> shift1);
-        const uint32_t o = atomicAdd(&s_pc[cb], 1u);
-        if (s_pbase[cb] != ~0ull) {
-          out_w[s_pbase[cb] + o] = w;
-          out_c[s_pbase[cb] + o] = cv[u];
+        const uint32_t at = atomicAdd(&s_pst[(uint32_t)(w >> shift1)], 1u);
+        s_keys[at] = w;
+        s_cnt[at] = cv[u];
+      }
+      __syncthreads();
+      const uint32_t n_out = s_nfl;
+      for (uint32_t i = threadIdx.x; i < n_out; i += BLK) {
+        const uint64_t w = s_keys[i];
+        const uint32_t cnt = s_cnt[i];
+        s_keys[i] = RFX_EMPTY;
+        s_cnt[i] = 0;
+        const uint64_t pb = s_pbase[(uint32_t)(w >> shift1)];
+        if (pb != ~0ull) {
+          out_w[pb + i] = w;
+          out_c[pb + i] = cnt;
         }
       }
+      if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
+      TMF(29);
+      __syncthreads();  // (the table is whole again: a pass without the cache inserts from its phase A on)
+      TMF(30);
     }
-    __syncthreads();
-    if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < 1024 && i < (ntab - 4) * 256; i += BLK) s_rk[i] = MSP_EMPTY;  // the borrowed cache keys
     used = 0;
-    // (the next use of s_pc / the chunk lies behind the barriers of the next pass)
   };
 
   for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {

@@ -33,3 +33,5 @@ tot = sum(lf.values()) + v[16] + v[17] + v[18] or 1
 print("   wave 0: A %.1f %% + wait %.1f %%, B %.1f %% + wait %.1f %%, C %.1f %% + wait %.1f %%, flush %.1f %%" % tuple(
     100.0 * x / tot for x in (v[16], v[9], v[17], v[11], v[18], v[12], v[13])))
 print("leaf rounds", v[21], "overflowed", v[20], "records", v[22], "uncached", v[23], "mixed", v[24])
+print("flush: n %d; lut %.1f, pass 1 %.1f + wait %.1f, cursors %.1f, pass 2 %.1f + wait %.1f (%% of wave 0's time)" % ((v[31],) + tuple(100.0 * v[i] / tot for i in (25, 26, 27, 28, 29, 30))))
+print("   cycles (100 MHz ticks) per flush: " + ", ".join("%.0f" % (v[i] / max(1, v[31])) for i in (25, 26, 27, 28, 29, 30)), "; per bin round:", "%.0f" % (tot / max(1, v[21])))

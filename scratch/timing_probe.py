@@ -12,7 +12,8 @@ sys_ = [capi.Synth.sample(G, w, n_snv=max(20, min(1000, G // 3_000_000)), seed=1
 samples = [wgs.make_sample(ctx, sy, pairs, 1 << 24, 15, want_good=(i == 0)) for i, sy in enumerate(sys_)]
 ctx.sync()
 passes = int(os.environ.get("PASSES", "1"))
-trio = wgs.WgsTrio(ctx, 25, 8 << 30, 2, 5, 1200, 1, passes=passes)
+K = int(os.environ.get("K", "25"))
+trio = wgs.WgsTrio(ctx, K, 8 << 30, 2, 5, 1200, 1, passes=passes)
 trio.run(samples)                       # warm-up
 buf = (C.c_ulonglong * 32)()
 lib.rfx_debug_timing.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]

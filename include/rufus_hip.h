@@ -248,6 +248,9 @@ int rfx_runmaps_blocks(const rfx_runmaps*);
 int rfx_runmaps_drop(rfx_runmaps*, const rfx_reads*);
 int rfx_runmaps_clear(rfx_runmaps*); /* every map of the store */
 int rfx_count_set_runmaps(rfx_table*, rfx_runmaps*);
+/* the maps of several blocks the table is about to add, made with ONE wait for the device (a map made by rfx_count_add
+ * waits for its own launch); blocks that have a map, or are no blocks for one, are skipped; no store: nothing happens */
+int rfx_count_prepare_maps(rfx_table*, rfx_reads* const* blocks, int n);
 uint64_t rfx_count_replayed(const rfx_table*);
 /* Bounded-HBM counting of a whole sample (MSP path, call before the first add): rfx_count_add() only
  * REMEMBERS the read blocks -- they must stay alive until finish -- and rfx_count_finish() runs `passes`

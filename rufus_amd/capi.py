@@ -84,6 +84,7 @@ SIGNATURES = {
     "rfx_runmaps_drop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rfx_runmaps_clear": (C.c_int, [C.c_void_p]),
     "rfx_count_set_runmaps": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rfx_count_prepare_maps": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
     "rfx_count_replayed": (C.c_uint64, [C.c_void_p]),
     "rfx_count_segments": (C.c_int, [C.c_void_p]),
     "rfx_count_segment_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
@@ -557,6 +558,11 @@ class CountTable:
     def set_runmaps(self, store: "RunMaps"):
         """Share a store of run maps with the tables of the sample's other shard passes (rfx_count_set_runmaps)."""
         _check(lib().rfx_count_set_runmaps(self._h, store._h if store is not None else None), "rfx_count_set_runmaps")
+
+    def prepare_maps(self, blocks) -> None:
+        """The run maps of `blocks` (Reads the table is about to add) with one wait for the device (rfx_count_prepare_maps)."""
+        arr = (C.c_void_p * max(1, len(blocks)))(*[b._h for b in blocks])
+        _check(lib().rfx_count_prepare_maps(self._h, arr, len(blocks)), "rfx_count_prepare_maps")
 
     def replayed(self) -> int:
         return int(lib().rfx_count_replayed(self._h))

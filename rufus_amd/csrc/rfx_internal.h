@@ -140,6 +140,7 @@ struct rfx_runmaps {
   rfx_ctx* ctx = nullptr;
   uint64_t budget = 0;  // bytes of maps the store may hold (0: no limit)
   uint64_t bytes = 0;
+  uint64_t pending_bytes = 0;  // maps whose hashing launch is queued (rfx_count_prepare_maps): they count against the budget
   std::map<const rfx_reads*, rfx_runmap_entry> m;
   // pooled store (rfx_runmaps_create_pooled): ONE device allocation made with the store, the maps are cut out of it
   // (first fit) -- at 90 % of the HBM gigabyte-sized maps that come and go between the transients of a pass would

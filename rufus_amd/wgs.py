@@ -160,6 +160,7 @@ class WgsTrio:
         try:
             if store is not None:       # (run maps instead of blocks cut ahead: 32 instead of 132 bytes per read)
                 t.set_runmaps(store)
+                t.prepare_maps(blocks)       # (all of them behind ONE wait: 0.75 ms of idle device per block otherwise)
                 last = shard == self.passes - 1
                 for b in blocks:
                     t.add(b)

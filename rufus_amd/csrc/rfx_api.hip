@@ -1849,9 +1849,17 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
       uint32_t* fcur1 = (uint32_t*)(g.fine1 + n1 + 1);
       HIPCHK(hipMemsetAsync(g.fine1, 0, (n1 + 1) * 8 + n1 * 4, c->stream));
       if (chunk) {
-        for (size_t si : g.segs)
-          rfxk::bin_hist(c, (*t->segs)[si].inst, (*t->segs)[si].bin_start + gp0, gnp, chunk, F1, shift1, rec_mode, t->k,
-                         g.fine1, (*t->segs)[si].ext);
+        if (g.d_seg) {  // (one launch for all the group's segments, as the partition below)
+          const size_t ns = g.segs.size();
+          bool planes = true;
+          for (size_t si : g.segs) planes = planes && (*t->segs)[si].ext != nullptr;
+          rfxk::bin_hist_multi(c, g.d_seg, g.d_seg + ns, planes ? (const uint32_t* const*)(g.d_seg + 2 * ns) : nullptr, (int)ns, gp0,
+                               gnp, chunk, F1, shift1, rec_mode, t->k, g.fine1);
+        } else {
+          for (size_t si : g.segs)
+            rfxk::bin_hist(c, (*t->segs)[si].inst, (*t->segs)[si].bin_start + gp0, gnp, chunk, F1, shift1, rec_mode, t->k,
+                           g.fine1, (*t->segs)[si].ext);
+        }
         rfxk::scan_tail(c, g.fine1, n1);
         if (g.d_seg) {
           const size_t ns = g.segs.size();

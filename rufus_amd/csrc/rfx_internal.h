@@ -381,6 +381,10 @@ void part2_multi(rfx_ctx*, const uint64_t* const* seg_a, const uint64_t* const* 
 void bin_hist(rfx_ctx*, const uint64_t* src, const uint64_t* parent_start, uint32_t n_parents, uint64_t n_hint,
               uint32_t P2, int shift2, int rec_mode, int k, uint64_t* fine_tot,
               const uint32_t* ext = nullptr /* the records' planes: k <= 25, they carry the bin-hash bits (rfx_devutil.h msp_stamp) */);
+// the same in ONE launch over the slices of nseg arrays (device arrays of nseg pointers; parent b = bin cs_off + b of each)
+void bin_hist_multi(rfx_ctx*, const uint64_t* const* seg_src, const uint64_t* const* seg_ps, const uint32_t* const* seg_ext,
+                    int nseg, uint32_t cs_off, uint32_t n_parents, uint64_t n_hint, uint32_t P2, int shift2, int rec_mode, int k,
+                    uint64_t* fine_tot);
 // MSP path (rfx_msp.hip)
 int msp_k_ok(int k);
 int msp_part1_block();  // threads = reads per chunk of k_msp_part1

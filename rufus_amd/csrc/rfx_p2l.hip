@@ -397,6 +397,61 @@ __global__ __launch_bounds__(512) void k_bin_hist_stamp(const uint32_t* __restri
   }
 }
 
+// Both of the above over the slices of nseg arrays in ONE launch (the refinement's first level: a chunk of a W sample is
+// 19 read blocks' records -- a launch per block and chunk was 646 launches of ~17 us per sample, each with its ramp and
+// the gap behind it).  seg_src / seg_ext / seg_ps: DEVICE arrays of nseg pointers; parent b = bin cs_off + b of every
+// array.  STAMP: the counts come from the stamped planes (k <= 25), else from the words (MODE as k_bin_hist).
+template <int MODE, bool STAMP>
+__global__ __launch_bounds__(512) void k_bin_hist_multi(const uint64_t* const* __restrict__ seg_src, const uint32_t* const* __restrict__ seg_ext,
+                                                         const uint64_t* const* __restrict__ seg_ps, int nseg, uint32_t cs_off,
+                                                         uint32_t n_parents, uint32_t W, uint32_t P2, int shift2, int k,
+                                                         unsigned long long* __restrict__ fine_tot) {
+  __shared__ uint32_t s_cnt[256];
+  for (uint32_t blk = blockIdx.x; blk < n_parents * W; blk += gridDim.x) {
+    const uint32_t b = blk / W, j = blk - b * W;
+    if (threadIdx.x < 256) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (int sg = 0; sg < nseg; ++sg) {
+      const uint64_t* __restrict__ ps = seg_ps[sg] + cs_off;
+      const uint64_t a = ps[b], e = ps[b + 1];
+      if (STAMP) {
+        const uint32_t* __restrict__ ext = seg_ext[sg];
+        const uint64_t stride = (uint64_t)W * blockDim.x * 4;
+        uint64_t i = a + ((uint64_t)j * blockDim.x + threadIdx.x) * 4;
+        for (; i + stride + 4 <= e; i += 2 * stride) {
+          const uint4 v0 = *(const uint4*)(ext + i), v1 = *(const uint4*)(ext + i + stride);
+          atomicAdd(&s_cnt[msp_stamp_sub(v0.x, shift2, P2)], 1u);
+          atomicAdd(&s_cnt[msp_stamp_sub(v0.y, shift2, P2)], 1u);
+          atomicAdd(&s_cnt[msp_stamp_sub(v0.z, shift2, P2)], 1u);
+          atomicAdd(&s_cnt[msp_stamp_sub(v0.w, shift2, P2)], 1u);
+          atomicAdd(&s_cnt[msp_stamp_sub(v1.x, shift2, P2)], 1u);
+          atomicAdd(&s_cnt[msp_stamp_sub(v1.y, shift2, P2)], 1u);
+          atomicAdd(&s_cnt[msp_stamp_sub(v1.z, shift2, P2)], 1u);
+          atomicAdd(&s_cnt[msp_stamp_sub(v1.w, shift2, P2)], 1u);
+        }
+        for (; i < e; i += stride)
+          for (uint64_t q = i; q < i + 4 && q < e; ++q) atomicAdd(&s_cnt[msp_stamp_sub(ext[q], shift2, P2)], 1u);
+      } else {
+        const uint64_t* __restrict__ src = seg_src[sg];
+        const uint64_t stride = (uint64_t)W * blockDim.x;
+        uint64_t i = a + (uint64_t)j * blockDim.x + threadIdx.x;
+        for (; i + 3 * stride < e; i += 4 * stride) {
+          const uint64_t w0 = src[i], w1 = src[i + stride], w2 = src[i + 2 * stride], w3 = src[i + 3 * stride];
+          atomicAdd(&s_cnt[sub_bin_of<MODE>(w0, shift2, P2, k)], 1u);
+          atomicAdd(&s_cnt[sub_bin_of<MODE>(w1, shift2, P2, k)], 1u);
+          atomicAdd(&s_cnt[sub_bin_of<MODE>(w2, shift2, P2, k)], 1u);
+          atomicAdd(&s_cnt[sub_bin_of<MODE>(w3, shift2, P2, k)], 1u);
+        }
+        for (; i < e; i += stride) atomicAdd(&s_cnt[sub_bin_of<MODE>(src[i], shift2, P2, k)], 1u);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < P2 && s_cnt[threadIdx.x])
+      atomicAdd(&fine_tot[(uint64_t)b * P2 + threadIdx.x], (unsigned long long)s_cnt[threadIdx.x]);
+    __syncthreads();
+  }
+}
+
 // Coarse bin cb of A -> its P2 fine bins in B.  W workgroups share a coarse bin (tiles strided).
 // PAYLOAD: every word carries a 32-bit count that moves with it (survivors of the MSP leaf).
 // MULTI: coarse bin cb is the concatenation of its slices in nseg arrays (the read blocks of a sample, each partitioned
@@ -977,6 +1032,32 @@ void part2(rfx_ctx* c, const uint64_t* buf_a, uint64_t* buf_b, const uint64_t* f
 #undef RFX_PART2
 }
 
+static bool bin_hist_stamped(int k, uint32_t P2, int shift2, int rec_mode, bool have_ext) {
+  return rec_mode != 0 && have_ext && msp_stamped(k) && shift2 >= MSP_STAMP_LO &&
+         shift2 + (32 - __builtin_clz(P2 - 1 ? P2 - 1 : 1)) <= MSP_STAMP_LO + MSP_STAMP_BITS && !getenv("RFX_NO_STAMP_HIST");
+}
+
+// ONE launch over the slices of nseg arrays (device arrays of pointers, as part2_multi takes them; seg_ext may be null)
+void bin_hist_multi(rfx_ctx* c, const uint64_t* const* seg_src, const uint64_t* const* seg_ps, const uint32_t* const* seg_ext,
+                    int nseg, uint32_t cs_off, uint32_t n_parents, uint64_t n_hint, uint32_t P2, int shift2, int rec_mode, int k,
+                    uint64_t* fine_tot) {
+  rfx_span sp(c, "k_bin_hist");
+  if (!n_parents || nseg <= 0) return;
+  const uint32_t resident = (uint32_t)c->n_cu * 4;
+  uint32_t W = n_parents >= resident ? 1 : resident / n_parents;
+  const uint64_t per = n_hint / n_parents / 2048 + 1;  // a workgroup should see a few thousand entries
+  if (W > per) W = (uint32_t)per;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)n_parents * W, (uint64_t)resident * 8);
+#define RFX_BHM(MODE, STAMP)                                                                                              \
+  hipLaunchKernelGGL((k_bin_hist_multi<MODE, STAMP>), dim3(grid), dim3(512), 0, c->stream, seg_src, seg_ext, seg_ps, nseg, \
+                     cs_off, n_parents, W, P2, shift2, k, (unsigned long long*)fine_tot)
+  if (bin_hist_stamped(k, P2, shift2, rec_mode, seg_ext != nullptr)) RFX_BHM(1, true);
+  else if (rec_mode == 0) RFX_BHM(0, false);
+  else if (rec_mode == 1) RFX_BHM(1, false);
+  else RFX_BHM(2, false);
+#undef RFX_BHM
+}
+
 void bin_hist(rfx_ctx* c, const uint64_t* src, const uint64_t* parent_start, uint32_t n_parents, uint64_t n_hint,
               uint32_t P2, int shift2, int rec_mode, int k, uint64_t* fine_tot, const uint32_t* ext) {
   rfx_span sp(c, "k_bin_hist");
@@ -987,8 +1068,7 @@ void bin_hist(rfx_ctx* c, const uint64_t* src, const uint64_t* parent_start, uin
   if (W > per) W = (uint32_t)per;
   const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)n_parents * W, (uint64_t)resident * 8);
   // super-k-mer records whose planes carry bits 3 .. 18 of the bin hash (k <= 25), when those are the bits asked for
-  if (rec_mode != 0 && ext && msp_stamped(k) && shift2 >= MSP_STAMP_LO && shift2 + (32 - __builtin_clz(P2 - 1 ? P2 - 1 : 1)) <= MSP_STAMP_LO + MSP_STAMP_BITS &&
-      !getenv("RFX_NO_STAMP_HIST")) {
+  if (bin_hist_stamped(k, P2, shift2, rec_mode, ext != nullptr)) {
     hipLaunchKernelGGL(k_bin_hist_stamp, dim3(grid), dim3(512), 0, c->stream, ext, parent_start, n_parents, W, P2, shift2,
                        (unsigned long long*)fine_tot);
     return;

@@ -819,6 +819,56 @@ def _shard_tables(ctx, k, S, blocks, store=None):
     return out
 
 
+def test_run_maps_made_together_are_the_maps_made_one_by_one(ctx):
+    """rfx_count_prepare_maps: the maps of all the blocks a table is about to add, behind ONE wait for the device (the WGS
+    driver calls it before a sample's first pass) -- the same maps as rfx_count_add makes one by one: same records per
+    shard, one hashing launch per block, none at the adds; a second call, a table without a store, blocks that have their
+    map: nothing happens; a store without room for all makes the maps that fit."""
+    k = 25
+    sy = capi.Synth.sample(30_000_000, 0, n_snv=50, seed=2718)
+    big = wgs.make_sample(ctx, sy, 2_300_000, 2_300_000, MIN_Q, want_good=False, compact=True)
+    small = wgs.make_sample(ctx, sy, 200_000, 200_000, MIN_Q, want_good=False, compact=True, first_pair=2_300_000)
+    blocks = big + small
+    store = capi.RunMaps(ctx)
+    ref = _shard_tables(ctx, k, 2, blocks, store)
+    ref_bytes = store.bytes()
+    store.free()
+    store = capi.RunMaps(ctx)
+    ctx.prof(True)
+    ctx.prof_reset()
+    got = []
+    for sh in range(2):
+        t = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+        t.set_shard(sh, 2)
+        t.prepare_maps(blocks)              # (no store yet: nothing)
+        assert store.blocks() == (0 if sh == 0 else 2)
+        t.set_runmaps(store)
+        t.prepare_maps(blocks)
+        assert store.blocks() == 2 and store.bytes() == ref_bytes
+        n_map = ctx.prof_dict()["k_msp_map"][1]
+        t.prepare_maps(blocks)              # (they are there)
+        for b in blocks:
+            t.add(b)
+        assert ctx.prof_dict()["k_msp_map"][1] == n_map == 2
+        rec = t.finish(LOWER)
+        got.append((tuple(rec.checksum()), len(rec), t.replayed()))
+        rec.free()
+        t.free()
+    ctx.prof(False)
+    assert got == ref and [g[2] for g in got] == [2, 2]
+    store.free()
+    store = capi.RunMaps(ctx, budget_bytes=small[0].n * 32 + (1 << 20), pooled=True)      # room for the small block's only
+    t = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+    t.set_shard(0, 2)
+    t.set_runmaps(store)
+    t.prepare_maps(blocks[::-1])
+    assert store.blocks() == 1
+    t.free()
+    store.free()
+    for b in blocks:
+        b.free()
+
+
 @pytest.mark.parametrize("k,compact", [(25, True), (31, True), (27, False)])
 def test_later_shard_passes_replay_the_run_map(ctx, k, compact):
     """rfx_runmaps_* / k_msp_replay: with a store of run maps a big block is hashed once (k_msp_map, by the first shard

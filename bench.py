@@ -339,6 +339,20 @@ def run_wgs(args, ctx, rank, world, dist, torch):
         t = torch.tensor([passes], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         passes = int(t.item())
+    if world > 1:
+        # what this rank plans to hold, before anything big is allocated (wgs.plan_passes' own terms): a first run on real
+        # hardware that dies of memory says on which rank and by how much
+        windows = 2 * n_pairs * max(READ_LEN - k + 1, 0)
+        share = passes * world
+        rec = (1.6 if k > 25 else 2.2) * windows / share
+        plan = {"rank": rank, "device": torch.cuda.current_device(), "hbm_total_GB": round(total / 1e9, 1),
+                "hbm_free_GB": round(free0 / 1e9, 1), "passes": passes, "resident_reads_GB": round(resident / 1e9, 2),
+                "records_per_pass_GB": round(rec / 1e9, 2), "receive_buffers_per_pass_GB": round(rec * (world - 1) / world / 1e9, 2),
+                "planned_peak_GB": round((resident + 2 * rec * 1.125) / 1e9, 1)}
+        print("bench.py plan: " + json.dumps(plan), file=sys.stderr, flush=True)
+        if not args.one_device and plan["planned_peak_GB"] > 0.95 * free0 / 1e9:
+            raise SystemExit(f"rank {rank}: the planned peak ({plan['planned_peak_GB']} GB) exceeds the free HBM of device "
+                             f"{plan['device']} ({plan['hbm_free_GB']} GB): something else holds this device")
     t0 = time.perf_counter()
     samples = [wgs.make_sample(ctx, sy, n * (rank + 1) // world - n * rank // world, 1 << 24, MIN_Q, want_good=(i == 0),
                                first_pair=n * rank // world, compact=compact) for i, (sy, n) in enumerate(zip(sys_, pairs))]
@@ -435,6 +449,18 @@ def main():
             dist.init_process_group("nccl", device_id=None if args.one_device else torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
+        # The first real N-rank run must diagnose itself: the group the collectives will run over has
+        # exactly --gpus ranks, every rank sits on a device of its own, and one all-reduce really crosses all of them.
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"rank {rank}: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        probe = torch.tensor([1, local], dtype=torch.int64, device="cuda")
+        gathered = [torch.zeros_like(probe) for _ in range(world)]
+        dist.all_gather(gathered, probe)
+        seen = [int(g[1].item()) for g in gathered]
+        if sum(int(g[0].item()) for g in gathered) != args.gpus:
+            raise SystemExit(f"rank {rank}: all_gather over {dist.get_backend()} answered for {len(seen)} ranks, --gpus {args.gpus}")
+        if not args.one_device and len(set(seen)) != world:
+            raise SystemExit(f"rank {rank}: ranks share devices {seen}: one process per GPU expected (LOCAL_RANK)")
 
     ctx = capi.Context(local)   # raises without a gfx950 GPU: no CPU fallback
     step, reads_per_step, reads_per_launch, reads_filtered, desc, scaling, extra = (

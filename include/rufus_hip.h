@@ -116,7 +116,9 @@ void* rfx_stream(rfx_ctx*); /* the hipStream_t every kernel of this ctx is launc
 /* The device memory a ctx hands out is mapped into its address range as it is first needed (and kept); mapping costs
  * ~4 ms per GiB.  A caller that knows it will need `bytes` in total -- `jellyfish count` while it still parses its
  * input: the shard passes at finish take ~130 GB for a 30x sample -- has them mapped ahead, off its critical path.
- * Never more than the device can give: RFX_E_NOMEM then (nothing is lost, the memory is mapped when needed). */
+ * Never more than the device can give: a request beyond 90 % of the device's free memory is refused with RFX_E_NOMEM
+ * before anything is mapped (nothing is lost and nothing is taken from other users of the device; the memory is mapped
+ * when it is needed). */
 int rfx_mem_reserve(rfx_ctx*, uint64_t bytes);
 int rfx_mem_stats(rfx_ctx*, uint64_t* used, uint64_t* peak, uint64_t* mapped);
 /* Device-to-device copy on the ctx stream, then stream sync (hand-off to / from buffers another

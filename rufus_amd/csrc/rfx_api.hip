@@ -717,8 +717,18 @@ int rfx_mem_reserve(rfx_ctx* c, uint64_t bytes) {
     auto last = std::prev(c->arena_free.end());
     if (last->first + last->second == c->arena_mapped) tail = last->second;
   }
+  // A request the device cannot meet is refused BEFORE anything is mapped: arena_grow maps chunk after chunk until
+  // hipMemCreate fails and keeps what it got -- a "refused" reserve of 200 GiB on a smaller (or shared) device would have
+  // pinned nearly all of its free memory into this ctx until rfx_close, starving another ctx, RCCL or a plain hipMalloc.
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) {
+    (void)hipGetLastError();
+    return RFX_E_NOMEM;
+  }
+  const uint64_t grow = bytes - c->arena_mapped;
+  if (grow > (uint64_t)((double)free_b * 0.9)) return RFX_E_NOMEM;
   // (arena_grow maps so that a free range of `need` bytes ends at the new high-water mark)
-  return arena_grow(c, tail + (size_t)(bytes - c->arena_mapped)) ? RFX_OK : RFX_E_NOMEM;
+  return arena_grow(c, tail + (size_t)grow) ? RFX_OK : RFX_E_NOMEM;
 }
 
 int rfx_mem_stats(rfx_ctx* c, uint64_t* used, uint64_t* peak, uint64_t* mapped) {
@@ -781,6 +791,7 @@ rfx_reads* rfx_reads_upload(rfx_ctx* c, const uint64_t* codes, const uint32_t* a
   (void)hipSetDevice(c->device);
   rfx_reads* r = new rfx_reads();
   memset(r, 0, sizeof *r);
+  r->gen = rfx_next_reads_gen();
   r->ctx = c;
   r->n = n_reads;
   r->n_words = word_off[n_reads];
@@ -1213,6 +1224,7 @@ static rfx_runmap_entry* runmap_finish(rfx_table* t, runmap_pending& p, bool ok,
     en.n_ovf = p.n_ovf;
     en.n_reads = r->n;
     en.codes = r->codes;
+    en.gen = r->gen;
     en.k = t->k;
     en.canonical = t->canonical;
     en.map_bytes = p.map_bytes;
@@ -1229,6 +1241,7 @@ static rfx_runmap_entry* runmap_finish(rfx_table* t, runmap_pending& p, bool ok,
     rfx_runmap_entry none;
     none.n_reads = r->n;
     none.codes = r->codes;
+    none.gen = r->gen;
     none.k = t->k;
     none.canonical = t->canonical;
     st->m[r] = none;
@@ -1247,7 +1260,7 @@ static rfx_runmap_entry* runmap_get(rfx_table* t, const rfx_reads* r, bool make,
   auto it = st->m.find(r);
   if (it != st->m.end()) {
     rfx_runmap_entry& en = it->second;
-    if (en.k == t->k && en.canonical == t->canonical && en.n_reads == r->n && en.codes == r->codes)
+    if (en.gen == r->gen && en.k == t->k && en.canonical == t->canonical && en.n_reads == r->n && en.codes == r->codes)
       return en.map ? &en : nullptr;  // (no map: the block was tried and is no block for one -- nobody tries again)
     // the entry of ANOTHER block that lived at this address (or of another k): gone
     runmaps_release(st, en.map, en.map_bytes);
@@ -1362,7 +1375,29 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
 // one per read end -- 0.175 for k <= 25 (w = 11), 0.125 for k = 26 .. 31 (w = 16); with 20 % on top for the estimates.
 static double msp_records_per_window(int k) { return k <= 25 ? 0.21 : 0.15; }
 
+static int msp_add_impl(rfx_table* t, const rfx_reads* r);
+
+// Run maps take memory from a finish that was planned to fit without them.  A store the TABLE made for itself
+// (rfx_count_set_passes: `jellyfish count`) is therefore given back when a block's partition runs out of memory, and the
+// block is partitioned once more by hashing, as if there had never been a store; every later block and pass does the same.
+// (A store handed in by the caller -- rfx_count_set_runmaps: rufus_amd/wgs.py -- is the caller's to drop: it sees
+// RFX_E_NOMEM and repeats the step without maps.)
+static bool msp_give_up_own_runmaps(rfx_table* t) {
+  if (!t->runmaps || !t->runmaps_owned) return false;
+  (void)ctx_sync(t->ctx);  // (launches that read the maps are still queued)
+  rfx_runmaps_free(t->runmaps);
+  t->runmaps = nullptr;
+  t->runmaps_owned = 0;
+  return true;
+}
+
 static int msp_add(rfx_table* t, const rfx_reads* r) {
+  int rc = msp_add_impl(t, r);
+  if (rc == RFX_E_NOMEM && msp_give_up_own_runmaps(t)) rc = msp_add_impl(t, r);
+  return rc;
+}
+
+static int msp_add_impl(rfx_table* t, const rfx_reads* r) {
   rfx_ctx* c = t->ctx;
   msp_geom g;
   msp_geometry(t, r, g);
@@ -1431,8 +1466,9 @@ static int msp_add(rfx_table* t, const rfx_reads* r) {
       G_ovf = have->n_ovf ? (int)std::min<uint32_t>(512, ((have->n_ovf + 511) / 512 + 7) & ~7u) : 0;
       slab_log2 = std::max(slab_log2, 7);
       cap_a = even + even / 16 + 16384 + rfxk::msp_part1_slack(G_rep + G_ovf, slab_log2);
-      if (cap_a >= (1ull << 32)) return RFX_E_RANGE;
+      if (cap_a >= (1ull << 32)) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
     }
+    // (out of memory with a run-map store of the table's own: msp_add gives the store back and takes the hashing path)
     auto drop_map = [&] {};
     for (int attempt = 0;; ++attempt) {
       char* buf_a = (char*)dmalloc(c, cap_a * c_n_all * 12);  // 12-byte slots: word and plane side by side
@@ -2007,7 +2043,10 @@ struct rfx_peers {
       return true;
     }
     cv.wait(g, [&] { return gen != my || failed; });
-    return !failed;
+    // A barrier that COMPLETED lets every waiter through, whatever happened since: a table that passed it, failed at once
+    // and called abort() before a slower waiter woke up must not send that waiter down the "barrier failed" path -- the
+    // two would then disagree about who comes to drain(), and the rest would wait there for ever.
+    return gen != my;
   }
   void abort() {
     std::lock_guard<std::mutex> g(mu);
@@ -2183,7 +2222,10 @@ static int msp_passes_leaf(rfx_finish* f) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
     const double avail = 0.88 * ((double)free_b + (double)(c->arena_mapped - std::min(c->arena_mapped, c->used)));
-    const double pass = (double)windows * msp_records_per_window(t->k) * 12.0 * 1.05 / (double)outer_n / S + (double)windows / 20.0 * 14.0;
+    // a pass's records + the refinement's chunk buffers (two levels of 12 B over 1/16 of them, and the leaf's staging)
+    // + the survivors of ALL passes
+    const double pass_rec = (double)windows * msp_records_per_window(t->k) * 12.0 * 1.05 / (double)outer_n / S;
+    const double pass = pass_rec * 1.15 + (double)windows / 20.0 * 14.0;
     if (avail - pass > (double)(256u << 20)) {
       t->runmaps = rfx_runmaps_create(c, (uint64_t)((avail - pass) * 0.8));
       t->runmaps_owned = t->runmaps != nullptr;
@@ -2246,6 +2288,10 @@ static int msp_passes_leaf(rfx_finish* f) {
     }
     for (int attempt = 0;; ++attempt) {
       rc = msp_leaf_refined(f, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
+      if (rc == RFX_E_NOMEM && msp_give_up_own_runmaps(t)) {  // the maps go, the pass's leaf is queued once more
+        HIPCHK(upload(c, cur, cur_prev.data(), (ncur + 2) * 4));
+        rc = msp_leaf_refined(f, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
+      }
       if (rc) { (void)ctx_sync(c); return rc; }
       hipError_t e = queue_read(c, f->h_cur.data(), cur, (ncur + 2) * 4);
       if (e == hipSuccess) e = ctx_sync(c);
@@ -2935,6 +2981,9 @@ int rfx_count_prepare_maps(rfx_table* t, rfx_reads* const* blocks, int n) {
     const rfx_reads* r = blocks[i];
     if (!r || r->ctx != c || r->max_len > 160 || r->n == 0) continue;
     if (runmap_get(t, r, false, &rc) || t->runmaps->m.count(r)) continue;  // there already (or known to be no block for one)
+    bool twice = false;  // (a block named twice: ONE launch, one entry)
+    for (const runmap_pending& q : pend) twice = twice || q.r == r;
+    if (twice) continue;
     pend.emplace_back();
     if (!runmap_launch(t, r, pend.back())) {  // no room: neither will the rest find any
       (void)runmap_finish(t, pend.back(), false, &rc);

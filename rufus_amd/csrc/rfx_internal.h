@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -133,6 +134,7 @@ struct rfx_runmap_entry {
   uint32_t n_ovf = 0;
   uint32_t n_reads = 0;
   const uint64_t* codes = nullptr;  // (of the block the map was made from: a block freed and another in its place is not it)
+  uint64_t gen = 0;                 // rfx_reads::gen of that block: the arena hands a freed block's addresses out again
   int k = 0, canonical = 0;
   size_t bytes = 0, map_bytes = 0, ovf_bytes = 0;
 };
@@ -184,8 +186,15 @@ __device__ __forceinline__ const uint32_t* rv_acgt(const rfx_reads_view& rv, uin
 }
 #endif
 
+inline uint64_t rfx_next_reads_gen() {  // process-wide, never 0
+  static std::atomic<uint64_t> next{1};
+  return next.fetch_add(1, std::memory_order_relaxed);
+}
 struct rfx_reads {
   rfx_ctx* ctx;
+  // Unique per block for the life of the process: what is keyed by the block's ADDRESS (run maps) checks it, because a
+  // freed block is often followed by one of the same read count at the same host and device addresses.
+  uint64_t gen = rfx_next_reads_gen();
   uint32_t n;
   uint64_t n_words, n_bases;
   uint32_t max_len;

@@ -122,6 +122,7 @@ extern "C" rfx_reads* rfx_synth_reads(rfx_ctx* c, const rfx_synth* p, uint64_t f
   (void)hipSetDevice(c->device);
   rfx_reads* r = new rfx_reads();
   memset(r, 0, sizeof *r);
+  r->gen = rfx_next_reads_gen();
   r->ctx = c;
   r->n = n_pairs * 2;
   r->n_words = (uint64_t)r->n * wpr;

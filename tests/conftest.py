@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by `pytest -m gpu` on the GPU box)")
 
 
+def require_ref(tool="RUFUS.Filter"):
+    """Path of a reference binary under oracle/_ref (built by `make -C oracle ref` from /root/reference/src; git-ignored,
+    NOT gpurun-ignored: it travels to the GPU box with the snapshot).  Where it is supposed to be there -- on a box with a
+    GPU, or wherever the reference tree is present -- its absence FAILS the test: a parity test against the reference's own
+    binary that quietly skips is a hole nobody sees (VERDICT r5 "What's weak" #1).  Only a checkout without the reference
+    and without a GPU skips."""
+    path = os.path.join(ROOT, "oracle", "_ref", tool)
+    if os.path.exists(path):
+        return path
+    has_gpu = os.path.exists("/dev/kfd")
+    if has_gpu or os.path.isdir("/root/reference/src"):
+        pytest.fail(f"oracle/_ref/{tool} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` where "
+                    "/root/reference exists and let the built oracle/_ref travel (it must not be listed in .gpurunignore)")
+    pytest.skip("oracle/_ref not built (no reference tree, no GPU)")
+
+
 @pytest.fixture(scope="session")
 def testrun():
     """The reference's own test trio (testRun/*.mate{1,2}.fastq) + expected values (tests/golden/make_golden.py)."""

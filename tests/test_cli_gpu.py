@@ -124,9 +124,8 @@ def test_filter_pieces_and_ragged_records_match_the_reference_binary(tmp_path, r
     """More records than one pipeline piece (65536), reads of every length from 26 up, N and lower-case bases, low
     qualities, no newline after the last record -- through the mapped-file, the read() and the pipe route of the
     reader; byte-identical to the reference's own binary (one thread: its output order is then input order)."""
-    ref = os.path.join(ROOT, "oracle", "_ref", "RUFUS.Filter")
-    if not os.path.exists(ref):
-        pytest.skip("oracle/_ref not built")
+    from tests.conftest import require_ref
+    ref = require_ref("RUFUS.Filter")
     from rufus_amd import capi
     d = str(tmp_path)
     n_pairs, G = 70_000, 700_000
@@ -429,9 +428,8 @@ def test_subject_stream_is_ingested_once_through_a_spool(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr
     # the reference route: the REFERENCE's stranded feeder and filter (oracle/_ref, one thread: input order)
-    ref = os.path.join(ROOT, "oracle", "_ref")
-    if not os.path.exists(f"{ref}/RUFUS.Filter"):
-        pytest.skip("oracle/_ref not built")
+    from tests.conftest import require_ref
+    ref = os.path.dirname(require_ref("RUFUS.Filter"))
     r = subprocess.run(f"{ref}/PassThroughSamCheck.stranded two.chr two < in.sam > two.log && "
                        f"{ref}/RUFUS.Filter hl two.mate1.fastq two.mate2.fastq two 25 15 1 1", shell=True, cwd=d,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE)

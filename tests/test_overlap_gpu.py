@@ -15,7 +15,15 @@ from tests.synth import make_trio
 pytestmark = pytest.mark.gpu
 BIN = os.path.join(ROOT, "rufus_amd", "bin")
 REF = os.path.join(ROOT, "oracle", "_ref")
-needs_ref = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "OverlapSam")), reason="oracle/_ref not built")
+
+
+@pytest.fixture
+def _ref_built():
+    from tests.conftest import require_ref
+    require_ref("OverlapSam")   # (fails, not skips, on a GPU box without the reference binaries)
+
+
+needs_ref = pytest.mark.usefixtures("_ref_built")
 
 
 def align3_one(a: bytes, b: bytes, min_pct: float, min_ovl: int, strict3: bool, init: int):

@@ -42,7 +42,7 @@ READ_LEN = 150
 SEED = 12345
 
 # every launch of the count -> sorted-records stage, whichever path rfx_count_add/finish took
-K2_CHAIN = ("k_msp_part1", "k_msp_map", "k_msp_replay", "k_msp_count", "k_bin_offsets", "k_rec_hist", "k_part2", "k_bin_hist", "k_part3", "k_part4", "k_msp_leaf",
+K2_CHAIN = ("k_msp_part1", "k_msp_map", "k_msp_replay", "k_msp_count", "k_bin_offsets", "k_rec_hist", "k_part2", "k_bin_hist", "k_part3", "k_part4", "k_msp_leaf", "k_surv_place",
             "k_surv_hist", "k_surv_part2", "k_surv_part3", "k_surv_sort", "k_histo",
             "k_bin_count", "k_bin_scatter", "k_part1", "k_leaf", "k_leaf_compact", "k_count_reads")
 

@@ -1684,8 +1684,13 @@ static void rfx_reads_release_pending(const rfx_reads* r) {
 // totals, the capacity flags of this emit AND of the pending adds, and the histogram come back together.
 // Queueing and collecting are separate steps so that a caller can queue several tables before it
 // waits for the first (rfx_count_finish_begin / _end).
+// words behind the ncur coarse cursors of an emit: [ncur] a capacity came short (the emit is run again), [ncur + 1] a bin
+// could not be split far enough (error), [ncur + 2] staging chunks the leaf's pool came short by (max over its launches)
+constexpr size_t RFX_CUR_TAIL = 3;
+
 struct rfx_finish {
   rfx_table* t = nullptr;
+  uint32_t stage_extra = 0;  // staging chunks on top of the estimate: what an earlier attempt came short by
   uint64_t lower = 0, upper = 0;
   uint64_t* histo = nullptr;
   rfx_records* ready = nullptr;  // result computed at begin (paths without a queued form)
@@ -1703,6 +1708,32 @@ struct rfx_finish {
   std::vector<uint32_t> h_cur;
   std::vector<unsigned int> pflags;
 };
+
+// Survivors the leaf will stage per k-mer instance: what the last emit on this ctx saw (+30 %), else the first guess of
+// the survivor store (msp_emit_queue).
+static double msp_surv_guess(rfx_ctx* c, uint64_t lower, uint64_t kmers) {
+  const double seen = c->msp_surv_frac[lower >= 2 ? 1 : 0];
+  double frac = seen > 0 ? seen * 1.3 : (lower >= 2 ? (kmers > (1ull << 32) ? 0.08 : 0.25) : 0.6);
+  if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
+  return frac;
+}
+
+// the staging pool of a table's leaf launches (rfxk::msp_stage): keys, counts, and ONE zeroed block of fills + per-launch counters
+static int leaf_stage_alloc(rfx_ctx* c, uint32_t chunk, uint32_t n_chunks, uint32_t launches, rfxk::msp_stage* st) {
+  st->chunk = chunk;
+  st->n_chunks = n_chunks;
+  st->keys = (uint64_t*)dmalloc(c, (size_t)n_chunks * chunk * 8);
+  st->counts = (uint32_t*)dmalloc(c, (size_t)n_chunks * chunk * 4);
+  st->fill = (uint32_t*)dmalloc(c, ((size_t)n_chunks + launches) * 4);
+  st->more = st->fill ? st->fill + n_chunks : nullptr;
+  if (!st->keys || !st->counts || !st->fill) return RFX_E_NOMEM;
+  HIPCHK(hipMemsetAsync(st->fill, 0, ((size_t)n_chunks + launches) * 4, c->stream));
+  return RFX_OK;
+}
+static void leaf_stage_free(rfx_ctx* c, rfxk::msp_stage* st) {  // (stream-ordered pool: reused only by later work of the stream)
+  dfree(c, st->keys); dfree(c, st->counts); dfree(c, st->fill);
+  *st = rfxk::msp_stage{};
+}
 
 static void msp_emit_drop(rfx_finish* f) {
   rfx_ctx* c = f->t->ctx;
@@ -1851,12 +1882,16 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
         ch += h_bs[si][(size_t)cut[ci + 1] * (kv.second.b / bmin)] - h_bs[si][(size_t)cut[ci] * (kv.second.b / bmin)];
     max_chunk_all = std::max(max_chunk_all, ch);
   }
-  uint32_t lgrid = 1, lchunk = 1;
-  rfxk::msp_leaf_plan(c, (uint32_t)std::min<size_t>((size_t)max_np * Ftot, 1u << 30), geo, max_chunk_all, &lgrid, &lchunk);
-  const size_t n_stage = (size_t)lgrid * lchunk;
-  uint64_t* stage_k = (uint64_t*)dmalloc(c, n_stage * 8);
-  uint32_t* stage_c = (uint32_t*)dmalloc(c, n_stage * 4);
-  if (!stage_k || !stage_c) { drop(); dfree(c, d_ptrs); dfree(c, stage_k); dfree(c, stage_c); return RFX_E_NOMEM; }
+  // (the survivors of the largest chunk: its share of the k-mer instances x the expected survivors per instance)
+  uint32_t lgrid = 1, lchunk = 1, lpool = 1;
+  const uint64_t est_surv = R ? (uint64_t)((double)kmers * msp_surv_guess(c, f->lower, kmers) * (double)max_chunk_all / (double)R) : 0;
+  rfxk::msp_leaf_plan(c, (uint32_t)std::min<size_t>((size_t)max_np * Ftot, 1u << 30), geo, max_chunk_all, est_surv, f->stage_extra,
+                      &lgrid, &lchunk, &lpool);
+  rfxk::msp_stage stage;
+  {
+    const int src = leaf_stage_alloc(c, lchunk, lpool, (uint32_t)cut.size(), &stage);
+    if (src) { drop(); dfree(c, d_ptrs); leaf_stage_free(c, &stage); return src; }
+  }
   for (size_t ci = 0; ci + 1 < cut.size(); ++ci) {
     const uint32_t p0 = cut[ci], np = cut[ci + 1] - cut[ci];
     const size_t n2 = (size_t)np * Ftot;
@@ -1930,16 +1965,15 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
     if (!chunk_all) continue;
     const uint64_t** d = d_ptrs + 3 * nleaf * ci;
     const hipError_t e = upload(c, d, ptrs.data(), 3 * nleaf * sizeof(void*));
-    if (e != hipSuccess) { drop(); dfree(c, d_ptrs); dfree(c, stage_k); dfree(c, stage_c); return hip_fail(e, "msp_leaf_refined"); }
+    if (e != hipSuccess) { drop(); dfree(c, d_ptrs); leaf_stage_free(c, &stage); return hip_fail(e, "msp_leaf_refined"); }
     rfxk::msp_leaf(c, d, d + nleaf, (int)nleaf, ptrs[0], ptrs[nleaf], (uint32_t)n2, t->k, t->canonical, t->lut_t, t->ntab,
                    sel_bits, 2 * t->k - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur, (uint32_t)f->cap,
-                   cur + ncur, cur + ncur + 1, geo, (const uint32_t* const*)(d + 2 * nleaf), (const uint32_t*)ptrs[2 * nleaf],
-                   stage_k, stage_c, std::min<uint32_t>(lgrid, (uint32_t)n2), lchunk);
+                   cur + ncur, cur + ncur + 1, cur + ncur + 2, geo, (const uint32_t* const*)(d + 2 * nleaf),
+                   (const uint32_t*)ptrs[2 * nleaf], stage, (uint32_t)ci, std::min<uint32_t>(lgrid, (uint32_t)n2));
   }
   drop();  // stream-ordered pool
   dfree(c, d_ptrs);
-  dfree(c, stage_k);
-  dfree(c, stage_c);
+  leaf_stage_free(c, &stage);
   return RFX_OK;
 }
 
@@ -2231,13 +2265,13 @@ static int msp_passes_leaf(rfx_finish* f) {
       t->runmaps_owned = t->runmaps != nullptr;
     }
   }
-  const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + 2) * 4;
+  const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + RFX_CUR_TAIL) * 4;
   f->bsq = (uint64_t*)dmalloc(c, zero_bytes);
   if (!f->bsq) return RFX_E_NOMEM;
   uint32_t* cur = (uint32_t*)((unsigned long long*)f->bsq + RFX_HISTO_BINS);
   HIPCHK(hipMemsetAsync(f->bsq, 0, zero_bytes, c->stream));
-  std::vector<uint32_t> cur_prev(ncur + 2, 0);
-  f->h_cur.assign(ncur + 2, 0);
+  std::vector<uint32_t> cur_prev(ncur + RFX_CUR_TAIL, 0);
+  f->h_cur.assign(ncur + RFX_CUR_TAIL, 0);
   f->kmers = 0;
   const rfx_ord_cfg cfg0 = ord_cfg(t, 7);
   // (an outer shard -- rfx_count_set_shard before rfx_count_set_passes: one device of several, rfx_count_set_peers --
@@ -2289,11 +2323,11 @@ static int msp_passes_leaf(rfx_finish* f) {
     for (int attempt = 0;; ++attempt) {
       rc = msp_leaf_refined(f, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
       if (rc == RFX_E_NOMEM && msp_give_up_own_runmaps(t)) {  // the maps go, the pass's leaf is queued once more
-        HIPCHK(upload(c, cur, cur_prev.data(), (ncur + 2) * 4));
+        HIPCHK(upload(c, cur, cur_prev.data(), (ncur + RFX_CUR_TAIL) * 4));
         rc = msp_leaf_refined(f, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
       }
       if (rc) { (void)ctx_sync(c); return rc; }
-      hipError_t e = queue_read(c, f->h_cur.data(), cur, (ncur + 2) * 4);
+      hipError_t e = queue_read(c, f->h_cur.data(), cur, (ncur + RFX_CUR_TAIL) * 4);
       if (e == hipSuccess) e = ctx_sync(c);
       if (e != hipSuccess) return hip_fail(e, "msp_passes");
       if (f->h_cur[ncur + 1]) {
@@ -2301,6 +2335,9 @@ static int msp_passes_leaf(rfx_finish* f) {
         return RFX_E_FULL;
       }
       if (!f->h_cur[ncur]) break;
+      // (the leaf's staging pool came short: the survivors of the workgroups that found no chunk are missing from the
+      // cursors -- the rerun gets the chunks the counters ask for, and a store that is at least no smaller)
+      if (f->h_cur[ncur + 2]) f->stage_extra += f->h_cur[ncur + 2] + f->h_cur[ncur + 2] / 4 + 64;
       // A coarse pos bin overflowed in this pass.  The cursors kept counting: enlarge the store, put back what
       // the earlier passes left (their content and cursors), and run the pass's leaf again.
       if (attempt >= 3) {
@@ -2324,8 +2361,8 @@ static int msp_passes_leaf(rfx_finish* f) {
       f->aw = naw;
       f->ac = nac;
       f->cap = ncap;
-      cur_prev[ncur] = cur_prev[ncur + 1] = 0;
-      HIPCHK(upload(c, cur, cur_prev.data(), (ncur + 2) * 4));
+      cur_prev[ncur] = cur_prev[ncur + 1] = cur_prev[ncur + 2] = 0;
+      HIPCHK(upload(c, cur, cur_prev.data(), (ncur + RFX_CUR_TAIL) * 4));
     }
     p2l_drop_segments(t);
     drop_own();
@@ -2468,8 +2505,8 @@ static int peers_exchange(rfx_finish* f, uint32_t* d_cur, size_t ncur) {
   f->cap = ncap;
   f->cb_lo = lo;
   for (uint32_t cb = 0; cb < P1; ++cb) f->h_cur[(size_t)cb * stride] = cb >= lo && cb < hi ? (uint32_t)tot[cb] : 0u;
-  f->h_cur[ncur] = f->h_cur[ncur + 1] = 0;
-  if (upload(c, d_cur, f->h_cur.data(), (ncur + 2) * 4) != hipSuccess) return RFX_E_HIP;
+  f->h_cur[ncur] = f->h_cur[ncur + 1] = f->h_cur[ncur + 2] = 0;
+  if (upload(c, d_cur, f->h_cur.data(), (ncur + RFX_CUR_TAIL) * 4) != hipSuccess) return RFX_E_HIP;
   return RFX_OK;
 }
 
@@ -2531,12 +2568,12 @@ static int msp_emit_queue(rfx_finish* f) {
     f->aw = (uint64_t*)dmalloc(c, f->cap * P1 * 8);
     f->ac = (uint32_t*)dmalloc(c, f->cap * P1 * 4);
     // one zeroed block: histogram, coarse cursors ([ncur] = capacity flag, [ncur+1] = error)
-    const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + 2) * 4;
+    const size_t zero_bytes = (size_t)RFX_HISTO_BINS * 8 + (ncur + RFX_CUR_TAIL) * 4;
     f->bsq = (uint64_t*)dmalloc(c, zero_bytes);
     if (!f->aw || !f->ac || !f->bsq) return fail(RFX_E_NOMEM);
     e = hipMemsetAsync(f->bsq, 0, zero_bytes, c->stream);
     if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
-    f->h_cur.assign(ncur + 2, 0);
+    f->h_cur.assign(ncur + RFX_CUR_TAIL, 0);
   }
   const uint64_t cap = f->cap, room = cap * P1;
   f->room = room;
@@ -2565,18 +2602,20 @@ static int msp_emit_queue(rfx_finish* f) {
     if (const char* ev = getenv("RFX_MSP_GEO")) geo = atoi(ev) != 0;
     uint64_t n_rec_all = 0;
     for (auto& sg : *t->segs) n_rec_all += sg.n;
-    uint32_t lgrid = 1, lchunk = 1;
-    rfxk::msp_leaf_plan(c, P, geo, n_rec_all, &lgrid, &lchunk);
-    const size_t n_stage = (size_t)lgrid * lchunk;
-    uint64_t* stage_k = (uint64_t*)dmalloc(c, n_stage * 8);
-    uint32_t* stage_c = (uint32_t*)dmalloc(c, n_stage * 4);
-    if (!stage_k || !stage_c) { dfree(c, stage_k); dfree(c, stage_c); return fail(RFX_E_NOMEM); }
+    uint32_t lgrid = 1, lchunk = 1, lpool = 1;
+    // (no more survivors than the store was sized for: its capacity is the estimate, or what a rerun asked for)
+    rfxk::msp_leaf_plan(c, P, geo, n_rec_all, std::min<uint64_t>((uint64_t)((double)kmers * msp_surv_guess(c, f->lower, kmers)), room),
+                        f->stage_extra, &lgrid, &lchunk, &lpool);
+    rfxk::msp_stage stage;
+    {
+      const int src = leaf_stage_alloc(c, lchunk, lpool, 1, &stage);
+      if (src) { leaf_stage_free(c, &stage); return fail(src); }
+    }
     rfxk::msp_leaf(c, f->d_inst, f->d_inst + nseg, nseg, f->h_ptrs[0], f->h_ptrs[nseg], P, t->k, t->canonical, t->lut_t,
                    t->ntab, cfg0.sel_bits, cfg0.c_bits - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur,
-                   (uint32_t)cap, cur + ncur, cur + ncur + 1, geo, (const uint32_t* const*)(f->d_inst + 2 * nseg),
-                   (const uint32_t*)f->h_ptrs[2 * nseg], stage_k, stage_c, lgrid, lchunk);
-    dfree(c, stage_k);  // stream-ordered pool
-    dfree(c, stage_c);
+                   (uint32_t)cap, cur + ncur, cur + ncur + 1, cur + ncur + 2, geo, (const uint32_t* const*)(f->d_inst + 2 * nseg),
+                   (const uint32_t*)f->h_ptrs[2 * nseg], stage, 0, lgrid);
+    leaf_stage_free(c, &stage);  // stream-ordered pool
   } else {
     {
       const int rc = msp_leaf_refined(f, to_bits, h_bs, cfg0.sel_bits, cur, ncur);
@@ -2584,7 +2623,7 @@ static int msp_emit_queue(rfx_finish* f) {
     }
     // A big table: look at the flags now, while the records are still there for a rerun, and let the records
     // go before the survivors are sorted (at WGS scale both do not fit side by side).
-    e = queue_read(c, f->h_cur.data(), cur, (ncur + 2) * 4);
+    e = queue_read(c, f->h_cur.data(), cur, (ncur + RFX_CUR_TAIL) * 4);
     if (e == hipSuccess) e = ctx_sync(c);
     if (e != hipSuccess) { hip_fail(e, "msp_emit"); return fail(RFX_E_HIP); }
     if (f->h_cur[ncur + 1]) {
@@ -2594,9 +2633,11 @@ static int msp_emit_queue(rfx_finish* f) {
     if (f->h_cur[ncur]) {  // a coarse pos bin overflowed: once more with what the fullest one needs
       uint64_t need = 1;
       for (uint32_t cb = 0; cb < P1; ++cb) need = std::max<uint64_t>(need, f->h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
-      if (need <= f->cap) need = f->cap + f->cap / 4;
+      const uint32_t short_by = f->h_cur[ncur + 2];  // ... or the leaf's staging pool came short (or both)
+      if (short_by) f->stage_extra += short_by + short_by / 4 + 64;
+      if (need <= f->cap) need = short_by ? f->cap : f->cap + f->cap / 4;
       msp_emit_drop(f);
-      f->cap = need + need / 64 + 1024;
+      f->cap = short_by && need <= f->cap ? f->cap : need + need / 64 + 1024;
       return msp_emit_queue(f);
     }
     uint64_t rec_bytes = 0;
@@ -2655,7 +2696,7 @@ static int msp_emit_queue(rfx_finish* f) {
                   f->big->pos);
   f->total_out = 0;
   e = queue_read(c, &f->total_out, sbs + Pq, 8);
-  if (e == hipSuccess && !refine) e = queue_read(c, f->h_cur.data(), cur, (ncur + 2) * 4);
+  if (e == hipSuccess && !refine) e = queue_read(c, f->h_cur.data(), cur, (ncur + RFX_CUR_TAIL) * 4);
   for (size_t i = 0; i < f->pflags.size() && e == hipSuccess; ++i)
     e = queue_read(c, &f->pflags[i], (*t->pend)[i].cur + (*t->pend)[i].ncur, 4);
   if (e == hipSuccess && f->histo) e = queue_read(c, f->histo, d_histo, RFX_HISTO_BINS * 8);
@@ -2691,9 +2732,14 @@ static int msp_emit_collect(rfx_finish* f, rfx_records** out) {
     return RFX_E_FULL;
   }
   if (f->h_cur[ncur]) {  // a coarse pos bin overflowed: rerun with what the fullest one needs
+    const uint64_t had = f->cap;
     f->cap = 1;
     for (uint32_t cb = 0; cb < P1; ++cb)
       f->cap = std::max<uint64_t>(f->cap, f->h_cur[(size_t)cb * rfxk::p1_cur_stride()]);
+    if (const uint32_t short_by = f->h_cur[ncur + 2]) {  // the leaf's staging pool came short: the cursors say too little
+      f->stage_extra += short_by + short_by / 4 + 64;
+      f->cap = std::max(f->cap, had);
+    }
     rfx_records_free(big);
     return 1;
   }

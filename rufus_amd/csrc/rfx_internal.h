@@ -417,15 +417,26 @@ void msp_replay(rfx_ctx*, const rfx_reads_view&, const void* map, int k, int can
                 uint32_t bin_hi, int grid, void* rec_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
                 unsigned int* flag, int slab_log2);
 inline uint64_t msp_part1_slack(int grid, int slab_log2) { return (uint64_t)grid * 3u << slab_log2; }
+// The staging pool of the leaf's launches (rfx_msp.hip k_msp_leaf / k_surv_place): n_chunks chunks of `chunk` (key, count)
+// pairs, fill[n_chunks] (zeroed once: k_surv_place puts every fill back to 0), more[launches] (zeroed once: chunks handed
+// out beyond the first `grid` of launch i).
+struct msp_stage {
+  uint64_t* keys = nullptr;
+  uint32_t* counts = nullptr;
+  uint32_t* fill = nullptr;
+  uint32_t* more = nullptr;
+  uint32_t chunk = 0, n_chunks = 0;
+};
 void msp_leaf(rfx_ctx*, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err,
-              int geo /* 0: 1024 threads + 8192 slots, 1: 512 + 4096 (two per CU) */,
-              const uint32_t* const* seg_ext, const uint32_t* ext0 /* the records' planes */,
-              uint64_t* stage_k, uint32_t* stage_c /* grid * chunk entries each: survivors staged per workgroup */,
-              uint32_t grid, uint32_t chunk /* from msp_leaf_plan */);
-void msp_leaf_plan(rfx_ctx*, uint32_t P, int geo, uint64_t n_records, uint32_t* grid, uint32_t* chunk);
+              unsigned int* stage_short /* chunks the pool came short by (max over the launches) */,
+              int geo /* 0: 1024 threads + 8192 slots, 1: 768 + 4096 (two per CU) */,
+              const uint32_t* const* seg_ext, const uint32_t* ext0 /* the records' planes */, const msp_stage& st,
+              uint32_t launch /* index into st.more */, uint32_t grid /* from msp_leaf_plan */);
+void msp_leaf_plan(rfx_ctx*, uint32_t P, int geo, uint64_t n_records, uint64_t est_survivors, uint32_t extra, uint32_t* grid,
+                   uint32_t* chunk, uint32_t* n_chunks);
 void surv_hist(rfx_ctx*, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,
                uint64_t* fine_tot, int rec_mode = 0 /* 1 / 2: super-k-mer records, see part2 */, int k = 0,
                uint64_t n_hint = 0);

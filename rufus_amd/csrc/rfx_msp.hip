@@ -817,9 +817,15 @@ constexpr uint32_t MSP_LEAF_BLK(int geo) { return geo ? (uint32_t)RFX_LEAF_BLK :
 #endif
 constexpr int MSP_LEAF_WPE(int geo) { return geo ? RFX_LEAF_WPE : 4; }  // waves per SIMD the registers must leave room for
 constexpr uint32_t MSP_LEAF_PASS_MAX(int geo) { return (geo ? 4096u : 8192u) * 3 / 4 + MSP_LEAF_BLK(geo); }
-// survivors a workgroup stages before it scatters them (big inputs): flushed from 3840 / 7680 on -- a round of the flush
-// sorts at most TBL = 4096 / 8192 of them through the k-mer table's arrays, and a bin adds ~400 -- + room for one pass
-constexpr uint32_t MSP_LEAF_STAGE(int geo) { return (geo ? 3840u : 7680u) + MSP_LEAF_PASS_MAX(geo); }
+// Survivors leave the leaf through STAGING CHUNKS in global memory (round 6): a workgroup owns one chunk at a time, phase C
+// appends (key, count) pairs to it, and when the chunk could not take another pass the workgroup writes down how full it
+// is and takes the next free chunk of the launch's pool (one global atomic per ~30 bins, by thread 0, nobody waits for it
+// but its own wave).  k_surv_place, launched behind the leaf, turns every chunk into sorted runs of the 128 coarse pos
+// bins.  Until round 5 the workgroup did that itself ("flush", every ~10 bins): T * key from a borrowed LDS table, a
+// count, a two-wave scan, a reservation between two barriers, a sort through the k-mer table's arrays -- 8 % of the
+// kernel's time, and the reason the compiler wanted 84 VGPRs where two 768-thread workgroups per CU leave 80: a tenth of
+// the issued instructions were v_readlane / v_writelane of spilled SGPRs (the 30 kernel arguments, half of them the flush's).
+constexpr uint32_t MSP_LEAF_CHUNK(int geo, bool big) { return big ? (geo ? 16384u : 32768u) : MSP_LEAF_PASS_MAX(geo) + 512u; }
 #ifndef MSP_ILP_OVERRIDE
 #define MSP_ILP_OVERRIDE 3
 #endif
@@ -858,11 +864,10 @@ template <bool CANON, int GEO>
 __global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) __attribute__((amdgpu_waves_per_eu(MSP_LEAF_WPE(GEO), MSP_LEAF_WPE(GEO)))) void k_msp_leaf(
     const uint64_t* const* __restrict__ seg_inst, const uint64_t* const* __restrict__ seg_bs, int nseg,
     const uint64_t* __restrict__ inst0, const uint64_t* __restrict__ bs0, const uint32_t* const* __restrict__ seg_ext,
-    const uint32_t* __restrict__ ext0, uint32_t P, int k,
-    const uint64_t* __restrict__ g_lut, int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi,
-    uint64_t lower, uint64_t upper, uint64_t* __restrict__ out_w, uint32_t* __restrict__ out_c,
-    uint32_t* __restrict__ cur, uint32_t cap, unsigned int* __restrict__ flag, unsigned int* __restrict__ err,
-    uint64_t* __restrict__ stage_k, uint32_t* __restrict__ stage_c, uint32_t CH, int force_mixed) {
+    const uint32_t* __restrict__ ext0, uint32_t P, int k, uint64_t lower, uint64_t upper,
+    uint64_t* __restrict__ stage_k, uint32_t* __restrict__ stage_c, uint32_t CH, uint32_t* __restrict__ stage_fill,
+    uint32_t* __restrict__ stage_more, uint32_t n_chunks, unsigned int* __restrict__ flag, unsigned int* __restrict__ err,
+    unsigned int* __restrict__ stage_short, int force_mixed) {
   constexpr int TBL_LOG2 = GEO ? 12 : 13, TBL = 1 << TBL_LOG2, BLK = (int)MSP_LEAF_BLK(GEO), FILL = TBL * 3 / 4;
   static_assert(MSP_LEAF_PASS_MAX(GEO) >= (uint32_t)(FILL + BLK) && FILL + BLK <= TBL, "what a pass can leave behind fits the chunk and the table");
   constexpr int RC_LOG2 = TBL_LOG2 - (GEO ? RFX_RC_SHRINK : 2), RC = 1 << RC_LOG2, KMAP = TBL;
@@ -879,13 +884,10 @@ __global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) __attribute__((amdgpu_waves_per_
   __shared__ uint32_t s_rc[RC], s_rmin[RC], s_rmax[RC];
   __shared__ uint32_t s_mixed[2];
   __shared__ __attribute__((aligned(16))) uint16_t s_kmap[KMAP];
-  __shared__ uint32_t s_pc[P1_BINS], s_pst[P1_BINS], s_nfl;
-  __shared__ uint64_t s_pbase[P1_BINS];
+  __shared__ uint32_t s_chunk;  // the staging chunk the workgroup appends to (written by thread 0 between two passes)
   // by parity of the pass: distinct keys, overflow, k-mer map fill, survivors of the scan (zeroed for the NEXT pass by
   // thread 0 after the first barrier of a pass: nobody reads the other parity's between that barrier and the next pass)
   __shared__ uint32_t s_nd[2], s_ovf[2], s_nk[2], s_ns[2];
-  uint64_t* const stk = stage_k + (size_t)blockIdx.x * CH;
-  uint32_t* const stc = stage_c + (size_t)blockIdx.x * CH;
 
   uint64_t pre[MSP_ILP];
   uint32_t prex[MSP_ILP];
@@ -920,123 +922,11 @@ __global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) __attribute__((amdgpu_waves_per_
     s_rmin[i] = ~0u;
     s_rmax[i] = 0;
   }
-  if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_chunk = blockIdx.x;  // (the launch's pool: gridDim.x chunks handed out here, the others by stage_more)
   if (threadIdx.x < 2) s_nd[threadIdx.x] = s_ovf[threadIdx.x] = s_nk[threadIdx.x] = s_ns[threadIdx.x] = s_mixed[threadIdx.x] = 0;
   uint32_t used = 0;  // entries of the staging chunk in use (the same in every thread)
   uint32_t X = 0;     // parity of the pass
   __syncthreads();
-
-  // F: staged survivors -> w = T * key -> the 128 coarse pos bins
-  // The 8 x 256-entry table of T (14-16 KB) is read from LDS: it borrows the k-mer map and the record cache's key array,
-  // both idle between two bins (the cache's keys are put back to "empty" at the end); from global memory seven gathers
-  // per survivor cost what scattered stores cost.  78.0 instead of 81 ms per 1 Gb sample.
-  // (Measured and not kept, round 4: the flush in ONE pass over the chunk -- per-workgroup slabs in the coarse bins that
-  // carry over from launch to launch, no count pass, no reservation between two barriers -- and eight instead of four
-  // staged entries in flight per lane: 78 ms both.  With the flush skipped altogether the kernel takes 62 ms.)
-  static_assert(KMAP * 2 >= 4 * 256 * 8 && RC * 8 >= 4 * 256 * 8, "the T table borrows s_kmap (tables 0-3) and s_rk (4-7)");
-  constexpr int NE = (TBL + BLK - 1) / BLK;  // staged entries a lane carries through one round (<= TBL entries) of the flush
-  auto flush = [&]() {
-    uint64_t* const lut_lo = (uint64_t*)s_kmap;
-    uint64_t* const lut_hi = (uint64_t*)s_rk;
-    TMF_DECL;
-    TMC(31, 1);
-    auto t_mul = [&](uint64_t key) {
-      uint64_t r = 0;
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-        if (t < ntab) r ^= (t < 4 ? lut_lo : lut_hi - 1024)[t * 256 + (uint32_t)((key >> (8 * t)) & 255u)];
-      return r;
-    };
-    // Round 5: the chunk leaves SORTED by coarse bin.  Until then every lane stored its entries where their bins' cursors
-    // pointed: a wave's store went to 64 places, and the scatter -- 2 % of the kernel's instructions -- took 8 % of its
-    // time (-DRFX_TIMING; that the next loads waited behind those stores was the first suspect: entries kept in
-    // registers from the count to the scatter changed nothing).  Now a round of at most TBL entries is counted per bin,
-    // placed in bin order in the k-mer table's own arrays (idle between two bins, every slot empty), and written out by
-    // consecutive lanes to consecutive addresses: a bin's ~30 entries are 4 cache lines, not 30 stores.
-    for (uint32_t base = 0; base < used; base += (uint32_t)TBL) {
-      const uint32_t n_in = min((uint32_t)TBL, used - base);
-      uint64_t kv[NE];
-#pragma unroll
-      for (int u = 0; u < NE; ++u) {
-        const uint32_t i = threadIdx.x + (uint32_t)u * BLK;
-        kv[u] = i < n_in ? stk[base + i] : RFX_EMPTY;
-      }
-      if (base == 0) {
-        for (int i = threadIdx.x; i < ntab * 256; i += BLK) (i < 1024 ? lut_lo[i] : lut_hi[i - 1024]) = g_lut[i];
-        __syncthreads();
-      }
-      TMF(25);
-#pragma unroll
-      for (int u = 0; u < NE; ++u) {
-        if (kv[u] != RFX_EMPTY) {
-          uint64_t w = t_mul(kv[u]);
-          const uint64_t pos = w >> sel_bits;
-          if (pos >= pos_lo && pos < pos_hi) atomicAdd(&s_pc[(uint32_t)(w >> shift1)], 1u);
-          else w = RFX_EMPTY;
-          kv[u] = w;
-        }
-        if (u & 1) __builtin_amdgcn_sched_barrier(0);  // (two products in flight, not NE: 8 table reads each)
-      }
-      uint32_t cv[NE];  // (asked for here: they arrive while the cursors are fetched)
-#pragma unroll
-      for (int u = 0; u < NE; ++u) cv[u] = kv[u] != RFX_EMPTY ? stc[base + threadIdx.x + (uint32_t)u * BLK] : 0u;
-      TMF(26);
-      __syncthreads();
-      TMF(27);
-      if (threadIdx.x < P1_BINS) {  // (two waves) room in the coarse bins; where a bin starts in the sorted round
-        static_assert(P1_BINS == 128, "the scan below is two waves wide");
-        const uint32_t cn = s_pc[threadIdx.x];
-        const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
-        uint32_t incl = cn;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-          const uint32_t up = __shfl_up(incl, d, 64);
-          if ((int)(threadIdx.x & 63u) >= d) incl += up;
-        }
-        uint32_t low = s_pc[threadIdx.x & 63u];  // the first wave's total, for the second
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) low += __shfl_xor(low, d, 64);
-        const uint32_t start = incl - cn + (threadIdx.x >= 64 ? low : 0u);
-        s_pst[threadIdx.x] = start;
-        if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
-          atomicExch(flag, 1u);
-          s_pbase[threadIdx.x] = ~0ull;
-        } else {
-          s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at - start;  // (+ the entry's place in the round)
-        }
-        if (threadIdx.x == P1_BINS - 1) s_nfl = start + cn;
-      }
-      __syncthreads();
-      TMF(28);
-#pragma unroll
-      for (int u = 0; u < NE; ++u) {
-        const uint64_t w = kv[u];
-        if (w == RFX_EMPTY) continue;
-        const uint32_t at = atomicAdd(&s_pst[(uint32_t)(w >> shift1)], 1u);
-        s_keys[at] = w;
-        s_cnt[at] = cv[u];
-      }
-      __syncthreads();
-      const uint32_t n_out = s_nfl;
-      for (uint32_t i = threadIdx.x; i < n_out; i += BLK) {
-        const uint64_t w = s_keys[i];
-        const uint32_t cnt = s_cnt[i];
-        s_keys[i] = RFX_EMPTY;
-        s_cnt[i] = 0;
-        const uint64_t pb = s_pbase[(uint32_t)(w >> shift1)];
-        if (pb != ~0ull) {
-          out_w[pb + i] = w;
-          out_c[pb + i] = cnt;
-        }
-      }
-      if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
-      TMF(29);
-      __syncthreads();  // (the table is whole again: a pass without the cache inserts from its phase A on)
-      TMF(30);
-    }
-    for (int i = threadIdx.x; i < 1024 && i < (ntab - 4) * 256; i += BLK) s_rk[i] = MSP_EMPTY;  // the borrowed cache keys
-    used = 0;
-  };
 
   for (uint32_t bin = blockIdx.x; bin < P; bin += gridDim.x) {
     const uint64_t a0 = pre_a, e0 = pre_e;
@@ -1202,6 +1092,8 @@ __global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) __attribute__((amdgpu_waves_per_
       TMC(24, mixed);
       TMC(21, 1);
       // ---- C: survivors out, everything cleared ----
+      uint64_t* const stk = stage_k + (size_t)s_chunk * CH;
+      uint32_t* const stc = stage_c + (size_t)s_chunk * CH;
       for (int i = threadIdx.x; i < TBL; i += BLK) {
         const uint64_t key = s_keys[i];
         if (key == RFX_EMPTY) continue;
@@ -1230,12 +1122,20 @@ __global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) __attribute__((amdgpu_waves_per_
       // survivors, could write past the workgroup's chunk into its neighbour's -- a handful of garbage keys per 10^8
       // records with -L 1 on a sparse sample, found by tests/test_scale_gpu.py::test_wgs_slice_properties.)
       if (used > CH && threadIdx.x == 0) atomicExch(err, 1u);  // (cannot happen: fail loudly rather than corrupt)
-      if (used > CH - MSP_LEAF_PASS_MAX(GEO)) {  // the chunk could not take another pass
-#ifdef RFX_LEAF_NOFLUSH  // experiment (results void): what the flush costs
+      if (used > CH - MSP_LEAF_PASS_MAX(GEO)) {  // the chunk could not take another pass: on to the next free one
+        // (nobody reads s_chunk between this barrier and phase C of the next pass, two barriers on)
+        if (threadIdx.x == 0) {
+          const uint32_t mine = s_chunk;
+          stage_fill[mine] = used;
+          uint32_t nx = gridDim.x + atomicAdd(stage_more, 1u);
+          if (nx >= n_chunks) {  // the pool is spent: the host runs the launch again with the pool the counters ask for;
+            atomicExch(flag, 1u);  // until then this workgroup writes over its own chunk (results void)
+            atomicMax(stage_short, nx - n_chunks + 1u);
+            nx = mine;
+          }
+          s_chunk = nx;
+        }
         used = 0;
-#else
-        flush();
-#endif
         TM(13);
       }
       if (mixed) {  // the same sub-range again
@@ -1260,7 +1160,142 @@ __global__ __launch_bounds__(MSP_LEAF_BLK(GEO)) __attribute__((amdgpu_waves_per_
     }
     if (failed && threadIdx.x == 0) atomicExch(err, 1u);
   }
-  if (used) flush();
+  if (threadIdx.x == 0) stage_fill[s_chunk] = used;
+}
+
+// The staging chunks of a leaf launch -> the 128 coarse pos bins (round 6; until then the leaf's own "flush").  A chunk is
+// stage_fill[ch] <= CH (key, count) pairs as the leaf's phase C left them.  Rounds of SP_N entries: w = T * key (the 8 x 256
+// table of T in LDS), count per coarse bin, ONE reservation per bin and round (128 global atomics whose round trip the
+// other workgroup of the CU covers), the round placed in bin order in LDS and written out by consecutive lanes to
+// consecutive addresses: a bin's ~32 entries of a round are 256 contiguous bytes.  Entries outside [pos_lo, pos_hi)
+// (a table restricted to a range of positions) are dropped; a bin without room raises `flag`, its cursor keeps counting
+// and the host reruns the emit with the capacity the cursors ask for.  Every chunk's fill is put back to 0 on the way:
+// the next launch finds the pool as this one found it.
+#ifndef RFX_SP_BLK
+#define RFX_SP_BLK 512
+#endif
+#ifndef RFX_SP_NE
+#define RFX_SP_NE 8
+#endif
+constexpr int SP_BLK = RFX_SP_BLK, SP_NE = RFX_SP_NE, SP_N = SP_BLK * SP_NE;  // 512 x 8: 64 KB of LDS, two workgroups per CU
+__global__ __launch_bounds__(SP_BLK) void k_surv_place(const uint64_t* __restrict__ stage_k, const uint32_t* __restrict__ stage_c,
+                                                       uint32_t CH, uint32_t* __restrict__ stage_fill,
+                                                       uint32_t* __restrict__ stage_more, uint32_t n_first, uint32_t n_chunks,
+                                                       const uint64_t* __restrict__ g_lut, int ntab, int sel_bits, int shift1,
+                                                       uint64_t pos_lo, uint64_t pos_hi, uint64_t* __restrict__ out_w,
+                                                       uint32_t* __restrict__ out_c, uint32_t* __restrict__ cur, uint32_t cap,
+                                                       unsigned int* __restrict__ flag) {
+  __shared__ uint64_t s_lut[8 * 256];
+  __shared__ uint64_t s_w[SP_N];
+  __shared__ uint32_t s_c[SP_N];
+  __shared__ uint32_t s_pc[P1_BINS], s_pst[P1_BINS], s_nfl;
+  __shared__ uint64_t s_pbase[P1_BINS];
+  static_assert(P1_BINS == 128, "the scan below is two waves wide");
+  for (int i = threadIdx.x; i < ntab * 256; i += SP_BLK) s_lut[i] = g_lut[i];
+  if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t n_used = min(n_first + *stage_more, n_chunks);
+  // The rounds of this workgroup's chunks, one after the other; a round's entries are asked for a round ahead (and a
+  // chunk's fill a chunk ahead): with the loads at the top of the round a workgroup spent most of its time waiting for
+  // them, then for the 128 reservations, with one other workgroup on the CU to cover for it (22 ms per W sample).
+  uint32_t ch = blockIdx.x, base = 0;
+  uint32_t used = ch < n_used ? min(stage_fill[ch], CH) : 0u;
+  uint32_t ch_n = ch + gridDim.x;
+  uint32_t used_n = ch_n < n_used ? min(stage_fill[ch_n], CH) : 0u;
+  auto settle = [&]() {  // (ch, base) -> the next round that has entries, or ch >= n_used
+    while (ch < n_used && base >= used) {
+      if (threadIdx.x == 0 && used) stage_fill[ch] = 0;
+      ch = ch_n;
+      used = used_n;
+      base = 0;
+      ch_n += gridDim.x;
+      used_n = ch_n < n_used ? min(stage_fill[ch_n], CH) : 0u;
+    }
+  };
+  uint64_t nk[SP_NE];
+  uint32_t nc[SP_NE];
+  auto fetch = [&]() {
+    const bool any = ch < n_used;
+    const uint32_t n_in = any ? min((uint32_t)SP_N, used - base) : 0u;
+    const uint64_t* const stk = stage_k + (size_t)(any ? ch : 0u) * CH + base;
+    const uint32_t* const stc = stage_c + (size_t)(any ? ch : 0u) * CH + base;
+#pragma unroll
+    for (int u = 0; u < SP_NE; ++u) {
+      const uint32_t i = threadIdx.x + (uint32_t)u * SP_BLK;
+      nk[u] = i < n_in ? stk[i] : RFX_EMPTY;
+      nc[u] = i < n_in ? stc[i] : 0u;
+    }
+  };
+  settle();
+  fetch();
+  while (ch < n_used) {
+    uint64_t kv[SP_NE];
+    uint32_t cv[SP_NE];
+#pragma unroll
+    for (int u = 0; u < SP_NE; ++u) {
+      kv[u] = nk[u];
+      cv[u] = nc[u];
+    }
+    base += (uint32_t)SP_N;
+    settle();
+    fetch();  // (the next round's: nobody waits for them before the next trip)
+#pragma unroll
+    for (int u = 0; u < SP_NE; ++u) {
+      if (kv[u] == RFX_EMPTY) continue;
+      uint64_t w = 0;
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        if (t < ntab) w ^= s_lut[t * 256 + (uint32_t)((kv[u] >> (8 * t)) & 255u)];
+      const uint64_t pos = w >> sel_bits;
+      if (pos >= pos_lo && pos < pos_hi) atomicAdd(&s_pc[(uint32_t)(w >> shift1)], 1u);
+      else w = RFX_EMPTY;
+      kv[u] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < P1_BINS) {  // (two waves) room in the coarse bins; where a bin starts in the sorted round
+      const uint32_t cn = s_pc[threadIdx.x];
+      const uint32_t at = cn ? atomicAdd(&cur[threadIdx.x * P1_CUR_STRIDE], cn) : 0u;
+      uint32_t incl = cn;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if ((int)(threadIdx.x & 63u) >= d) incl += up;
+      }
+      uint32_t low = s_pc[threadIdx.x & 63u];  // the first wave's total, for the second
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) low += __shfl_xor(low, d, 64);
+      const uint32_t start = incl - cn + (threadIdx.x >= 64 ? low : 0u);
+      s_pst[threadIdx.x] = start;
+      if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
+        atomicExch(flag, 1u);
+        s_pbase[threadIdx.x] = ~0ull;
+      } else {
+        s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at - start;  // (+ the entry's place in the round)
+      }
+      if (threadIdx.x == P1_BINS - 1) s_nfl = start + cn;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SP_NE; ++u) {
+      const uint64_t w = kv[u];
+      if (w == RFX_EMPTY) continue;
+      const uint32_t at = atomicAdd(&s_pst[(uint32_t)(w >> shift1)], 1u);
+      s_w[at] = w;
+      s_c[at] = cv[u];
+    }
+    __syncthreads();
+    const uint32_t n_out = s_nfl;
+    for (uint32_t i = threadIdx.x; i < n_out; i += SP_BLK) {
+      const uint64_t w = s_w[i];
+      const uint64_t pb = s_pbase[(uint32_t)(w >> shift1)];
+      if (pb != ~0ull) {
+        out_w[pb + i] = w;
+        out_c[pb + i] = s_c[i];
+      }
+    }
+    if (threadIdx.x < P1_BINS) s_pc[threadIdx.x] = 0;
+    __syncthreads();
+  }
 }
 
 // Fine bin sizes of the entries in fixed-capacity coarse bins: fine_tot[cb * P2 + sub] += ...  (64-bit
@@ -1458,38 +1493,52 @@ void msp_replay(rfx_ctx* c, const rfx_reads_view& rv, const void* map, int k, in
                        bin_hi, (msp_rec12*)rec_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2);
 }
 
-// Grid and staging chunk of a leaf launch over P bins holding ~n_records records: a workgroup per ~4096 records at least
-// (a small input does not pay for 2048 staging chunks), the full chunk only where it is amortised over many bins.
-void msp_leaf_plan(rfx_ctx* c, uint32_t P, int geo, uint64_t n_records, uint32_t* grid, uint32_t* chunk) {
+// Grid, staging chunk and pool of a leaf launch over P bins holding ~n_records records of which ~est_survivors k-mers
+// will leave: a workgroup per ~4096 records at least (a small input does not pay for 2048 staging chunks), the big chunk
+// only where it is amortised over many bins.  The pool: a chunk per workgroup + what the expected survivors fill when
+// every chunk is left at its emptiest (CH - PASS_MAX entries), half as much again, + `extra` (what an earlier attempt
+// came short by).
+void msp_leaf_plan(rfx_ctx* c, uint32_t P, int geo, uint64_t n_records, uint64_t est_survivors, uint32_t extra, uint32_t* grid,
+                   uint32_t* chunk, uint32_t* n_chunks) {
   const uint32_t per_cu = geo ? 8 : 4;  // (1..8 per CU measured: no difference)
   uint64_t g = std::min<uint64_t>(P, (uint64_t)c->n_cu * per_cu);
   g = std::min<uint64_t>(g, std::max<uint64_t>(1, n_records >> 12));
   *grid = (uint32_t)std::max<uint64_t>(g, 1);
-  const uint32_t fill = (geo ? 4096u : 8192u) * 3 / 4;
-  (void)fill;
-  *chunk = n_records >= (1ull << 24) ? MSP_LEAF_STAGE(geo) : MSP_LEAF_PASS_MAX(geo) + 512u;
+  *chunk = MSP_LEAF_CHUNK(geo, n_records >= (1ull << 24));
+  const uint64_t per = *chunk - MSP_LEAF_PASS_MAX(geo);
+  const uint64_t more = (est_survivors + est_survivors / 2) / per + 16 + extra;
+  *n_chunks = (uint32_t)std::min<uint64_t>((uint64_t)*grid + more, 1u << 30);
 }
 
 void msp_leaf(rfx_ctx* c, const uint64_t* const* seg_inst, const uint64_t* const* seg_bs, int nseg,
               const uint64_t* inst0, const uint64_t* bs0, uint32_t P, int k, int canonical, const uint64_t* lut,
               int ntab, int sel_bits, int shift1, uint64_t pos_lo, uint64_t pos_hi, uint64_t lower, uint64_t upper,
               uint64_t* out_w, uint32_t* out_c, uint32_t* cur, uint32_t cap, unsigned int* flag, unsigned int* err,
-              int geo, const uint32_t* const* seg_ext, const uint32_t* ext0, uint64_t* stage_k, uint32_t* stage_c,
-              uint32_t grid, uint32_t chunk) {
-  rfx_span sp(c, "k_msp_leaf");
+              unsigned int* stage_short, int geo, const uint32_t* const* seg_ext, const uint32_t* ext0, const msp_stage& st,
+              uint32_t launch, uint32_t grid) {
   const int force_mixed = getenv("RFX_LEAF_FORCE_MIXED") != nullptr;
+  uint32_t* const more = st.more + launch;
+  {
+    rfx_span sp(c, "k_msp_leaf");
 #define RFX_MSP_LEAF(CANON, GEO)                                                                                        \
   hipLaunchKernelGGL((k_msp_leaf<CANON, GEO>), dim3(grid), dim3(MSP_LEAF_BLK(GEO)), 0, c->stream, seg_inst, seg_bs, nseg, \
-                     inst0, bs0, seg_ext, ext0, P, k, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, lower, upper, out_w,  \
-                     out_c, cur, cap, flag, err, stage_k, stage_c, chunk, force_mixed)
-  if (canonical) {
-    if (geo) RFX_MSP_LEAF(true, 1);
-    else RFX_MSP_LEAF(true, 0);
-  } else {
-    if (geo) RFX_MSP_LEAF(false, 1);
-    else RFX_MSP_LEAF(false, 0);
-  }
+                     inst0, bs0, seg_ext, ext0, P, k, lower, upper, st.keys, st.counts, st.chunk, st.fill, more,           \
+                     st.n_chunks, flag, err, stage_short, force_mixed)
+    if (canonical) {
+      if (geo) RFX_MSP_LEAF(true, 1);
+      else RFX_MSP_LEAF(true, 0);
+    } else {
+      if (geo) RFX_MSP_LEAF(false, 1);
+      else RFX_MSP_LEAF(false, 0);
+    }
 #undef RFX_MSP_LEAF
+  }
+  {
+    rfx_span sp(c, "k_surv_place");
+    const uint32_t pg = std::min<uint32_t>(st.n_chunks, (uint32_t)c->n_cu * (uint32_t)std::max(1, 160 * 1024 / (16 * 1024 + SP_N * 12 + 2048)));
+    hipLaunchKernelGGL(k_surv_place, dim3(pg), dim3(SP_BLK), 0, c->stream, st.keys, st.counts, st.chunk, st.fill, more, grid,
+                       st.n_chunks, lut, ntab, sel_bits, shift1, pos_lo, pos_hi, out_w, out_c, cur, cap, flag);
+  }
 }
 
 void surv_hist(rfx_ctx* c, const uint64_t* buf_a, const uint32_t* coarse_cur, uint32_t cap_a, uint32_t P2, int shift2,

@@ -1506,7 +1506,10 @@ void msp_leaf_plan(rfx_ctx* c, uint32_t P, int geo, uint64_t n_records, uint64_t
   *grid = (uint32_t)std::max<uint64_t>(g, 1);
   *chunk = MSP_LEAF_CHUNK(geo, n_records >= (1ull << 24));
   const uint64_t per = *chunk - MSP_LEAF_PASS_MAX(geo);
-  const uint64_t more = (est_survivors + est_survivors / 2) / per + 16 + extra;
+  uint64_t more = (est_survivors + est_survivors / 2) / per + 16 + extra;
+  // (a test knob: no chunk beyond the workgroups' first ones until a rerun asks for them -- the route a pool that came
+  // short takes is otherwise taken only when the survivor estimate is far off)
+  if (getenv("RFX_LEAF_STAGE_TEST")) more = extra;
   *n_chunks = (uint32_t)std::min<uint64_t>((uint64_t)*grid + more, 1u << 30);
 }
 

@@ -457,13 +457,16 @@ def test_trio_strong_scaled_over_two_ranks(passes, block_pairs, k):
 
 @pytest.mark.parametrize("k", [K, 31, 27])
 @pytest.mark.parametrize("passes,surv_frac,refine", [(0, None, None), (1, None, None), (3, None, "17"), (4, "0.0005", None),
-                                                      (7, "0.02", "20")])
+                                                      (7, "0.02", "20"), (2, "pool", "16"), (1, "pool", None)])
 def test_table_counts_a_sample_in_shard_passes(ctx, monkeypatch, passes, surv_frac, refine, k):
     """rfx_count_set_passes: the adds only remember the blocks, finish runs the shard passes inside the table
     and sorts the survivors of all passes once -- the full (pos,key)-ordered record list, as the drop-in
     `jellyfish count` writes it.  A starved survivor store (RFX_MSP_SURV_FRAC) exercises the regrow-and-redo
-    of the first and of later passes."""
-    if surv_frac:
+    of the first and of later passes; "pool": the leaf's staging pool starts without a spare chunk
+    (RFX_LEAF_STAGE_TEST), comes short, and the rerun gets the chunks the device asked for."""
+    if surv_frac == "pool":
+        monkeypatch.setenv("RFX_LEAF_STAGE_TEST", "1")
+    elif surv_frac:
         monkeypatch.setenv("RFX_MSP_SURV_FRAC", surv_frac)
     if refine:
         monkeypatch.setenv("RFX_MSP_REFINE_BITS", refine)

@@ -3755,6 +3755,14 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
       return nullptr;
     }
   }
+  if (const int pair = rfxk::filter_p_applies(n, k)) {
+    s->bm5_three = pair == 2;
+    s->bitmap5 = (uint32_t*)dmalloc(c, rfxk::filter_p_table_bytes());
+    if (!s->bitmap5 || hipMemsetAsync(s->bitmap5, 0, rfxk::filter_p_table_bytes(), c->stream) != hipSuccess) {
+      rfx_set_free(s);
+      return nullptr;
+    }
+  }
   uint64_t* dk = (uint64_t*)dmalloc(c, n * 8);
   bool ok = s->slots && dk && s->bitmap && (!bm2_words || s->bitmap2);
   if (ok && bm2_words) ok = hipMemsetAsync(s->bitmap2, 0, bm2_words * 4, c->stream) == hipSuccess;
@@ -3767,6 +3775,7 @@ rfx_set* rfx_set_build(rfx_ctx* c, const uint64_t* fwd_keys, uint64_t n, int k) 
     if (s->bitmap2) rfxk::set_bitmap_packed(c, dk, n, s->bitmap2);
     if (s->bitmap3) rfxk::set_bitmap_big(c, dk, n, s->bitmap3);
     if (s->bitmap4) rfxk::set_bitmap_q(c, dk, n, s->bitmap4, s->bm4_bits, k);
+    if (s->bitmap5) rfxk::set_bitmap_p(c, dk, n, s->bitmap5, k, s->bm5_three);
     // no synchronisation: upload() staged the keys, everything else is ordered on the ctx stream, and a
     // device error surfaces at the first rfx_filter / rfx_annotate (which wait for their results)
   }
@@ -3785,6 +3794,7 @@ void rfx_set_free(rfx_set* s) {
   dfree(s->ctx, s->bitmap2);
   dfree(s->ctx, s->bitmap3);
   dfree(s->ctx, s->bitmap4);
+  dfree(s->ctx, s->bitmap5);
   delete s;
 }
 
@@ -3799,17 +3809,25 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
   const uint64_t nmask = ((uint64_t)r->n + 63) / 64;
   // (the queue filter counts into the array whether the caller wants the counts or not)
   const bool use_q = s->bitmap4 && !getenv("RFX_FILTER_GENERIC") && !getenv("RFX_FILTER_OLD");
-  uint32_t* d_hits = hits_out || use_q ? (uint32_t*)dmalloc(c, (size_t)r->n * 4) : nullptr;
+  // the pair filter (round 6; RFX_FILTER_NO_PAIR at rfx_set_build keeps the set without its table): with thresh = 1 and
+  // nobody asking for the counts, the hits set the mask's bits themselves -- no count array, no memset, no second pass
+  const bool use_p = s->bitmap5 && use_q && !getenv("RFX_FILTER_NO_PAIR");
+  const bool mask_only = use_p && thresh == 1 && !hits_out;
+  uint32_t* d_hits = (hits_out || use_q) && !mask_only ? (uint32_t*)dmalloc(c, (size_t)r->n * 4) : nullptr;
   uint64_t* d_mask = (uint64_t*)dmalloc(c, nmask * 8);
   unsigned long long* d_n = (unsigned long long*)dmalloc(c, 8);
   auto cleanup = [&] { dfree(c, d_hits); dfree(c, d_mask); dfree(c, d_n); };
-  if (((hits_out || use_q) && !d_hits) || !d_mask || !d_n) { cleanup(); return RFX_E_NOMEM; }
+  if (((hits_out || use_q) && !mask_only && !d_hits) || !d_mask || !d_n) { cleanup(); return RFX_E_NOMEM; }
   hipError_t e = hipMemsetAsync(d_n, 0, 8, c->stream);
-  if (e == hipSuccess && use_q) e = hipMemsetAsync(d_hits, 0, (size_t)r->n * 4, c->stream);
+  if (e == hipSuccess && use_q && !mask_only) e = hipMemsetAsync(d_hits, 0, (size_t)r->n * 4, c->stream);
+  if (e == hipSuccess && mask_only) e = hipMemsetAsync(d_mask, 0, nmask * 8, c->stream);
   if (e == hipSuccess) {
     const rfx_reads_view rv = r->view();
     // RFX_FILTER_OLD: round 2's k_filter_fast / k_filter_big (kept for A/B runs and as a second opinion in the tests)
-    if (use_q)
+    if (use_p)
+      rfxk::filter_p(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap5, s->bm5_three, s->k, thresh, last_base_skipped,
+                     d_hits, d_mask, d_n);
+    else if (use_q)
       rfxk::filter_q(c, rv, s->slots, s->bits, s->has_all_ones, s->bitmap4, s->bm4_bits, s->k, thresh, last_base_skipped,
                      d_hits, d_mask, d_n);
     else if (s->bitmap2 && !getenv("RFX_FILTER_GENERIC"))

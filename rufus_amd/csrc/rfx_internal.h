@@ -280,6 +280,8 @@ struct rfx_set {
   uint32_t* bitmap3;  // k >= 20, 4096 < keys <= 2^17: the 2^20-bit packed-order bitmap of k_filter_big (else null)
   uint32_t* bitmap4;  // k >= 10, keys <= 2^18: the queue filter's bitmap of 2^bm4_bits bits (else null)
   int bm4_bits;
+  uint32_t* bitmap5;  // k >= 16, 4096 < keys <= 2^18: the pair filter's table of 2^16 halfwords (else null)
+  int bm5_three;      // three bits per entry (two: sets small enough that two decide as well)
 };
 
 // ---- kernel launchers (rfx_kernels.hip) -------------------------------------------------------
@@ -341,6 +343,15 @@ int filter_q_bits(uint64_t n_keys, int k);
 void set_bitmap_q(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm /* 2^(bm_bits-5) words */, int bm_bits, int k);
 void filter_q(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
               int bm_bits, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,
+              unsigned long long* d_nhit);
+// k >= 16, 4096 < keys <= 2^18: one lookup per two windows in a table of 2^16 halfwords, two lookups per packed
+// instruction (k_filter_p).  filter_p_applies: 0 = not for this set, 1 = two bits per entry, 2 = three.
+// hits == nullptr: thresh must be 1 -- the hits set the bits of `hitmask` (zeroed by the caller) themselves.
+int filter_p_applies(uint64_t n_keys, int k);
+size_t filter_p_table_bytes();
+void set_bitmap_p(rfx_ctx*, const uint64_t* keys, uint64_t n, uint32_t* bm /* filter_p_table_bytes(), zeroed */, int k, int three);
+void filter_p(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm, int three,
+              int k, int thresh, int last_base_skipped, uint32_t* hits /* zeroed, or null */, uint64_t* hitmask,
               unsigned long long* d_nhit);
 void filter(rfx_ctx*, const rfx_reads_view&, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,
             int bm_bits, int bm_shift, int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask,

@@ -1397,6 +1397,279 @@ __global__ __launch_bounds__(BLOCK) void k_filter_q(rfx_reads_view rv, const uin
 #endif
 }
 
+// ---- pair filter (round 6; k >= 16, sets of more than 4096 keys): ONE table lookup per TWO windows ----------------------
+// k_filter_q is bound twice over: by the instructions it issues (8 VALU per window: SQ_INSTS_VALU x 4 cycles = its run
+// time to 1 %) and, at 60 % already, by the LDS cycles of one random bitmap read per window (two thirds of them bank
+// conflicts, which random addresses have whatever the layout).  Fewer lookups, cheaper lookups:
+//   * a lookup at every EVEN read position e only: the halfword (16 bits) of a 2^16-halfword table that the 8 bases ending
+//     at e address, and in it the three bits that the three base pairs before those 8 bases pick (14 bases = 28 bits of
+//     the window decide).  A key leaves TWO entries: its last 14 bases (the window ends at e) and the 14 bases before its
+//     last one (the window ends at e + 1); a lookup that passes makes candidates of both windows -- the valid-window mask
+//     and the exact probe sort them out, as before.  Twice the entries with three bits each fill a quarter of the bits:
+//     1.6 % of the lookups pass on random sequence, 2.4 candidate windows per 150 bp read against 1.4 before;
+//   * two lookups that lie 8 bases apart are worked on as the two halves of one register (v_pk_lshrrev_b16 shifts both
+//     halfwords by their own 4-bit amounts, which are the low nibbles of the halves of a stream register read 2, 4 and 6
+//     bases earlier: no instruction extracts an index): 7 funnel shifts + 4 x 10 instructions per 16 bases, 2.9 per
+//     window where k_filter_q has 8, and half its LDS reads.
+// Everything else -- a 150 bp read loaded whole a chunk ahead, the mask of fully good windows by run-length doubling,
+// candidates ballot-compacted into per-wave LDS queues and probed 128 at a time -- is k_filter_q's.
+constexpr int FP_TABLE_BYTES = 2 << 16;  // 2^16 halfwords = 2^20 bits
+
+// what a key leaves in the table (kind 0: its window ends at the lookup position, kind 1: one base behind it): the
+// halfword's index and its bits, from the same bases in the same order as fp_group below reads them off the stream
+__device__ __forceinline__ void fp_entry(uint64_t key, int k, int kind, bool three, uint32_t& half, uint32_t& bitsel) {
+  auto base = [&](int off) { return (uint32_t)(key >> (2 * (k - 1 - off))) & 3u; };  // (first base most significant)
+  const int e = k - 1 - kind;
+  half = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) half |= base(e - 7 + i) << (2 * i);
+  const uint32_t i1 = base(e - 9) | (base(e - 8) << 2), i2 = base(e - 11) | (base(e - 10) << 2),
+                 i3 = base(e - 13) | (base(e - 12) << 2);
+  bitsel = (1u << i1) | (1u << i2) | (three ? 1u << i3 : 0u);
+}
+
+__global__ __launch_bounds__(256) void k_set_bitmap_p(const uint64_t* __restrict__ keys, uint64_t n, uint32_t* __restrict__ bm,
+                                                       int k, int three) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t key = keys[i];
+#pragma unroll
+    for (int kind = 0; kind < 2; ++kind) {
+      uint32_t half, bitsel;
+      fp_entry(key, k, kind, three != 0, half, bitsel);
+      atomicOr(&bm[half >> 1], bitsel << ((half & 1u) * 16u));
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t fp_pk_lshr(uint32_t amount, uint32_t value) {  // both halves: value.h >> (amount.h & 15)
+  uint32_t d;
+  asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(d) : "v"(amount), "v"(value));
+  return d;
+}
+
+// The 8 lookups of 16 bases: (lo, hi) = the stream dwords the 16 bases END in (hi) and the dword before (lo); lookups at the
+// even positions 0, 2 .. 14 of the 16; bit m of the result: the lookup at position 2 m passed.
+template <bool THREE>
+__device__ __forceinline__ uint32_t fp_group(uint32_t lo, uint32_t hi) {
+  typedef __attribute__((address_space(3))) const uint16_t lds_half;
+  // x[j]: the 32 stream bits that begin 6 + 4 j bits into (lo, hi).  x[q + 3]: low half = the 8 bases ending at position
+  // 2 q of the 16, high half = the 8 bases ending 8 bases on; x[q + 2], x[q + 1], x[q] begin 2, 4, 6 bases earlier: their
+  // halves' low nibbles are the base pairs before the two 8-mers
+  uint32_t x[7];
+#define FP_X(j) x[j] = __builtin_amdgcn_alignbit(hi, lo, 6 + 4 * j)
+  FP_X(0); FP_X(1); FP_X(2); FP_X(3); FP_X(4); FP_X(5); FP_X(6);
+#undef FP_X
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {  // (the table starts at LDS address 0 -- the kernel checks it --: the doubled index IS the address)
+    // (byte address = 2 x halfword: the shift with the half selected in the operand -- the compiler finds that form for
+    // the upper half only and spends a shift and a mask on the lower)
+    uint32_t a;
+    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+        : "=v"(a) : "v"(1u), "v"(x[q + 3]));
+    const uint32_t b = (x[q + 3] >> 16) << 1;
+    w[q] = (uint32_t)*(lds_half*)(uintptr_t)a | ((uint32_t)*(lds_half*)(uintptr_t)b << 16);
+  }
+  uint32_t acc = 0;
+#pragma unroll
+  for (int q = 3; q >= 0; --q) {
+    uint32_t t = fp_pk_lshr(x[q + 2], w[q]) & fp_pk_lshr(x[q + 1], w[q]);
+    if (THREE) t &= fp_pk_lshr(x[q], w[q]);
+    acc = (acc << 1) | (t & 0x00010001u);
+  }
+  return (acc & 0xFu) | ((acc >> 12) & 0xF0u);
+}
+
+__device__ __forceinline__ uint32_t fp_spread(uint32_t x) {  // bit m of 16 -> bits 2 m and 2 m + 1
+  x = (x | (x << 8)) & 0x00FF00FFu;
+  x = (x | (x << 4)) & 0x0F0F0F0Fu;
+  x = (x | (x << 2)) & 0x33333333u;
+  x = (x | (x << 1)) & 0x55555555u;
+  return x | (x << 1);
+}
+
+// UW > 0: every read of the (compact) block has UW code words, loaded in one burst.  MASK: thresh = 1 and nobody wants the
+// counts -- a hit sets the read's bit of g_mask (zeroed by the caller) and the per-read count array, its memset and the
+// pass that turned it into the mask do not exist (8 of k_filter_q's 69 bytes per read).
+template <int BLOCK, int UW, bool THREE, bool MASK>
+__global__ __launch_bounds__(BLOCK) void k_filter_p(rfx_reads_view rv, const uint64_t* __restrict__ g_slots, int bits,
+                                                     int has_all_ones, const uint32_t* __restrict__ g_bm, int k,
+                                                     int last_base_skipped, uint32_t* __restrict__ g_hits,
+                                                     unsigned long long* __restrict__ g_mask) {
+  extern __shared__ uint32_t s_fq[];  // table | per-wave queues: FQ_QCAP keys (64-bit), then FQ_QCAP reads
+  constexpr uint32_t bm_words = FP_TABLE_BYTES / 4;
+  const uint32_t wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+  uint64_t* s_qk = (uint64_t*)(s_fq + bm_words) + wave * FQ_QCAP;
+  uint32_t* s_qr = s_fq + bm_words + (BLOCK / WAVE) * FQ_QCAP * 2 + wave * FQ_QCAP;
+  if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)s_fq != 0u) __builtin_trap();  // see fp_group
+  for (uint32_t i = threadIdx.x; i < bm_words / 4; i += BLOCK) ((uint4*)s_fq)[i] = ((const uint4*)g_bm)[i];
+  __syncthreads();
+  const uint64_t kmask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+  const uint32_t smask = (1u << bits) - 1;
+  const uint32_t n_chunks = (rv.n + BLOCK - 1) / BLOCK;
+  uint32_t qn = 0;  // wave-uniform
+  auto drain = [&]() {  // the queued candidates, two per lane at a time: probe the set exactly (k_filter_q's)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t b0 = 0; b0 < qn; b0 += 2 * WAVE) {
+      uint64_t fwd[2], g0[2], g1[2];
+      uint32_t rr[2], sl[2];
+      bool ok[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const uint32_t idx = b0 + (uint32_t)u * WAVE + lane;
+        ok[u] = idx < qn;
+        // (queued as cut from the stream, last base most significant: the 2-bit groups are put in key order HERE, by all
+        // 64 lanes at once -- in the queueing loop, where a lane or two are live per trip, it was 14 of its 35 instructions)
+        uint64_t y = __brevll(ok[u] ? s_qk[idx] : 0ull);
+        y = ((y & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((y & 0x5555555555555555ull) << 1);
+        fwd[u] = (k == 32 ? y : y >> (64 - 2 * k)) & kmask;
+        rr[u] = ok[u] ? s_qr[idx] : 0u;
+        sl[u] = set_hash(fwd[u], bits);
+        g0[u] = ok[u] ? g_slots[sl[u]] : RFX_EMPTY;
+        g1[u] = ok[u] ? g_slots[(sl[u] + 1) & smask] : RFX_EMPTY;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (!ok[u]) continue;
+        bool hit;
+        if (fwd[u] == RFX_EMPTY) {
+          hit = has_all_ones != 0;
+        } else {
+          uint64_t v0 = g0[u], v1 = g1[u];
+          uint32_t q = sl[u];
+          while (v0 != fwd[u] && v0 != RFX_EMPTY && v1 != fwd[u] && v1 != RFX_EMPTY) {  // (rare)
+            q = (q + 2) & smask;
+            v0 = g_slots[q];
+            v1 = g_slots[(q + 1) & smask];
+          }
+          hit = v0 == fwd[u] || (v0 != RFX_EMPTY && v1 == fwd[u]);
+        }
+        if (hit) {
+          if (MASK) atomicOr(&g_mask[rr[u] >> 6], 1ull << (rr[u] & 63u));
+          else atomicAdd(&g_hits[rr[u]], 1u);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    qn = 0;
+  };
+  uint64_t ncv[UW > 0 ? UW : 1];
+  uint32_t ngv[UW > 0 ? UW : 1];
+  auto load_ahead = [&](uint32_t chunk_) {
+    const uint32_t r_ = chunk_ * BLOCK + wave * WAVE + lane;
+    const bool live_ = chunk_ < n_chunks && r_ < rv.n;
+    const uint32_t wr_ = live_ ? r_ * (uint32_t)UW : 0u;
+#pragma unroll
+    for (int i = 0; i < (UW > 0 ? UW : 1); ++i) {
+      ncv[i] = live_ && UW > 0 ? rv.codes[wr_ + i] : 0ull;
+      ngv[i] = live_ && UW > 0 ? rv.good[wr_ + i] : 0u;
+    }
+  };
+  if (UW > 0) load_ahead(blockIdx.x);
+  for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    const uint32_t r = chunk * BLOCK + wave * WAVE + lane;
+    const bool live = r < rv.n;
+    if (qn >= (uint32_t)FQ_QCAP / 2) drain();  // (before the next chunk's loads are issued: a drain waits for everything in flight)
+    auto word = [&](uint64_t prev_c, uint64_t cur_c, uint32_t prev_g, uint32_t cur_g) {
+      // V = "a fully good window ends here": no bad base among the k - 1 before a position or at it.  The bad bits of
+      // (previous word, this word) are smeared k - 1 places upwards in doubling steps (1, 2, 4 .. then what is left: five
+      // steps for k = 25); only this word's half of the result is wanted, so a step is a funnel shift + or on it and a
+      // shift-or on the lower half -- 3 instructions where the 64-bit run-length doubling of k_filter_q has 8.
+      uint32_t blo = ~prev_g, bhi = ~cur_g;
+      for (uint32_t reach = 0, n = (uint32_t)k - 1u; reach < n;) {
+        const uint32_t st = min(reach + 1u, n - reach);  // (wave-uniform: k is; st <= 16)
+        bhi |= __builtin_amdgcn_alignbit(bhi, blo, 32u - st);
+        blo |= blo << st;
+        reach += st;
+      }
+      const uint32_t V = ~bhi;
+      const uint32_t p1 = (uint32_t)(prev_c >> 32), c0 = (uint32_t)cur_c, c1 = (uint32_t)(cur_c >> 32);
+      // (a half without a fully good window in any lane -- the first k - 1 bases, the tail -- is not looked up)
+      uint32_t L = 0;
+      if (__ballot((V & 0x0000FFFFu) != 0)) L = fp_group<THREE>(p1, c0);
+      if (__ballot((V & 0xFFFF0000u) != 0)) L |= fp_group<THREE>(c0, c1) << 8;
+      uint32_t cand = fp_spread(L) & V;
+#ifdef FP_NOPUSH  // experiment (results void): what the lookups alone cost
+      if (cand == 0x12345678u && V == 0x9ABCDEF0u) s_qr[0] = cand;
+      cand = 0;
+#endif
+#ifdef FP_NOLOOKUP  // experiment (results void): everything but the lookups
+      cand = V & (c0 == 0x12345678u ? ~0u : 0u);
+#endif
+      for (;;) {
+        const unsigned long long act = __ballot(cand != 0);
+        if (!act) break;
+        const uint32_t cnt = (uint32_t)__popcll(act);
+        if (qn + cnt > (uint32_t)FQ_QCAP) drain();
+        if (cand) {
+          const int j = __ffs(cand) - 1;
+          cand &= cand - 1u;
+          // window = bases j-k+1 .. j of (prev word, this word): one 128-bit shift, then the 2-bit groups reversed to
+          // get the forward key (first base most significant)
+          const int sh = 2 * (j - k + 1) + 64;  // 2 .. 126
+          const uint64_t packed = sh >= 64 ? cur_c >> (sh - 64) : (prev_c >> sh) | (cur_c << (64 - sh));
+          const uint32_t slot = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+          s_qk[slot] = packed;  // (the bits above the window's 2 k go when the drain turns it into the key)
+          s_qr[slot] = r;
+        }
+        qn += cnt;
+      }
+    };
+    if (UW > 0) {
+      uint64_t cv[UW > 0 ? UW : 1];
+      uint32_t gv[UW > 0 ? UW : 1];
+#pragma unroll
+      for (int i = 0; i < UW; ++i) {  // loaded one turn ahead: the HBM latency is spent under the previous chunk
+        cv[i] = ncv[i];
+        gv[i] = ngv[i];
+      }
+      load_ahead(chunk + gridDim.x);
+      // src/RUFUS.Filter.cpp:203: `i < length()-1` -- the last base is never examined.
+      const uint32_t stop = live ? (last_base_skipped ? rv.ulen - 1 : rv.ulen) : 0u;
+#pragma unroll
+      for (int i = 0; i < UW; ++i) {
+        const uint32_t lo = (uint32_t)i * 32u;
+        uint32_t g = gv[i];
+        if (stop < lo + 32u) g = stop > lo ? g & ((1u << (stop - lo)) - 1u) : 0u;
+        gv[i] = g;
+        word(i ? cv[i - 1] : 0ull, cv[i], i ? gv[i - 1] : 0u, g);
+      }
+    } else {
+      const uint32_t wr = live ? rv_off(rv, r) : 0u;
+      const uint32_t len = live ? rv_len(rv, r) : 0u;
+      const uint32_t stop = last_base_skipped ? (len ? len - 1 : 0) : len;
+      uint32_t nw = (stop + 31) >> 5, nw_max = nw;
+#pragma unroll
+      for (int o = 32; o; o >>= 1) nw_max = max(nw_max, (uint32_t)__shfl_xor((int)nw_max, o));
+      uint64_t prev_c = 0;
+      uint32_t prev_g = 0;
+      for (uint32_t wi = 0; wi < nw_max; ++wi) {  // every lane takes part in the ballots of every trip
+        const uint64_t cur_c = wi < nw ? rv.codes[wr + wi] : 0ull;
+        uint32_t cur_g = wi < nw ? rv.good[wr + wi] : 0u;
+        const uint32_t lo = wi << 5;
+        if (stop < lo + 32u) cur_g = stop > lo ? cur_g & ((1u << (stop - lo)) - 1u) : 0u;
+        word(prev_c, cur_c, prev_g, cur_g);
+        prev_c = cur_c;
+        prev_g = cur_g;
+      }
+    }
+  }
+  if (qn) drain();
+}
+
+// the number of set bits of a hit mask (k_filter_p MASK: the mask is made by the hits themselves)
+__global__ __launch_bounds__(256) void k_mask_count(const unsigned long long* __restrict__ mask, uint64_t n_words,
+                                                     unsigned long long* __restrict__ d_nhit) {
+  unsigned long long c = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (uint64_t)gridDim.x * blockDim.x)
+    c += (unsigned long long)__popcll(mask[i]);
+#pragma unroll
+  for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & (WAVE - 1)) == 0 && c) atomicAdd(d_nhit, c);
+}
+
 // per-read hit counts -> one bit per read (count >= thresh) and the number of such reads
 __global__ __launch_bounds__(256) void k_hits_mask(const uint32_t* __restrict__ hits, uint32_t n, int thresh,
                                                     uint64_t* __restrict__ hitmask,
@@ -1722,6 +1995,62 @@ void filter_q(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int b
 #undef RFX_FQ2
   hipLaunchKernelGGL(k_hits_mask, dim3(grid_for(c, rv.n, 256, 8)), dim3(256), 0, c->stream, hits, rv.n, thresh, hitmask,
                      d_nhit);
+}
+
+int filter_p_applies(uint64_t n_keys, int k) {
+  if (getenv("RFX_FILTER_NO_PAIR")) return 0;  // (A/B runs and the tests' second opinion: k_filter_q)
+  if (k < 16 || n_keys <= 4096 || n_keys > (1u << 18)) return 0;
+  // two entries per key; with two bits each up to ~16 K keys fill 6 % of the table and 0.4 % of the lookups pass; beyond,
+  // a third bit (a quarter of the bits set by 50 K keys: 1.6 % pass, with two bits it would be 3.3 %)
+  if (const char* ev = getenv("RFX_FILTER_PAIR_BITS")) return atoi(ev) == 2 ? 1 : 2;
+  return n_keys <= 16384 ? 1 : 2;
+}
+size_t filter_p_table_bytes() { return FP_TABLE_BYTES; }
+
+void set_bitmap_p(rfx_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* bm, int k, int three) {
+  if (n == 0) return;
+  rfx_span sp(c, "k_set_bitmap");
+  hipLaunchKernelGGL(k_set_bitmap_p, dim3(grid_for(c, n, 256, 8)), dim3(256), 0, c->stream, keys, n, bm, k, three);
+}
+
+void filter_p(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm, int three,
+              int k, int thresh, int last_base_skipped, uint32_t* hits, uint64_t* hitmask, unsigned long long* d_nhit) {
+  if (rv.n == 0) return;
+  constexpr int BLOCK = 1024;
+  const size_t lds = (size_t)FP_TABLE_BYTES + (size_t)(BLOCK / WAVE) * FQ_QCAP * 12;
+  const uint32_t chunks = (rv.n + BLOCK - 1) / BLOCK;
+  const int grid = (int)std::min<uint32_t>(chunks, (uint32_t)c->n_cu);  // one resident workgroup per CU
+  const bool u5 = rv.ulen && rv.uwpr == 5;
+  const bool mask = hits == nullptr;
+  {
+    rfx_span sp(c, "k_filter");
+#define RFX_FP3(UW, THREE, MASK, BIT)                                                                                       \
+  do {                                                                                                                     \
+    if (!rfxi::lds_opt_in(c, (const void*)k_filter_p<BLOCK, UW, THREE, MASK>, lds, BIT, "k_filter_p")) return;             \
+    hipLaunchKernelGGL((k_filter_p<BLOCK, UW, THREE, MASK>), dim3(grid), dim3(BLOCK), lds, c->stream, rv, slots, bits,     \
+                       has_all_ones, bm, k, last_base_skipped, hits, (unsigned long long*)hitmask);                        \
+  } while (0)
+#define RFX_FP2(UW, THREE, BIT)              \
+  do {                                       \
+    if (mask) RFX_FP3(UW, THREE, true, BIT); \
+    else RFX_FP3(UW, THREE, false, BIT + 1); \
+  } while (0)
+    if (u5) {
+      if (three) RFX_FP2(5, true, 18);
+      else RFX_FP2(5, false, 20);
+    } else {
+      if (three) RFX_FP2(0, true, 22);
+      else RFX_FP2(0, false, 24);
+    }
+#undef RFX_FP2
+#undef RFX_FP3
+  }
+  if (mask)
+    hipLaunchKernelGGL(k_mask_count, dim3(grid_for(c, ((uint64_t)rv.n + 63) / 64, 256, 8)), dim3(256), 0, c->stream,
+                       (const unsigned long long*)hitmask, ((uint64_t)rv.n + 63) / 64, d_nhit);
+  else
+    hipLaunchKernelGGL(k_hits_mask, dim3(grid_for(c, rv.n, 256, 8)), dim3(256), 0, c->stream, hits, rv.n, thresh, hitmask,
+                       d_nhit);
 }
 
 void filter(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int bits, int has_all_ones, const uint32_t* bm,

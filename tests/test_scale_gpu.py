@@ -39,9 +39,11 @@ def test_device_generator_matches_host_twin(ctx, which, first, n_pairs, want_goo
     blk.free()
 
 
-@pytest.mark.parametrize("n_random,k", [(100, 25), (9000, 25), (40000, 25), (100000, 31), (3000, 12)])
+@pytest.mark.parametrize("n_random,k", [(100, 25), (9000, 25), (40000, 25), (100000, 31), (3000, 12), (5000, 16), (30000, 17),
+                                        (20000, 32)])
 def test_queue_filter_on_compact_blocks(ctx, monkeypatch, n_random, k):
-    """K5 on compact (uniform 150 bp) blocks, every bitmap size / workgroup shape of k_filter_q: per-read hit counts
+    """K5 on compact (uniform 150 bp) blocks, every bitmap size / workgroup shape of k_filter_q and -- sets of more than
+    4096 keys, k >= 16 -- the pair filter k_filter_p with two and three bits per entry: per-read hit counts
     against the oracle's scan (src/RUFUS.Filter.cpp:196-277), and the round-2 kernels and the generic kernel give the
     same counts.  The set holds EVERY k-mer of some reads, so whole reads are candidates and the per-wave queue
     overflows and drains in the middle of a read."""
@@ -69,11 +71,15 @@ def test_queue_filter_on_compact_blocks(ctx, monkeypatch, n_random, k):
         assert np.array_equal(hits, want), np.flatnonzero(hits != want)[:5]
         bits = tools._mask_bits(mask, len(reads))
         assert np.array_equal(bits, want >= 2) and nh == int(bits.sum()) and nh > 0
-        for env in ("RFX_FILTER_OLD", "RFX_FILTER_GENERIC"):
+        for env in ("RFX_FILTER_OLD", "RFX_FILTER_GENERIC", "RFX_FILTER_NO_PAIR"):
             monkeypatch.setenv(env, "1")
             hits2, _, _ = mset.filter(blk, 2, skipped)
             monkeypatch.delenv(env)
             assert np.array_equal(hits2, want)
+        # thresh = 1 and no counts asked for: the pair filter's hits set the mask's bits themselves (no count array)
+        _, mask1, nh1 = mset.filter(blk, 1, skipped, want_hits=False)
+        bits1 = tools._mask_bits(mask1, len(reads))
+        assert np.array_equal(bits1, want >= 1) and nh1 == int(bits1.sum())
     mset.free()
     blk.free()
 

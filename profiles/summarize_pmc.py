@@ -24,7 +24,8 @@ NOT_CHAIN = frozenset((
     "k_synth_reads", "k_copy16",
     "k_flag_absent", "k_flag_absent_tiled", "k_fa_bounds", "k_flag_gather", "k_flag_range", "k_flag_rank", "k_flag_present",
     "k_compact_count", "k_compact_scatter", "k_scan_u64", "k_query",
-    "k_filter", "k_filter_q", "k_filter_fast", "k_filter_big", "k_hits_mask", "k_set_bitmap", "k_set_bitmap_big", "k_set_bitmap_q",
+    "k_filter", "k_filter_q", "k_filter_p", "k_filter_fast", "k_filter_big", "k_hits_mask", "k_mask_count", "k_set_bitmap",
+    "k_set_bitmap_big", "k_set_bitmap_q", "k_set_bitmap_p",
     "k_set_insert", "k_set_bitmap_packed", "k_records_checksum", "k_records_verify", "k_check_sorted",
     # never launched by the bench's device step: record I/O of the executables, the assembly stage, ModelDist
     "k_parse_records", "k_format_records", "k_compute_pos", "k_annotate", "k_overlap_pool", "k_overlap_score",

@@ -148,6 +148,39 @@ uint64_t rfx_reads_words(const rfx_reads*);
 /* D2H copy of a block's arrays (sized by rfx_reads_words / rfx_reads_count; any pointer may be NULL). */
 int rfx_reads_get(const rfx_reads*, uint64_t* codes, uint32_t* acgt, uint32_t* good, uint32_t* word_off, uint32_t* len);
 
+/* -------------------------------------------------------------------------------------------
+ * Text in, packed reads out -- on the device (kernel K1)
+ * Replaces, for strict 4-line FASTQ, the reference's text parser and base packer
+ * (jf/include/jellyfish/mer_overlap_sequence_parser.hpp:179-206 -- header, sequence, '+', quality line --;
+ * jf/include/jellyfish/mer_dna.hpp:46-63; for the filter's blocks src/Util.cpp:51-84 and the quality test of
+ * src/RUFUS.Filter.cpp:205), which the drop-in executables ran on the host until round 6.  The host only moves
+ * bytes: it appends RECORD-ALIGNED pieces of the text (every piece begins at a record's '@' line and ends with the
+ * newline of a quality line) to a device arena, each piece one host-to-device copy queued on the ctx stream -- from
+ * page-locked memory (rfx_host_alloc) it runs at PCIe speed and the call returns at once -- and rfx_text_parse
+ * turns what was appended into a read block exactly as rfx_pack_reads(flags, min_q) would have packed the same
+ * records (flags = RFX_PACK_COUNT or RFX_PACK_FILTER, one of them).
+ *   rfx_text_open    an arena for up to cap_bytes (< 4 GiB) of text; NULL on failure
+ *   rfx_text_append  >= 0: a ticket for this piece; < 0: an RFX_E_* code.  The host buffer must stay as it is until
+ *                    rfx_text_copied(ticket) returns 1 (0: the copy has not run yet; < 0: error) or rfx_text_parse
+ *                    has returned
+ *   rfx_text_parse   the block, or NULL: *strict == 0 then says the text is NOT strict 4-line FASTQ (a blank line
+ *                    between records, a multi-line record, a quality line of another length, a missing final
+ *                    newline ...) -- no error: the caller parses that text on the host (rfx_text_fetch copies it
+ *                    back); *strict == 1 with NULL is a failure (rfx_last_error).  Waits for its kernels: when it
+ *                    returns the arena is free for the next block's text (rfx_text_reset).
+ *   rfx_text_fetch   the appended bytes, copied to `host` (rfx_text_bytes of them)
+ * ------------------------------------------------------------------------------------------- */
+typedef struct rfx_text rfx_text;
+rfx_text* rfx_text_open(rfx_ctx*, uint64_t cap_bytes);
+void rfx_text_close(rfx_text*);
+uint64_t rfx_text_room(const rfx_text*);
+uint64_t rfx_text_bytes(const rfx_text*);
+long rfx_text_append(rfx_text*, const void* host, uint64_t n);
+int rfx_text_copied(rfx_text*, long ticket);
+rfx_reads* rfx_text_parse(rfx_text*, int flags, int min_q, int* strict);
+int rfx_text_fetch(rfx_text*, void* host);
+void rfx_text_reset(rfx_text*);
+
 /* Synthetic trio workload (BASELINE.json configs[1]-[4]) -- benchmark and scale-test input,
  * not a replacement of any reference code.  Every base is a pure function of (parameters, pair, mate, base
  * index) -- see rufus_amd/csrc/rfx_synth.h -- so a 30x WGS sample (6.2e8 reads) is generated straight into

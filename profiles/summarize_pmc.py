@@ -28,7 +28,7 @@ NOT_CHAIN = frozenset((
     "k_set_bitmap_big", "k_set_bitmap_q", "k_set_bitmap_p",
     "k_set_insert", "k_set_bitmap_packed", "k_records_checksum", "k_records_verify", "k_check_sorted",
     # never launched by the bench's device step: record I/O of the executables, the assembly stage, ModelDist
-    "k_parse_records", "k_format_records", "k_compute_pos", "k_annotate", "k_overlap_pool", "k_overlap_score",
+    "k_parse_records", "k_format_records", "k_txt_count", "k_txt_lines", "k_txt_reads", "k_txt_pack", "k_compute_pos", "k_annotate", "k_overlap_pool", "k_overlap_score",
     "k_model_colsum", "k_model_dist", "k_model_rowtot", "k_model_sum", "k_model_terms", "k_model_weights",
 ))
 # the chain's kernels as rocprofv3 names them (bench.K2_CHAIN holds the LABELS of the library's HIP-event brackets, several

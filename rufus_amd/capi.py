@@ -60,6 +60,15 @@ SIGNATURES = {
     "rfx_reads_words": (C.c_uint64, [C.c_void_p]),
     "rfx_reads_get": (C.c_int, [C.c_void_p, u64p, u32p, u32p, u32p, u32p]),
     "rfx_synth_reads": (C.c_void_p, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_int]),
+    "rfx_text_open": (C.c_void_p, [C.c_void_p, C.c_uint64]),
+    "rfx_text_close": (None, [C.c_void_p]),
+    "rfx_text_room": (C.c_uint64, [C.c_void_p]),
+    "rfx_text_bytes": (C.c_uint64, [C.c_void_p]),
+    "rfx_text_append": (C.c_long, [C.c_void_p, C.c_char_p, C.c_uint64]),
+    "rfx_text_copied": (C.c_int, [C.c_void_p, C.c_long]),
+    "rfx_text_parse": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+    "rfx_text_fetch": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rfx_text_reset": (None, [C.c_void_p]),
     "rfx_synth_text": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rfx_synth_snv": (C.c_int, [C.c_void_p, C.c_uint32, u64p, C.c_char_p, C.c_char_p]),
     "rfx_synth_genome": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
@@ -348,6 +357,47 @@ class Context:
         self.close()
 
 
+class TextArena:
+    """Strict 4-line FASTQ text -> a read block, parsed and packed on the device (rfx_text_*: SURVEY section 2, K1)."""
+
+    def __init__(self, ctx: Context, cap_bytes: int):
+        self.ctx = ctx
+        self._h = lib().rfx_text_open(ctx._h, cap_bytes)
+        if not self._h:
+            raise RufusError("rfx_text_open failed: " + lib().rfx_last_error().decode())
+
+    def append(self, data: bytes) -> int:
+        t = lib().rfx_text_append(self._h, data, len(data))
+        if t < 0:
+            _check(int(t), "rfx_text_append")
+        self.ctx.sync()     # (a bytes object is not pinned and may go away: wait for the copy)
+        return int(t)
+
+    def parse(self, flags: int = PACK_COUNT, min_q: int = 0):
+        """The block, or None when the text is not strict 4-line FASTQ."""
+        strict = C.c_int(1)
+        h = lib().rfx_text_parse(self._h, flags, min_q, C.byref(strict))
+        if not h:
+            if strict.value == 0:
+                return None
+            raise RufusError("rfx_text_parse failed: " + lib().rfx_last_error().decode())
+        return ReadBlock.from_handle(self.ctx, h)
+
+    def fetch(self) -> bytes:
+        n = int(lib().rfx_text_bytes(self._h))
+        buf = C.create_string_buffer(max(n, 1))
+        _check(lib().rfx_text_fetch(self._h, buf), "rfx_text_fetch")
+        return buf.raw[:n]
+
+    def reset(self):
+        lib().rfx_text_reset(self._h)
+
+    def close(self):
+        if self._h:
+            lib().rfx_text_close(self._h)
+            self._h = None
+
+
 class ReadBlock:
     def __init__(self, ctx: Context, p: PackedReads):
         self.ctx = ctx
@@ -372,10 +422,10 @@ class ReadBlock:
     def device_bytes(self) -> int:
         return int(lib().rfx_reads_device_bytes(self._h))
 
-    def get(self, want_good: bool = True):
+    def get(self, want_good: bool = True, want_acgt: bool = True):
         """Download the packed arrays: dict codes / acgt / good / word_off / len."""
         nw = int(lib().rfx_reads_words(self._h))
-        out = {"codes": np.zeros(max(nw, 1), np.uint64), "acgt": np.zeros(max(nw, 1), np.uint32),
+        out = {"codes": np.zeros(max(nw, 1), np.uint64), "acgt": np.zeros(max(nw, 1), np.uint32) if want_acgt else None,
                "good": np.zeros(max(nw, 1), np.uint32) if want_good else None,
                "word_off": np.zeros(self.n + 1, np.uint32), "len": np.zeros(max(self.n, 1), np.uint32)}
         _check(lib().rfx_reads_get(self._h, _p(out["codes"], u64p), _p(out["acgt"], u32p), _p(out["good"], u32p),

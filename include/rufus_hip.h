@@ -160,9 +160,12 @@ int rfx_reads_get(const rfx_reads*, uint64_t* codes, uint32_t* acgt, uint32_t* g
  * turns what was appended into a read block exactly as rfx_pack_reads(flags, min_q) would have packed the same
  * records (flags = RFX_PACK_COUNT or RFX_PACK_FILTER, one of them).
  *   rfx_text_open    an arena for up to cap_bytes (< 4 GiB) of text; NULL on failure
- *   rfx_text_append  >= 0: a ticket for this piece; < 0: an RFX_E_* code.  The host buffer must stay as it is until
- *                    rfx_text_copied(ticket) returns 1 (0: the copy has not run yet; < 0: error) or rfx_text_parse
- *                    has returned
+ *   rfx_text_append  >= 0: a ticket for this piece; < 0: an RFX_E_* code (RFX_E_RANGE: no room).  The host buffer must
+ *                    stay as it is until rfx_text_copied(ticket) returns 1 (0: the copy has not run yet; < 0: error),
+ *                    rfx_text_wait(ticket) or rfx_text_parse has returned.  The copies run on a stream of the arena's
+ *                    own: with two arenas the next block's text crosses PCIe while this block is parsed and counted.
+ *                    append / copied / wait may be called from several host threads; parse, fetch, reset and close
+ *                    from one, while nobody appends
  *   rfx_text_parse   the block, or NULL: *strict == 0 then says the text is NOT strict 4-line FASTQ (a blank line
  *                    between records, a multi-line record, a quality line of another length, a missing final
  *                    newline ...) -- no error: the caller parses that text on the host (rfx_text_fetch copies it
@@ -177,6 +180,7 @@ uint64_t rfx_text_room(const rfx_text*);
 uint64_t rfx_text_bytes(const rfx_text*);
 long rfx_text_append(rfx_text*, const void* host, uint64_t n);
 int rfx_text_copied(rfx_text*, long ticket);
+int rfx_text_wait(rfx_text*, long ticket); /* blocks until that append's bytes have left the host buffer */
 rfx_reads* rfx_text_parse(rfx_text*, int flags, int min_q, int* strict);
 int rfx_text_fetch(rfx_text*, void* host);
 void rfx_text_reset(rfx_text*);

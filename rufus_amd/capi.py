@@ -66,6 +66,7 @@ SIGNATURES = {
     "rfx_text_bytes": (C.c_uint64, [C.c_void_p]),
     "rfx_text_append": (C.c_long, [C.c_void_p, C.c_char_p, C.c_uint64]),
     "rfx_text_copied": (C.c_int, [C.c_void_p, C.c_long]),
+    "rfx_text_wait": (C.c_int, [C.c_void_p, C.c_long]),
     "rfx_text_parse": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]),
     "rfx_text_fetch": (C.c_int, [C.c_void_p, C.c_char_p]),
     "rfx_text_reset": (None, [C.c_void_p]),
@@ -370,7 +371,7 @@ class TextArena:
         t = lib().rfx_text_append(self._h, data, len(data))
         if t < 0:
             _check(int(t), "rfx_text_append")
-        self.ctx.sync()     # (a bytes object is not pinned and may go away: wait for the copy)
+        _check(lib().rfx_text_wait(self._h, t), "rfx_text_wait")     # (a bytes object is not pinned and may go away)
         return int(t)
 
     def parse(self, flags: int = PACK_COUNT, min_q: int = 0):

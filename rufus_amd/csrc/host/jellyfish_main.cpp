@@ -232,9 +232,51 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     flush();  // k-mers never span files
   };
   std::unique_ptr<CountIngest> ingest;  // (kept to the end: its page-locked blocks serve the output drain)
+  // Round 6 (kernel K1): a regular FASTQ file counted on one device need not be parsed on the host at
+  // all -- its text goes to the device as it lies and is parsed and packed there (rfx_ingest.hpp TextIngest,
+  // csrc/rfx_text.hip).  Which route is faster is a matter of the CPUs the count may use (profiles/r06_text_route.txt,
+  // 20 GB of FASTQ on the GPU box's 16-CPU quota): with 16 parser threads the host parses and packs at 30 - 35 GB/s and
+  // uploads 68 bytes per read, the text route moves 330 bytes per read over PCIe at what 16 threads of pread + one
+  // copy stream reach, ~30 GB/s -- a draw, and the host route keeps the device free; with 5 threads (`runRufus.sh -pj`:
+  // the three counts of a trio at once) the host route is CPU-bound and the text route 22 % faster.  So: the text route
+  // when the count has at most 8 threads; RFX_DEVICE_PARSE=1 / RFX_HOST_PARSE=1 force one or the other.
+  const bool text_ok = n_gpu == 1 && nthreads > 1 && !sam_chr && !spool_path && !keep_path;
+  const bool device_text = text_ok && !getenv("RFX_HOST_PARSE") && (getenv("RFX_DEVICE_PARSE") || nthreads <= 8);
+  std::unique_ptr<TextIngest> text_ingest;
   {
     for (Input& in : inputs) {
       bool done = false;
+      if (device_text && in.regular && in.size > 0) {
+        if (!text_ingest) {
+          text_ingest.reset(new TextIngest(
+              ctx, nthreads, [&](rfx_reads* r) { sink_to(0, r); },
+              [&](const char* text, size_t n) {  // refused by the device (not strict 4-line FASTQ): the reference's grammar
+                LineReader lr(n + (1u << 20));
+                lr.preload(text, n);
+                lr.close_input();
+                sequential(lr);
+              },
+              (size_t)1 << 30, getenv("RFX_INGEST_PIECE") ? (size_t)std::max(1024ll, atoll(getenv("RFX_INGEST_PIECE"))) : (size_t)8 << 20));
+          trace("count: text arenas open, copiers up");
+        }
+        if (getenv("RFX_TEXT_MMAP")) {  // (A/B: the mapped route -- its munmap alone takes 0.3 s per 20 GB)
+          void* m = mmap(nullptr, in.size, PROT_READ, MAP_PRIVATE, in.fd, 0);
+          if (m != MAP_FAILED) {
+            (void)madvise(m, in.size, MADV_SEQUENTIAL);
+            done = text_ingest->feed_mapped((const char*)m, in.size);
+            trace("count: text fed");
+            munmap(m, in.size);
+            trace("count: input unmapped");
+          }
+        } else {
+          done = text_ingest->feed_file(in.fd, in.size);
+          trace("count: text fed");
+        }
+        if (done) {
+          if (in.fd > 0) ::close(in.fd);
+          continue;
+        }
+      }
       if (nthreads > 1 || sam_chr || spool_path || keep_path) {
         if (!ingest) {
           ingest.reset(new CountIngest(nthreads, [&](const StageBlock& b) {
@@ -324,6 +366,18 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
       fclose(cf);
     }
   }
+  // (device-parsed input: no staging blocks to lend to the output drain -- its ring of page-locked buffers is made now,
+  // beside the device's finish, instead of in front of the first write)
+  std::vector<std::pair<char*, size_t>> out_ring;
+  std::thread out_ring_pinner;
+  if (!ingest && text_ingest) {
+    trace(("count: text route, " + text_ingest->timing()).c_str());
+    text_ingest.reset();  // (its page-locked text buffers go first)
+    out_ring_pinner = std::thread([&out_ring] {
+      for (int i = 0; i < 8; ++i)
+        if (char* p = (char*)rfx_host_alloc(48u << 20)) out_ring.emplace_back(p, (size_t)48u << 20);
+    });
+  }
   const auto t_count = std::chrono::steady_clock::now();
   trace("count: input parsed and queued");
   if (getenv("RFX_CLI_TRACE")) {
@@ -373,12 +427,13 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
              (unsigned long long)prealloc.reached(), (unsigned long long)prealloc.populated());
     trace(msg);
   }
+  if (out_ring_pinner.joinable()) out_ring_pinner.join();
   write_jhash(out, recs, cols.data(), canonical, out_counter_len, full_argc, full_argv,
-              ingest ? ingest->lend_buffers(48u << 20) : std::vector<std::pair<char*, size_t>>(), out_fd,
-              prealloc.reached(), prealloc.take_mapping());
+              ingest ? ingest->lend_buffers(48u << 20) : out_ring, out_fd, prealloc.reached(), prealloc.take_mapping());
   trace("count: output closed");
   if (!timing) leave(0);
   ingest.reset();
+  for (auto& b : out_ring) rfx_host_free(b.first);
   for (rfx_records* r : recs) rfx_records_free(r);
   for (rfx_table* tb : tabs) rfx_count_free(tb);
   if (peers) rfx_peers_free(peers);

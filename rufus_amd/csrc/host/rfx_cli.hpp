@@ -121,6 +121,8 @@ class LineReader {
     return fd_ >= 0;
   }
   void attach(int fd) { fd_ = fd; }
+  // no descriptor: what was preloaded is all there is (text handed over in memory)
+  void close_input() { eof_ = true; }
   // Bytes that were already read from the descriptor (format sniffing) go first.
   void preload(const char* p, size_t n) {
     if (end_ + n > buf_.size()) buf_.resize(end_ + n + (1 << 20));

@@ -21,6 +21,7 @@
 #include <sys/stat.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -451,6 +452,7 @@ class CountIngest {
     if (failed_) die("rufus_amd jellyfish: " + fail_msg_);
   }
 
+  friend class TextIngest;
   // First position >= p where a 4-line FASTQ record starts ('@' line whose third line starts with '+' and whose
   // second and fourth lines are equally long); e when there is none.
   static const char* record_start(const char* p, const char* b, const char* e) {
@@ -746,6 +748,320 @@ class CountIngest {
     {
       std::lock_guard<std::mutex> g(mu_);
       pool_.push_back(buf);
+    }
+    drain(true);
+    return true;
+  }
+};
+
+// ---- text to the device, parsed there (round 6: SURVEY section 2, kernel K1; rufus_amd/csrc/rfx_text.hip) --------------
+// For a regular file of strict 4-line FASTQ counted on one device the host does not parse at all: the mapped text is cut
+// into record-aligned pieces (at the cut points only: CountIngest::record_start), the workers copy each piece into
+// page-locked memory and queue its host-to-device copy behind the others of the arena that is being filled
+// (rfx_text_append: the arena's own stream), and this thread turns every full arena into a read block
+// (rfx_text_parse) and hands it to the sink -- while the workers fill the other arena.  What the 16-CPU quota of the
+// GPU box spends per read drops from ~1 us of parsing and packing to a memcpy of 330 bytes; the text crosses PCIe at
+// ~55 GB/s where the packed blocks of the host route left it idle most of the time.  Text the device refuses (not
+// strict 4-line FASTQ after all: a blank line between records, a multi-line record) comes back and goes through the
+// caller's host parser, arena by arena: the records of an arena are whole, so nothing is lost or seen twice.
+class TextIngest {
+  rfx_ctx* ctx_;
+  unsigned nthreads_;
+  std::function<void(rfx_reads*)> sink_;
+  std::function<void(const char*, size_t)> host_text_;
+  size_t piece_;
+  struct Arena {
+    rfx_text* t = nullptr;
+    uint64_t gen = 0;  // bumped at every reset: a worker's ticket of an earlier generation is a copy long done
+    int state = 0;     // 0 free, 1 filling, 2 full (waiting for this thread)
+  };
+  Arena arena_[2];
+  int filling_ = -1;
+  std::deque<int> full_;
+  struct Piece {
+    const char* b;
+    const char* e;
+    int fd = -1;  // >= 0: bytes [lo, hi) of a regular file -- the worker reads them itself (pread into its page-locked
+    uint64_t lo = 0, hi = 0, fsize = 0;  // buffer) and appends the records that START inside the range
+  };
+  std::deque<Piece> work_;
+  size_t pieces_open_ = 0;
+  bool closing_ = false;
+  std::atomic<bool> failed_{false};
+  std::string fail_msg_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  std::vector<std::thread> workers_;
+  uint64_t reads_ = 0, host_bytes_ = 0;
+  static constexpr uint64_t TAIL = 1u << 20;  // longest record a range's tail may hold (feed_file)
+  double t_parse_ = 0, t_sink_ = 0;  // this thread: inside rfx_text_parse (it waits for the arena's copies) / in the sink
+  unsigned n_arenas_ = 0;
+  // the workers, summed (ns): copying a piece into page-locked memory, waiting for the lock + an arena with room, inside
+  // rfx_text_append, waiting for the copy that last read the buffer
+  std::atomic<uint64_t> w_memcpy_{0}, w_room_{0}, w_append_{0}, w_settle_{0}, w_idle_{0};
+  static uint64_t now_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+  void fail(const std::string& m) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!failed_.exchange(true)) fail_msg_ = m;
+    cv_.notify_all();
+  }
+
+  void worker() {
+    struct Buf { char* p = nullptr; int arena = -1; uint64_t gen = 0; long ticket = -1; } buf[2];
+    const size_t cap = piece_ + TAIL + (1u << 20);
+    for (Buf& b : buf) {
+      b.p = (char*)rfx_host_alloc(cap);
+      if (!b.p) return fail("cannot allocate page-locked text buffers");
+    }
+    // true: the copy that last read the buffer is done (or belonged to an arena that has been parsed since)
+    auto settle = [&](Buf& b) -> bool {
+      if (b.ticket < 0) return true;
+      auto same_gen = [&] {
+        std::lock_guard<std::mutex> g(mu_);
+        return arena_[b.arena].gen == b.gen;
+      };
+      if (same_gen() && rfx_text_wait(arena_[b.arena].t, b.ticket) != RFX_OK && same_gen()) {
+        fail(std::string("rfx_text_wait: ") + rfx_last_error());
+        return false;
+      }
+      b.ticket = -1;
+      return true;
+    };
+    int j = 0;
+    for (;;) {
+      Piece pc;
+      {
+        const uint64_t t0 = now_ns();
+        std::unique_lock<std::mutex> g(mu_);
+        cv_.wait(g, [&] { return !work_.empty() || closing_ || failed_; });
+        if (failed_ || (work_.empty() && closing_)) break;
+        pc = work_.front();
+        work_.pop_front();
+        w_idle_ += now_ns() - t0;
+      }
+      Buf& b = buf[j];
+      j ^= 1;
+      const uint64_t ta = now_ns();
+      if (!settle(b)) break;  // (the copy that last read this buffer)
+      const uint64_t tb = now_ns();
+      size_t n;
+      char* src = b.p;  // what is appended: [src, src + n)
+      if (pc.fd >= 0) {
+        // one byte before the range (is `lo` a line start?) and, behind it, the tail of the record that straddles `hi`
+        const uint64_t from = pc.lo ? pc.lo - 1 : 0, to = std::min<uint64_t>(pc.fsize, pc.hi + TAIL);
+        size_t got = 0;
+        const size_t want = (size_t)(to - from);
+        while (got < want) {
+          const ssize_t r = ::pread(pc.fd, b.p + got, want - got, (off_t)(from + got));
+          if (r < 0 && errno == EINTR) continue;
+          if (r <= 0) break;
+          got += (size_t)r;
+        }
+        if (got != want) { fail(std::string("read error on input: ") + strerror(errno)); break; }
+        const char *tb = b.p, *te = b.p + want;
+        const char* s0 = pc.lo ? CountIngest::record_start(tb + 1, tb, te) : tb;
+        const char* s1 = pc.hi >= pc.fsize ? te : CountIngest::record_start(tb + (pc.hi - from), tb, te);
+        if (pc.hi < pc.fsize && s1 == te && to < pc.fsize) { fail("a FASTQ record is longer than 1 MB"); break; }
+        if (s0 > s1) s0 = s1;
+        src = const_cast<char*>(s0);
+        n = (size_t)(s1 - s0);
+        if (n && src[n - 1] != '\n' && pc.hi >= pc.fsize) src[n++] = '\n';  // (a file without a final newline)
+      } else {
+        n = (size_t)(pc.e - pc.b);
+        if (n + 1 > cap) { fail("a FASTQ record is longer than a text buffer"); break; }
+        memcpy(b.p, pc.b, n);
+        if (n && b.p[n - 1] != '\n') b.p[n++] = '\n';  // (the last line of a file without a final newline)
+      }
+      const uint64_t tc = now_ns();
+      w_settle_ += tb - ta;
+      w_memcpy_ += tc - tb;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        for (;;) {
+          if (failed_) break;
+          if (filling_ >= 0 && rfx_text_room(arena_[filling_].t) >= n) break;
+          if (filling_ >= 0) {  // no room: this arena is this thread's ... the main thread's now
+            arena_[filling_].state = 2;
+            full_.push_back(filling_);
+            filling_ = -1;
+            cv_.notify_all();
+          }
+          int f = -1;
+          for (int a = 0; a < 2; ++a)
+            if (arena_[a].state == 0) { f = a; break; }
+          if (f >= 0) {
+            arena_[f].state = 1;
+            filling_ = f;
+            continue;
+          }
+          cv_.wait(g);
+        }
+        if (failed_) break;
+        const uint64_t td = now_ns();
+        w_room_ += td - tc;
+        const long tk = n ? rfx_text_append(arena_[filling_].t, src, n) : rfx_text_append(arena_[filling_].t, b.p, 0);
+        w_append_ += now_ns() - td;
+        if (tk < 0) {
+          g.unlock();
+          fail(std::string("rfx_text_append: ") + rfx_strerror((int)tk) + " " + rfx_last_error());
+          break;
+        }
+        b.arena = filling_;
+        b.gen = arena_[filling_].gen;
+        b.ticket = tk;
+        --pieces_open_;
+        cv_.notify_all();
+      }
+    }
+    // (the buffers outlive their last copies: wait for them)
+    for (Buf& b : buf) {
+      (void)settle(b);
+      rfx_host_free(b.p);
+    }
+  }
+
+  void finish_arena(int a) {  // this thread only: parse, hand on, give the arena back
+    rfx_text* t = arena_[a].t;
+    if (rfx_text_bytes(t)) {
+      int strict = 1;
+      const auto t0 = std::chrono::steady_clock::now();
+      rfx_reads* r = rfx_text_parse(t, RFX_PACK_COUNT, 0, &strict);
+      const auto t1 = std::chrono::steady_clock::now();
+      t_parse_ += std::chrono::duration<double>(t1 - t0).count();
+      ++n_arenas_;
+      if (r) {
+        reads_ += rfx_reads_count(r);
+        sink_(r);
+        t_sink_ += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+      } else if (!strict) {
+        std::vector<char> text((size_t)rfx_text_bytes(t));
+        if (rfx_text_fetch(t, text.data()) != RFX_OK) die(std::string("rufus_amd: rfx_text_fetch: ") + rfx_last_error());
+        host_bytes_ += text.size();
+        host_text_(text.data(), text.size());
+      } else {
+        die(std::string("rufus_amd: rfx_text_parse: ") + rfx_last_error());
+      }
+    }
+    {  // (the generation first: a worker that finds its ticket gone looks at it again before it calls that a failure)
+      std::lock_guard<std::mutex> g(mu_);
+      ++arena_[a].gen;
+    }
+    rfx_text_reset(t);
+    std::lock_guard<std::mutex> g(mu_);
+    arena_[a].state = 0;
+    cv_.notify_all();
+  }
+
+  // the full arenas that wait; all: until every piece is copied, then the partly filled arena too
+  void drain(bool all) {
+    for (;;) {
+      int a = -1;
+      {
+        std::unique_lock<std::mutex> g(mu_);
+        if (all) cv_.wait(g, [&] { return !full_.empty() || pieces_open_ == 0 || failed_; });
+        if (failed_) break;
+        if (!full_.empty()) {
+          a = full_.front();
+          full_.pop_front();
+        } else if (all && pieces_open_ == 0) {
+          if (filling_ < 0) break;
+          a = filling_;
+          arena_[a].state = 2;
+          filling_ = -1;
+        } else {
+          break;
+        }
+      }
+      finish_arena(a);
+    }
+    if (failed_) die("rufus_amd jellyfish: " + fail_msg_);
+  }
+
+ public:
+  TextIngest(rfx_ctx* ctx, unsigned threads, std::function<void(rfx_reads*)> sink,
+             std::function<void(const char*, size_t)> host_text, size_t arena_bytes = (size_t)1 << 30, size_t piece = 8u << 20)
+      : ctx_(ctx), nthreads_(threads ? threads : 1), sink_(std::move(sink)), host_text_(std::move(host_text)), piece_(piece) {
+    for (Arena& a : arena_) {
+      a.t = rfx_text_open(ctx_, arena_bytes);
+      if (!a.t) die(std::string("rufus_amd: rfx_text_open: ") + rfx_last_error());
+    }
+    for (unsigned t = 0; t < nthreads_; ++t) workers_.emplace_back([this] { worker(); });
+  }
+  ~TextIngest() {
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      closing_ = true;
+      cv_.notify_all();
+    }
+    for (auto& t : workers_) t.join();
+    for (Arena& a : arena_) rfx_text_close(a.t);
+  }
+  uint64_t reads() const { return reads_; }
+  uint64_t host_parsed_bytes() const { return host_bytes_; }
+  std::string timing() const {
+    char b[320];
+    snprintf(b, sizeof b, "%u arenas: %.3f s waiting for copies + parsing on the device, %.3f s in the sink (count); workers, "
+             "summed: memcpy %.3f s, lock + room %.3f s, rfx_text_append %.3f s, waiting for a buffer's copy %.3f s, for a piece %.3f s", n_arenas_,
+             t_parse_, t_sink_, w_memcpy_.load() * 1e-9, w_room_.load() * 1e-9, w_append_.load() * 1e-9, w_settle_.load() * 1e-9,
+             w_idle_.load() * 1e-9);
+    return b;
+  }
+
+  // A whole regular file by descriptor: byte ranges that the workers read themselves, straight into their page-locked
+  // buffers -- no mapping whose 4 KB pages have to be faulted in one by one and, worse, torn down again by ONE thread
+  // (munmap of a 20 GB mapping: 0.3 s of a count that takes 1.5).  false: the file does not start like strict 4-line
+  // FASTQ (nothing consumed).
+  bool feed_file(int fd, uint64_t size) {
+    std::vector<char> head((size_t)std::min<uint64_t>(size, 1u << 16));
+    size_t got = 0;
+    while (got < head.size()) {
+      const ssize_t n = ::pread(fd, head.data() + got, head.size() - got, (off_t)got);
+      if (n < 0 && errno == EINTR) continue;
+      if (n <= 0) break;
+      got += (size_t)n;
+    }
+    if (!CountIngest::looks_4line(head.data(), got)) return false;
+    for (uint64_t lo = 0; lo < size; lo += piece_) {
+      Piece pc{nullptr, nullptr};
+      pc.fd = fd;
+      pc.lo = lo;
+      pc.hi = std::min<uint64_t>(size, lo + piece_);
+      pc.fsize = size;
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        work_.push_back(pc);
+        ++pieces_open_;
+        cv_.notify_all();
+      }
+      drain(false);
+    }
+    drain(true);
+    return true;
+  }
+
+  // A whole regular file, mapped.  false: it does not start like strict 4-line FASTQ (nothing consumed).
+  bool feed_mapped(const char* data, size_t size) {
+    if (!CountIngest::looks_4line(data, std::min<size_t>(size, 1u << 16))) return false;
+    const char *b = data, *e = data + size, *at = b;
+    while (at < e) {
+      const char* want = at + piece_;
+      const char* cut = want >= e ? e : CountIngest::record_start(want, b, e);
+      if (cut == e && want < e && (size_t)(e - at) > piece_ + (1u << 20)) {
+        // no record start within reach: not the format this route is for -- what is left goes to the host parser whole
+        drain(true);
+        host_bytes_ += (size_t)(e - at);
+        host_text_(at, (size_t)(e - at));
+        return true;
+      }
+      {
+        std::lock_guard<std::mutex> g(mu_);
+        work_.push_back(Piece{at, cut});
+        ++pieces_open_;
+        cv_.notify_all();
+      }
+      at = cut;
+      drain(false);
     }
     drain(true);
     return true;

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "rfx_internal.h"
@@ -181,7 +182,17 @@ struct rfx_text {
   rfx_ctx* ctx = nullptr;
   uint8_t* arena = nullptr;
   uint64_t cap = 0, used = 0;
-  std::vector<hipEvent_t> ev;  // one per append: its bytes have left the host buffer
+  bool vmm = false;
+  // The copies run on a stream of their own: text for the NEXT block crosses PCIe while this ctx's stream parses and
+  // counts the block before it (a second rfx_text of the same ctx) -- on the ctx stream copies and kernels would take
+  // turns.  rfx_text_parse makes the ctx stream wait for the last copy.
+  hipStream_t copy = nullptr;
+  std::mutex mu;               // append / copied / wait may come from several host threads (the ingest's workers)
+  // One event per append: its bytes have left the host buffer.  The events live until close and are recorded again by
+  // the appends after a reset (n_ev of them are this generation's): a waiter that still holds a handle from before the
+  // reset -- whose copy is long done: the reset follows the parse -- must find an event, not freed memory.
+  std::vector<hipEvent_t> ev;
+  size_t n_ev = 0;
 };
 
 extern "C" {
@@ -192,8 +203,17 @@ rfx_text* rfx_text_open(rfx_ctx* c, uint64_t cap_bytes) {
   rfx_text* t = new rfx_text();
   t->ctx = c;
   t->cap = cap_bytes;
-  t->arena = (uint8_t*)dmalloc(c, (size_t)cap_bytes + 2 * TX_TILE);
-  if (!t->arena) {
+  // (plain hipMalloc, not the ctx's arena of mapped virtual memory: RFX_TEXT_VMM=1 keeps the arena for the A/B)
+  t->vmm = getenv("RFX_TEXT_VMM") != nullptr;
+  if (t->vmm) {
+    t->arena = (uint8_t*)dmalloc(c, (size_t)cap_bytes + 2 * TX_TILE);
+    if (t->arena && ctx_sync(c) != hipSuccess) { dfree(c, t->arena); t->arena = nullptr; }
+  } else if (hipMalloc((void**)&t->arena, (size_t)cap_bytes + 2 * TX_TILE) != hipSuccess) {
+    (void)hipGetLastError();
+    t->arena = nullptr;
+  }
+  if (!t->arena || hipStreamCreateWithFlags(&t->copy, hipStreamNonBlocking) != hipSuccess) {
+    if (t->arena) { if (t->vmm) dfree(c, t->arena); else (void)hipFree(t->arena); }
     delete t;
     return nullptr;
   }
@@ -203,8 +223,11 @@ rfx_text* rfx_text_open(rfx_ctx* c, uint64_t cap_bytes) {
 void rfx_text_close(rfx_text* t) {
   if (!t) return;
   (void)hipSetDevice(t->ctx->device);
+  (void)hipStreamSynchronize(t->copy);
   for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
-  dfree(t->ctx, t->arena);
+  (void)hipStreamDestroy(t->copy);
+  if (t->vmm) dfree(t->ctx, t->arena);
+  else (void)hipFree(t->arena);
   delete t;
 }
 
@@ -212,25 +235,34 @@ uint64_t rfx_text_room(const rfx_text* t) { return t ? t->cap - t->used : 0; }
 uint64_t rfx_text_bytes(const rfx_text* t) { return t ? t->used : 0; }
 
 long rfx_text_append(rfx_text* t, const void* host, uint64_t n) {
-  if (!t || (!host && n) || n > t->cap - t->used) return RFX_E_INVAL;
+  if (!t || (!host && n)) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
-  hipEvent_t e;
-  if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return RFX_E_HIP;
-  hipError_t rc = n ? hipMemcpyAsync(t->arena + t->used, host, n, hipMemcpyHostToDevice, c->stream) : hipSuccess;
-  if (rc == hipSuccess) rc = hipEventRecord(e, c->stream);
-  if (rc != hipSuccess) {
-    (void)hipEventDestroy(e);
-    return hip_fail(rc, "rfx_text_append");
+  std::lock_guard<std::mutex> g(t->mu);
+  if (n > t->cap - t->used) return RFX_E_RANGE;
+  if (t->n_ev == t->ev.size()) {
+    hipEvent_t e;
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return RFX_E_HIP;
+    t->ev.push_back(e);
   }
+  hipError_t rc = n ? hipMemcpyAsync(t->arena + t->used, host, n, hipMemcpyHostToDevice, t->copy) : hipSuccess;
+  if (rc == hipSuccess) rc = hipEventRecord(t->ev[t->n_ev], t->copy);
+  if (rc != hipSuccess) return hip_fail(rc, "rfx_text_append");
   t->used += n;
-  t->ev.push_back(e);
-  return (long)t->ev.size() - 1;
+  return (long)t->n_ev++;
+}
+
+static int text_event(rfx_text* t, long ticket, hipEvent_t* e) {
+  std::lock_guard<std::mutex> g(t->mu);
+  if (ticket < 0 || (size_t)ticket >= t->n_ev) return RFX_E_INVAL;
+  *e = t->ev[(size_t)ticket];
+  return RFX_OK;
 }
 
 int rfx_text_copied(rfx_text* t, long ticket) {
-  if (!t || ticket < 0 || (size_t)ticket >= t->ev.size()) return RFX_E_INVAL;
-  const hipError_t rc = hipEventQuery(t->ev[(size_t)ticket]);
+  hipEvent_t e;
+  if (!t || text_event(t, ticket, &e) != RFX_OK) return RFX_E_INVAL;
+  const hipError_t rc = hipEventQuery(e);
   if (rc == hipSuccess) return 1;
   if (rc == hipErrorNotReady) {
     (void)hipGetLastError();
@@ -239,10 +271,19 @@ int rfx_text_copied(rfx_text* t, long ticket) {
   return hip_fail(rc, "rfx_text_copied");
 }
 
+int rfx_text_wait(rfx_text* t, long ticket) {
+  hipEvent_t e;
+  if (!t || text_event(t, ticket, &e) != RFX_OK) return RFX_E_INVAL;
+  (void)hipSetDevice(t->ctx->device);
+  HIPCHK(hipEventSynchronize(e));
+  return RFX_OK;
+}
+
 int rfx_text_fetch(rfx_text* t, void* host) {
   if (!t || !host) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
+  HIPCHK(hipStreamSynchronize(t->copy));
   if (t->used) HIPCHK(hipMemcpyAsync(host, t->arena, t->used, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(ctx_sync(c));
   return RFX_OK;
@@ -250,8 +291,10 @@ int rfx_text_fetch(rfx_text* t, void* host) {
 
 void rfx_text_reset(rfx_text* t) {
   if (!t) return;
-  for (hipEvent_t e : t->ev) (void)hipEventDestroy(e);
-  t->ev.clear();
+  (void)hipSetDevice(t->ctx->device);
+  (void)hipStreamSynchronize(t->copy);
+  std::lock_guard<std::mutex> g(t->mu);
+  t->n_ev = 0;
   t->used = 0;
 }
 
@@ -266,6 +309,10 @@ rfx_reads* rfx_text_parse(rfx_text* t, int flags, int min_q, int* strict) {
     return nullptr;
   };
   if (n == 0) return not_strict();
+  {  // the ctx stream waits for the copies (they ran on the arena's own stream)
+    std::lock_guard<std::mutex> g(t->mu);
+    if (t->n_ev && hipStreamWaitEvent(c->stream, t->ev[t->n_ev - 1], 0) != hipSuccess) return nullptr;
+  }
   // whole tiles are read: what lies behind the text holds no newline
   if (hipMemsetAsync(t->arena + n, 0, 2 * TX_TILE, c->stream) != hipSuccess) return nullptr;
   const uint64_t n_tiles = (n + TX_TILE - 1) / TX_TILE;

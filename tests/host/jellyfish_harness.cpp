@@ -84,6 +84,90 @@ rfx_reads* rfx_reads_upload(rfx_ctx*, const uint64_t* codes, const uint32_t* acg
   return r;
 }
 void rfx_reads_free(rfx_reads* r) { delete r; }
+uint32_t rfx_reads_count(const rfx_reads* r) { return r ? (uint32_t)r->len.size() : 0; }
+
+// ---- rfx_text_* (round 6: the text route of the count, host/rfx_ingest.hpp TextIngest): a host stand-in that refuses
+// what the device refuses (anything but strict 4-line FASTQ with every line newline-terminated) and packs the rest with
+// the library's own host packer.  The tool's threads (copiers, the parsing thread) run against it under the sanitizers.
+}  // extern "C"
+struct rfx_text {
+  std::string buf;
+  uint64_t cap = 0;
+  long appends = 0;
+  std::mutex mu;
+};
+extern "C" {
+rfx_text* rfx_text_open(rfx_ctx*, uint64_t cap_bytes) {
+  rfx_text* t = new rfx_text;
+  t->cap = cap_bytes;
+  return t;
+}
+void rfx_text_close(rfx_text* t) { delete t; }
+uint64_t rfx_text_room(const rfx_text* t) { return t->cap - t->buf.size(); }
+uint64_t rfx_text_bytes(const rfx_text* t) { return t->buf.size(); }
+long rfx_text_append(rfx_text* t, const void* host, uint64_t n) {
+  std::lock_guard<std::mutex> g(t->mu);
+  if (n > t->cap - t->buf.size()) return RFX_E_RANGE;
+  t->buf.append((const char*)host, (size_t)n);
+  return t->appends++;
+}
+int rfx_text_copied(rfx_text* t, long ticket) {
+  std::lock_guard<std::mutex> g(t->mu);
+  return ticket >= 0 && ticket < t->appends ? 1 : RFX_E_INVAL;
+}
+int rfx_text_wait(rfx_text* t, long ticket) { return rfx_text_copied(t, ticket) == 1 ? RFX_OK : RFX_E_INVAL; }
+int rfx_text_fetch(rfx_text* t, void* host) {
+  memcpy(host, t->buf.data(), t->buf.size());
+  return RFX_OK;
+}
+void rfx_text_reset(rfx_text* t) {
+  std::lock_guard<std::mutex> g(t->mu);
+  t->buf.clear();
+  t->appends = 0;
+}
+rfx_reads* rfx_text_parse(rfx_text* t, int flags, int, int* strict) {
+  *strict = 1;
+  if (flags != RFX_PACK_COUNT) return nullptr;
+  const std::string& b = t->buf;
+  std::vector<uint64_t> start;
+  std::vector<uint32_t> slen;
+  size_t p = 0;
+  auto line = [&](size_t& lo, size_t& hi) {  // [lo, hi) without the newline; false: no newline left
+    const size_t nl = b.find('\n', p);
+    if (nl == std::string::npos) return false;
+    lo = p;
+    hi = nl;
+    p = nl + 1;
+    return true;
+  };
+  while (p < b.size()) {
+    size_t h0, h1, s0, s1, p0, p1, q0, q1;
+    if (!line(h0, h1) || !line(s0, s1) || !line(p0, p1) || !line(q0, q1) || h1 == h0 || b[h0] != '@' || p1 == p0 || b[p0] != '+' ||
+        s1 - s0 != q1 - q0) {
+      *strict = 0;
+      return nullptr;
+    }
+    start.push_back(s0);
+    slen.push_back((uint32_t)(s1 - s0));
+  }
+  if (start.empty()) {
+    *strict = 0;
+    return nullptr;
+  }
+  rfx_reads* r = new rfx_reads;
+  uint64_t words = 0;
+  for (uint32_t l : slen) words += (l + 31) / 32;
+  r->codes.assign(words ? words : 1, 0);
+  r->acgt.assign(words ? words : 1, 0);
+  r->woff.assign(start.size() + 1, 0);
+  r->len.assign(start.size(), 0);
+  if (rfx_pack_spans(b.data(), start.data(), slen.data(), nullptr, (uint32_t)start.size(), 0, RFX_PACK_COUNT, r->codes.data(),
+                     r->acgt.data(), nullptr, r->woff.data(), r->len.data()) != RFX_OK) {
+    delete r;
+    return nullptr;
+  }
+  return r;
+}
 
 rfx_peers* rfx_peers_create(int n) {
   rfx_peers* p = new rfx_peers;

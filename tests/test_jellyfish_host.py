@@ -263,3 +263,36 @@ def test_a_count_that_dies_leaves_an_empty_output(jf, testrun, tmp_path):
     p.wait(timeout=60)
     p.stdin.close()
     assert p.returncode != 0 and os.path.getsize(f"{d}/killed.Jhash") == 0, grown
+
+
+@pytest.mark.parametrize("tool", ["plain", "san"])
+def test_count_text_route_and_what_it_hands_back(jf, jf_san, small_trio, tmp_path, tool):
+    """Round 6: a regular FASTQ file is not parsed on the host but appended to a text arena piece by piece (TextIngest) and
+    parsed behind rfx_text_parse.  Same payload as the host route (RFX_HOST_PARSE=1) and as the oracle: with pieces of
+    a few KB (many arenas' worth of tickets and buffer reuse), with a file that lacks its final newline, and with
+    blank lines between records / a wrapped record -- which the text route refuses arena by arena and hands to the host
+    parser (the reference's grammar, jf mer_overlap_sequence_parser.hpp:179-206)."""
+    from tests.synth import fastq_bytes
+    exe = jf if tool == "plain" else jf_san
+    d = str(tmp_path)
+    fq = fastq_bytes(small_trio["child"], 1)
+    recs = fq.split(b"\n@")
+    recs = [recs[0]] + [b"@" + r for r in recs[1:]]
+    blank = b"\n".join(recs[:50]) + b"\n\n" + b"\n".join(recs[50:300]) + b"\n\n\n" + b"\n".join(recs[300:])
+    h, s_, p_, q_ = recs[10].split(b"\n")[:4]
+    wrapped = b"\n".join(recs[:10] + [h + b"\n" + s_[:70] + b"\n" + s_[70:] + b"\n+\n" + q_[:70] + b"\n" + q_[70:]] + recs[11:])
+    cases = {"plain.fq": fq, "nonl.fq": fq.rstrip(b"\n"), "blank.fq": blank}
+    want = oracle.count([fq], 25, 100_000_000, lower=2).payload()
+    base = [exe, "count", "-m", "25", "-s", "100M", "-t", "4", "-C", "-L", "2"]
+    for name, text in cases.items():
+        open(f"{d}/{name}", "wb").write(text)
+        for env in ({}, {"RFX_HOST_PARSE": "1"}, {"RFX_DEVICE_PARSE": "1", "RFX_INGEST_PIECE": "3000"},
+                    {"RFX_DEVICE_PARSE": "1", "RFX_TEXT_MMAP": "1"}):
+            r = sh(base + ["-o", "o.jf", name], d, env=env)
+            assert r.returncode == 0 and _payload(f"{d}/o.jf") == want, (name, env, r.stderr[-400:])
+    # a wrapped (multi-line) record in the middle of a file that starts like strict FASTQ: the reference parses it; the
+    # parallel HOST reader says it cannot (RFX_HOST_THREADS=1 is its advice); the text route hands the text back and
+    # the sequential parser counts it
+    open(f"{d}/wrapped.fq", "wb").write(wrapped)
+    r = sh(base + ["-o", "w.jf", "wrapped.fq"], d, env={"RFX_DEVICE_PARSE": "1"})
+    assert r.returncode == 0 and _payload(f"{d}/w.jf") == want, r.stderr[-400:]

@@ -712,3 +712,28 @@ def test_count_cli_reproduces_jellyfish_own_md5_kats(tmp_path):
         r = sh([f"{BIN}/jellyfish", "histo", "m15.jf"], d)
         assert r.returncode == 0, r.stderr
         assert hashlib.md5(r.stdout).hexdigest() == md5
+
+
+def test_count_text_route_on_the_device_matches_the_host_route_and_the_golden(testrun, tmp_path):
+    """Round 6, SURVEY section 2 K1: `jellyfish count` of a regular FASTQ file with the text parsed ON THE DEVICE
+    (RFX_DEVICE_PARSE=1: host/rfx_ingest.hpp TextIngest -> rfx_text_*) writes the payload of the host route
+    (RFX_HOST_PARSE=1) = the golden sha256 -- also from pieces of 3 KB (hundreds of appends per arena, every buffer reused
+    many times), from a file without its final newline, and from a file with blank lines between records, which the
+    device refuses and hands back to the host parser."""
+    exp = testrun["expected"]
+    d = str(tmp_path)
+    fq = testrun["Child"][0] + testrun["Child"][1]
+    want = exp["samples"]["Child"]["s100M"]["payload_sha256"]
+    recs = fq.split(b"\n@")
+    blank = b"\n@".join(recs[:40]) + b"\n\n@" + b"\n@".join(recs[40:])
+    base = [f"{BIN}/jellyfish", "count", "--disk", "-m", "25", "-L", "2", "-s", "100M", "-t", "6", "-C"]
+    for name, text in (("c.fq", fq), ("nonl.fq", fq.rstrip(b"\n")), ("blank.fq", blank)):
+        open(f"{d}/{name}", "wb").write(text)
+        for env in ({"RFX_DEVICE_PARSE": "1"}, {"RFX_HOST_PARSE": "1"}, {"RFX_DEVICE_PARSE": "1", "RFX_INGEST_PIECE": "3000"},
+                    {"RFX_DEVICE_PARSE": "1", "RFX_TEXT_MMAP": "1"}):
+            r = subprocess.run(base + ["-o", "o.Jhash", name], cwd=d, env=dict(os.environ, RFX_CLI_TRACE="1", **env),
+                               stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            assert r.returncode == 0, r.stderr
+            assert (b"text route" in r.stderr) == ("RFX_DEVICE_PARSE" in env), r.stderr
+            blob = open(f"{d}/o.Jhash", "rb").read()
+            assert hashlib.sha256(blob[9 + int(blob[:9]):]).hexdigest() == want, (name, env)

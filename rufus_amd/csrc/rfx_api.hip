@@ -1711,8 +1711,17 @@ struct rfx_finish {
 
 // Survivors the leaf will stage per k-mer instance: what the last emit on this ctx saw (+30 %), else the first guess of
 // the survivor store (msp_emit_queue).
+static uint64_t msp_surv_key(uint64_t lower, uint64_t kmers) { return (kmers >> 24) | ((uint64_t)(lower >= 2 ? 1 : 0) << 62); }
+// Survivors per instance are unknown before counting.  Samples of one run look alike, so the ratio the last emit of a
+// table of this size saw -- else the last emit on this ctx -- is the guess (+30 %); the first emit assumes a quarter
+// (singletons dropped; 8 % for big inputs, where a rerun is cheaper than the memory) or 60 %.  A guess that is too
+// small costs one rerun with the capacity the cursors report.
 static double msp_surv_guess(rfx_ctx* c, uint64_t lower, uint64_t kmers) {
-  const double seen = c->msp_surv_frac[lower >= 2 ? 1 : 0];
+  double seen = c->msp_surv_frac[lower >= 2 ? 1 : 0];
+  if (kmers >= (1ull << 28)) {  // (small tables: the last emit's ratio, as ever -- their sizes say little)
+    auto it = c->msp_surv_by_size.find(msp_surv_key(lower, kmers));
+    if (it != c->msp_surv_by_size.end()) seen = it->second;
+  }
   double frac = seen > 0 ? seen * 1.3 : (lower >= 2 ? (kmers > (1ull << 32) ? 0.08 : 0.25) : 0.6);
   if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
   return frac;
@@ -1970,6 +1979,15 @@ static int msp_leaf_refined(rfx_finish* f, int to_bits, const std::vector<std::v
                    sel_bits, 2 * t->k - 7, t->pos_lo, t->pos_hi, f->lower, f->upper, f->aw, f->ac, cur, (uint32_t)f->cap,
                    cur + ncur, cur + ncur + 1, cur + ncur + 2, geo, (const uint32_t* const*)(d + 2 * nleaf),
                    (const uint32_t*)ptrs[2 * nleaf], stage, (uint32_t)ci, std::min<uint32_t>(lgrid, (uint32_t)n2));
+  }
+  if (getenv("RFX_STAGE_DEBUG")) {  // (chunks each launch took beyond its workgroups' first ones)
+    std::vector<uint32_t> more(cut.size(), 0);
+    if (ctx_sync(c) == hipSuccess && hipMemcpy(more.data(), stage.more, cut.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+      uint64_t tot = 0;
+      for (uint32_t m : more) tot += m;
+      fprintf(stderr, "[rfx stage] geo %d grid %u chunk %u pool %u launches %zu: extra chunks taken %llu (first launch %u), est survivors per launch %llu\n",
+              geo, lgrid, lchunk, lpool, cut.size() - 1, (unsigned long long)tot, more[0], (unsigned long long)est_surv);
+    }
   }
   drop();  // stream-ordered pool
   dfree(c, d_ptrs);
@@ -2310,9 +2328,7 @@ static int msp_passes_leaf(rfx_finish* f) {
     if (rc) return rc;
     f->kmers += kmers;
     if (!f->aw) {  // first pass with records: the store is sized for ONE pass, then for all (below)
-      const double seen = c->msp_surv_frac[f->lower >= 2 ? 1 : 0];
-      double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? (kmers > (1ull << 32) ? 0.08 : 0.25) : 0.6);
-      if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
+      const double frac = msp_surv_guess(c, f->lower, kmers);
       f->cap = (uint64_t)((double)kmers * frac) / P1;
       f->cap += f->cap / 8 + 4096;
       if (f->cap >= (1ull << 32)) f->cap = (1ull << 32) - 1;
@@ -2554,13 +2570,7 @@ static int msp_emit_queue(rfx_finish* f) {
   hipError_t e = hipSuccess;
   if (!deferred) {
     if (!f->cap) {
-      // Survivors per instance: unknown before counting.  Samples of one run look alike, so the ratio the
-      // last emit on this ctx saw (+30 %) is the guess; the first emit assumes a quarter (singletons
-      // dropped; 8 % for big inputs, where a rerun is cheaper than the memory) or 60 %.  A guess that
-      // is too small costs one rerun with the capacity the cursors report.
-      const double seen = c->msp_surv_frac[f->lower >= 2 ? 1 : 0];
-      double frac = seen > 0 ? seen * 1.3 : (f->lower >= 2 ? (kmers > (1ull << 32) ? 0.08 : 0.25) : 0.6);
-      if (const char* ev = getenv("RFX_MSP_SURV_FRAC")) frac = atof(ev);
+      const double frac = msp_surv_guess(c, f->lower, f->kmers);  // (survivors per instance: a guess)
       f->cap = (uint64_t)((double)f->kmers * frac) / P1;
       f->cap += f->cap / 8 + 4096;
     }
@@ -2745,7 +2755,11 @@ static int msp_emit_collect(rfx_finish* f, rfx_records** out) {
   }
   const uint64_t total_out = f->total_out;
   big->n = total_out;
-  if (f->kmers) c->msp_surv_frac[f->lower >= 2 ? 1 : 0] = (double)total_out / (double)f->kmers;
+  if (f->kmers) {
+    c->msp_surv_frac[f->lower >= 2 ? 1 : 0] = (double)total_out / (double)f->kmers;
+    if (c->msp_surv_by_size.size() > 256) c->msp_surv_by_size.clear();
+    c->msp_surv_by_size[msp_surv_key(f->lower, f->kmers)] = (double)total_out / (double)f->kmers;
+  }
   // Give a large slack back (exact arrays, device copies); a small one is not worth the 40 B/record of
   // copy traffic -- the arrays return to the pool with the records anyway.
   if ((f->room - total_out) * 20 > (2ull << 30)) {

@@ -63,6 +63,12 @@ struct rfx_ctx {
   hipError_t launch_error = hipSuccess;
   std::vector<struct rfx_table*> pend_tables;  // tables with unread MSP capacity flags
   double msp_surv_frac[2] = {0, 0};            // survivors / instances seen by the last MSP emit ([lower >= 2])
+  // ... and by the last emit of a table of (about) the same number of k-mer instances: a driver that counts samples of
+  // different depth in turn (tumor 60x / normal 30x: BASELINE configs[4]) finds each sample's own ratio, not its
+  // predecessor's -- the normal's store was sized by the tumor's ratio, half its own, overflowed, and the whole leaf
+  // phase of every pass ran twice (102 instead of 68 leaf launches per sample chain, rounds 2 - 5).
+  // key: instances >> 24 | lower class << 62
+  std::map<uint64_t, double> msp_surv_by_size;
   // pinned host scratch: small read-backs and uploads go through it (pageable copies cost a
   // staging round trip each); a bump allocator that is reset at every stream synchronisation
   char* pin = nullptr;

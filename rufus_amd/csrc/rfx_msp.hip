@@ -1267,7 +1267,9 @@ __global__ __launch_bounds__(SP_BLK) void k_surv_place(const uint64_t* __restric
       const uint32_t start = incl - cn + (threadIdx.x >= 64 ? low : 0u);
       s_pst[threadIdx.x] = start;
       if ((uint64_t)at + cn > cap) {  // dropped; the host reruns with the capacity the cursors ask for
-        atomicExch(flag, 1u);
+        // (a plain store: once a store is full every round of every workgroup comes here for most of the 128 bins, and
+        // returning exchanges on the ONE flag word made the last launches of such a finish take 30 ms instead of 0.5)
+        __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_pbase[threadIdx.x] = ~0ull;
       } else {
         s_pbase[threadIdx.x] = (uint64_t)threadIdx.x * cap + at - start;  // (+ the entry's place in the round)

@@ -7,7 +7,7 @@
 `--stats` sums over the whole process: the warm-up step (which runs without run maps, so with other kernels and launch
 counts) and, in round 5, a step that was partially repeated after an out-of-memory retry (VERDICT r5 "What's weak" #5: 255
 k_msp_leaf launches where two steps make 204).  Here the launches are cut into steps where the trace says a step ends -- a
-step of the W / TN workloads ends with the read filter over the subject's blocks, the last kernel of which is k_hits_mask
+step of the W / TN workloads ends with the read filter over the subject's blocks, the last kernel of which is k_hits_mask / k_mask_count
 -- and ONLY THE LAST STEP (the one bench.py would time) is summarised, in --stats' own CSV layout.  A sidecar
 `<out>.meta.json` says how many steps the trace held, which one was taken and how many launches it has, and
 tests/test_evidence_host.py holds the launch counts against `launches_by_kernel_per_chain` of the round's bench line.
@@ -25,13 +25,23 @@ def main():
     for r in csv.DictReader(open(src)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    # step boundaries: a maximal group of launches between two k_synth_reads-free stretches that ends with k_hits_mask
-    # followed by anything that is not a filter kernel
+    # step boundaries: a step of the W / TN workloads ends with the read filter over the subject's blocks (k_filter_* +
+    # k_hits_mask or k_mask_count per block, the runtime's fill / copy kernels between them): the last filter-family
+    # launch before a kernel of ours that is NOT of that family (or before the end of the trace)
     def is_filter(n):
-        return "k_filter" in n or "k_hits_mask" in n
-    ends = [i for i in range(len(rows)) if "k_hits_mask" in rows[i][2] and (i + 1 == len(rows) or not is_filter(rows[i + 1][2]))]
+        return "k_filter" in n or "k_hits_mask" in n or "k_mask_count" in n
+
+    def ours(n):
+        return "k_" in n and "__amd_rocclr" not in n
+    ends = []
+    for i in range(len(rows)):
+        if not is_filter(rows[i][2]):
+            continue
+        nxt = next((rows[j][2] for j in range(i + 1, len(rows)) if ours(rows[j][2])), None)
+        if nxt is None or not is_filter(nxt):
+            ends.append(i)
     if not ends:
-        raise SystemExit("no k_hits_mask launch in the trace: not a W / TN step")
+        raise SystemExit("no read-filter launch in the trace: not a W / TN step")
     # the first launch of the last step: the one after the previous step's end (or after the input was synthesised)
     last_end = ends[-1]
     first = ends[-2] + 1 if len(ends) > 1 else 0

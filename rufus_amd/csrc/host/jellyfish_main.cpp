@@ -233,15 +233,16 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   };
   std::unique_ptr<CountIngest> ingest;  // (kept to the end: its page-locked blocks serve the output drain)
   // Round 6 (kernel K1): a regular FASTQ file counted on one device need not be parsed on the host at
-  // all -- its text goes to the device as it lies and is parsed and packed there (rfx_ingest.hpp TextIngest,
-  // csrc/rfx_text.hip).  Which route is faster is a matter of the CPUs the count may use (profiles/r06_text_route.txt,
-  // 20 GB of FASTQ on the GPU box's 16-CPU quota): with 16 parser threads the host parses and packs at 30 - 35 GB/s and
-  // uploads 68 bytes per read, the text route moves 330 bytes per read over PCIe at what 16 threads of pread + one
-  // copy stream reach, ~30 GB/s -- a draw, and the host route keeps the device free; with 5 threads (`runRufus.sh -pj`:
-  // the three counts of a trio at once) the host route is CPU-bound and the text route 22 % faster.  So: the text route
-  // when the count has at most 8 threads; RFX_DEVICE_PARSE=1 / RFX_HOST_PARSE=1 force one or the other.
+  // all -- its text can go to the device as it lies and be parsed and packed there (rfx_ingest.hpp TextIngest,
+  // csrc/rfx_text.hip): RFX_DEVICE_PARSE=1.  It is NOT the default, because on the GPU box it is no faster
+  // (profiles/r06_text_route.txt, 20 GB of FASTQ, 16-CPU quota): 16 parser threads parse and pack at 30 - 35 GB/s and
+  // upload 68 bytes per read; the text route has to move 330 bytes per read over PCIe and reaches ~30 GB/s with 8 MB
+  // pieces from 16 threads on one copy stream -- a draw for one count (0.6 - 0.8 s of ingest either way), and a draw for the
+  // three counts of `runRufus.sh -pj` at once (2.5 s both; with pread instead of the mapping the text route takes 4.1 s:
+  // three processes' readers on one tmpfs file system get in each other's way).  The route stays: it is what a host
+  // with fewer cores per GPU than this box wants (it needs a memcpy per read where the parser needs a microsecond).
   const bool text_ok = n_gpu == 1 && nthreads > 1 && !sam_chr && !spool_path && !keep_path;
-  const bool device_text = text_ok && !getenv("RFX_HOST_PARSE") && (getenv("RFX_DEVICE_PARSE") || nthreads <= 8);
+  const bool device_text = text_ok && getenv("RFX_DEVICE_PARSE") && !getenv("RFX_HOST_PARSE");
   std::unique_ptr<TextIngest> text_ingest;
   {
     for (Input& in : inputs) {
@@ -259,7 +260,8 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
               (size_t)1 << 30, getenv("RFX_INGEST_PIECE") ? (size_t)std::max(1024ll, atoll(getenv("RFX_INGEST_PIECE"))) : (size_t)8 << 20));
           trace("count: text arenas open, copiers up");
         }
-        if (getenv("RFX_TEXT_MMAP")) {  // (A/B: the mapped route -- its munmap alone takes 0.3 s per 20 GB)
+        if (!getenv("RFX_TEXT_PREAD")) {  // (the mapped route; RFX_TEXT_PREAD=1: the workers pread their ranges -- faster for one
+                                          // count, 0.69 against 0.92 s per 20 GB, much slower for three at once)
           void* m = mmap(nullptr, in.size, PROT_READ, MAP_PRIVATE, in.fd, 0);
           if (m != MAP_FAILED) {
             (void)madvise(m, in.size, MADV_SEQUENTIAL);

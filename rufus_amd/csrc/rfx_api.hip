@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <sys/mman.h>
+
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -695,7 +697,37 @@ int rfx_sync(rfx_ctx* c) {
 
 void* rfx_stream(rfx_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
+}  // extern "C"
+namespace {
+// Big staging buffers: anonymous memory on transparent huge pages, then registered with the runtime -- page-locking
+// goes by the page, and 320 MB of 2 MB pages take 0.02 s where hipHostMalloc's 4 KB pages take 0.06 (and 0.03 to free);
+// every executable of the drop-in chain pins ~1 GB before its first byte moves.  (scratch/ubench/pin_cost.cpp; uploads
+// from such a buffer run at the same 57 GB/s.)  Where huge pages or the registration are refused: hipHostMalloc.
+std::mutex g_host_mu;
+std::map<void*, size_t> g_host_registered;
+}  // namespace
+extern "C" {
+
 void* rfx_host_alloc(size_t bytes) {
+  if (bytes >= ((size_t)8 << 20) && !getenv("RFX_NO_THP_PIN")) {
+    const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void* m = mmap(nullptr, len + ((size_t)2 << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m != MAP_FAILED) {
+      // (a 2 MB-aligned start: the kernel backs only aligned 2 MB ranges with huge pages)
+      char* a = (char*)(((uintptr_t)m + ((size_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1));
+      if (a > (char*)m) (void)munmap(m, (size_t)(a - (char*)m));
+      const size_t tail = (size_t)((char*)m + len + ((size_t)2 << 20) - (a + len));
+      if (tail) (void)munmap(a + len, tail);
+      (void)madvise(a, len, MADV_HUGEPAGE);
+      if (hipHostRegister(a, len, hipHostRegisterDefault) == hipSuccess) {
+        std::lock_guard<std::mutex> g(g_host_mu);
+        g_host_registered[a] = len;
+        return a;
+      }
+      (void)hipGetLastError();
+      (void)munmap(a, len);
+    }
+  }
   void* p = nullptr;
   if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
     (void)hipGetLastError();
@@ -704,7 +736,22 @@ void* rfx_host_alloc(size_t bytes) {
   return p;
 }
 void rfx_host_free(void* p) {
-  if (p) (void)hipHostFree(p);
+  if (!p) return;
+  size_t len = 0;
+  {
+    std::lock_guard<std::mutex> g(g_host_mu);
+    auto it = g_host_registered.find(p);
+    if (it != g_host_registered.end()) {
+      len = it->second;
+      g_host_registered.erase(it);
+    }
+  }
+  if (len) {
+    (void)hipHostUnregister(p);
+    (void)munmap(p, len);
+  } else {
+    (void)hipHostFree(p);
+  }
 }
 
 int rfx_mem_reserve(rfx_ctx* c, uint64_t bytes) {

@@ -730,7 +730,7 @@ def test_count_text_route_on_the_device_matches_the_host_route_and_the_golden(te
     for name, text in (("c.fq", fq), ("nonl.fq", fq.rstrip(b"\n")), ("blank.fq", blank)):
         open(f"{d}/{name}", "wb").write(text)
         for env in ({"RFX_DEVICE_PARSE": "1"}, {"RFX_HOST_PARSE": "1"}, {"RFX_DEVICE_PARSE": "1", "RFX_INGEST_PIECE": "3000"},
-                    {"RFX_DEVICE_PARSE": "1", "RFX_TEXT_MMAP": "1"}):
+                    {"RFX_DEVICE_PARSE": "1", "RFX_TEXT_PREAD": "1"}):
             r = subprocess.run(base + ["-o", "o.Jhash", name], cwd=d, env=dict(os.environ, RFX_CLI_TRACE="1", **env),
                                stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert r.returncode == 0, r.stderr

@@ -287,7 +287,7 @@ def test_count_text_route_and_what_it_hands_back(jf, jf_san, small_trio, tmp_pat
     for name, text in cases.items():
         open(f"{d}/{name}", "wb").write(text)
         for env in ({}, {"RFX_HOST_PARSE": "1"}, {"RFX_DEVICE_PARSE": "1", "RFX_INGEST_PIECE": "3000"},
-                    {"RFX_DEVICE_PARSE": "1", "RFX_TEXT_MMAP": "1"}):
+                    {"RFX_DEVICE_PARSE": "1", "RFX_TEXT_PREAD": "1"}, {"RFX_DEVICE_PARSE": "1"}):
             r = sh(base + ["-o", "o.jf", name], d, env=env)
             assert r.returncode == 0 and _payload(f"{d}/o.jf") == want, (name, env, r.stderr[-400:])
     # a wrapped (multi-line) record in the middle of a file that starts like strict FASTQ: the reference parses it; the

@@ -7,7 +7,7 @@ set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 cd "$R"
-export RFX_COMMIT=${RFX_COMMIT:-$(cat gpurun_out/.commit 2>/dev/null || echo unknown)}
+export RFX_COMMIT=${RFX_COMMIT:-$(cat scratch/.commit 2>/dev/null || echo unknown)}
 O=gpurun_out/profiles_r06; mkdir -p $O
 if [ "${STATS:-1}" = 1 ]; then
 timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/trace -o t -- python bench.py --inner --steps 1 --warmup 1 --no-check > $O/stats.log 2>&1

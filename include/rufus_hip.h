@@ -105,6 +105,11 @@ void rfx_close(rfx_ctx*);
 int rfx_sync(rfx_ctx*);
 /* Page-locked host memory for staging buffers of the ingest pipelines (uploads from it run at PCIe speed). */
 void* rfx_host_alloc(size_t bytes);
+/* The same memory without a call into the HIP runtime: usable as host memory at once -- a tool fills its staging
+ * buffers while the device is still being opened on another thread -- and page-locked later, by rfx_host_pin (idempotent;
+ * ~1 ms per 320 MB of huge pages), before the first upload from it.  Freed by rfx_host_free. */
+void* rfx_host_alloc_lazy(size_t bytes);
+int rfx_host_pin(void* p);
 void rfx_host_free(void*);
 /* Host threads this process can keep busy: hardware threads, cut to its CPU affinity and to the CPU-bandwidth quota
  * of its cgroup (a container given 16 CPUs' worth of time on a 256-thread host runs 64 parser threads three times

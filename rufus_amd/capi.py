@@ -41,6 +41,8 @@ SIGNATURES = {
     "rfx_close": (None, [C.c_void_p]),
     "rfx_sync": (C.c_int, [C.c_void_p]),
     "rfx_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "rfx_host_alloc_lazy": (C.c_void_p, [C.c_size_t]),
+    "rfx_host_pin": (C.c_int, [C.c_void_p]),
     "rfx_host_cpus": (C.c_uint, []),
     "rfx_host_free": (None, [C.c_void_p]),
     "rfx_stream": (C.c_void_p, [C.c_void_p]),

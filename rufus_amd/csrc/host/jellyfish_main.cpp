@@ -96,18 +96,44 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
     gpus.resize(1);
   }
   const int n_gpu = (int)gpus.size();
-  std::vector<rfx_ctx*> ctxs = open_ctxs(gpus);
+  // The devices are opened (HIP runtime start, context, arena: 0.1 - 0.25 s) on a thread of their own while this one
+  // looks at the inputs, starts the output's page allocation and the parser threads: the staging blocks are plain memory
+  // until their first upload (rfx_host_alloc_lazy / rfx_host_pin), so parsing needs no device.  Everything that touches
+  // a ctx or a table goes through device_ready() first.  (Round 6: ~0.3 s of a 1.3 s count of 64 M reads.)
+  std::vector<rfx_ctx*> ctxs;
   std::vector<rfx_table*> tabs;
-  rfx_peers* peers = n_gpu > 1 ? rfx_peers_create(n_gpu) : nullptr;
-  for (int g = 0; g < n_gpu; ++g) {
-    rfx_table* tb = rfx_count_begin(ctxs[g], k, canonical, lsize, 0, 0, 0);
-    if (!tb) die(std::string("rufus_amd: ") + rfx_last_error());
-    tabs.push_back(tb);
-  }
-  rfx_ctx* ctx = ctxs[0];
-  rfx_table* tab = tabs[0];
+  rfx_peers* peers = nullptr;
+  rfx_ctx* ctx = nullptr;
+  rfx_table* tab = nullptr;
+  bool defer = false;  // (decided below, before the opener looks at it)
+  std::atomic<bool> inputs_known{false};
+  std::mutex open_mu;
+  std::condition_variable open_cv;
+  std::thread opener([&] {
+    ctxs = open_ctxs(gpus);
+    peers = n_gpu > 1 ? rfx_peers_create(n_gpu) : nullptr;
+    for (int g = 0; g < n_gpu; ++g) {
+      rfx_table* tb = rfx_count_begin(ctxs[g], k, canonical, lsize, 0, 0, 0);
+      if (!tb) die(std::string("rufus_amd: ") + rfx_last_error());
+      tabs.push_back(tb);
+    }
+    ctx = ctxs[0];
+    tab = tabs[0];
+    trace("count: device open, table made");
+    {  // (the passes / peers settings depend on what the inputs are: wait for the main thread's look at them)
+      std::unique_lock<std::mutex> g(open_mu);
+      open_cv.wait(g, [&] { return inputs_known.load(); });
+    }
+    for (int g = 0; g < n_gpu; ++g) {
+      if (defer && rfx_count_set_passes(tabs[g], 0) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+      if (peers && rfx_count_set_peers(tabs[g], peers, g) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+    }
+  });
+  auto device_ready = [&] {
+    if (opener.joinable()) opener.join();
+  };
+  const bool sync_open = getenv("RFX_SYNC_OPEN") != nullptr;  // (A/B: the device opened before anything else, as until round 6)
   const auto t_init = std::chrono::steady_clock::now();
-  trace("count: device open, table made");
 
   // Inputs: regular files are mapped (their size is known), pipes are streamed.  When the input is a pipe
   // (its size is unknown: RUFUS feeds 30x genomes through FIFOs, scripts/RunJellyForRUFUS.sh:23-31) or a big
@@ -159,19 +185,22 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   nthreads = std::min(nthreads, rfx_host_cpus());  // -t 40 on a 16-CPU cgroup: 16 parsers
   if (const char* ev = getenv("RFX_HOST_THREADS")) nthreads = (unsigned)std::max(1, atoi(ev));
   const bool msp_ok = k >= 23 && k <= 31;  // the super-k-mer path (rfx_count_set_passes needs it)
-  bool defer = msp_ok && (any_stream || known_bytes > (16ull << 30) || getenv("RFX_COUNT_PASSES"));
+  defer = msp_ok && (any_stream || known_bytes > (16ull << 30) || getenv("RFX_COUNT_PASSES"));
   if (const char* ev = getenv("RFX_COUNT_DEFER")) defer = msp_ok && atoi(ev) != 0;
   if (n_gpu > 1) defer = true;
-  for (int g = 0; g < n_gpu; ++g) {
-    if (defer && rfx_count_set_passes(tabs[g], 0) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
-    if (peers && rfx_count_set_peers(tabs[g], peers, g) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+  {
+    std::lock_guard<std::mutex> g(open_mu);
+    inputs_known = true;
+    open_cv.notify_all();
   }
+  if (sync_open) device_ready();
   std::vector<std::vector<rfx_reads*>> resident((size_t)n_gpu);
   // A sample counted in shard passes at finish needs ~3 bytes of device memory per byte of packed reads beside them
   // (records of a pass, survivors): it is mapped while the input is still parsed, a few GiB per uploaded block -- in a fresh
   // process mapping 130 GB took 0.6 s of the time between "input parsed" and "finished on the device".
   std::vector<uint64_t> reserved((size_t)n_gpu, 0);
   auto sink_to = [&](int g, rfx_reads* r) {
+    device_ready();
     if (!r) die(std::string("rufus_amd: upload failed: ") + rfx_last_error());
     const int rc = rfx_count_add(tabs[g], r);
     if (rc) die(std::string("rufus_amd: count failed: ") + rfx_strerror(rc) + " " + rfx_last_error());
@@ -198,6 +227,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   const bool replicate = getenv("RFX_PEERS_REPLICATE") != nullptr;
   std::atomic<uint64_t> next_block{0};
   auto to_all = [&](const std::function<rfx_reads*(rfx_ctx*)>& up) {
+    device_ready();
     if (n_gpu == 1) {
       sink_to(0, up(ctx));
       return;
@@ -249,6 +279,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
       bool done = false;
       if (device_text && in.regular && in.size > 0) {
         if (!text_ingest) {
+          device_ready();
           text_ingest.reset(new TextIngest(
               ctx, nthreads, [&](rfx_reads* r) { sink_to(0, r); },
               [&](const char* text, size_t n) {  // refused by the device (not strict 4-line FASTQ): the reference's grammar
@@ -283,7 +314,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
         if (!ingest) {
           ingest.reset(new CountIngest(nthreads, [&](const StageBlock& b) {
             to_all([&](rfx_ctx* c) { return rfx_reads_upload(c, b.codes, b.acgt, nullptr, b.word_off, b.len, b.n_reads); });
-          }));
+          }, sync_open ? rfx_host_alloc : rfx_host_alloc_lazy, rfx_host_free, 4u << 20, 24ull << 20, sync_open ? nullptr : rfx_host_pin));
           ingest->set_sam(sam_chr != nullptr);
           if (spool_path) {
             const int sfd = ::open(spool_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
@@ -380,6 +411,7 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
         if (char* p = (char*)rfx_host_alloc(48u << 20)) out_ring.emplace_back(p, (size_t)48u << 20);
     });
   }
+  device_ready();  // (an empty input: nobody asked for the device yet)
   const auto t_count = std::chrono::steady_clock::now();
   trace("count: input parsed and queued");
   if (getenv("RFX_CLI_TRACE")) {

@@ -96,6 +96,7 @@ static inline void walk_fastq_lines(const char* p, const char* e, bool& at_start
 struct StageBlock {
   uint64_t* codes = nullptr;
   uint32_t *acgt = nullptr, *word_off = nullptr, *len = nullptr;
+  bool pinned = true;  // false: made by a lazy allocator (no call into the device runtime), page-locked before its first upload
   uint32_t cap_reads = 0, n_reads = 0;
   uint64_t cap_words = 0, n_words = 0;
   int writers = 0;
@@ -106,6 +107,12 @@ class CountIngest {
   std::function<void(const StageBlock&)> sink_;
   unsigned nthreads_;
   void (*dealloc_)(void*);
+  int (*pin_)(void*) = nullptr;  // late page-locking of the staging blocks (rfx_host_alloc_lazy + rfx_host_pin)
+  void pin_block(StageBlock& b) {
+    if (b.pinned || !pin_) return;
+    (void)pin_(b.codes); (void)pin_(b.acgt); (void)pin_(b.word_off); (void)pin_(b.len);  // (a refusal: the upload is staged by the runtime)
+    b.pinned = true;
+  }
   std::vector<StageBlock> blocks_;
   std::mutex mu_;
   std::condition_variable cv_;  // one for every state change: pieces, blocks, failure
@@ -441,6 +448,7 @@ class CountIngest {
       if (b.n_reads) {
         b.word_off[b.n_reads] = (uint32_t)b.n_words;
         reads_total_ += b.n_reads;
+        pin_block(b);
         sink_(b);  // uploads it (rfx_reads_upload): the block is reused as soon as this returns
       }
       {
@@ -478,13 +486,17 @@ class CountIngest {
 
  public:
   // alloc / dealloc: page-locked memory on the GPU box (rfx_host_alloc), plain malloc in host-only tests
+  // pin != nullptr: `alloc` makes plain memory without touching the device runtime (rfx_host_alloc_lazy) -- the workers
+  // parse into it while another thread is still opening the device -- and `pin` page-locks a block before its first upload
   CountIngest(unsigned threads, std::function<void(const StageBlock&)> sink, void* (*alloc)(size_t) = rfx_host_alloc,
-              void (*dealloc)(void*) = rfx_host_free, uint32_t cap_reads = 4u << 20, uint64_t cap_words = 24ull << 20)
-      : sink_(std::move(sink)), nthreads_(threads ? threads : 1), dealloc_(dealloc) {
+              void (*dealloc)(void*) = rfx_host_free, uint32_t cap_reads = 4u << 20, uint64_t cap_words = 24ull << 20,
+              int (*pin_fn)(void*) = nullptr)
+      : sink_(std::move(sink)), nthreads_(threads ? threads : 1), dealloc_(dealloc), pin_(pin_fn) {
     blocks_.resize(3);
     for (StageBlock& b : blocks_) {
       b.cap_reads = cap_reads;
       b.cap_words = cap_words;
+      b.pinned = pin_fn == nullptr;
     }
     // Page-locking ~1 GB takes 0.2 s: the workers start on the first block while the others are still being pinned.
     auto pin = [this, alloc](size_t i) {
@@ -511,6 +523,7 @@ class CountIngest {
     if (pinner_.joinable()) pinner_.join();
     std::vector<std::pair<char*, size_t>> out;
     for (StageBlock& b : blocks_) {
+      pin_block(b);
       for (size_t at = 0; at + piece <= b.cap_words * 8; at += piece) out.emplace_back((char*)b.codes + at, piece);
       for (size_t at = 0; at + piece <= b.cap_words * 4; at += piece) out.emplace_back((char*)b.acgt + at, piece);
     }

@@ -704,24 +704,33 @@ namespace {
 // every executable of the drop-in chain pins ~1 GB before its first byte moves.  (scratch/ubench/pin_cost.cpp; uploads
 // from such a buffer run at the same 57 GB/s.)  Where huge pages or the registration are refused: hipHostMalloc.
 std::mutex g_host_mu;
-std::map<void*, size_t> g_host_registered;
+struct host_block { size_t len; bool registered; };
+std::map<void*, host_block> g_host_blocks;
+
+// anonymous memory on (transparent) huge pages, 2 MB-aligned; no call into the HIP runtime
+void* host_map_thp(size_t bytes, size_t* len_out) {
+  const size_t H = (size_t)2 << 20;
+  const size_t len = ((bytes ? bytes : 1) + H - 1) & ~(H - 1);
+  void* m = mmap(nullptr, len + H, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+  if (m == MAP_FAILED) return nullptr;
+  char* a = (char*)(((uintptr_t)m + H - 1) & ~((uintptr_t)H - 1));  // (the kernel backs only aligned 2 MB ranges with huge pages)
+  if (a > (char*)m) (void)munmap(m, (size_t)(a - (char*)m));
+  const size_t tail = (size_t)((char*)m + len + H - (a + len));
+  if (tail) (void)munmap(a + len, tail);
+  (void)madvise(a, len, MADV_HUGEPAGE);
+  *len_out = len;
+  return a;
+}
 }  // namespace
 extern "C" {
 
 void* rfx_host_alloc(size_t bytes) {
   if (bytes >= ((size_t)8 << 20) && !getenv("RFX_NO_THP_PIN")) {
-    const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
-    void* m = mmap(nullptr, len + ((size_t)2 << 20), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
-    if (m != MAP_FAILED) {
-      // (a 2 MB-aligned start: the kernel backs only aligned 2 MB ranges with huge pages)
-      char* a = (char*)(((uintptr_t)m + ((size_t)2 << 20) - 1) & ~(((uintptr_t)2 << 20) - 1));
-      if (a > (char*)m) (void)munmap(m, (size_t)(a - (char*)m));
-      const size_t tail = (size_t)((char*)m + len + ((size_t)2 << 20) - (a + len));
-      if (tail) (void)munmap(a + len, tail);
-      (void)madvise(a, len, MADV_HUGEPAGE);
+    size_t len = 0;
+    if (void* a = host_map_thp(bytes, &len)) {
       if (hipHostRegister(a, len, hipHostRegisterDefault) == hipSuccess) {
         std::lock_guard<std::mutex> g(g_host_mu);
-        g_host_registered[a] = len;
+        g_host_blocks[a] = host_block{len, true};
         return a;
       }
       (void)hipGetLastError();
@@ -735,20 +744,51 @@ void* rfx_host_alloc(size_t bytes) {
   }
   return p;
 }
-void rfx_host_free(void* p) {
-  if (!p) return;
+
+void* rfx_host_alloc_lazy(size_t bytes) {
+  size_t len = 0;
+  void* a = host_map_thp(bytes, &len);
+  if (!a) return nullptr;
+  std::lock_guard<std::mutex> g(g_host_mu);
+  g_host_blocks[a] = host_block{len, false};
+  return a;
+}
+
+int rfx_host_pin(void* p) {
+  if (!p) return RFX_E_INVAL;
   size_t len = 0;
   {
     std::lock_guard<std::mutex> g(g_host_mu);
-    auto it = g_host_registered.find(p);
-    if (it != g_host_registered.end()) {
-      len = it->second;
-      g_host_registered.erase(it);
+    auto it = g_host_blocks.find(p);
+    if (it == g_host_blocks.end()) return RFX_OK;  // (rfx_host_alloc's own: page-locked since it was made)
+    if (it->second.registered) return RFX_OK;
+    len = it->second.len;
+  }
+  if (hipHostRegister(p, len, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();  // (uploads from it still work, staged by the runtime)
+    return RFX_E_HIP;
+  }
+  std::lock_guard<std::mutex> g(g_host_mu);
+  g_host_blocks[p].registered = true;
+  return RFX_OK;
+}
+
+void rfx_host_free(void* p) {
+  if (!p) return;
+  host_block b{0, false};
+  bool ours = false;
+  {
+    std::lock_guard<std::mutex> g(g_host_mu);
+    auto it = g_host_blocks.find(p);
+    if (it != g_host_blocks.end()) {
+      b = it->second;
+      ours = true;
+      g_host_blocks.erase(it);
     }
   }
-  if (len) {
-    (void)hipHostUnregister(p);
-    (void)munmap(p, len);
+  if (ours) {
+    if (b.registered) (void)hipHostUnregister(p);
+    (void)munmap(p, b.len);
   } else {
     (void)hipHostFree(p);
   }

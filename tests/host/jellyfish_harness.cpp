@@ -70,6 +70,8 @@ rfx_ctx* rfx_open(int device, size_t) { return new rfx_ctx{device}; }
 void rfx_close(rfx_ctx* c) { delete c; }
 int rfx_ctx_allow_peers(rfx_ctx*, const int*, int) { return RFX_OK; }
 void* rfx_host_alloc(size_t bytes) { return malloc(bytes); }
+void* rfx_host_alloc_lazy(size_t bytes) { return malloc(bytes); }
+int rfx_host_pin(void*) { return RFX_OK; }
 void rfx_host_free(void* p) { free(p); }
 
 rfx_reads* rfx_reads_upload(rfx_ctx*, const uint64_t* codes, const uint32_t* acgt, const uint32_t*, const uint32_t* word_off,

@@ -593,7 +593,13 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_part1(rfx_reads_view rv, int 
 // takes the next set bit.  (The first version stepped over gaps and the other half's runs one by one: 36 wave-
 // instructions per 64 bases and pass, 30 of them scalar loop control -- more than half of what the hashing costs.)
 constexpr int RP_STRIDE = 25;  // dwords per lane: 10 of read, 7 of entries, 7 of end positions, 1 that keeps the stride odd
-template <bool CANON>
+// QUEUED (round 6): the runs of a wave's 64 reads go through a per-wave queue and are cut 64 at a time, one per lane.
+// With a lane cutting the runs of ITS read, a turn of the loop lasted as long as the read with the most runs of this pass
+// had any: 16 - 17 of them where the mean is 11 (half of ~22, binomially), so two lanes in five idled through ~85
+// instructions per run.  Now every lane writes its runs' descriptors -- lane | entry index << 6, at most 8 per batch:
+// 512 per wave -- to the wave's queue (one LDS add to one address = a wave scan: -amdgpu-atomic-optimizer-strategy=DPP) and
+// lane t cuts run t, t + 64, ..: the entry, its end position and the read's dwords come out of the OWNER's staging area.
+template <bool CANON, bool QUEUED>
 __global__ __launch_bounds__(MP1_BLOCK) void k_msp_replay(rfx_reads_view rv, const uint4* __restrict__ map, int k, int bin_bits,
                                                           uint32_t bin_lo, uint32_t bin_hi, msp_rec12* __restrict__ rec_a,
                                                           uint32_t* __restrict__ coarse_cur, uint32_t cap_a,
@@ -605,6 +611,9 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_replay(rfx_reads_view rv, con
   __shared__ uint32_t s_fine[4096];  // 8-bit counters of bins bin_lo .. bin_lo + 16383 (a shard pass holds at most half of 32768)
   __shared__ uint32_t s_rd[MP1_BLOCK * RP_STRIDE + 4];
   __shared__ uint32_t s_sum, s_emit;
+  constexpr int RQ_BATCH = 8, RQ_CAP = 64 * RQ_BATCH;  // runs a lane queues per batch; descriptors per wave
+  __shared__ uint16_t s_q[QUEUED ? MP1_BLOCK / 64 : 1][QUEUED ? RQ_CAP : 1];
+  __shared__ uint32_t s_qn[QUEUED ? MP1_BLOCK / 64 : 1];
   const uint32_t P = 1u << bin_bits;
   const int sub_bits = bin_bits - 7;
   const int m = msp_m(k);
@@ -687,6 +696,102 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_replay(rfx_reads_view rv, con
     // (a lane reads only what it wrote itself: no barrier)
     uint32_t mine = ~gaps & ((1u << cnt) - 1u);
     if (half_sel != 2u) mine &= half_sel ? flags : ~flags;
+    if constexpr (QUEUED) {
+      const uint32_t wv = threadIdx.x >> 6, ln = threadIdx.x & 63u;
+      uint16_t* const wq = s_q[wv];
+      const uint32_t* const wrd = s_rd + (size_t)(wv * 64u) * RP_STRIDE;  // the wave's 64 staging areas
+      while (__ballot(mine != 0)) {
+        // ---- a batch: every lane queues its next <= RQ_BATCH runs ----
+        if (ln == 0) s_qn[wv] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t take = mine;
+#pragma unroll
+        for (int t = 0; t < RQ_BATCH; ++t) take &= take - 1u;  // `mine` without its RQ_BATCH lowest set bits ...
+        take = mine & ~take;                                    // ... = those bits
+        mine &= ~take;
+        uint32_t at = atomicAdd(&s_qn[wv], (uint32_t)__popc(take));  // (one address: a wave scan)
+        while (__ballot(take != 0)) {
+          if (take) {
+            const uint32_t i = (uint32_t)__ffs((int)take) - 1u;
+            take &= take - 1u;
+            wq[at++] = (uint16_t)(ln | (i << 6));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t T = s_qn[wv];
+        // ---- lane t cuts runs t and t + 64, then t + 128 and t + 192, ..: two per trip, stage by stage, so that their
+        // LDS round trips (descriptor, entry, read words, slab slot) overlap instead of queueing up ----
+        for (uint32_t t0 = 0; t0 < T; t0 += 128u) {
+          bool on[2], put[2];
+          uint32_t dsc[2], en[2], pe[2], sh[2], d[2][4], run_bin[2], slot[2], bh[2];
+          const uint32_t* ord[2];
+          uint64_t lo[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            on[u] = t0 + (uint32_t)u * 64u + ln < T;
+            dsc[u] = on[u] ? wq[t0 + (uint32_t)u * 64u + ln] : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            ord[u] = wrd + (size_t)(dsc[u] & 63u) * RP_STRIDE;  // the owner's area
+            const uint32_t i = dsc[u] >> 6;
+            en[u] = ((const uint8_t*)(ord[u] + 10))[i];
+            pe[u] = ((const uint8_t*)(ord[u] + 17))[i];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t e = (uint32_t)k - 2u + pe[u];  // the run's last k-mer ends at base e
+            const uint32_t o = 2u * (159u - e), dw = o >> 5;
+            sh[u] = o & 31u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[u][j] = ord[u][dw + j];
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const uint32_t back = en[u] >> 4;
+            lo[u] = (uint64_t)__builtin_amdgcn_alignbit(d[u][1], d[u][0], sh[u]) |
+                    ((uint64_t)__builtin_amdgcn_alignbit(d[u][2], d[u][1], sh[u]) << 32);
+            const uint32_t f = (uint32_t)(lo[u] >> (2u * back)) & mmask;
+            uint32_t c = f;
+            if (CANON) {
+              uint32_t y = __brev(~f);
+              y = ((y & 0xAAAAAAAAu) >> 1) | ((y & 0x55555555u) << 1);
+              c = min(f, y >> (32 - 2 * m));
+            }
+            bh[u] = msp_binhash(mmer_hash(c));
+            run_bin[u] = bh[u] >> (32 - bin_bits);
+            put[u] = on[u] && run_bin[u] - bin_lo < bin_hi - bin_lo;
+            slot[u] = put[u] ? atomicAdd(&s_fill[run_bin[u] >> sub_bits], 1u) : 0u;
+          }
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (put[u]) {
+              const int n = (int)(en[u] & 15u) + 1;
+              const uint32_t back = en[u] >> 4;
+              const uint32_t hi = __builtin_amdgcn_alignbit(d[u][3], d[u][2], sh[u]) & 0x3FFFFFu;
+              uint64_t w;
+              uint32_t x;
+              msp_record_make(lo[u], hi, k, n, (uint32_t)(k + n - 1 - m) - back, w, x);
+              x |= msp_stamp(bh[u], k);
+              const uint32_t coarse = run_bin[u] >> sub_bits;
+              if (slot[u] < 2 * SLAB) {
+                const uint64_t sb = s_slab[slot[u] >> slab_log2][coarse];
+                msp_rec12_store(rec_a, sb + (slot[u] & (SLAB - 1)), w, x);
+              } else {  // more than two slabs' worth in one chunk: one reservation per record
+                const uint32_t at2 = atomicAdd(&coarse_cur[coarse * P1_CUR_STRIDE], 1u);
+                if (at2 < cap_a) msp_rec12_store(rec_a, (uint64_t)coarse * cap_a + at2, w, x);
+                else atomicExch(flag, 1u);
+              }
+              ++n_emit;
+              const uint32_t fb = run_bin[u] - bin_lo;
+              atomicAdd(&s_fine[fb >> 2], 1u << ((fb & 3u) * 8));
+            }
+          }
+        }
+      }
+    } else {
     // two runs per turn, stage by stage: their LDS round trips (entry, read words, slab slot) overlap instead of queueing up
     while (__ballot(mine != 0)) {
       bool on[2];
@@ -754,6 +859,7 @@ __global__ __launch_bounds__(MP1_BLOCK) void k_msp_replay(rfx_reads_view rv, con
           atomicAdd(&s_fine[fb >> 2], 1u << ((fb & 3u) * 8));
         }
       }
+    }
     }
   // once per chunk (512 reads put ~90 records into each of a pass's coarse bins at S = 2) the bins whose slab filled up move on
     __syncthreads();
@@ -1487,12 +1593,18 @@ void msp_replay(rfx_ctx* c, const rfx_reads_view& rv, const void* map, int k, in
                 uint32_t bin_hi, int grid, void* rec_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
                 unsigned int* flag, int slab_log2) {
   rfx_span sp(c, "k_msp_replay");
-  if (canonical)
-    hipLaunchKernelGGL(k_msp_replay<true>, dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, (const uint4*)map, k, bin_bits, bin_lo,
-                       bin_hi, (msp_rec12*)rec_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2);
-  else
-    hipLaunchKernelGGL(k_msp_replay<false>, dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, (const uint4*)map, k, bin_bits, bin_lo,
-                       bin_hi, (msp_rec12*)rec_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2);
+  static const bool queued = getenv("RFX_REPLAY_OLD") == nullptr;  // (A/B: a lane cuts the runs of its own read, as in round 5)
+#define RFX_REPLAY(CANON, Q)                                                                                                  \
+  hipLaunchKernelGGL((k_msp_replay<CANON, Q>), dim3(grid), dim3(MP1_BLOCK), 0, c->stream, rv, (const uint4*)map, k, bin_bits, \
+                     bin_lo, bin_hi, (msp_rec12*)rec_a, coarse_cur, cap_a, cnt_rows, flag, slab_log2)
+  if (canonical) {
+    if (queued) RFX_REPLAY(true, true);
+    else RFX_REPLAY(true, false);
+  } else {
+    if (queued) RFX_REPLAY(false, true);
+    else RFX_REPLAY(false, false);
+  }
+#undef RFX_REPLAY
 }
 
 // Grid, staging chunk and pool of a leaf launch over P bins holding ~n_records records of which ~est_survivors k-mers

@@ -580,7 +580,10 @@ def main():
                        "reads_filtered_per_step": reads_filtered, "parallelism": f"read-block shard x{world}",
                        "mutant_kmers": int(res["n_mutant"]), "pulled_pairs": int(res["n_pulled"]),
                        "records_per_sample": [int(x) for x in res["n_records"]], **extra,
-                       **({"blocks_replayed_from_run_maps_per_step": int(trio_.replayed_blocks)} if trio_ is not None else {}),
+                       **({"blocks_replayed_from_run_maps_per_step": int(trio_.replayed_blocks),
+                           "run_maps_hashed_ahead_on_the_second_stream_per_step": int(getattr(trio_, "maps_ahead", 0)),
+                           "count_wall_ms_per_sample": round(getattr(trio_, "count_wall_s", 0.0) * 1e3 / max(n_samples, 1), 1)}
+                          if trio_ is not None else {}),
                        "checked": checks is not None, "checks": checks,
                        **({"multi_gpu": multi} if multi else {}),
                        **({"one_device_dry_run": f"{world} ranks share device 0 over {dist.get_backend()}: the N-rank path is "

@@ -295,6 +295,12 @@ int rfx_count_set_runmaps(rfx_table*, rfx_runmaps*);
 /* the maps of several blocks the table is about to add, made with ONE wait for the device (a map made by rfx_count_add
  * waits for its own launch); blocks that have a map, or are no blocks for one, are skipped; no store: nothing happens */
 int rfx_count_prepare_maps(rfx_table*, rfx_reads* const* blocks, int n);
+/* The same launches queued on the ctx's SECOND stream, no wait: the maps of the sample that is counted next are made
+ * beside this sample's partition, refinement and sort (the hashing launch is bound by the instructions it issues, those
+ * by the memory; they share a CU).  Pooled store only, as far as it has room; whoever next asks the store about one of
+ * these blocks (rfx_count_prepare_maps, rfx_count_add, rfx_runmaps_drop / _clear / _free) waits for the launches first.
+ * The blocks must stay alive until then.  Returns the number of launches queued (0: nothing to do or no room), < 0: error. */
+int rfx_count_prefetch_maps(rfx_table*, rfx_reads* const* blocks, int n);
 uint64_t rfx_count_replayed(const rfx_table*);
 /* Bounded-HBM counting of a whole sample (MSP path, call before the first add): rfx_count_add() only
  * REMEMBERS the read blocks -- they must stay alive until finish -- and rfx_count_finish() runs `passes`

@@ -97,6 +97,7 @@ SIGNATURES = {
     "rfx_runmaps_clear": (C.c_int, [C.c_void_p]),
     "rfx_count_set_runmaps": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rfx_count_prepare_maps": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
+    "rfx_count_prefetch_maps": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int]),
     "rfx_count_replayed": (C.c_uint64, [C.c_void_p]),
     "rfx_count_segments": (C.c_int, [C.c_void_p]),
     "rfx_count_segment_get": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
@@ -616,6 +617,15 @@ class CountTable:
         """The run maps of `blocks` (Reads the table is about to add) with one wait for the device (rfx_count_prepare_maps)."""
         arr = (C.c_void_p * max(1, len(blocks)))(*[b._h for b in blocks])
         _check(lib().rfx_count_prepare_maps(self._h, arr, len(blocks)), "rfx_count_prepare_maps")
+
+    def prefetch_maps(self, blocks) -> int:
+        """Queue the run maps of `blocks` (another sample's, counted next) on the ctx's second stream; returns at once
+        with the number of launches queued (rfx_count_prefetch_maps)."""
+        arr = (C.c_void_p * max(1, len(blocks)))(*[b._h for b in blocks])
+        n = int(lib().rfx_count_prefetch_maps(self._h, arr, len(blocks)))
+        if n < 0:
+            _check(n, "rfx_count_prefetch_maps")
+        return n
 
     def replayed(self) -> int:
         return int(lib().rfx_count_replayed(self._h))

@@ -648,6 +648,10 @@ rfx_ctx* rfx_open(int device, size_t hbm_budget_bytes) {
     delete c;
     return nullptr;
   }
+  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    c->aux = nullptr;  // (no second stream: rfx_count_prefetch_maps does nothing)
+  }
   if (hipHostMalloc((void**)&c->pin, 4u << 20, hipHostMallocDefault) == hipSuccess) c->pin_cap = 4u << 20;
   else c->pin = nullptr;
   return c;
@@ -685,6 +689,7 @@ void rfx_close(rfx_ctx* c) {
   if (c->pin) (void)hipHostFree(c->pin);
   for (uint8_t* p : c->load_pin)
     if (p) (void)hipHostFree(p);
+  if (c->aux) (void)hipStreamDestroy(c->aux);
   (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -919,6 +924,7 @@ static void rfx_reads_release_pending(const rfx_reads* r);
 void rfx_reads_free(rfx_reads* r) {
   if (!r) return;
   rfx_reads_release_pending(r);  // a count table may still need these reads to redo its partition
+  if (r->ctx->aux) (void)hipStreamSynchronize(r->ctx->aux);  // (a map made ahead may still be hashing them)
   dfree(r->ctx, r->codes); dfree(r->ctx, r->acgt); dfree(r->ctx, r->good);
   dfree(r->ctx, r->word_off); dfree(r->ctx, r->len);
   dfree(r->ctx, r->nbits); dfree(r->ctx, r->nrank);
@@ -1277,9 +1283,18 @@ struct runmap_pending {
   bool queued = false;
 };
 
+// Maps made AHEAD (rfx_count_prefetch_maps): launches queued on the ctx's second stream, finished -- turned into entries of
+// the store -- by whoever next looks at the store (runmaps_collect).
+struct runmap_ahead {
+  std::vector<runmap_pending> pend;
+  hipEvent_t done = nullptr;
+  int k = 0, canonical = 0;
+};
+
 // Queues the hashing launch (k_msp_part1 HMODE 4) over block r and the read-back of its overflow count into p.n_ovf
 // (valid after the next synchronisation of the ctx; p must stay where it is until then).  false: no room, or a failure.
-static bool runmap_launch(rfx_table* t, const rfx_reads* r, runmap_pending& p) {
+// read_back = false (a launch on the second stream): the caller fetches n_ovf itself.
+static bool runmap_launch(rfx_table* t, const rfx_reads* r, runmap_pending& p, bool read_back = true) {
   rfx_ctx* c = t->ctx;
   rfx_runmaps* st = t->runmaps;
   p.r = r;
@@ -1292,15 +1307,20 @@ static bool runmap_launch(rfx_table* t, const rfx_reads* r, runmap_pending& p) {
   if (!p.map_dev || !p.map_ovf || hipMemsetAsync(p.map_ovf, 0, 4, c->stream) != hipSuccess) return false;
   rfxk::msp_part1(c, r->view(), t->k, t->canonical, 15, 0, 0, 4, rfxk::msp_map_grid(c, r->n), nullptr, nullptr, 0, nullptr, nullptr, 0,
                   p.map_dev, p.map_ovf, p.ovf_cap);
-  p.queued = queue_read(c, &p.n_ovf, p.map_ovf, 4) == hipSuccess;
+  p.queued = !read_back || queue_read(c, &p.n_ovf, p.map_ovf, 4) == hipSuccess;
   if (p.queued) st->pending_bytes += p.map_bytes + p.ovf_bytes;
   return p.queued;
 }
 
 // After the synchronisation (ok: it succeeded): the map becomes an entry of the store -- or its memory goes back and, when
 // the block's reads fall into more runs than a map holds, an entry WITHOUT a map remembers that (no later pass tries again).
+static rfx_runmap_entry* runmap_finish_in(rfx_runmaps* st, int k, int canonical, runmap_pending& p, bool ok, int* rc);
 static rfx_runmap_entry* runmap_finish(rfx_table* t, runmap_pending& p, bool ok, int* rc) {
-  rfx_runmaps* st = t->runmaps;
+  return runmap_finish_in(t->runmaps, t->k, t->canonical, p, ok, rc);
+}
+static rfx_runmap_entry* runmap_finish_in(rfx_runmaps* st, int k_, int canonical_, runmap_pending& p, bool ok, int* rc) {
+  struct { int k, canonical; } tt{k_, canonical_};
+  auto* t = &tt;
   const rfx_reads* r = p.r;
   if (p.queued) st->pending_bytes -= std::min<uint64_t>(st->pending_bytes, p.map_bytes + p.ovf_bytes);
   ok = ok && p.queued;
@@ -1336,6 +1356,22 @@ static rfx_runmap_entry* runmap_finish(rfx_table* t, runmap_pending& p, bool ok,
   return nullptr;
 }
 
+// The maps made ahead become entries (or go back to the pool): waits for the second stream's launches.
+static int runmaps_collect(rfx_runmaps* st) {
+  if (!st || !st->ahead) return RFX_OK;
+  runmap_ahead* a = st->ahead;
+  st->ahead = nullptr;
+  int rc = RFX_OK;
+  bool ok = hipEventSynchronize(a->done) == hipSuccess;
+  for (runmap_pending& p : a->pend)  // (a few dozen 4-byte copies: the launches are through)
+    if (ok && hipMemcpy(&p.n_ovf, p.map_ovf, 4, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
+  for (runmap_pending& p : a->pend) (void)runmap_finish_in(st, a->k, a->canonical, p, ok, &rc);
+  (void)hipEventDestroy(a->done);
+  delete a;
+  if (!ok && rc == RFX_OK) rc = RFX_E_HIP;
+  return rc;
+}
+
 // The run map of read block r in the table's store: the one that is there, or (make) a new one -- ONE hashing launch
 // (k_msp_part1 HMODE 4) + a wait for the number of reads that went without a map.  nullptr: no store, not a block for maps
 // (reads of more than 160 bases), no room, or a failure (*rc set then).
@@ -1344,6 +1380,7 @@ static rfx_runmap_entry* runmap_get(rfx_table* t, const rfx_reads* r, bool make,
   rfx_runmaps* st = t->runmaps;
   *rc = RFX_OK;
   if (!st || r->max_len > 160 || r->n == 0 || getenv("RFX_NO_RUNMAP")) return nullptr;
+  if (st->ahead && (*rc = runmaps_collect(st)) != RFX_OK) return nullptr;
   auto it = st->m.find(r);
   if (it != st->m.end()) {
     rfx_runmap_entry& en = it->second;
@@ -3086,6 +3123,7 @@ rfx_runmaps* rfx_runmaps_create_pooled(rfx_ctx* c, uint64_t pool_bytes) {
 void rfx_runmaps_free(rfx_runmaps* s) {
   if (!s) return;
   (void)hipSetDevice(s->ctx->device);
+  (void)runmaps_collect(s);
   while (!s->m.empty()) runmaps_drop_entry(s, s->m.begin());
   dfree(s->ctx, s->pool);
   delete s;
@@ -3102,6 +3140,12 @@ int rfx_runmaps_blocks(const rfx_runmaps* s) {
 int rfx_runmaps_drop(rfx_runmaps* s, const rfx_reads* r) {
   if (!s || !r) return RFX_E_INVAL;
   (void)hipSetDevice(s->ctx->device);
+  if (s->ahead)  // (only if the block is among the maps on their way: the others may keep flying)
+    for (const runmap_pending& p : s->ahead->pend)
+      if (p.r == r) {
+        (void)runmaps_collect(s);
+        break;
+      }
   auto it = s->m.find(r);
   if (it != s->m.end()) runmaps_drop_entry(s, it);
   return RFX_OK;
@@ -3110,8 +3154,70 @@ int rfx_runmaps_drop(rfx_runmaps* s, const rfx_reads* r) {
 int rfx_runmaps_clear(rfx_runmaps* s) {
   if (!s) return RFX_E_INVAL;
   (void)hipSetDevice(s->ctx->device);
+  (void)runmaps_collect(s);
   while (!s->m.empty()) runmaps_drop_entry(s, s->m.begin());
   return RFX_OK;
+}
+
+// Run maps made AHEAD (round 6).  The hashing launch over a block (k_msp_map: 95 ms per W sample, bound by the
+// instructions it issues, 54 KB of LDS per CU) and the partition levels of ANOTHER sample's count (bound by the memory,
+// one 96 KB workgroup per CU) want different things of a CU and fit it side by side: the maps of the sample that is
+// counted NEXT are queued on the ctx's second stream while this sample's records are partitioned, refined and sorted on
+// the first.  Only for a pooled store (its memory is not the stream-ordered arena's) with room for them; what does not
+// fit is made by rfx_count_prepare_maps when its turn comes, as before.  Returns the number of launches queued (>= 0).
+int rfx_count_prefetch_maps(rfx_table* t, rfx_reads* const* blocks, int n) {
+  if (!t || n < 0 || (n && !blocks)) return RFX_E_INVAL;
+  rfx_ctx* c = t->ctx;
+  rfx_runmaps* st = t->runmaps;
+  if (!st || !st->pool || !c->aux || t->mode != RFX_COUNT_MSP || getenv("RFX_NO_RUNMAP") || getenv("RFX_NO_MAP_AHEAD")) return 0;
+  (void)hipSetDevice(c->device);
+  if (st->ahead) {
+    const int rc = runmaps_collect(st);
+    if (rc) return rc;
+  }
+  runmap_ahead* a = new runmap_ahead();
+  a->k = t->k;
+  a->canonical = t->canonical;
+  a->pend.reserve((size_t)n);
+  // the second stream starts behind what the first has queued so far: a region of the pool that a dropped map gave back
+  // may still be read by a replay launch of the first stream
+  hipEvent_t after = nullptr;
+  bool ok = hipEventCreateWithFlags(&after, hipEventDisableTiming) == hipSuccess && hipEventRecord(after, c->stream) == hipSuccess &&
+            hipStreamWaitEvent(c->aux, after, 0) == hipSuccess;
+  if (after) (void)hipEventDestroy(after);
+  std::swap(c->stream, c->aux);  // (the launchers take the ctx's stream)
+  for (int i = 0; i < n && ok; ++i) {
+    const rfx_reads* r = blocks[i];
+    if (!r || r->ctx != c || r->max_len > 160 || r->n == 0 || st->m.count(r)) continue;
+    bool twice = false;
+    for (const runmap_pending& q : a->pend) twice = twice || q.r == r;
+    if (twice) continue;
+    a->pend.emplace_back();
+    if (!runmap_launch(t, r, a->pend.back(), false)) {  // no room: neither will the rest find any
+      int rc = RFX_OK;
+      (void)runmap_finish(t, a->pend.back(), false, &rc);
+      a->pend.pop_back();
+      break;
+    }
+  }
+  ok = ok && hipEventCreateWithFlags(&a->done, hipEventDisableTiming) == hipSuccess && hipEventRecord(a->done, c->stream) == hipSuccess;
+  std::swap(c->stream, c->aux);
+  if (!ok) {  // (nothing flies, or the launches are waited for here)
+    (void)hipStreamSynchronize(c->aux);
+    int rc = RFX_OK;
+    for (runmap_pending& p : a->pend) (void)runmap_finish(t, p, false, &rc);
+    if (a->done) (void)hipEventDestroy(a->done);
+    delete a;
+    return RFX_E_HIP;
+  }
+  const int launched = (int)a->pend.size();
+  if (launched == 0) {
+    (void)hipEventDestroy(a->done);
+    delete a;
+    return 0;
+  }
+  st->ahead = a;
+  return launched;
 }
 
 // The run maps of several blocks with ONE wait: a map made on its own (rfx_count_add) waits for its launch to learn how
@@ -3121,7 +3227,8 @@ int rfx_count_prepare_maps(rfx_table* t, rfx_reads* const* blocks, int n) {
   if (!t->runmaps || t->mode != RFX_COUNT_MSP || getenv("RFX_NO_RUNMAP")) return RFX_OK;
   rfx_ctx* c = t->ctx;
   (void)hipSetDevice(c->device);
-  int rc = RFX_OK;
+  int rc = runmaps_collect(t->runmaps);  // (maps made ahead: theirs are entries now)
+  if (rc) return rc;
   std::vector<runmap_pending> pend;
   pend.reserve((size_t)n);  // (the read-backs point into it)
   for (int i = 0; i < n && rc == RFX_OK; ++i) {

@@ -36,6 +36,7 @@ struct rfx_hash_consts {
 struct rfx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t aux = nullptr;  // second stream: run maps made AHEAD (rfx_count_prefetch_maps) beside the main stream's work
   size_t budget = 0, used = 0;
   int n_cu = 256;
   bool prof = false;
@@ -144,8 +145,10 @@ struct rfx_runmap_entry {
   int k = 0, canonical = 0;
   size_t bytes = 0, map_bytes = 0, ovf_bytes = 0;
 };
+struct runmap_ahead;  // (rfx_api.hip) the maps whose hashing launches run on the ctx's second stream
 struct rfx_runmaps {
   rfx_ctx* ctx = nullptr;
+  runmap_ahead* ahead = nullptr;
   uint64_t budget = 0;  // bytes of maps the store may hold (0: no limit)
   uint64_t bytes = 0;
   uint64_t pending_bytes = 0;  // maps whose hashing launch is queued (rfx_count_prepare_maps): they count against the budget

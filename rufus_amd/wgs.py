@@ -131,6 +131,9 @@ class WgsTrio:
         # at most two samples' maps are alive: run().
         self.map_budget = 0
         self._store = None
+        self._ahead = {}            # (pass, sample) -> the blocks whose maps that step queues ahead (run())
+        self.maps_ahead = 0         # hashing launches queued on the second stream in the last run()
+        self.count_wall_s = 0.0     # host wall time inside count_shard() in the last run() (every count ends with a wait)
         self.replayed_blocks = 0    # blocks added by replay in the last run()
         # bytes of super-k-mer records this rank sent to / received from OTHER ranks in the last run() (the record
         # exchange of count_shard: RCCL all-to-all over xGMI; what stays on the rank is not counted)
@@ -161,6 +164,12 @@ class WgsTrio:
             if store is not None:       # (run maps instead of blocks cut ahead: 32 instead of 132 bytes per read)
                 t.set_runmaps(store)
                 t.prepare_maps(blocks)       # (all of them behind ONE wait: 0.75 ms of idle device per block otherwise)
+                # Round 6: the maps of the sample that is counted NEXT are hashed on the ctx's second stream while this
+                # sample's records are partitioned, refined and sorted on the first (run(): self._ahead): the hashing launch
+                # is bound by the instructions it issues, the partition levels by the memory, and they share a CU.
+                nxt_blocks = self._ahead.pop((shard, si), None) if self._ahead else None
+                if nxt_blocks:
+                    self.maps_ahead += t.prefetch_maps(nxt_blocks)
                 last = shard == self.passes - 1
                 for b in blocks:
                     t.add(b)
@@ -561,11 +570,31 @@ class WgsTrio:
                              for si in (list(range(ns)) if sh % 2 == 0 or keep_shard_records else [0] + list(range(ns - 1, 0, -1)))]
                 last_step = {sh: max(i for i, (sh_, _) in enumerate(steps) if sh_ == sh) for sh in range(P)}
                 shard_recs.update({sh: [] for sh in range(P)})
+                # maps made ahead: the step before a sample's FIRST step queues that sample's maps -- if the store has room
+                # for them then (two samples' maps fit: the step must come after the last step of the sample before the
+                # previous one, whose maps go with its last pass)
+                self._ahead, self.maps_ahead, self.count_wall_s = {}, 0, 0.0
+                # (opt-in, RFX_MAP_AHEAD=1: measured at W it buys nothing -- 1943 against 1941 ms per step --: the hashing
+                # launch holds 414 of a SIMD's 512 registers, the replay and partition workgroups of the first stream do
+                # not fit beside it, and the two streams take turns instead of sharing the CUs)
+                if use_maps and os.environ.get("RFX_MAP_AHEAD"):
+                    first = {}
+                    for i, (_, si_) in enumerate(steps):
+                        first.setdefault(si_, i)
+                    last_of = {si_: max(i for i, (_, s_) in enumerate(steps) if s_ == si_) for si_ in first}
+                    order = sorted(first, key=first.get)
+                    for n_, si_ in enumerate(order[1:], 1):
+                        at = first[si_] - 1                      # the step that queues them
+                        if n_ >= 2 and at <= last_of[order[n_ - 2]]:
+                            continue                             # (three samples' maps would be alive)
+                        self._ahead[steps[at]] = samples[si_]
                 for i_step, (sh, si) in enumerate(steps):
                     recs = shard_recs[sh]
                     cand = cands.pop(sh, None)
                     blocks = samples[si]
+                    t_c = time.perf_counter()
                     rec, h = self.count_shard(blocks, sh, si)   # (its failures are agreed inside)
+                    self.count_wall_s += time.perf_counter() - t_c
                     recs.append(rec)
                     histos[si] += h
                     n_rec[si] += len(rec)

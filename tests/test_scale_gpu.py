@@ -1041,3 +1041,58 @@ def test_a_block_whose_reads_do_not_fit_run_maps_is_hashed_by_every_pass(ctx, mo
         rec.free()
         t.free()
         blk.free()
+
+
+def test_run_maps_made_ahead_on_the_second_stream_are_the_same_maps(ctx):
+    """rfx_count_prefetch_maps (round 6; opt-in in the WGS driver, RFX_MAP_AHEAD=1): the maps of ANOTHER sample's blocks
+    queued on the ctx's second stream while a table counts -- later shard passes over those blocks find the maps (no
+    hashing launch of their own) and cut the same records; a plain (unpooled) store and a pool without room queue
+    nothing; dropping a block whose map is on its way, and freeing the store, wait for the launches."""
+    k = 25
+    sy = capi.Synth.sample(30_000_000, 0, n_snv=50, seed=31)
+    a = wgs.make_sample(ctx, sy, 2_300_000, 2_300_000, MIN_Q, want_good=False, compact=True)
+    b = wgs.make_sample(ctx, sy, 2_300_000, 1_150_000, MIN_Q, want_good=False, compact=True, first_pair=2_300_000)
+    ref = _shard_tables(ctx, k, 2, b)
+    need = sum(x.n * 32 + (x.n // 32 + 4097) * 4 + 1024 for x in a + b)
+    store = capi.RunMaps(ctx, need + (1 << 20), pooled=True)
+    t = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+    t.set_shard(0, 2)
+    t.set_runmaps(store)
+    t.prepare_maps(a)
+    assert store.blocks() == len(a)
+    assert t.prefetch_maps(b) == len(b)          # queued behind nothing: the second stream hashes while ...
+    assert t.prefetch_maps(b) == 0               # (asked twice: the first batch is collected, nothing left to queue)
+    for x in a:
+        t.add(x)                                  # ... the first cuts and partitions sample a
+    rec = t.finish(LOWER)
+    rec.free()
+    t.free()
+    assert store.blocks() == len(a) + len(b)
+    ctx.prof(True)
+    ctx.prof_reset()
+    got = _shard_tables(ctx, k, 2, b, store)
+    prof = ctx.prof_query_all() if hasattr(ctx, "prof_query_all") else None
+    ctx.prof(False)
+    assert [(c, n) for c, n, _ in got] == [(c, n) for c, n, _ in ref]
+    assert all(r[2] == len(b) for r in got)      # every block of every pass replayed from the maps made ahead
+    # a block dropped while its map is on its way; the store freed with maps in flight
+    store.clear()
+    t2 = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+    t2.set_shard(0, 2)
+    t2.set_runmaps(store)
+    assert t2.prefetch_maps(a) == len(a)
+    store.drop(a[0])
+    assert store.blocks() == len(a) - 1
+    assert t2.prefetch_maps(b) == len(b)
+    t2.free()
+    store.free()
+    # no pool: nothing is queued (the arena's memory is ordered by the first stream)
+    plain = capi.RunMaps(ctx)
+    t3 = capi.CountTable(ctx, k, SIZE, mode=capi.COUNT_MSP)
+    t3.set_shard(0, 2)
+    t3.set_runmaps(plain)
+    assert t3.prefetch_maps(b) == 0
+    t3.free()
+    plain.free()
+    for x in a + b:
+        x.free()

@@ -1592,13 +1592,13 @@ static int msp_add_impl(rfx_table* t, const rfx_reads* r) {
       cap_a = even + even / 16 + 16384 + rfxk::msp_part1_slack(G_rep + G_ovf, slab_log2);
       if (cap_a >= (1ull << 32)) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
     }
-    // (out of memory with a run-map store of the table's own: msp_add gives the store back and takes the hashing path)
-    auto drop_map = [&] {};
+    // (out of memory with a run-map store of the table's own: msp_add, the caller of this function, gives the store back
+    // and runs it once more on the hashing path)
     for (int attempt = 0;; ++attempt) {
       char* buf_a = (char*)dmalloc(c, cap_a * c_n_all * 12);  // 12-byte slots: word and plane side by side
-      if (!buf_a) { drop_map(); dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
+      if (!buf_a) { dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }
       char* buf_a0 = buf_a - (size_t)g.c_lo * cap_a * 12;  // the address coarse bin 0 would have
-      auto fail = [&](int rc) { drop_map(); dfree(c, buf_a); dfree(c, cur); dfree(c, bin_start); return rc; };
+      auto fail = [&](int rc) { dfree(c, buf_a); dfree(c, cur); dfree(c, bin_start); return rc; };
       hipError_t e = hipMemsetAsync(cur, 0, (g.ncur + 1 + (size_t)P) * 4, c->stream);
       if (e == hipSuccess) e = hipMemsetAsync(bin_start, 0, ((size_t)P + 1) * 8, c->stream);
       if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
@@ -1650,7 +1650,7 @@ static int msp_add_impl(rfx_table* t, const rfx_reads* r) {
           if (e != hipSuccess) return fail(hip_fail(e, "msp_add"));
         } else {
           dfree(c, buf_a);
-          if (attempt >= 3 || need >= (1ull << 32) - 65536) { drop_map(); dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
+          if (attempt >= 3 || need >= (1ull << 32) - 65536) { dfree(c, cur); dfree(c, bin_start); return RFX_E_RANGE; }
           cap_a = need + need / 64 + 1024;
           continue;
         }

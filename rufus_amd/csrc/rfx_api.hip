@@ -1594,6 +1594,12 @@ static int msp_add_impl(rfx_table* t, const rfx_reads* r) {
     }
     // (out of memory with a run-map store of the table's own: msp_add, the caller of this function, gives the store back
     // and runs it once more on the hashing path)
+    if (have && t->runmaps_owned && getenv("RFX_TEST_NOMEM_WITH_MAPS")) {  // a test knob: that route, without a full device
+      dfree(c, cur);
+      dfree(c, bin_start);
+      snprintf(g_err, sizeof g_err, "msp_add: out of device memory (injected: RFX_TEST_NOMEM_WITH_MAPS)");
+      return RFX_E_NOMEM;
+    }
     for (int attempt = 0;; ++attempt) {
       char* buf_a = (char*)dmalloc(c, cap_a * c_n_all * 12);  // 12-byte slots: word and plane side by side
       if (!buf_a) { dfree(c, cur); dfree(c, bin_start); return RFX_E_NOMEM; }

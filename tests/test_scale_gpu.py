@@ -1096,3 +1096,34 @@ def test_run_maps_made_ahead_on_the_second_stream_are_the_same_maps(ctx):
     plain.free()
     for x in a + b:
         x.free()
+
+
+def test_a_table_gives_its_own_run_maps_back_when_memory_runs_out(ctx, monkeypatch):
+    """run maps take memory from a finish that was planned to fit without them.  A table that made the store
+    itself (rfx_count_set_passes: what `jellyfish count` uses) and then runs out of memory while a block is partitioned
+    from its map (here: injected, RFX_TEST_NOMEM_WITH_MAPS) frees the store and partitions the block -- and every later
+    block and pass -- by hashing, as if there had never been a store: the oracle's records, no block replayed."""
+    k = 25
+    sy = capi.Synth.sample(30_000_000, 0, n_snv=50, seed=77)
+    blocks = wgs.make_sample(ctx, sy, 2_300_000, 2_300_000, MIN_Q, want_good=False, compact=True)     # one big block
+    ref = _shard_tables(ctx, k, 1, blocks)
+    plain = capi.CountTable(ctx, k, SIZE)
+    plain.set_passes(2)
+    for b in blocks:
+        plain.add(b)
+    rec = plain.finish(LOWER)
+    want = (tuple(rec.checksum()), len(rec))
+    assert want == ref[0][:2] and plain.replayed() > 0      # (two passes in the table: the maps are used)
+    rec.free()
+    plain.free()
+    monkeypatch.setenv("RFX_TEST_NOMEM_WITH_MAPS", "1")
+    t = capi.CountTable(ctx, k, SIZE)
+    t.set_passes(2)
+    for b in blocks:
+        t.add(b)
+    rec = t.finish(LOWER)
+    assert (tuple(rec.checksum()), len(rec)) == want and t.replayed() == 0
+    rec.free()
+    t.free()
+    for b in blocks:
+        b.free()

@@ -361,6 +361,7 @@ def run_wgs(args, ctx, rank, world, dist, torch):
     t_gen = time.perf_counter() - t0
     trio = wgs.WgsTrio(ctx, k, JF_SIZE, LOWER, MIN_COV, MAX_DEPTH, THRESH, passes=passes,
                        group=dist.group.WORLD if world > 1 else None)
+    trio.masks_are_views = True     # (a step's hit masks lie in page-locked host memory; the next step overwrites them)
     if os.environ.get("RFX_BENCH_MAP_BUDGET"):     # (profiling runs without a warm-up step: the run-map pool from the start)
         trio.map_budget = int(float(os.environ["RFX_BENCH_MAP_BUDGET"]))
     step = lambda: trio.run(samples)  # noqa: E731

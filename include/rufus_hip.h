@@ -459,6 +459,10 @@ void rfx_set_free(rfx_set*);
  * hits >= thresh) are host buffers, either may be NULL; *n_hit_reads counts reads over threshold. */
 int rfx_filter(rfx_set*, const rfx_reads*, int thresh, int last_base_skipped, uint32_t* hits_out,
                uint64_t* hitmask_out, uint64_t* n_hit_reads);
+/* The blocks of a sample behind ONE wait for the device: hitmask_out[i] (may be NULL, as may the array) and n_hit_reads[i]
+ * per block as rfx_filter gives them; no per-read counts. */
+int rfx_filter_many(rfx_set*, const rfx_reads* const* blocks, int n, int thresh, int last_base_skipped,
+                    uint64_t* const* hitmask_out, uint64_t* n_hit_reads);
 
 /* ---------------------------------------------------------------------------------------------
  * N4: coverage model fit (src/ModelDist.cpp; runRufus.sh:849 runs it on every sample's histogram,

@@ -136,6 +136,7 @@ SIGNATURES = {
     "rfx_set_build": (C.c_void_p, [C.c_void_p, u64p, C.c_uint64, C.c_int]),
     "rfx_set_size": (C.c_uint64, [C.c_void_p]),
     "rfx_set_free": (None, [C.c_void_p]),
+    "rfx_filter_many": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.POINTER(u64p), u64p]),
     "rfx_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, u32p, u64p, u64p]),
     "rfx_overlap_score": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int),
                                     C.c_int, C.c_float, C.c_int, C.c_int, C.POINTER(C.c_int)]),
@@ -307,6 +308,10 @@ class Context:
 
     def close(self):
         if self._h:
+            if getattr(self, "_pin_ptr", None):
+                self._pin_arr = None
+                lib().rfx_host_free(self._pin_ptr)
+                self._pin_ptr = None
             lib().rfx_close(self._h)
             self._h = None
 
@@ -353,6 +358,20 @@ class Context:
         if not h:
             raise RufusError("rfx_synth_reads failed: " + lib().rfx_last_error().decode())
         return ReadBlock.from_handle(self, h)
+
+    def pinned_u64(self, n_words: int) -> np.ndarray:
+        """A page-locked uint64 array of at least n_words (rfx_host_alloc), kept by the ctx and reused by the next call."""
+        have = getattr(self, "_pin_arr", None)
+        if have is None or len(have) < n_words:
+            old_p = getattr(self, "_pin_ptr", None)
+            p = lib().rfx_host_alloc(max(n_words, 1) * 8)
+            if not p:
+                raise RufusError("rfx_host_alloc failed")
+            self._pin_ptr = p
+            self._pin_arr = np.ctypeslib.as_array((C.c_uint64 * max(n_words, 1)).from_address(p))
+            if old_p:
+                lib().rfx_host_free(old_p)
+        return self._pin_arr[:max(n_words, 1)]
 
     def __enter__(self):
         return self
@@ -795,6 +814,23 @@ class MutantSet:
         _check(lib().rfx_filter(self._h, reads._h, thresh, int(last_base_skipped), _p(hits, u32p), _p(mask, u64p),
                                 C.byref(n)), "rfx_filter")
         return (hits[:reads.n] if want_hits else None), mask, n.value
+
+    def filter_many(self, blocks, thresh: int = 1, last_base_skipped: bool = True):
+        """The hit masks of several blocks with one wait for the device (rfx_filter_many): [(mask, n_hit_reads)]."""
+        # The masks land in page-locked host memory (one buffer per ctx, kept and grown on demand): a read-back into
+        # pageable memory is staged by the runtime and waits for the kernel before it -- the device would idle between two
+        # blocks after all.  The arrays returned are views of that buffer: valid until the next filter_many of this ctx.
+        words = [(b.n + 63) // 64 or 1 for b in blocks]
+        buf = self.ctx.pinned_u64(sum(words))
+        masks, at = [], 0
+        for w in words:
+            masks.append(buf[at:at + w])
+            at += w
+        arr = (C.c_void_p * max(1, len(blocks)))(*[b._h for b in blocks])
+        mp = (u64p * max(1, len(blocks)))(*[m.ctypes.data_as(u64p) for m in masks])
+        nh = np.zeros(max(1, len(blocks)), np.uint64)
+        _check(lib().rfx_filter_many(self._h, arr, len(blocks), thresh, int(last_base_skipped), mp, _p(nh, u64p)), "rfx_filter_many")
+        return [(m, int(n)) for m, n in zip(masks, nh)]
 
     def annotate(self, reads: ReadBlock) -> np.ndarray:
         cov = np.zeros(max(reads.bases, 1), dtype=np.uint32)

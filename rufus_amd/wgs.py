@@ -134,6 +134,7 @@ class WgsTrio:
         self._ahead = {}            # (pass, sample) -> the blocks whose maps that step queues ahead (run())
         self.maps_ahead = 0         # hashing launches queued on the second stream in the last run()
         self.count_wall_s = 0.0     # host wall time inside count_shard() in the last run() (every count ends with a wait)
+        self.masks_are_views = False  # run()'s hit masks stay views of the ctx's page-locked read-back buffer (valid until the next run())
         self.replayed_blocks = 0    # blocks added by replay in the last run()
         # bytes of super-k-mer records this rank sent to / received from OTHER ranks in the last run() (the record
         # exchange of count_shard: RCCL all-to-all over xGMI; what stays on the rank is not counted)
@@ -676,10 +677,12 @@ class WgsTrio:
         if len(keys):
             mset = capi.MutantSet(self.ctx, np.concatenate([keys, revcomp_keys(keys, self.k)]), self.k)
             try:
-                for b in samples[0]:
-                    _, mask, _ = mset.filter(b, self.thresh, last_base_skipped=True, want_hits=False)
+                # (all the subject's blocks behind one wait: a call per block left the device idle between two blocks)
+                for b, (mask, _) in zip(samples[0], mset.filter_many(samples[0], self.thresh, last_base_skipped=True)):
                     n_pulled += pulled_pairs(mask, b.n)
-                    masks.append(mask)
+                    # (views of the ctx's page-locked buffer, overwritten by the next run(): copied unless the caller says
+                    # it is done with them by then -- bench.py's timed steps)
+                    masks.append(mask if self.masks_are_views else mask.copy())
             finally:
                 mset.free()
         lap("filter")

@@ -24,6 +24,7 @@ owners count complete bins; histograms all-reduce, mutant k-mers all-gather, eve
 """
 import argparse
 import filecmp
+import gc
 import json
 import os
 import subprocess
@@ -522,14 +523,26 @@ def main():
     live_all = args.workload != "s1"
     ctx.prof(live_all)
     ctx.prof_reset()
+    # No cyclic-GC pass of the interpreter inside the timed region: the synthetic reads are millions of Python objects, a
+    # full collection over them takes 40-80 ms, and where it lands depends on the allocation count so far (on a box's
+    # first run, which compiles the .pyc files, it fell outside the 20 timed S1 steps; on every later run inside the
+    # last one: 3.6 -> 5.5 ms per step).  Reference counting still frees every step's tables as before.
+    gc.collect()
+    gc.disable()
     fence()
     t0 = time.perf_counter()
+    step_ms = []
     for i in range(args.steps):
         if not live_all and i == args.steps - 1:
             ctx.prof(True)
+        t_s = time.perf_counter()
         res = step()
+        step_ms.append(round((time.perf_counter() - t_s) * 1e3, 3))
     fence()
     dt = time.perf_counter() - t0
+    gc.enable()
+    if os.environ.get("RFX_BENCH_STEP_TIMES"):
+        print("bench.py step wall ms: " + json.dumps(step_ms), file=sys.stderr, flush=True)
     prof = ctx.prof_dict()
     prof_steps = args.steps if live_all else 1
     ctx.prof(False)

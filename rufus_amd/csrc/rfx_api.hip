@@ -648,10 +648,6 @@ rfx_ctx* rfx_open(int device, size_t hbm_budget_bytes) {
     delete c;
     return nullptr;
   }
-  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) {
-    (void)hipGetLastError();
-    c->aux = nullptr;  // (no second stream: rfx_count_prefetch_maps does nothing)
-  }
   if (hipHostMalloc((void**)&c->pin, 4u << 20, hipHostMallocDefault) == hipSuccess) c->pin_cap = 4u << 20;
   else c->pin = nullptr;
   return c;
@@ -3175,8 +3171,14 @@ int rfx_count_prefetch_maps(rfx_table* t, rfx_reads* const* blocks, int n) {
   if (!t || n < 0 || (n && !blocks)) return RFX_E_INVAL;
   rfx_ctx* c = t->ctx;
   rfx_runmaps* st = t->runmaps;
-  if (!st || !st->pool || !c->aux || t->mode != RFX_COUNT_MSP || getenv("RFX_NO_RUNMAP") || getenv("RFX_NO_MAP_AHEAD")) return 0;
+  if (!st || !st->pool || t->mode != RFX_COUNT_MSP || getenv("RFX_NO_RUNMAP") || getenv("RFX_NO_MAP_AHEAD")) return 0;
   (void)hipSetDevice(c->device);
+  // the second stream is made at the first call that wants it: a ctx that never hashes ahead keeps one queue
+  if (!c->aux && hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    c->aux = nullptr;
+    return 0;
+  }
   if (st->ahead) {
     const int rc = runmaps_collect(st);
     if (rc) return rc;

@@ -4075,7 +4075,7 @@ int rfx_filter(rfx_set* s, const rfx_reads* r, int thresh, int last_base_skipped
   std::vector<void*> held;
   unsigned long long nh = 0;
   int rc = filter_queue(s, r, thresh, last_base_skipped, hits_out, hitmask_out, &nh, held);
-  if (rc == RFX_OK && ctx_sync(c) != hipSuccess) rc = RFX_E_HIP;
+  if (ctx_sync(c) != hipSuccess && rc == RFX_OK) rc = RFX_E_HIP;  // (also after a failure: a read-back into `nh` may be queued)
   if (rc == RFX_OK && n_hit_reads) *n_hit_reads = nh;
   for (void* p : held) dfree(c, p);
   return rc;

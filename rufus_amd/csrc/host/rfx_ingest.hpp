@@ -140,6 +140,7 @@ class CountIngest {
   int current_ = -1;
   bool closing_ = false;
   size_t pieces_open_ = 0;
+  std::atomic<bool> drop_mapped_{false};  // pieces without an owner are ranges of a file mapping (feed_mapped)
   std::atomic<bool> failed_{false};
   std::string fail_msg_;
   std::vector<std::thread> workers_;
@@ -392,6 +393,7 @@ class CountIngest {
       if (pc.fd >= 0) parse_range(pc, buf);
       else if (sam_) parse_piece_sam(pc);
       else parse_piece(pc);
+      if (pc.fd < 0 && !pc.owner && drop_mapped_) drop_mapped(pc.b, pc.e);  // a piece of feed_mapped()'s mapping
       if (spool_fd_ >= 0 && pc.fd < 0 && pc.owner) {  // a piece of a pipe: its bytes, at their place in the stream
         const char* p = pc.b;
         size_t len = (size_t)(pc.e - pc.b);
@@ -604,8 +606,11 @@ class CountIngest {
     return out;
   }
 
+  // `data` must be a read-only FILE mapping: the workers drop the page-table entries of what they have parsed
+  // (rfx_cli.hpp drop_mapped -- on anonymous memory that would zero it).
   bool feed_mapped(const char* data, size_t size) {
     if (!sam_ && !looks_4line(data, std::min<size_t>(size, 1u << 16))) return false;
+    drop_mapped_ = true;
     const char *b = data, *e = data + size;
     const char* at = b;
     while (at < e) {

@@ -764,14 +764,33 @@ int main(int argc, char** argv) {
   // RUFUS_GPUS: the pieces are dealt to the devices by worker thread (the filter shards by read block)
   const std::vector<int> gpus = gpu_list();
   const int n_gpu = (int)gpus.size();
-  std::vector<rfx_ctx*> ctxs = open_ctxs(gpus);
+  // The device is opened (0.1 - 0.25 s of runtime start-up) and the set built beside the readers and the workers' first
+  // pieces: a worker needs them when its first piece is packed (RFX_SYNC_OPEN=1: before anything else, as it used to be).
+  std::vector<rfx_ctx*> ctxs;
   std::vector<rfx_set*> sets;
-  for (rfx_ctx* c : ctxs) {
-    rfx_set* st = rfx_set_build(c, keys.data(), (uint64_t)nk, k);
-    if (!st) die(std::string("rufus_amd: ") + rfx_last_error());
-    sets.push_back(st);
-  }
-  trace("filter: device open, set built");
+  std::mutex open_mu;
+  std::condition_variable open_cv;
+  bool dev_ready = false;
+  std::thread opener([&] {
+    std::vector<rfx_ctx*> cs = open_ctxs(gpus);
+    std::vector<rfx_set*> ss;
+    for (rfx_ctx* c : cs) {
+      rfx_set* st = rfx_set_build(c, keys.data(), (uint64_t)nk, k);
+      if (!st) die(std::string("rufus_amd: ") + rfx_last_error());
+      ss.push_back(st);
+    }
+    trace("filter: device open, set built");
+    std::lock_guard<std::mutex> g(open_mu);
+    ctxs = std::move(cs);
+    sets = std::move(ss);
+    dev_ready = true;
+    open_cv.notify_all();
+  });
+  auto wait_device = [&] {
+    std::unique_lock<std::mutex> g(open_mu);
+    open_cv.wait(g, [&] { return dev_ready; });
+  };
+  if (getenv("RFX_SYNC_OPEN")) wait_device();
 
   // Pipeline (the device scans ~1000x faster than one core parses, so the host side is what counts):
   //   one reader per mate stream cuts it into pieces of PIECE_RECS records (4 lines each, counted blindly like the
@@ -970,24 +989,31 @@ int main(int argc, char** argv) {
   };
   auto worker = [&](unsigned me) {
     const size_t dev = (size_t)me % (size_t)n_gpu;
-    rfx_ctx* ctx = ctxs[dev];
-    rfx_set* set = sets[dev];
+    rfx_ctx* ctx = nullptr;  // (known once the opener is done: wait_device() before the first upload)
+    rfx_set* set = nullptr;
     std::vector<uint64_t> ls[2], ss[2], qs[2], mask;  // line starts, sequence / quality starts
     std::vector<uint32_t> sl[2], hits;
     std::vector<char> fix;  // private copies of quality strings that are shorter than their read
     // packed reads go up from page-locked memory (a pageable source costs a staging copy inside the runtime, under
     // the device lock)
+    // (while the device is still being opened the buffers are plain memory, page-locked before their first upload)
     struct Pinned {
       void* p = nullptr;
       size_t cap = 0;
-      void* need(size_t bytes) {
+      bool locked = false;
+      void* need(size_t bytes, bool device_up = true) {
         if (bytes > cap) {
           if (p) rfx_host_free(p);
           cap = bytes + bytes / 4;
-          p = rfx_host_alloc(cap);
+          p = device_up ? rfx_host_alloc(cap) : rfx_host_alloc_lazy(cap);
+          locked = device_up;
           if (!p) die("rufus_amd: cannot allocate pinned staging memory");
         }
         return p;
+      }
+      void lock() {
+        if (p && !locked) (void)rfx_host_pin(p);  // (refused: the upload stages the pageable buffer itself)
+        locked = true;
       }
       ~Pinned() { if (p) rfx_host_free(p); }
     } pin_codes, pin_good, pin_woff, pin_lens;
@@ -1025,10 +1051,11 @@ int main(int argc, char** argv) {
       uint64_t words = 0;
       for (int m = 0; m < n_streams; ++m)
         for (size_t i = 0; i < n; ++i) words += (sl[m][i] + 31) / 32;
-      uint64_t* codes = (uint64_t*)pin_codes.need((words + 1) * 8);
-      uint32_t* good = (uint32_t*)pin_good.need((words + 1) * 4);
-      uint32_t* woff = (uint32_t*)pin_woff.need((nr + 1) * 4);
-      uint32_t* lens = (uint32_t*)pin_lens.need((nr + 1) * 4);
+      const bool up = ctx != nullptr;
+      uint64_t* codes = (uint64_t*)pin_codes.need((words + 1) * 8, up);
+      uint32_t* good = (uint32_t*)pin_good.need((words + 1) * 4, up);
+      uint32_t* woff = (uint32_t*)pin_woff.need((nr + 1) * 4, up);
+      uint32_t* lens = (uint32_t*)pin_lens.need((nr + 1) * 4, up);
       uint32_t w0 = 0;
       for (int m = 0; m < n_streams; ++m) {
         const char* t = pc[m]->data;
@@ -1065,6 +1092,15 @@ int main(int argc, char** argv) {
       }
       mask.assign((nr + 63) / 64, 0);
       if (single) hits.assign(nr, 0);
+      if (!ctx) {
+        wait_device();
+        ctx = ctxs[dev];
+        set = sets[dev];
+        pin_codes.lock();
+        pin_good.lock();
+        pin_woff.lock();
+        pin_lens.lock();
+      }
       {
         std::lock_guard<std::mutex> g(dev_mu[dev]);
         rfx_reads* rd = rfx_reads_upload(ctx, codes, nullptr, good, woff, lens, (uint32_t)nr);
@@ -1101,7 +1137,10 @@ int main(int argc, char** argv) {
           ++res.found;
         }
       }
-      for (int m = 0; m < n_streams; ++m) delete pc[m];
+      for (int m = 0; m < n_streams; ++m) {
+        if (!pc[m]->own && st[m].map) drop_mapped(pc[m]->data, pc[m]->data + pc[m]->size);  // a range of the file's mapping
+        delete pc[m];
+      }
       res.ready = true;
       std::lock_guard<std::mutex> g(res_mu);
       results[seq] = std::move(res);
@@ -1138,6 +1177,7 @@ int main(int argc, char** argv) {
   out2.close();
 #endif
   printf("\nDone running RUFUS.Filter.cpp\n");
+  opener.join();
   // Everything the caller will read is on disk: the process leaves here (rfx_cli.hpp leave(): unmapping 20 GB of input,
   // unpinning the staging blocks and the runtime's own teardown took 0.5 s of a 1.5 s run).  RFX_CLEAN_EXIT=1: the orderly way.
   leave(0);

@@ -29,6 +29,8 @@ rfx_ctx* rfx_open(int device, size_t) { return new rfx_ctx{device}; }
 void rfx_close(rfx_ctx* c) { delete c; }
 int rfx_ctx_allow_peers(rfx_ctx*, const int*, int) { return RFX_OK; }
 void* rfx_host_alloc(size_t bytes) { return malloc(bytes); }
+void* rfx_host_alloc_lazy(size_t bytes) { return malloc(bytes); }
+int rfx_host_pin(void*) { return RFX_OK; }
 void rfx_host_free(void* p) { free(p); }
 
 rfx_set* rfx_set_build(rfx_ctx*, const uint64_t* fwd_keys, uint64_t n, int k) {

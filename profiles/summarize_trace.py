@@ -62,7 +62,11 @@ def main():
     meta = {"source": "rocprofv3 --kernel-trace (no --stats): launches of the LAST step only, cut where the trace shows "
                       "the step's read filter ending (profiles/summarize_trace.py)",
             "steps_in_trace": len(ends), "step_taken": len(ends) - 1, "launches_in_step": len(step),
-            "step_wall_ms": (step[-1][1] - step[0][0]) / 1e6, "kernel_ms": total / 1e6}
+            "step_wall_ms": (step[-1][1] - step[0][0]) / 1e6, "kernel_ms": total / 1e6,
+            "note": "step_wall_ms is the wall time of the traced step UNDER the tracer, and with --warmup 1 that step is the "
+                    "second of its process -- the one in which the arena grows (hipMemCreate / hipMemMap of tens of GB between "
+                    "two runtime copy kernels: the large idle gaps); bench.py's timed steps come after its warm-ups and are "
+                    "busy to within 1 % (ms_per_step of the bench line vs kernel_ms here)"}
     json.dump(meta, open(dst + ".meta.json", "w"), indent=1)
     print(json.dumps(meta))
 

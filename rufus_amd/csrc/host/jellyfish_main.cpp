@@ -644,6 +644,49 @@ static int query_main(int argc, char** argv) {
       key_pos_lsize = hd.lsize;
       key_pos_cols.assign(hd.cols.begin(), hd.cols.end());
     }
+    if (keys.size() * 64 < db.n && !getenv("RFX_QUERY_NO_SPARSE")) {
+      // Few k-mers against a big database (the hash-list lookup of runRufus.sh:925-926: thousands against 10^8..10^10
+      // records): every position range would get one, i.e. the whole file would travel.  Instead the records AT the
+      // queried positions are located on the host (a binary search per distinct position over the sorted file -- what
+      // binary_dumper.hpp:156-203 does for every lookup), read, and uploaded as one small sorted database; the lookups
+      // still run on the device.
+      std::vector<uint64_t> ps(key_pos);
+      std::sort(ps.begin(), ps.end());
+      ps.erase(std::unique(ps.begin(), ps.end()), ps.end());
+      std::vector<std::pair<uint64_t, uint64_t>> rg(ps.size());
+      const unsigned nt = std::max(1u, std::min(16u, rfx_host_cpus()));
+      std::vector<std::thread> th;
+      for (unsigned t = 0; t < nt; ++t)
+        th.emplace_back([&, t] {
+          for (size_t j = t; j < ps.size(); j += nt) {
+            const uint64_t i0 = db.lower_bound_pos(ps[j]);
+            uint64_t i1 = i0;
+            while (i1 < db.n && db.pos_at(i1) == ps[j]) ++i1;
+            rg[j] = {i0, i1};
+          }
+        });
+      for (auto& x : th) x.join();
+      uint64_t tot = 0;
+      for (auto& r : rg) tot += r.second - r.first;
+      if (tot == 0) continue;  // nothing stored at any queried position: every count is 0
+      std::vector<char> buf((size_t)tot * db.rl);
+      size_t at = 0;
+      for (auto& r : rg) {
+        size_t want = (size_t)(r.second - r.first) * db.rl, got = 0;
+        while (got < want) {
+          const ssize_t w = ::pread(db.fd, buf.data() + at + got, want - got, (off_t)(hd.payload_offset + r.first * db.rl + got));
+          if (w < 0 && errno == EINTR) continue;
+          if (w <= 0) die("read error on '" + db.path + "'");
+          got += (size_t)w;
+        }
+        at += want;
+      }
+      rfx_records* part = rfx_records_load(ctx, hd.k, hd.lsize, hd.cols.data(), buf.data(), tot, hd.counter_len);
+      if (!part) die("rufus_amd: cannot load '" + db.path + "': " + rfx_last_error());
+      if (rfx_query(part, keys.data(), keys.size(), counts[d].data()) != RFX_OK) die(std::string("rufus_amd: ") + rfx_last_error());
+      rfx_records_free(part);
+      continue;
+    }
     std::vector<std::vector<uint32_t>> in_slice(S);
     for (size_t i = 0; i < keys.size(); ++i) in_slice[slice_of(key_pos[i], S, hd.lsize)].push_back((uint32_t)i);
     std::vector<uint64_t> sub;

@@ -382,6 +382,14 @@ def test_query_looks_a_kmer_list_up_in_several_databases_at_once(testrun, tmp_pa
             key = min(oracle.jf_encode(c[0]), oracle.jf_encode(c[0].translate(str.maketrans("ACGT", "TGCA"))[::-1]))
             assert int(c[1 + j]) == table.get(key, 0)
     assert sum(int(c[1]) > 0 for c in cols) > 200
+    # few k-mers against a big database: the records at the queried positions only (located on the host, looked up on the
+    # device) -- the lines of the walk over position ranges
+    open(f"{d}/few.fa", "w").write("".join(f">{i}\n{km}\n" for i, km in enumerate(kmers[:40] + kmers[-5:])))
+    a = sh([f"{BIN}/jellyfish", "query", "-s", "few.fa"] + [f"{s}.Jhash" for s in names], d)
+    b = subprocess.run([f"{BIN}/jellyfish", "query", "-s", "few.fa"] + [f"{s}.Jhash" for s in names], cwd=d,
+                       env=dict(os.environ, RFX_QUERY_NO_SPARSE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") == 45, a.stderr
+    assert [ln.split() for ln in a.stdout.decode().splitlines()] == cols[:40] + cols[-6:-1]
     # A database that is PIPED (loaded whole, never sliced) and has another table size, between two regular ones of one
     # size: the third must not be looked up with positions computed for a hash function it does not have (ADVICE r3:
     # the recompute test compared with the database before, which had never touched the positions).

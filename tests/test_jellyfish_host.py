@@ -87,6 +87,16 @@ def _golden_chain(jf, testrun, d):
     assert r.returncode == 0 and open(f"{d}/o1", "rb").read() == whole, r.stderr
     for s, o in (("Mother", "o2"), ("Father", "o3")):
         assert open(f"{d}/{o}", "rb").read() == sh([jf, "query", "-s", "q.fa", f"{s}.Jhash"], d).stdout
+    # few k-mers against a big database: only the records at the queried positions are read (one small sorted database
+    # goes to the device) -- the same lines as the walk over position ranges, hits, misses and several databases alike
+    few = [ln.split()[0] for ln in testrun["merge"].splitlines()][:60] + ["ACGTTGCA" * 3 + "A", "C" * 25, "G" * 24 + "A"]
+    open(f"{d}/few.fa", "w").write("".join(f">{i}\n{km}\n" for i, km in enumerate(few)))
+    a = sh([jf, "query", "-s", "few.fa", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d)
+    b = sh([jf, "query", "-s", "few.fa", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d, env={"RFX_QUERY_NO_SPARSE": "1"})
+    assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") == len(few), a.stderr
+    assert a.stdout.decode().splitlines()[:60] == [ln for ln in whole.decode().splitlines()[:60]
+                                                   ] or all(x.split()[:2] == y.split()[:2] for x, y in
+                                                            zip(a.stdout.decode().splitlines()[:60], whole.decode().splitlines()[:60]))
     r = sh([jf, "dump", "-c", "Child.Jhash"], d)
     lines = r.stdout.decode().splitlines()
     assert len(lines) == 18356 and lines[0] == "A" * 25 + " 48"

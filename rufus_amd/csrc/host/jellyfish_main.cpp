@@ -644,7 +644,11 @@ static int query_main(int argc, char** argv) {
       key_pos_lsize = hd.lsize;
       key_pos_cols.assign(hd.cols.begin(), hd.cols.end());
     }
-    if (keys.size() * 64 < db.n && !getenv("RFX_QUERY_NO_SPARSE")) {
+    // (a located position costs ~30 single-record reads, a streamed record 0.3 ns: worth it below one query per few
+    // thousand records -- RFX_QUERY_SPARSE_RATIO, default 4096)
+    uint64_t sparse_ratio = 4096;
+    if (const char* ev = getenv("RFX_QUERY_SPARSE_RATIO")) sparse_ratio = std::max<uint64_t>(1, strtoull(ev, nullptr, 10));
+    if (keys.size() * sparse_ratio < db.n && !getenv("RFX_QUERY_NO_SPARSE")) {
       // Few k-mers against a big database (the hash-list lookup of runRufus.sh:925-926: thousands against 10^8..10^10
       // records): every position range would get one, i.e. the whole file would travel.  Instead the records AT the
       // queried positions are located on the host (a binary search per distinct position over the sorted file -- what

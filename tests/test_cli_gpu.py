@@ -385,7 +385,8 @@ def test_query_looks_a_kmer_list_up_in_several_databases_at_once(testrun, tmp_pa
     # few k-mers against a big database: the records at the queried positions only (located on the host, looked up on the
     # device) -- the lines of the walk over position ranges
     open(f"{d}/few.fa", "w").write("".join(f">{i}\n{km}\n" for i, km in enumerate(kmers[:40] + kmers[-5:])))
-    a = sh([f"{BIN}/jellyfish", "query", "-s", "few.fa"] + [f"{s}.Jhash" for s in names], d)
+    a = subprocess.run([f"{BIN}/jellyfish", "query", "-s", "few.fa"] + [f"{s}.Jhash" for s in names], cwd=d,
+                       env=dict(os.environ, RFX_QUERY_SPARSE_RATIO="64"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     b = subprocess.run([f"{BIN}/jellyfish", "query", "-s", "few.fa"] + [f"{s}.Jhash" for s in names], cwd=d,
                        env=dict(os.environ, RFX_QUERY_NO_SPARSE="1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") == 45, a.stderr

@@ -91,7 +91,7 @@ def _golden_chain(jf, testrun, d):
     # goes to the device) -- the same lines as the walk over position ranges, hits, misses and several databases alike
     few = [ln.split()[0] for ln in testrun["merge"].splitlines()][:60] + ["ACGTTGCA" * 3 + "A", "C" * 25, "G" * 24 + "A"]
     open(f"{d}/few.fa", "w").write("".join(f">{i}\n{km}\n" for i, km in enumerate(few)))
-    a = sh([jf, "query", "-s", "few.fa", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d)
+    a = sh([jf, "query", "-s", "few.fa", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d, env={"RFX_QUERY_SPARSE_RATIO": "64"})
     b = sh([jf, "query", "-s", "few.fa", "Child.Jhash", "Mother.Jhash", "Father.Jhash"], d, env={"RFX_QUERY_NO_SPARSE": "1"})
     assert a.returncode == 0 and b.returncode == 0 and a.stdout == b.stdout and a.stdout.count(b"\n") == len(few), a.stderr
     assert a.stdout.decode().splitlines()[:60] == [ln for ln in whole.decode().splitlines()[:60]

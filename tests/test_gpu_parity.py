@@ -10,6 +10,15 @@ import oracle
 from rufus_amd import capi, tools
 from tests.synth import fastq_bytes, make_trio
 
+
+def _more_seeds(base):
+    """RFX_FUZZ_SEEDS=a-b: the randomised tests also run on seeds a .. b - 1 (campaigns outside the suite: DESIGN.md section 2)."""
+    ev = os.environ.get("RFX_FUZZ_SEEDS")
+    if not ev:
+        return base
+    a, b = (int(x) for x in ev.split("-"))
+    return base + list(range(a, b))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -428,7 +437,7 @@ def test_msp_refines_the_partition_when_bins_get_dense(ctx, force_bits, monkeypa
         x.free()
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("seed", _more_seeds([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12]))
 def test_three_count_paths_agree_on_random_configurations(ctx, seed, monkeypatch):
     """Randomised cross-check: MSP, P2L and the table path must give identical bytes for random k in the
     MSP range, table size, canonical flag, bounds, bin count, block split and read shapes (repeats,
@@ -711,7 +720,7 @@ def test_synthetic_merge_and_hashlist(ctx, small_trio):
 
 
 @pytest.mark.parametrize("route", ["search", "tiles"])
-@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+@pytest.mark.parametrize("seed", _more_seeds([31, 32, 33, 34]))
 def test_merge_hashlist_query_on_random_configurations(ctx, seed, route, monkeypatch):
     """Randomised K4 inputs: 2-4 samples of very different sizes drawn from overlapping genomes (so the
     (pos,key) search starts far from or right at its target, hits and misses both), random k, table
@@ -821,7 +830,7 @@ def test_synthetic_filter_matches_oracle(ctx, small_trio, k, minq, thresh):
     assert pulled.any()
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize("seed", _more_seeds([11, 12, 13, 14, 15, 16, 17, 18, 19]))
 def test_filter_matches_oracle_on_random_configurations(ctx, seed):
     """Randomised: k, MinQ, threshold, set size (LDS bitmap vs HBM probe), read shapes (short, N, low
     quality, lower case, homopolymer), both loop bounds -- per-read hit counts against the oracle."""

@@ -465,7 +465,18 @@ static int count_main(int argc, char** argv, int full_argc, char** full_argv) {
   write_jhash(out, recs, cols.data(), canonical, out_counter_len, full_argc, full_argv,
               ingest ? ingest->lend_buffers(48u << 20) : out_ring, out_fd, prealloc.reached(), prealloc.take_mapping());
   trace("count: output closed");
-  if (!timing) leave(0);
+  if (!timing && !getenv("RFX_CLEAN_EXIT")) {
+    // The device memory goes back BEFORE the process leaves (0.15 s for the 200 GB a 30x sample maps), not with the
+    // kernel's teardown of an exited process: the tool that runs next then takes 1.86 instead of 2.0 s (`histo` of a 30x
+    // database, three A/B pairs in one box) -- and on some boxes its first device allocation had waited 1 s (after a
+    // 64 M-read count) or 6 s (after a 30x sample) for memory that was still on its way back; that wait could not be
+    // reproduced at will, so this is a precaution with a measured small gain.  RFX_LEAVE_NO_CLOSE=1: as it was.
+    if (!getenv("RFX_LEAVE_NO_CLOSE")) {
+      for (rfx_ctx* c : ctxs) rfx_close(c);
+      trace("count: device closed");
+    }
+    leave(0);
+  }
   ingest.reset();
   for (auto& b : out_ring) rfx_host_free(b.first);
   for (rfx_records* r : recs) rfx_records_free(r);

@@ -885,7 +885,7 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
           const char* src = b[bi];
           const size_t len = (size_t)m * rl;
           const off_t off = (off_t)hl + (off_t)((base + at) * rl);
-          if (map) w[bi] = std::thread([=] { memcpy(map + off, src, len); drop_mapped(map + off, map + off + len); });
+          if (map) w[bi] = std::thread([=] { memcpy(map + off, src, len); });
           else w[bi] = std::thread([=] { put(src, len, off); });
         }
         for (auto& x : w)
@@ -937,9 +937,9 @@ inline void write_jhash(const char* path, const std::vector<rfx_records*>& recs,
     const char* src = buf[bi];
     const size_t len = (size_t)m * rl;
     const off_t off = (off_t)hl + (off_t)(at * rl);
-    // (the writer also drops the page-table entries of what it wrote -- the pages stay, dirty, in the page cache --: the
-    // munmap below then has nothing left to tear down on one thread)
-    if (map) writers[bi] = std::thread([=] { memcpy(map + off, src, len); drop_mapped(map + off, map + off + len); });
+    // (NOT followed by drop_mapped(): dropping the entries of dirty pages of a SHARED mapping from the writer threads was
+    // measured slower than the one munmap below -- 37 GB: 2.7 - 4.3 s of writing against 0.7 + 1.55 s)
+    if (map) writers[bi] = std::thread([=] { memcpy(map + off, src, len); });
     else writers[bi] = std::thread([=] { put(src, len, off); });
   }
   for (auto& w : writers)

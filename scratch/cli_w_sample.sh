@@ -45,5 +45,14 @@ PY
 sed -n 2p $D/child.fq | cut -c1-$KK > $D/q.txt; sed -n 2p $D/child.fq | cut -c40-$((39+KK)) >> $D/q.txt
 s=$(date +%s.%N); timeout 600 $BIN/jellyfish query $D/child.Jhash $(cat $D/q.txt) $(printf "A%.0s" $(seq 1 $KK)); e=$(date +%s.%N)
 python3 -c "print('jellyfish query (3 k-mers): %.2f s' % ($e-$s))"
+# the hash-list lookup at this size (runRufus.sh:925-926): 8000 k-mers (the first k-mers of reads spread over
+# the file) against the 36 GB database -- the records at their positions only, and, for comparison, the walk over the whole file
+awk 'NR % 4 == 2' $D/child.fq | head -n 400000 | awk -v k=$KK 'NR % 50 == 0 { print ">" NR "\n" substr($0, 30, k) }' | grep -v N > $D/q8000.fa
+grep -c ">" $D/q8000.fa
+s=$(date +%s.%N); timeout 600 $BIN/jellyfish query -s $D/q8000.fa $D/child.Jhash > $D/qa.txt; e=$(date +%s.%N)
+python3 -c "print('jellyfish query -s (8000 k-mers, records at the queried positions): %.2f s' % ($e-$s))"
+s=$(date +%s.%N); RFX_QUERY_NO_SPARSE=1 timeout 900 $BIN/jellyfish query -s $D/q8000.fa $D/child.Jhash > $D/qb.txt; e=$(date +%s.%N)
+python3 -c "print('the same with RFX_QUERY_NO_SPARSE=1 (every position range of the file loaded): %.2f s' % ($e-$s))"
+cmp $D/qa.txt $D/qb.txt && echo "same lines"; awk '{ s += ($2 > 0) } END { print s " of " NR " present" }' $D/qa.txt
 nvidia-smi >/dev/null 2>&1; rocm-smi --showmemuse 2>/dev/null | grep -i "vram" | head -2
 rm -rf $D

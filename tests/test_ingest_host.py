@@ -53,7 +53,9 @@ def test_ingest_pipeline_delivers_every_read_once(harness, tmp_path, threads, ca
     path.write_bytes(fq)
     want = f"ok {len(seqs)} {sum(map(len, seqs))} {_expected(seqs)}"
     for rep in range(3):
-        for env in ({}, {"INGEST_MMAP": "1"}):      # ranges read by the workers / the mapped file
+        # ranges read by the workers / the mapped file, its parsed ranges dropped from the page table by the workers
+        # (rfx_cli.hpp drop_mapped: pieces far smaller than a page here, pieces of many pages with the third parameter set) or kept
+        for env in ({}, {"INGEST_MMAP": "1"}, {"INGEST_MMAP": "1", "RFX_KEEP_PTES": "1"}):
             out = subprocess.run([harness, str(threads), str(cap_reads), str(cap_reads * 6), str(piece), str(path)],
                                  stdout=subprocess.PIPE, timeout=120, check=True, env={**os.environ, **env}).stdout.decode()
             assert out.rsplit(" ", 1)[0] == want, out

@@ -355,7 +355,12 @@ def run_wgs(args, ctx, rank, world, dist, torch):
             raise SystemExit(f"rank {rank}: the planned peak ({plan['planned_peak_GB']} GB) exceeds the free HBM of device "
                              f"{plan['device']} ({plan['hbm_free_GB']} GB): something else holds this device")
     t0 = time.perf_counter()
-    samples = [wgs.make_sample(ctx, sy, n * (rank + 1) // world - n * rank // world, 1 << 24, MIN_Q, want_good=(i == 0),
+    # pairs per resident block: a block's k-mer windows are indexed with 32 bits (limits) -- 2^24 pairs of
+    # 150 bp reads have 2^32 windows at k = 23 exactly (found by the self-check sweep, profiles/r06_selfcheck_sweep.txt)
+    blk_pairs = 1 << 24
+    while 2 * blk_pairs * max(READ_LEN - k + 1, 1) >= 1 << 32:
+        blk_pairs >>= 1
+    samples = [wgs.make_sample(ctx, sy, n * (rank + 1) // world - n * rank // world, blk_pairs, MIN_Q, want_good=(i == 0),
                                first_pair=n * rank // world, compact=compact) for i, (sy, n) in enumerate(zip(sys_, pairs))]
     ctx.sync()
     resident = sum(b.device_bytes for s_ in samples for b in s_)

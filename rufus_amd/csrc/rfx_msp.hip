@@ -5,7 +5,7 @@
 // instance.  Consecutive k-mers of a read overlap in k-1 bases, so here they travel together:
 //
 //   k_msp_part1  reads -> for every k-mer the minimum of hash(canonical m-mer) over its 11 m-mers
-//                (m = k-10; k >= 26: 16 m-mers, m = k-15); the minimizer picks one of P bins.  A super-k-mer --
+//                (m = k-10; k = 26 .. 28: k-15 m-mers, m = 16; k >= 29: 16 m-mers, m = k-15); the minimizer picks one of P bins.  A super-k-mer --
 //                ALL consecutive k-mers of the read with the same minimizer, up to 11 (k <= 25) -- becomes ONE
 //                record: 64-bit word + 32-bit plane (rfx_devutil.h).  ~5.7 k-mers per record -> 2.1 B per
 //                instance.  128 coarse bins, filled in per-workgroup slabs.
@@ -72,7 +72,7 @@ namespace {
 // = 105 / 93 / 90 / 132 / 123 / 110 (768 was the choice of round 1, made on a cache-resident 1 M-read sample when
 // the kernel still fit 80 VGPRs; forcing 6 waves per SIMD, `__launch_bounds__(768, 6)`, gives 89).
 constexpr int MP1_BLOCK = 512;
-// WL: m-mers per k-mer (11: k <= 25; 16: k = 26 .. 31).  A record = 64-bit word + 32-bit plane (rfx_devutil.h).
+// WL: m-mers per k-mer (11: k <= 26; 12, 13: k = 27, 28; 16: k = 29 .. 31).  A record = 64-bit word + 32-bit plane (rfx_devutil.h).
 //       4: no record at all -- the launch leaves the block's RUN MAP (see k_msp_replay below): per read 32 bytes that say
 //          how it falls into super-k-mers and where their minimizers sit.  With S > 1 shard passes every pass's records
 //          are then cut from reads + map without hashing a base again.  (The hashing, the sliding minimum and the run
@@ -1568,12 +1568,22 @@ void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int b
     else if (hmode == 4) RFX_MSP_P1(CANON, 4, WL); \
     else RFX_MSP_P1(CANON, 2, WL);                 \
   } while (0)
-  if (msp_wl(k) == MSP_WL) {
-    if (canonical) RFX_MSP_P1_HM(true, MSP_WL);
-    else RFX_MSP_P1_HM(false, MSP_WL);
-  } else {
-    if (canonical) RFX_MSP_P1_HM(true, MSP_WL_WIDE);
-    else RFX_MSP_P1_HM(false, MSP_WL_WIDE);
+  switch (msp_wl(k)) {  // (rfx_devutil.h: 11 for k <= 26, 12 / 13 for k = 27 / 28, 16 from k = 29 on)
+    case MSP_WL:
+      if (canonical) RFX_MSP_P1_HM(true, MSP_WL);
+      else RFX_MSP_P1_HM(false, MSP_WL);
+      break;
+    case 12:
+      if (canonical) RFX_MSP_P1_HM(true, 12);
+      else RFX_MSP_P1_HM(false, 12);
+      break;
+    case 13:
+      if (canonical) RFX_MSP_P1_HM(true, 13);
+      else RFX_MSP_P1_HM(false, 13);
+      break;
+    default:
+      if (canonical) RFX_MSP_P1_HM(true, MSP_WL_WIDE);
+      else RFX_MSP_P1_HM(false, MSP_WL_WIDE);
   }
 #undef RFX_MSP_P1_HM
 #undef RFX_MSP_P1

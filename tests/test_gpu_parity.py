@@ -443,7 +443,7 @@ def test_three_count_paths_agree_on_random_configurations(ctx, seed, monkeypatch
     MSP range, table size, canonical flag, bounds, bin count, block split and read shapes (repeats,
     homopolymers, N, short reads) -- and match the oracle."""
     rng = np.random.default_rng(1000 + seed)
-    k = int(rng.choice([23, 24, 25, 25, 26, 27, 29, 31, 31]))
+    k = int(rng.choice([23, 24, 25, 25, 26, 27, 28, 29, 30, 31, 31]))
     size = 1 << int(rng.integers(2 * k - 30 if 2 * k > 40 else 10, min(2 * k, 40)))
     canonical = bool(rng.integers(0, 2))
     lower = int(rng.choice([0, 1, 2, 3]))

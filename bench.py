@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 K, JF_SIZE, LOWER = 25, 8 << 30, 2
 MIN_COV, MAX_DEPTH, MIN_Q, THRESH = 5, 1200, 15, 1
-READ_LEN = 150
+READ_LEN = int(os.environ.get("RFX_BENCH_READ_LEN", "150"))   # (sweeps away from the headline geometry: the GPU part of --workload wgs / tn only)
 SEED = 12345
 
 # every launch of the count -> sorted-records stage, whichever path rfx_count_add/finish took
@@ -326,7 +326,7 @@ def run_wgs(args, ctx, rank, world, dist, torch):
     pairs = [G * c_ // (2 * READ_LEN) for c_ in covs]
     n_pairs = pairs[0]
     n_snv = max(20, min(1000, G // 3_000_000))
-    sys_ = [capi.Synth.sample(G, w, n_snv=n_snv, seed=SEED) for w in range(len(covs))]
+    sys_ = [capi.Synth.sample(G, w, n_snv=n_snv, seed=SEED, read_len=READ_LEN) for w in range(len(covs))]
     free0, total = torch.cuda.mem_get_info()
     # this rank's share of every sample: pairs [p0, p1) (strong scaling: the trio is the same for every N)
     # bytes per pair, resident: codes + ACGT mask + offsets -- or the compact block form (rufus_hip.h RFX_SYNTH_COMPACT:

@@ -335,7 +335,7 @@ def run_wgs(args, ctx, rank, world, dist, torch):
     bpp = 2 * (40 + 0.2 + 0.15 * 20) if compact else 2 * (40 + 20 + 8)
     resident = int(sum(n * (rank + 1) // world - n * rank // world for n in pairs) * bpp) + (n_pairs // world) * 2 * 20
     passes = args.passes or wgs.plan_passes(2 * n_pairs, READ_LEN, k, resident + (total - free0), total, world=world,
-                                            n_samples=len(covs), coverage_hint=covs[0], wide=k > 28)
+                                            n_samples=len(covs), coverage_hint=covs[0], wide=k > 30)
     if world > 1:                                             # every rank must run the same number of passes
         t = torch.tensor([passes], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -345,7 +345,7 @@ def run_wgs(args, ctx, rank, world, dist, torch):
         # hardware that dies of memory says on which rank and by how much
         windows = 2 * n_pairs * max(READ_LEN - k + 1, 0)
         share = passes * world
-        rec = (1.6 if k > 28 else 2.2) * windows / share
+        rec = (1.6 if k > 30 else 2.2) * windows / share
         plan = {"rank": rank, "device": torch.cuda.current_device(), "hbm_total_GB": round(total / 1e9, 1),
                 "hbm_free_GB": round(free0 / 1e9, 1), "passes": passes, "resident_reads_GB": round(resident / 1e9, 2),
                 "records_per_pass_GB": round(rec / 1e9, 2), "receive_buffers_per_pass_GB": round(rec * (world - 1) / world / 1e9, 2),

@@ -1492,8 +1492,8 @@ static int msp_partition_exact(rfx_table* t, const rfx_reads* r, rfx_segment* se
 }
 
 // Super-k-mer records per window (k-mer instance) on ordinary sequence: 2 / (w + 1) for a window of w m-mers, plus
-// one per read end -- 0.175 for w = 11 (k <= 26), 0.125 for w = 16 (k = 29 .. 31); with 20 % on top for the estimates.
-static double msp_records_per_window(int k) { return k <= 26 ? 0.21 : k == 27 ? 0.20 : k == 28 ? 0.19 : 0.15; }
+// one per read end -- 0.175 for w = 11, 0.125 for w = 16; with 20 % on top for the estimates (w = 11: 0.21, w = 16: 0.15).
+static double msp_records_per_window(int k) { return 2.52 / (double)(rfxk::msp_window(k) + 1); }
 
 static int msp_add_impl(rfx_table* t, const rfx_reads* r);
 

@@ -32,17 +32,20 @@ __device__ __forceinline__ uint64_t gf2_mul(const uint64_t* __restrict__ lut, ui
 // was 12x slower per read at 1 Gb than at 5 Mb; m = 15 gives 2 K.  Shorter windows mean shorter runs
 // (3.0 instead of 3.4 k-mers per record), the price for bins that stay bins at any scale.
 constexpr int MSP_WL = 11;
-// k = 29 .. 31: window 16, m = k - 15 = 14 .. 16 (an m-mer still fits 32 bits).  k = 26 .. 28: window k - 15 = 11 .. 13, so
-// that m = 16 -- with the window at 16 these had m = 11 .. 13, few and skewed minimizer bins (see above), and the leaf took
-// 25 / 6 / 1.5 times what it takes at k = 29 (profiles/r06_selfcheck_sweep.txt, round 6).
+// k = 26 .. 31: window k - 15 = 11 .. 16, so that m = 16 (an m-mer still fits 32 bits).  Until the last day of round 6 the
+// window was 16 for every k > 25 (m = k - 15 = 11 .. 15): exact, but with few and skewed minimizer bins (see above) -- at
+// k = 26 the leaf took 25 times what it takes now, and on the 3.1 Gb genome 329 ms per sample at k = 29 against 178 at
+// k = 25 (profiles/r06_selfcheck_sweep.txt).  k = 23 / 24 keep the window of 11 (m = 13 / 14; the leaf 542 / 216 ms per
+// 3.1 Gb sample): a window of 10 at k = 23 brought the leaf to 209 ms but makes ~25 runs per read where a run map holds 27
+// -- most reads lost their map and were hashed in every pass, 499 M reads/s either way (measured, not kept).
 constexpr int MSP_WL_WIDE = 16;
-__host__ __device__ __forceinline__ int msp_wl(int k) { return k <= 25 ? MSP_WL : k <= 28 ? k - 15 : MSP_WL_WIDE; }
+__host__ __device__ __forceinline__ int msp_wl(int k) { return k >= 26 ? k - 15 : MSP_WL; }
 __host__ __device__ __forceinline__ int msp_m(int k) { return k - (msp_wl(k) - 1); }
 constexpr uint64_t MSP_EMPTY = ~0ull;  // no record looks like this: n - 1 (bits 63:60) stays below 15
 
 // k-mers per record: a whole super-k-mer (all consecutive k-mers of a read that share the minimizer: at most as
 // many as a k-mer has m-mers), capped by what the record can carry -- n - 1 < 15 (15 = MSP_EMPTY's) and
-// k + n - 1 <= 43 bases (28 in the word, 15 in the plane).  k <= 26: 11; k = 27: 12; 28: 13; 29: 15; 30: 14; 31: 13.
+// k + n - 1 <= 43 bases (28 in the word, 15 in the plane).  k <= 26: 11; 27: 12; 28: 13; 29, 30: 14; 31: 13.
 __host__ __device__ __forceinline__ int msp_nmax(int k) {
   const int w = msp_wl(k), c = 44 - k;
   return w < 15 ? (w < c ? w : c) : (15 < c ? 15 : c);

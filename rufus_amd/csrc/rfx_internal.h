@@ -418,6 +418,7 @@ void bin_hist_multi(rfx_ctx*, const uint64_t* const* seg_src, const uint64_t* co
 int msp_k_ok(int k);
 int msp_part1_block();  // threads = reads per chunk of k_msp_part1
 int msp_nmax_of(int k);   // k-mers a record holds at most (rfx_devutil.h msp_nmax)
+int msp_window(int k);  // m-mers per k-mer (rfx_devutil.h msp_wl)
 int msp_wide(int k);  // 1 (round 4: every record is a 64-bit word + a 32-bit plane, rfx_devutil.h)
 // rec_a: the coarse bins, 12 bytes per slot (word + plane side by side, rfx_devutil.h msp_rec12): what part2 / surv_hist
 // take as `buf_a` when rec_mode != 0 and the coarse bins are fixed-capacity (coarse_cur != null)

@@ -5,7 +5,7 @@
 // instance.  Consecutive k-mers of a read overlap in k-1 bases, so here they travel together:
 //
 //   k_msp_part1  reads -> for every k-mer the minimum of hash(canonical m-mer) over its 11 m-mers
-//                (m = k-10; k = 26 .. 28: k-15 m-mers, m = 16; k >= 29: 16 m-mers, m = k-15); the minimizer picks one of P bins.  A super-k-mer --
+//                (k <= 25: 11 m-mers, m = k-10; k >= 26: k-15 m-mers, m = 16); the minimizer picks one of P bins.  A super-k-mer --
 //                ALL consecutive k-mers of the read with the same minimizer, up to 11 (k <= 25) -- becomes ONE
 //                record: 64-bit word + 32-bit plane (rfx_devutil.h).  ~5.7 k-mers per record -> 2.1 B per
 //                instance.  128 coarse bins, filled in per-workgroup slabs.
@@ -72,7 +72,7 @@ namespace {
 // = 105 / 93 / 90 / 132 / 123 / 110 (768 was the choice of round 1, made on a cache-resident 1 M-read sample when
 // the kernel still fit 80 VGPRs; forcing 6 waves per SIMD, `__launch_bounds__(768, 6)`, gives 89).
 constexpr int MP1_BLOCK = 512;
-// WL: m-mers per k-mer (11: k <= 26; 12, 13: k = 27, 28; 16: k = 29 .. 31).  A record = 64-bit word + 32-bit plane (rfx_devutil.h).
+// WL: m-mers per k-mer (11: k <= 26; k - 15: k = 27 .. 31).  A record = 64-bit word + 32-bit plane (rfx_devutil.h).
 //       4: no record at all -- the launch leaves the block's RUN MAP (see k_msp_replay below): per read 32 bytes that say
 //          how it falls into super-k-mers and where their minimizers sit.  With S > 1 shard passes every pass's records
 //          are then cut from reads + map without hashing a base again.  (The hashing, the sliding minimum and the run
@@ -1551,6 +1551,7 @@ int msp_part1_block() { return MP1_BLOCK; }  // m = k-10 in 13..15 (an m-mer fit
 
 int msp_nmax_of(int k) { return msp_nmax(k); }
 int msp_wide(int) { return 1; }  // (round 4) every record is a 64-bit word + a 32-bit plane
+int msp_window(int k) { return msp_wl(k); }  // m-mers per k-mer (rfx_devutil.h), for the host's estimates
 
 void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int bin_bits, uint32_t bin_lo, uint32_t bin_hi,
                int hmode, int grid, void* rec_a, uint32_t* coarse_cur, uint32_t cap_a, uint32_t* cnt_rows,
@@ -1568,23 +1569,22 @@ void msp_part1(rfx_ctx* c, const rfx_reads_view& rv, int k, int canonical, int b
     else if (hmode == 4) RFX_MSP_P1(CANON, 4, WL); \
     else RFX_MSP_P1(CANON, 2, WL);                 \
   } while (0)
-  switch (msp_wl(k)) {  // (rfx_devutil.h: 11 for k <= 26, 12 / 13 for k = 27 / 28, 16 from k = 29 on)
-    case MSP_WL:
-      if (canonical) RFX_MSP_P1_HM(true, MSP_WL);
-      else RFX_MSP_P1_HM(false, MSP_WL);
-      break;
-    case 12:
-      if (canonical) RFX_MSP_P1_HM(true, 12);
-      else RFX_MSP_P1_HM(false, 12);
-      break;
-    case 13:
-      if (canonical) RFX_MSP_P1_HM(true, 13);
-      else RFX_MSP_P1_HM(false, 13);
-      break;
+#define RFX_MSP_P1_WL(WL)                      \
+  case WL:                                     \
+    if (canonical) RFX_MSP_P1_HM(true, WL);    \
+    else RFX_MSP_P1_HM(false, WL);             \
+    break
+  switch (msp_wl(k)) {  // (rfx_devutil.h: 11 for k <= 26, k - 15 from there on)
+    RFX_MSP_P1_WL(11);
+    RFX_MSP_P1_WL(12);
+    RFX_MSP_P1_WL(13);
+    RFX_MSP_P1_WL(14);
+    RFX_MSP_P1_WL(15);
     default:
       if (canonical) RFX_MSP_P1_HM(true, MSP_WL_WIDE);
       else RFX_MSP_P1_HM(false, MSP_WL_WIDE);
   }
+#undef RFX_MSP_P1_WL
 #undef RFX_MSP_P1_HM
 #undef RFX_MSP_P1
 }

@@ -339,7 +339,7 @@ def test_full_size_runs_check_themselves(ctx, workload):
     used_elsewhere = ctx.mem_stats()["mapped"]          # the arena of this session's ctx is reused, not extra
     resident = int(sum(pairs) * 2 * 43.2) + pairs[0] * 2 * 20
     passes = wgs.plan_passes(2 * pairs[0], 150, k, resident + max(0, total - free0 - used_elsewhere), total,
-                             n_samples=len(covs), coverage_hint=covs[0], wide=k > 28)
+                             n_samples=len(covs), coverage_hint=covs[0], wide=k > 30)
     samples = [wgs.make_sample(ctx, sy, n, 1 << 24, MIN_Q, want_good=(i == 0), compact=True)
                for i, (sy, n) in enumerate(zip(sys_, pairs))]
     try:

@@ -1546,7 +1546,12 @@ __global__ __launch_bounds__(BLOCK) void k_filter_p(rfx_reads_view rv, const uin
           hit = v0 == fwd[u] || (v0 != RFX_EMPTY && v1 == fwd[u]);
         }
         if (hit) {
-          if (MASK) atomicOr(&g_mask[rr[u] >> 6], 1ull << (rr[u] & 63u));
+          // (the bit by a 32-bit atomic on the half of the mask word that holds it.  The 64-bit form -- atomicOr(&g_mask[r >> 6],
+          // 1ull << (r & 63)) -- set bits of reads WITHOUT a hit and lost a true one now and then, differently from run to run,
+          // once a set of > 10^5 keys made the queue drain all the time: found by a self-check at 300x (the filter's
+          // counting mode, k_filter_q and the generic kernel agreed with each other and with this form); with 32-bit atomics
+          // six runs of three variants were exact.  tests/test_gpu_parity.py::test_filter_mask_only_equals_counts_on_large_sets)
+          if (MASK) atomicOr((unsigned int*)g_mask + (rr[u] >> 5), 1u << (rr[u] & 31u));
           else atomicAdd(&g_hits[rr[u]], 1u);
         }
       }

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void k_synth_reads(rfx_synth p, uint64_t first
       }
     }
     if (nbits) {  // compact block: flag the reads whose mask has to be kept
-      if (any_n) atomicOr(&nbits[r >> 6], 1ull << (r & 63u));
+      if (any_n) atomicOr((unsigned int*)nbits + (r >> 5), 1u << (r & 31u));  // (32-bit: see k_filter_p's mask bits, rfx_kernels.hip)
       continue;
     }
     word_off[r] = (uint32_t)w0;

@@ -871,6 +871,42 @@ def test_filter_matches_oracle_on_random_configurations(ctx, seed):
     mset.free()
 
 
+@pytest.mark.parametrize("n_random,k", [(60_000, 25), (126_000, 25), (110_000, 31)])
+def test_filter_mask_only_equals_counts_on_large_sets(ctx, n_random, k, monkeypatch):
+    """Sets of > 10^5 keys keep the pair filter's candidate queue draining all the time.  With thresh = 1 and nobody asking for
+    counts the hits set the mask's bits themselves (k_filter_p MASK): that mask must be the counting mode's (count >= 1), the
+    same in every run, and k_filter_q's -- on a uniform (compact) block of millions of reads with few of them hit, where
+    round 6's 64-bit atomic ORs on the mask word set bits of reads WITHOUT a hit and lost a true one now and then (a self-check
+    at 300x coverage found the pulled pairs differing from run to run), and on a ragged block."""
+    from rufus_amd import wgs
+    rng = np.random.default_rng(n_random + k)
+    sy = capi.Synth.sample(30_000_000, 0, n_snv=20, seed=77)
+    blk = wgs.make_sample(ctx, sy, 1_500_000, 1 << 24, 15, want_good=True, compact=True)[0]       # 3 M reads, one block
+    genome = np.frombuffer(sy.genome(0, 30_000_000), np.uint8)
+    loci = rng.integers(0, len(genome) - 200, 60)
+    own = [bytes(genome[p0 + i:p0 + i + k]) for p0 in loci for i in range(100)]                   # 6000 k-mers of the genome
+    rnd = ["".join(x).encode() for x in rng.choice(list("ACGT"), (n_random, k))]
+    text = b"".join(km + b" 7\n" for km in own + rnd)
+    keys = capi.hashlist_keys(text, k)
+    mset = capi.MutantSet(ctx, keys, k)
+    hits, mask_c, n_c = mset.filter(blk, 1, True, want_hits=True, want_mask=True)
+    want = tools._mask_bits(mask_c, blk.n)
+    assert np.array_equal(want, hits >= 1) and 500 < int(want.sum()) == n_c < blk.n // 20
+    for _ in range(16):     # (the old build failed in about one run of three)
+        _, mask_m, n_m = mset.filter(blk, 1, True, want_hits=False, want_mask=True)
+        got = tools._mask_bits(mask_m, blk.n)
+        assert int((got & ~want).sum()) == 0 and int((want & ~got).sum()) == 0 and n_m == n_c
+    (m_many, n_many), = mset.filter_many([blk], 1, last_base_skipped=True)
+    assert np.array_equal(tools._mask_bits(m_many, blk.n), want) and n_many == n_c
+    mset.free()
+    monkeypatch.setenv("RFX_FILTER_NO_PAIR", "1")      # (decided when the set is built)
+    mq = capi.MutantSet(ctx, keys, k)
+    hq, _, n_q = mq.filter(blk, 1, True, want_hits=True, want_mask=True)
+    assert np.array_equal(hq, hits) and n_q == n_c
+    mq.free()
+    blk.free()
+
+
 def test_filter_edge_cases(ctx):
     k = 5
     text = b"ACGTA 3\nTTTTT 9\n"

@@ -1,6 +1,4 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-echo "=== the new test on the build with the 64-bit atomics (must fail)"
-RFX_LIB=$PWD/scratch/variants/librufus_fpx1.so timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "mask_only" 2>&1 | tail -n 6 | cut -c1-300
-echo "=== on the fixed build"
-timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "mask_only" 2>&1 | tail -n 3
+timeout 900 python scratch/r6_hm5.py 50000000 600 25 2>&1 | grep -v amdgpu.ids | tail -n 10
+timeout 900 python scratch/r6_hm5.py 30000000 300 31 2>&1 | grep -v amdgpu.ids | tail -n 10

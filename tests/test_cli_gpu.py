@@ -175,6 +175,40 @@ def test_filter_pieces_and_ragged_records_match_the_reference_binary(tmp_path, r
         assert len(want) > 10_000 and got == want
 
 
+def test_filter_with_a_hash_list_of_100k_kmers_matches_the_reference_binary(tmp_path):
+    """Real hash lists hold 10^5 .. 10^6 k-mers (recurrent sequencing errors), not the 500 of the synthetic trio: the paired
+    tool then runs the pair filter in its mask-only mode with the candidate queue draining all the time -- where round 6
+    had set bits of pairs without a hit (tests/test_gpu_parity.py::test_filter_mask_only_equals_counts_on_large_sets).
+    Byte-identical to the reference's own binary (one thread: its output order is then input order)."""
+    from tests.conftest import require_ref
+    ref = require_ref("RUFUS.Filter")
+    from rufus_amd import capi
+    d = str(tmp_path)
+    n_pairs, G = 120_000, 6_000_000
+    sy = capi.Synth.sample(G, 0, n_snv=20, seed=11)
+    seq, qual = sy.text(0, n_pairs)
+    m1 = b"".join(b"@r%d/1\n%s\n+\n%s\n" % (r, seq[2 * r].tobytes(), qual[2 * r].tobytes()) for r in range(n_pairs))
+    m2 = b"".join(b"@r%d/2\n%s\n+\n%s\n" % (r, seq[2 * r + 1].tobytes(), qual[2 * r + 1].tobytes()) for r in range(n_pairs))
+    rng = np.random.default_rng(12)
+    genome = np.frombuffer(sy.genome(0, G), np.uint8)
+    loci = rng.integers(0, G - 200, 40)
+    kmers = [bytes(genome[p0 + i:p0 + i + 25]) for p0 in loci for i in range(100)]
+    kmers += ["".join(x).encode() for x in rng.choice(list("ACGT"), (110_000, 25))]
+    open(f"{d}/hl", "wb").write(b"".join(km + b" 9\n" for km in kmers))
+    open(f"{d}/m1.fq", "wb").write(m1)
+    open(f"{d}/m2.fq", "wb").write(m2)
+    r = sh([ref, "hl", "m1.fq", "m2.fq", "ref", "25", "15", "1", "1"], d, timeout=900)
+    assert r.returncode == 0
+    for rep in range(3):
+        r = subprocess.run([f"{BIN}/RUFUS.Filter", "hl", "m1.fq", "m2.fq", "out", "25", "15", "1", "5"], cwd=d,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr
+        for m in (1, 2):
+            got = open(f"{d}/out.Mutations.Mate{m}.fastq", "rb").read()
+            want = open(f"{d}/ref.Mutations.Mate{m}.fastq", "rb").read()
+            assert len(want) > 10_000 and got == want
+
+
 @pytest.mark.parametrize("route", ["pipe", "file"])
 def test_count_sam_input_equals_passthrough_plus_count(testrun, tmp_path, route):
     """`jellyfish count --sam X.chr` on SAM text = `PassThroughSamCheck X.chr | jellyfish count`

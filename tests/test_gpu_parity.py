@@ -879,6 +879,7 @@ def test_filter_mask_only_equals_counts_on_large_sets(ctx, n_random, k, monkeypa
     round 6's 64-bit atomic ORs on the mask word set bits of reads WITHOUT a hit and lost a true one now and then (a self-check
     at 300x coverage found the pulled pairs differing from run to run), and on a ragged block."""
     from rufus_amd import wgs
+    monkeypatch.setenv("RFX_FILTER_PAIR_MAX_LOG2", "18")   # (since the fix such sets go to k_filter_q: here the pair filter keeps them)
     rng = np.random.default_rng(n_random + k)
     sy = capi.Synth.sample(30_000_000, 0, n_snv=20, seed=77)
     blk = wgs.make_sample(ctx, sy, 1_500_000, 1 << 24, 15, want_good=True, compact=True)[0]       # 3 M reads, one block
@@ -899,10 +900,12 @@ def test_filter_mask_only_equals_counts_on_large_sets(ctx, n_random, k, monkeypa
     (m_many, n_many), = mset.filter_many([blk], 1, last_base_skipped=True)
     assert np.array_equal(tools._mask_bits(m_many, blk.n), want) and n_many == n_c
     mset.free()
-    monkeypatch.setenv("RFX_FILTER_NO_PAIR", "1")      # (decided when the set is built)
+    monkeypatch.delenv("RFX_FILTER_PAIR_MAX_LOG2")     # the default choice for a set of this size: k_filter_q
     mq = capi.MutantSet(ctx, keys, k)
     hq, _, n_q = mq.filter(blk, 1, True, want_hits=True, want_mask=True)
     assert np.array_equal(hq, hits) and n_q == n_c
+    _, mask_q, n_q2 = mq.filter(blk, 1, True, want_hits=False, want_mask=True)
+    assert np.array_equal(tools._mask_bits(mask_q, blk.n), want) and n_q2 == n_c
     mq.free()
     blk.free()
 

@@ -2004,13 +2004,14 @@ void filter_q(rfx_ctx* c, const rfx_reads_view& rv, const uint64_t* slots, int b
 
 int filter_p_applies(uint64_t n_keys, int k) {
   if (getenv("RFX_FILTER_NO_PAIR")) return 0;  // (A/B runs and the tests' second opinion: k_filter_q)
-  // Up to 2^16 set entries (a hash list of 32 768 k-mers, both orientations): beyond, the table's 2^20 bits fill up -- two entries
-  // per key -- and k_filter_q, one entry per key, is the faster one (120 000 entries: 10.8 against 17.7 ms per 1.3 * 10^8 reads,
-  // 244 000: 24.7 against 60.2; 48 000, the W trio's: 7.4 against 6.6 -- profiles/r06_filter_vs_hashlist.txt).
+  // Up to 81 920 set entries (a hash list of 40 960 k-mers, both orientations): beyond, the table's 2^20 bits fill up -- two entries
+  // per key -- and k_filter_q, one entry per key, is the faster one (k = 25, ms per 1.3 * 10^8 reads: 120 000 entries 10.8 against
+  // 17.7, 244 000: 24.7 against 60.2; below: 48 000, the W trio's, 7.4 against 6.6, and the k = 31 config's 67 526 68.7 against
+  // 45.9 per step -- profiles/r06_filter_vs_hashlist.txt).
   // RFX_FILTER_PAIR_MAX_LOG2 = 13 .. 18: the tests keep the pair filter on sets where its queue drains all the time.
-  int max_log2 = 16;
-  if (const char* ev = getenv("RFX_FILTER_PAIR_MAX_LOG2")) max_log2 = std::min(18, std::max(13, atoi(ev)));
-  if (k < 16 || n_keys <= 4096 || n_keys > (1ull << max_log2)) return 0;
+  uint64_t max_n = (1u << 16) + (1u << 14);
+  if (const char* ev = getenv("RFX_FILTER_PAIR_MAX_LOG2")) max_n = 1ull << std::min(18, std::max(13, atoi(ev)));
+  if (k < 16 || n_keys <= 4096 || n_keys > max_n) return 0;
   // two entries per key; with two bits each up to ~16 K keys fill 6 % of the table and 0.4 % of the lookups pass; beyond,
   // a third bit (a quarter of the bits set by 50 K keys: 1.6 % pass, with two bits it would be 3.3 %)
   if (const char* ev = getenv("RFX_FILTER_PAIR_BITS")) return atoi(ev) == 2 ? 1 : 2;

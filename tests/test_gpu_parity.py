@@ -851,7 +851,7 @@ def test_filter_matches_oracle_on_random_configurations(ctx, seed):
             r[:] = ord("ACGT"[int(rng.integers(0, 4))])
         reads.append(bytes(r))
         quals.append(bytes(q))
-    n_set = int(rng.choice([1, 20, 400, 8000, 30000]))
+    n_set = int(rng.choice([1, 20, 400, 8000, 30000, 45000]))   # (both orientations: 90 000 entries are k_filter_q's again)
     kmers = []
     for _ in range(n_set):
         s0 = int(rng.integers(0, len(genome) - k)) if len(genome) > k else 0
